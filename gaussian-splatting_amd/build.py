@@ -1,0 +1,88 @@
+"""Build libgsr_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python gaussian-splatting_amd/build.py [--force]
+
+Translation units and their flags:
+  preprocess.hip   -ffp-contract=off   (bit-exact radii / tile counts, see csrc/gsr_math.h)
+  sort.hip, binning.hip                (integer)
+  render_fwd.hip, render_bwd.hip       (FMA contraction allowed; image tolerance 1e-5)
+  gsr_api.cpp                          (host glue, C ABI)
+The library is built IN-TREE (gaussian-splatting_amd/lib/) so it travels to the GPU box with the snapshot.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "lib")
+LIB = os.path.join(OUT, "libgsr_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+          "-Wall", "-Wno-unused-function"]
+UNITS = [
+    ("preprocess.hip", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]),
+    ("sort.hip", []),
+    ("binning.hip", []),
+    ("render_fwd.hip", ["-ffp-contract=fast"]),
+    ("render_bwd.hip", ["-ffp-contract=fast"]),
+    ("gsr_api.cpp", ["-x", "hip"]),
+]
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(ROOT, "include", "gsr.h"))
+    hs.append(os.path.abspath(__file__))
+    return hs
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OUT, exist_ok=True)
+    headers = _headers()
+    jobs = []
+    objs = []
+    for src, flags in UNITS:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OUT, os.path.splitext(src)[0] + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            if "-x" in flags:
+                cmd = [HIPCC] + COMMON + flags + ["-c", s, "-o", o]
+            else:
+                cmd = [HIPCC] + COMMON + flags + ["-c", s, "-o", o]
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        if verbose and r.stderr.strip():
+            print(r.stderr, flush=True)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs +
+            ["-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,169 @@
+// Binning kernels: prefix sum of tiles_touched in depth order, instance emission
+// (K3 duplicateWithKeys) and per-tile ranges (K5 identifyTileRanges) of the reference rasterizer,
+// redesigned for wave64 (algorithm: SURVEY.md Appendix A.3).
+#include "gsr_internal.h"
+
+namespace {
+
+constexpr int SC_THREADS = 256;
+constexpr int SC_IPT = GSR_SCAN_ITEMS / SC_THREADS;   // 4 consecutive items per thread
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// pass 1: per-workgroup totals of tiles[order[j]]
+__global__ void __launch_bounds__(SC_THREADS)
+scan_block_sums(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
+                uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t wsum[SC_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * GSR_SCAN_ITEMS + tid * SC_IPT;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SC_IPT; ++k)
+        if (base + k < P) s += tiles[order[base + k]];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) wsum[w] = s;
+    __syncthreads();
+    if (tid == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// pass 2: every workgroup sums the totals of the workgroups before it (a few KB from L2), then scans its
+// own 1024 items.  offsets[j] = inclusive prefix in depth order; the last workgroup publishes R.
+__global__ void __launch_bounds__(SC_THREADS)
+scan_finish(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
+            const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ offsets, uint32_t* __restrict__ num_rendered) {
+    __shared__ uint32_t wsum[SC_THREADS / 64];
+    __shared__ uint32_t wtot[SC_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    uint32_t pre = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += SC_THREADS) pre += block_sums[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off, 64);
+    if (lane == 0) wsum[w] = pre;
+    const int64_t base = (int64_t)blockIdx.x * GSR_SCAN_ITEMS + tid * SC_IPT;
+    uint32_t v[SC_IPT];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SC_IPT; ++k) {
+        v[k] = (base + k < P) ? tiles[order[base + k]] : 0u;
+        s += v[k];
+    }
+    const uint32_t incl = wave_incl_scan(s, lane);
+    if (lane == 63) wtot[w] = incl;
+    __syncthreads();
+    uint32_t run = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+#pragma unroll
+    for (int k = 0; k < SC_THREADS / 64; ++k)
+        if (k < w) run += wtot[k];
+    run += incl - s;
+#pragma unroll
+    for (int k = 0; k < SC_IPT; ++k) {
+        run += v[k];
+        if (base + k < P) offsets[base + k] = run;
+        if (base + k == (int64_t)P - 1) num_rendered[0] = run;
+    }
+}
+
+// Instance emission in depth order.  One wave per 64 consecutive Gaussians of the depth order; the wave
+// writes its instances as one contiguous, fully coalesced run: output slot k (lane = k mod 64) finds its
+// source Gaussian with a 6-step binary search over the wave's inclusive prefix (held one per lane,
+// fetched with ds_bpermute shuffles), then derives its tile from the Gaussian's rectangle (y-major, x fastest).
+__global__ void __launch_bounds__(256)
+emit_instances(int P, int gx, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
+               const uint2* __restrict__ rect, uint32_t* __restrict__ inst_keys, uint32_t* __restrict__ inst_vals) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t j0 = wave * 64;
+    if (j0 >= P) return;
+    const int64_t j = j0 + lane;
+    uint32_t id = 0, incl = 0, minx = 0, w = 1, miny = 0;
+    const uint32_t base = j0 > 0 ? offsets[j0 - 1] : 0u;   // wave-uniform
+    if (j < P) {
+        id = order[j];
+        incl = offsets[j] - base;
+        const uint2 r = rect[id];
+        minx = r.x & 0xFFFFu;
+        w = (r.x >> 16) - minx;
+        miny = r.y & 0xFFFFu;
+    } else {
+        incl = 0xFFFFFFFFu;   // never selected: search looks for the first prefix > k
+    }
+    // lanes past P must carry the total so that __shfl(…,63) below is right
+    const int last = (int)((P - j0) < 64 ? (P - j0 - 1) : 63);
+    const uint32_t total = __shfl(incl, last, 64);
+    const uint32_t excl_self = incl - ((j < P) ? (offsets[j] - (j > 0 ? offsets[j - 1] : 0u)) : 0u);
+    for (uint32_t k0 = 0; k0 < total; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        int lo = 0, hi = last;
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int mid = (lo + hi) >> 1;
+            const uint32_t v = __shfl(incl, mid, 64);
+            if (v > k) hi = mid; else lo = mid + 1;
+        }
+        if (lo > last) lo = last;
+        const uint32_t src_excl = __shfl(excl_self, lo, 64);
+        const uint32_t src_id = __shfl(id, lo, 64);
+        const uint32_t src_minx = __shfl(minx, lo, 64);
+        const uint32_t src_w = __shfl(w, lo, 64);
+        const uint32_t src_miny = __shfl(miny, lo, 64);
+        if (k < total) {
+            const uint32_t local = k - src_excl;
+            const uint32_t ry = local / src_w;
+            const uint32_t rx = local - ry * src_w;
+            const uint32_t tile = (src_miny + ry) * (uint32_t)gx + src_minx + rx;
+            inst_keys[(int64_t)base + k] = tile;
+            inst_vals[(int64_t)base + k] = src_id;
+        }
+    }
+}
+
+// ranges[t] = [first, last+1) of tile t's run in the sorted instance list; untouched tiles stay (0,0)
+__global__ void __launch_bounds__(256)
+tile_ranges(int64_t R, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t t = keys[i];
+        if (i == 0) {
+            ranges[t].x = 0;
+        } else {
+            const uint32_t p = keys[i - 1];
+            if (p != t) {
+                ranges[p].y = (uint32_t)i;
+                ranges[t].x = (uint32_t)i;
+            }
+        }
+        if (i == R - 1) ranges[t].y = (uint32_t)R;
+    }
+}
+
+}  // namespace
+
+void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles, uint32_t* offsets,
+                           uint32_t* block_sums, uint32_t* num_rendered, hipStream_t st) {
+    const int nb = (P + GSR_SCAN_ITEMS - 1) / GSR_SCAN_ITEMS;
+    hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(SC_THREADS), 0, st, P, order, tiles, block_sums);
+    hipLaunchKernelGGL(scan_finish, dim3(nb), dim3(SC_THREADS), 0, st, P, order, tiles, block_sums, offsets, num_rendered);
+}
+
+void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect,
+                     uint32_t* inst_keys, uint32_t* inst_vals, hipStream_t st) {
+    const int64_t waves = ((int64_t)P + 63) / 64;
+    const int nb = (int)((waves + 3) / 4);
+    hipLaunchKernelGGL(emit_instances, dim3(nb), dim3(256), 0, st, P, gx, order, offsets, rect, inst_keys, inst_vals);
+}
+
+void gsr_launch_ranges(int64_t R, int n_tiles, const uint32_t* sorted_keys, uint2* ranges, hipStream_t st) {
+    (void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)n_tiles, st);
+    if (R <= 0) return;
+    int64_t nb = (R + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(tile_ranges, dim3((int)nb), dim3(256), 0, st, R, sorted_keys, ranges);
+}

@@ -1,0 +1,377 @@
+// C ABI of libgsr_hip.so (include/gsr.h): argument checking, scratch carving, kernel orchestration.
+// Host-side counterpart of the reference's rasterize_points.cu / CudaRasterizer::Rasterizer glue
+// (un-vendored; call sites gaussian_renderer/__init__.py:91-110, train.py:142) -- re-designed around a
+// depth-sort + stable tile-sort binning pipeline instead of one 64-bit key sort.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "gsr_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_OK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(GSR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+// ---- options / profiling ----
+int g_render_fwd_variant = 0;
+int g_render_bwd_variant = 0;
+
+struct PendingEvent { int stage; hipEvent_t a, b; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<PendingEvent> g_pending;
+std::vector<hipEvent_t> g_pool;
+double g_stage_ms[GSR_STAGE_COUNT] = {0};
+int g_stage_n[GSR_STAGE_COUNT] = {0};
+
+hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+struct StageTimer {
+    int stage; hipStream_t st; bool on; hipEvent_t a, b;
+    StageTimer(int stage_, hipStream_t st_) : stage(stage_), st(st_), on(g_prof_on) {
+        if (on) { std::lock_guard<std::mutex> l(g_prof_mu); a = get_event(); b = get_event(); (void)hipEventRecord(a, st); }
+    }
+    ~StageTimer() {
+        if (on) { (void)hipEventRecord(b, st); std::lock_guard<std::mutex> l(g_prof_mu); g_pending.push_back({stage, a, b}); }
+    }
+};
+
+int check_stage(const GsrRasterSettings* s, hipStream_t st, const char* what) {
+    if (s->debug) {
+        hipError_t e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) return fail(GSR_ERR_HIP, std::string("after ") + what + ": " + hipGetErrorString(e));
+    }
+    return GSR_OK;
+}
+#define STAGE_CHECK(what) do { int rc_ = check_stage(settings, st, what); if (rc_ != GSR_OK) return rc_; } while (0)
+
+int bits_for(uint32_t n_values) {   // number of bits needed to represent 0 .. n_values-1
+    int b = 0;
+    while (b < 32 && (1ull << b) < (unsigned long long)n_values) ++b;
+    return b < 1 ? 1 : b;
+}
+
+int make_cam(const GsrRasterSettings* s, int M, GsrCamDev& c) {
+    if (!s) return fail(GSR_ERR_INVALID_ARG, "settings is NULL");
+    if (s->image_width <= 0 || s->image_height <= 0) return fail(GSR_ERR_INVALID_ARG, "image size must be positive");
+    if (!s->bg || !s->viewmatrix || !s->projmatrix || !s->campos)
+        return fail(GSR_ERR_INVALID_ARG, "bg / viewmatrix / projmatrix / campos must be device pointers");
+    if (s->sh_degree < 0 || s->sh_degree > 3) return fail(GSR_ERR_UNSUPPORTED, "sh_degree must be 0..3");
+    c.W = s->image_width;
+    c.H = s->image_height;
+    c.gx = (c.W + GSR_TILE - 1) / GSR_TILE;
+    c.gy = (c.H + GSR_TILE - 1) / GSR_TILE;
+    if (c.gx > 65535 || c.gy > 65535) return fail(GSR_ERR_UNSUPPORTED, "more than 65535 tiles per axis");
+    // fp32 host arithmetic, same expression as oracle/torch_oracle.py:preprocess
+    c.focal_x = (float)c.W / (2.0f * s->tanfovx);
+    c.focal_y = (float)c.H / (2.0f * s->tanfovy);
+    c.limx = 1.3f * s->tanfovx;
+    c.limy = 1.3f * s->tanfovy;
+    c.scale_modifier = s->scale_modifier;
+    c.sh_degree = s->sh_degree;
+    c.M = M;
+    c.antialiasing = s->antialiasing ? 1 : 0;
+    int y0 = s->tile_y0, y1 = s->tile_y1;
+    if (y1 <= 0) { y0 = 0; y1 = c.gy; }
+    if (y0 < 0) y0 = 0;
+    if (y1 > c.gy) y1 = c.gy;
+    if (y0 > y1) y0 = y1;
+    c.tile_y0 = y0;
+    c.tile_y1 = y1;
+    c.view = s->viewmatrix;
+    c.proj = s->projmatrix;
+    c.campos = s->campos;
+    c.bg = s->bg;
+    return GSR_OK;
+}
+
+int check_inputs(int P, int M, const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
+                 int sh_degree) {
+    if (P < 0) return fail(GSR_ERR_INVALID_ARG, "P < 0");
+    if (P == 0) return GSR_OK;
+    if (!means3D || !opacities) return fail(GSR_ERR_INVALID_ARG, "means3D / opacities are NULL");
+    if ((shs == nullptr) == (colors_precomp == nullptr))
+        return fail(GSR_ERR_INVALID_ARG, "provide exactly one of shs / colors_precomp");
+    const bool sr = scales != nullptr && rotations != nullptr;
+    if ((scales == nullptr) != (rotations == nullptr) || sr == (cov3D_precomp != nullptr))
+        return fail(GSR_ERR_INVALID_ARG, "provide exactly one of (scales, rotations) / cov3D_precomp");
+    if (shs) {
+        if (M <= 0 || M > 16) return fail(GSR_ERR_UNSUPPORTED, "SH coefficient count M must be 1..16");
+        if ((sh_degree + 1) * (sh_degree + 1) > M) return fail(GSR_ERR_INVALID_ARG, "sh_degree needs more coefficients than M");
+    }
+    return GSR_OK;
+}
+
+thread_local uint32_t* g_host_word = nullptr;
+
+bool use_small_blocks(int64_t n) { return n < (int64_t)2 * 1024 * 1024; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+GsrGeom gsr_carve_geom(char* base, int P) {
+    GsrGeom g;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off = gsr_align128(off + bytes); return p; };
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    g.splats = (float4*)take(n * 48);
+    g.rect = (uint2*)take(n * 8);
+    g.tiles = (uint32_t*)take(n * 4);
+    g.clamped = (uint32_t*)take(n * 4);
+    g.keys[0] = (uint32_t*)take(n * 4);
+    g.keys[1] = (uint32_t*)take(n * 4);
+    g.vals[0] = (uint32_t*)take(n * 4);
+    g.vals[1] = (uint32_t*)take(n * 4);
+    g.offsets = (uint32_t*)take(n * 4);
+    g.block_sums = (uint32_t*)take(((n + GSR_SCAN_ITEMS - 1) / GSR_SCAN_ITEMS) * 4);
+    g.sort_hist = (uint32_t*)take((size_t)256 * (size_t)gsr_sort_blocks((int64_t)n, use_small_blocks((int64_t)n)) * 4);
+    g.digit_total = (uint32_t*)take(256 * 4);
+    g.num_rendered = (uint32_t*)take(128);
+    g.bytes = off;
+    return g;
+}
+
+GsrBinning gsr_carve_binning(char* base, int64_t R) {
+    GsrBinning b;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off = gsr_align128(off + bytes); return p; };
+    const size_t n = (size_t)(R > 0 ? R : 1);
+    b.keys[0] = (uint32_t*)take(n * 4);
+    b.keys[1] = (uint32_t*)take(n * 4);
+    b.vals[0] = (uint32_t*)take(n * 4);
+    b.vals[1] = (uint32_t*)take(n * 4);
+    b.sort_hist = (uint32_t*)take((size_t)256 * (size_t)gsr_sort_blocks((int64_t)n, use_small_blocks((int64_t)n)) * 4);
+    b.digit_total = (uint32_t*)take(256 * 4);
+    b.meta = (uint32_t*)take(128);
+    b.bytes = off;
+    return b;
+}
+
+GsrImage gsr_carve_image(char* base, int W, int H) {
+    GsrImage im;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off = gsr_align128(off + bytes); return p; };
+    const size_t npix = (size_t)W * (size_t)H;
+    const size_t nt = (size_t)((W + GSR_TILE - 1) / GSR_TILE) * (size_t)((H + GSR_TILE - 1) / GSR_TILE);
+    im.final_T = (float*)take(npix * 4);
+    im.n_contrib = (uint32_t*)take(npix * 4);
+    im.ranges = (uint2*)take(nt * 8);
+    im.bytes = off;
+    return im;
+}
+
+extern "C" {
+
+int gsr_abi_version(void) { return GSR_ABI_VERSION; }
+const char* gsr_last_error(void) { return g_err.c_str(); }
+
+size_t gsr_geometry_bytes(int P) { return gsr_carve_geom(nullptr, P).bytes; }
+size_t gsr_binning_bytes(int64_t R, int n_tiles) { (void)n_tiles; return gsr_carve_binning(nullptr, R).bytes; }
+size_t gsr_image_bytes(int width, int height) { return gsr_carve_image(nullptr, width, height).bytes; }
+
+int gsr_set_option(const char* name, int value) {
+    if (!name) return fail(GSR_ERR_INVALID_ARG, "option name is NULL");
+    if (!strcmp(name, "render_fwd_variant")) { g_render_fwd_variant = value; return GSR_OK; }
+    if (!strcmp(name, "render_bwd_variant")) { g_render_bwd_variant = value; return GSR_OK; }
+    return fail(GSR_ERR_INVALID_ARG, std::string("unknown option ") + name);
+}
+
+int gsr_profile_enable(int on) { std::lock_guard<std::mutex> l(g_prof_mu); g_prof_on = on != 0; return GSR_OK; }
+int gsr_profile_reset(void) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    for (auto& p : g_pending) { (void)hipEventSynchronize(p.b); g_pool.push_back(p.a); g_pool.push_back(p.b); }
+    g_pending.clear();
+    for (int i = 0; i < GSR_STAGE_COUNT; ++i) { g_stage_ms[i] = 0; g_stage_n[i] = 0; }
+    return GSR_OK;
+}
+int gsr_profile_read(float* ms_out, int32_t* count_out, int n) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    for (auto& p : g_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            g_stage_ms[p.stage] += ms;
+            g_stage_n[p.stage] += 1;
+        }
+        g_pool.push_back(p.a);
+        g_pool.push_back(p.b);
+    }
+    g_pending.clear();
+    for (int i = 0; i < n && i < GSR_STAGE_COUNT; ++i) {
+        if (ms_out) ms_out[i] = (float)g_stage_ms[i];
+        if (count_out) count_out[i] = g_stage_n[i];
+    }
+    return GSR_OK;
+}
+
+int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const float* means3D, const float* shs,
+                          const float* colors_precomp, const float* opacities, const float* scales,
+                          const float* rotations, const float* cov3D_precomp, GsrResizeFn geom_resize, void* geom_user,
+                          GsrResizeFn binning_resize, void* binning_user, GsrResizeFn image_resize, void* image_user,
+                          float* out_color, float* out_invdepth, int32_t* radii, int32_t* num_rendered, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    GsrCamDev cam;
+    int rc = make_cam(settings, M, cam);
+    if (rc != GSR_OK) return rc;
+    rc = check_inputs(P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, cam.sh_degree);
+    if (rc != GSR_OK) return rc;
+    if (!out_color || !num_rendered) return fail(GSR_ERR_INVALID_ARG, "out_color / num_rendered are NULL");
+    const size_t npix = (size_t)cam.W * cam.H;
+    *num_rendered = 0;
+    if (P == 0) {   // reference behaviour: zero image (not background), nothing else touched
+        HIP_OK(hipMemsetAsync(out_color, 0, npix * 3 * sizeof(float), st));
+        if (out_invdepth) HIP_OK(hipMemsetAsync(out_invdepth, 0, npix * sizeof(float), st));
+        return GSR_OK;
+    }
+    if (!radii) return fail(GSR_ERR_INVALID_ARG, "radii is NULL");
+    if (!geom_resize || !binning_resize || !image_resize) return fail(GSR_ERR_INVALID_ARG, "resize callbacks are NULL");
+
+    char* gbase = (char*)geom_resize(geom_user, gsr_geometry_bytes(P));
+    if (!gbase) return fail(GSR_ERR_ALLOC, "geometry buffer resize returned NULL");
+    GsrGeom g = gsr_carve_geom(gbase, P);
+
+    {   StageTimer t(GSR_STAGE_PREPROCESS, st);
+        gsr_launch_preprocess(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, st);
+    }
+    STAGE_CHECK("preprocess");
+    int order_buf;
+    {   StageTimer t(GSR_STAGE_DEPTH_SORT, st);
+        order_buf = gsr_radix_sort_pairs(g.keys, g.vals, P, 32, g.sort_hist, g.digit_total, use_small_blocks(P), st);
+    }
+    STAGE_CHECK("depth sort");
+    {   StageTimer t(GSR_STAGE_SCAN, st);
+        gsr_launch_scan_tiles(P, g.vals[order_buf], g.tiles, g.offsets, g.block_sums, g.num_rendered, st);
+    }
+    if (!g_host_word) HIP_OK(hipHostMalloc((void**)&g_host_word, 64, hipHostMallocDefault));
+    HIP_OK(hipMemcpyAsync(g_host_word, g.num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    const int64_t R = (int64_t)g_host_word[0];
+    if (R > 0x7FFFFFFFll) return fail(GSR_ERR_UNSUPPORTED, "more than 2^31-1 tile instances");
+    *num_rendered = (int32_t)R;
+
+    const int n_tiles = cam.gx * cam.gy;
+    char* bbase = (char*)binning_resize(binning_user, gsr_binning_bytes(R, n_tiles));
+    char* ibase = (char*)image_resize(image_user, gsr_image_bytes(cam.W, cam.H));
+    if (!bbase || !ibase) return fail(GSR_ERR_ALLOC, "binning / image buffer resize returned NULL");
+    GsrBinning b = gsr_carve_binning(bbase, R);
+    GsrImage im = gsr_carve_image(ibase, cam.W, cam.H);
+
+    int list_buf = 0;
+    if (R > 0) {
+        {   StageTimer t(GSR_STAGE_EMIT, st);
+            gsr_launch_emit(P, cam.gx, g.vals[order_buf], g.offsets, g.rect, b.keys[0], b.vals[0], st);
+        }
+        STAGE_CHECK("emit");
+        {   StageTimer t(GSR_STAGE_TILE_SORT, st);
+            list_buf = gsr_radix_sort_pairs(b.keys, b.vals, R, bits_for((uint32_t)n_tiles), b.sort_hist, b.digit_total,
+                                            use_small_blocks(R), st);
+        }
+        STAGE_CHECK("tile sort");
+    }
+    {   StageTimer t(GSR_STAGE_RANGES, st);
+        gsr_launch_ranges(R, n_tiles, b.keys[list_buf], im.ranges, st);
+    }
+    STAGE_CHECK("ranges");
+    {   StageTimer t(GSR_STAGE_RENDER, st);
+        gsr_launch_render_forward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib, out_color,
+                                  out_invdepth, g_render_fwd_variant, st);
+    }
+    STAGE_CHECK("render");
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
+}
+
+static int list_buffer_index(int n_tiles) { return ((bits_for((uint32_t)n_tiles) + 7) / 8) & 1; }
+
+int gsr_rasterize_backward(const GsrRasterSettings* settings, int P, int M, int32_t num_rendered, const float* means3D,
+                           const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
+                           const float* rotations, const float* cov3D_precomp, const int32_t* radii,
+                           const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+                           const float* dL_dout_color, const float* dL_dout_invdepth, float* dL_dmeans2D,
+                           float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                           float* dL_dscales, float* dL_drotations, void* splat_grads_scratch, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    GsrCamDev cam;
+    int rc = make_cam(settings, M, cam);
+    if (rc != GSR_OK) return rc;
+    rc = check_inputs(P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, cam.sh_degree);
+    if (rc != GSR_OK) return rc;
+    if (P == 0) return GSR_OK;
+    if (!radii || !geom_buffer || !binning_buffer || !image_buffer || !dL_dout_color || !splat_grads_scratch)
+        return fail(GSR_ERR_INVALID_ARG, "radii / state buffers / dL_dout_color / splat_grads_scratch are NULL");
+    if (!dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D)
+        return fail(GSR_ERR_INVALID_ARG, "gradient outputs are NULL");
+    if (shs && !dL_dsh) return fail(GSR_ERR_INVALID_ARG, "dL_dsh is NULL");
+    if (scales && (!dL_dscales || !dL_drotations)) return fail(GSR_ERR_INVALID_ARG, "dL_dscales / dL_drotations are NULL");
+    GsrGeom g = gsr_carve_geom((char*)geom_buffer, P);
+    GsrBinning b = gsr_carve_binning((char*)binning_buffer, num_rendered);
+    GsrImage im = gsr_carve_image((char*)image_buffer, cam.W, cam.H);
+    const int list_buf = num_rendered > 0 ? list_buffer_index(cam.gx * cam.gy) : 0;
+    float* sg = (float*)splat_grads_scratch;
+    {   StageTimer t(GSR_STAGE_RENDER_BWD, st);
+        HIP_OK(hipMemsetAsync(sg, 0, (size_t)P * 12 * sizeof(float), st));
+        if (num_rendered > 0)
+            gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib,
+                                       dL_dout_color, dL_dout_invdepth, sg, g_render_bwd_variant, st);
+    }
+    STAGE_CHECK("render backward");
+    {   StageTimer t(GSR_STAGE_PREPROCESS_BWD, st);
+        gsr_launch_preprocess_backward(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                       radii, g, sg, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D,
+                                       dL_dsh, scales ? dL_dscales : nullptr, scales ? dL_drotations : nullptr, st);
+    }
+    STAGE_CHECK("preprocess backward");
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     void* stream) {
+    (void)projmatrix;
+    if (P < 0) return fail(GSR_ERR_INVALID_ARG, "P < 0");
+    if (P == 0) return GSR_OK;
+    if (!means3D || !viewmatrix || !present) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
+    gsr_launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_forward_views(int P, int64_t R, int width, int height, const void* geom_buffer, const void* binning_buffer,
+                      const void* image_buffer, GsrForwardViews* out) {
+    if (!out || !geom_buffer || !image_buffer) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
+    GsrGeom g = gsr_carve_geom((char*)geom_buffer, P);
+    GsrImage im = gsr_carve_image((char*)image_buffer, width, height);
+    const int n_tiles = ((width + GSR_TILE - 1) / GSR_TILE) * ((height + GSR_TILE - 1) / GSR_TILE);
+    out->splats = (const float*)g.splats;
+    out->tiles_touched = g.tiles;
+    out->depth_order = g.vals[0];   // 4 passes -> result back in buffer 0
+    out->point_list = nullptr;
+    if (binning_buffer && R > 0) {
+        GsrBinning b = gsr_carve_binning((char*)binning_buffer, R);
+        out->point_list = b.vals[list_buffer_index(n_tiles)];
+    }
+    out->ranges = (const uint32_t*)im.ranges;
+    out->final_T = im.final_T;
+    out->n_contrib = im.n_contrib;
+    return GSR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+// Internal declarations shared by the translation units of libgsr_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "gsr.h"
+#include "gsr_math.h"
+
+// ---- per-call camera block handed to kernels by value (matrices are read from device memory) ----
+struct GsrCamDev {
+    int W, H, gx, gy;
+    float focal_x, focal_y, limx, limy, scale_modifier;
+    int sh_degree, M, antialiasing, tile_y0, tile_y1;
+    const float* view;
+    const float* proj;
+    const float* campos;
+    const float* bg;
+};
+
+// ---- scratch layouts (GeometryState / BinningState / ImageState), 128-byte aligned carve ----
+static inline size_t gsr_align128(size_t x) { return (x + 127) & ~(size_t)127; }
+
+#define GSR_SORT_ITEMS 4096      // items per workgroup in a radix pass (256 threads x 16)
+#define GSR_SORT_ITEMS_SMALL 1024
+#define GSR_SCAN_ITEMS 1024      // items per workgroup in the tiles_touched scan
+
+struct GsrGeom {                 // P-sized
+    float4* splats;              // [3P]  (x,y,conA,conB) (conC,opacity,r,g) (b,depth,0,0)
+    uint2* rect;                 // [P]   x = minx | maxx<<16 ; y = miny | maxy<<16 (band-clamped)
+    uint32_t* tiles;             // [P]   tiles_touched
+    uint32_t* clamped;           // [P]   colour clamp bits
+    uint32_t* keys[2];           // [P]x2 depth-sort keys (ping-pong)
+    uint32_t* vals[2];           // [P]x2 Gaussian ids   (ping-pong); vals[order_buf] = depth order
+    uint32_t* offsets;           // [P]   inclusive scan of tiles_touched in depth order
+    uint32_t* block_sums;        // [ceil(P/GSR_SCAN_ITEMS)]
+    uint32_t* sort_hist;         // [256 * nblocks_small(P)] radix block histograms
+    uint32_t* digit_total;       // [256]
+    uint32_t* num_rendered;      // [1] (+ order_buf index in [1])
+    size_t bytes;
+};
+GsrGeom gsr_carve_geom(char* base, int P);
+
+struct GsrBinning {              // R-sized
+    uint32_t* keys[2];           // [R]x2 tile ids (ping-pong)
+    uint32_t* vals[2];           // [R]x2 Gaussian ids (ping-pong); final sorted list = point_list
+    uint32_t* sort_hist;         // [256 * nblocks(R)]
+    uint32_t* digit_total;       // [256]
+    uint32_t* meta;              // [4]: [0] = index of the buffer holding the sorted list
+    size_t bytes;
+};
+GsrBinning gsr_carve_binning(char* base, int64_t R);
+
+struct GsrImage {
+    float* final_T;              // [H*W]
+    uint32_t* n_contrib;         // [H*W]
+    uint2* ranges;               // [n_tiles]
+    size_t bytes;
+};
+GsrImage gsr_carve_image(char* base, int W, int H);
+
+// ---- kernel launchers (one per translation unit) ----
+// preprocess.hip  (compiled with -ffp-contract=off)
+void gsr_launch_preprocess(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* opacities, const float* scales,
+                           const float* rotations, const float* cov3D_precomp, GsrGeom g, int32_t* radii,
+                           hipStream_t st);
+void gsr_launch_preprocess_backward(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
+                                    const float* colors_precomp, const float* opacities, const float* scales,
+                                    const float* rotations, const float* cov3D_precomp, const int32_t* radii,
+                                    GsrGeom g, const float* splat_grads /*[P,12]*/, float* dL_dmeans2D,
+                                    float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D,
+                                    float* dL_dsh, float* dL_dscales, float* dL_drotations, hipStream_t st);
+void gsr_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st);
+
+// sort.hip: LSD radix sort of (u32 key, u32 value) pairs on bits [0, nbits); returns the index (0/1) of the
+// ping-pong buffer that holds the result.  n is known on the host.
+int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, uint32_t* hist,
+                         uint32_t* digit_total, bool small_blocks, hipStream_t st);
+static inline int64_t gsr_sort_blocks(int64_t n, bool small_blocks) {
+    const int64_t items = small_blocks ? GSR_SORT_ITEMS_SMALL : GSR_SORT_ITEMS;
+    return (n + items - 1) / items;
+}
+
+// binning.hip: scan of tiles_touched in depth order, instance emission, tile ranges
+void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles, uint32_t* offsets,
+                           uint32_t* block_sums, uint32_t* num_rendered, hipStream_t st);
+void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect,
+                     uint32_t* inst_keys, uint32_t* inst_vals, hipStream_t st);
+void gsr_launch_ranges(int64_t R, int n_tiles, const uint32_t* sorted_keys, uint2* ranges, hipStream_t st);
+
+// render_fwd.hip / render_bwd.hip
+void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,
+                               const float4* splats, float* final_T, uint32_t* n_contrib, float* out_color,
+                               float* out_invdepth, int variant, hipStream_t st);
+void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,
+                                const float4* splats, const float* final_T, const uint32_t* n_contrib,
+                                const float* dL_dpix, const float* dL_dinvdepth, float* splat_grads /*[P,12]*/,
+                                int variant, hipStream_t st);

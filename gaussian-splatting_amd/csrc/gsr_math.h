@@ -1,0 +1,446 @@
+// Per-Gaussian fp32 math of the rasterizer's preprocess stage (forward and backward), written once as
+// host+device inline functions.  The HIP kernels in preprocess.hip call these per lane; tests/ compiles
+// the same header with g++ (tests/host_math_harness.cpp) to check the arithmetic against the CPU oracle
+// without a GPU.
+//
+// ARITHMETIC CONTRACT (matches oracle/torch_oracle.py): every expression below is evaluated in fp32,
+// one IEEE-754 rounding per written operation, left to right, with NO fused multiply-add -- this file
+// must be compiled with -ffp-contract=off and IEEE-correct divide/sqrt (hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt).  That is what makes radii / tiles_touched bit-exact.
+//
+// Algorithm: SURVEY.md Appendix A.2 (forward) and A.6 (backward); the in-tree restatements it must agree
+// with are utils/sh_utils.py:57-112 (SH), utils/general_utils.py:78-110 (Sigma3D) and
+// scene/cameras.py:80-89 (matrix layout) of the reference.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define GSR_HD __host__ __device__ __forceinline__
+#else
+#define GSR_HD inline
+#endif
+
+#define GSR_TILE 16
+#define GSR_NEAR_Z 0.2f
+#define GSR_LOWPASS 0.3f
+#define GSR_AA_FLOOR 0.000025f
+#define GSR_ALPHA_MIN (1.0f / 255.0f)
+#define GSR_ALPHA_MAX 0.99f
+#define GSR_T_EPS 0.0001f
+
+// utils/sh_utils.py:26-54 rounded to fp32
+#define GSR_SH_C0 0.28209479177387814f
+#define GSR_SH_C1 0.4886025119029199f
+#define GSR_SH_C2_0 1.0925484305920792f
+#define GSR_SH_C2_1 -1.0925484305920792f
+#define GSR_SH_C2_2 0.31539156525252005f
+#define GSR_SH_C2_3 -1.0925484305920792f
+#define GSR_SH_C2_4 0.5462742152960396f
+#define GSR_SH_C3_0 -0.5900435899266435f
+#define GSR_SH_C3_1 2.890611442640554f
+#define GSR_SH_C3_2 -0.4570457994644658f
+#define GSR_SH_C3_3 0.3731763325901154f
+#define GSR_SH_C3_4 -0.4570457994644658f
+#define GSR_SH_C3_5 1.445305721320277f
+#define GSR_SH_C3_6 -0.5900435899266435f
+
+struct GsrCam {
+    int W, H, gx, gy;
+    float focal_x, focal_y;   // W / (2 tanfovx), H / (2 tanfovy)
+    float limx, limy;         // 1.3 * tanfov
+    float scale_modifier;
+    int sh_degree, M;
+    int antialiasing;
+    int tile_y0, tile_y1;     // band of tile rows that is binned
+    float view[16];           // flat, as passed (transposed math matrix)
+    float proj[16];
+    float campos[3];
+};
+
+struct GsrSplat {             // result of the forward preprocess for one Gaussian
+    float px, py;             // pixel-space centre
+    float conA, conB, conC;   // inverse 2-D covariance
+    float opacity;            // opacity * aa
+    float r, g, b;
+    float depth;              // view-space z
+    int radius;               // 0 = not visible
+    uint32_t minx, miny, maxx, maxy;  // tile rectangle, y already clamped to the band
+    uint32_t tiles;           // (maxx-minx)*(maxy-miny) within the band
+    uint32_t clamped;         // bit c set: colour channel c was clamped at 0
+};
+
+GSR_HD void gsr_cov3d(const float* s, float mod, const float* q, float* cov) {
+    const float s0 = mod * s[0], s1 = mod * s[1], s2 = mod * s[2];
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    const float R00 = 1.0f - 2.0f * (y * y + z * z), R01 = 2.0f * (x * y - r * z), R02 = 2.0f * (x * z + r * y);
+    const float R10 = 2.0f * (x * y + r * z), R11 = 1.0f - 2.0f * (x * x + z * z), R12 = 2.0f * (y * z - r * x);
+    const float R20 = 2.0f * (x * z - r * y), R21 = 2.0f * (y * z + r * x), R22 = 1.0f - 2.0f * (x * x + y * y);
+    const float M00 = R00 * s0, M01 = R01 * s1, M02 = R02 * s2;
+    const float M10 = R10 * s0, M11 = R11 * s1, M12 = R12 * s2;
+    const float M20 = R20 * s0, M21 = R21 * s1, M22 = R22 * s2;
+    cov[0] = M00 * M00 + M01 * M01 + M02 * M02;
+    cov[1] = M00 * M10 + M01 * M11 + M02 * M12;
+    cov[2] = M00 * M20 + M01 * M21 + M02 * M22;
+    cov[3] = M10 * M10 + M11 * M11 + M12 * M12;
+    cov[4] = M10 * M20 + M11 * M21 + M12 * M22;
+    cov[5] = M20 * M20 + M21 * M21 + M22 * M22;
+}
+
+// Everything that depends on the Gaussian's position / covariance.  Returns false when the Gaussian is
+// culled (near plane, singular Sigma2D, empty tile rectangle); out.radius/out.tiles are 0 then.
+// `cov` is Sigma3D packed [xx,xy,xz,yy,yz,zz].
+GSR_HD bool gsr_project(const GsrCam& cam, const float* mean, const float* cov, float opacity_in, GsrSplat& out) {
+    const float* vm = cam.view;
+    const float* pm = cam.proj;
+    const float x = mean[0], y = mean[1], z = mean[2];
+    out.radius = 0;
+    out.tiles = 0;
+    out.minx = out.miny = out.maxx = out.maxy = 0;
+    const float pvx = vm[0] * x + vm[4] * y + vm[8] * z + vm[12];
+    const float pvy = vm[1] * x + vm[5] * y + vm[9] * z + vm[13];
+    const float pvz = vm[2] * x + vm[6] * y + vm[10] * z + vm[14];
+    out.depth = pvz;
+    if (!(pvz > GSR_NEAR_Z)) return false;
+    const float hx = pm[0] * x + pm[4] * y + pm[8] * z + pm[12];
+    const float hy = pm[1] * x + pm[5] * y + pm[9] * z + pm[13];
+    const float hw = pm[3] * x + pm[7] * y + pm[11] * z + pm[15];
+    const float pw = 1.0f / (hw + 1e-7f);
+    const float projx = hx * pw, projy = hy * pw;
+
+    const float txtz = pvx / pvz, tytz = pvy / pvz;
+    const float tx = fminf(cam.limx, fmaxf(-cam.limx, txtz)) * pvz;
+    const float ty = fminf(cam.limy, fmaxf(-cam.limy, tytz)) * pvz;
+    const float tz = pvz;
+    const float tz2 = tz * tz;
+    const float J00 = cam.focal_x / tz;
+    const float J02 = -(cam.focal_x * tx) / tz2;
+    const float J11 = cam.focal_y / tz;
+    const float J12 = -(cam.focal_y * ty) / tz2;
+    const float T00 = J00 * vm[0] + J02 * vm[2];
+    const float T01 = J00 * vm[4] + J02 * vm[6];
+    const float T02 = J00 * vm[8] + J02 * vm[10];
+    const float T10 = J11 * vm[1] + J12 * vm[2];
+    const float T11 = J11 * vm[5] + J12 * vm[6];
+    const float T12 = J11 * vm[9] + J12 * vm[10];
+    const float S00 = cov[0], S01 = cov[1], S02 = cov[2], S11 = cov[3], S12 = cov[4], S22 = cov[5];
+    const float u0 = S00 * T00 + S01 * T01 + S02 * T02;
+    const float u1 = S01 * T00 + S11 * T01 + S12 * T02;
+    const float u2 = S02 * T00 + S12 * T01 + S22 * T02;
+    const float v0 = S00 * T10 + S01 * T11 + S02 * T12;
+    const float v1 = S01 * T10 + S11 * T11 + S12 * T12;
+    const float v2 = S02 * T10 + S12 * T11 + S22 * T12;
+    const float a0 = T00 * u0 + T01 * u1 + T02 * u2;
+    const float b = T10 * u0 + T11 * u1 + T12 * u2;
+    const float c0 = T10 * v0 + T11 * v1 + T12 * v2;
+
+    const float det0 = a0 * c0 - b * b;
+    const float a = a0 + GSR_LOWPASS;
+    const float c = c0 + GSR_LOWPASS;
+    const float det = a * c - b * b;
+    float aa = 1.0f;
+    if (cam.antialiasing) aa = sqrtf(fmaxf(det0 / det, GSR_AA_FLOOR));
+    if (det == 0.0f) return false;
+    const float det_inv = 1.0f / det;
+    out.conA = c * det_inv;
+    out.conB = -b * det_inv;
+    out.conC = a * det_inv;
+
+    const float mid = 0.5f * (a + c);
+    const float disc = sqrtf(fmaxf(mid * mid - det, 0.1f));
+    const float lam = fmaxf(mid + disc, mid - disc);
+    const float radius_f = ceilf(3.0f * sqrtf(lam));
+
+    const float pixx = ((projx + 1.0f) * (float)cam.W - 1.0f) * 0.5f;
+    const float pixy = ((projy + 1.0f) * (float)cam.H - 1.0f) * 0.5f;
+    out.px = pixx;
+    out.py = pixy;
+
+    // tile rectangle: C truncation of the float quotient, clamped to the grid in float (NaN -> 0)
+    const float gxf = (float)cam.gx, gyf = (float)cam.gy;
+    const float lox = fminf(fmaxf(truncf((pixx - radius_f) / 16.0f), 0.0f), gxf);
+    const float hix = fminf(fmaxf(truncf((pixx + radius_f + 15.0f) / 16.0f), 0.0f), gxf);
+    const float loy = fminf(fmaxf(truncf((pixy - radius_f) / 16.0f), 0.0f), gyf);
+    const float hiy = fminf(fmaxf(truncf((pixy + radius_f + 15.0f) / 16.0f), 0.0f), gyf);
+    const int minx = (int)lox, maxx = (int)hix, miny = (int)loy, maxy = (int)hiy;
+    if ((maxx - minx) * (maxy - miny) <= 0) return false;
+    if (!(radius_f < 2.0e9f)) return false;   // inf / NaN radius: treated as culled (oracle: radii = 0)
+    out.radius = (int)radius_f;
+    const int bminy = miny < cam.tile_y0 ? cam.tile_y0 : (miny > cam.tile_y1 ? cam.tile_y1 : miny);
+    const int bmaxy = maxy < cam.tile_y0 ? cam.tile_y0 : (maxy > cam.tile_y1 ? cam.tile_y1 : maxy);
+    out.minx = (uint32_t)minx;
+    out.maxx = (uint32_t)maxx;
+    out.miny = (uint32_t)bminy;
+    out.maxy = (uint32_t)bmaxy;
+    out.tiles = (uint32_t)((maxx - minx) * (bmaxy - bminy));
+    out.opacity = opacity_in * aa;
+    return true;
+}
+
+// SH -> RGB in the expression order of utils/sh_utils.py:78-104, then +0.5, clamp >= 0.
+// sh points at this Gaussian's [M][3] block.
+GSR_HD void gsr_sh_to_rgb(int deg, const float* sh, const float* mean, const float* campos, float* rgb, uint32_t& clamped) {
+    const float dx = mean[0] - campos[0], dy = mean[1] - campos[1], dz = mean[2] - campos[2];
+    const float n = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float x = dx / n, y = dy / n, z = dz / n;
+    clamped = 0;
+    for (int ch = 0; ch < 3; ++ch) {
+        float result = GSR_SH_C0 * sh[0 * 3 + ch];
+        if (deg > 0) {
+            result = result - GSR_SH_C1 * y * sh[1 * 3 + ch] + GSR_SH_C1 * z * sh[2 * 3 + ch] - GSR_SH_C1 * x * sh[3 * 3 + ch];
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z;
+                const float xy = x * y, yz = y * z, xz = x * z;
+                result = result + GSR_SH_C2_0 * xy * sh[4 * 3 + ch] + GSR_SH_C2_1 * yz * sh[5 * 3 + ch] +
+                         GSR_SH_C2_2 * (2.0f * zz - xx - yy) * sh[6 * 3 + ch] + GSR_SH_C2_3 * xz * sh[7 * 3 + ch] +
+                         GSR_SH_C2_4 * (xx - yy) * sh[8 * 3 + ch];
+                if (deg > 2) {
+                    result = result + GSR_SH_C3_0 * y * (3.0f * xx - yy) * sh[9 * 3 + ch] +
+                             GSR_SH_C3_1 * xy * z * sh[10 * 3 + ch] +
+                             GSR_SH_C3_2 * y * (4.0f * zz - xx - yy) * sh[11 * 3 + ch] +
+                             GSR_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[12 * 3 + ch] +
+                             GSR_SH_C3_4 * x * (4.0f * zz - xx - yy) * sh[13 * 3 + ch] +
+                             GSR_SH_C3_5 * z * (xx - yy) * sh[14 * 3 + ch] +
+                             GSR_SH_C3_6 * x * (xx - 3.0f * yy) * sh[15 * 3 + ch];
+                }
+            }
+        }
+        result = result + 0.5f;
+        if (result < 0.0f) clamped |= (1u << ch);
+        rgb[ch] = fmaxf(result, 0.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward.  Conventions: gradients w.r.t. the *plain* conic entries
+// (dA, dB, dC with B the scalar in power = -0.5(A dx^2 + C dy^2) - B dx dy); dpix in pixel units.
+// ------------------------------------------------------------------------------------------------
+struct GsrSplatGrad {          // what the render backward accumulates per Gaussian
+    float dpx, dpy;            // dL/d(pixel-space centre)
+    float dconA, dconB, dconC; // dL/d(conic)
+    float dopacity;            // dL/d(opacity*aa)
+    float dr, dg, db;          // dL/d(rgb after clamp)
+    float dinvdepth;           // dL/d(1/depth) from the inverse-depth image
+};
+
+// Inputs: the forward inputs of this Gaussian; Outputs: accumulated into dmean[3], dcov[6], dopacity_in.
+// Returns false if the Gaussian was culled by the near plane (nothing written).
+GSR_HD void gsr_project_backward(const GsrCam& cam, const float* mean, const float* cov, float opacity_in,
+                                 const GsrSplatGrad& g, float* dmean, float* dcov, float& dopacity_in) {
+    const float* vm = cam.view;
+    const float* pm = cam.proj;
+    const float x = mean[0], y = mean[1], z = mean[2];
+    const float pvx = vm[0] * x + vm[4] * y + vm[8] * z + vm[12];
+    const float pvy = vm[1] * x + vm[5] * y + vm[9] * z + vm[13];
+    const float pvz = vm[2] * x + vm[6] * y + vm[10] * z + vm[14];
+    const float txtz = pvx / pvz, tytz = pvy / pvz;
+    const float inx = (txtz < -cam.limx || txtz > cam.limx) ? 0.0f : 1.0f;
+    const float iny = (tytz < -cam.limy || tytz > cam.limy) ? 0.0f : 1.0f;
+    const float tx = fminf(cam.limx, fmaxf(-cam.limx, txtz)) * pvz;
+    const float ty = fminf(cam.limy, fmaxf(-cam.limy, tytz)) * pvz;
+    const float tz = pvz;
+    const float tz2 = tz * tz;
+    const float itz = 1.0f / tz, itz2 = 1.0f / tz2;
+    const float fx = cam.focal_x, fy = cam.focal_y;
+    const float J00 = fx * itz, J02 = -(fx * tx) * itz2, J11 = fy * itz, J12 = -(fy * ty) * itz2;
+    const float W00 = vm[0], W01 = vm[4], W02 = vm[8];
+    const float W10 = vm[1], W11 = vm[5], W12 = vm[9];
+    const float W20 = vm[2], W21 = vm[6], W22 = vm[10];
+    const float T00 = J00 * W00 + J02 * W20, T01 = J00 * W01 + J02 * W21, T02 = J00 * W02 + J02 * W22;
+    const float T10 = J11 * W10 + J12 * W20, T11 = J11 * W11 + J12 * W21, T12 = J11 * W12 + J12 * W22;
+    const float S00 = cov[0], S01 = cov[1], S02 = cov[2], S11 = cov[3], S12 = cov[4], S22 = cov[5];
+    const float u0 = S00 * T00 + S01 * T01 + S02 * T02;
+    const float u1 = S01 * T00 + S11 * T01 + S12 * T02;
+    const float u2 = S02 * T00 + S12 * T01 + S22 * T02;
+    const float v0 = S00 * T10 + S01 * T11 + S02 * T12;
+    const float v1 = S01 * T10 + S11 * T11 + S12 * T12;
+    const float v2 = S02 * T10 + S12 * T11 + S22 * T12;
+    const float a0 = T00 * u0 + T01 * u1 + T02 * u2;
+    const float b = T10 * u0 + T11 * u1 + T12 * u2;
+    const float c0 = T10 * v0 + T11 * v1 + T12 * v2;
+    const float det0 = a0 * c0 - b * b;
+    const float a = a0 + GSR_LOWPASS, c = c0 + GSR_LOWPASS;
+    const float det = a * c - b * b;
+
+    // --- opacity * aa ---
+    float da = 0.0f, db = 0.0f, dc = 0.0f;   // dL/d(a,b,c) of the low-passed Sigma2D (b = off-diagonal entry)
+    float aa = 1.0f;
+    if (cam.antialiasing) {
+        const float ratio = det0 / det;
+        aa = sqrtf(fmaxf(ratio, GSR_AA_FLOOR));
+        if (ratio > GSR_AA_FLOOR) {
+            // opacity = o * sqrt(det0/det): d/d(ratio) = o * 0.5 / aa
+            const float dratio = g.dopacity * opacity_in * 0.5f / aa;
+            const float ddet0 = dratio / det;
+            const float ddet = -dratio * det0 / (det * det);
+            // det0 = a0 c0 - b^2 ; det = a c - b^2 ; a = a0 + h, c = c0 + h
+            da += ddet0 * c0 + ddet * c;
+            dc += ddet0 * a0 + ddet * a;
+            db += -2.0f * b * (ddet0 + ddet);
+        }
+    }
+    dopacity_in = g.dopacity * aa;
+
+    // --- conic = inverse(Sigma2D), reference uses 1/(det^2 + 1e-7) ---
+    {
+        const float d2 = 1.0f / (det * det + 1e-7f);
+        const float gA = g.dconA, gB = g.dconB, gC = g.dconC;
+        da += d2 * (-c * c * gA + b * c * gB + (det - a * c) * gC);
+        dc += d2 * (-a * a * gC + a * b * gB + (det - a * c) * gA);
+        db += d2 * (2.0f * b * c * gA - (det + 2.0f * b * b) * gB + 2.0f * a * b * gC);
+    }
+
+    // --- Sigma2D = T Sigma T^T  (a = T0.S.T0, b = T1.S.T0, c = T1.S.T1) ---
+    // dL/dSigma (symmetric, independent entries S00,S01,S02,S11,S12,S22; off-diagonals appear twice)
+    dcov[0] += T00 * T00 * da + T00 * T10 * db + T10 * T10 * dc;
+    dcov[3] += T01 * T01 * da + T01 * T11 * db + T11 * T11 * dc;
+    dcov[5] += T02 * T02 * da + T02 * T12 * db + T12 * T12 * dc;
+    dcov[1] += 2.0f * T00 * T01 * da + (T00 * T11 + T01 * T10) * db + 2.0f * T10 * T11 * dc;
+    dcov[2] += 2.0f * T00 * T02 * da + (T00 * T12 + T02 * T10) * db + 2.0f * T10 * T12 * dc;
+    dcov[4] += 2.0f * T01 * T02 * da + (T01 * T12 + T02 * T11) * db + 2.0f * T11 * T12 * dc;
+    // dL/dT: a = sum T0j u_j (u = S T0): da/dT0j = 2 u_j ; b = sum T1j u_j: db/dT1j = u_j, db/dT0j = v_j ; dc/dT1j = 2 v_j
+    const float dT00 = 2.0f * u0 * da + v0 * db, dT01 = 2.0f * u1 * da + v1 * db, dT02 = 2.0f * u2 * da + v2 * db;
+    const float dT10 = 2.0f * v0 * dc + u0 * db, dT11 = 2.0f * v1 * dc + u1 * db, dT12 = 2.0f * v2 * dc + u2 * db;
+    // T0j = J00 W0j + J02 W2j ; T1j = J11 W1j + J12 W2j
+    const float dJ00 = W00 * dT00 + W01 * dT01 + W02 * dT02;
+    const float dJ02 = W20 * dT00 + W21 * dT01 + W22 * dT02;
+    const float dJ11 = W10 * dT10 + W11 * dT11 + W12 * dT12;
+    const float dJ12 = W20 * dT10 + W21 * dT11 + W22 * dT12;
+    // J00 = fx/tz, J02 = -fx tx/tz^2, J11 = fy/tz, J12 = -fy ty/tz^2 ; tx, ty constant w.r.t. tz when clamped
+    const float itz3 = itz2 * itz;
+    float dtx = inx * (-fx * itz2 * dJ02);
+    float dty = iny * (-fy * itz2 * dJ12);
+    float dtz = -fx * itz2 * dJ00 - fy * itz2 * dJ11 + 2.0f * fx * tx * itz3 * dJ02 + 2.0f * fy * ty * itz3 * dJ12;
+    // inverse depth image: D += (1/depth) w  => dL/d(depth) = -dinvdepth / tz^2
+    dtz += -g.dinvdepth * itz2;
+
+    // --- pixel centre through the perspective divide of the full projection ---
+    const float hx = pm[0] * x + pm[4] * y + pm[8] * z + pm[12];
+    const float hy = pm[1] * x + pm[5] * y + pm[9] * z + pm[13];
+    const float hw = pm[3] * x + pm[7] * y + pm[11] * z + pm[15];
+    const float pw = 1.0f / (hw + 1e-7f);
+    const float dprojx = g.dpx * 0.5f * (float)cam.W;   // pix = ((proj+1) W - 1)/2
+    const float dprojy = g.dpy * 0.5f * (float)cam.H;
+    const float dhx = dprojx * pw, dhy = dprojy * pw;
+    const float dhw = -(dprojx * hx + dprojy * hy) * pw * pw;
+    dmean[0] += pm[0] * dhx + pm[1] * dhy + pm[3] * dhw;
+    dmean[1] += pm[4] * dhx + pm[5] * dhy + pm[7] * dhw;
+    dmean[2] += pm[8] * dhx + pm[9] * dhy + pm[11] * dhw;
+    // --- view-space position t = W p + t0 ---
+    dmean[0] += W00 * dtx + W10 * dty + W20 * dtz;
+    dmean[1] += W01 * dtx + W11 * dty + W21 * dtz;
+    dmean[2] += W02 * dtx + W12 * dty + W22 * dtz;
+}
+
+// SH backward: drgb = dL/d(rgb after clamp).  Writes dsh[M][3] (all M rows; rows above the active degree
+// are zero) and accumulates the view-direction term into dmean.
+GSR_HD void gsr_sh_backward(int deg, int M, const float* sh, const float* mean, const float* campos,
+                            uint32_t clamped, const float* drgb_in, float* dsh, float* dmean) {
+    const float ox = mean[0] - campos[0], oy = mean[1] - campos[1], oz = mean[2] - campos[2];
+    const float n = sqrtf(ox * ox + oy * oy + oz * oz);
+    const float x = ox / n, y = oy / n, z = oz / n;
+    float drgb[3];
+    for (int ch = 0; ch < 3; ++ch) drgb[ch] = (clamped & (1u << ch)) ? 0.0f : drgb_in[ch];
+    float ddx = 0.0f, ddy = 0.0f, ddz = 0.0f;   // dL/d(unit direction)
+    for (int k = 0; k < M * 3; ++k) dsh[k] = 0.0f;
+    float basis[16], bx[16], by[16], bz[16];
+    for (int k = 0; k < 16; ++k) basis[k] = bx[k] = by[k] = bz[k] = 0.0f;
+    basis[0] = GSR_SH_C0;
+    int nb = 1;
+    if (deg > 0) {
+        basis[1] = -GSR_SH_C1 * y; by[1] = -GSR_SH_C1;
+        basis[2] = GSR_SH_C1 * z;  bz[2] = GSR_SH_C1;
+        basis[3] = -GSR_SH_C1 * x; bx[3] = -GSR_SH_C1;
+        nb = 4;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            basis[4] = GSR_SH_C2_0 * xy;                  bx[4] = GSR_SH_C2_0 * y; by[4] = GSR_SH_C2_0 * x;
+            basis[5] = GSR_SH_C2_1 * yz;                  by[5] = GSR_SH_C2_1 * z; bz[5] = GSR_SH_C2_1 * y;
+            basis[6] = GSR_SH_C2_2 * (2.0f * zz - xx - yy);
+            bx[6] = GSR_SH_C2_2 * -2.0f * x; by[6] = GSR_SH_C2_2 * -2.0f * y; bz[6] = GSR_SH_C2_2 * 4.0f * z;
+            basis[7] = GSR_SH_C2_3 * xz;                  bx[7] = GSR_SH_C2_3 * z; bz[7] = GSR_SH_C2_3 * x;
+            basis[8] = GSR_SH_C2_4 * (xx - yy);           bx[8] = GSR_SH_C2_4 * 2.0f * x; by[8] = GSR_SH_C2_4 * -2.0f * y;
+            nb = 9;
+            if (deg > 2) {
+                basis[9] = GSR_SH_C3_0 * y * (3.0f * xx - yy);
+                bx[9] = GSR_SH_C3_0 * 6.0f * xy; by[9] = GSR_SH_C3_0 * (3.0f * xx - 3.0f * yy);
+                basis[10] = GSR_SH_C3_1 * xy * z;
+                bx[10] = GSR_SH_C3_1 * yz; by[10] = GSR_SH_C3_1 * xz; bz[10] = GSR_SH_C3_1 * xy;
+                basis[11] = GSR_SH_C3_2 * y * (4.0f * zz - xx - yy);
+                bx[11] = GSR_SH_C3_2 * -2.0f * xy; by[11] = GSR_SH_C3_2 * (4.0f * zz - xx - 3.0f * yy); bz[11] = GSR_SH_C3_2 * 8.0f * yz;
+                basis[12] = GSR_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                bx[12] = GSR_SH_C3_3 * -6.0f * xz; by[12] = GSR_SH_C3_3 * -6.0f * yz; bz[12] = GSR_SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy);
+                basis[13] = GSR_SH_C3_4 * x * (4.0f * zz - xx - yy);
+                bx[13] = GSR_SH_C3_4 * (4.0f * zz - 3.0f * xx - yy); by[13] = GSR_SH_C3_4 * -2.0f * xy; bz[13] = GSR_SH_C3_4 * 8.0f * xz;
+                basis[14] = GSR_SH_C3_5 * z * (xx - yy);
+                bx[14] = GSR_SH_C3_5 * 2.0f * xz; by[14] = GSR_SH_C3_5 * -2.0f * yz; bz[14] = GSR_SH_C3_5 * (xx - yy);
+                basis[15] = GSR_SH_C3_6 * x * (xx - 3.0f * yy);
+                bx[15] = GSR_SH_C3_6 * (3.0f * xx - 3.0f * yy); by[15] = GSR_SH_C3_6 * -6.0f * xy;
+                nb = 16;
+            }
+        }
+    }
+    // fully unrolled with constant indices so basis/bx/by/bz stay in registers (no scratch)
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 16; ++k) {
+        if (k >= nb || k >= M) continue;
+        float dot = 0.0f;
+        for (int ch = 0; ch < 3; ++ch) {
+            dsh[k * 3 + ch] = basis[k] * drgb[ch];
+            dot += sh[k * 3 + ch] * drgb[ch];
+        }
+        ddx += bx[k] * dot;
+        ddy += by[k] * dot;
+        ddz += bz[k] * dot;
+    }
+    // d = o / |o|  =>  dL/do = (dL/dd - d (d . dL/dd)) / |o|
+    const float dd = x * ddx + y * ddy + z * ddz;
+    const float inv = 1.0f / n;
+    dmean[0] += (ddx - x * dd) * inv;
+    dmean[1] += (ddy - y * dd) * inv;
+    dmean[2] += (ddz - z * dd) * inv;
+}
+
+// Sigma3D = (R S)(R S)^T backward: dcov (independent packed entries) -> dscale[3], drot[4]
+// (w.r.t. the quaternion as given, no normalisation backward).
+GSR_HD void gsr_cov3d_backward(const float* s, float mod, const float* q, const float* dcov, float* dscale, float* drot) {
+    const float s0 = mod * s[0], s1 = mod * s[1], s2 = mod * s[2];
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    const float R[3][3] = {{1.0f - 2.0f * (y * y + z * z), 2.0f * (x * y - r * z), 2.0f * (x * z + r * y)},
+                           {2.0f * (x * y + r * z), 1.0f - 2.0f * (x * x + z * z), 2.0f * (y * z - r * x)},
+                           {2.0f * (x * z - r * y), 2.0f * (y * z + r * x), 1.0f - 2.0f * (x * x + y * y)}};
+    const float sv[3] = {s0, s1, s2};
+    float Mm[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Mm[i][j] = R[i][j] * sv[j];
+    // full symmetric gradient matrix G with G_ij = dL/dSigma_ij counting each off-diagonal independent
+    // entry once split over both positions: Sigma = M M^T => dL/dM = (G + G^T) M with G upper-packed/2
+    const float G[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                           {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                           {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+    float dM[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float acc = 0.0f;
+            for (int k = 0; k < 3; ++k) acc += 2.0f * G[i][k] * Mm[k][j];
+            dM[i][j] = acc;
+        }
+    float dR[3][3];
+    for (int j = 0; j < 3; ++j) {
+        float acc = 0.0f;
+        for (int i = 0; i < 3; ++i) {
+            acc += dM[i][j] * R[i][j];
+            dR[i][j] = dM[i][j] * sv[j];
+        }
+        dscale[j] = acc * mod;
+    }
+    drot[0] = 2.0f * (z * (dR[1][0] - dR[0][1]) + y * (dR[0][2] - dR[2][0]) + x * (dR[2][1] - dR[1][2]));
+    drot[1] = 2.0f * (y * (dR[0][1] + dR[1][0]) + z * (dR[0][2] + dR[2][0]) + r * (dR[2][1] - dR[1][2])) -
+              4.0f * x * (dR[1][1] + dR[2][2]);
+    drot[2] = 2.0f * (x * (dR[0][1] + dR[1][0]) + r * (dR[0][2] - dR[2][0]) + z * (dR[1][2] + dR[2][1])) -
+              4.0f * y * (dR[0][0] + dR[2][2]);
+    drot[3] = 2.0f * (r * (dR[1][0] - dR[0][1]) + x * (dR[0][2] + dR[2][0]) + y * (dR[1][2] + dR[2][1])) -
+              4.0f * z * (dR[0][0] + dR[1][1]);
+}

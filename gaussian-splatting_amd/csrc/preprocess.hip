@@ -1,0 +1,221 @@
+// Per-Gaussian streaming kernels: forward preprocess, fused backward (K8+K9), markVisible (K10).
+// Replaces preprocessCUDA / computeCov2DCUDA / checkFrustum of the un-vendored reference rasterizer
+// (reference call site: gaussian_renderer/__init__.py:91-110; algorithm: SURVEY.md Appendix A.2 / A.6).
+//
+// COMPILE WITH -ffp-contract=off : the integer-deciding arithmetic (radius, tile rectangle) must match
+// oracle/torch_oracle.py bit for bit (see gsr_math.h).
+//
+// gfx950 notes: HBM-streaming, one Gaussian per lane, 256-thread workgroups, grid-stride capped at 2048
+// workgroups (8 per CU).  The 192-byte SH record per Gaussian dominates the input stream; it is skipped
+// for culled Gaussians and read with 16-byte loads.  Camera matrices are wave-uniform -> scalar loads.
+#include "gsr_internal.h"
+
+namespace {
+
+__device__ __forceinline__ void load_cam(const GsrCamDev& c, GsrCam& cam) {
+    cam.W = c.W; cam.H = c.H; cam.gx = c.gx; cam.gy = c.gy;
+    cam.focal_x = c.focal_x; cam.focal_y = c.focal_y; cam.limx = c.limx; cam.limy = c.limy;
+    cam.scale_modifier = c.scale_modifier; cam.sh_degree = c.sh_degree; cam.M = c.M;
+    cam.antialiasing = c.antialiasing; cam.tile_y0 = c.tile_y0; cam.tile_y1 = c.tile_y1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { cam.view[i] = c.view[i]; cam.proj[i] = c.proj[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cam.campos[i] = c.campos[i];
+}
+
+// Load this Gaussian's SH block [M][3] into registers with 16-byte loads (the block is 12*M bytes,
+// 16-byte aligned whenever M is a multiple of 4, i.e. max degree 1 or 3; otherwise scalar loads).
+template <int MAXC>
+__device__ __forceinline__ void load_sh(const float* __restrict__ shs, int64_t i, int M, int ncoef, float* sh) {
+    const float* p = shs + i * (int64_t)M * 3;
+    if ((M & 3) == 0) {
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll
+        for (int k = 0; k < MAXC * 3 / 4; ++k) {
+            if (k * 4 < ncoef * 3) {
+                const float4 v = p4[k];
+                sh[k * 4 + 0] = v.x; sh[k * 4 + 1] = v.y; sh[k * 4 + 2] = v.z; sh[k * 4 + 3] = v.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < MAXC * 3; ++k)
+            if (k < ncoef * 3) sh[k] = p[k];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
+                      const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+                      const float* __restrict__ scales, const float* __restrict__ rotations,
+                      const float* __restrict__ cov3D_precomp, float4* __restrict__ splats,
+                      uint2* __restrict__ rect, uint32_t* __restrict__ tiles, uint32_t* __restrict__ clamped_out,
+                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int32_t* __restrict__ radii) {
+    GsrCam cam;
+    load_cam(camd, cam);
+    const int ncoef = (cam.sh_degree + 1) * (cam.sh_degree + 1);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const float mean[3] = {means3D[i * 3 + 0], means3D[i * 3 + 1], means3D[i * 3 + 2]};
+        float cov[6];
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) cov[k] = cov3D_precomp[i * 6 + k];
+        } else {
+            const float s[3] = {scales[i * 3 + 0], scales[i * 3 + 1], scales[i * 3 + 2]};
+            const float4 q4 = reinterpret_cast<const float4*>(rotations)[i];
+            const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+            gsr_cov3d(s, cam.scale_modifier, q, cov);
+        }
+        GsrSplat sp;
+        const bool vis = gsr_project(cam, mean, cov, opacities[i], sp);
+        uint32_t clampbits = 0;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+        if (vis) {
+            float rgb[3];
+            if (colors_precomp) {
+                rgb[0] = colors_precomp[i * 3 + 0]; rgb[1] = colors_precomp[i * 3 + 1]; rgb[2] = colors_precomp[i * 3 + 2];
+            } else {
+                float sh[48];
+                load_sh<16>(shs, i, cam.M, ncoef, sh);
+                gsr_sh_to_rgb(cam.sh_degree, sh, mean, cam.campos, rgb, clampbits);
+            }
+            q0 = make_float4(sp.px, sp.py, sp.conA, sp.conB);
+            q1 = make_float4(sp.conC, sp.opacity, rgb[0], rgb[1]);
+            q2 = make_float4(rgb[2], sp.depth, 0.f, 0.f);
+        }
+        splats[i * 3 + 0] = q0;
+        splats[i * 3 + 1] = q1;
+        splats[i * 3 + 2] = q2;
+        rect[i] = make_uint2(sp.minx | (sp.maxx << 16), sp.miny | (sp.maxy << 16));
+        tiles[i] = sp.tiles;
+        clamped_out[i] = clampbits;
+        radii[i] = sp.radius;
+        // depth-sort key: positive fp32 bit patterns order like the floats; Gaussians with no tile in
+        // the band sort last.
+        keys[i] = sp.tiles ? __float_as_uint(sp.depth) : 0xFFFFFFFFu;
+        vals[i] = (uint32_t)i;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
+                      const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
+                      const float* __restrict__ scales, const float* __restrict__ rotations,
+                      const float* __restrict__ cov3D_precomp, const int32_t* __restrict__ radii,
+                      const uint32_t* __restrict__ clamped, const float4* __restrict__ grads,
+                      float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
+                      float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+                      float* __restrict__ dL_dscales, float* __restrict__ dL_drotations) {
+    GsrCam cam;
+    load_cam(camd, cam);
+    const int M = cam.M;
+    const int ncoef = (cam.sh_degree + 1) * (cam.sh_degree + 1);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        float dmean[3] = {0.f, 0.f, 0.f};
+        float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float dscale[3] = {0.f, 0.f, 0.f};
+        float drot[4] = {0.f, 0.f, 0.f, 0.f};
+        float dop = 0.f;
+        float dm2x = 0.f, dm2y = 0.f;
+        float drgb[3] = {0.f, 0.f, 0.f};
+        const bool vis = radii[i] > 0;
+        if (vis) {
+            const float4 g0 = grads[i * 3 + 0], g1 = grads[i * 3 + 1], g2 = grads[i * 3 + 2];
+            GsrSplatGrad g;
+            g.dpx = g0.x; g.dpy = g0.y; g.dconA = g0.z; g.dconB = g0.w;
+            g.dconC = g1.x; g.dopacity = g1.y; g.dr = g1.z; g.dg = g1.w;
+            g.db = g2.x; g.dinvdepth = g2.y;
+            drgb[0] = g.dr; drgb[1] = g.dg; drgb[2] = g.db;
+            const float mean[3] = {means3D[i * 3 + 0], means3D[i * 3 + 1], means3D[i * 3 + 2]};
+            float cov[6];
+            float s[3], q[4];
+            if (cov3D_precomp) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) cov[k] = cov3D_precomp[i * 6 + k];
+            } else {
+                s[0] = scales[i * 3 + 0]; s[1] = scales[i * 3 + 1]; s[2] = scales[i * 3 + 2];
+                const float4 q4 = reinterpret_cast<const float4*>(rotations)[i];
+                q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+                gsr_cov3d(s, cam.scale_modifier, q, cov);
+            }
+            gsr_project_backward(cam, mean, cov, opacities[i], g, dmean, dcov, dop);
+            // the returned means2D gradient is in NDC-scaled units (SURVEY A.5 units trap)
+            dm2x = g.dpx * (0.5f * (float)cam.W);
+            dm2y = g.dpy * (0.5f * (float)cam.H);
+            if (!cov3D_precomp) gsr_cov3d_backward(s, cam.scale_modifier, q, dcov, dscale, drot);
+            if (shs) {
+                float sh[48];
+                float dsh[48];
+                load_sh<16>(shs, i, M, ncoef, sh);
+                gsr_sh_backward(cam.sh_degree, M < 16 ? M : 16, sh, mean, cam.campos, clamped[i], drgb, dsh, dmean);
+                float* o = dL_dsh + i * (int64_t)M * 3;
+                if ((M & 3) == 0) {
+                    float4* o4 = reinterpret_cast<float4*>(o);
+#pragma unroll
+                    for (int k = 0; k < 12; ++k)
+                        if (k * 4 < M * 3) o4[k] = make_float4(dsh[k * 4], dsh[k * 4 + 1], dsh[k * 4 + 2], dsh[k * 4 + 3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 48; ++k)
+                        if (k < M * 3) o[k] = dsh[k];
+                }
+            }
+        } else if (shs) {
+            float* o = dL_dsh + i * (int64_t)M * 3;
+            for (int k = 0; k < M * 3; ++k) o[k] = 0.f;
+        }
+        dL_dmeans2D[i * 3 + 0] = dm2x; dL_dmeans2D[i * 3 + 1] = dm2y; dL_dmeans2D[i * 3 + 2] = 0.f;
+        dL_dcolors[i * 3 + 0] = drgb[0]; dL_dcolors[i * 3 + 1] = drgb[1]; dL_dcolors[i * 3 + 2] = drgb[2];
+        dL_dopacity[i] = dop;
+        dL_dmeans3D[i * 3 + 0] = dmean[0]; dL_dmeans3D[i * 3 + 1] = dmean[1]; dL_dmeans3D[i * 3 + 2] = dmean[2];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dL_dcov3D[i * 6 + k] = dcov[k];
+        if (dL_dscales) {
+            dL_dscales[i * 3 + 0] = dscale[0]; dL_dscales[i * 3 + 1] = dscale[1]; dL_dscales[i * 3 + 2] = dscale[2];
+            reinterpret_cast<float4*>(dL_drotations)[i] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ vm, uint8_t* __restrict__ present) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = means3D[i * 3 + 0], y = means3D[i * 3 + 1], z = means3D[i * 3 + 2];
+        const float pvz = vm[2] * x + vm[6] * y + vm[10] * z + vm[14];
+        present[i] = pvz > GSR_NEAR_Z ? 1 : 0;
+    }
+}
+
+inline int stream_grid(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+void gsr_launch_preprocess(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* opacities, const float* scales,
+                           const float* rotations, const float* cov3D_precomp, GsrGeom g, int32_t* radii,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs,
+                       colors_precomp, opacities, scales, rotations, cov3D_precomp, g.splats, g.rect, g.tiles,
+                       g.clamped, g.keys[0], g.vals[0], radii);
+}
+
+void gsr_launch_preprocess_backward(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
+                                    const float* colors_precomp, const float* opacities, const float* scales,
+                                    const float* rotations, const float* cov3D_precomp, const int32_t* radii,
+                                    GsrGeom g, const float* splat_grads, float* dL_dmeans2D, float* dL_dcolors,
+                                    float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                                    float* dL_dscales, float* dL_drotations, hipStream_t st) {
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs,
+                       colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g.clamped,
+                       reinterpret_cast<const float4*>(splat_grads), dL_dmeans2D, dL_dcolors, dL_dopacity,
+                       dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
+}
+
+void gsr_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st) {
+    hipLaunchKernelGGL(mark_visible_kernel, dim3(stream_grid(P)), dim3(256), 0, st, P, means3D, view, present);
+}

@@ -1,0 +1,217 @@
+// Forward alpha-compositing of the per-tile depth-sorted splat lists -- replaces renderCUDA (forward) of the
+// un-vendored reference rasterizer (algorithm SURVEY.md Appendix A.4; caller:
+// gaussian_renderer/__init__.py:91-110).
+//
+// Two gfx950 designs behind one launcher (variant chosen by gsr_set_option("render_fwd_variant")):
+//
+//  variant 1  "block"  : one 256-thread workgroup per 16x16 tile (4 waves x 4 rows), the tile's list staged
+//                        through LDS 256 entries at a time, every lane evaluates every entry (LDS broadcast
+//                        reads), workgroup-wide "all done" vote per batch.  The classic structure; kept as the
+//                        A/B baseline.
+//  variant 0  "wave"   : (default) one wave64 per 8x8 pixel block, no LDS, no barriers.  The 64 lanes first act
+//                        as 64 *Gaussian* lanes: each loads one list entry (coalesced index read + 48-byte record
+//                        gather) and tests it against the wave's 8x8 pixel box with an exact min-of-quadratic-
+//                        over-a-box test -- entries that cannot reach alpha >= 1/255 anywhere in the box are
+//                        dropped.  A 64-bit ballot gives the survivor mask; the wave then walks the set bits
+//                        (s_ff1) and the lanes switch to *pixel* lanes, each blending the survivor (record
+//                        broadcast with v_readlane into SGPRs).  Dropping is exact: a dropped entry would have
+//                        been skipped by every pixel of the box anyway (alpha < 1/255), and skipped entries
+//                        leave no trace in any output (contributor numbering is by list position).
+//                        The blend loop is fp32-VALU/exp bound; the box test removes the pair
+//                        evaluations that the reference's square 3-sigma binning wastes.
+//
+// Numerics: fp32, FMA contraction allowed, exp through v_exp_f32 (__expf).  Image parity with the oracle is
+// <= 1e-5 except at pixels where a hard threshold (alpha<1/255, T<1e-4, power>0) is within rounding noise
+// (tests/ use the oracle's "fragile" mask for those).
+#include "gsr_internal.h"
+
+namespace {
+
+struct PixState {
+    float T, C0, C1, C2, D;
+    uint32_t last;
+    bool done;
+};
+
+// One (pixel, Gaussian) step of Appendix A.4.  pos = 1-based position of the entry in the tile's list.
+__device__ __forceinline__ void blend_step(PixState& s, float pxf, float pyf, float gx_, float gy_, float cA, float cB,
+                                           float cC, float op, float r, float g, float b, float invd, uint32_t pos) {
+    const float dx = gx_ - pxf, dy = gy_ - pyf;
+    const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
+    if (power > 0.0f) return;
+    const float alpha = fminf(GSR_ALPHA_MAX, op * __expf(power));
+    if (alpha < GSR_ALPHA_MIN) return;
+    const float testT = s.T * (1.0f - alpha);
+    if (testT < GSR_T_EPS) { s.done = true; return; }
+    const float w = alpha * s.T;
+    s.C0 += r * w; s.C1 += g * w; s.C2 += b * w; s.D += invd * w;
+    s.T = testT;
+    s.last = pos;
+}
+
+// ------------------------------------------------------------------------------------------------
+// variant 1: workgroup per tile, LDS staging
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+render_fwd_block(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                 const float4* __restrict__ splats, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                 float* __restrict__ out_color, float* __restrict__ out_invdepth) {
+    __shared__ float4 s_q0[256];
+    __shared__ float4 s_q1[256];
+    __shared__ float2 s_q2[256];
+    const int tid = threadIdx.x;
+    const int tile = cam.tile_y0 * cam.gx + blockIdx.x;
+    const int tx = tile % cam.gx, ty = tile / cam.gx;
+    const int px = tx * GSR_TILE + (tid & 15), py = ty * GSR_TILE + (tid >> 4);
+    const bool inside = px < cam.W && py < cam.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const uint2 range = ranges[tile];
+    PixState s = {1.0f, 0.f, 0.f, 0.f, 0.f, 0u, !inside};
+    for (uint32_t base = range.x; base < range.y; base += 256) {
+        if (__syncthreads_count(s.done) == 256) break;
+        const uint32_t n = min(256u, range.y - base);
+        if ((uint32_t)tid < n) {
+            const uint32_t id = point_list[base + tid];
+            s_q0[tid] = splats[id * 3 + 0];
+            s_q1[tid] = splats[id * 3 + 1];
+            const float4 q2 = splats[id * 3 + 2];
+            s_q2[tid] = make_float2(q2.x, 1.0f / q2.y);
+        }
+        __syncthreads();
+        if (!s.done) {
+            for (uint32_t j = 0; j < n; ++j) {
+                const float4 q0 = s_q0[j];
+                const float4 q1 = s_q1[j];
+                const float2 q2 = s_q2[j];
+                blend_step(s, pxf, pyf, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, base - range.x + j + 1);
+                if (s.done) break;
+            }
+        }
+    }
+    if (inside) {
+        const int64_t pix = (int64_t)py * cam.W + px;
+        const int64_t HW = (int64_t)cam.H * cam.W;
+        final_T[pix] = s.T;
+        n_contrib[pix] = s.last;
+        out_color[pix] = s.C0 + s.T * cam.bg[0];
+        out_color[HW + pix] = s.C1 + s.T * cam.bg[1];
+        out_color[2 * HW + pix] = s.C2 + s.T * cam.bg[2];
+        if (out_invdepth) out_invdepth[pix] = s.D;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// variant 0: wave per 8x8 pixel block, box culling, readlane broadcast
+// ------------------------------------------------------------------------------------------------
+// Smallest value of q(d) = A dx^2 + 2 B dx dy + C dy^2 over the pixel box [x0,x1]x[y0,y1] for a Gaussian centred
+// at (mx,my).  Exact for positive-definite (A,B,C): the minimiser is the centre if it is inside, otherwise it
+// lies on an edge facing the centre, where q restricted to the edge is a 1-D parabola with a clamped optimum.
+__device__ __forceinline__ float min_q_over_box(float mx, float my, float A, float B, float C, float x0, float x1,
+                                                float y0, float y1) {
+    const float lx = x0 - mx, hx = x1 - mx, ly = y0 - my, hy = y1 - my;   // box in centre-relative coords
+    const bool in_x = (lx <= 0.0f) && (hx >= 0.0f);
+    const bool in_y = (ly <= 0.0f) && (hy >= 0.0f);
+    float q = 3.0e38f;
+    if (in_x && in_y) return 0.0f;
+    if (!in_x) {
+        const float dx = lx > 0.0f ? lx : hx;                 // facing vertical edge
+        const float dy = fminf(hy, fmaxf(ly, -B * dx / C));   // clamped optimum along it
+        q = fminf(q, A * dx * dx + 2.0f * B * dx * dy + C * dy * dy);
+    }
+    if (!in_y) {
+        const float dy = ly > 0.0f ? ly : hy;
+        const float dx = fminf(hx, fmaxf(lx, -B * dy / A));
+        q = fminf(q, A * dx * dx + 2.0f * B * dx * dy + C * dy * dy);
+    }
+    return q;
+}
+
+__device__ __forceinline__ float bcast(float v, int srclane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
+}
+
+__global__ void __launch_bounds__(64)
+render_fwd_wave(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ranges,
+                const uint32_t* __restrict__ point_list, const float4* __restrict__ splats,
+                float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+                float* __restrict__ out_invdepth) {
+    // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed).  The four 8x8 quadrants of a tile share one
+    // splat list, so they are given ids b, b+8, b+16, b+24 -> same XCD -> same L2.
+    const int b = blockIdx.x;
+    const int grp = b >> 5, r32 = b & 31;
+    const int tile_local = grp * 8 + (r32 & 7);
+    const int quad = r32 >> 3;
+    if (tile_local >= n_band_tiles) return;
+    const int tile = cam.tile_y0 * cam.gx + tile_local;
+    const int tx = tile % cam.gx, ty = tile / cam.gx;
+    const int lane = threadIdx.x;
+    const int bx0 = tx * GSR_TILE + (quad & 1) * 8, by0 = ty * GSR_TILE + (quad >> 1) * 8;
+    if (bx0 >= cam.W || by0 >= cam.H) return;                         // whole 8x8 block outside the image
+    const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
+    const bool inside = px < cam.W && py < cam.H;
+    const float pxf = (float)px, pyf = (float)py;
+    // the box holds only pixels that exist
+    const float x0 = (float)bx0, x1 = (float)min(bx0 + 7, cam.W - 1);
+    const float y0 = (float)by0, y1 = (float)min(by0 + 7, cam.H - 1);
+    const uint2 range = ranges[tile];
+    PixState s = {1.0f, 0.f, 0.f, 0.f, 0.f, 0u, !inside};
+
+    for (uint32_t base = range.x; base < range.y; base += 64) {
+        const uint32_t n = min(64u, range.y - base);
+        // ---- Gaussian lanes: load one entry each, box test ----
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+        float colb = 0.f, invd = 0.f;
+        bool keep = false;
+        if ((uint32_t)lane < n) {
+            const uint32_t id = point_list[base + lane];
+            q0 = splats[id * 3 + 0];
+            q1 = splats[id * 3 + 1];
+            const float4 q2 = splats[id * 3 + 2];
+            colb = q2.x;
+            invd = 1.0f / q2.y;
+            // alpha = op * exp(-q/2) >= 1/255  <=>  q <= 2 ln(255 op).  0.01 slack keeps the test conservative
+            // against rounding (alpha at the slack boundary is 0.995/255).
+            const float tau = 2.0f * __logf(255.0f * q1.y) + 0.01f;
+            const float qmin = min_q_over_box(q0.x, q0.y, q0.z, q0.w, q1.x, x0, x1, y0, y1);
+            keep = !(qmin > tau);
+        }
+        uint64_t mask = __ballot(keep);
+        // ---- pixel lanes: blend the survivors in list order ----
+        while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const float gx_ = bcast(q0.x, j), gy_ = bcast(q0.y, j), cA = bcast(q0.z, j), cB = bcast(q0.w, j);
+            const float cC = bcast(q1.x, j), op = bcast(q1.y, j), cr = bcast(q1.z, j), cg = bcast(q1.w, j);
+            const float cb = bcast(colb, j), id_ = bcast(invd, j);
+            if (!s.done) blend_step(s, pxf, pyf, gx_, gy_, cA, cB, cC, op, cr, cg, cb, id_, base - range.x + j + 1);
+        }
+        if (__ballot(!s.done) == 0ull) break;
+    }
+    if (inside) {
+        const int64_t pix = (int64_t)py * cam.W + px;
+        const int64_t HW = (int64_t)cam.H * cam.W;
+        final_T[pix] = s.T;
+        n_contrib[pix] = s.last;
+        out_color[pix] = s.C0 + s.T * cam.bg[0];
+        out_color[HW + pix] = s.C1 + s.T * cam.bg[1];
+        out_color[2 * HW + pix] = s.C2 + s.T * cam.bg[2];
+        if (out_invdepth) out_invdepth[pix] = s.D;
+    }
+}
+
+}  // namespace
+
+void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,
+                               const float4* splats, float* final_T, uint32_t* n_contrib, float* out_color,
+                               float* out_invdepth, int variant, hipStream_t st) {
+    const int n_band_tiles = cam.gx * (cam.tile_y1 - cam.tile_y0);
+    if (n_band_tiles <= 0) return;
+    if (variant == 1) {
+        hipLaunchKernelGGL(render_fwd_block, dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats,
+                           final_T, n_contrib, out_color, out_invdepth);
+    } else {
+        const int groups = (n_band_tiles + 7) / 8;
+        hipLaunchKernelGGL(render_fwd_wave, dim3(groups * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list,
+                           splats, final_T, n_contrib, out_color, out_invdepth);
+    }
+}

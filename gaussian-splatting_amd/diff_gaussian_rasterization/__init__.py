@@ -1,0 +1,240 @@
+"""MI355X-native drop-in for the reference's `diff_gaussian_rasterization` package.
+
+Exports exactly what gaussian_renderer/__init__.py:14 imports -- `GaussianRasterizationSettings` and
+`GaussianRasterizer` -- with the same constructor fields (gaussian_renderer/__init__.py:36-50), the same
+keyword call (gaussian_renderer/__init__.py:102-110), the same 3-tuple return `(color[3,H,W], radii[P],
+invdepth[1,H,W])` and the same autograd contract (gradients to means3D, means2D (NDC-scaled dummy, read at
+scene/gaussian_model.py:472), shs / colors_precomp, opacities, scales, rotations / cov3D_precomp).
+
+It deliberately does NOT export `SparseGaussianAdam`, so train.py:37-41 falls back to the plain call form
+(SURVEY.md 8(b)).  All compute goes through the C ABI of libgsr_hip.so (include/gsr.h, hand-written gfx950
+HIP kernels); there is no CPU or eager-PyTorch fallback -- a missing library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import GsrError, GsrRasterSettings, RESIZE_FN  # noqa: F401
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "GsrError"]
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    antialiasing: bool = False
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class _Buffer:
+    """A growable uint8 device tensor handed to the library through a resize callback (the reference's
+    resizeFunctional lambda)."""
+
+    def __init__(self, device):
+        self.t = torch.empty(0, dtype=torch.uint8, device=device)
+
+        def _resize(_user, nbytes):
+            if self.t.numel() < nbytes:
+                self.t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            return self.t.data_ptr()
+
+        self.cb = RESIZE_FN(_resize)
+
+
+def _make_settings(rs: GaussianRasterizationSettings, keep: list, tile_rows) -> GsrRasterSettings:
+    dev_t = [_f32c(rs.bg), _f32c(rs.viewmatrix), _f32c(rs.projmatrix), _f32c(rs.campos)]
+    keep.extend(dev_t)
+    s = GsrRasterSettings()
+    s.image_height = int(rs.image_height)
+    s.image_width = int(rs.image_width)
+    s.tanfovx = float(rs.tanfovx)
+    s.tanfovy = float(rs.tanfovy)
+    s.bg = dev_t[0].data_ptr()
+    s.scale_modifier = float(rs.scale_modifier)
+    s.viewmatrix = dev_t[1].data_ptr()
+    s.projmatrix = dev_t[2].data_ptr()
+    s.sh_degree = int(rs.sh_degree)
+    s.campos = dev_t[3].data_ptr()
+    s.prefiltered = int(bool(rs.prefiltered))
+    s.debug = int(bool(rs.debug))
+    s.antialiasing = int(bool(rs.antialiasing))
+    if tile_rows is None:
+        s.tile_y0, s.tile_y1 = 0, 0
+    else:
+        s.tile_y0, s.tile_y1 = int(tile_rows[0]), int(tile_rows[1])
+    return s
+
+
+def _stream_ptr(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_cuda(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise GsrError(f"{name} must live on a HIP device ('cuda'); the MI355X rasterizer has no CPU path")
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings, tile_rows):
+        lib = _lib.load()
+        _require_cuda(means3D, "means3D")
+        device = means3D.device
+        P = int(means3D.shape[0])
+        H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+        means3D_c, sh_c, col_c = _f32c(means3D), _f32c(sh), _f32c(colors_precomp)
+        op_c, sc_c, rot_c, cov_c = _f32c(opacities), _f32c(scales), _f32c(rotations), _f32c(cov3Ds_precomp)
+        M = int(sh_c.shape[1]) if sh_c is not None and sh_c.dim() == 3 else 0
+        keep: list = []
+        with torch.cuda.device(device):
+            s = _make_settings(raster_settings, keep, tile_rows)
+            color = torch.empty(3, H, W, dtype=torch.float32, device=device)
+            invdepth = torch.empty(1, H, W, dtype=torch.float32, device=device)
+            if tile_rows is not None:   # rows outside the band are not written by the kernels
+                color.zero_()
+                invdepth.zero_()
+            radii = torch.empty(P, dtype=torch.int32, device=device)
+            geom, binning, img = _Buffer(device), _Buffer(device), _Buffer(device)
+            nr = C.c_int32(0)
+            args = (C.byref(s), P, M, _ptr(means3D_c), _ptr(sh_c), _ptr(col_c), _ptr(op_c), _ptr(sc_c), _ptr(rot_c),
+                    _ptr(cov_c), geom.cb, None, binning.cb, None, img.cb, None, _ptr(color), _ptr(invdepth),
+                    _ptr(radii), C.byref(nr), _stream_ptr(device))
+            if raster_settings.debug:
+                cpu_args = _cpu_copy((means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                      raster_settings))
+                try:
+                    _lib.check(lib.gsr_rasterize_forward(*args), "gsr_rasterize_forward")
+                except Exception as ex:
+                    torch.save(cpu_args, "snapshot_fw.dump")
+                    print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                    raise ex
+            else:
+                _lib.check(lib.gsr_rasterize_forward(*args), "gsr_rasterize_forward")
+        ctx.raster_settings = raster_settings
+        ctx.tile_rows = tile_rows
+        ctx.num_rendered = int(nr.value)
+        ctx.M = M
+        ctx.op_shape = tuple(opacities.shape)
+        ctx.flags = (sh is not None, colors_precomp is not None, scales is not None, rotations is not None,
+                     cov3Ds_precomp is not None)
+        ctx.save_for_backward(means3D_c, sh_c if sh_c is not None else means3D_c.new_empty(0),
+                              col_c if col_c is not None else means3D_c.new_empty(0), op_c,
+                              sc_c if sc_c is not None else means3D_c.new_empty(0),
+                              rot_c if rot_c is not None else means3D_c.new_empty(0),
+                              cov_c if cov_c is not None else means3D_c.new_empty(0),
+                              radii, geom.t, binning.t, img.t)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, invdepth
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_out_depth):
+        lib = _lib.load()
+        (means3D, sh, col, op, sc, rot, cov, radii, geom, binning, img) = ctx.saved_tensors
+        has_sh, has_col, has_sc, has_rot, has_cov = ctx.flags
+        rs = ctx.raster_settings
+        device = means3D.device
+        P = int(means3D.shape[0])
+        M = ctx.M
+        f = dict(dtype=torch.float32, device=device)
+        dL_dmeans2D = torch.empty(P, 3, **f)
+        dL_dcolors = torch.empty(P, 3, **f)
+        dL_dopacity = torch.empty(P, 1, **f)
+        dL_dmeans3D = torch.empty(P, 3, **f)
+        dL_dcov3D = torch.empty(P, 6, **f)
+        dL_dsh = torch.empty(P, M, 3, **f) if has_sh else None
+        dL_dscales = torch.empty(P, 3, **f) if has_sc else None
+        dL_drot = torch.empty(P, 4, **f) if has_rot else None
+        if P > 0:
+            g_color = _f32c(grad_out_color)
+            g_depth = _f32c(grad_out_depth) if grad_out_depth is not None else None
+            scratch = torch.empty(P, 12, **f)
+            keep: list = []
+            with torch.cuda.device(device):
+                s = _make_settings(rs, keep, ctx.tile_rows)
+                args = (C.byref(s), P, M, ctx.num_rendered, _ptr(means3D), _ptr(sh) if has_sh else None,
+                        _ptr(col) if has_col else None, _ptr(op), _ptr(sc) if has_sc else None,
+                        _ptr(rot) if has_rot else None, _ptr(cov) if has_cov else None, _ptr(radii),
+                        _ptr(geom), _ptr(binning), _ptr(img), _ptr(g_color), _ptr(g_depth),
+                        _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
+                        _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drot), _ptr(scratch), _stream_ptr(device))
+                if rs.debug:
+                    cpu_args = _cpu_copy((means3D, radii, col, sc, rot, cov, sh, grad_out_color, rs))
+                    try:
+                        _lib.check(lib.gsr_rasterize_backward(*args), "gsr_rasterize_backward")
+                    except Exception as ex:
+                        torch.save(cpu_args, "snapshot_bw.dump")
+                        print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                        raise ex
+                else:
+                    _lib.check(lib.gsr_rasterize_backward(*args), "gsr_rasterize_backward")
+        dL_dopacity = dL_dopacity.view(ctx.op_shape)
+        return (dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors if has_col else None, dL_dopacity, dL_dscales, dL_drot,
+                dL_dcov3D if has_cov else None, None, None)
+
+
+def _cpu_copy(args):
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings, tile_rows: Optional[Tuple[int, int]] = None):
+    """Functional form.  `tile_rows=(y0, y1)` (extension) restricts binning + blending to that
+    band of 16-pixel tile rows; pixels outside the band come back as zeros."""
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings, tile_rows)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """bool[P]: in front of the near plane (the reference's mark_visible / checkFrustum)."""
+        lib = _lib.load()
+        _require_cuda(positions, "positions")
+        rs = self.raster_settings
+        with torch.no_grad(), torch.cuda.device(positions.device):
+            pos = _f32c(positions)
+            vm, pm = _f32c(rs.viewmatrix), _f32c(rs.projmatrix)
+            present = torch.empty(pos.shape[0], dtype=torch.uint8, device=pos.device)
+            _lib.check(lib.gsr_mark_visible(int(pos.shape[0]), _ptr(pos), _ptr(vm), _ptr(pm), _ptr(present),
+                                            _stream_ptr(pos.device)), "gsr_mark_visible")
+        return present.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   self.raster_settings, getattr(self, "tile_rows", None))

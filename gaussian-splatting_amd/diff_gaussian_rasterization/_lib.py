@@ -1,0 +1,133 @@
+"""ctypes binding of libgsr_hip.so (include/gsr.h).
+
+This file is the "reference-side binding" INTEGRATION.md describes: it replaces the pybind11 module
+`diff_gaussian_rasterization._C` of the reference's un-vendored submodule (call sites
+gaussian_renderer/__init__.py:14,91-110).  There is NO fallback: if the shared library is missing or was
+not built for this GPU, loading raises -- the product path never routes through a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgsr_hip.so")
+
+GSR_OK = 0
+STAGES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "render", "render_bwd", "preprocess_bwd"]
+
+
+class GsrRasterSettings(C.Structure):
+    _fields_ = [
+        ("image_height", C.c_int32), ("image_width", C.c_int32),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+        ("bg", C.c_void_p), ("scale_modifier", C.c_float),
+        ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
+        ("sh_degree", C.c_int32), ("campos", C.c_void_p),
+        ("prefiltered", C.c_int32), ("debug", C.c_int32), ("antialiasing", C.c_int32),
+        ("tile_y0", C.c_int32), ("tile_y1", C.c_int32),
+    ]
+
+
+class GsrForwardViews(C.Structure):
+    _fields_ = [("splats", C.c_void_p), ("tiles_touched", C.c_void_p), ("depth_order", C.c_void_p),
+                ("point_list", C.c_void_p), ("ranges", C.c_void_p), ("final_T", C.c_void_p),
+                ("n_contrib", C.c_void_p)]
+
+
+RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+EXPORTS = [
+    "gsr_abi_version", "gsr_last_error", "gsr_geometry_bytes", "gsr_binning_bytes", "gsr_image_bytes",
+    "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_mark_visible", "gsr_forward_views",
+    "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_set_option",
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+class GsrError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.environ.get("GSR_LIB", _LIB_PATH)
+
+
+def load() -> C.CDLL:
+    """Load libgsr_hip.so.  torch must own the HIP runtime: torch bundles its own libamdhip64.so (SONAME
+    libamdhip64.so.7) and our library NEEDs the same SONAME, so importing torch first makes both resolve to
+    one runtime -- stream handles and device pointers are then interchangeable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise GsrError(f"{path} not found: build it with `python gaussian-splatting_amd/build.py` "
+                       f"(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    try:
+        import torch  # noqa: F401  (loads torch's libamdhip64 first)
+    except Exception:  # pragma: no cover - torch-less use (pure C hosts) links /opt/rocm's runtime
+        pass
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    lib.gsr_abi_version.restype = C.c_int
+    lib.gsr_last_error.restype = C.c_char_p
+    lib.gsr_geometry_bytes.restype = C.c_size_t
+    lib.gsr_geometry_bytes.argtypes = [C.c_int]
+    lib.gsr_binning_bytes.restype = C.c_size_t
+    lib.gsr_binning_bytes.argtypes = [C.c_int64, C.c_int]
+    lib.gsr_image_bytes.restype = C.c_size_t
+    lib.gsr_image_bytes.argtypes = [C.c_int, C.c_int]
+    vp = C.c_void_p
+    lib.gsr_rasterize_forward.restype = C.c_int
+    lib.gsr_rasterize_forward.argtypes = [C.POINTER(GsrRasterSettings), C.c_int, C.c_int,
+                                          vp, vp, vp, vp, vp, vp, vp,
+                                          RESIZE_FN, vp, RESIZE_FN, vp, RESIZE_FN, vp,
+                                          vp, vp, vp, C.POINTER(C.c_int32), vp]
+    lib.gsr_rasterize_backward.restype = C.c_int
+    lib.gsr_rasterize_backward.argtypes = [C.POINTER(GsrRasterSettings), C.c_int, C.c_int, C.c_int32,
+                                           vp, vp, vp, vp, vp, vp, vp, vp,
+                                           vp, vp, vp, vp, vp,
+                                           vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_mark_visible.restype = C.c_int
+    lib.gsr_mark_visible.argtypes = [C.c_int, vp, vp, vp, vp, vp]
+    lib.gsr_forward_views.restype = C.c_int
+    lib.gsr_forward_views.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, vp, vp, vp, C.POINTER(GsrForwardViews)]
+    lib.gsr_profile_enable.restype = C.c_int
+    lib.gsr_profile_enable.argtypes = [C.c_int]
+    lib.gsr_profile_reset.restype = C.c_int
+    lib.gsr_profile_read.restype = C.c_int
+    lib.gsr_profile_read.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int]
+    lib.gsr_set_option.restype = C.c_int
+    lib.gsr_set_option.argtypes = [C.c_char_p, C.c_int]
+    if lib.gsr_abi_version() != 1:
+        raise GsrError(f"{path}: ABI version {lib.gsr_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != GSR_OK:
+        msg = load().gsr_last_error()
+        raise GsrError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def set_option(name: str, value: int) -> None:
+    check(load().gsr_set_option(name.encode(), int(value)), "gsr_set_option")
+
+
+def profile_enable(on: bool) -> None:
+    load().gsr_profile_enable(1 if on else 0)
+
+
+def profile_reset() -> None:
+    load().gsr_profile_reset()
+
+
+def profile_read() -> dict:
+    n = len(STAGES)
+    ms = (C.c_float * n)()
+    cnt = (C.c_int32 * n)()
+    load().gsr_profile_read(ms, cnt, n)
+    return {STAGES[i]: {"ms": float(ms[i]), "launches": int(cnt[i])} for i in range(n)}

@@ -1,0 +1,174 @@
+/*
+ * gsr.h -- C ABI of libgsr_hip.so, the MI355X (gfx950) differentiable Gaussian-splat rasterizer.
+ *
+ * This is the drop-in boundary for ONE path of graphdeco-inria/gaussian-splatting: the native
+ * operator behind `GaussianRasterizer` / `GaussianRasterizationSettings`
+ * (reference call sites: gaussian_renderer/__init__.py:14, :36-52, :91-110; backward via
+ * loss.backward() at train.py:142).  In the reference that operator lives in the un-vendored
+ * submodule `submodules/diff-gaussian-rasterization` (.gitmodules:4-7) whose torch extension `_C`
+ * exports `rasterize_gaussians`, `rasterize_gaussians_backward` and `mark_visible`; each entry point
+ * below names the `_C` function it replaces.  A maintainer binds these with ctypes (see
+ * INTEGRATION.md; gaussian-splatting_amd/diff_gaussian_rasterization/_lib.py is that binding).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only, no torch / C++ types; every data pointer is a DEVICE pointer
+ *     (tensor.data_ptr()) to contiguous fp32 / int32 data unless stated otherwise.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream).
+ *     gsr_rasterize_forward synchronises that stream once (the 4-byte num_rendered read-back that
+ *     sizes the binning buffer -- the reference has the same sync).
+ *   - return value: GSR_OK (0) or a negative GsrStatus; gsr_last_error() gives the message for the
+ *     calling thread.  No exception crosses the ABI.
+ *   - no device allocation inside: scratch memory is caller-owned and obtained through the three
+ *     resize callbacks (geometry / binning / image state), exactly like the reference's
+ *     resizeFunctional lambdas; forward returns with the three buffers populated and the caller keeps
+ *     them alive for gsr_rasterize_backward.
+ */
+#ifndef GSR_H
+#define GSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_ABI_VERSION 1
+
+typedef enum GsrStatus {
+    GSR_OK = 0,
+    GSR_ERR_INVALID_ARG = -1,   /* bad size / NULL pointer / inconsistent optional inputs */
+    GSR_ERR_HIP = -2,           /* a HIP runtime call or kernel launch failed */
+    GSR_ERR_ALLOC = -3,         /* a resize callback returned NULL */
+    GSR_ERR_UNSUPPORTED = -4    /* e.g. more than 2^24 tiles, SH degree > 3 */
+} GsrStatus;
+
+/* Mirrors GaussianRasterizationSettings (gaussian_renderer/__init__.py:36-50), same field meaning.
+ * bg / viewmatrix / projmatrix / campos are device pointers (they are CUDA tensors in the
+ * reference).  viewmatrix / projmatrix are the row-major tensors the reference passes, i.e. the
+ * TRANSPOSED math matrices (scene/cameras.py:86-88): flat index i + 4*j = math element (row i, col j). */
+typedef struct GsrRasterSettings {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    const float* bg;          /* [3] */
+    float scale_modifier;
+    const float* viewmatrix;  /* [16] */
+    const float* projmatrix;  /* [16] */
+    int32_t sh_degree;        /* active degree 0..3 */
+    const float* campos;      /* [3] */
+    int32_t prefiltered;      /* always 0 in the reference (gaussian_renderer/__init__.py:47) */
+    int32_t debug;            /* 1: synchronise + check after every kernel */
+    int32_t antialiasing;
+    /* Extension for screen-tile sharding across GPUs (not in the reference):
+     * only tile rows [tile_y0, tile_y1) are binned and rendered; pixels outside are left untouched.
+     * tile_y1 <= 0 means "all rows". radii are unaffected by the band. */
+    int32_t tile_y0;
+    int32_t tile_y1;
+} GsrRasterSettings;
+
+/* Resize callback: make the buffer at least `bytes` long and return its (device) base address,
+ * 128-byte aligned or better.  Mirrors the reference's std::function<char*(size_t)> lambdas that
+ * call tensor.resize_(). */
+typedef void* (*GsrResizeFn)(void* user, size_t bytes);
+
+int gsr_abi_version(void);
+const char* gsr_last_error(void);
+
+/* Scratch sizes (bytes) -- mirrors the reference's required<GeometryState/BinningState/ImageState>(). */
+size_t gsr_geometry_bytes(int P);
+size_t gsr_binning_bytes(int64_t R, int n_tiles);
+size_t gsr_image_bytes(int width, int height);
+
+/*
+ * Replaces _C.rasterize_gaussians.
+ *   P            number of Gaussians; M = SH coefficients per channel in `shs` ((max_degree+1)^2).
+ *   means3D[P,3], opacities[P], shs[P,M,3] XOR colors_precomp[P,3],
+ *   (scales[P,3] AND rotations[P,4]) XOR cov3D_precomp[P,6]; absent inputs are NULL.
+ *   out_color[3,H,W], out_invdepth[1,H,W] (may be NULL), radii[P] int32.
+ *   *num_rendered receives R, the number of (Gaussian, tile) instances.
+ * P == 0: out_color / out_invdepth are zero-filled, *num_rendered = 0, no callback is invoked.
+ */
+int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M,
+                          const float* means3D, const float* shs, const float* colors_precomp,
+                          const float* opacities, const float* scales, const float* rotations,
+                          const float* cov3D_precomp,
+                          GsrResizeFn geom_resize, void* geom_user,
+                          GsrResizeFn binning_resize, void* binning_user,
+                          GsrResizeFn image_resize, void* image_user,
+                          float* out_color, float* out_invdepth, int32_t* radii,
+                          int32_t* num_rendered, void* stream);
+
+/*
+ * Replaces _C.rasterize_gaussians_backward.
+ *   geom/binning/image buffers: the three buffers forward filled (same P, R, settings, inputs).
+ *   dL_dout_color[3,H,W]; dL_dout_invdepth[1,H,W] or NULL (treated as zero).
+ * Outputs (every element is overwritten -- zeros for Gaussians with radii == 0 -- so the caller may pass
+ * uninitialised memory; the reference's glue allocates them with torch::zeros):
+ *   dL_dmeans2D[P,3]  (x,y in NDC-scaled units = pixel gradient * (0.5 W, 0.5 H); z = 0)
+ *   dL_dcolors[P,3], dL_dopacity[P], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3] (NULL if no shs),
+ *   dL_dscales[P,3], dL_drotations[P,4] (NULL if cov3D_precomp was given).
+ *   splat_grads_scratch: caller-owned scratch of P*12 floats (zeroed internally) that receives the
+ *   per-Gaussian 2-D gradient record accumulated by the blend backward; after the call it holds, per
+ *   Gaussian, [dpx,dpy,dA,dB,dC,dopacity,dr,dg,db,dinvdepth,0,0] -- the 48-byte record that is
+ *   reduce-scattered between GPUs when the screen is sharded.
+ */
+int gsr_rasterize_backward(const GsrRasterSettings* settings, int P, int M, int32_t num_rendered,
+                           const float* means3D, const float* shs, const float* colors_precomp,
+                           const float* opacities, const float* scales, const float* rotations,
+                           const float* cov3D_precomp, const int32_t* radii,
+                           const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+                           const float* dL_dout_color, const float* dL_dout_invdepth,
+                           float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
+                           float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                           float* dL_dscales, float* dL_drotations, void* splat_grads_scratch,
+                           void* stream);
+
+/* Replaces _C.mark_visible: present[i] = 1 iff Gaussian i is in front of the 0.2 near plane. */
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream);
+
+/*
+ * Introspection for tests and bench (no reference counterpart).  Views into the buffers forward filled.
+ * Pointers are device pointers valid while the buffers live.
+ */
+typedef struct GsrForwardViews {
+    const float* splats;          /* [P,12] x,y,conA,conB | conC,opacity,r,g | b,depth,0,0 */
+    const uint32_t* tiles_touched;/* [P] */
+    const uint32_t* depth_order;  /* [P] Gaussian ids in (depth, id) order; culled ones last */
+    const uint32_t* point_list;   /* [R] Gaussian ids sorted by (tile, depth, id) */
+    const uint32_t* ranges;       /* [n_tiles,2] start,end */
+    const float* final_T;         /* [H*W] */
+    const uint32_t* n_contrib;    /* [H*W] */
+} GsrForwardViews;
+int gsr_forward_views(int P, int64_t R, int width, int height,
+                      const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+                      GsrForwardViews* out);
+
+/* Per-stage GPU timing (HIP events on `stream`, recorded around each kernel group when enabled).
+ * Stage ids index GSR_STAGE_*; times accumulate until reset.  Used by bench.py for roofline.achieved. */
+enum {
+    GSR_STAGE_PREPROCESS = 0,
+    GSR_STAGE_DEPTH_SORT = 1,
+    GSR_STAGE_SCAN = 2,
+    GSR_STAGE_EMIT = 3,
+    GSR_STAGE_TILE_SORT = 4,
+    GSR_STAGE_RANGES = 5,
+    GSR_STAGE_RENDER = 6,
+    GSR_STAGE_RENDER_BWD = 7,
+    GSR_STAGE_PREPROCESS_BWD = 8,
+    GSR_STAGE_COUNT = 9
+};
+int gsr_profile_enable(int on);
+int gsr_profile_reset(void);
+/* Resolves pending events (synchronises them) and returns accumulated ms and launch counts per stage. */
+int gsr_profile_read(float* ms_out, int32_t* count_out, int n);
+
+/* Variant selection for A/B measurement of the render kernels (0 = default). */
+int gsr_set_option(const char* name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H */
