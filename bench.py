@@ -1,0 +1,283 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric: "Mpix/s forward + train iters/s, 1 M Gaussians @1080p, 1/2/4/8 MI355X".
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one forward render of the whole frame (preprocess -> depth sort -> scan -> emit -> tile sort -> ranges
+-> blend, including the 4-byte num_rendered read-back) of the synthetic stand-in for configs[1] ("garden", ~1 M
+Gaussians, 1080p): P = 1e6, 1920x1080, SURVEY.md 8(d) generator, seed 0, s_med 0.012.  With N > 1 GPUs the SAME
+frame is split into N bands of tile rows (strong scaling), every rank renders its band and the strips are
+all-gathered over RCCL; value = W*H / (max-over-ranks time per frame).
+
+The JSON line also carries
+  train_iters_per_s : forward + L1 loss + backward + Adam on all parameters (same scene), steps/s
+  roofline          : the dominant kernel (forward blend), algorithmic bytes / its mean duration from HIP events
+                      recorded on the launch stream by the library (gsr_profile_*), against the 8 TB/s HBM peak
+  cpu_baseline      : the pure-PyTorch CPU oracle on this host's cores, on a bounded sample of the same frame
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "gaussian-splatting_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
+FP32_VALU_PEAK_TF = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--P", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--s-med", type=float, default=0.012)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=0, help="render_fwd_variant (0 wave/box-cull, 1 block/LDS)")
+    ap.add_argument("--train-steps", type=int, default=-1, help="-1: same as --steps; 0 disables the train leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tiles", type=int, default=96, help="tiles blended by the CPU baseline sample")
+    ap.add_argument("--uniform-bands", action="store_true")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(P, V, R, T, npix, M=16):
+    """B_fwd, inference layout, sort counted as one read + one write of 12-byte pairs."""
+    pre_in = 12 * P + V * (32 + 12 * M)
+    pre_out = 8 * P + 40 * V
+    scan = 8 * P
+    dup_in = 8 * P + 16 * V
+    dup_out = 12 * R
+    sort = 24 * R
+    ranges = 8 * R + 8 * T
+    blend = 44 * R + 24 * npix
+    return {"total": pre_in + pre_out + scan + dup_in + dup_out + sort + ranges + blend, "blend": blend,
+            "preprocess": pre_in + pre_out, "sort": sort + dup_out}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from gsr_synth import make_camera, make_scene
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _lib, rasterize_gaussians
+    from diff_gaussian_rasterization.debug import forward_with_views
+    from diff_gaussian_rasterization.parallel import BandPlan, gather_strips, row_costs_from_ranges
+
+    _lib.load()
+    _lib.set_option("render_fwd_variant", a.variant)
+    W, H, P = a.width, a.height, a.P
+    cam = make_camera(W, H)
+    scene_cpu = make_scene(P, cam, seed=a.seed, s_med=a.s_med)
+    sc = scene_cpu.to(dev)
+    camd = cam.to(dev)
+    bg = torch.zeros(3, device=dev)
+    rs = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, bg, 1.0, camd.world_view_transform,
+                                       camd.full_proj_transform, 3, camd.camera_center, False, False, False)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    npix = W * H
+
+    # ---- scene statistics (V, R) + band plan from a dry run ----
+    with torch.no_grad():
+        v0 = forward_with_views(rs, sc.means3D, sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+        V = int((v0["radii"] > 0).sum())
+        R = int(v0["R"])
+        row_cost = row_costs_from_ranges(v0["ranges"].long(), gx, gy)
+        del v0
+    plan = BandPlan.uniform(gy, world) if (a.uniform_bands or world == 1) else BandPlan.balanced(row_cost, world)
+    band = None if world == 1 else plan.band(rank)
+
+    def forward_step():
+        with torch.no_grad():
+            color, radii, invd = rasterize_gaussians(sc.means3D, None, sc.shs, None, sc.opacities, sc.scales,
+                                                     sc.rotations, None, rs, band)
+            if world > 1:
+                color = gather_strips(color, plan, H)
+        return color
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- timed forward ----
+    for _ in range(a.warmup):
+        forward_step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        forward_step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    ms_per_step = dt / a.steps * 1e3
+    mpix_s = npix / (dt / a.steps) / 1e6
+
+    # ---- per-stage HIP-event timing (separate pass: event pairs around every stage perturb the pipeline) ----
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    for _ in range(a.steps):
+        forward_step()
+    torch.cuda.synchronize()
+    stages = _lib.profile_read()
+    _lib.profile_enable(False)
+    stage_ms = {k: (v["ms"] / max(1, v["launches"])) for k, v in stages.items() if v["launches"]}
+
+    # ---- train leg: fwd + L1 + bwd + Adam (all parameters) ----
+    train_ips = None
+    train_ms = None
+    tsteps = a.steps if a.train_steps < 0 else a.train_steps
+    if tsteps > 0:
+        params = [t.detach().clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+        opt = torch.optim.Adam(params, lr=1e-5, eps=1e-15)
+        gt = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+        from diff_gaussian_rasterization.parallel import render_sharded
+
+        def hip_band(inp, tile_rows):
+            m, sh, o, s_, r_ = inp
+            return rasterize_gaussians(m, None, sh, None, o, s_, r_, None, rs, tile_rows if world > 1 else None)
+
+        def train_step():
+            opt.zero_grad(set_to_none=True)
+            m, sh, o, s_, r_ = params
+            if world > 1:
+                color, radii, invd = render_sharded(hip_band, params, plan)
+            else:
+                color, radii, invd = hip_band(params, None)
+            loss = (color - gt).abs().mean()
+            loss.backward()
+            opt.step()
+
+        for _ in range(max(2, a.warmup // 2)):
+            train_step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(tsteps):
+            train_step()
+        sync_all()
+        tdt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+        train_ms = float(tdt.item()) / tsteps * 1e3
+        train_ips = 1e3 / train_ms
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        for _ in range(min(10, tsteps)):
+            train_step()
+        torch.cuda.synchronize()
+        tstages = _lib.profile_read()
+        _lib.profile_enable(False)
+        for k in ("render_bwd", "preprocess_bwd"):
+            if tstages[k]["launches"]:
+                stage_ms[k] = tstages[k]["ms"] / tstages[k]["launches"]
+        del params, opt
+
+    # ---- CPU baseline (rank 0, N=1 only): pure-PyTorch oracle on a bounded sample of the same frame ----
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import torch_oracle as O   # cpu_baseline leg only
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        s = O.settings_from_camera(cam, torch.zeros(3))
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            pre = O.preprocess(scene_cpu.means3D, scene_cpu.opacities, s, shs=scene_cpu.shs, scales=scene_cpu.scales,
+                               rotations=scene_cpu.rotations)
+            t_pre = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            bins = O.bin_and_sort(pre)
+            t_bin = time.perf_counter() - t0
+            ntile = gx * gy
+            k = max(1, min(a.cpu_tiles, ntile))
+            sample = [int(i * ntile / k) for i in range(k)]
+            t0 = time.perf_counter()
+            O.render_tiles(pre, bins, s, tiles=sample)
+            t_blend = time.perf_counter() - t0
+        inst_sample = int((bins["ranges"][sample, 1] - bins["ranges"][sample, 0]).sum())
+        # extrapolate the blend by instance count (the blend cost is proportional to list length)
+        t_full = t_pre + t_bin + t_blend * (bins["R"] / max(1, inst_sample))
+        cpu_baseline = {"value": round(npix / t_full / 1e6, 4), "unit": "Mpix/s", "cores": cores, "kind": "port",
+                        "sample": f"full preprocess ({t_pre:.1f}s) + full binning/sort ({t_bin:.1f}s) on all {P} Gaussians; "
+                                  f"blend timed on {k} of {ntile} tiles ({inst_sample} of {bins['R']} instances, {t_blend:.1f}s) "
+                                  f"and scaled by instance count; pure-PyTorch oracle, torch threads={cores}"}
+
+    if rank == 0:
+        ab = algorithmic_bytes(P, V, R, gx * gy, npix)
+        render_ms = stage_ms.get("render")
+        roof = None
+        if render_ms:
+            # per-launch algorithmic bytes of the blend kernel on THIS rank's band: 44 B per instance + 24 B per pixel
+            frac_rows = 1.0 if world == 1 else (plan.band(0)[1] - plan.band(0)[0]) / gy
+            blend_bytes = ab["blend"] if world == 1 else ab["blend"] * frac_rows
+            ach = blend_bytes / (render_ms * 1e-3) / 1e9
+            pairs = 256.0 * R * (frac_rows if world > 1 else 1.0)
+            roof = {"bound": "hbm", "kernel": "render_fwd_wave" if a.variant == 0 else "render_fwd_block",
+                    "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                    "traffic": None, "kernel_ms": round(render_ms, 4),
+                    "algorithmic_bytes_per_launch": int(blend_bytes),
+                    "note": "blend is fp32-VALU/exp bound (SURVEY 8(d)); listed pair evaluations (256*R) per second and "
+                            "the equivalent 25-FLOP/pair rate vs the 157.3 TF vector peak are given alongside",
+                    "listed_pairs_per_s": round(pairs / (render_ms * 1e-3), 1),
+                    "valu_equiv_tflops": round(pairs * 25 / (render_ms * 1e-3) / 1e12, 3),
+                    "valu_frac": round(pairs * 25 / (render_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TF, 4)}
+        whole = ab["total"] / (ms_per_step * 1e-3) / 1e9
+        out = {
+            "metric": "Mpix/s forward (1 M Gaussians @1080p); train iters/s alongside",
+            "value": round(mpix_s, 2), "unit": "Mpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1] stand-in: 1M random Gaussians (SURVEY 8(d) generator, seed %d, s_med %.4g), "
+                                   "%dx%d forward render, SH degree 3" % (a.seed, a.s_med, W, H),
+                       "P": P, "visible": V, "num_rendered": R, "tiles": gx * gy,
+                       "parallelism": "tile-row bands x%d%s" % (world, "" if world == 1 else
+                                                                (" (uniform)" if a.uniform_bands else " (instance-balanced)")),
+                       "render_fwd_variant": a.variant},
+            "train_iters_per_s": None if train_ips is None else round(train_ips, 3),
+            "train_ms_per_iter": None if train_ms is None else round(train_ms, 4),
+            "train_step": "forward + L1 loss + backward + torch Adam over all 59 floats/Gaussian",
+            "whole_forward": {"algorithmic_bytes": int(ab["total"]), "achieved_GBs": round(whole, 2),
+                              "frac_of_8TBs": round(whole / HBM_PEAK_GBS, 5),
+                              "roofline_predicted_Mpix_s": round(npix / (ab["total"] / (HBM_PEAK_GBS * 1e9)) / 1e6, 1)},
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "roofline": roof,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -142,6 +142,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = int(nr.value)
         ctx.M = M
         ctx.op_shape = tuple(opacities.shape)
+        ctx.has_means2D = means2D is not None
         ctx.flags = (sh is not None, colors_precomp is not None, scales is not None, rotations is not None,
                      cov3Ds_precomp is not None)
         ctx.save_for_backward(means3D_c, sh_c if sh_c is not None else means3D_c.new_empty(0),
@@ -195,7 +196,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 else:
                     _lib.check(lib.gsr_rasterize_backward(*args), "gsr_rasterize_backward")
         dL_dopacity = dL_dopacity.view(ctx.op_shape)
-        return (dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors if has_col else None, dL_dopacity, dL_dscales, dL_drot,
+        return (dL_dmeans3D, dL_dmeans2D if ctx.has_means2D else None, dL_dsh, dL_dcolors if has_col else None, dL_dopacity, dL_dscales, dL_drot,
                 dL_dcov3D if has_cov else None, None, None)
 
 

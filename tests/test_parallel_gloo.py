@@ -1,0 +1,103 @@
+"""world_size-2 (and 3) gloo tests of the screen-tile sharding logic (band plan, strip all-gather, gradient
+all-reduce) on CPU, with the oracle standing in for the band renderer -- the collectives and index math are the
+code under test; on the GPU box the same functions get the HIP rasterizer (bench.py --gpus N)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import O, make_camera, make_scene, make_edge_scene, oracle_settings
+
+
+def test_band_plan():
+    from diff_gaussian_rasterization.parallel import BandPlan
+    p = BandPlan.uniform(68, 4)
+    assert p.bounds == [0, 17, 34, 51, 68]
+    cost = [1.0] * 10 + [9.0] * 10                      # bottom half 9x as expensive
+    q = BandPlan.balanced(cost, 2)
+    assert q.bounds[0] == 0 and q.bounds[-1] == 20 and 14 <= q.bounds[1] <= 16
+    loads = [sum(cost[q.bounds[g]:q.bounds[g + 1]]) for g in range(2)]
+    assert max(loads) / (sum(cost) / 2) < 1.15
+    r = BandPlan.balanced([0.0] * 5, 3)
+    assert r.bounds[0] == 0 and r.bounds[-1] == 5 and sorted(r.bounds) == r.bounds
+    e = BandPlan.balanced([5.0, 0, 0, 0], 4)             # empty bands allowed, monotone
+    assert sorted(e.bounds) == e.bounds and e.bounds[-1] == 4
+    assert q.pixel_rows(1, 310) == (q.bounds[1] * 16, 310)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, balanced, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from diff_gaussian_rasterization.parallel import BandPlan, render_sharded, row_costs_from_ranges
+    cam = make_camera(112, 96)
+    sc = make_edge_scene(500, cam, seed=33)
+    s = oracle_settings(cam, bg=torch.tensor([0.2, 0.4, 0.6]))
+    gy = 6
+    plan = BandPlan.uniform(gy, world)
+    if balanced:   # re-balance from the per-row instance histogram (each rank knows its own band only)
+        with torch.no_grad():
+            *_, aux = O.rasterize(sc.means3D, None, sc.opacities, s, shs=sc.shs, scales=sc.scales, rotations=sc.rotations,
+                                  tile_y0=plan.band(rank)[0], tile_y1=plan.band(rank)[1], return_aux=True)
+        plan = BandPlan.balanced(row_costs_from_ranges(aux["ranges"], 7, gy), world)
+    leaves = [t.clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+    m2 = torch.zeros(sc.P, 3, requires_grad=True)
+
+    def band_renderer(inp, rows):
+        m, sh, o, scl, rot, m2_ = inp
+        return O.rasterize(m, m2_, o, s, shs=sh, scales=scl, rotations=rot, tile_y0=rows[0], tile_y1=rows[1])
+
+    color, radii, invd = render_sharded(band_renderer, leaves + [m2], plan)
+    g = torch.Generator().manual_seed(7)
+    wc, wd = torch.randn(3, 96, 112, generator=g), torch.randn(1, 96, 112, generator=g)
+    ((color * wc).sum() + (invd * wd).sum()).backward()
+    if rank == 0:
+        torch.save({"color": color.detach(), "invd": invd.detach(), "radii": radii, "bounds": plan.bounds,
+                    "grads": [t.grad for t in leaves] + [m2.grad]}, out_q)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,balanced", [(2, False), (2, True), (3, True)])
+def test_sharded_render_equals_single_device(world, balanced):
+    import tempfile
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "rank0.pt")
+        procs = [ctx.Process(target=_worker, args=(r, world, port, balanced, path)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=900)
+            assert p.exitcode == 0
+        res = torch.load(path)
+    # single-device reference
+    cam = make_camera(112, 96)
+    sc = make_edge_scene(500, cam, seed=33)
+    s = oracle_settings(cam, bg=torch.tensor([0.2, 0.4, 0.6]))
+    leaves = [t.clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+    m2 = torch.zeros(sc.P, 3, requires_grad=True)
+    color, radii, invd = O.rasterize(leaves[0], m2, leaves[2], s, shs=leaves[1], scales=leaves[3], rotations=leaves[4])
+    g = torch.Generator().manual_seed(7)
+    wc, wd = torch.randn(3, 96, 112, generator=g), torch.randn(1, 96, 112, generator=g)
+    ((color * wc).sum() + (invd * wd).sum()).backward()
+    assert res["bounds"][0] == 0 and res["bounds"][-1] == 6
+    assert torch.equal(res["radii"], radii)
+    assert torch.equal(res["color"], color.detach())          # strips tile the image exactly
+    assert torch.equal(res["invd"], invd.detach())
+    for a, b in zip(res["grads"], [t.grad for t in leaves] + [m2.grad]):
+        # fp32 partial sums are combined in a different order across bands: compare against the gradient's scale
+        assert (a - b).abs().max().item() <= 3e-5 * b.abs().max().item()
