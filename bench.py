@@ -49,10 +49,10 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--s-med", type=float, default=0.012)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--variant", type=int, default=0, help="render_fwd_variant (0 wave/box-cull, 1 block/LDS)")
+    ap.add_argument("--variant", type=int, default=0, help="render_fwd_variant (0 wave + LDS broadcast, 1 workgroup-per-tile baseline, 2 wave + readlane)")
     ap.add_argument("--train-steps", type=int, default=-1, help="-1: same as --steps; 0 disables the train leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tiles", type=int, default=96, help="tiles blended by the CPU baseline sample")
+    ap.add_argument("--cpu-tiles", type=int, default=48, help="tiles blended by the CPU baseline sample")
     ap.add_argument("--uniform-bands", action="store_true")
     return ap.parse_args()
 
@@ -207,7 +207,9 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import torch_oracle as O   # cpu_baseline leg only
-        cores = os.cpu_count() or 1
+        # many small tensor ops: beyond ~16 threads torch's intra-op pool only adds overhead (measured: 256
+        # threads on the GPU box's host were >10x slower than 16), so the baseline uses min(cores, 16) threads
+        cores = min(os.cpu_count() or 1, 16)
         torch.set_num_threads(cores)
         s = O.settings_from_camera(cam, torch.zeros(3))
         with torch.no_grad():
@@ -227,7 +229,7 @@ def main():
         inst_sample = int((bins["ranges"][sample, 1] - bins["ranges"][sample, 0]).sum())
         # extrapolate the blend by instance count (the blend cost is proportional to list length)
         t_full = t_pre + t_bin + t_blend * (bins["R"] / max(1, inst_sample))
-        cpu_baseline = {"value": round(npix / t_full / 1e6, 4), "unit": "Mpix/s", "cores": cores, "kind": "port",
+        cpu_baseline = {"value": round(npix / t_full / 1e6, 6), "host_cores": os.cpu_count(), "unit": "Mpix/s", "cores": cores, "kind": "port",
                         "sample": f"full preprocess ({t_pre:.1f}s) + full binning/sort ({t_bin:.1f}s) on all {P} Gaussians; "
                                   f"blend timed on {k} of {ntile} tiles ({inst_sample} of {bins['R']} instances, {t_blend:.1f}s) "
                                   f"and scaled by instance count; pure-PyTorch oracle, torch threads={cores}"}
@@ -242,7 +244,7 @@ def main():
             blend_bytes = ab["blend"] if world == 1 else ab["blend"] * frac_rows
             ach = blend_bytes / (render_ms * 1e-3) / 1e9
             pairs = 256.0 * R * (frac_rows if world > 1 else 1.0)
-            roof = {"bound": "hbm", "kernel": "render_fwd_wave" if a.variant == 0 else "render_fwd_block",
+            roof = {"bound": "hbm", "kernel": {0: "render_fwd_wave_bf<LDS>", 1: "render_fwd_block", 2: "render_fwd_wave_bf<readlane>"}.get(a.variant, "?"),
                     "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                     "traffic": None, "kernel_ms": round(render_ms, 4),
                     "algorithmic_bytes_per_launch": int(blend_bytes),

@@ -81,7 +81,9 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             }
             q0 = make_float4(sp.px, sp.py, sp.conA, sp.conB);
             q1 = make_float4(sp.conC, sp.opacity, rgb[0], rgb[1]);
-            q2 = make_float4(rgb[2], sp.depth, 0.f, 0.f);
+            // tau = 2 ln(255 opacity) + slack: a splat reaches alpha >= 1/255 only where its quadratic form is <= tau
+            // (box-cull threshold of the blend kernels); 1/depth feeds the inverse-depth image.
+            q2 = make_float4(rgb[2], sp.depth, 2.0f * logf(255.0f * sp.opacity) + 0.01f, 1.0f / sp.depth);
         }
         splats[i * 3 + 0] = q0;
         splats[i * 3 + 1] = q1;

@@ -2,23 +2,22 @@
 // un-vendored reference rasterizer (algorithm SURVEY.md Appendix A.4; caller:
 // gaussian_renderer/__init__.py:91-110).
 //
-// Two gfx950 designs behind one launcher (variant chosen by gsr_set_option("render_fwd_variant")):
+// gfx950 designs behind one launcher (variant chosen by gsr_set_option("render_fwd_variant")):
 //
-//  variant 1  "block"  : one 256-thread workgroup per 16x16 tile (4 waves x 4 rows), the tile's list staged
-//                        through LDS 256 entries at a time, every lane evaluates every entry (LDS broadcast
-//                        reads), workgroup-wide "all done" vote per batch.  The classic structure; kept as the
-//                        A/B baseline.
-//  variant 0  "wave"   : (default) one wave64 per 8x8 pixel block, no LDS, no barriers.  The 64 lanes first act
-//                        as 64 *Gaussian* lanes: each loads one list entry (coalesced index read + 48-byte record
-//                        gather) and tests it against the wave's 8x8 pixel box with an exact min-of-quadratic-
-//                        over-a-box test -- entries that cannot reach alpha >= 1/255 anywhere in the box are
-//                        dropped.  A 64-bit ballot gives the survivor mask; the wave then walks the set bits
-//                        (s_ff1) and the lanes switch to *pixel* lanes, each blending the survivor (record
-//                        broadcast with v_readlane into SGPRs).  Dropping is exact: a dropped entry would have
-//                        been skipped by every pixel of the box anyway (alpha < 1/255), and skipped entries
-//                        leave no trace in any output (contributor numbering is by list position).
-//                        The blend loop is fp32-VALU/exp bound; the box test removes the pair
-//                        evaluations that the reference's square 3-sigma binning wastes.
+//  variant 0  "wave/LDS" : (default) one wave64 per 8x8 pixel block, no barriers.  The 64 lanes first act as 64
+//                        *Gaussian* lanes: each loads one list entry (coalesced index read + 48-byte record gather)
+//                        and tests it against the wave's 8x8 pixel box with an exact min-of-quadratic-over-a-box
+//                        test -- entries that cannot reach alpha >= 1/255 anywhere in the box are dropped.  A
+//                        64-bit ballot gives the survivor mask; the batch is parked in the wave's private 3 KB of
+//                        LDS; the wave then walks the set bits (s_ff1) and the lanes switch to *pixel* lanes, each
+//                        blending the survivor read back with wave-uniform ds_read_b128 (LDS broadcast) through a
+//                        BRANCH-FREE body.  Dropping is exact: a dropped entry would have been skipped by every
+//                        pixel of the box anyway (alpha < 1/255), and skipped entries leave no trace in any output
+//                        (contributor numbering is by list position).
+//  variant 1  "block"    : one 256-thread workgroup per 16x16 tile, list staged through LDS 256 entries at a time,
+//                        every lane evaluates every entry, workgroup-wide "all done" vote.  The classic structure;
+//                        A/B baseline (measured 0.408 ms vs 0.161 ms for variant 0 on the 1 M / 1080p frame).
+//  variant 2  "wave/readlane": as variant 0 but the record is broadcast with v_readlane into SGPRs (0.291 ms).
 //
 // Numerics: fp32, FMA contraction allowed, exp through v_exp_f32 (__expf).  Image parity with the oracle is
 // <= 1e-5 except at pixels where a hard threshold (alpha<1/255, T<1e-4, power>0) is within rounding noise
@@ -101,7 +100,7 @@ render_fwd_block(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// variant 0: wave per 8x8 pixel block, box culling, readlane broadcast
+// wave per 8x8 pixel block: helpers (exact box test, cross-lane broadcast)
 // ------------------------------------------------------------------------------------------------
 // Smallest value of q(d) = A dx^2 + 2 B dx dy + C dy^2 over the pixel box [x0,x1]x[y0,y1] for a Gaussian centred
 // at (mx,my).  Exact for positive-definite (A,B,C): the minimiser is the centre if it is inside, otherwise it
@@ -130,13 +129,49 @@ __device__ __forceinline__ float bcast(float v, int srclane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// variants 0 / 2: wave per 8x8 pixel block with a BRANCH-FREE blend body.
+// The blend loop issues VALU and SALU instructions at comparable rates, so exec-mask branches (s_and_saveexec /
+// s_cbranch / s_or per skip condition) cost as much as the arithmetic they skip.  Here every surviving entry is
+// evaluated by all 64 lanes with the three hard conditions folded into selects (weight 0 when skipped), the conic
+// is pre-scaled to log2 units by the Gaussian lanes (power -> one v_exp_f32, no multiply), and tau / 1/depth come
+// precomputed from the splat record.  Variant 0 stages the batch in the wave's private 3 KB of LDS and re-reads it
+// with wave-uniform ds_read_b128 (broadcast); variant 2 broadcasts the record with v_readlane (SGPR operands).
+// ------------------------------------------------------------------------------------------------
+struct PixAcc {
+    float T, C0, C1, C2, D;
+    uint32_t last;
+};
+
+__device__ __forceinline__ void blend_step_bf(PixAcc& s, bool& done, float pxf, float pyf, float gx_, float gy_, float a2,
+                                              float b2, float c2, float op, float r, float g, float b, float invd,
+                                              uint32_t pos) {
+    const float dx = gx_ - pxf, dy = gy_ - pyf;
+    const float t = fmaf(b2, dy, a2 * dx);
+    const float p2 = fmaf(dx, t, (c2 * dy) * dy);           // log2(e) * power
+    const float alpha = fminf(GSR_ALPHA_MAX, op * __builtin_amdgcn_exp2f(p2));
+    const bool valid = (!done) & (p2 <= 0.0f) & (alpha >= GSR_ALPHA_MIN);
+    const float testT = fmaf(-alpha, s.T, s.T);              // T (1 - alpha)
+    const bool term = valid & (testT < GSR_T_EPS);
+    const bool contrib = valid & (!term);
+    const float w = contrib ? alpha * s.T : 0.0f;
+    s.C0 = fmaf(r, w, s.C0);
+    s.C1 = fmaf(g, w, s.C1);
+    s.C2 = fmaf(b, w, s.C2);
+    s.D = fmaf(invd, w, s.D);
+    s.T = contrib ? testT : s.T;
+    s.last = contrib ? pos : s.last;
+    done = done | term;
+}
+
+template <bool USE_LDS>
 __global__ void __launch_bounds__(64)
-render_fwd_wave(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ranges,
-                const uint32_t* __restrict__ point_list, const float4* __restrict__ splats,
-                float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-                float* __restrict__ out_invdepth) {
-    // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed).  The four 8x8 quadrants of a tile share one
-    // splat list, so they are given ids b, b+8, b+16, b+24 -> same XCD -> same L2.
+render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ranges,
+                   const uint32_t* __restrict__ point_list, const float4* __restrict__ splats,
+                   float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+                   float* __restrict__ out_invdepth) {
+    __shared__ float4 s_rec[USE_LDS ? 64 * 3 : 1];
     const int b = blockIdx.x;
     const int grp = b >> 5, r32 = b & 31;
     const int tile_local = grp * 8 + (r32 & 7);
@@ -146,19 +181,19 @@ render_fwd_wave(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const int lane = threadIdx.x;
     const int bx0 = tx * GSR_TILE + (quad & 1) * 8, by0 = ty * GSR_TILE + (quad >> 1) * 8;
-    if (bx0 >= cam.W || by0 >= cam.H) return;                         // whole 8x8 block outside the image
+    if (bx0 >= cam.W || by0 >= cam.H) return;
     const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
     const bool inside = px < cam.W && py < cam.H;
     const float pxf = (float)px, pyf = (float)py;
-    // the box holds only pixels that exist
     const float x0 = (float)bx0, x1 = (float)min(bx0 + 7, cam.W - 1);
     const float y0 = (float)by0, y1 = (float)min(by0 + 7, cam.H - 1);
     const uint2 range = ranges[tile];
-    PixState s = {1.0f, 0.f, 0.f, 0.f, 0.f, 0u, !inside};
+    PixAcc s = {1.0f, 0.f, 0.f, 0.f, 0.f, 0u};
+    bool done = !inside;
+    constexpr float LOG2E = 1.4426950408889634f;
 
     for (uint32_t base = range.x; base < range.y; base += 64) {
         const uint32_t n = min(64u, range.y - base);
-        // ---- Gaussian lanes: load one entry each, box test ----
         float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
         float colb = 0.f, invd = 0.f;
         bool keep = false;
@@ -168,24 +203,36 @@ render_fwd_wave(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
             q1 = splats[id * 3 + 1];
             const float4 q2 = splats[id * 3 + 2];
             colb = q2.x;
-            invd = 1.0f / q2.y;
-            // alpha = op * exp(-q/2) >= 1/255  <=>  q <= 2 ln(255 op).  0.01 slack keeps the test conservative
-            // against rounding (alpha at the slack boundary is 0.995/255).
-            const float tau = 2.0f * __logf(255.0f * q1.y) + 0.01f;
+            invd = q2.w;
             const float qmin = min_q_over_box(q0.x, q0.y, q0.z, q0.w, q1.x, x0, x1, y0, y1);
-            keep = !(qmin > tau);
+            keep = !(qmin > q2.z);                 // q2.z = 2 ln(255 opacity) + 0.01, written by the preprocess
+            q0.z *= -0.5f * LOG2E;                  // conic -> log2 units, sign folded in
+            q0.w *= -LOG2E;
+            q1.x *= -0.5f * LOG2E;
+        }
+        if (USE_LDS) {
+            s_rec[lane * 3 + 0] = q0;
+            s_rec[lane * 3 + 1] = q1;
+            s_rec[lane * 3 + 2] = make_float4(colb, invd, 0.f, 0.f);
         }
         uint64_t mask = __ballot(keep);
-        // ---- pixel lanes: blend the survivors in list order ----
+        const uint32_t pos_base = base - range.x + 1;
         while (mask) {
             const int j = __builtin_ctzll(mask);
             mask &= mask - 1;
-            const float gx_ = bcast(q0.x, j), gy_ = bcast(q0.y, j), cA = bcast(q0.z, j), cB = bcast(q0.w, j);
-            const float cC = bcast(q1.x, j), op = bcast(q1.y, j), cr = bcast(q1.z, j), cg = bcast(q1.w, j);
-            const float cb = bcast(colb, j), id_ = bcast(invd, j);
-            if (!s.done) blend_step(s, pxf, pyf, gx_, gy_, cA, cB, cC, op, cr, cg, cb, id_, base - range.x + j + 1);
+            if (USE_LDS) {
+                const float4 r0 = s_rec[j * 3 + 0];
+                const float4 r1 = s_rec[j * 3 + 1];
+                const float2 r2 = *reinterpret_cast<const float2*>(&s_rec[j * 3 + 2]);
+                blend_step_bf(s, done, pxf, pyf, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, pos_base + j);
+            } else {
+                const float gx_ = bcast(q0.x, j), gy_ = bcast(q0.y, j), a2 = bcast(q0.z, j), b2 = bcast(q0.w, j);
+                const float c2 = bcast(q1.x, j), op = bcast(q1.y, j), cr = bcast(q1.z, j), cg = bcast(q1.w, j);
+                const float cb = bcast(colb, j), id_ = bcast(invd, j);
+                blend_step_bf(s, done, pxf, pyf, gx_, gy_, a2, b2, c2, op, cr, cg, cb, id_, pos_base + j);
+            }
         }
-        if (__ballot(!s.done) == 0ull) break;
+        if (__ballot(!done) == 0ull) break;
     }
     if (inside) {
         const int64_t pix = (int64_t)py * cam.W + px;
@@ -211,7 +258,11 @@ void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const 
                            final_T, n_contrib, out_color, out_invdepth);
     } else {
         const int groups = (n_band_tiles + 7) / 8;
-        hipLaunchKernelGGL(render_fwd_wave, dim3(groups * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list,
-                           splats, final_T, n_contrib, out_color, out_invdepth);
+        if (variant == 2)
+            hipLaunchKernelGGL(render_fwd_wave_bf<false>, dim3(groups * 32), dim3(64), 0, st, cam, n_band_tiles, ranges,
+                               point_list, splats, final_T, n_contrib, out_color, out_invdepth);
+        else
+            hipLaunchKernelGGL(render_fwd_wave_bf<true>, dim3(groups * 32), dim3(64), 0, st, cam, n_band_tiles, ranges,
+                               point_list, splats, final_T, n_contrib, out_color, out_invdepth);
     }
 }

@@ -12,6 +12,12 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle issues many small tensor ops; on a 256-core host torch's default intra-op pool is >10x slower
+    try:
+        import torch
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+    except Exception:
+        pass
 
 
 def _has_gpu():

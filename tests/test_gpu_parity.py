@@ -100,14 +100,15 @@ def check_forward(s, col, radii, invd, aux, out, band=None):
     # blend state kept for backward
     assert torch.equal(out["n_contrib"].cpu().to(torch.int64)[rows][ok[rows]], aux["n_contrib"][rows][ok[rows]])
     terr = (out["final_T"].cpu() - aux["final_T"]).abs()
-    assert terr[rows][ok[rows]].max().item() <= 2e-6
+    # T is a running product of up to hundreds of (1 - alpha) factors; T(1-alpha) vs fma(-alpha,T,T) differ by an ulp each
+    assert terr[rows][ok[rows]].max().item() <= 5e-6
     if band is not None:   # rows outside the band untouched (zeros)
         mask = torch.ones(H, dtype=torch.bool)
         mask[rows] = False
         assert g_col[:, mask].abs().max().item() == 0.0
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("name", ["c1", "odd_aa", "edge_lookat", "edge_aa_scale", "deg1", "deg0_dense"])
 def test_forward_parity(name, variant):
     cam, sc, opts = mk(name)
