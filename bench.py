@@ -198,7 +198,7 @@ def main():
         torch.cuda.synchronize()
         tstages = _lib.profile_read()
         _lib.profile_enable(False)
-        for k in ("render_bwd", "preprocess_bwd"):
+        for k in ("render_bwd", "gather_bwd", "preprocess_bwd"):
             if tstages[k]["launches"]:
                 stage_ms[k] = tstages[k]["ms"] / tstages[k]["launches"]
         del params, opt

@@ -78,7 +78,8 @@ scan_finish(int P, const uint32_t* __restrict__ order, const uint32_t* __restric
 // fetched with ds_bpermute shuffles), then derives its tile from the Gaussian's rectangle (y-major, x fastest).
 __global__ void __launch_bounds__(256)
 emit_instances(int P, int gx, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
-               const uint2* __restrict__ rect, uint32_t* __restrict__ inst_keys, uint32_t* __restrict__ inst_vals) {
+               const uint2* __restrict__ rect, uint32_t* __restrict__ inst_keys, uint32_t* __restrict__ inst_vals,
+               float4* __restrict__ splats) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t j0 = wave * 64;
@@ -100,6 +101,9 @@ emit_instances(int P, int gx, const uint32_t* __restrict__ order, const uint32_t
     const int last = (int)((P - j0) < 64 ? (P - j0 - 1) : 63);
     const uint32_t total = __shfl(incl, last, 64);
     const uint32_t excl_self = incl - ((j < P) ? (offsets[j] - (j > 0 ? offsets[j - 1] : 0u)) : 0u);
+    // first emission index of this Gaussian -> 4th quad of its splat record (the blend backward writes its
+    // per-instance gradient records at emission indices, see render_bwd.hip)
+    if (j < P) reinterpret_cast<uint32_t*>(splats + (int64_t)id * 4 + 3)[2] = base + excl_self;
     for (uint32_t k0 = 0; k0 < total; k0 += 64) {
         const uint32_t k = k0 + lane;
         int lo = 0, hi = last;
@@ -154,10 +158,10 @@ void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles, 
 }
 
 void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect,
-                     uint32_t* inst_keys, uint32_t* inst_vals, hipStream_t st) {
+                     uint32_t* inst_keys, uint32_t* inst_vals, float4* splats, hipStream_t st) {
     const int64_t waves = ((int64_t)P + 63) / 64;
     const int nb = (int)((waves + 3) / 4);
-    hipLaunchKernelGGL(emit_instances, dim3(nb), dim3(256), 0, st, P, gx, order, offsets, rect, inst_keys, inst_vals);
+    hipLaunchKernelGGL(emit_instances, dim3(nb), dim3(256), 0, st, P, gx, order, offsets, rect, inst_keys, inst_vals, splats);
 }
 
 void gsr_launch_ranges(int64_t R, int n_tiles, const uint32_t* sorted_keys, uint2* ranges, hipStream_t st) {

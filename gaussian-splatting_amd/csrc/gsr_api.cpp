@@ -133,7 +133,7 @@ GsrGeom gsr_carve_geom(char* base, int P) {
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off = gsr_align128(off + bytes); return p; };
     const size_t n = (size_t)(P > 0 ? P : 1);
-    g.splats = (float4*)take(n * 48);
+    g.splats = (float4*)take(n * 64);
     g.rect = (uint2*)take(n * 8);
     g.tiles = (uint32_t*)take(n * 4);
     g.clamped = (uint32_t*)take(n * 4);
@@ -166,6 +166,17 @@ GsrBinning gsr_carve_binning(char* base, int64_t R) {
     return b;
 }
 
+GsrBwdScratch gsr_carve_bwd(char* base, int P, int64_t R) {
+    GsrBwdScratch b;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off = gsr_align128(off + bytes); return p; };
+    const size_t np = (size_t)(P > 0 ? P : 1), nr = (size_t)(R > 0 ? R : 1);
+    b.splat_grads = (float*)take(np * 48);
+    b.inst_grads = (float*)take(nr * 48);
+    b.bytes = off;
+    return b;
+}
+
 GsrImage gsr_carve_image(char* base, int W, int H) {
     GsrImage im;
     size_t off = 0;
@@ -187,6 +198,7 @@ const char* gsr_last_error(void) { return g_err.c_str(); }
 size_t gsr_geometry_bytes(int P) { return gsr_carve_geom(nullptr, P).bytes; }
 size_t gsr_binning_bytes(int64_t R, int n_tiles) { (void)n_tiles; return gsr_carve_binning(nullptr, R).bytes; }
 size_t gsr_image_bytes(int width, int height) { return gsr_carve_image(nullptr, width, height).bytes; }
+size_t gsr_backward_scratch_bytes(int P, int64_t R) { return gsr_carve_bwd(nullptr, P, R).bytes; }
 
 int gsr_set_option(const char* name, int value) {
     if (!name) return fail(GSR_ERR_INVALID_ARG, "option name is NULL");
@@ -277,7 +289,7 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
     int list_buf = 0;
     if (R > 0) {
         {   StageTimer t(GSR_STAGE_EMIT, st);
-            gsr_launch_emit(P, cam.gx, g.vals[order_buf], g.offsets, g.rect, b.keys[0], b.vals[0], st);
+            gsr_launch_emit(P, cam.gx, g.vals[order_buf], g.offsets, g.rect, b.keys[0], b.vals[0], g.splats, st);
         }
         STAGE_CHECK("emit");
         {   StageTimer t(GSR_STAGE_TILE_SORT, st);
@@ -307,7 +319,7 @@ int gsr_rasterize_backward(const GsrRasterSettings* settings, int P, int M, int3
                            const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
                            const float* dL_dout_color, const float* dL_dout_invdepth, float* dL_dmeans2D,
                            float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
-                           float* dL_dscales, float* dL_drotations, void* splat_grads_scratch, void* stream) {
+                           float* dL_dscales, float* dL_drotations, void* bwd_scratch, float** splat_grads_out, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     GsrCamDev cam;
     int rc = make_cam(settings, M, cam);
@@ -315,8 +327,8 @@ int gsr_rasterize_backward(const GsrRasterSettings* settings, int P, int M, int3
     rc = check_inputs(P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, cam.sh_degree);
     if (rc != GSR_OK) return rc;
     if (P == 0) return GSR_OK;
-    if (!radii || !geom_buffer || !binning_buffer || !image_buffer || !dL_dout_color || !splat_grads_scratch)
-        return fail(GSR_ERR_INVALID_ARG, "radii / state buffers / dL_dout_color / splat_grads_scratch are NULL");
+    if (!radii || !geom_buffer || !binning_buffer || !image_buffer || !dL_dout_color || !bwd_scratch)
+        return fail(GSR_ERR_INVALID_ARG, "radii / state buffers / dL_dout_color / bwd_scratch are NULL");
     if (!dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D)
         return fail(GSR_ERR_INVALID_ARG, "gradient outputs are NULL");
     if (shs && !dL_dsh) return fail(GSR_ERR_INVALID_ARG, "dL_dsh is NULL");
@@ -325,13 +337,29 @@ int gsr_rasterize_backward(const GsrRasterSettings* settings, int P, int M, int3
     GsrBinning b = gsr_carve_binning((char*)binning_buffer, num_rendered);
     GsrImage im = gsr_carve_image((char*)image_buffer, cam.W, cam.H);
     const int list_buf = num_rendered > 0 ? list_buffer_index(cam.gx * cam.gy) : 0;
-    float* sg = (float*)splat_grads_scratch;
+    GsrBwdScratch w = gsr_carve_bwd((char*)bwd_scratch, P, num_rendered);
+    float* sg = w.splat_grads;
+    if (splat_grads_out) *splat_grads_out = sg;
+    const int n_tiles = cam.gx * cam.gy;
     {   StageTimer t(GSR_STAGE_RENDER_BWD, st);
-        HIP_OK(hipMemsetAsync(sg, 0, (size_t)P * 12 * sizeof(float), st));
-        if (num_rendered > 0)
+        if (g_render_bwd_variant == 1 || num_rendered <= 0) {
+            HIP_OK(hipMemsetAsync(sg, 0, (size_t)P * 12 * sizeof(float), st));
+            if (num_rendered > 0)
+                gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib,
+                                           dL_dout_color, dL_dout_invdepth, sg, nullptr, 1, st);
+        } else {
+            // a band leaves the tiles outside it without instances; their (non-existent) records need no zeroing
             gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib,
-                                       dL_dout_color, dL_dout_invdepth, sg, g_render_bwd_variant, st);
+                                       dL_dout_color, dL_dout_invdepth, nullptr, w.inst_grads, 0, st);
+        }
     }
+    STAGE_CHECK("render backward blend");
+    if (g_render_bwd_variant != 1 && num_rendered > 0) {
+        StageTimer t(GSR_STAGE_GATHER_BWD, st);
+        const int order_buf = 0;   // 4 depth-sort passes end in buffer 0
+        gsr_launch_reduce_instances(P, g.vals[order_buf], g.offsets, g.tiles, w.inst_grads, sg, st);
+    }
+    (void)n_tiles;
     STAGE_CHECK("render backward");
     {   StageTimer t(GSR_STAGE_PREPROCESS_BWD, st);
         gsr_launch_preprocess_backward(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,

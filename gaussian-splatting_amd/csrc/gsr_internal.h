@@ -25,7 +25,7 @@ static inline size_t gsr_align128(size_t x) { return (x + 127) & ~(size_t)127; }
 #define GSR_SCAN_ITEMS 1024      // items per workgroup in the tiles_touched scan
 
 struct GsrGeom {                 // P-sized
-    float4* splats;              // [3P]  (x,y,conA,conB) (conC,opacity,r,g) (b,depth,0,0)
+    float4* splats;              // [4P]  (x,y,conA,conB) (conC,opacity,r,g) (b,depth,tau,1/depth) (rect.x,rect.y,goffset,tiles as bits)
     uint2* rect;                 // [P]   x = minx | maxx<<16 ; y = miny | maxy<<16 (band-clamped)
     uint32_t* tiles;             // [P]   tiles_touched
     uint32_t* clamped;           // [P]   colour clamp bits
@@ -85,7 +85,7 @@ static inline int64_t gsr_sort_blocks(int64_t n, bool small_blocks) {
 void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles, uint32_t* offsets,
                            uint32_t* block_sums, uint32_t* num_rendered, hipStream_t st);
 void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect,
-                     uint32_t* inst_keys, uint32_t* inst_vals, hipStream_t st);
+                     uint32_t* inst_keys, uint32_t* inst_vals, float4* splats, hipStream_t st);
 void gsr_launch_ranges(int64_t R, int n_tiles, const uint32_t* sorted_keys, uint2* ranges, hipStream_t st);
 
 // render_fwd.hip / render_bwd.hip
@@ -94,5 +94,15 @@ void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const 
                                float* out_invdepth, int variant, hipStream_t st);
 void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,
                                 const float4* splats, const float* final_T, const uint32_t* n_contrib,
-                                const float* dL_dpix, const float* dL_dinvdepth, float* splat_grads /*[P,12]*/,
-                                int variant, hipStream_t st);
+                                const float* dL_dpix, const float* dL_dinvdepth, float* splat_grads /*[P,12] variant 1*/,
+                                float* inst_grads /*[R,12] variant 0*/, int variant, hipStream_t st);
+void gsr_launch_reduce_instances(int P, const uint32_t* order, const uint32_t* offsets, const uint32_t* tiles,
+                                 const float* inst_grads, float* splat_grads, hipStream_t st);
+
+// backward scratch (caller-owned, gsr_backward_scratch_bytes): per-Gaussian record, per-instance records, maps
+struct GsrBwdScratch {
+    float* splat_grads;     // [P,12]
+    float* inst_grads;      // [R,12]
+    size_t bytes;
+};
+GsrBwdScratch gsr_carve_bwd(char* base, int P, int64_t R);

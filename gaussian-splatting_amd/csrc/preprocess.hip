@@ -85,10 +85,13 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             // (box-cull threshold of the blend kernels); 1/depth feeds the inverse-depth image.
             q2 = make_float4(rgb[2], sp.depth, 2.0f * logf(255.0f * sp.opacity) + 0.01f, 1.0f / sp.depth);
         }
-        splats[i * 3 + 0] = q0;
-        splats[i * 3 + 1] = q1;
-        splats[i * 3 + 2] = q2;
-        rect[i] = make_uint2(sp.minx | (sp.maxx << 16), sp.miny | (sp.maxy << 16));
+        const uint2 rc = make_uint2(sp.minx | (sp.maxx << 16), sp.miny | (sp.maxy << 16));
+        splats[i * 4 + 0] = q0;
+        splats[i * 4 + 1] = q1;
+        splats[i * 4 + 2] = q2;
+        // 4th quad: tile rectangle, first emission index (filled in by emit_instances), tiles_touched -- as raw bits
+        splats[i * 4 + 3] = make_float4(__uint_as_float(rc.x), __uint_as_float(rc.y), 0.f, __uint_as_float(sp.tiles));
+        rect[i] = rc;
         tiles[i] = sp.tiles;
         clamped_out[i] = clampbits;
         radii[i] = sp.radius;

@@ -71,9 +71,9 @@ render_fwd_block(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t
         const uint32_t n = min(256u, range.y - base);
         if ((uint32_t)tid < n) {
             const uint32_t id = point_list[base + tid];
-            s_q0[tid] = splats[id * 3 + 0];
-            s_q1[tid] = splats[id * 3 + 1];
-            const float4 q2 = splats[id * 3 + 2];
+            s_q0[tid] = splats[id * 4 +0];
+            s_q1[tid] = splats[id * 4 +1];
+            const float4 q2 = splats[id * 4 +2];
             s_q2[tid] = make_float2(q2.x, 1.0f / q2.y);
         }
         __syncthreads();
@@ -199,9 +199,9 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
         bool keep = false;
         if ((uint32_t)lane < n) {
             const uint32_t id = point_list[base + lane];
-            q0 = splats[id * 3 + 0];
-            q1 = splats[id * 3 + 1];
-            const float4 q2 = splats[id * 3 + 2];
+            q0 = splats[id * 4 +0];
+            q1 = splats[id * 4 +1];
+            const float4 q2 = splats[id * 4 +2];
             colb = q2.x;
             invd = q2.w;
             const float qmin = min_q_over_box(q0.x, q0.y, q0.z, q0.w, q1.x, x0, x1, y0, y1);

@@ -83,6 +83,8 @@ rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
     __shared__ uint32_t wave_cnt[RS_WAVES][256];
     __shared__ uint32_t digit_base[256];
     __shared__ uint32_t wsum[RS_WAVES];
+    __shared__ uint32_t s_key[RS_THREADS * IPT];
+    __shared__ uint32_t s_val[RS_THREADS * IPT];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 
     // digit_base[d] = (exclusive scan of digit totals)[d] + (keys with digit d in earlier workgroups)
@@ -134,14 +136,36 @@ rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    {   // exclusive prefix over waves for every digit, on top of digit_base
-        uint32_t run = digit_base[tid];
+    // Local (in-workgroup) sorted position of every item: exclusive prefix over digits of the workgroup's digit
+    // counts, then over waves within a digit.  Items are first scattered into LDS in that order and then written
+    // out by consecutive threads, so every digit's run leaves the CU as one contiguous, coalesced store burst
+    // instead of 4-byte stores scattered over 256 destinations (measured 104 us -> see profiles/ for this pass).
+    {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; ++k) tot += wave_cnt[k][tid];
+        uint32_t incl = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        __syncthreads();                 // wsum is re-used (its first use finished before the previous barrier)
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; ++k)
+            if (k < w) wbase += wsum[k];
+        const uint32_t lbase = wbase + incl - tot;      // first local slot of digit `tid`
+        uint32_t run = lbase;
 #pragma unroll
         for (int k = 0; k < RS_WAVES; ++k) {
             const uint32_t t = wave_cnt[k][tid];
             wave_cnt[k][tid] = run;
             run += t;
         }
+        digit_base[tid] -= lbase;                       // global position = digit_base[d] + local slot
     }
     __syncthreads();
 #pragma unroll
@@ -149,9 +173,22 @@ rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
         const int64_t idx = wave_base + r * 64 + lane;
         if (idx < n) {
             const uint32_t d = (key[r] >> shift) & 255u;
-            const uint32_t pos = wave_cnt[w][d] + rank[r];
-            keys_out[pos] = key[r];
-            vals_out[pos] = val[r];
+            const uint32_t lp = wave_cnt[w][d] + rank[r];
+            s_key[lp] = key[r];
+            s_val[lp] = val[r];
+        }
+    }
+    __syncthreads();
+    const int64_t block_base = (int64_t)blockIdx.x * (RS_THREADS * IPT);
+    const uint32_t nvalid = (uint32_t)((n - block_base) < (int64_t)(RS_THREADS * IPT) ? (n - block_base) : (RS_THREADS * IPT));
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+        const uint32_t i = (uint32_t)r * RS_THREADS + tid;
+        if (i < nvalid) {
+            const uint32_t k = s_key[i];
+            const uint32_t pos = digit_base[(k >> shift) & 255u] + i;
+            keys_out[pos] = k;
+            vals_out[pos] = s_val[i];
         }
     }
 }

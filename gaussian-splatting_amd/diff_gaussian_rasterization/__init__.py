@@ -175,7 +175,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if P > 0:
             g_color = _f32c(grad_out_color)
             g_depth = _f32c(grad_out_depth) if grad_out_depth is not None else None
-            scratch = torch.empty(P, 12, **f)
+            scratch = torch.empty(int(lib.gsr_backward_scratch_bytes(P, ctx.num_rendered)), dtype=torch.uint8, device=device)
             keep: list = []
             with torch.cuda.device(device):
                 s = _make_settings(rs, keep, ctx.tile_rows)
@@ -184,7 +184,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                         _ptr(rot) if has_rot else None, _ptr(cov) if has_cov else None, _ptr(radii),
                         _ptr(geom), _ptr(binning), _ptr(img), _ptr(g_color), _ptr(g_depth),
                         _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
-                        _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drot), _ptr(scratch), _stream_ptr(device))
+                        _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drot), _ptr(scratch), None, _stream_ptr(device))
                 if rs.debug:
                     cpu_args = _cpu_copy((means3D, radii, col, sc, rot, cov, sh, grad_out_color, rs))
                     try:

@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgsr_hip.so")
 
 GSR_OK = 0
-STAGES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "render", "render_bwd", "preprocess_bwd"]
+STAGES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "render", "render_bwd", "preprocess_bwd",
+          "gather_bwd"]
 
 
 class GsrRasterSettings(C.Structure):
@@ -40,6 +41,7 @@ RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 EXPORTS = [
     "gsr_abi_version", "gsr_last_error", "gsr_geometry_bytes", "gsr_binning_bytes", "gsr_image_bytes",
+    "gsr_backward_scratch_bytes",
     "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_mark_visible", "gsr_forward_views",
     "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_set_option",
 ]
@@ -79,6 +81,8 @@ def load() -> C.CDLL:
     lib.gsr_binning_bytes.argtypes = [C.c_int64, C.c_int]
     lib.gsr_image_bytes.restype = C.c_size_t
     lib.gsr_image_bytes.argtypes = [C.c_int, C.c_int]
+    lib.gsr_backward_scratch_bytes.restype = C.c_size_t
+    lib.gsr_backward_scratch_bytes.argtypes = [C.c_int, C.c_int64]
     vp = C.c_void_p
     lib.gsr_rasterize_forward.restype = C.c_int
     lib.gsr_rasterize_forward.argtypes = [C.POINTER(GsrRasterSettings), C.c_int, C.c_int,
@@ -89,7 +93,7 @@ def load() -> C.CDLL:
     lib.gsr_rasterize_backward.argtypes = [C.POINTER(GsrRasterSettings), C.c_int, C.c_int, C.c_int32,
                                            vp, vp, vp, vp, vp, vp, vp, vp,
                                            vp, vp, vp, vp, vp,
-                                           vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+                                           vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_void_p), vp]
     lib.gsr_mark_visible.restype = C.c_int
     lib.gsr_mark_visible.argtypes = [C.c_int, vp, vp, vp, vp, vp]
     lib.gsr_forward_views.restype = C.c_int

@@ -47,7 +47,7 @@ def forward_with_views(rs: GaussianRasterizationSettings, means3D, opacities, sh
         _lib.check(lib.gsr_forward_views(P, R, W, H, _ptr(geom.t), _ptr(binning.t), _ptr(img.t), C.byref(v)),
                    "gsr_forward_views")
         gx, gy = (W + 15) // 16, (H + 15) // 16
-        out["splats"] = _view(geom.t, v.splats, P * 48, torch.float32).view(P, 12)
+        out["splats"] = _view(geom.t, v.splats, P * 64, torch.float32).view(P, 16)
         out["tiles_touched"] = _view(geom.t, v.tiles_touched, P * 4, torch.int32)
         out["depth_order"] = _view(geom.t, v.depth_order, P * 4, torch.int32)
         out["point_list"] = (_view(binning.t, v.point_list, R * 4, torch.int32) if R > 0

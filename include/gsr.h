@@ -80,6 +80,7 @@ const char* gsr_last_error(void);
 size_t gsr_geometry_bytes(int P);
 size_t gsr_binning_bytes(int64_t R, int n_tiles);
 size_t gsr_image_bytes(int width, int height);
+size_t gsr_backward_scratch_bytes(int P, int64_t R);
 
 /*
  * Replaces _C.rasterize_gaussians.
@@ -109,9 +110,10 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M,
  *   dL_dmeans2D[P,3]  (x,y in NDC-scaled units = pixel gradient * (0.5 W, 0.5 H); z = 0)
  *   dL_dcolors[P,3], dL_dopacity[P], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3] (NULL if no shs),
  *   dL_dscales[P,3], dL_drotations[P,4] (NULL if cov3D_precomp was given).
- *   splat_grads_scratch: caller-owned scratch of P*12 floats (zeroed internally) that receives the
- *   per-Gaussian 2-D gradient record accumulated by the blend backward; after the call it holds, per
- *   Gaussian, [dpx,dpy,dA,dB,dC,dopacity,dr,dg,db,dinvdepth,0,0] -- the 48-byte record that is
+ *   bwd_scratch: caller-owned scratch of gsr_backward_scratch_bytes(P, num_rendered) bytes (per-instance
+ *   gradient records, the emission-order inverse map and the per-Gaussian 2-D gradient record).
+ *   If splat_grads_out is non-NULL it receives the device address (inside bwd_scratch) of the per-Gaussian
+ *   record [P,12] = [dpx,dpy,dA,dB,dC,dopacity,dr,dg,db,dinvdepth,0,0] -- the 48-byte payload that is
  *   reduce-scattered between GPUs when the screen is sharded.
  */
 int gsr_rasterize_backward(const GsrRasterSettings* settings, int P, int M, int32_t num_rendered,
@@ -122,8 +124,8 @@ int gsr_rasterize_backward(const GsrRasterSettings* settings, int P, int M, int3
                            const float* dL_dout_color, const float* dL_dout_invdepth,
                            float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
                            float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
-                           float* dL_dscales, float* dL_drotations, void* splat_grads_scratch,
-                           void* stream);
+                           float* dL_dscales, float* dL_drotations, void* bwd_scratch,
+                           float** splat_grads_out, void* stream);
 
 /* Replaces _C.mark_visible: present[i] = 1 iff Gaussian i is in front of the 0.2 near plane. */
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
@@ -134,7 +136,7 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  * Pointers are device pointers valid while the buffers live.
  */
 typedef struct GsrForwardViews {
-    const float* splats;          /* [P,12] x,y,conA,conB | conC,opacity,r,g | b,depth,0,0 */
+    const float* splats;          /* [P,16] x,y,conA,conB | conC,opacity,r,g | b,depth,tau,1/depth | rect,goffset,tiles (bits) */
     const uint32_t* tiles_touched;/* [P] */
     const uint32_t* depth_order;  /* [P] Gaussian ids in (depth, id) order; culled ones last */
     const uint32_t* point_list;   /* [R] Gaussian ids sorted by (tile, depth, id) */
@@ -158,7 +160,8 @@ enum {
     GSR_STAGE_RENDER = 6,
     GSR_STAGE_RENDER_BWD = 7,
     GSR_STAGE_PREPROCESS_BWD = 8,
-    GSR_STAGE_COUNT = 9
+    GSR_STAGE_GATHER_BWD = 9,
+    GSR_STAGE_COUNT = 10
 };
 int gsr_profile_enable(int on);
 int gsr_profile_reset(void);
