@@ -39,7 +39,8 @@ scan_block_sums(int P, const uint32_t* __restrict__ order, const uint32_t* __res
 // own 1024 items.  offsets[j] = inclusive prefix in depth order; the last workgroup publishes R.
 __global__ void __launch_bounds__(SC_THREADS)
 scan_finish(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
-            const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ offsets, uint32_t* __restrict__ num_rendered) {
+            const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ offsets, uint32_t* __restrict__ num_rendered,
+            uint32_t* host_word, uint32_t seq) {
     __shared__ uint32_t wsum[SC_THREADS / 64];
     __shared__ uint32_t wtot[SC_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -68,7 +69,13 @@ scan_finish(int P, const uint32_t* __restrict__ order, const uint32_t* __restric
     for (int k = 0; k < SC_IPT; ++k) {
         run += v[k];
         if (base + k < P) offsets[base + k] = run;
-        if (base + k == (int64_t)P - 1) num_rendered[0] = run;
+        if (base + k == (int64_t)P - 1) {
+            num_rendered[0] = run;
+            if (host_word) {   // publish R to the spinning host: value first, then the sequence number (system-scope release)
+                __hip_atomic_store(&host_word[0], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&host_word[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 
@@ -151,10 +158,11 @@ tile_ranges(int64_t R, const uint32_t* __restrict__ keys, uint2* __restrict__ ra
 }  // namespace
 
 void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles, uint32_t* offsets,
-                           uint32_t* block_sums, uint32_t* num_rendered, hipStream_t st) {
+                           uint32_t* block_sums, uint32_t* num_rendered, uint32_t* host_word, uint32_t seq, hipStream_t st) {
     const int nb = (P + GSR_SCAN_ITEMS - 1) / GSR_SCAN_ITEMS;
     hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(SC_THREADS), 0, st, P, order, tiles, block_sums);
-    hipLaunchKernelGGL(scan_finish, dim3(nb), dim3(SC_THREADS), 0, st, P, order, tiles, block_sums, offsets, num_rendered);
+    hipLaunchKernelGGL(scan_finish, dim3(nb), dim3(SC_THREADS), 0, st, P, order, tiles, block_sums, offsets, num_rendered,
+                       host_word, seq);
 }
 
 void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect,

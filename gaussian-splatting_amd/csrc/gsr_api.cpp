@@ -4,6 +4,7 @@
 // depth-sort + stable tile-sort binning pipeline instead of one 64-bit key sort.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -30,6 +31,7 @@ int fail(int code, const std::string& msg) {
 // ---- options / profiling ----
 int g_render_fwd_variant = 0;
 int g_render_bwd_variant = 0;
+int g_depth_digit_bits = GSR_DEPTH_DIGIT_BITS;
 
 struct PendingEvent { int stage; hipEvent_t a, b; };
 std::mutex g_prof_mu;
@@ -121,9 +123,13 @@ int check_inputs(int P, int M, const float* means3D, const float* shs, const flo
     return GSR_OK;
 }
 
-thread_local uint32_t* g_host_word = nullptr;
+thread_local uint32_t* g_host_word = nullptr;       // mapped pinned host memory: [0] = R, [1] = sequence number
+thread_local uint32_t* g_host_word_dev = nullptr;   // its device-side address
+thread_local uint32_t g_host_seq = 0;
+std::atomic<int64_t> g_last_R{0};
 
-bool use_small_blocks(int64_t n) { return n < (int64_t)2 * 1024 * 1024; }
+int64_t g_small_block_threshold = (int64_t)2 * 1024 * 1024;   // below this a radix pass uses 1024-item workgroups
+bool use_small_blocks(int64_t n) { return n < g_small_block_threshold; }
 
 }  // namespace
 
@@ -143,8 +149,11 @@ GsrGeom gsr_carve_geom(char* base, int P) {
     g.vals[1] = (uint32_t*)take(n * 4);
     g.offsets = (uint32_t*)take(n * 4);
     g.block_sums = (uint32_t*)take(((n + GSR_SCAN_ITEMS - 1) / GSR_SCAN_ITEMS) * 4);
-    g.sort_hist = (uint32_t*)take((size_t)256 * (size_t)gsr_sort_blocks((int64_t)n, use_small_blocks((int64_t)n)) * 4);
-    g.digit_total = (uint32_t*)take(256 * 4);
+    {   // worst case over the two layouts the depth sort may use: 256 bins x small workgroups, 2048 bins x large ones
+        const size_t a = (size_t)256 * (size_t)gsr_sort_blocks((int64_t)n, true), b2 = (size_t)2048 * (size_t)gsr_sort_blocks((int64_t)n, false);
+        g.sort_hist = (uint32_t*)take((a > b2 ? a : b2) * 4);
+    }
+    g.digit_total = (uint32_t*)take(2048 * 4);
     g.num_rendered = (uint32_t*)take(128);
     g.bytes = off;
     return g;
@@ -159,7 +168,7 @@ GsrBinning gsr_carve_binning(char* base, int64_t R) {
     b.keys[1] = (uint32_t*)take(n * 4);
     b.vals[0] = (uint32_t*)take(n * 4);
     b.vals[1] = (uint32_t*)take(n * 4);
-    b.sort_hist = (uint32_t*)take((size_t)256 * (size_t)gsr_sort_blocks((int64_t)n, use_small_blocks((int64_t)n)) * 4);
+    b.sort_hist = (uint32_t*)take((size_t)256 * (size_t)gsr_sort_blocks((int64_t)n, true) * 4);   // worst case
     b.digit_total = (uint32_t*)take(256 * 4);
     b.meta = (uint32_t*)take(128);
     b.bytes = off;
@@ -204,6 +213,8 @@ int gsr_set_option(const char* name, int value) {
     if (!name) return fail(GSR_ERR_INVALID_ARG, "option name is NULL");
     if (!strcmp(name, "render_fwd_variant")) { g_render_fwd_variant = value; return GSR_OK; }
     if (!strcmp(name, "render_bwd_variant")) { g_render_bwd_variant = value; return GSR_OK; }
+    if (!strcmp(name, "sort_small_block_threshold")) { g_small_block_threshold = value; return GSR_OK; }
+    if (!strcmp(name, "depth_digit_bits")) { g_depth_digit_bits = (value > 8) ? 11 : 8; return GSR_OK; }
     return fail(GSR_ERR_INVALID_ARG, std::string("unknown option ") + name);
 }
 
@@ -266,22 +277,55 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
     STAGE_CHECK("preprocess");
     int order_buf;
     {   StageTimer t(GSR_STAGE_DEPTH_SORT, st);
-        order_buf = gsr_radix_sort_pairs(g.keys, g.vals, P, 32, g.sort_hist, g.digit_total, use_small_blocks(P), st);
+        // 11-bit digits need the large (4096-item) workgroups to keep the 2048-row histogram table small
+        order_buf = gsr_radix_sort_pairs(g.keys, g.vals, P, 32, g_depth_digit_bits, g.sort_hist, g.digit_total,
+                                         g_depth_digit_bits > 8 ? false : use_small_blocks(P), st);
     }
     STAGE_CHECK("depth sort");
-    {   StageTimer t(GSR_STAGE_SCAN, st);
-        gsr_launch_scan_tiles(P, g.vals[order_buf], g.tiles, g.offsets, g.block_sums, g.num_rendered, st);
+    // R = number of (Gaussian, tile) instances sizes the binning buffer, so the host must learn it mid-pipeline (the
+    // reference has the same read-back).  To keep the GPU-idle bubble short: (1) the scan kernel stores R + a sequence
+    // number straight into mapped pinned host memory (system-scope release) and the host spins on it instead of going
+    // through hipMemcpyAsync + hipStreamSynchronize; (2) the image buffer and a speculative binning buffer (last R + 25 %)
+    // are obtained through the callbacks WHILE the GPU is still working, so in steady state no callback sits in the bubble.
+    if (!g_host_word) {
+        HIP_OK(hipHostMalloc((void**)&g_host_word, 64, hipHostMallocMapped));
+        HIP_OK(hipHostGetDevicePointer((void**)&g_host_word_dev, g_host_word, 0));
+        g_host_word[0] = g_host_word[1] = 0;
     }
-    if (!g_host_word) HIP_OK(hipHostMalloc((void**)&g_host_word, 64, hipHostMallocDefault));
-    HIP_OK(hipMemcpyAsync(g_host_word, g.num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));
+    const uint32_t seq = ++g_host_seq;
+    {   StageTimer t(GSR_STAGE_SCAN, st);
+        gsr_launch_scan_tiles(P, g.vals[order_buf], g.tiles, g.offsets, g.block_sums, g.num_rendered, g_host_word_dev, seq, st);
+    }
+    const int n_tiles = cam.gx * cam.gy;
+    char* ibase = (char*)image_resize(image_user, gsr_image_bytes(cam.W, cam.H));
+    char* bbase = nullptr;
+    size_t spec_bytes = 0;
+    const int64_t last_R = g_last_R.load();
+    if (last_R > 0) {
+        spec_bytes = gsr_binning_bytes(last_R + last_R / 4 + 4096, n_tiles);
+        bbase = (char*)binning_resize(binning_user, spec_bytes);
+    }
+    {
+        volatile uint32_t* hw = g_host_word;
+        bool got = false;
+        for (uint64_t spin = 0; spin < (1ull << 26); ++spin) {
+            if (hw[1] == seq) { got = true; break; }
+            __builtin_ia32_pause();
+        }
+        if (!got) {   // kernel fault or a very slow queue: fall back to the blocking path, which also surfaces errors
+            HIP_OK(hipStreamSynchronize(st));
+            if (hw[1] != seq) {
+                HIP_OK(hipMemcpy((void*)g_host_word, g.num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost));
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
     const int64_t R = (int64_t)g_host_word[0];
     if (R > 0x7FFFFFFFll) return fail(GSR_ERR_UNSUPPORTED, "more than 2^31-1 tile instances");
     *num_rendered = (int32_t)R;
-
-    const int n_tiles = cam.gx * cam.gy;
-    char* bbase = (char*)binning_resize(binning_user, gsr_binning_bytes(R, n_tiles));
-    char* ibase = (char*)image_resize(image_user, gsr_image_bytes(cam.W, cam.H));
+    g_last_R.store(R);
+    const size_t need_bytes = gsr_binning_bytes(R, n_tiles);
+    if (!bbase || need_bytes > spec_bytes) bbase = (char*)binning_resize(binning_user, need_bytes);
     if (!bbase || !ibase) return fail(GSR_ERR_ALLOC, "binning / image buffer resize returned NULL");
     GsrBinning b = gsr_carve_binning(bbase, R);
     GsrImage im = gsr_carve_image(ibase, cam.W, cam.H);
@@ -293,8 +337,8 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
         }
         STAGE_CHECK("emit");
         {   StageTimer t(GSR_STAGE_TILE_SORT, st);
-            list_buf = gsr_radix_sort_pairs(b.keys, b.vals, R, bits_for((uint32_t)n_tiles), b.sort_hist, b.digit_total,
-                                            use_small_blocks(R), st);
+            list_buf = gsr_radix_sort_pairs(b.keys, b.vals, R, bits_for((uint32_t)n_tiles), GSR_TILE_DIGIT_BITS, b.sort_hist,
+                                            b.digit_total, use_small_blocks(R), st);
         }
         STAGE_CHECK("tile sort");
     }
@@ -311,7 +355,14 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
     return GSR_OK;
 }
 
-static int list_buffer_index(int n_tiles) { return ((bits_for((uint32_t)n_tiles) + 7) / 8) & 1; }
+static int list_buffer_index(int n_tiles) {
+    int pb[8];
+    return gsr_sort_plan(bits_for((uint32_t)n_tiles), GSR_TILE_DIGIT_BITS, pb) & 1;
+}
+static int depth_order_buffer_index() {
+    int pb[8];
+    return gsr_sort_plan(32, g_depth_digit_bits, pb) & 1;
+}
 
 int gsr_rasterize_backward(const GsrRasterSettings* settings, int P, int M, int32_t num_rendered, const float* means3D,
                            const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
@@ -348,7 +399,8 @@ int gsr_rasterize_backward(const GsrRasterSettings* settings, int P, int M, int3
                 gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib,
                                            dL_dout_color, dL_dout_invdepth, sg, nullptr, 1, st);
         } else {
-            // a band leaves the tiles outside it without instances; their (non-existent) records need no zeroing
+            // records of instances that contributed nowhere are never written by the blend backward: clear them all first
+            HIP_OK(hipMemsetAsync(w.inst_grads, 0, (size_t)num_rendered * 12 * sizeof(float), st));
             gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib,
                                        dL_dout_color, dL_dout_invdepth, nullptr, w.inst_grads, 0, st);
         }
@@ -356,7 +408,7 @@ int gsr_rasterize_backward(const GsrRasterSettings* settings, int P, int M, int3
     STAGE_CHECK("render backward blend");
     if (g_render_bwd_variant != 1 && num_rendered > 0) {
         StageTimer t(GSR_STAGE_GATHER_BWD, st);
-        const int order_buf = 0;   // 4 depth-sort passes end in buffer 0
+        const int order_buf = depth_order_buffer_index();
         gsr_launch_reduce_instances(P, g.vals[order_buf], g.offsets, g.tiles, w.inst_grads, sg, st);
     }
     (void)n_tiles;
@@ -390,7 +442,7 @@ int gsr_forward_views(int P, int64_t R, int width, int height, const void* geom_
     const int n_tiles = ((width + GSR_TILE - 1) / GSR_TILE) * ((height + GSR_TILE - 1) / GSR_TILE);
     out->splats = (const float*)g.splats;
     out->tiles_touched = g.tiles;
-    out->depth_order = g.vals[0];   // 4 passes -> result back in buffer 0
+    out->depth_order = g.vals[depth_order_buffer_index()];
     out->point_list = nullptr;
     if (binning_buffer && R > 0) {
         GsrBinning b = gsr_carve_binning((char*)binning_buffer, R);

@@ -74,8 +74,12 @@ void gsr_launch_mark_visible(int P, const float* means3D, const float* view, uin
 
 // sort.hip: LSD radix sort of (u32 key, u32 value) pairs on bits [0, nbits); returns the index (0/1) of the
 // ping-pong buffer that holds the result.  n is known on the host.
-int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, uint32_t* hist,
+int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
                          uint32_t* digit_total, bool small_blocks, hipStream_t st);
+// pass plan shared by the sorter and by code that must know which ping-pong buffer holds the result
+int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits /*[8]*/);
+#define GSR_DEPTH_DIGIT_BITS 8      // 32-bit depth keys: 4 passes of 8 bits (3 x 11 bits measured slower: 113 vs 91 us)
+#define GSR_TILE_DIGIT_BITS 8       // tile ids: ceil(bits/8) passes of equal width
 static inline int64_t gsr_sort_blocks(int64_t n, bool small_blocks) {
     const int64_t items = small_blocks ? GSR_SORT_ITEMS_SMALL : GSR_SORT_ITEMS;
     return (n + items - 1) / items;
@@ -83,7 +87,8 @@ static inline int64_t gsr_sort_blocks(int64_t n, bool small_blocks) {
 
 // binning.hip: scan of tiles_touched in depth order, instance emission, tile ranges
 void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles, uint32_t* offsets,
-                           uint32_t* block_sums, uint32_t* num_rendered, hipStream_t st);
+                           uint32_t* block_sums, uint32_t* num_rendered, uint32_t* host_word /*mapped pinned, may be NULL*/,
+                           uint32_t seq, hipStream_t st);
 void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect,
                      uint32_t* inst_keys, uint32_t* inst_vals, float4* splats, hipStream_t st);
 void gsr_launch_ranges(int64_t R, int n_tiles, const uint32_t* sorted_keys, uint2* ranges, hipStream_t st);

@@ -332,75 +332,73 @@ GSR_HD void gsr_project_backward(const GsrCam& cam, const float* mean, const flo
     dmean[2] += W02 * dtx + W12 * dty + W22 * dtz;
 }
 
-// SH backward: drgb = dL/d(rgb after clamp).  Writes dsh[M][3] (all M rows; rows above the active degree
-// are zero) and accumulates the view-direction term into dmean.
+// SH backward, streaming: drgb = dL/d(rgb after clamp).  `sh` / `dsh` point at this Gaussian's [M][3] blocks (global or
+// host memory); one coefficient (3 floats) is read, used and written at a time, so no per-thread arrays are needed
+// (the first, array-based version spilled 208 B/lane to scratch in the fused backward kernel).  All M rows of dsh are
+// written (rows above the active degree are zero); the view-direction term is accumulated into dmean.
+struct GsrShBwdAcc {
+    float drgb[3];
+    float ddx, ddy, ddz;
+};
+GSR_HD void gsr_sh_bwd_term(GsrShBwdAcc& a, const float* sh, float* dsh, int k, float basis, float bx, float by, float bz) {
+    const float s0 = sh[k * 3 + 0], s1 = sh[k * 3 + 1], s2 = sh[k * 3 + 2];
+    dsh[k * 3 + 0] = basis * a.drgb[0];
+    dsh[k * 3 + 1] = basis * a.drgb[1];
+    dsh[k * 3 + 2] = basis * a.drgb[2];
+    const float dot = s0 * a.drgb[0] + s1 * a.drgb[1] + s2 * a.drgb[2];
+    a.ddx += bx * dot;
+    a.ddy += by * dot;
+    a.ddz += bz * dot;
+}
 GSR_HD void gsr_sh_backward(int deg, int M, const float* sh, const float* mean, const float* campos,
                             uint32_t clamped, const float* drgb_in, float* dsh, float* dmean) {
     const float ox = mean[0] - campos[0], oy = mean[1] - campos[1], oz = mean[2] - campos[2];
     const float n = sqrtf(ox * ox + oy * oy + oz * oz);
     const float x = ox / n, y = oy / n, z = oz / n;
-    float drgb[3];
-    for (int ch = 0; ch < 3; ++ch) drgb[ch] = (clamped & (1u << ch)) ? 0.0f : drgb_in[ch];
-    float ddx = 0.0f, ddy = 0.0f, ddz = 0.0f;   // dL/d(unit direction)
-    for (int k = 0; k < M * 3; ++k) dsh[k] = 0.0f;
-    float basis[16], bx[16], by[16], bz[16];
-    for (int k = 0; k < 16; ++k) basis[k] = bx[k] = by[k] = bz[k] = 0.0f;
-    basis[0] = GSR_SH_C0;
+    GsrShBwdAcc a;
+    for (int ch = 0; ch < 3; ++ch) a.drgb[ch] = (clamped & (1u << ch)) ? 0.0f : drgb_in[ch];
+    a.ddx = a.ddy = a.ddz = 0.0f;
     int nb = 1;
+    gsr_sh_bwd_term(a, sh, dsh, 0, GSR_SH_C0, 0.0f, 0.0f, 0.0f);
     if (deg > 0) {
-        basis[1] = -GSR_SH_C1 * y; by[1] = -GSR_SH_C1;
-        basis[2] = GSR_SH_C1 * z;  bz[2] = GSR_SH_C1;
-        basis[3] = -GSR_SH_C1 * x; bx[3] = -GSR_SH_C1;
+        gsr_sh_bwd_term(a, sh, dsh, 1, -GSR_SH_C1 * y, 0.0f, -GSR_SH_C1, 0.0f);
+        gsr_sh_bwd_term(a, sh, dsh, 2, GSR_SH_C1 * z, 0.0f, 0.0f, GSR_SH_C1);
+        gsr_sh_bwd_term(a, sh, dsh, 3, -GSR_SH_C1 * x, -GSR_SH_C1, 0.0f, 0.0f);
         nb = 4;
         if (deg > 1) {
             const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-            basis[4] = GSR_SH_C2_0 * xy;                  bx[4] = GSR_SH_C2_0 * y; by[4] = GSR_SH_C2_0 * x;
-            basis[5] = GSR_SH_C2_1 * yz;                  by[5] = GSR_SH_C2_1 * z; bz[5] = GSR_SH_C2_1 * y;
-            basis[6] = GSR_SH_C2_2 * (2.0f * zz - xx - yy);
-            bx[6] = GSR_SH_C2_2 * -2.0f * x; by[6] = GSR_SH_C2_2 * -2.0f * y; bz[6] = GSR_SH_C2_2 * 4.0f * z;
-            basis[7] = GSR_SH_C2_3 * xz;                  bx[7] = GSR_SH_C2_3 * z; bz[7] = GSR_SH_C2_3 * x;
-            basis[8] = GSR_SH_C2_4 * (xx - yy);           bx[8] = GSR_SH_C2_4 * 2.0f * x; by[8] = GSR_SH_C2_4 * -2.0f * y;
+            gsr_sh_bwd_term(a, sh, dsh, 4, GSR_SH_C2_0 * xy, GSR_SH_C2_0 * y, GSR_SH_C2_0 * x, 0.0f);
+            gsr_sh_bwd_term(a, sh, dsh, 5, GSR_SH_C2_1 * yz, 0.0f, GSR_SH_C2_1 * z, GSR_SH_C2_1 * y);
+            gsr_sh_bwd_term(a, sh, dsh, 6, GSR_SH_C2_2 * (2.0f * zz - xx - yy), GSR_SH_C2_2 * -2.0f * x, GSR_SH_C2_2 * -2.0f * y,
+                            GSR_SH_C2_2 * 4.0f * z);
+            gsr_sh_bwd_term(a, sh, dsh, 7, GSR_SH_C2_3 * xz, GSR_SH_C2_3 * z, 0.0f, GSR_SH_C2_3 * x);
+            gsr_sh_bwd_term(a, sh, dsh, 8, GSR_SH_C2_4 * (xx - yy), GSR_SH_C2_4 * 2.0f * x, GSR_SH_C2_4 * -2.0f * y, 0.0f);
             nb = 9;
             if (deg > 2) {
-                basis[9] = GSR_SH_C3_0 * y * (3.0f * xx - yy);
-                bx[9] = GSR_SH_C3_0 * 6.0f * xy; by[9] = GSR_SH_C3_0 * (3.0f * xx - 3.0f * yy);
-                basis[10] = GSR_SH_C3_1 * xy * z;
-                bx[10] = GSR_SH_C3_1 * yz; by[10] = GSR_SH_C3_1 * xz; bz[10] = GSR_SH_C3_1 * xy;
-                basis[11] = GSR_SH_C3_2 * y * (4.0f * zz - xx - yy);
-                bx[11] = GSR_SH_C3_2 * -2.0f * xy; by[11] = GSR_SH_C3_2 * (4.0f * zz - xx - 3.0f * yy); bz[11] = GSR_SH_C3_2 * 8.0f * yz;
-                basis[12] = GSR_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
-                bx[12] = GSR_SH_C3_3 * -6.0f * xz; by[12] = GSR_SH_C3_3 * -6.0f * yz; bz[12] = GSR_SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy);
-                basis[13] = GSR_SH_C3_4 * x * (4.0f * zz - xx - yy);
-                bx[13] = GSR_SH_C3_4 * (4.0f * zz - 3.0f * xx - yy); by[13] = GSR_SH_C3_4 * -2.0f * xy; bz[13] = GSR_SH_C3_4 * 8.0f * xz;
-                basis[14] = GSR_SH_C3_5 * z * (xx - yy);
-                bx[14] = GSR_SH_C3_5 * 2.0f * xz; by[14] = GSR_SH_C3_5 * -2.0f * yz; bz[14] = GSR_SH_C3_5 * (xx - yy);
-                basis[15] = GSR_SH_C3_6 * x * (xx - 3.0f * yy);
-                bx[15] = GSR_SH_C3_6 * (3.0f * xx - 3.0f * yy); by[15] = GSR_SH_C3_6 * -6.0f * xy;
+                gsr_sh_bwd_term(a, sh, dsh, 9, GSR_SH_C3_0 * y * (3.0f * xx - yy), GSR_SH_C3_0 * 6.0f * xy,
+                                GSR_SH_C3_0 * (3.0f * xx - 3.0f * yy), 0.0f);
+                gsr_sh_bwd_term(a, sh, dsh, 10, GSR_SH_C3_1 * xy * z, GSR_SH_C3_1 * yz, GSR_SH_C3_1 * xz, GSR_SH_C3_1 * xy);
+                gsr_sh_bwd_term(a, sh, dsh, 11, GSR_SH_C3_2 * y * (4.0f * zz - xx - yy), GSR_SH_C3_2 * -2.0f * xy,
+                                GSR_SH_C3_2 * (4.0f * zz - xx - 3.0f * yy), GSR_SH_C3_2 * 8.0f * yz);
+                gsr_sh_bwd_term(a, sh, dsh, 12, GSR_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), GSR_SH_C3_3 * -6.0f * xz,
+                                GSR_SH_C3_3 * -6.0f * yz, GSR_SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy));
+                gsr_sh_bwd_term(a, sh, dsh, 13, GSR_SH_C3_4 * x * (4.0f * zz - xx - yy), GSR_SH_C3_4 * (4.0f * zz - 3.0f * xx - yy),
+                                GSR_SH_C3_4 * -2.0f * xy, GSR_SH_C3_4 * 8.0f * xz);
+                gsr_sh_bwd_term(a, sh, dsh, 14, GSR_SH_C3_5 * z * (xx - yy), GSR_SH_C3_5 * 2.0f * xz, GSR_SH_C3_5 * -2.0f * yz,
+                                GSR_SH_C3_5 * (xx - yy));
+                gsr_sh_bwd_term(a, sh, dsh, 15, GSR_SH_C3_6 * x * (xx - 3.0f * yy), GSR_SH_C3_6 * (3.0f * xx - 3.0f * yy),
+                                GSR_SH_C3_6 * -6.0f * xy, 0.0f);
                 nb = 16;
             }
         }
     }
-    // fully unrolled with constant indices so basis/bx/by/bz stay in registers (no scratch)
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-    for (int k = 0; k < 16; ++k) {
-        if (k >= nb || k >= M) continue;
-        float dot = 0.0f;
-        for (int ch = 0; ch < 3; ++ch) {
-            dsh[k * 3 + ch] = basis[k] * drgb[ch];
-            dot += sh[k * 3 + ch] * drgb[ch];
-        }
-        ddx += bx[k] * dot;
-        ddy += by[k] * dot;
-        ddz += bz[k] * dot;
-    }
+    for (int k = nb; k < M; ++k) { dsh[k * 3 + 0] = 0.0f; dsh[k * 3 + 1] = 0.0f; dsh[k * 3 + 2] = 0.0f; }
     // d = o / |o|  =>  dL/do = (dL/dd - d (d . dL/dd)) / |o|
-    const float dd = x * ddx + y * ddy + z * ddz;
+    const float dd = x * a.ddx + y * a.ddy + z * a.ddz;
     const float inv = 1.0f / n;
-    dmean[0] += (ddx - x * dd) * inv;
-    dmean[1] += (ddy - y * dd) * inv;
-    dmean[2] += (ddz - z * dd) * inv;
+    dmean[0] += (a.ddx - x * dd) * inv;
+    dmean[1] += (a.ddy - y * dd) * inv;
+    dmean[2] += (a.ddz - z * dd) * inv;
 }
 
 // Sigma3D = (R S)(R S)^T backward: dcov (independent packed entries) -> dscale[3], drot[4]

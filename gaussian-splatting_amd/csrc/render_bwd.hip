@@ -145,12 +145,14 @@ __device__ __forceinline__ uint32_t emission_index(const float4 q3, uint32_t tx,
     const uint32_t minx = rx & 0xFFFFu, w = (rx >> 16) - minx, miny = ry & 0xFFFFu;
     return goff + (ty - miny) * w + (tx - minx);
 }
-constexpr int SB = 256;            // super-batch of list entries staged in LDS
 constexpr int REC_STRIDE = 5;      // float4 per staged entry (80 B: conflict-free per-lane ds_read_b128)
 
 // ------------------------------------------------------------------------------------------------
 // default: workgroup per tile, per-instance gradient records, no global atomics
 // ------------------------------------------------------------------------------------------------
+// SB = super-batch: list entries staged in LDS at a time (256: one per thread; 128 halves the LDS footprint -> more
+// resident workgroups)
+template <int SB>
 __global__ void __launch_bounds__(256)
 render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                 const float4* __restrict__ splats, const float* __restrict__ final_T,
@@ -190,18 +192,11 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
     __syncthreads();
     const uint32_t nlist = range.y - range.x;
     const uint32_t end = min(nlist, max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
-    // entries at list positions >= end contributed to no pixel of the tile: their records are zero.  Records live at
+    // Entries at list positions >= end contributed to no pixel of the tile: their records stay zero (the whole record
+    // array is cleared by a streaming memset before this kernel -- looking up the emission index of every tail entry
+    // just to store zeros cost a 64-byte gather per entry, 590 MB of fetches on the 1 M / 1080p frame).  Records live at
     // the instance's EMISSION index k (contiguous per Gaussian): k = goffset + (ty - miny) * w + (tx - minx), with the
     // rectangle and goffset read from the 4th quad of the 64-byte splat record.
-    {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (uint32_t i = end + tid; i < nlist; i += 256) {
-            const uint32_t id = point_list[range.x + i];
-            const uint32_t k = emission_index(splats[id * 4 + 3], (uint32_t)tx, (uint32_t)ty);
-            float4* o = inst_grads + (int64_t)k * 3;
-            o[0] = z; o[1] = z; o[2] = z;
-        }
-    }
     if (end == 0) return;
 
     BwdPix s = {T_final, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -221,8 +216,7 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
             s_rec[tid * REC_STRIDE + 3] = make_float4(-0.5f * LOG2E * q1.x, q2.z, 0.f, 0.f);              // c2, tau
             s_k[tid] = emission_index(splats[id * 4 + 3], (uint32_t)tx, (uint32_t)ty);
         }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) s_grad4[tid * 3 + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < SB * 3; i += 256) s_grad4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
 
         if (quad_alive) {
@@ -450,9 +444,12 @@ void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const
         const int groups = (n_band_tiles + 7) / 8;
         hipLaunchKernelGGL(render_bwd_wave, dim3(groups * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list,
                            splats, final_T, n_contrib, dL_dpix, dL_dinvdepth, splat_grads);
+    } else if (variant == 2) {
+        hipLaunchKernelGGL(render_bwd_tile<128>, dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats,
+                           final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads));
     } else {
-        hipLaunchKernelGGL(render_bwd_tile, dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats, final_T,
-                           n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads));
+        hipLaunchKernelGGL(render_bwd_tile<256>, dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats,
+                           final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads));
     }
 }
 

@@ -165,21 +165,33 @@ __device__ __forceinline__ void blend_step_bf(PixAcc& s, bool& done, float pxf, 
     done = done | term;
 }
 
-template <bool USE_LDS>
-__global__ void __launch_bounds__(64)
+// WPB = waves per workgroup: 1 -> one 64-thread workgroup per 8x8 block (workgroup ids arranged so that the four blocks
+// of a tile land on one XCD); 4 -> one 256-thread workgroup per tile whose four waves run independently (no barriers),
+// which lifts the resident-wave count when the per-CU workgroup limit, not registers/LDS, caps occupancy.
+template <bool USE_LDS, int WPB>
+__global__ void __launch_bounds__(64 * WPB)
 render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ranges,
                    const uint32_t* __restrict__ point_list, const float4* __restrict__ splats,
                    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
                    float* __restrict__ out_invdepth) {
-    __shared__ float4 s_rec[USE_LDS ? 64 * 3 : 1];
-    const int b = blockIdx.x;
-    const int grp = b >> 5, r32 = b & 31;
-    const int tile_local = grp * 8 + (r32 & 7);
-    const int quad = r32 >> 3;
+    __shared__ float4 s_rec_all[USE_LDS ? WPB * 64 * 3 : 1];
+    float4* s_rec = s_rec_all + (USE_LDS ? (threadIdx.x >> 6) * 64 * 3 : 0);
+    int tile_local, quad;
+    if (WPB == 1) {
+        // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed).  The four 8x8 blocks of a tile share one splat
+        // list, so they get ids b, b+8, b+16, b+24 -> same XCD -> same L2.
+        const int b = blockIdx.x;
+        const int grp = b >> 5, r32 = b & 31;
+        tile_local = grp * 8 + (r32 & 7);
+        quad = r32 >> 3;
+    } else {
+        tile_local = blockIdx.x;
+        quad = threadIdx.x >> 6;
+    }
     if (tile_local >= n_band_tiles) return;
     const int tile = cam.tile_y0 * cam.gx + tile_local;
     const int tx = tile % cam.gx, ty = tile / cam.gx;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int bx0 = tx * GSR_TILE + (quad & 1) * 8, by0 = ty * GSR_TILE + (quad >> 1) * 8;
     if (bx0 >= cam.W || by0 >= cam.H) return;
     const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
@@ -259,10 +271,13 @@ void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const 
     } else {
         const int groups = (n_band_tiles + 7) / 8;
         if (variant == 2)
-            hipLaunchKernelGGL(render_fwd_wave_bf<false>, dim3(groups * 32), dim3(64), 0, st, cam, n_band_tiles, ranges,
+            hipLaunchKernelGGL((render_fwd_wave_bf<false, 1>), dim3(groups * 32), dim3(64), 0, st, cam, n_band_tiles, ranges,
+                               point_list, splats, final_T, n_contrib, out_color, out_invdepth);
+        else if (variant == 3)
+            hipLaunchKernelGGL((render_fwd_wave_bf<true, 4>), dim3(n_band_tiles), dim3(256), 0, st, cam, n_band_tiles, ranges,
                                point_list, splats, final_T, n_contrib, out_color, out_invdepth);
         else
-            hipLaunchKernelGGL(render_fwd_wave_bf<true>, dim3(groups * 32), dim3(64), 0, st, cam, n_band_tiles, ranges,
+            hipLaunchKernelGGL((render_fwd_wave_bf<true, 1>), dim3(groups * 32), dim3(64), 0, st, cam, n_band_tiles, ranges,
                                point_list, splats, final_T, n_contrib, out_color, out_invdepth);
     }
 }

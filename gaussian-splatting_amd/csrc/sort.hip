@@ -3,16 +3,18 @@
 //
 // How it is used (binning design): instead of one 64-bit (tile|depth) sort over all R
 // instances (6+ eight-bit passes over 12-byte pairs), the P Gaussians are sorted by 32-bit depth once
-// (4 passes over P pairs), instances are emitted in depth order, and the R instances are then sorted
-// STABLY by tile id only (2 passes for <= 65536 tiles).  Stability makes the final order identical to
-// the reference's (tile, depth, emission order).
+// (4 passes of 8 bits over P pairs; 3 x 11 bits is implemented but measured slower), instances are emitted in depth
+// order, and the R instances are then sorted STABLY by tile id only (2 passes of ceil(bits/2) bits for <= 65536 tiles).  Stability makes the
+// final order identical to the reference's (tile, depth, emission order).
 //
-// One pass = three launches:
-//   rs_hist    : per-workgroup 256-bin digit histogram                  (reads keys)
+// One pass = three launches (a chained-scan "onesweep" pass was rejected: a cross-workgroup hop costs
+// 1-3 us under load on this part, MI355X_MICROARCH.md handoff rows, and the look-back chain is serial):
+//   rs_hist    : per-workgroup digit histogram                          (reads keys)
 //   rs_scan    : one workgroup per digit scans its row over workgroups  (tiny)
-//   rs_scatter : wave64 ballot-match ranking, stable, direct scatter    (reads keys+vals, writes both)
+//   rs_scatter : wave64 ballot-match ranking, stable; items are re-ordered in LDS first so that every
+//                digit's run leaves the CU as one contiguous store burst (reads keys+vals, writes both)
 // Ranking idiom: each wave owns a contiguous run of the workgroup's items and walks it 64 at a time; the
-// 64-bit match mask of a lane's digit comes from 8 ballots; rank = running per-wave digit count (LDS) +
+// 64-bit match mask of a lane's digit comes from BITS ballots; rank = running per-wave digit count (LDS) +
 // popcount(mask & lanes_below); the lowest matching lane bumps the count.  No atomics, deterministic.
 #include "gsr_internal.h"
 
@@ -21,28 +23,42 @@ namespace {
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / 64;
 
-template <int IPT>
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+template <int IPT, int BITS>
 __global__ void __launch_bounds__(RS_THREADS)
 rs_hist(const uint32_t* __restrict__ keys, int64_t n, int shift, uint32_t* __restrict__ block_hist, int nblocks) {
-    __shared__ uint32_t h[RS_WAVES][256];
+    constexpr int NB = 1 << BITS;
+    constexpr int NCOPY = (NB <= 256) ? RS_WAVES : 1;     // per-wave copies only when they are cheap
+    __shared__ uint32_t h[NCOPY][NB];
     const int tid = threadIdx.x, w = tid >> 6;
+    for (int d = tid; d < NB; d += RS_THREADS)
 #pragma unroll
-    for (int i = 0; i < RS_WAVES; ++i) h[i][tid] = 0;
+        for (int i = 0; i < NCOPY; ++i) h[i][d] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * (RS_THREADS * IPT);
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
         const int64_t idx = base + i * RS_THREADS + tid;
-        if (idx < n) atomicAdd(&h[w][(keys[idx] >> shift) & 255u], 1u);
+        if (idx < n) atomicAdd(&h[NCOPY == 1 ? 0 : w][(keys[idx] >> shift) & (NB - 1)], 1u);
     }
     __syncthreads();
-    uint32_t s = 0;
+    for (int d = tid; d < NB; d += RS_THREADS) {
+        uint32_t s = 0;
 #pragma unroll
-    for (int i = 0; i < RS_WAVES; ++i) s += h[i][tid];
-    block_hist[(int64_t)tid * nblocks + blockIdx.x] = s;
+        for (int i = 0; i < NCOPY; ++i) s += h[i][d];
+        block_hist[(int64_t)d * nblocks + blockIdx.x] = s;
+    }
 }
 
-// grid = 256 (one workgroup per digit).  In place: row[b] <- sum_{b' < b} row[b'];  digit_total[d] = row sum.
+// grid = number of digits (one workgroup per digit).  In place: row[b] <- sum_{b' < b} row[b'];  digit_total[d] = row sum.
 __global__ void __launch_bounds__(RS_THREADS)
 rs_scan(uint32_t* __restrict__ block_hist, int nblocks, uint32_t* __restrict__ digit_total) {
     __shared__ uint32_t wsum[RS_WAVES];
@@ -54,12 +70,7 @@ rs_scan(uint32_t* __restrict__ block_hist, int nblocks, uint32_t* __restrict__ d
     for (int base = 0; base < nblocks; base += RS_THREADS) {
         const int i = base + tid;
         const uint32_t v = i < nblocks ? row[i] : 0u;
-        uint32_t incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
+        const uint32_t incl = wave_incl_scan_u32(v, lane);
         if (lane == 63) wsum[w] = incl;
         __syncthreads();
         uint32_t wbase = 0;
@@ -75,13 +86,33 @@ rs_scan(uint32_t* __restrict__ block_hist, int nblocks, uint32_t* __restrict__ d
     if (tid == 0) digit_total[blockIdx.x] = carry_s;
 }
 
-template <int IPT>
+// Exclusive scan of NB values held DPT per thread (thread t owns digits t*DPT .. t*DPT+DPT-1); returns the exclusive
+// prefix of the thread's first digit.  wsum is a 4-entry LDS scratch; contains two barriers.
+template <int DPT>
+__device__ __forceinline__ uint32_t block_excl_scan(const uint32_t (&v)[DPT], uint32_t* wsum, int lane, int w) {
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) tsum += v[i];
+    const uint32_t incl = wave_incl_scan_u32(tsum, lane);
+    __syncthreads();
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+#pragma unroll
+    for (int k = 0; k < RS_WAVES; ++k)
+        if (k < w) wbase += wsum[k];
+    return wbase + incl - tsum;
+}
+
+template <int IPT, int BITS>
 __global__ void __launch_bounds__(RS_THREADS)
 rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
            uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int shift,
            const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_total, int nblocks) {
-    __shared__ uint32_t wave_cnt[RS_WAVES][256];
-    __shared__ uint32_t digit_base[256];
+    constexpr int NB = 1 << BITS;
+    constexpr int DPT = (NB + RS_THREADS - 1) / RS_THREADS;   // digits per thread (1 for <= 256 bins, 8 for 2048)
+    __shared__ uint32_t wave_cnt[RS_WAVES][NB];
+    __shared__ uint32_t digit_base[NB];
     __shared__ uint32_t wsum[RS_WAVES];
     __shared__ uint32_t s_key[RS_THREADS * IPT];
     __shared__ uint32_t s_val[RS_THREADS * IPT];
@@ -89,22 +120,23 @@ rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
 
     // digit_base[d] = (exclusive scan of digit totals)[d] + (keys with digit d in earlier workgroups)
     {
-        const uint32_t v = digit_total[tid];
-        uint32_t incl = v;
+        uint32_t v[DPT];
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
+        for (int i = 0; i < DPT; ++i) {
+            const int d = tid * DPT + i;
+            v[i] = d < NB ? digit_total[d] : 0u;
         }
-        if (lane == 63) wsum[w] = incl;
+        uint32_t run = block_excl_scan<DPT>(v, wsum, lane, w);
 #pragma unroll
-        for (int i = 0; i < RS_WAVES; ++i) wave_cnt[i][tid] = 0;
-        __syncthreads();
-        uint32_t wbase = 0;
+        for (int i = 0; i < DPT; ++i) {
+            const int d = tid * DPT + i;
+            if (d < NB) {
+                digit_base[d] = run + block_hist[(int64_t)d * nblocks + blockIdx.x];
 #pragma unroll
-        for (int k = 0; k < RS_WAVES; ++k)
-            if (k < w) wbase += wsum[k];
-        digit_base[tid] = wbase + incl - v + block_hist[(int64_t)tid * nblocks + blockIdx.x];
+                for (int k = 0; k < RS_WAVES; ++k) wave_cnt[k][d] = 0;
+            }
+            run += v[i];
+        }
     }
     __syncthreads();
 
@@ -122,10 +154,10 @@ rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
     for (int r = 0; r < IPT; ++r) {
         const int64_t idx = wave_base + r * 64 + lane;
         const bool valid = idx < n;
-        const uint32_t d = (key[r] >> shift) & 255u;
+        const uint32_t d = (key[r] >> shift) & (NB - 1);
         uint64_t mask = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < BITS; ++b) {
             const bool bit = (d >> b) & 1u;
             const uint64_t bal = __ballot(bit);
             mask &= bit ? bal : ~bal;
@@ -137,42 +169,44 @@ rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
     }
     __syncthreads();
     // Local (in-workgroup) sorted position of every item: exclusive prefix over digits of the workgroup's digit
-    // counts, then over waves within a digit.  Items are first scattered into LDS in that order and then written
-    // out by consecutive threads, so every digit's run leaves the CU as one contiguous, coalesced store burst
-    // instead of 4-byte stores scattered over 256 destinations (measured 104 us -> see profiles/ for this pass).
+    // counts, then over waves within a digit.  Items are scattered into LDS in that order and then written out by
+    // consecutive threads, so every digit's run leaves the CU as one contiguous, coalesced store burst instead of
+    // 4-byte stores scattered over all destinations (measured 104 us -> 55 us per pass on 11.3 M pairs).
     {
-        uint32_t tot = 0;
+        uint32_t tot[DPT];
 #pragma unroll
-        for (int k = 0; k < RS_WAVES; ++k) tot += wave_cnt[k][tid];
-        uint32_t incl = tot;
+        for (int i = 0; i < DPT; ++i) {
+            const int d = tid * DPT + i;
+            uint32_t t = 0;
+            if (d < NB) {
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
+                for (int k = 0; k < RS_WAVES; ++k) t += wave_cnt[k][d];
+            }
+            tot[i] = t;
         }
-        __syncthreads();                 // wsum is re-used (its first use finished before the previous barrier)
-        if (lane == 63) wsum[w] = incl;
-        __syncthreads();
-        uint32_t wbase = 0;
+        uint32_t lbase = block_excl_scan<DPT>(tot, wsum, lane, w);
 #pragma unroll
-        for (int k = 0; k < RS_WAVES; ++k)
-            if (k < w) wbase += wsum[k];
-        const uint32_t lbase = wbase + incl - tot;      // first local slot of digit `tid`
-        uint32_t run = lbase;
+        for (int i = 0; i < DPT; ++i) {
+            const int d = tid * DPT + i;
+            if (d < NB) {
+                uint32_t run = lbase;
 #pragma unroll
-        for (int k = 0; k < RS_WAVES; ++k) {
-            const uint32_t t = wave_cnt[k][tid];
-            wave_cnt[k][tid] = run;
-            run += t;
+                for (int k = 0; k < RS_WAVES; ++k) {
+                    const uint32_t t = wave_cnt[k][d];
+                    wave_cnt[k][d] = run;
+                    run += t;
+                }
+                digit_base[d] -= lbase;                  // global position = digit_base[d] + local slot
+            }
+            lbase += tot[i];
         }
-        digit_base[tid] -= lbase;                       // global position = digit_base[d] + local slot
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < IPT; ++r) {
         const int64_t idx = wave_base + r * 64 + lane;
         if (idx < n) {
-            const uint32_t d = (key[r] >> shift) & 255u;
+            const uint32_t d = (key[r] >> shift) & (NB - 1);
             const uint32_t lp = wave_cnt[w][d] + rank[r];
             s_key[lp] = key[r];
             s_val[lp] = val[r];
@@ -186,36 +220,69 @@ rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
         const uint32_t i = (uint32_t)r * RS_THREADS + tid;
         if (i < nvalid) {
             const uint32_t k = s_key[i];
-            const uint32_t pos = digit_base[(k >> shift) & 255u] + i;
+            const uint32_t pos = digit_base[(k >> shift) & (NB - 1)] + i;
             keys_out[pos] = k;
             vals_out[pos] = s_val[i];
         }
     }
 }
 
-template <int IPT>
+template <int IPT, int BITS>
 void sort_pass(uint32_t* kin, uint32_t* vin, uint32_t* kout, uint32_t* vout, int64_t n, int shift, uint32_t* hist,
                uint32_t* digit_total, int nblocks, hipStream_t st) {
-    hipLaunchKernelGGL(rs_hist<IPT>, dim3(nblocks), dim3(RS_THREADS), 0, st, kin, n, shift, hist, nblocks);
-    hipLaunchKernelGGL(rs_scan, dim3(256), dim3(RS_THREADS), 0, st, hist, nblocks, digit_total);
-    hipLaunchKernelGGL(rs_scatter<IPT>, dim3(nblocks), dim3(RS_THREADS), 0, st, kin, vin, kout, vout, n, shift, hist,
+    hipLaunchKernelGGL((rs_hist<IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, n, shift, hist, nblocks);
+    hipLaunchKernelGGL(rs_scan, dim3(1 << BITS), dim3(RS_THREADS), 0, st, hist, nblocks, digit_total);
+    hipLaunchKernelGGL((rs_scatter<IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, vin, kout, vout, n, shift, hist,
                        digit_total, nblocks);
+}
+
+template <int IPT>
+void sort_pass_bits(int bits, uint32_t* kin, uint32_t* vin, uint32_t* kout, uint32_t* vout, int64_t n, int shift,
+                    uint32_t* hist, uint32_t* digit_total, int nblocks, hipStream_t st) {
+    switch (bits) {
+        case 11: sort_pass<IPT, 11>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
+        case 8: sort_pass<IPT, 8>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
+        case 7: sort_pass<IPT, 7>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
+        case 6: sort_pass<IPT, 6>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
+        case 5: sort_pass<IPT, 5>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
+        default: sort_pass<IPT, 4>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
+    }
 }
 
 }  // namespace
 
-int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, uint32_t* hist,
+int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits) {
+    // number of passes and bits per pass: ceil(nbits / max) passes of (almost) equal width, each in {4..8, 11}
+    int passes = (nbits + max_digit_bits - 1) / max_digit_bits;
+    if (passes < 1) passes = 1;
+    int left = nbits;
+    for (int i = 0; i < passes; ++i) {
+        int b = (left + (passes - i) - 1) / (passes - i);
+        if (b > 8 && b < 11) b = 11;
+        if (b < 4) b = 4;
+        pass_bits[i] = b;
+        left -= b;
+        if (left < 0) left = 0;
+    }
+    return passes;
+}
+
+int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
                          uint32_t* digit_total, bool small_blocks, hipStream_t st) {
     int cur = 0;
     if (n <= 0) return cur;
     const int nblocks = (int)gsr_sort_blocks(n, small_blocks);
-    for (int shift = 0; shift < nbits; shift += 8) {
+    int pass_bits[8];
+    const int passes = gsr_sort_plan(nbits, max_digit_bits, pass_bits);
+    int shift = 0;
+    for (int p = 0; p < passes; ++p) {
         if (small_blocks)
-            sort_pass<GSR_SORT_ITEMS_SMALL / RS_THREADS>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
-                                                         digit_total, nblocks, st);
+            sort_pass_bits<GSR_SORT_ITEMS_SMALL / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n,
+                                                              shift, hist, digit_total, nblocks, st);
         else
-            sort_pass<GSR_SORT_ITEMS / RS_THREADS>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
-                                                   digit_total, nblocks, st);
+            sort_pass_bits<GSR_SORT_ITEMS / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift,
+                                                        hist, digit_total, nblocks, st);
+        shift += pass_bits[p];
         cur ^= 1;
     }
     return cur;

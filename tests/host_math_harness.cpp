@@ -81,10 +81,8 @@ void host_preprocess_backward(const HostCam* hc, int P, const float* means, cons
             dm2y = g.dpy * (0.5f * (float)cam.H);
             if (!cov_pre) gsr_cov3d_backward(scales + 3 * i, cam.scale_modifier, rots + 4 * i, dcov, dscale, drot);
             if (shs) {
-                float dshl[48];
-                gsr_sh_backward(cam.sh_degree, cam.M < 16 ? cam.M : 16, shs + (size_t)i * cam.M * 3, means + 3 * i,
-                                cam.campos, clamped[i], drgb, dshl, dmean);
-                memcpy(dsh + (size_t)i * cam.M * 3, dshl, sizeof(float) * cam.M * 3);
+                gsr_sh_backward(cam.sh_degree, cam.M, shs + (size_t)i * cam.M * 3, means + 3 * i, cam.campos, clamped[i], drgb,
+                                dsh + (size_t)i * cam.M * 3, dmean);
             }
         }
         dmeans2D[3 * i] = dm2x; dmeans2D[3 * i + 1] = dm2y; dmeans2D[3 * i + 2] = 0;

@@ -139,6 +139,39 @@ def test_forward_tile_band():
     check_forward(s, col, radii, invd, aux, out, band=band)
 
 
+def test_tile_bands_tile_the_frame_forward_and_backward():
+    """What every rank of a screen-sharded run computes (HIP path, tile_rows extension): the bands' strips tile the
+    full image bit-exactly and the bands' gradients sum to the full-frame gradients (the all-reduce of parallel.py)."""
+    from diff_gaussian_rasterization import rasterize_gaussians
+    dev = torch.device("cuda:0")
+    cam = make_camera(400, 300)
+    sc = make_edge_scene(6000, cam, seed=41).to(dev)
+    s = oracle_settings(cam, bg=torch.tensor([0.3, 0.2, 0.1]))
+    rs = gpu_settings(s, dev)
+    H, W = 300, 400
+    wc = torch.randn(3, H, W, generator=torch.Generator().manual_seed(3)).to(dev)
+    wd = torch.randn(1, H, W, generator=torch.Generator().manual_seed(4)).to(dev)
+
+    def run(band):
+        L = [t.detach().clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+        m2 = torch.zeros(sc.P, 3, device=dev, requires_grad=True)
+        col, radii, invd = rasterize_gaussians(L[0], m2, L[1], None, L[2], L[3], L[4], None, rs, band)
+        rows = slice(0, H) if band is None else slice(band[0] * 16, min(band[1] * 16, H))
+        ((col[:, rows] * wc[:, rows]).sum() + (invd[:, rows] * wd[:, rows]).sum()).backward()
+        torch.cuda.synchronize()
+        return col.detach(), radii, [t.grad for t in L] + [m2.grad]
+
+    full_col, full_radii, full_g = run(None)
+    bands = [(0, 5), (5, 6), (6, 14), (14, 19)]
+    parts = [run(b) for b in bands]
+    assert torch.equal(sum(p[0] for p in parts), full_col)
+    for p in parts:
+        assert torch.equal(p[1], full_radii)
+    for i, fg in enumerate(full_g):
+        tot = sum(p[2][i] for p in parts)
+        assert (tot - fg).abs().max().item() <= 3e-5 * fg.abs().max().item()
+
+
 def _loss_weights(H, W, seed):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g) * 0.3
