@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--variant", type=int, default=0, help="render_fwd_variant (0 wave + LDS broadcast, 1 workgroup-per-tile baseline, 2 wave + readlane)")
     ap.add_argument("--train-steps", type=int, default=-1, help="-1: same as --steps; 0 disables the train leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tiles", type=int, default=48, help="tiles blended by the CPU baseline sample")
+    ap.add_argument("--cpu-tiles", type=int, default=1200, help="tiles blended by the CPU baseline sample")
     ap.add_argument("--uniform-bands", action="store_true")
     return ap.parse_args()
 
@@ -109,7 +109,7 @@ def main():
         v0 = forward_with_views(rs, sc.means3D, sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
         V = int((v0["radii"] > 0).sum())
         R = int(v0["R"])
-        row_cost = row_costs_from_ranges(v0["ranges"].long(), gx, gy)
+        row_cost = row_costs_from_ranges(v0["ranges"].long(), gx, gy, banded=False)   # full frame on every rank
         del v0
     plan = BandPlan.uniform(gy, world) if (a.uniform_bands or world == 1) else BandPlan.balanced(row_cost, world)
     band = None if world == 1 else plan.band(rank)
@@ -154,54 +154,55 @@ def main():
     _lib.profile_enable(False)
     stage_ms = {k: (v["ms"] / max(1, v["launches"])) for k, v in stages.items() if v["launches"]}
 
-    # ---- train leg: fwd + L1 + bwd + Adam (all parameters) ----
-    train_ips = None
-    train_ms = None
+    # ---- train leg: fwd + L1 + bwd + Adam (all parameters), once with the fused HIP Adam and once with torch.optim.Adam ----
+    train = {}
     tsteps = a.steps if a.train_steps < 0 else a.train_steps
     if tsteps > 0:
-        params = [t.detach().clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
-        opt = torch.optim.Adam(params, lr=1e-5, eps=1e-15)
+        from diff_gaussian_rasterization.parallel import render_sharded, hip_band_renderer
+        from gsr_optim import FusedAdam
+        band_renderer = hip_band_renderer(rs)
         gt = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
-        from diff_gaussian_rasterization.parallel import render_sharded
+        for opt_name in ("fused", "torch"):
+            params = [t.detach().clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+            opt = (FusedAdam if opt_name == "fused" else torch.optim.Adam)(params, lr=1e-5, eps=1e-15)
 
-        def hip_band(inp, tile_rows):
-            m, sh, o, s_, r_ = inp
-            return rasterize_gaussians(m, None, sh, None, o, s_, r_, None, rs, tile_rows if world > 1 else None)
+            def train_step():
+                opt.zero_grad(set_to_none=True)
+                m, sh, o, s_, r_ = params
+                if world > 1:
+                    # own band -> strips all-gathered; backward: 48-byte per-Gaussian records all-reduced (parallel.py)
+                    color, radii, invd = render_sharded(band_renderer, params, plan, reduce="records")
+                else:
+                    color, radii, invd = rasterize_gaussians(m, None, sh, None, o, s_, r_, None, rs, None)
+                loss = (color - gt).abs().mean()
+                loss.backward()
+                opt.step()
 
-        def train_step():
-            opt.zero_grad(set_to_none=True)
-            m, sh, o, s_, r_ = params
+            for _ in range(max(2, a.warmup // 2)):
+                train_step()
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(tsteps):
+                train_step()
+            sync_all()
+            tdt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
             if world > 1:
-                color, radii, invd = render_sharded(hip_band, params, plan)
-            else:
-                color, radii, invd = hip_band(params, None)
-            loss = (color - gt).abs().mean()
-            loss.backward()
-            opt.step()
-
-        for _ in range(max(2, a.warmup // 2)):
-            train_step()
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(tsteps):
-            train_step()
-        sync_all()
-        tdt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-        train_ms = float(tdt.item()) / tsteps * 1e3
-        train_ips = 1e3 / train_ms
-        _lib.profile_reset()
-        _lib.profile_enable(True)
-        for _ in range(min(10, tsteps)):
-            train_step()
-        torch.cuda.synchronize()
-        tstages = _lib.profile_read()
-        _lib.profile_enable(False)
-        for k in ("render_bwd", "gather_bwd", "preprocess_bwd"):
-            if tstages[k]["launches"]:
-                stage_ms[k] = tstages[k]["ms"] / tstages[k]["launches"]
-        del params, opt
+                dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+            train[opt_name] = float(tdt.item()) / tsteps * 1e3
+            if opt_name == "fused":
+                _lib.profile_reset()
+                _lib.profile_enable(True)
+                for _ in range(min(10, tsteps)):
+                    train_step()
+                torch.cuda.synchronize()
+                tstages = _lib.profile_read()
+                _lib.profile_enable(False)
+                for k in ("render_bwd", "gather_bwd", "preprocess_bwd"):
+                    if tstages[k]["launches"]:
+                        stage_ms[k] = tstages[k]["ms"] / tstages[k]["launches"]
+            del params, opt
+    train_ms = train.get("fused")
+    train_ips = None if train_ms is None else 1e3 / train_ms
 
     # ---- CPU baseline (rank 0, N=1 only): pure-PyTorch oracle on a bounded sample of the same frame ----
     cpu_baseline = None
@@ -248,11 +249,10 @@ def main():
                     "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                     "traffic": None, "kernel_ms": round(render_ms, 4),
                     "algorithmic_bytes_per_launch": int(blend_bytes),
-                    "note": "blend is fp32-VALU/exp bound (SURVEY 8(d)); listed pair evaluations (256*R) per second and "
-                            "the equivalent 25-FLOP/pair rate vs the 157.3 TF vector peak are given alongside",
+                    "note": "blend is fp32-VALU/exp bound, not HBM bound (SURVEY 8(d)); listed (pixel,Gaussian) pairs = 256*R per "
+                            "launch; most are never evaluated (early termination + exact box culling, DESIGN.md 3.3)",
                     "listed_pairs_per_s": round(pairs / (render_ms * 1e-3), 1),
-                    "valu_equiv_tflops": round(pairs * 25 / (render_ms * 1e-3) / 1e12, 3),
-                    "valu_frac": round(pairs * 25 / (render_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TF, 4)}
+                                        }
         whole = ab["total"] / (ms_per_step * 1e-3) / 1e9
         out = {
             "metric": "Mpix/s forward (1 M Gaussians @1080p); train iters/s alongside",
@@ -267,7 +267,8 @@ def main():
                        "render_fwd_variant": a.variant},
             "train_iters_per_s": None if train_ips is None else round(train_ips, 3),
             "train_ms_per_iter": None if train_ms is None else round(train_ms, 4),
-            "train_step": "forward + L1 loss + backward + torch Adam over all 59 floats/Gaussian",
+            "train_step": "forward + L1 loss + backward + Adam over all 59 floats/Gaussian (fused HIP Adam, gsr_optim.FusedAdam)",
+            "train_iters_per_s_torch_adam": None if "torch" not in train else round(1e3 / train["torch"], 3),
             "whole_forward": {"algorithmic_bytes": int(ab["total"]), "achieved_GBs": round(whole, 2),
                               "frac_of_8TBs": round(whole / HBM_PEAK_GBS, 5),
                               "roofline_predicted_Mpix_s": round(npix / (ab["total"] / (HBM_PEAK_GBS * 1e9)) / 1e6, 1)},

@@ -32,6 +32,7 @@ UNITS = [
     ("binning.hip", []),
     ("render_fwd.hip", ["-ffp-contract=fast"]),
     ("render_bwd.hip", ["-ffp-contract=fast"]),
+    ("adam.hip", ["-ffp-contract=off"]),
     ("gsr_api.cpp", ["-x", "hip"]),
 ]
 

@@ -1,0 +1,67 @@
+// Fused dense Adam step -- first "next row" beyond the rasterizer: the optimizer step that follows
+// loss.backward() in every training iteration (train.py:177-186, torch.optim.Adam groups built at
+// scene/gaussian_model.py:178-211, eps 1e-15).  torch's foreach Adam issues several multi-tensor kernels and measured
+// 0.94 ms per step on the 59 floats x 1 M Gaussians of the bench scene; one fused pass reads p, g, m, v and writes p, m, v
+// once (28 B per parameter = 1.65 GB -> HBM-bound).  Arithmetic follows torch.optim.Adam (no weight decay, no amsgrad):
+//   m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g g;  p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+#include "gsr_internal.h"
+
+namespace {
+
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float om_b1, float b2, float om_b2, float step_size,
+                                      float inv_bc2_sqrt, float eps) {
+    m = m + (g - m) * om_b1;
+    v = v * b2 + om_b2 * g * g;
+    const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+    p = p - step_size * (m / denom);
+}
+
+__global__ void __launch_bounds__(256)
+adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+            float om_b1, float b2, float om_b2, float step_size, float inv_bc2_sqrt, float eps, int vec) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        float4* p4 = reinterpret_cast<float4*>(p);
+        const float4* g4 = reinterpret_cast<const float4*>(g);
+        float4* m4 = reinterpret_cast<float4*>(m);
+        float4* v4 = reinterpret_cast<float4*>(v);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            float4 pp = p4[i], mm = m4[i], vv = v4[i];
+            const float4 gg = g4[i];
+            adam1(pp.x, gg.x, mm.x, vv.x, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
+            adam1(pp.y, gg.y, mm.y, vv.y, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
+            adam1(pp.z, gg.z, mm.z, vv.z, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
+            adam1(pp.w, gg.w, mm.w, vv.w, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
+            p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        }
+        for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            float pp = p[i], mm = m[i], vv = v[i];
+            adam1(pp, g[i], mm, vv, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
+            p[i] = pp; m[i] = mm; v[i] = vv;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            float pp = p[i], mm = m[i], vv = v[i];
+            adam1(pp, g[i], mm, vv, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
+            p[i] = pp; m[i] = mm; v[i] = vv;
+        }
+    }
+}
+
+}  // namespace
+
+void gsr_launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                     int step, hipStream_t st) {
+    if (n <= 0) return;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    const int vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) ? 1 : 0;
+    int64_t work = vec ? (n + 3) / 4 : n;
+    int64_t nb = (work + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((int)nb), dim3(256), 0, st, p, g, m, v, n, 1.0f - beta1, beta2, 1.0f - beta2,
+                       step_size, inv_bc2_sqrt, eps, vec);
+}

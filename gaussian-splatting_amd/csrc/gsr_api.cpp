@@ -364,26 +364,17 @@ static int depth_order_buffer_index() {
     return gsr_sort_plan(32, g_depth_digit_bits, pb) & 1;
 }
 
-int gsr_rasterize_backward(const GsrRasterSettings* settings, int P, int M, int32_t num_rendered, const float* means3D,
-                           const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
-                           const float* rotations, const float* cov3D_precomp, const int32_t* radii,
-                           const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
-                           const float* dL_dout_color, const float* dL_dout_invdepth, float* dL_dmeans2D,
-                           float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
-                           float* dL_dscales, float* dL_drotations, void* bwd_scratch, float** splat_grads_out, void* stream) {
+int gsr_backward_blend(const GsrRasterSettings* settings, int P, int32_t num_rendered, const void* geom_buffer,
+                       const void* binning_buffer, const void* image_buffer, const float* dL_dout_color,
+                       const float* dL_dout_invdepth, void* bwd_scratch, float** splat_grads_out, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     GsrCamDev cam;
-    int rc = make_cam(settings, M, cam);
+    int rc = make_cam(settings, 0, cam);
     if (rc != GSR_OK) return rc;
-    rc = check_inputs(P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, cam.sh_degree);
-    if (rc != GSR_OK) return rc;
+    if (P < 0) return fail(GSR_ERR_INVALID_ARG, "P < 0");
     if (P == 0) return GSR_OK;
-    if (!radii || !geom_buffer || !binning_buffer || !image_buffer || !dL_dout_color || !bwd_scratch)
-        return fail(GSR_ERR_INVALID_ARG, "radii / state buffers / dL_dout_color / bwd_scratch are NULL");
-    if (!dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D)
-        return fail(GSR_ERR_INVALID_ARG, "gradient outputs are NULL");
-    if (shs && !dL_dsh) return fail(GSR_ERR_INVALID_ARG, "dL_dsh is NULL");
-    if (scales && (!dL_dscales || !dL_drotations)) return fail(GSR_ERR_INVALID_ARG, "dL_dscales / dL_drotations are NULL");
+    if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dout_color || !bwd_scratch)
+        return fail(GSR_ERR_INVALID_ARG, "state buffers / dL_dout_color / bwd_scratch are NULL");
     GsrGeom g = gsr_carve_geom((char*)geom_buffer, P);
     GsrBinning b = gsr_carve_binning((char*)binning_buffer, num_rendered);
     GsrImage im = gsr_carve_image((char*)image_buffer, cam.W, cam.H);
@@ -391,7 +382,6 @@ int gsr_rasterize_backward(const GsrRasterSettings* settings, int P, int M, int3
     GsrBwdScratch w = gsr_carve_bwd((char*)bwd_scratch, P, num_rendered);
     float* sg = w.splat_grads;
     if (splat_grads_out) *splat_grads_out = sg;
-    const int n_tiles = cam.gx * cam.gy;
     {   StageTimer t(GSR_STAGE_RENDER_BWD, st);
         if (g_render_bwd_variant == 1 || num_rendered <= 0) {
             HIP_OK(hipMemsetAsync(sg, 0, (size_t)P * 12 * sizeof(float), st));
@@ -402,23 +392,72 @@ int gsr_rasterize_backward(const GsrRasterSettings* settings, int P, int M, int3
             // records of instances that contributed nowhere are never written by the blend backward: clear them all first
             HIP_OK(hipMemsetAsync(w.inst_grads, 0, (size_t)num_rendered * 12 * sizeof(float), st));
             gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib,
-                                       dL_dout_color, dL_dout_invdepth, nullptr, w.inst_grads, 0, st);
+                                       dL_dout_color, dL_dout_invdepth, nullptr, w.inst_grads, g_render_bwd_variant, st);
         }
     }
     STAGE_CHECK("render backward blend");
     if (g_render_bwd_variant != 1 && num_rendered > 0) {
         StageTimer t(GSR_STAGE_GATHER_BWD, st);
-        const int order_buf = depth_order_buffer_index();
-        gsr_launch_reduce_instances(P, g.vals[order_buf], g.offsets, g.tiles, w.inst_grads, sg, st);
+        gsr_launch_reduce_instances(P, g.vals[depth_order_buffer_index()], g.offsets, g.tiles, w.inst_grads, sg, st);
     }
-    (void)n_tiles;
-    STAGE_CHECK("render backward");
+    STAGE_CHECK("render backward reduce");
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_backward_preprocess(const GsrRasterSettings* settings, int P, int M, const float* means3D, const float* shs,
+                            const float* colors_precomp, const float* opacities, const float* scales,
+                            const float* rotations, const float* cov3D_precomp, const int32_t* radii,
+                            const void* geom_buffer, const float* splat_grads, float* dL_dmeans2D, float* dL_dcolors,
+                            float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
+                            float* dL_drotations, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    GsrCamDev cam;
+    int rc = make_cam(settings, M, cam);
+    if (rc != GSR_OK) return rc;
+    rc = check_inputs(P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, cam.sh_degree);
+    if (rc != GSR_OK) return rc;
+    if (P == 0) return GSR_OK;
+    if (!radii || !geom_buffer || !splat_grads) return fail(GSR_ERR_INVALID_ARG, "radii / geometry buffer / splat_grads are NULL");
+    if (!dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D)
+        return fail(GSR_ERR_INVALID_ARG, "gradient outputs are NULL");
+    if (shs && !dL_dsh) return fail(GSR_ERR_INVALID_ARG, "dL_dsh is NULL");
+    if (scales && (!dL_dscales || !dL_drotations)) return fail(GSR_ERR_INVALID_ARG, "dL_dscales / dL_drotations are NULL");
+    GsrGeom g = gsr_carve_geom((char*)geom_buffer, P);
     {   StageTimer t(GSR_STAGE_PREPROCESS_BWD, st);
         gsr_launch_preprocess_backward(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                       radii, g, sg, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D,
+                                       radii, g, splat_grads, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D,
                                        dL_dsh, scales ? dL_dscales : nullptr, scales ? dL_drotations : nullptr, st);
     }
     STAGE_CHECK("preprocess backward");
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_rasterize_backward(const GsrRasterSettings* settings, int P, int M, int32_t num_rendered, const float* means3D,
+                           const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
+                           const float* rotations, const float* cov3D_precomp, const int32_t* radii,
+                           const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+                           const float* dL_dout_color, const float* dL_dout_invdepth, float* dL_dmeans2D,
+                           float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                           float* dL_dscales, float* dL_drotations, void* bwd_scratch, float** splat_grads_out, void* stream) {
+    if (P == 0) return GSR_OK;
+    float* sg = nullptr;
+    int rc = gsr_backward_blend(settings, P, num_rendered, geom_buffer, binning_buffer, image_buffer, dL_dout_color,
+                                dL_dout_invdepth, bwd_scratch, &sg, stream);
+    if (rc != GSR_OK) return rc;
+    if (splat_grads_out) *splat_grads_out = sg;
+    return gsr_backward_preprocess(settings, P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   radii, geom_buffer, sg, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D,
+                                   dL_dsh, dL_dscales, dL_drotations, stream);
+}
+
+int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int32_t step, void* stream) {
+    if (n < 0 || step < 1) return fail(GSR_ERR_INVALID_ARG, "n < 0 or step < 1");
+    if (n == 0) return GSR_OK;
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
+    gsr_launch_adam(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, (hipStream_t)stream);
     HIP_OK(hipGetLastError());
     return GSR_OK;
 }

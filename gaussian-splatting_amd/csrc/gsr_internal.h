@@ -111,3 +111,7 @@ struct GsrBwdScratch {
     size_t bytes;
 };
 GsrBwdScratch gsr_carve_bwd(char* base, int P, int64_t R);
+
+// adam.hip
+void gsr_launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                     int step, hipStream_t st);

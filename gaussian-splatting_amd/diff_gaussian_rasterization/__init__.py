@@ -103,7 +103,7 @@ def _require_cuda(t: torch.Tensor, name: str):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, tile_rows):
+                raster_settings, tile_rows, grad_sync):
         lib = _lib.load()
         _require_cuda(means3D, "means3D")
         device = means3D.device
@@ -139,6 +139,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _lib.check(lib.gsr_rasterize_forward(*args), "gsr_rasterize_forward")
         ctx.raster_settings = raster_settings
         ctx.tile_rows = tile_rows
+        ctx.grad_sync = grad_sync
         ctx.num_rendered = int(nr.value)
         ctx.M = M
         ctx.op_shape = tuple(opacities.shape)
@@ -179,25 +180,44 @@ class _RasterizeGaussians(torch.autograd.Function):
             keep: list = []
             with torch.cuda.device(device):
                 s = _make_settings(rs, keep, ctx.tile_rows)
-                args = (C.byref(s), P, M, ctx.num_rendered, _ptr(means3D), _ptr(sh) if has_sh else None,
-                        _ptr(col) if has_col else None, _ptr(op), _ptr(sc) if has_sc else None,
-                        _ptr(rot) if has_rot else None, _ptr(cov) if has_cov else None, _ptr(radii),
-                        _ptr(geom), _ptr(binning), _ptr(img), _ptr(g_color), _ptr(g_depth),
-                        _ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
-                        _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drot), _ptr(scratch), None, _stream_ptr(device))
+                st = _stream_ptr(device)
+                inputs = (_ptr(means3D), _ptr(sh) if has_sh else None, _ptr(col) if has_col else None, _ptr(op),
+                          _ptr(sc) if has_sc else None, _ptr(rot) if has_rot else None, _ptr(cov) if has_cov else None,
+                          _ptr(radii))
+                outs = (_ptr(dL_dmeans2D), _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
+                        _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drot))
+
+                def _run():
+                    if ctx.grad_sync is None:
+                        _lib.check(lib.gsr_rasterize_backward(C.byref(s), P, M, ctx.num_rendered, *inputs, _ptr(geom),
+                                                              _ptr(binning), _ptr(img), _ptr(g_color), _ptr(g_depth), *outs,
+                                                              _ptr(scratch), None, st), "gsr_rasterize_backward")
+                        return
+                    # screen-sharded training: blend backward on the own band -> sum the 48-byte per-Gaussian records
+                    # across ranks -> per-Gaussian backward (parallel.py)
+                    rec_ptr = C.c_void_p(0)
+                    _lib.check(lib.gsr_backward_blend(C.byref(s), P, ctx.num_rendered, _ptr(geom), _ptr(binning), _ptr(img),
+                                                      _ptr(g_color), _ptr(g_depth), _ptr(scratch), C.byref(rec_ptr), st),
+                               "gsr_backward_blend")
+                    off = int(rec_ptr.value) - scratch.data_ptr()
+                    records = scratch[off:off + P * 48].view(torch.float32).view(P, 12)
+                    ctx.grad_sync(records)
+                    _lib.check(lib.gsr_backward_preprocess(C.byref(s), P, M, *inputs, _ptr(geom), _ptr(records), *outs, st),
+                               "gsr_backward_preprocess")
+
                 if rs.debug:
                     cpu_args = _cpu_copy((means3D, radii, col, sc, rot, cov, sh, grad_out_color, rs))
                     try:
-                        _lib.check(lib.gsr_rasterize_backward(*args), "gsr_rasterize_backward")
+                        _run()
                     except Exception as ex:
                         torch.save(cpu_args, "snapshot_bw.dump")
                         print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                         raise ex
                 else:
-                    _lib.check(lib.gsr_rasterize_backward(*args), "gsr_rasterize_backward")
+                    _run()
         dL_dopacity = dL_dopacity.view(ctx.op_shape)
         return (dL_dmeans3D, dL_dmeans2D if ctx.has_means2D else None, dL_dsh, dL_dcolors if has_col else None, dL_dopacity, dL_dscales, dL_drot,
-                dL_dcov3D if has_cov else None, None, None)
+                dL_dcov3D if has_cov else None, None, None, None)
 
 
 def _cpu_copy(args):
@@ -205,11 +225,13 @@ def _cpu_copy(args):
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, tile_rows: Optional[Tuple[int, int]] = None):
-    """Functional form.  `tile_rows=(y0, y1)` (extension) restricts binning + blending to that
+                        raster_settings, tile_rows: Optional[Tuple[int, int]] = None, grad_sync=None):
+    """Functional form.  `grad_sync(records[P,12])`, if given, is called between the blend backward and the
+    per-Gaussian backward (multi-GPU: all-reduce of the 48-byte gradient records, parallel.py).
+    `tile_rows=(y0, y1)` (extension) restricts binning + blending to that
     band of 16-pixel tile rows; pixels outside the band come back as zeros."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, tile_rows)
+                                     cov3Ds_precomp, raster_settings, tile_rows, grad_sync)
 
 
 class GaussianRasterizer(nn.Module):

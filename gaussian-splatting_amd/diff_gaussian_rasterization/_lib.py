@@ -42,7 +42,8 @@ RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 EXPORTS = [
     "gsr_abi_version", "gsr_last_error", "gsr_geometry_bytes", "gsr_binning_bytes", "gsr_image_bytes",
     "gsr_backward_scratch_bytes",
-    "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_mark_visible", "gsr_forward_views",
+    "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_backward_blend", "gsr_backward_preprocess",
+    "gsr_mark_visible", "gsr_forward_views", "gsr_adam_step",
     "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_set_option",
 ]
 
@@ -94,6 +95,15 @@ def load() -> C.CDLL:
                                            vp, vp, vp, vp, vp, vp, vp, vp,
                                            vp, vp, vp, vp, vp,
                                            vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_void_p), vp]
+    lib.gsr_backward_blend.restype = C.c_int
+    lib.gsr_backward_blend.argtypes = [C.POINTER(GsrRasterSettings), C.c_int, C.c_int32, vp, vp, vp, vp, vp, vp,
+                                       C.POINTER(C.c_void_p), vp]
+    lib.gsr_backward_preprocess.restype = C.c_int
+    lib.gsr_backward_preprocess.argtypes = [C.POINTER(GsrRasterSettings), C.c_int, C.c_int,
+                                            vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                            vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_adam_step.restype = C.c_int
+    lib.gsr_adam_step.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, vp]
     lib.gsr_mark_visible.restype = C.c_int
     lib.gsr_mark_visible.argtypes = [C.c_int, vp, vp, vp, vp, vp]
     lib.gsr_forward_views.restype = C.c_int

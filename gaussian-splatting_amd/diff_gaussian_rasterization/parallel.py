@@ -5,16 +5,18 @@ has no multi-GPU code).  One process per GPU, torch.distributed (backend "nccl" 
 Partitioning
   * pixel axis: rank g owns a contiguous band of 16-pixel tile ROWS [y0_g, y1_g).  Bands are balanced by the
     per-row instance counts of the previous frame (uniform rows are imbalanced on real scenes), see BandPlan.
-  * Gaussian axis: parameters are replicated for the forward (every rank runs the HBM-streaming preprocess on
-    all P -- it costs less than all-gathering 48-byte splat records over xGMI at these sizes), and the
-    per-Gaussian 2-D gradient record is summed across ranks in the backward.
+  * Gaussian axis: parameters are replicated; every rank runs the HBM-streaming preprocess on all P (SH colours
+    are evaluated only for Gaussians that touch the rank's band) -- cheaper than all-gathering 64-byte splat
+    records over xGMI at these sizes and one collective fewer on the critical path.
 Exchange steps
-  * forward : all_gather of the rendered strips (3*H*W*4 bytes in total, +H*W*4 for the inverse-depth strip);
-  * backward: every rank back-propagates only its own band's dL/dpixel, producing dense partial per-Gaussian
-    gradients; they are combined with all_reduce(sum) (replicated parameters) or reduce_scatter (sharded
-    optimizer state, `owner_shard=True`).
+  * forward : ONE all_gather of the rendered strips (colour + inverse depth stacked: 4*H*W*4 bytes in total);
+  * backward: every rank back-propagates only its own band's dL/dpixel through the blend backward, which yields
+    the dense per-Gaussian 2-D gradient record [P,12] (48 B/Gaussian); the records are summed across ranks with
+    ONE all_reduce and the per-Gaussian backward (59 floats/Gaussian of output) then runs replicated -- 5x less
+    traffic than reducing the parameter gradients themselves.  (`reduce="params"` does the latter; it is what a
+    band renderer without a record hook -- the CPU oracle in the gloo tests -- uses.)
 The band renderer is injected (`render_band`) so the index math and collectives are testable on CPU with gloo;
-the product passes the HIP rasterizer.
+`hip_band_renderer` is the product's renderer.
 """
 from __future__ import annotations
 
@@ -29,7 +31,7 @@ TILE = 16
 
 @dataclass
 class BandPlan:
-    """Contiguous tile-row bands, one per rank."""
+    """Contiguous tile-row bands, one per rank (bands may be empty)."""
     bounds: List[int]            # len = world+1, bounds[g]..bounds[g+1]
 
     @staticmethod
@@ -38,8 +40,7 @@ class BandPlan:
 
     @staticmethod
     def balanced(row_cost: Sequence[float], world: int) -> "BandPlan":
-        """Split rows so that every band carries ~1/world of the total cost (prefix-sum cut points; every band
-        keeps at least one row while rows remain)."""
+        """Split rows so that every band carries ~1/world of the total cost (prefix-sum cut points)."""
         n = len(row_cost)
         total = float(sum(row_cost))
         if total <= 0 or world == 1:
@@ -68,82 +69,98 @@ class BandPlan:
         return min(y0 * TILE, H), min(y1 * TILE, H)
 
 
+def _world(group) -> int:
+    return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
 def gather_strips(local: torch.Tensor, plan: BandPlan, H: int, group=None) -> torch.Tensor:
     """local: [C,H,W] with only this rank's rows valid.  Returns the full [C,H,W] image on every rank.
-    Strips have different heights, so each rank contributes a max-height padded strip to one all_gather."""
-    world = dist.get_world_size(group)
+    Strips have different heights, so each rank contributes a max-height padded strip to ONE all_gather."""
+    world = _world(group)
+    if world == 1:
+        return local
     rank = dist.get_rank(group)
     C, _, W = local.shape
     rows = [plan.pixel_rows(g, H) for g in range(world)]
-    hmax = max(b - a for a, b in rows)
+    hmax = max(1, max(b - a for a, b in rows))
     a, b = rows[rank]
     send = local.new_zeros(C, hmax, W)
     send[:, : b - a] = local[:, a:b]
-    recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send, group=group)
+    recv = local.new_empty(world, C, hmax, W)
+    dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)   # flat: concat semantics on every backend
     full = torch.empty_like(local)
     for g, (ga, gb) in enumerate(rows):
-        full[:, ga:gb] = recv[g][:, : gb - ga]
+        full[:, ga:gb] = recv[g, :, : gb - ga]
     return full
 
 
-class _ShardedRaster(torch.autograd.Function):
-    """forward: render own band + all_gather strips; backward: mask dL/dpixel to the own band, run the band's
-    backward, sum the per-Gaussian gradients across ranks."""
+class _GatherStrips(torch.autograd.Function):
+    """forward: all_gather the strips; backward: keep only the own band's rows of dL/dpixel (the other rows belong
+    to other ranks, which receive the same upstream gradient because the loss is computed replicated)."""
 
     @staticmethod
-    def forward(ctx, render_band, plan, group, n_inputs, *inputs):
-        rank = dist.get_rank(group)
-        y0, y1 = plan.band(rank)
-        detached = [t.detach().requires_grad_(t.requires_grad) if isinstance(t, torch.Tensor) else t for t in inputs]
-        with torch.enable_grad():
-            color, radii, invdepth = render_band(detached, (y0, y1))
-        H = color.shape[1]
-        full_color = gather_strips(color.detach(), plan, H, group)
-        full_inv = gather_strips(invdepth.detach(), plan, H, group)
-        # radii are band-independent (every rank preprocesses all Gaussians)
-        ctx.saved = (detached, color, invdepth)
-        ctx.plan, ctx.group, ctx.H = plan, group, H
-        ctx.mark_non_differentiable(radii)
-        return full_color, radii, full_inv
+    def forward(ctx, local, plan, H, group):
+        ctx.rows = plan.pixel_rows(dist.get_rank(group) if dist.is_initialized() else 0, H)
+        return gather_strips(local, plan, H, group)
 
     @staticmethod
-    def backward(ctx, g_color, _g_radii, g_inv):
-        detached, color, invdepth = ctx.saved
-        rank = dist.get_rank(ctx.group)
-        a, b = ctx.plan.pixel_rows(rank, ctx.H)
-        gc = torch.zeros_like(color)
-        gi = torch.zeros_like(invdepth)
-        gc[:, a:b] = g_color[:, a:b]
-        if g_inv is not None:
-            gi[:, a:b] = g_inv[:, a:b]
-        diff = [t for t in detached if isinstance(t, torch.Tensor) and t.requires_grad]
-        grads = torch.autograd.grad([color, invdepth], diff, [gc, gi], allow_unused=True)
-        out = []
-        it = iter(grads)
-        for t in detached:
+    def backward(ctx, g):
+        a, b = ctx.rows
+        out = torch.zeros_like(g)
+        out[:, a:b] = g[:, a:b]
+        return out, None, None, None
+
+
+def render_sharded(render_band: Callable, inputs: Sequence, plan: BandPlan, group=None, reduce: str = "params"):
+    """render_band(inputs, (y0, y1)) -> (color[3,H,W], radii[P], invdepth[1,H,W]) with only the band's rows valid
+    (zeros elsewhere), differentiable w.r.t. the tensor inputs.  Returns the full image / radii / inverse depth on
+    every rank.  reduce="params": the parameter gradients are summed across ranks by hooks on `inputs`;
+    reduce="records": the band renderer sums its own per-Gaussian records (hip_band_renderer)."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = _world(group)
+    if reduce == "params" and world > 1:
+        def _mk(t):
+            def _hook(g):
+                g = g.contiguous().clone()
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+                return g
+            return _hook
+        hooked = []
+        for t in inputs:
             if isinstance(t, torch.Tensor) and t.requires_grad:
-                g = next(it)
-                if g is None:
-                    g = torch.zeros_like(t)
-                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
-                out.append(g)
+                v = t.view_as(t)          # non-leaf alias so that the hook fires once per backward of this render
+                v.register_hook(_mk(v))
+                hooked.append(v)
             else:
-                out.append(None)
-        return (None, None, None, None, *out)
+                hooked.append(t)
+        inputs = hooked
+    color, radii, invdepth = render_band(inputs, plan.band(rank))
+    H = color.shape[1]
+    both = _GatherStrips.apply(torch.cat([color, invdepth], dim=0), plan, H, group)
+    return both[:3], radii, both[3:4]
 
 
-def render_sharded(render_band: Callable, inputs: Sequence, plan: BandPlan, group=None):
-    """render_band(inputs, (y0, y1)) -> (color[3,H,W], radii[P], invdepth[1,H,W]) with only the band's rows valid.
-    Returns the full image / radii / inverse depth on every rank; differentiable w.r.t. the tensor inputs."""
-    return _ShardedRaster.apply(render_band, plan, group, len(inputs), *inputs)
+def hip_band_renderer(raster_settings, group=None):
+    """The product's band renderer: inputs = (means3D, shs, opacities, scales, rotations); the per-Gaussian 2-D
+    gradient records are all-reduced between the blend backward and the per-Gaussian backward."""
+    from . import rasterize_gaussians
+
+    def _sync(records: torch.Tensor):
+        if _world(group) > 1:
+            dist.all_reduce(records, op=dist.ReduceOp.SUM, group=group)
+
+    def _render(inputs, rows):
+        m, sh, o, s_, r_ = inputs
+        return rasterize_gaussians(m, None, sh, None, o, s_, r_, None, raster_settings, rows, _sync)
+
+    return _render
 
 
-def row_costs_from_ranges(ranges: torch.Tensor, gx: int, gy: int, group=None) -> List[float]:
-    """Per tile-row instance counts for re-balancing.  `ranges` [gx*gy,2] holds valid entries only for this
-    rank's band (zeros elsewhere), so a SUM all_reduce yields the global per-row histogram."""
+def row_costs_from_ranges(ranges: torch.Tensor, gx: int, gy: int, group=None, banded: bool = True) -> List[float]:
+    """Per tile-row instance counts for re-balancing.  With banded=True `ranges` [gx*gy,2] holds valid entries only
+    for this rank's band (zeros elsewhere), so a SUM all_reduce yields the global per-row histogram."""
     cnt = (ranges[:, 1] - ranges[:, 0]).to(torch.float32).view(gy, gx).sum(dim=1)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if banded and _world(group) > 1:
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
     # every row also costs a fixed amount (pixels to write)
     return (cnt + 256.0 * gx * 0.05).tolist()

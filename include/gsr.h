@@ -127,6 +127,34 @@ int gsr_rasterize_backward(const GsrRasterSettings* settings, int P, int M, int3
                            float* dL_dscales, float* dL_drotations, void* bwd_scratch,
                            float** splat_grads_out, void* stream);
 
+/*
+ * The two halves of gsr_rasterize_backward, exposed separately for screen-sharded multi-GPU training (SURVEY.md 8(e),
+ * no reference counterpart): every rank runs gsr_backward_blend on its own band of tiles, the 48-byte per-Gaussian
+ * records ([P,12], pointer returned in *splat_grads_out) are summed across ranks (RCCL all-reduce / reduce-scatter),
+ * and gsr_backward_preprocess turns the summed records into the parameter gradients.
+ * gsr_rasterize_backward == gsr_backward_blend followed by gsr_backward_preprocess on the same record array.
+ */
+int gsr_backward_blend(const GsrRasterSettings* settings, int P, int32_t num_rendered,
+                       const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+                       const float* dL_dout_color, const float* dL_dout_invdepth,
+                       void* bwd_scratch, float** splat_grads_out, void* stream);
+int gsr_backward_preprocess(const GsrRasterSettings* settings, int P, int M,
+                            const float* means3D, const float* shs, const float* colors_precomp,
+                            const float* opacities, const float* scales, const float* rotations,
+                            const float* cov3D_precomp, const int32_t* radii, const void* geom_buffer,
+                            const float* splat_grads,
+                            float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
+                            float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                            float* dL_dscales, float* dL_drotations, void* stream);
+
+/*
+ * Fused dense Adam step on one fp32 tensor of n elements (the optimizer step of train.py:177-186).
+ * Same arithmetic as torch.optim.Adam(betas, eps) without weight decay / amsgrad; `step` is the 1-based step count
+ * AFTER incrementing; state tensors exp_avg / exp_avg_sq are updated in place.
+ */
+int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
+
 /* Replaces _C.mark_visible: present[i] = 1 iff Gaussian i is in front of the 0.2 near plane. */
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);

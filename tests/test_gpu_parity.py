@@ -172,6 +172,43 @@ def test_tile_bands_tile_the_frame_forward_and_backward():
         assert (tot - fg).abs().max().item() <= 3e-5 * fg.abs().max().item()
 
 
+def test_two_phase_backward_with_record_hook():
+    """gsr_backward_blend + hook + gsr_backward_preprocess (the multi-GPU path) == the fused backward; the hook sees
+    the [P,12] record tensor and its edits propagate linearly (what an all-reduce over ranks does)."""
+    from diff_gaussian_rasterization import rasterize_gaussians
+    from diff_gaussian_rasterization.parallel import render_sharded, hip_band_renderer, BandPlan
+    dev = torch.device("cuda:0")
+    cam = make_camera(320, 240)
+    sc = make_scene(8000, cam, seed=23, s_med=0.03).to(dev)
+    s = oracle_settings(cam, bg=torch.tensor([0.2, 0.2, 0.2]))
+    rs = gpu_settings(s, dev)
+    wc = torch.randn(3, 240, 320, generator=torch.Generator().manual_seed(5)).to(dev)
+    seen = {}
+
+    def run(sync):
+        L = [t.detach().clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+        col, _, invd = rasterize_gaussians(L[0], None, L[1], None, L[2], L[3], L[4], None, rs, None, sync)
+        ((col * wc).sum() + invd.sum()).backward()
+        torch.cuda.synchronize()
+        return [t.grad for t in L]
+
+    def double(rec):
+        seen["shape"] = tuple(rec.shape)
+        rec.mul_(2.0)
+
+    fused, ident, twice = run(None), run(lambda rec: None), run(double)
+    assert seen["shape"] == (sc.P, 12)
+    for a, b, c in zip(fused, ident, twice):
+        assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item()
+        assert (c - 2 * a).abs().max().item() <= 2e-5 * a.abs().max().item()
+    # the single-process (world = 1) path of the sharded renderer is the plain renderer
+    L = [t.detach().clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+    col, radii, invd = render_sharded(hip_band_renderer(rs), L, BandPlan.uniform(15, 1), reduce="records")
+    ((col * wc).sum() + invd.sum()).backward()
+    for a, t in zip(fused, L):
+        assert (a - t.grad).abs().max().item() <= 1e-5 * a.abs().max().item()
+
+
 def _loss_weights(H, W, seed):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g) * 0.3
@@ -416,3 +453,35 @@ def test_full_size_invariants_and_determinism():
     out3 = run_gpu(s, sc, variant=1)
     diff = (out3["color"] - out["color"]).abs()
     assert float((diff > 1e-5).float().mean()) < 1e-3
+
+
+def test_fused_adam_matches_torch_adam():
+    """gsr_adam_step == torch.optim.Adam (eps=1e-15, per-group lr as in scene/gaussian_model.py:183-190)."""
+    from gsr_optim import FusedAdam
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    shapes = [(10007, 3), (10007, 16, 3), (10007, 1), (10007, 4), (5,)]
+    lrs = [1.6e-4, 2.5e-3, 0.025, 1e-3, 0.01]
+    a = [torch.randn(s, generator=g).to(dev).requires_grad_(True) for s in shapes]
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    oa = FusedAdam([{"params": [p], "lr": lr} for p, lr in zip(a, lrs)], lr=0.0, eps=1e-15)
+    ob = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(b, lrs)], lr=0.0, eps=1e-15)
+    for it in range(7):
+        for p, q in zip(a, b):
+            gr = torch.randn(p.shape, generator=g).to(dev) * (10.0 ** (it % 3 - 1))
+            if it == 3:
+                gr[::2] = 0          # zero gradients (invisible Gaussians): v stays, denominator ~ eps
+            p.grad = gr.clone()
+            q.grad = gr.clone()
+        if it == 4:
+            oa.param_groups[0]["lr"] = ob.param_groups[0]["lr"] = 8e-5      # update_learning_rate (train.py:91)
+        oa.step()
+        ob.step()
+    torch.cuda.synchronize()
+    for p, q, lr in zip(a, b, lrs):
+        assert (p - q).abs().max().item() <= 2e-6 * max(1.0, lr / 1e-3), (p - q).abs().max().item()
+    for p, q in zip(a, b):
+        sa, sb = oa.state[p], ob.state[q]
+        assert int(sa["step"]) == int(sb["step"])
+        for key in ("exp_avg", "exp_avg_sq"):      # fp32 round-off of different but equivalent update forms (lerp / fma)
+            assert (sa[key] - sb[key]).abs().max().item() <= 2e-6 * sb[key].abs().max().item()
