@@ -51,17 +51,18 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
 
 }  // namespace
 
-void gsr_launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+void gsr_launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
                      int step, hipStream_t st) {
     if (n <= 0) return;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
+    // hyper-parameters stay in double until the last moment, like torch: 1 - 0.999f would already be off by 1.3e-5 relative
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1);
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     const int vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) ? 1 : 0;
     int64_t work = vec ? (n + 3) / 4 : n;
     int64_t nb = (work + 255) / 256;
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(adam_kernel, dim3((int)nb), dim3(256), 0, st, p, g, m, v, n, 1.0f - beta1, beta2, 1.0f - beta2,
-                       step_size, inv_bc2_sqrt, eps, vec);
+    hipLaunchKernelGGL(adam_kernel, dim3((int)nb), dim3(256), 0, st, p, g, m, v, n, (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), step_size, inv_bc2_sqrt, (float)eps, vec);
 }

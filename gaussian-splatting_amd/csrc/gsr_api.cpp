@@ -182,6 +182,7 @@ GsrBwdScratch gsr_carve_bwd(char* base, int P, int64_t R) {
     const size_t np = (size_t)(P > 0 ? P : 1), nr = (size_t)(R > 0 ? R : 1);
     b.splat_grads = (float*)take(np * 48);
     b.inst_grads = (float*)take(nr * 48);
+    b.inst_flag = (uint8_t*)take(nr);
     b.bytes = off;
     return b;
 }
@@ -387,18 +388,19 @@ int gsr_backward_blend(const GsrRasterSettings* settings, int P, int32_t num_ren
             HIP_OK(hipMemsetAsync(sg, 0, (size_t)P * 12 * sizeof(float), st));
             if (num_rendered > 0)
                 gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib,
-                                           dL_dout_color, dL_dout_invdepth, sg, nullptr, 1, st);
+                                           dL_dout_color, dL_dout_invdepth, sg, nullptr, nullptr, 1, st);
         } else {
-            // records of instances that contributed nowhere are never written by the blend backward: clear them all first
-            HIP_OK(hipMemsetAsync(w.inst_grads, 0, (size_t)num_rendered * 12 * sizeof(float), st));
+            // instances that contributed nowhere get no record: only their 1-byte valid flags are cleared
+            HIP_OK(hipMemsetAsync(w.inst_flag, 0, (size_t)num_rendered, st));
             gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib,
-                                       dL_dout_color, dL_dout_invdepth, nullptr, w.inst_grads, g_render_bwd_variant, st);
+                                       dL_dout_color, dL_dout_invdepth, nullptr, w.inst_grads, w.inst_flag,
+                                       g_render_bwd_variant, st);
         }
     }
     STAGE_CHECK("render backward blend");
     if (g_render_bwd_variant != 1 && num_rendered > 0) {
         StageTimer t(GSR_STAGE_GATHER_BWD, st);
-        gsr_launch_reduce_instances(P, g.vals[depth_order_buffer_index()], g.offsets, g.tiles, w.inst_grads, sg, st);
+        gsr_launch_reduce_instances(P, g.vals[depth_order_buffer_index()], g.offsets, g.tiles, w.inst_grads, w.inst_flag, sg, st);
     }
     STAGE_CHECK("render backward reduce");
     HIP_OK(hipGetLastError());
@@ -452,8 +454,8 @@ int gsr_rasterize_backward(const GsrRasterSettings* settings, int P, int M, int3
                                    dL_dsh, dL_dscales, dL_drotations, stream);
 }
 
-int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                  float beta2, float eps, int32_t step, void* stream) {
+int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                  double beta2, double eps, int32_t step, void* stream) {
     if (n < 0 || step < 1) return fail(GSR_ERR_INVALID_ARG, "n < 0 or step < 1");
     if (n == 0) return GSR_OK;
     if (!param || !grad || !exp_avg || !exp_avg_sq) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");

@@ -100,18 +100,19 @@ void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const 
 void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,
                                 const float4* splats, const float* final_T, const uint32_t* n_contrib,
                                 const float* dL_dpix, const float* dL_dinvdepth, float* splat_grads /*[P,12] variant 1*/,
-                                float* inst_grads /*[R,12] variant 0*/, int variant, hipStream_t st);
+                                float* inst_grads /*[R,12] variant 0*/, uint8_t* inst_flag /*[R]*/, int variant, hipStream_t st);
 void gsr_launch_reduce_instances(int P, const uint32_t* order, const uint32_t* offsets, const uint32_t* tiles,
-                                 const float* inst_grads, float* splat_grads, hipStream_t st);
+                                 const float* inst_grads, const uint8_t* inst_flag, float* splat_grads, hipStream_t st);
 
 // backward scratch (caller-owned, gsr_backward_scratch_bytes): per-Gaussian record, per-instance records, maps
 struct GsrBwdScratch {
     float* splat_grads;     // [P,12]
     float* inst_grads;      // [R,12]
+    uint8_t* inst_flag;     // [R]  1 = the instance has a record
     size_t bytes;
 };
 GsrBwdScratch gsr_carve_bwd(char* base, int P, int64_t R);
 
 // adam.hip
-void gsr_launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+void gsr_launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
                      int step, hipStream_t st);

@@ -157,10 +157,12 @@ __global__ void __launch_bounds__(256)
 render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                 const float4* __restrict__ splats, const float* __restrict__ final_T,
                 const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                const float* __restrict__ dL_dinvdepth, float4* __restrict__ inst_grads) {
+                const float* __restrict__ dL_dinvdepth, float4* __restrict__ inst_grads,
+                uint8_t* __restrict__ inst_flag) {
     __shared__ float4 s_rec[SB * REC_STRIDE];   // 20 KB
     __shared__ float s_grad[SB * 12];           // 12 KB
     __shared__ uint32_t s_k[SB];                // emission index of every staged entry
+    __shared__ uint32_t s_touch[SB];            // entry received a contribution from some wave of the tile
     __shared__ uint32_t s_max[4];
     const int tid = threadIdx.x, lane = tid & 63, quad = tid >> 6;
     const int tile = cam.tile_y0 * cam.gx + blockIdx.x;
@@ -192,9 +194,9 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
     __syncthreads();
     const uint32_t nlist = range.y - range.x;
     const uint32_t end = min(nlist, max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
-    // Entries at list positions >= end contributed to no pixel of the tile: their records stay zero (the whole record
-    // array is cleared by a streaming memset before this kernel -- looking up the emission index of every tail entry
-    // just to store zeros cost a 64-byte gather per entry, 590 MB of fetches on the 1 M / 1080p frame).  Records live at
+    // Entries at list positions >= end contributed to no pixel of the tile: they get no record (their valid flag stays 0;
+    // looking up the emission index of every tail entry just to store zeros cost a 64-byte gather per entry, 590 MB of
+    // fetches on the 1 M / 1080p frame, and clearing all records by memset another 545 MB of writes).  Records live at
     // the instance's EMISSION index k (contiguous per Gaussian): k = goffset + (ty - miny) * w + (tx - minx), with the
     // rectangle and goffset read from the 4th quad of the 64-byte splat record.
     if (end == 0) return;
@@ -217,6 +219,7 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
             s_k[tid] = emission_index(splats[id * 4 + 3], (uint32_t)tx, (uint32_t)ty);
         }
         for (int i = tid; i < SB * 3; i += 256) s_grad4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < SB; i += 256) s_touch[i] = 0u;
         __syncthreads();
 
         if (quad_alive) {
@@ -254,15 +257,21 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
                         atomicAdd(o, v0);
                         atomicAdd(o + 4, v1);
                         if (lane < 32) atomicAdd(o + 8, v2);
+                        if (lane == 15) s_touch[entry] = 1u;
                     }
                 }
             }
         }
         __syncthreads();
-        // ---- flush: one 48-byte record per entry, at the entry's emission index (3 lanes per record) ----
+        // ---- flush: one 48-byte record per TOUCHED entry, at the entry's emission index (3 lanes per record), plus its
+        // valid flag.  Untouched entries write nothing: the reduce kernel skips records whose flag byte is 0, so neither a
+        // 48 B/instance memset nor zero records are needed (only the 1 B/instance flag array is cleared per backward).
         for (uint32_t i = tid; i < n * 3; i += 256) {
             const uint32_t e = i / 3, part = i - e * 3;
-            inst_grads[(int64_t)s_k[e] * 3 + part] = s_grad4[i];
+            if (s_touch[e]) {
+                inst_grads[(int64_t)s_k[e] * 3 + part] = s_grad4[i];
+                if (part == 0) inst_flag[s_k[e]] = 1;
+            }
         }
         __syncthreads();
     }
@@ -277,7 +286,8 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
 // a 2-tile one (a lane-per-Gaussian loop measured 0.49 ms on the 1 M / 1080p frame: the wave waits for its largest splat).
 __global__ void __launch_bounds__(256)
 bwd_reduce_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
-                     const float4* __restrict__ inst_grads, float4* __restrict__ splat_grads) {
+                     const float4* __restrict__ inst_grads, const uint8_t* __restrict__ inst_flag,
+                     float4* __restrict__ splat_grads) {
     __shared__ float s_acc[4][64 * 12];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -295,6 +305,8 @@ bwd_reduce_instances(int P, const uint32_t* __restrict__ order, const uint32_t* 
     for (uint32_t c0 = 0; c0 < total; c0 += 64) {
         const uint32_t r = c0 + lane;
         const bool valid = r < total;
+        const bool has_rec = valid && inst_flag[(int64_t)base + r] != 0;     // untouched instances have no record
+        if (__ballot(has_rec) == 0ull) continue;     // e.g. far Gaussians that every pixel terminated in front of
         int lo = 0, hi = last;
 #pragma unroll
         for (int it = 0; it < 6; ++it) {
@@ -304,7 +316,7 @@ bwd_reduce_instances(int P, const uint32_t* __restrict__ order, const uint32_t* 
         }
         const int s = valid ? (lo > last ? last : lo) : 64 + lane;     // invalid lanes never merge
         float v[10];
-        if (valid) {
+        if (has_rec) {
             const float4 u0 = stream[(int64_t)r * 3 + 0], u1 = stream[(int64_t)r * 3 + 1], u2 = stream[(int64_t)r * 3 + 2];
             v[0] = u0.x; v[1] = u0.y; v[2] = u0.z; v[3] = u0.w; v[4] = u1.x; v[5] = u1.y; v[6] = u1.z; v[7] = u1.w;
             v[8] = u2.x; v[9] = u2.y;
@@ -437,7 +449,7 @@ inline int stream_grid(int64_t n) {
 void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,
                                 const float4* splats, const float* final_T, const uint32_t* n_contrib,
                                 const float* dL_dpix, const float* dL_dinvdepth, float* splat_grads, float* inst_grads,
-                                int variant, hipStream_t st) {
+                                uint8_t* inst_flag, int variant, hipStream_t st) {
     const int n_band_tiles = cam.gx * (cam.tile_y1 - cam.tile_y0);
     if (n_band_tiles <= 0) return;
     if (variant == 1) {
@@ -446,17 +458,17 @@ void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const
                            splats, final_T, n_contrib, dL_dpix, dL_dinvdepth, splat_grads);
     } else if (variant == 2) {
         hipLaunchKernelGGL(render_bwd_tile<128>, dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats,
-                           final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads));
+                           final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads), inst_flag);
     } else {
         hipLaunchKernelGGL(render_bwd_tile<256>, dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats,
-                           final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads));
+                           final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads), inst_flag);
     }
 }
 
 void gsr_launch_reduce_instances(int P, const uint32_t* order, const uint32_t* offsets, const uint32_t* tiles,
-                                 const float* inst_grads, float* splat_grads, hipStream_t st) {
+                                 const float* inst_grads, const uint8_t* inst_flag, float* splat_grads, hipStream_t st) {
     (void)tiles;
     const int64_t waves = ((int64_t)P + 63) / 64;
     hipLaunchKernelGGL(bwd_reduce_instances, dim3((int)((waves + 3) / 4)), dim3(256), 0, st, P, order, offsets,
-                       reinterpret_cast<const float4*>(inst_grads), reinterpret_cast<float4*>(splat_grads));
+                       reinterpret_cast<const float4*>(inst_grads), inst_flag, reinterpret_cast<float4*>(splat_grads));
 }

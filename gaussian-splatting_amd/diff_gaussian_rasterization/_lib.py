@@ -103,7 +103,7 @@ def load() -> C.CDLL:
                                             vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                             vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_adam_step.restype = C.c_int
-    lib.gsr_adam_step.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, vp]
+    lib.gsr_adam_step.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, vp]
     lib.gsr_mark_visible.restype = C.c_int
     lib.gsr_mark_visible.argtypes = [C.c_int, vp, vp, vp, vp, vp]
     lib.gsr_forward_views.restype = C.c_int

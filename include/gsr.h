@@ -153,7 +153,7 @@ int gsr_backward_preprocess(const GsrRasterSettings* settings, int P, int M,
  * AFTER incrementing; state tensors exp_avg / exp_avg_sq are updated in place.
  */
 int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                  float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
+                  double lr, double beta1, double beta2, double eps, int32_t step, void* stream);
 
 /* Replaces _C.mark_visible: present[i] = 1 iff Gaussian i is in front of the 0.2 near plane. */
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
