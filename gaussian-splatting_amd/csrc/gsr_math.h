@@ -177,35 +177,73 @@ GSR_HD bool gsr_project(const GsrCam& cam, const float* mean, const float* cov, 
     return true;
 }
 
+// 12-float group load / store used by the SH routines; nf = number of valid floats (12 except for a ragged last group)
+GSR_HD void gsr_ld12(const float* p, int nf, float* dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (nf == 12 && ((uintptr_t)p & 15) == 0) {
+        const float4 v0 = reinterpret_cast<const float4*>(p)[0], v1 = reinterpret_cast<const float4*>(p)[1],
+                     v2 = reinterpret_cast<const float4*>(p)[2];
+        dst[0] = v0.x; dst[1] = v0.y; dst[2] = v0.z; dst[3] = v0.w; dst[4] = v1.x; dst[5] = v1.y; dst[6] = v1.z; dst[7] = v1.w;
+        dst[8] = v2.x; dst[9] = v2.y; dst[10] = v2.z; dst[11] = v2.w;
+        return;
+    }
+#endif
+    for (int i = 0; i < 12; ++i) dst[i] = i < nf ? p[i] : 0.0f;
+}
+GSR_HD void gsr_st12(float* p, int nf, const float* src) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (nf == 12 && ((uintptr_t)p & 15) == 0) {
+        reinterpret_cast<float4*>(p)[0] = make_float4(src[0], src[1], src[2], src[3]);
+        reinterpret_cast<float4*>(p)[1] = make_float4(src[4], src[5], src[6], src[7]);
+        reinterpret_cast<float4*>(p)[2] = make_float4(src[8], src[9], src[10], src[11]);
+        return;
+    }
+#endif
+    for (int i = 0; i < 12; ++i)
+        if (i < nf) p[i] = src[i];
+}
+
 // SH -> RGB in the expression order of utils/sh_utils.py:78-104, then +0.5, clamp >= 0.
-// sh points at this Gaussian's [M][3] block.
-GSR_HD void gsr_sh_to_rgb(int deg, const float* sh, const float* mean, const float* campos, float* rgb, uint32_t& clamped) {
+// sh points at this Gaussian's [M][3] block (global or host memory); it is consumed in groups of 4 coefficients
+// (12 floats = three 16-byte loads) so that only one group is live in registers.  Per channel the sum is built
+// left to right exactly as sh_utils writes it: result (+/-) (C * factor ...) * sh[k].
+GSR_HD void gsr_sh_to_rgb(int deg, int M, const float* sh, const float* mean, const float* campos, float* rgb, uint32_t& clamped) {
     const float dx = mean[0] - campos[0], dy = mean[1] - campos[1], dz = mean[2] - campos[2];
     const float n = sqrtf(dx * dx + dy * dy + dz * dz);
     const float x = dx / n, y = dy / n, z = dz / n;
+    const float xx = x * x, yy = y * y, zz = z * z;
+    const float xy = x * y, yz = y * z, xz = x * z;
+    float res[3] = {0.0f, 0.0f, 0.0f};
+    float s[12];
+    const int ncoef = (deg + 1) * (deg + 1);
+    for (int grp = 0; grp < 4; ++grp) {
+        const int k0 = grp * 4;
+        if (k0 >= ncoef) break;
+        gsr_ld12(sh + k0 * 3, (M - k0 >= 4 ? 4 : M - k0) * 3, s);
+        for (int ch = 0; ch < 3; ++ch) {
+            float r = res[ch];
+            if (grp == 0) {
+                r = GSR_SH_C0 * s[0 + ch];
+                if (deg > 0) r = r - GSR_SH_C1 * y * s[3 + ch] + GSR_SH_C1 * z * s[6 + ch] - GSR_SH_C1 * x * s[9 + ch];
+            } else if (grp == 1) {
+                r = r + GSR_SH_C2_0 * xy * s[0 + ch] + GSR_SH_C2_1 * yz * s[3 + ch] +
+                    GSR_SH_C2_2 * (2.0f * zz - xx - yy) * s[6 + ch] + GSR_SH_C2_3 * xz * s[9 + ch];
+            } else if (grp == 2) {
+                r = r + GSR_SH_C2_4 * (xx - yy) * s[0 + ch];
+                if (deg > 2)
+                    r = r + GSR_SH_C3_0 * y * (3.0f * xx - yy) * s[3 + ch] + GSR_SH_C3_1 * xy * z * s[6 + ch] +
+                        GSR_SH_C3_2 * y * (4.0f * zz - xx - yy) * s[9 + ch];
+            } else {
+                r = r + GSR_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * s[0 + ch] +
+                    GSR_SH_C3_4 * x * (4.0f * zz - xx - yy) * s[3 + ch] + GSR_SH_C3_5 * z * (xx - yy) * s[6 + ch] +
+                    GSR_SH_C3_6 * x * (xx - 3.0f * yy) * s[9 + ch];
+            }
+            res[ch] = r;
+        }
+    }
     clamped = 0;
     for (int ch = 0; ch < 3; ++ch) {
-        float result = GSR_SH_C0 * sh[0 * 3 + ch];
-        if (deg > 0) {
-            result = result - GSR_SH_C1 * y * sh[1 * 3 + ch] + GSR_SH_C1 * z * sh[2 * 3 + ch] - GSR_SH_C1 * x * sh[3 * 3 + ch];
-            if (deg > 1) {
-                const float xx = x * x, yy = y * y, zz = z * z;
-                const float xy = x * y, yz = y * z, xz = x * z;
-                result = result + GSR_SH_C2_0 * xy * sh[4 * 3 + ch] + GSR_SH_C2_1 * yz * sh[5 * 3 + ch] +
-                         GSR_SH_C2_2 * (2.0f * zz - xx - yy) * sh[6 * 3 + ch] + GSR_SH_C2_3 * xz * sh[7 * 3 + ch] +
-                         GSR_SH_C2_4 * (xx - yy) * sh[8 * 3 + ch];
-                if (deg > 2) {
-                    result = result + GSR_SH_C3_0 * y * (3.0f * xx - yy) * sh[9 * 3 + ch] +
-                             GSR_SH_C3_1 * xy * z * sh[10 * 3 + ch] +
-                             GSR_SH_C3_2 * y * (4.0f * zz - xx - yy) * sh[11 * 3 + ch] +
-                             GSR_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[12 * 3 + ch] +
-                             GSR_SH_C3_4 * x * (4.0f * zz - xx - yy) * sh[13 * 3 + ch] +
-                             GSR_SH_C3_5 * z * (xx - yy) * sh[14 * 3 + ch] +
-                             GSR_SH_C3_6 * x * (xx - 3.0f * yy) * sh[15 * 3 + ch];
-                }
-            }
-        }
-        result = result + 0.5f;
+        const float result = res[ch] + 0.5f;
         if (result < 0.0f) clamped |= (1u << ch);
         rgb[ch] = fmaxf(result, 0.0f);
     }
@@ -332,20 +370,21 @@ GSR_HD void gsr_project_backward(const GsrCam& cam, const float* mean, const flo
     dmean[2] += W02 * dtx + W12 * dty + W22 * dtz;
 }
 
-// SH backward, streaming: drgb = dL/d(rgb after clamp).  `sh` / `dsh` point at this Gaussian's [M][3] blocks (global or
-// host memory); one coefficient (3 floats) is read, used and written at a time, so no per-thread arrays are needed
-// (the first, array-based version spilled 208 B/lane to scratch in the fused backward kernel).  All M rows of dsh are
-// written (rows above the active degree are zero); the view-direction term is accumulated into dmean.
+// SH backward, streaming in groups of 4 coefficients (12 floats = three 16-byte accesses): drgb = dL/d(rgb after clamp).
+// `sh` / `dsh` point at this Gaussian's [M][3] blocks (global or host memory).  A group is loaded, used and stored
+// before the next one is touched, so no 48-float per-thread arrays are needed (the first, array-based version spilled
+// 208 B/lane to scratch in the fused backward kernel; storing coefficient by coefficient -- 12-byte stores -- avoided
+// the spill but measured 1.6x write amplification at the L2/HBM boundary).  All M rows of dsh are written (rows above
+// the active degree are zero); the view-direction term is accumulated into dmean.
 struct GsrShBwdAcc {
     float drgb[3];
     float ddx, ddy, ddz;
 };
-GSR_HD void gsr_sh_bwd_term(GsrShBwdAcc& a, const float* sh, float* dsh, int k, float basis, float bx, float by, float bz) {
-    const float s0 = sh[k * 3 + 0], s1 = sh[k * 3 + 1], s2 = sh[k * 3 + 2];
-    dsh[k * 3 + 0] = basis * a.drgb[0];
-    dsh[k * 3 + 1] = basis * a.drgb[1];
-    dsh[k * 3 + 2] = basis * a.drgb[2];
-    const float dot = s0 * a.drgb[0] + s1 * a.drgb[1] + s2 * a.drgb[2];
+GSR_HD void gsr_sh_bwd_term(GsrShBwdAcc& a, const float* s3, float* d3, float basis, float bx, float by, float bz) {
+    d3[0] = basis * a.drgb[0];
+    d3[1] = basis * a.drgb[1];
+    d3[2] = basis * a.drgb[2];
+    const float dot = s3[0] * a.drgb[0] + s3[1] * a.drgb[1] + s3[2] * a.drgb[2];
     a.ddx += bx * dot;
     a.ddy += by * dot;
     a.ddz += bz * dot;
@@ -358,41 +397,49 @@ GSR_HD void gsr_sh_backward(int deg, int M, const float* sh, const float* mean, 
     GsrShBwdAcc a;
     for (int ch = 0; ch < 3; ++ch) a.drgb[ch] = (clamped & (1u << ch)) ? 0.0f : drgb_in[ch];
     a.ddx = a.ddy = a.ddz = 0.0f;
-    int nb = 1;
-    gsr_sh_bwd_term(a, sh, dsh, 0, GSR_SH_C0, 0.0f, 0.0f, 0.0f);
-    if (deg > 0) {
-        gsr_sh_bwd_term(a, sh, dsh, 1, -GSR_SH_C1 * y, 0.0f, -GSR_SH_C1, 0.0f);
-        gsr_sh_bwd_term(a, sh, dsh, 2, GSR_SH_C1 * z, 0.0f, 0.0f, GSR_SH_C1);
-        gsr_sh_bwd_term(a, sh, dsh, 3, -GSR_SH_C1 * x, -GSR_SH_C1, 0.0f, 0.0f);
-        nb = 4;
-        if (deg > 1) {
-            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-            gsr_sh_bwd_term(a, sh, dsh, 4, GSR_SH_C2_0 * xy, GSR_SH_C2_0 * y, GSR_SH_C2_0 * x, 0.0f);
-            gsr_sh_bwd_term(a, sh, dsh, 5, GSR_SH_C2_1 * yz, 0.0f, GSR_SH_C2_1 * z, GSR_SH_C2_1 * y);
-            gsr_sh_bwd_term(a, sh, dsh, 6, GSR_SH_C2_2 * (2.0f * zz - xx - yy), GSR_SH_C2_2 * -2.0f * x, GSR_SH_C2_2 * -2.0f * y,
-                            GSR_SH_C2_2 * 4.0f * z);
-            gsr_sh_bwd_term(a, sh, dsh, 7, GSR_SH_C2_3 * xz, GSR_SH_C2_3 * z, 0.0f, GSR_SH_C2_3 * x);
-            gsr_sh_bwd_term(a, sh, dsh, 8, GSR_SH_C2_4 * (xx - yy), GSR_SH_C2_4 * 2.0f * x, GSR_SH_C2_4 * -2.0f * y, 0.0f);
-            nb = 9;
-            if (deg > 2) {
-                gsr_sh_bwd_term(a, sh, dsh, 9, GSR_SH_C3_0 * y * (3.0f * xx - yy), GSR_SH_C3_0 * 6.0f * xy,
-                                GSR_SH_C3_0 * (3.0f * xx - 3.0f * yy), 0.0f);
-                gsr_sh_bwd_term(a, sh, dsh, 10, GSR_SH_C3_1 * xy * z, GSR_SH_C3_1 * yz, GSR_SH_C3_1 * xz, GSR_SH_C3_1 * xy);
-                gsr_sh_bwd_term(a, sh, dsh, 11, GSR_SH_C3_2 * y * (4.0f * zz - xx - yy), GSR_SH_C3_2 * -2.0f * xy,
-                                GSR_SH_C3_2 * (4.0f * zz - xx - 3.0f * yy), GSR_SH_C3_2 * 8.0f * yz);
-                gsr_sh_bwd_term(a, sh, dsh, 12, GSR_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), GSR_SH_C3_3 * -6.0f * xz,
-                                GSR_SH_C3_3 * -6.0f * yz, GSR_SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy));
-                gsr_sh_bwd_term(a, sh, dsh, 13, GSR_SH_C3_4 * x * (4.0f * zz - xx - yy), GSR_SH_C3_4 * (4.0f * zz - 3.0f * xx - yy),
-                                GSR_SH_C3_4 * -2.0f * xy, GSR_SH_C3_4 * 8.0f * xz);
-                gsr_sh_bwd_term(a, sh, dsh, 14, GSR_SH_C3_5 * z * (xx - yy), GSR_SH_C3_5 * 2.0f * xz, GSR_SH_C3_5 * -2.0f * yz,
-                                GSR_SH_C3_5 * (xx - yy));
-                gsr_sh_bwd_term(a, sh, dsh, 15, GSR_SH_C3_6 * x * (xx - 3.0f * yy), GSR_SH_C3_6 * (3.0f * xx - 3.0f * yy),
-                                GSR_SH_C3_6 * -6.0f * xy, 0.0f);
-                nb = 16;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    float s[12], d[12];
+    for (int grp = 0; grp < 4; ++grp) {
+        const int k0 = grp * 4;
+        if (k0 >= M) break;
+        const int nf = (M - k0 >= 4 ? 4 : M - k0) * 3;
+        for (int i = 0; i < 12; ++i) d[i] = 0.0f;
+        const bool live = (grp == 0) || (grp == 1 && deg > 1) || (grp >= 2 && deg > (grp == 2 ? 1 : 2));
+        if (live) gsr_ld12(sh + k0 * 3, nf, s);
+        if (grp == 0) {
+            gsr_sh_bwd_term(a, s + 0, d + 0, GSR_SH_C0, 0.0f, 0.0f, 0.0f);
+            if (deg > 0) {
+                gsr_sh_bwd_term(a, s + 3, d + 3, -GSR_SH_C1 * y, 0.0f, -GSR_SH_C1, 0.0f);
+                gsr_sh_bwd_term(a, s + 6, d + 6, GSR_SH_C1 * z, 0.0f, 0.0f, GSR_SH_C1);
+                gsr_sh_bwd_term(a, s + 9, d + 9, -GSR_SH_C1 * x, -GSR_SH_C1, 0.0f, 0.0f);
             }
+        } else if (grp == 1 && deg > 1) {
+            gsr_sh_bwd_term(a, s + 0, d + 0, GSR_SH_C2_0 * xy, GSR_SH_C2_0 * y, GSR_SH_C2_0 * x, 0.0f);
+            gsr_sh_bwd_term(a, s + 3, d + 3, GSR_SH_C2_1 * yz, 0.0f, GSR_SH_C2_1 * z, GSR_SH_C2_1 * y);
+            gsr_sh_bwd_term(a, s + 6, d + 6, GSR_SH_C2_2 * (2.0f * zz - xx - yy), GSR_SH_C2_2 * -2.0f * x, GSR_SH_C2_2 * -2.0f * y,
+                            GSR_SH_C2_2 * 4.0f * z);
+            gsr_sh_bwd_term(a, s + 9, d + 9, GSR_SH_C2_3 * xz, GSR_SH_C2_3 * z, 0.0f, GSR_SH_C2_3 * x);
+        } else if (grp == 2 && deg > 1) {
+            gsr_sh_bwd_term(a, s + 0, d + 0, GSR_SH_C2_4 * (xx - yy), GSR_SH_C2_4 * 2.0f * x, GSR_SH_C2_4 * -2.0f * y, 0.0f);
+            if (deg > 2) {
+                gsr_sh_bwd_term(a, s + 3, d + 3, GSR_SH_C3_0 * y * (3.0f * xx - yy), GSR_SH_C3_0 * 6.0f * xy,
+                                GSR_SH_C3_0 * (3.0f * xx - 3.0f * yy), 0.0f);
+                gsr_sh_bwd_term(a, s + 6, d + 6, GSR_SH_C3_1 * xy * z, GSR_SH_C3_1 * yz, GSR_SH_C3_1 * xz, GSR_SH_C3_1 * xy);
+                gsr_sh_bwd_term(a, s + 9, d + 9, GSR_SH_C3_2 * y * (4.0f * zz - xx - yy), GSR_SH_C3_2 * -2.0f * xy,
+                                GSR_SH_C3_2 * (4.0f * zz - xx - 3.0f * yy), GSR_SH_C3_2 * 8.0f * yz);
+            }
+        } else if (grp == 3 && deg > 2) {
+            gsr_sh_bwd_term(a, s + 0, d + 0, GSR_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), GSR_SH_C3_3 * -6.0f * xz,
+                            GSR_SH_C3_3 * -6.0f * yz, GSR_SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy));
+            gsr_sh_bwd_term(a, s + 3, d + 3, GSR_SH_C3_4 * x * (4.0f * zz - xx - yy), GSR_SH_C3_4 * (4.0f * zz - 3.0f * xx - yy),
+                            GSR_SH_C3_4 * -2.0f * xy, GSR_SH_C3_4 * 8.0f * xz);
+            gsr_sh_bwd_term(a, s + 6, d + 6, GSR_SH_C3_5 * z * (xx - yy), GSR_SH_C3_5 * 2.0f * xz, GSR_SH_C3_5 * -2.0f * yz,
+                            GSR_SH_C3_5 * (xx - yy));
+            gsr_sh_bwd_term(a, s + 9, d + 9, GSR_SH_C3_6 * x * (xx - 3.0f * yy), GSR_SH_C3_6 * (3.0f * xx - 3.0f * yy),
+                            GSR_SH_C3_6 * -6.0f * xy, 0.0f);
         }
+        gsr_st12(dsh + k0 * 3, nf, d);
     }
-    for (int k = nb; k < M; ++k) { dsh[k * 3 + 0] = 0.0f; dsh[k * 3 + 1] = 0.0f; dsh[k * 3 + 2] = 0.0f; }
     // d = o / |o|  =>  dL/do = (dL/dd - d (d . dL/dd)) / |o|
     const float dd = x * a.ddx + y * a.ddy + z * a.ddz;
     const float inv = 1.0f / n;

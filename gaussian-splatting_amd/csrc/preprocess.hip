@@ -53,7 +53,6 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int32_t* __restrict__ radii) {
     GsrCam cam;
     load_cam(camd, cam);
-    const int ncoef = (cam.sh_degree + 1) * (cam.sh_degree + 1);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
         const float mean[3] = {means3D[i * 3 + 0], means3D[i * 3 + 1], means3D[i * 3 + 2]};
         float cov[6];
@@ -75,12 +74,9 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             if (colors_precomp) {
                 rgb[0] = colors_precomp[i * 3 + 0]; rgb[1] = colors_precomp[i * 3 + 1]; rgb[2] = colors_precomp[i * 3 + 2];
             } else {
-                // whole SH block into registers with 16-byte loads first: reading it coefficient by coefficient straight
-                // from global memory (48 dword loads at a 192-byte lane stride) halves the VGPR count but measured 0.157 ms
-                // instead of 0.089 ms
-                float sh[48];
-                load_sh<16>(shs, i, cam.M, ncoef, sh);
-                gsr_sh_to_rgb(cam.sh_degree, sh, mean, cam.campos, rgb, clampbits);
+                // the SH block is consumed in 48-byte groups (three 16-byte loads per 4 coefficients), see gsr_math.h;
+                // per-coefficient 12-byte loads halve the VGPRs too but measured 0.157 ms instead of 0.089 ms
+                gsr_sh_to_rgb(cam.sh_degree, cam.M, shs + i * (int64_t)cam.M * 3, mean, cam.campos, rgb, clampbits);
             }
             q0 = make_float4(sp.px, sp.py, sp.conA, sp.conB);
             q1 = make_float4(sp.conC, sp.opacity, rgb[0], rgb[1]);

@@ -46,7 +46,7 @@ void host_preprocess(const HostCam* hc, int P, const float* means, const float* 
         uint32_t clamped = 0;
         if (vis) {
             if (colors) memcpy(rgb, colors + 3 * i, sizeof(rgb));
-            else gsr_sh_to_rgb(cam.sh_degree, shs + (size_t)i * cam.M * 3, means + 3 * i, cam.campos, rgb, clamped);
+            else gsr_sh_to_rgb(cam.sh_degree, cam.M, shs + (size_t)i * cam.M * 3, means + 3 * i, cam.campos, rgb, clamped);
         }
         float* f = out_f + 12 * i;
         f[0] = sp.px; f[1] = sp.py; f[2] = sp.conA; f[3] = sp.conB; f[4] = sp.conC; f[5] = sp.opacity;

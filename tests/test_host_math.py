@@ -131,3 +131,37 @@ def test_backward_matches_oracle_autograd(aa, use_cov):
     # means2D gradient is the pixel gradient in NDC-scaled units
     np.testing.assert_allclose(o["m2"][:, 0], g[:, 0].numpy() * 0.5 * cam.image_width, rtol=1e-6)
     np.testing.assert_allclose(o["m2"][:, 1], g[:, 1].numpy() * 0.5 * cam.image_height, rtol=1e-6)
+
+
+@pytest.mark.parametrize("deg,M", [(0, 16), (1, 16), (2, 16), (1, 4), (2, 9), (0, 1)])
+def test_sh_backward_all_degrees_and_ragged_blocks(deg, M):
+    """The grouped (4 coefficients = 48 bytes at a time) SH backward for every active degree and for SH blocks whose
+    coefficient count is not a multiple of 4 (max degree 0 / 2)."""
+    cam = look_at_camera(160, 120, (0.1, 0.2, -0.4), (0.0, 0.0, 3.0))
+    sc = make_scene(400, cam, seed=31, s_med=0.05)
+    sc.shs = sc.shs[:, :M].contiguous()
+    s = oracle_settings(cam, sh_degree=deg)
+    P = sc.P
+    m = sc.means3D.clone().requires_grad_(True)
+    sh = sc.shs.clone().requires_grad_(True)
+    pre = O.preprocess(m, sc.opacities, s, shs=sh, scales=sc.scales, rotations=sc.rotations)
+    vis = pre["visible"]
+    g = torch.zeros(P, 12)
+    g[:, 6:9] = torch.randn(P, 3, generator=torch.Generator().manual_seed(1)) * vis[:, None]
+    (g[:, 6:9] * pre["rgb"]).sum().backward()
+    lib = host_math_lib()
+    hc = host_cam(s, M)
+    cl = pre["clamped"].numpy()
+    bits = (cl[:, 0].astype(np.uint32) | (cl[:, 1].astype(np.uint32) << 1) | (cl[:, 2].astype(np.uint32) << 2)).astype(np.uint32)
+    radii = np.ascontiguousarray(pre["radii"].numpy().astype(np.int32))
+    o = {k: np.full(shape, 7.0, np.float32) for k, shape in dict(m2=(P, 3), col=(P, 3), op=(P,), m3=(P, 3), cov=(P, 6),
+                                                                   sh=(P, M, 3), sc=(P, 3), rot=(P, 4)).items()}
+    lib.host_preprocess_backward(C.byref(hc), P, fptr(np32(sc.means3D)), fptr(np32(sc.scales)), fptr(np32(sc.rotations)), None,
+                                 fptr(np32(sc.opacities)), fptr(np32(sc.shs)), fptr(radii), fptr(bits), fptr(np32(g)),
+                                 fptr(o["m2"]), fptr(o["col"]), fptr(o["op"]), fptr(o["m3"]), fptr(o["cov"]), fptr(o["sh"]),
+                                 fptr(o["sc"]), fptr(o["rot"]))
+    ref = sh.grad.numpy()
+    assert np.abs(o["sh"] - ref).max() <= 2e-6 * max(1e-6, np.abs(ref).max())
+    assert np.abs(o["sh"][:, (deg + 1) ** 2:]).max() == 0 if M > (deg + 1) ** 2 else True
+    mref = m.grad.numpy() if m.grad is not None else np.zeros((P, 3), np.float32)   # degree 0 is view independent
+    assert np.abs(o["m3"] - mref).max() <= 2e-4 * max(1e-9, np.abs(mref).max())
