@@ -5,12 +5,18 @@
 // COMPILE WITH -ffp-contract=off : the integer-deciding arithmetic (radius, tile rectangle) must match
 // oracle/torch_oracle.py bit for bit (see gsr_math.h).
 //
-// gfx950 notes: HBM-streaming, one Gaussian per lane, 256-thread workgroups, grid-stride capped at 2048
-// workgroups (8 per CU).  The 192-byte SH record per Gaussian dominates the input stream; it is skipped
-// for culled Gaussians and read with 16-byte loads.  Camera matrices are wave-uniform -> scalar loads.
+// gfx950 notes: HBM-streaming, one Gaussian per lane, 256-thread workgroups, grid-stride capped at 2048 workgroups.
+// The 192-byte SH record per Gaussian (and its 192-byte gradient) dominates the streams.  A lane reading "its" record
+// directly touches 64 different cache lines per load instruction (192-byte lane stride), which measured ~55 % of the
+// achievable bandwidth; instead each wave moves the 12 KB SH block of its 64 consecutive Gaussians with fully
+// coalesced 16-byte accesses through a wave-private LDS tile (row stride 52 floats: conflict-free ds_read_b128 /
+// ds_write_b128 per lane), skipping rows of culled Gaussians at 16-byte granularity.  Camera matrices are
+// wave-uniform -> scalar loads.
 #include "gsr_internal.h"
 
 namespace {
+
+constexpr int SH_ROW = 52;        // LDS row stride in floats for a 48-float SH record (52*l mod 64 hits 16 distinct bank quads)
 
 __device__ __forceinline__ void load_cam(const GsrCamDev& c, GsrCam& cam) {
     cam.W = c.W; cam.H = c.H; cam.gx = c.gx; cam.gy = c.gy;
@@ -23,25 +29,31 @@ __device__ __forceinline__ void load_cam(const GsrCamDev& c, GsrCam& cam) {
     for (int i = 0; i < 3; ++i) cam.campos[i] = c.campos[i];
 }
 
-// Load this Gaussian's SH block [M][3] into registers with 16-byte loads (the block is 12*M bytes,
-// 16-byte aligned whenever M is a multiple of 4, i.e. max degree 1 or 3; otherwise scalar loads).
-template <int MAXC>
-__device__ __forceinline__ void load_sh(const float* __restrict__ shs, int64_t i, int M, int ncoef, float* sh) {
-    const float* p = shs + i * (int64_t)M * 3;
-    if ((M & 3) == 0) {
-        const float4* p4 = reinterpret_cast<const float4*>(p);
+// Cooperative, coalesced copy of the SH rows of the wave's 64 Gaussians [i0, i0+64) from global memory into the wave's
+// LDS tile.  Only rows whose bit is set in `rows` are fetched (16 bytes at a time).  M == 16 only.
+__device__ __forceinline__ void wave_load_sh16(const float* __restrict__ shs, int64_t i0, int P, uint64_t rows, int lane,
+                                               float* tile) {
+    const float4* src = reinterpret_cast<const float4*>(shs + i0 * 48);
 #pragma unroll
-        for (int k = 0; k < MAXC * 3 / 4; ++k) {
-            if (k * 4 < ncoef * 3) {
-                const float4 v = p4[k];
-                sh[k * 4 + 0] = v.x; sh[k * 4 + 1] = v.y; sh[k * 4 + 2] = v.z; sh[k * 4 + 3] = v.w;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < MAXC * 3; ++k)
-            if (k < ncoef * 3) sh[k] = p[k];
+    for (int it = 0; it < 12; ++it) {
+        const int idx = it * 64 + lane;          // float4 index inside the 64 x 12 block
+        const int g = idx / 12, part = idx - g * 12;
+        if (((rows >> g) & 1ull) && i0 + g < P)
+            *reinterpret_cast<float4*>(tile + g * SH_ROW + part * 4) = src[idx];
     }
+    __builtin_amdgcn_wave_barrier();
+}
+// ... and back: every row (all 64, or up to P) is written -- zero rows included.
+__device__ __forceinline__ void wave_store_sh16(float* __restrict__ dst_all, int64_t i0, int P, int lane, const float* tile) {
+    float4* dst = reinterpret_cast<float4*>(dst_all + i0 * 48);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        const int idx = it * 64 + lane;
+        const int g = idx / 12, part = idx - g * 12;
+        if (i0 + g < P) dst[idx] = *reinterpret_cast<const float4*>(tile + g * SH_ROW + part * 4);
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 __global__ void __launch_bounds__(256)
@@ -51,31 +63,48 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
                       const float* __restrict__ cov3D_precomp, float4* __restrict__ splats,
                       uint2* __restrict__ rect, uint32_t* __restrict__ tiles, uint32_t* __restrict__ clamped_out,
                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int32_t* __restrict__ radii) {
+    __shared__ __attribute__((aligned(16))) float s_sh[4][64 * SH_ROW];
     GsrCam cam;
     load_cam(camd, cam);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
-        const float mean[3] = {means3D[i * 3 + 0], means3D[i * 3 + 1], means3D[i * 3 + 2]};
-        float cov[6];
-        if (cov3D_precomp) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) cov[k] = cov3D_precomp[i * 6 + k];
-        } else {
-            const float s[3] = {scales[i * 3 + 0], scales[i * 3 + 1], scales[i * 3 + 2]};
-            const float4 q4 = reinterpret_cast<const float4*>(rotations)[i];
-            const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-            gsr_cov3d(s, cam.scale_modifier, q, cov);
-        }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* tile = s_sh[wv];
+    const bool staged_sh = shs != nullptr && cam.M == 16;
+    // wave-uniform trip count: every lane of a wave runs the same iterations (lanes past P idle inside)
+    for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < P; i0 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = i0 + lane;
+        const bool in_range = i < P;
         GsrSplat sp;
-        const bool vis = gsr_project(cam, mean, cov, opacities[i], sp);
+        sp.radius = 0; sp.tiles = 0; sp.minx = sp.miny = sp.maxx = sp.maxy = 0; sp.depth = 0.f;
+        float mean[3] = {0.f, 0.f, 0.f};
+        bool vis = false;
+        if (in_range) {
+            mean[0] = means3D[i * 3 + 0]; mean[1] = means3D[i * 3 + 1]; mean[2] = means3D[i * 3 + 2];
+            float cov[6];
+            if (cov3D_precomp) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) cov[k] = cov3D_precomp[i * 6 + k];
+            } else {
+                const float s[3] = {scales[i * 3 + 0], scales[i * 3 + 1], scales[i * 3 + 2]};
+                const float4 q4 = reinterpret_cast<const float4*>(rotations)[i];
+                const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+                gsr_cov3d(s, cam.scale_modifier, q, cov);
+            }
+            vis = gsr_project(cam, mean, cov, opacities[i], sp);
+        }
+        if (staged_sh) {
+            const uint64_t rows = __ballot(vis);
+            if (rows) wave_load_sh16(shs, i0, P, rows, lane, tile);
+        }
+        if (!in_range) continue;
         uint32_t clampbits = 0;
         float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
         if (vis) {
             float rgb[3];
             if (colors_precomp) {
                 rgb[0] = colors_precomp[i * 3 + 0]; rgb[1] = colors_precomp[i * 3 + 1]; rgb[2] = colors_precomp[i * 3 + 2];
+            } else if (staged_sh) {
+                gsr_sh_to_rgb(cam.sh_degree, 16, tile + lane * SH_ROW, mean, cam.campos, rgb, clampbits);
             } else {
-                // the SH block is consumed in 48-byte groups (three 16-byte loads per 4 coefficients), see gsr_math.h;
-                // per-coefficient 12-byte loads halve the VGPRs too but measured 0.157 ms instead of 0.089 ms
                 gsr_sh_to_rgb(cam.sh_degree, cam.M, shs + i * (int64_t)cam.M * 3, mean, cam.campos, rgb, clampbits);
             }
             q0 = make_float4(sp.px, sp.py, sp.conA, sp.conB);
@@ -110,10 +139,16 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
                       float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
                       float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
                       float* __restrict__ dL_dscales, float* __restrict__ dL_drotations) {
+    __shared__ __attribute__((aligned(16))) float s_sh[4][64 * SH_ROW];
     GsrCam cam;
     load_cam(camd, cam);
     const int M = cam.M;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* tile = s_sh[wv];
+    const bool staged_sh = shs != nullptr && M == 16;
+    for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < P; i0 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = i0 + lane;
+        const bool in_range = i < P;
         float dmean[3] = {0.f, 0.f, 0.f};
         float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float dscale[3] = {0.f, 0.f, 0.f};
@@ -121,7 +156,11 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         float dop = 0.f;
         float dm2x = 0.f, dm2y = 0.f;
         float drgb[3] = {0.f, 0.f, 0.f};
-        const bool vis = radii[i] > 0;
+        const bool vis = in_range && radii[i] > 0;
+        if (staged_sh) {
+            const uint64_t rows = __ballot(vis);
+            if (rows) wave_load_sh16(shs, i0, P, rows, lane, tile);
+        }
         if (vis) {
             const float4 g0 = grads[i * 3 + 0], g1 = grads[i * 3 + 1], g2 = grads[i * 3 + 2];
             GsrSplatGrad g;
@@ -146,13 +185,25 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             dm2x = g.dpx * (0.5f * (float)cam.W);
             dm2y = g.dpy * (0.5f * (float)cam.H);
             if (!cov3D_precomp) gsr_cov3d_backward(s, cam.scale_modifier, q, dcov, dscale, drot);
-            if (shs)   // streams the SH block: reads sh[k], writes dL_dsh[k] per coefficient, no per-thread arrays
-                gsr_sh_backward(cam.sh_degree, M, shs + i * (int64_t)M * 3, mean, cam.campos, clamped[i], drgb,
-                                dL_dsh + i * (int64_t)M * 3, dmean);
+            if (shs) {
+                if (staged_sh)   // in place in the LDS row: each 48-byte group is read before it is overwritten with its gradient
+                    gsr_sh_backward(cam.sh_degree, 16, tile + lane * SH_ROW, mean, cam.campos, clamped[i], drgb,
+                                    tile + lane * SH_ROW, dmean);
+                else
+                    gsr_sh_backward(cam.sh_degree, M, shs + i * (int64_t)M * 3, mean, cam.campos, clamped[i], drgb,
+                                    dL_dsh + i * (int64_t)M * 3, dmean);
+            }
         } else if (shs) {
-            float* o = dL_dsh + i * (int64_t)M * 3;
-            for (int k = 0; k < M * 3; ++k) o[k] = 0.f;
+            if (staged_sh) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) *reinterpret_cast<float4*>(tile + lane * SH_ROW + k * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if (in_range) {
+                float* o = dL_dsh + i * (int64_t)M * 3;
+                for (int k = 0; k < M * 3; ++k) o[k] = 0.f;
+            }
         }
+        if (staged_sh) wave_store_sh16(dL_dsh, i0, P, lane, tile);
+        if (!in_range) continue;
         dL_dmeans2D[i * 3 + 0] = dm2x; dL_dmeans2D[i * 3 + 1] = dm2y; dL_dmeans2D[i * 3 + 2] = 0.f;
         dL_dcolors[i * 3 + 0] = drgb[0]; dL_dcolors[i * 3 + 1] = drgb[1]; dL_dcolors[i * 3 + 2] = drgb[2];
         dL_dopacity[i] = dop;
