@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=1200, help="tiles blended by the CPU baseline sample")
     ap.add_argument("--uniform-bands", action="store_true")
+    ap.add_argument("--compare-torch-adam", action="store_true", help="also time the train step with torch.optim.Adam")
     return ap.parse_args()
 
 
@@ -154,17 +155,30 @@ def main():
     _lib.profile_enable(False)
     stage_ms = {k: (v["ms"] / max(1, v["launches"])) for k, v in stages.items() if v["launches"]}
 
-    # ---- train leg: fwd + L1 + bwd + Adam (all parameters), once with the fused HIP Adam and once with torch.optim.Adam ----
+    # ---- train leg: forward + loss + backward + Adam over all parameters (train.py:111-186 without densification) ----
+    #   "ssim"   : the reference's loss, 0.8 L1 + 0.2 (1 - SSIM)  (train.py:119-126) with the fused HIP SSIM (fused_ssim package)
+    #   "ssim_torch": same loss through utils/loss_utils.py-style torch conv2d ops (the reference's un-fused fallback)
+    #   "l1"     : L1 only (isolates the rasterizer + optimizer)
+    #   "l1_torch_adam": as "l1" but with torch.optim.Adam instead of the fused HIP Adam (gsr_optim.FusedAdam)
     train = {}
     tsteps = a.steps if a.train_steps < 0 else a.train_steps
     if tsteps > 0:
         from diff_gaussian_rasterization.parallel import render_sharded, hip_band_renderer
         from gsr_optim import FusedAdam
+        from gsr_synth.losses import train_loss, l1_loss
+        from fused_ssim import fused_ssim
+
+        def fused_train_loss(image, gt_image, lambda_dssim=0.2):      # train.py:119-126 with FUSED_SSIM_AVAILABLE
+            return (1.0 - lambda_dssim) * l1_loss(image, gt_image) + lambda_dssim * (1.0 - fused_ssim(image[None], gt_image[None]))
         band_renderer = hip_band_renderer(rs)
         gt = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
-        for opt_name in ("fused", "torch"):
+        legs = [("ssim", FusedAdam, fused_train_loss), ("l1", FusedAdam, l1_loss)]
+        if a.compare_torch_adam:
+            legs.append(("l1_torch_adam", torch.optim.Adam, l1_loss))
+            legs.append(("ssim_torch", FusedAdam, train_loss))
+        for leg, opt_cls, loss_fn in legs:
             params = [t.detach().clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
-            opt = (FusedAdam if opt_name == "fused" else torch.optim.Adam)(params, lr=1e-5, eps=1e-15)
+            opt = opt_cls(params, lr=1e-5, eps=1e-15)
 
             def train_step():
                 opt.zero_grad(set_to_none=True)
@@ -174,7 +188,7 @@ def main():
                     color, radii, invd = render_sharded(band_renderer, params, plan, reduce="records")
                 else:
                     color, radii, invd = rasterize_gaussians(m, None, sh, None, o, s_, r_, None, rs, None)
-                loss = (color - gt).abs().mean()
+                loss = loss_fn(color, gt)
                 loss.backward()
                 opt.step()
 
@@ -188,8 +202,8 @@ def main():
             tdt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
             if world > 1:
                 dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-            train[opt_name] = float(tdt.item()) / tsteps * 1e3
-            if opt_name == "fused":
+            train[leg] = float(tdt.item()) / tsteps * 1e3
+            if leg == "l1":
                 _lib.profile_reset()
                 _lib.profile_enable(True)
                 for _ in range(min(10, tsteps)):
@@ -201,7 +215,8 @@ def main():
                     if tstages[k]["launches"]:
                         stage_ms[k] = tstages[k]["ms"] / tstages[k]["launches"]
             del params, opt
-    train_ms = train.get("fused")
+            torch.cuda.empty_cache()
+    train_ms = train.get("ssim")
     train_ips = None if train_ms is None else 1e3 / train_ms
 
     # ---- CPU baseline (rank 0, N=1 only): pure-PyTorch oracle on a bounded sample of the same frame ----
@@ -267,8 +282,11 @@ def main():
                        "render_fwd_variant": a.variant},
             "train_iters_per_s": None if train_ips is None else round(train_ips, 3),
             "train_ms_per_iter": None if train_ms is None else round(train_ms, 4),
-            "train_step": "forward + L1 loss + backward + Adam over all 59 floats/Gaussian (fused HIP Adam, gsr_optim.FusedAdam)",
-            "train_iters_per_s_torch_adam": None if "torch" not in train else round(1e3 / train["torch"], 3),
+            "train_step": "forward + loss 0.8 L1 + 0.2 (1-SSIM) (train.py:119-126; fused HIP SSIM) + backward + fused HIP Adam over "
+                          "all 59 floats/Gaussian; *_l1 = L1 loss only; *_ssim_torch = SSIM through torch conv2d ops",
+            "train_iters_per_s_ssim_torch": None if "ssim_torch" not in train else round(1e3 / train["ssim_torch"], 3),
+            "train_iters_per_s_l1": None if "l1" not in train else round(1e3 / train["l1"], 3),
+            "train_iters_per_s_l1_torch_adam": None if "l1_torch_adam" not in train else round(1e3 / train["l1_torch_adam"], 3),
             "whole_forward": {"algorithmic_bytes": int(ab["total"]), "achieved_GBs": round(whole, 2),
                               "frac_of_8TBs": round(whole / HBM_PEAK_GBS, 5),
                               "roofline_predicted_Mpix_s": round(npix / (ab["total"] / (HBM_PEAK_GBS * 1e9)) / 1e6, 1)},

@@ -33,6 +33,7 @@ UNITS = [
     ("render_fwd.hip", ["-ffp-contract=fast"]),
     ("render_bwd.hip", ["-ffp-contract=fast"]),
     ("adam.hip", ["-ffp-contract=off"]),
+    ("ssim.hip", ["-ffp-contract=fast"]),
     ("gsr_api.cpp", ["-x", "hip"]),
 ]
 

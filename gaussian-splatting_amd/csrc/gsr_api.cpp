@@ -464,6 +464,31 @@ int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
     return GSR_OK;
 }
 
+int gsr_ssim_forward(int planes, int H, int W, const float* img1, const float* img2, float* ssim_map, float* dm_dmu1,
+                     float* dm_dsigma1_sq, float* dm_dsigma12, void* stream) {
+    if (planes < 0 || H <= 0 || W <= 0) return fail(GSR_ERR_INVALID_ARG, "bad image size");
+    if (planes == 0) return GSR_OK;
+    if (planes > 65535) return fail(GSR_ERR_UNSUPPORTED, "more than 65535 image planes");
+    if (!img1 || !img2 || !ssim_map) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
+    if ((dm_dmu1 == nullptr) != (dm_dsigma1_sq == nullptr) || (dm_dmu1 == nullptr) != (dm_dsigma12 == nullptr))
+        return fail(GSR_ERR_INVALID_ARG, "give all three derivative maps or none");
+    gsr_launch_ssim_forward(planes, H, W, img1, img2, ssim_map, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, (hipStream_t)stream);
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_ssim_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dmap,
+                      const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1, void* stream) {
+    if (planes < 0 || H <= 0 || W <= 0) return fail(GSR_ERR_INVALID_ARG, "bad image size");
+    if (planes == 0) return GSR_OK;
+    if (planes > 65535) return fail(GSR_ERR_UNSUPPORTED, "more than 65535 image planes");
+    if (!img1 || !img2 || !dL_dmap || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1)
+        return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
+    gsr_launch_ssim_backward(planes, H, W, img1, img2, dL_dmap, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1, (hipStream_t)stream);
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
+}
+
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
                      void* stream) {
     (void)projmatrix;

@@ -116,3 +116,9 @@ GsrBwdScratch gsr_carve_bwd(char* base, int P, int64_t R);
 // adam.hip
 void gsr_launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
                      int step, hipStream_t st);
+
+// ssim.hip
+void gsr_launch_ssim_forward(int planes, int H, int W, const float* img1, const float* img2, float* ssim_map, float* dm_dmu1,
+                             float* dm_dex2, float* dm_dexy, hipStream_t st);
+void gsr_launch_ssim_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dmap,
+                              const float* dm_dmu1, const float* dm_dex2, const float* dm_dexy, float* dL_dimg1, hipStream_t st);

@@ -43,7 +43,7 @@ EXPORTS = [
     "gsr_abi_version", "gsr_last_error", "gsr_geometry_bytes", "gsr_binning_bytes", "gsr_image_bytes",
     "gsr_backward_scratch_bytes",
     "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_backward_blend", "gsr_backward_preprocess",
-    "gsr_mark_visible", "gsr_forward_views", "gsr_adam_step",
+    "gsr_mark_visible", "gsr_forward_views", "gsr_adam_step", "gsr_ssim_forward", "gsr_ssim_backward",
     "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_set_option",
 ]
 
@@ -104,6 +104,10 @@ def load() -> C.CDLL:
                                             vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_adam_step.restype = C.c_int
     lib.gsr_adam_step.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, vp]
+    lib.gsr_ssim_forward.restype = C.c_int
+    lib.gsr_ssim_forward.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_ssim_backward.restype = C.c_int
+    lib.gsr_ssim_backward.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_mark_visible.restype = C.c_int
     lib.gsr_mark_visible.argtypes = [C.c_int, vp, vp, vp, vp, vp]
     lib.gsr_forward_views.restype = C.c_int

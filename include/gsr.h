@@ -155,6 +155,19 @@ int gsr_backward_preprocess(const GsrRasterSettings* settings, int P, int M,
 int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   double lr, double beta1, double beta2, double eps, int32_t step, void* stream);
 
+/*
+ * Fused SSIM map: replaces the un-vendored `fused_ssim` extension (train.py:31-35,122; its
+ * `fusedssim` / `fusedssim_backward`), same numerics as utils/loss_utils.py:56-87 (11x11 Gaussian window, sigma 1.5,
+ * zero padding 5, C1 = 0.01^2, C2 = 0.03^2).  Images are [planes, H, W] fp32 (planes = batch x channels).
+ * forward writes the SSIM map and -- when the three derivative maps are non-NULL (training) -- dm/dmu1, dm/dE[x^2],
+ * dm/dE[xy]; backward turns dL/dmap into dL/dimg1.
+ */
+int gsr_ssim_forward(int planes, int H, int W, const float* img1, const float* img2, float* ssim_map,
+                     float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream);
+int gsr_ssim_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dmap,
+                      const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
+                      float* dL_dimg1, void* stream);
+
 /* Replaces _C.mark_visible: present[i] = 1 iff Gaussian i is in front of the 0.2 near plane. */
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);

@@ -80,6 +80,12 @@ def reference_fragments():
     center = wvt.inverse()[3, :3]                                              # :89
     out.update(cam_R=Rm, cam_T=T, cam_fov=np.array([fovx, fovy]), cam_wvt=wvt.numpy(), cam_proj=proj.numpy(),
                cam_full=full.numpy(), cam_center=center.numpy())
+    # ---- training loss (the step on the far side of the operator: train.py:119-126, utils/loss_utils.py:40-87) ----
+    from utils.loss_utils import ssim as ref_ssim, l1_loss as ref_l1
+    img = torch.rand(3, 61, 83, generator=g)
+    gt = (img + 0.15 * torch.randn(3, 61, 83, generator=g)).clamp(0, 1)
+    out.update(loss_img=img.numpy(), loss_gt=gt.numpy(), loss_ssim=np.float64(ref_ssim(img, gt).item()),
+               loss_l1=np.float64(ref_l1(img, gt).item()))
     np.savez_compressed(os.path.join(HERE, "reference_fragments.npz"), **out)
     print("wrote reference_fragments.npz", {k: v.shape for k, v in out.items()})
 

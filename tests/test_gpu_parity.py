@@ -485,3 +485,27 @@ def test_fused_adam_matches_torch_adam():
         assert int(sa["step"]) == int(sb["step"])
         for key in ("exp_avg", "exp_avg_sq"):      # fp32 round-off of different but equivalent update forms (lerp / fma)
             assert (sa[key] - sb[key]).abs().max().item() <= 2e-6 * sb[key].abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 67, 93), (2, 3, 128, 160), (1, 1, 16, 16), (1, 3, 11, 300)])
+def test_fused_ssim_matches_reference_formula(shape):
+    """fused_ssim (HIP) == utils/loss_utils.py:56-87 (restated in gsr_synth.losses, which is pinned to the
+    reference by tests/test_oracle.py::test_train_loss_matches_reference_loss_utils) -- value and gradient."""
+    from fused_ssim import fused_ssim
+    from gsr_synth.losses import ssim as torch_ssim
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(shape[2])
+    a = torch.rand(shape, generator=g)
+    b = (a + 0.2 * torch.randn(shape, generator=g)).clamp(0, 1)
+    a1 = a.clone().to(dev).requires_grad_(True)
+    a2 = a.clone().double().requires_grad_(True)
+    v1 = fused_ssim(a1, b.to(dev))
+    v2 = torch_ssim(a2, b.double())           # fp64 CPU reference of the same formula
+    assert abs(v1.item() - v2.item()) < 2e-6
+    (v1 * 3.0).backward()
+    (v2 * 3.0).backward()
+    torch.cuda.synchronize()
+    d = (a1.grad.cpu().double() - a2.grad).abs().max().item()
+    assert d <= 2e-5 * a2.grad.abs().max().item(), d
+    with torch.no_grad():                      # inference form: no derivative maps kept
+        assert abs(fused_ssim(a.to(dev), b.to(dev), train=False).item() - v2.item()) < 2e-6

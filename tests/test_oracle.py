@@ -335,3 +335,12 @@ def test_means2D_gradient_is_ndc_scaled_pixel_gradient():
         fd = (img_loss(d) - img_loss(-d)) / (2 * eps)
     assert abs(m2.grad[k, 0].item() - fd * 0.5 * 48) <= 1e-5 * max(1.0, abs(fd * 24))
     assert m2.grad[:, 2].abs().max().item() == 0
+
+
+def test_train_loss_matches_reference_loss_utils(frag):
+    """gsr_synth.losses (used by bench.py's train step) == utils/loss_utils.py l1_loss / ssim of the reference."""
+    from gsr_synth.losses import ssim, l1_loss, train_loss
+    img, gt = torch.tensor(frag["loss_img"]), torch.tensor(frag["loss_gt"])
+    assert abs(ssim(img, gt).item() - float(frag["loss_ssim"])) < 1e-6
+    assert abs(l1_loss(img, gt).item() - float(frag["loss_l1"])) < 1e-7
+    assert abs(train_loss(img, gt).item() - (0.8 * float(frag["loss_l1"]) + 0.2 * (1 - float(frag["loss_ssim"])))) < 1e-6
