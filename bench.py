@@ -260,9 +260,21 @@ def main():
             blend_bytes = ab["blend"] if world == 1 else ab["blend"] * frac_rows
             ach = blend_bytes / (render_ms * 1e-3) / 1e9
             pairs = 256.0 * R * (frac_rows if world > 1 else 1.0)
+            # HBM traffic of this kernel cannot be collected in-process: it comes from the committed rocprofv3 --pmc passes
+            # of this same command (profiles/pmc_latest.json: FETCH_SIZE and WRITE_SIZE in separate runs, bytes =
+            # (2*FETCH + WRITE)*1024 per MI355X_MICROARCH.md); null when the file or the kernel is missing
+            pmc_traffic, pmc_note = None, None
+            try:
+                pk = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"]
+                kn = {0: "render_fwd_wave_bf<true, 1>", 1: "render_fwd_block", 2: "render_fwd_wave_bf<false, 1>"}.get(a.variant)
+                if world == 1 and kn in pk and (P, W, H) == (1_000_000, 1920, 1080):
+                    pmc_traffic = int(pk[kn]["hbm_bytes_corrected"])
+                    pmc_note = "profiles/pmc_latest.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
+            except Exception:
+                pass
             roof = {"bound": "hbm", "kernel": {0: "render_fwd_wave_bf<LDS>", 1: "render_fwd_block", 2: "render_fwd_wave_bf<readlane>"}.get(a.variant, "?"),
                     "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                    "traffic": None, "kernel_ms": round(render_ms, 4),
+                    "traffic": pmc_traffic, "traffic_source": pmc_note, "kernel_ms": round(render_ms, 4),
                     "algorithmic_bytes_per_launch": int(blend_bytes),
                     "note": "blend is fp32-VALU/exp bound, not HBM bound (SURVEY 8(d)); listed (pixel,Gaussian) pairs = 256*R per "
                             "launch; most are never evaluated (early termination + exact box culling, DESIGN.md 3.3)",

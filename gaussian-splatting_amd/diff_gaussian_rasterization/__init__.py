@@ -86,6 +86,10 @@ def _make_settings(rs: GaussianRasterizationSettings, keep: list, tile_rows) -> 
     s.antialiasing = int(bool(rs.antialiasing))
     if tile_rows is None:
         s.tile_y0, s.tile_y1 = 0, 0
+    elif int(tile_rows[1]) <= int(tile_rows[0]):
+        # empty band (a rank that owns no tile rows): (0, 0) would mean "all rows" in the C ABI, so hand over a
+        # band past the last row, which the library clamps to an empty one
+        s.tile_y0 = s.tile_y1 = 1 << 20
     else:
         s.tile_y0, s.tile_y1 = int(tile_rows[0]), int(tile_rows[1])
     return s
