@@ -91,16 +91,21 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             }
             vis = gsr_project(cam, mean, cov, opacities[i], sp);
         }
+        // colours are needed only by Gaussians that touch this rank's band of tile rows (all visible ones on one GPU):
+        // with the screen sharded over N GPUs each rank streams ~1/N of the SH records
+        const bool need_color = vis && sp.tiles > 0;
         if (staged_sh) {
-            const uint64_t rows = __ballot(vis);
+            const uint64_t rows = __ballot(need_color);
             if (rows) wave_load_sh16(shs, i0, P, rows, lane, tile);
         }
         if (!in_range) continue;
         uint32_t clampbits = 0;
         float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
         if (vis) {
-            float rgb[3];
-            if (colors_precomp) {
+            float rgb[3] = {0.f, 0.f, 0.f};
+            if (!need_color) {
+                // visible but outside the band: never blended here, record keeps geometry only
+            } else if (colors_precomp) {
                 rgb[0] = colors_precomp[i * 3 + 0]; rgb[1] = colors_precomp[i * 3 + 1]; rgb[2] = colors_precomp[i * 3 + 2];
             } else if (staged_sh) {
                 gsr_sh_to_rgb(cam.sh_degree, 16, tile + lane * SH_ROW, mean, cam.campos, rgb, clampbits);
@@ -186,12 +191,20 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             dm2y = g.dpy * (0.5f * (float)cam.H);
             if (!cov3D_precomp) gsr_cov3d_backward(s, cam.scale_modifier, q, dcov, dscale, drot);
             if (shs) {
-                if (staged_sh)   // in place in the LDS row: each 48-byte group is read before it is overwritten with its gradient
-                    gsr_sh_backward(cam.sh_degree, 16, tile + lane * SH_ROW, mean, cam.campos, clamped[i], drgb,
+                // The colour clamp mask is recomputed from the SH record (a few hundred FLOPs on data that is loaded anyway)
+                // instead of being read from the forward's array: under screen sharding the forward evaluates colours
+                // only for Gaussians in the rank's band, while this kernel runs for every visible Gaussian on every rank.
+                float rgb_unused[3];
+                uint32_t clampbits = 0;
+                if (staged_sh) {   // in place in the LDS row: each 48-byte group is read before it is overwritten with its gradient
+                    gsr_sh_to_rgb(cam.sh_degree, 16, tile + lane * SH_ROW, mean, cam.campos, rgb_unused, clampbits);
+                    gsr_sh_backward(cam.sh_degree, 16, tile + lane * SH_ROW, mean, cam.campos, clampbits, drgb,
                                     tile + lane * SH_ROW, dmean);
-                else
-                    gsr_sh_backward(cam.sh_degree, M, shs + i * (int64_t)M * 3, mean, cam.campos, clamped[i], drgb,
+                } else {
+                    gsr_sh_to_rgb(cam.sh_degree, M, shs + i * (int64_t)M * 3, mean, cam.campos, rgb_unused, clampbits);
+                    gsr_sh_backward(cam.sh_degree, M, shs + i * (int64_t)M * 3, mean, cam.campos, clampbits, drgb,
                                     dL_dsh + i * (int64_t)M * 3, dmean);
+                }
             }
         } else if (shs) {
             if (staged_sh) {
