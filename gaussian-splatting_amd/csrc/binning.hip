@@ -110,7 +110,7 @@ emit_instances(int P, int gx, const uint32_t* __restrict__ order, const uint32_t
     const uint32_t excl_self = incl - ((j < P) ? (offsets[j] - (j > 0 ? offsets[j - 1] : 0u)) : 0u);
     // first emission index of this Gaussian -> 4th quad of its splat record (the blend backward writes its
     // per-instance gradient records at emission indices, see render_bwd.hip)
-    if (j < P) reinterpret_cast<uint32_t*>(splats + (int64_t)id * 4 + 3)[2] = base + excl_self;
+    if (splats && j < P) reinterpret_cast<uint32_t*>(splats + (int64_t)id * 4 + 3)[2] = base + excl_self;
     for (uint32_t k0 = 0; k0 < total; k0 += 64) {
         const uint32_t k = k0 + lane;
         int lo = 0, hi = last;

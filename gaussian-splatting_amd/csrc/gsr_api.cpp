@@ -334,7 +334,8 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
     int list_buf = 0;
     if (R > 0) {
         {   StageTimer t(GSR_STAGE_EMIT, st);
-            gsr_launch_emit(P, cam.gx, g.vals[order_buf], g.offsets, g.rect, b.keys[0], b.vals[0], g.splats, st);
+            gsr_launch_emit(P, cam.gx, g.vals[order_buf], g.offsets, g.rect, b.keys[0], b.vals[0],
+                            settings->no_backward ? nullptr : g.splats, st);
         }
         STAGE_CHECK("emit");
         {   StageTimer t(GSR_STAGE_TILE_SORT, st);
@@ -348,8 +349,9 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
     }
     STAGE_CHECK("ranges");
     {   StageTimer t(GSR_STAGE_RENDER, st);
-        gsr_launch_render_forward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib, out_color,
-                                  out_invdepth, g_render_fwd_variant, st);
+        gsr_launch_render_forward(cam, im.ranges, b.vals[list_buf], g.splats, settings->no_backward ? nullptr : im.final_T,
+                                  settings->no_backward ? nullptr : im.n_contrib, out_color, out_invdepth,
+                                  g_render_fwd_variant, st);
     }
     STAGE_CHECK("render");
     HIP_OK(hipGetLastError());

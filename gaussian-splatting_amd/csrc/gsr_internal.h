@@ -90,7 +90,7 @@ void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles, 
                            uint32_t* block_sums, uint32_t* num_rendered, uint32_t* host_word /*mapped pinned, may be NULL*/,
                            uint32_t seq, hipStream_t st);
 void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect,
-                     uint32_t* inst_keys, uint32_t* inst_vals, float4* splats, hipStream_t st);
+                     uint32_t* inst_keys, uint32_t* inst_vals, float4* splats /*NULL: skip the goffset write*/, hipStream_t st);
 void gsr_launch_ranges(int64_t R, int n_tiles, const uint32_t* sorted_keys, uint2* ranges, hipStream_t st);
 
 // render_fwd.hip / render_bwd.hip

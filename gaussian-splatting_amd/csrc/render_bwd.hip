@@ -152,7 +152,9 @@ constexpr int REC_STRIDE = 5;      // float4 per staged entry (80 B: conflict-fr
 // ------------------------------------------------------------------------------------------------
 // SB = super-batch: list entries staged in LDS at a time (256: one per thread; 128 halves the LDS footprint -> more
 // resident workgroups)
-template <int SB>
+// ABLATE (measurement only, results are wrong when != 0): 1 = no cross-lane reduction / LDS adds, 2 = additionally no
+// per-pixel gradient math after the alpha evaluation
+template <int SB, int ABLATE = 0>
 __global__ void __launch_bounds__(256)
 render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                 const float4* __restrict__ splats, const float* __restrict__ final_T,
@@ -248,6 +250,11 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
                                                  r0.y, r0.z, r0.w, r1.x, r2.z, r2.w, c2, r1.y, r1.z, r1.w, r2.x, r2.y, g_px,
                                                  g_py, g_A, g_B, g_C, g_op, g_r, g_g, g_b, g_d);
                     if (__ballot(active) == 0ull) continue;
+                    if (ABLATE >= 1) {
+                        asm volatile("" ::"v"(g_px), "v"(g_py), "v"(g_A), "v"(g_B), "v"(g_C), "v"(g_op), "v"(g_r), "v"(g_g), "v"(g_b), "v"(g_d));
+                        if (lane == 15) s_touch[entry] = 1u;
+                        continue;
+                    }
                     // slots in lanes 15 / 31 / 47 / 63 = first / third / second / fourth argument
                     const float v0 = reduce4(g_px, g_A, g_py, g_B);     // -> slots 0,1,2,3
                     const float v1 = reduce4(g_C, g_r, g_op, g_g);      // -> slots 4,5,6,7
@@ -456,6 +463,9 @@ void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const
         const int groups = (n_band_tiles + 7) / 8;
         hipLaunchKernelGGL(render_bwd_wave, dim3(groups * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list,
                            splats, final_T, n_contrib, dL_dpix, dL_dinvdepth, splat_grads);
+    } else if (variant == 11) {
+        hipLaunchKernelGGL((render_bwd_tile<256, 1>), dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats,
+                           final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads), inst_flag);
     } else if (variant == 2) {
         hipLaunchKernelGGL(render_bwd_tile<128>, dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats,
                            final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads), inst_flag);

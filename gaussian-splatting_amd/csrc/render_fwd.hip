@@ -90,8 +90,10 @@ render_fwd_block(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t
     if (inside) {
         const int64_t pix = (int64_t)py * cam.W + px;
         const int64_t HW = (int64_t)cam.H * cam.W;
-        final_T[pix] = s.T;
-        n_contrib[pix] = s.last;
+        if (final_T) {      // NULL in inference mode: only the backward reads these
+            final_T[pix] = s.T;
+            n_contrib[pix] = s.last;
+        }
         out_color[pix] = s.C0 + s.T * cam.bg[0];
         out_color[HW + pix] = s.C1 + s.T * cam.bg[1];
         out_color[2 * HW + pix] = s.C2 + s.T * cam.bg[2];
@@ -249,8 +251,10 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
     if (inside) {
         const int64_t pix = (int64_t)py * cam.W + px;
         const int64_t HW = (int64_t)cam.H * cam.W;
-        final_T[pix] = s.T;
-        n_contrib[pix] = s.last;
+        if (final_T) {      // NULL in inference mode: only the backward reads these
+            final_T[pix] = s.T;
+            n_contrib[pix] = s.last;
+        }
         out_color[pix] = s.C0 + s.T * cam.bg[0];
         out_color[HW + pix] = s.C1 + s.T * cam.bg[1];
         out_color[2 * HW + pix] = s.C2 + s.T * cam.bg[2];

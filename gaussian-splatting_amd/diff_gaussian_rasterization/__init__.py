@@ -67,7 +67,7 @@ class _Buffer:
         self.cb = RESIZE_FN(_resize)
 
 
-def _make_settings(rs: GaussianRasterizationSettings, keep: list, tile_rows) -> GsrRasterSettings:
+def _make_settings(rs: GaussianRasterizationSettings, keep: list, tile_rows, no_backward: bool = False) -> GsrRasterSettings:
     dev_t = [_f32c(rs.bg), _f32c(rs.viewmatrix), _f32c(rs.projmatrix), _f32c(rs.campos)]
     keep.extend(dev_t)
     s = GsrRasterSettings()
@@ -84,6 +84,7 @@ def _make_settings(rs: GaussianRasterizationSettings, keep: list, tile_rows) -> 
     s.prefiltered = int(bool(rs.prefiltered))
     s.debug = int(bool(rs.debug))
     s.antialiasing = int(bool(rs.antialiasing))
+    s.no_backward = int(bool(no_backward))
     if tile_rows is None:
         s.tile_y0, s.tile_y1 = 0, 0
     elif int(tile_rows[1]) <= int(tile_rows[0]):
@@ -118,7 +119,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         M = int(sh_c.shape[1]) if sh_c is not None and sh_c.dim() == 3 else 0
         keep: list = []
         with torch.cuda.device(device):
-            s = _make_settings(raster_settings, keep, tile_rows)
+            # inside autograd.Function.forward grad mode is off; needs_input_grad tells whether a backward can follow
+            no_backward = not any(ctx.needs_input_grad[:8])
+            s = _make_settings(raster_settings, keep, tile_rows, no_backward)
             color = torch.empty(3, H, W, dtype=torch.float32, device=device)
             invdepth = torch.empty(1, H, W, dtype=torch.float32, device=device)
             if tile_rows is not None:   # rows outside the band are not written by the kernels

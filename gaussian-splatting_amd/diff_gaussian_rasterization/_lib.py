@@ -27,7 +27,7 @@ class GsrRasterSettings(C.Structure):
         ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
         ("sh_degree", C.c_int32), ("campos", C.c_void_p),
         ("prefiltered", C.c_int32), ("debug", C.c_int32), ("antialiasing", C.c_int32),
-        ("tile_y0", C.c_int32), ("tile_y1", C.c_int32),
+        ("tile_y0", C.c_int32), ("tile_y1", C.c_int32), ("no_backward", C.c_int32),
     ]
 
 

@@ -66,6 +66,9 @@ typedef struct GsrRasterSettings {
      * tile_y1 <= 0 means "all rows". radii are unaffected by the band. */
     int32_t tile_y0;
     int32_t tile_y1;
+    /* Extension: 1 = the caller will not run the backward for this forward (inference / torch.no_grad()): state that only
+     * the backward reads (final_T, n_contrib, first-emission indices) is not written.  0 = reference behaviour. */
+    int32_t no_backward;
 } GsrRasterSettings;
 
 /* Resize callback: make the buffer at least `bytes` long and return its (device) base address,

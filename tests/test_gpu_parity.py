@@ -387,6 +387,37 @@ def test_kat_depth_order_two_gaussians():
     assert abs(c[0].item() - 0.6) < 1e-5 and abs(c[1].item() - 0.4 * 0.6) < 1e-5
 
 
+def test_degenerate_sizes_forward_and_backward():
+    """P = 1, everything culled (R = 0: image = background, all gradients zero), and a 17x9 image smaller than one tile
+    row -- forward and backward must not touch out-of-range memory or hang."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = torch.device("cuda:0")
+    for (W, H, z_vals) in ((64, 48, [4.0]), (64, 48, [0.1, -2.0, 0.05]), (17, 9, [3.0, 5.0]), (300, 2, [3.0, 5.0])):
+        cam = make_camera(W, H).to(dev)
+        rs = GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, torch.tensor([0.2, 0.4, 0.6], device=dev), 1.0,
+                                           cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center,
+                                           False, True, False)
+        n = len(z_vals)
+        means = torch.tensor([[0.0, 0.0, z] for z in z_vals], device=dev, requires_grad=True)
+        shs = (torch.randn(n, 16, 3, device=dev) * 0.3).requires_grad_(True)
+        op = torch.full((n, 1), 0.7, device=dev, requires_grad=True)
+        sc = torch.full((n, 3), 0.1, device=dev, requires_grad=True)
+        rot = torch.tensor([[1.0, 0, 0, 0]] * n, device=dev, requires_grad=True)
+        m2 = torch.zeros(n, 3, device=dev, requires_grad=True)
+        col, radii, invd = GaussianRasterizer(rs)(means3D=means, means2D=m2, opacities=op, shs=shs, scales=sc, rotations=rot)
+        (col.sum() + invd.sum()).backward()
+        torch.cuda.synchronize()
+        assert col.shape == (3, H, W) and torch.isfinite(col).all()
+        for t in (means, shs, op, sc, rot, m2):
+            assert t.grad is not None and torch.isfinite(t.grad).all()
+        if all(z <= 0.2 for z in z_vals):
+            assert int(radii.abs().sum()) == 0
+            assert torch.equal(col.cpu(), torch.tensor([0.2, 0.4, 0.6])[:, None, None].expand(3, H, W))
+            assert all(float(t.grad.abs().max()) == 0.0 for t in (means, shs, op, sc, rot, m2))
+        else:
+            assert int((radii > 0).sum()) == n and float(op.grad.abs().sum()) > 0
+
+
 def test_api_errors_empty_and_mark_visible():
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     dev = torch.device("cuda:0")
