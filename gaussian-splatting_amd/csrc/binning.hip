@@ -83,9 +83,10 @@ scan_finish(int P, const uint32_t* __restrict__ order, const uint32_t* __restric
 // writes its instances as one contiguous, fully coalesced run: output slot k (lane = k mod 64) finds its
 // source Gaussian with a 6-step binary search over the wave's inclusive prefix (held one per lane,
 // fetched with ds_bpermute shuffles), then derives its tile from the Gaussian's rectangle (y-major, x fastest).
+template <typename KeyT>
 __global__ void __launch_bounds__(256)
 emit_instances(int P, int gx, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
-               const uint2* __restrict__ rect, uint32_t* __restrict__ inst_keys, uint32_t* __restrict__ inst_vals,
+               const uint2* __restrict__ rect, KeyT* __restrict__ inst_keys, uint32_t* __restrict__ inst_vals,
                float4* __restrict__ splats) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -131,15 +132,16 @@ emit_instances(int P, int gx, const uint32_t* __restrict__ order, const uint32_t
             const uint32_t ry = local / src_w;
             const uint32_t rx = local - ry * src_w;
             const uint32_t tile = (src_miny + ry) * (uint32_t)gx + src_minx + rx;
-            inst_keys[(int64_t)base + k] = tile;
+            inst_keys[(int64_t)base + k] = (KeyT)tile;
             inst_vals[(int64_t)base + k] = src_id;
         }
     }
 }
 
 // ranges[t] = [first, last+1) of tile t's run in the sorted instance list; untouched tiles stay (0,0)
+template <typename KeyT>
 __global__ void __launch_bounds__(256)
-tile_ranges(int64_t R, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges) {
+tile_ranges(int64_t R, const KeyT* __restrict__ keys, uint2* __restrict__ ranges) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t t = keys[i];
         if (i == 0) {
@@ -166,16 +168,24 @@ void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles, 
 }
 
 void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect,
-                     uint32_t* inst_keys, uint32_t* inst_vals, float4* splats, hipStream_t st) {
+                     void* inst_keys, bool key16, uint32_t* inst_vals, float4* splats, hipStream_t st) {
     const int64_t waves = ((int64_t)P + 63) / 64;
     const int nb = (int)((waves + 3) / 4);
-    hipLaunchKernelGGL(emit_instances, dim3(nb), dim3(256), 0, st, P, gx, order, offsets, rect, inst_keys, inst_vals, splats);
+    if (key16)
+        hipLaunchKernelGGL(emit_instances<uint16_t>, dim3(nb), dim3(256), 0, st, P, gx, order, offsets, rect,
+                           (uint16_t*)inst_keys, inst_vals, splats);
+    else
+        hipLaunchKernelGGL(emit_instances<uint32_t>, dim3(nb), dim3(256), 0, st, P, gx, order, offsets, rect,
+                           (uint32_t*)inst_keys, inst_vals, splats);
 }
 
-void gsr_launch_ranges(int64_t R, int n_tiles, const uint32_t* sorted_keys, uint2* ranges, hipStream_t st) {
+void gsr_launch_ranges(int64_t R, int n_tiles, const void* sorted_keys, bool key16, uint2* ranges, hipStream_t st) {
     (void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)n_tiles, st);
     if (R <= 0) return;
     int64_t nb = (R + 255) / 256;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(tile_ranges, dim3((int)nb), dim3(256), 0, st, R, sorted_keys, ranges);
+    if (key16)
+        hipLaunchKernelGGL(tile_ranges<uint16_t>, dim3((int)nb), dim3(256), 0, st, R, (const uint16_t*)sorted_keys, ranges);
+    else
+        hipLaunchKernelGGL(tile_ranges<uint32_t>, dim3((int)nb), dim3(256), 0, st, R, (const uint32_t*)sorted_keys, ranges);
 }

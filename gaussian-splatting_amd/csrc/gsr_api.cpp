@@ -333,19 +333,26 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
 
     int list_buf = 0;
     if (R > 0) {
+        const bool key16 = n_tiles <= 65536;     // tile ids fit 16 bits: 25 % less sort traffic
         {   StageTimer t(GSR_STAGE_EMIT, st);
-            gsr_launch_emit(P, cam.gx, g.vals[order_buf], g.offsets, g.rect, b.keys[0], b.vals[0],
+            gsr_launch_emit(P, cam.gx, g.vals[order_buf], g.offsets, g.rect, b.keys[0], key16, b.vals[0],
                             settings->no_backward ? nullptr : g.splats, st);
         }
         STAGE_CHECK("emit");
         {   StageTimer t(GSR_STAGE_TILE_SORT, st);
-            list_buf = gsr_radix_sort_pairs(b.keys, b.vals, R, bits_for((uint32_t)n_tiles), GSR_TILE_DIGIT_BITS, b.sort_hist,
-                                            b.digit_total, use_small_blocks(R), st);
+            if (key16) {
+                uint16_t* k16[2] = {(uint16_t*)b.keys[0], (uint16_t*)b.keys[1]};
+                list_buf = gsr_radix_sort_pairs_k16(k16, b.vals, R, bits_for((uint32_t)n_tiles), GSR_TILE_DIGIT_BITS, b.sort_hist,
+                                                    b.digit_total, use_small_blocks(R), st);
+            } else {
+                list_buf = gsr_radix_sort_pairs(b.keys, b.vals, R, bits_for((uint32_t)n_tiles), GSR_TILE_DIGIT_BITS, b.sort_hist,
+                                                b.digit_total, use_small_blocks(R), st);
+            }
         }
         STAGE_CHECK("tile sort");
     }
     {   StageTimer t(GSR_STAGE_RANGES, st);
-        gsr_launch_ranges(R, n_tiles, b.keys[list_buf], im.ranges, st);
+        gsr_launch_ranges(R, n_tiles, b.keys[list_buf], n_tiles <= 65536, im.ranges, st);
     }
     STAGE_CHECK("ranges");
     {   StageTimer t(GSR_STAGE_RENDER, st);

@@ -76,6 +76,8 @@ void gsr_launch_mark_visible(int P, const float* means3D, const float* view, uin
 // ping-pong buffer that holds the result.  n is known on the host.
 int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
                          uint32_t* digit_total, bool small_blocks, hipStream_t st);
+int gsr_radix_sort_pairs_k16(uint16_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
+                             uint32_t* digit_total, bool small_blocks, hipStream_t st);
 // pass plan shared by the sorter and by code that must know which ping-pong buffer holds the result
 int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits /*[8]*/);
 #define GSR_DEPTH_DIGIT_BITS 8      // 32-bit depth keys: 4 passes of 8 bits (3 x 11 bits measured slower: 113 vs 91 us)
@@ -89,9 +91,11 @@ static inline int64_t gsr_sort_blocks(int64_t n, bool small_blocks) {
 void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles, uint32_t* offsets,
                            uint32_t* block_sums, uint32_t* num_rendered, uint32_t* host_word /*mapped pinned, may be NULL*/,
                            uint32_t seq, hipStream_t st);
+// key16: tile ids are stored as uint16_t (frames with <= 65536 tiles), else uint32_t
 void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect,
-                     uint32_t* inst_keys, uint32_t* inst_vals, float4* splats /*NULL: skip the goffset write*/, hipStream_t st);
-void gsr_launch_ranges(int64_t R, int n_tiles, const uint32_t* sorted_keys, uint2* ranges, hipStream_t st);
+                     void* inst_keys, bool key16, uint32_t* inst_vals, float4* splats /*NULL: skip the goffset write*/,
+                     hipStream_t st);
+void gsr_launch_ranges(int64_t R, int n_tiles, const void* sorted_keys, bool key16, uint2* ranges, hipStream_t st);
 
 // render_fwd.hip / render_bwd.hip
 void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,

@@ -206,16 +206,25 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
     bool done = !inside;
     constexpr float LOG2E = 1.4426950408889634f;
 
+    // Software pipeline over the batches of 64 list entries: every batch needs two dependent global loads (list id ->
+    // 64-byte record gather), ~1-2 us under load, while a wave walks only a handful of batches before its pixels
+    // terminate -- un-pipelined the kernel was latency-bound on that chain.  Ids are fetched two batches ahead and
+    // records one batch ahead; the survivor loop in between touches only LDS, so the loads stay in flight across it.
+    auto load_id = [&](uint32_t b) -> uint32_t { return (b + lane < range.y) ? point_list[b + lane] : 0xFFFFFFFFu; };
+    uint32_t id_n1 = load_id(range.x);                    // ids of the batch whose records are fetched next
+    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+    if (id_n1 != 0xFFFFFFFFu) { n0 = splats[id_n1 * 4 + 0]; n1 = splats[id_n1 * 4 + 1]; n2 = splats[id_n1 * 4 + 2]; }
+    id_n1 = load_id(range.x + 64);
     for (uint32_t base = range.x; base < range.y; base += 64) {
         const uint32_t n = min(64u, range.y - base);
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+        float4 q0 = n0, q1 = n1;
+        const float4 q2 = n2;
+        // issue the next batch's record gather and the id fetch of the batch after it
+        if (id_n1 != 0xFFFFFFFFu) { n0 = splats[id_n1 * 4 + 0]; n1 = splats[id_n1 * 4 + 1]; n2 = splats[id_n1 * 4 + 2]; }
+        id_n1 = load_id(base + 128);
         float colb = 0.f, invd = 0.f;
         bool keep = false;
         if ((uint32_t)lane < n) {
-            const uint32_t id = point_list[base + lane];
-            q0 = splats[id * 4 +0];
-            q1 = splats[id * 4 +1];
-            const float4 q2 = splats[id * 4 +2];
             colb = q2.x;
             invd = q2.w;
             const float qmin = min_q_over_box(q0.x, q0.y, q0.z, q0.w, q1.x, x0, x1, y0, y1);

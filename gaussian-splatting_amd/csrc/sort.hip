@@ -32,9 +32,9 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
     return v;
 }
 
-template <int IPT, int BITS>
+template <typename KeyT, int IPT, int BITS>
 __global__ void __launch_bounds__(RS_THREADS)
-rs_hist(const uint32_t* __restrict__ keys, int64_t n, int shift, uint32_t* __restrict__ block_hist, int nblocks) {
+rs_hist(const KeyT* __restrict__ keys, int64_t n, int shift, uint32_t* __restrict__ block_hist, int nblocks) {
     constexpr int NB = 1 << BITS;
     constexpr int NCOPY = (NB <= 256) ? RS_WAVES : 1;     // per-wave copies only when they are cheap
     __shared__ uint32_t h[NCOPY][NB];
@@ -47,7 +47,7 @@ rs_hist(const uint32_t* __restrict__ keys, int64_t n, int shift, uint32_t* __res
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
         const int64_t idx = base + i * RS_THREADS + tid;
-        if (idx < n) atomicAdd(&h[NCOPY == 1 ? 0 : w][(keys[idx] >> shift) & (NB - 1)], 1u);
+        if (idx < n) atomicAdd(&h[NCOPY == 1 ? 0 : w][((uint32_t)keys[idx] >> shift) & (NB - 1)], 1u);
     }
     __syncthreads();
     for (int d = tid; d < NB; d += RS_THREADS) {
@@ -104,17 +104,17 @@ __device__ __forceinline__ uint32_t block_excl_scan(const uint32_t (&v)[DPT], ui
     return wbase + incl - tsum;
 }
 
-template <int IPT, int BITS>
+template <typename KeyT, int IPT, int BITS>
 __global__ void __launch_bounds__(RS_THREADS)
-rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int shift,
+rs_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+           KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int shift,
            const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_total, int nblocks) {
     constexpr int NB = 1 << BITS;
     constexpr int DPT = (NB + RS_THREADS - 1) / RS_THREADS;   // digits per thread (1 for <= 256 bins, 8 for 2048)
     __shared__ uint32_t wave_cnt[RS_WAVES][NB];
     __shared__ uint32_t digit_base[NB];
     __shared__ uint32_t wsum[RS_WAVES];
-    __shared__ uint32_t s_key[RS_THREADS * IPT];
+    __shared__ KeyT s_key[RS_THREADS * IPT];
     __shared__ uint32_t s_val[RS_THREADS * IPT];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 
@@ -147,7 +147,7 @@ rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
     for (int r = 0; r < IPT; ++r) {
         const int64_t idx = wave_base + r * 64 + lane;
         const bool valid = idx < n;
-        key[r] = valid ? keys_in[idx] : 0u;
+        key[r] = valid ? (uint32_t)keys_in[idx] : 0u;
         val[r] = valid ? vals_in[idx] : 0u;
     }
 #pragma unroll
@@ -208,7 +208,7 @@ rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
         if (idx < n) {
             const uint32_t d = (key[r] >> shift) & (NB - 1);
             const uint32_t lp = wave_cnt[w][d] + rank[r];
-            s_key[lp] = key[r];
+            s_key[lp] = (KeyT)key[r];
             s_val[lp] = val[r];
         }
     }
@@ -219,34 +219,56 @@ rs_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ va
     for (int r = 0; r < IPT; ++r) {
         const uint32_t i = (uint32_t)r * RS_THREADS + tid;
         if (i < nvalid) {
-            const uint32_t k = s_key[i];
+            const uint32_t k = (uint32_t)s_key[i];
             const uint32_t pos = digit_base[(k >> shift) & (NB - 1)] + i;
-            keys_out[pos] = k;
+            keys_out[pos] = (KeyT)k;
             vals_out[pos] = s_val[i];
         }
     }
 }
 
-template <int IPT, int BITS>
-void sort_pass(uint32_t* kin, uint32_t* vin, uint32_t* kout, uint32_t* vout, int64_t n, int shift, uint32_t* hist,
+template <typename KeyT, int IPT, int BITS>
+void sort_pass(KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vout, int64_t n, int shift, uint32_t* hist,
                uint32_t* digit_total, int nblocks, hipStream_t st) {
-    hipLaunchKernelGGL((rs_hist<IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, n, shift, hist, nblocks);
+    hipLaunchKernelGGL((rs_hist<KeyT, IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, n, shift, hist, nblocks);
     hipLaunchKernelGGL(rs_scan, dim3(1 << BITS), dim3(RS_THREADS), 0, st, hist, nblocks, digit_total);
-    hipLaunchKernelGGL((rs_scatter<IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, vin, kout, vout, n, shift, hist,
+    hipLaunchKernelGGL((rs_scatter<KeyT, IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, vin, kout, vout, n, shift, hist,
                        digit_total, nblocks);
 }
 
-template <int IPT>
-void sort_pass_bits(int bits, uint32_t* kin, uint32_t* vin, uint32_t* kout, uint32_t* vout, int64_t n, int shift,
+template <typename KeyT, int IPT>
+void sort_pass_bits(int bits, KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vout, int64_t n, int shift,
                     uint32_t* hist, uint32_t* digit_total, int nblocks, hipStream_t st) {
     switch (bits) {
-        case 11: sort_pass<IPT, 11>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
-        case 8: sort_pass<IPT, 8>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
-        case 7: sort_pass<IPT, 7>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
-        case 6: sort_pass<IPT, 6>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
-        case 5: sort_pass<IPT, 5>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
-        default: sort_pass<IPT, 4>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
+        case 11: sort_pass<KeyT, IPT, 11>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
+        case 8: sort_pass<KeyT, IPT, 8>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
+        case 7: sort_pass<KeyT, IPT, 7>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
+        case 6: sort_pass<KeyT, IPT, 6>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
+        case 5: sort_pass<KeyT, IPT, 5>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
+        default: sort_pass<KeyT, IPT, 4>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
     }
+}
+
+template <typename KeyT>
+int sort_pairs_t(KeyT* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
+                 uint32_t* digit_total, bool small_blocks, hipStream_t st) {
+    int cur = 0;
+    if (n <= 0) return cur;
+    const int nblocks = (int)gsr_sort_blocks(n, small_blocks);
+    int pass_bits[8];
+    const int passes = gsr_sort_plan(nbits, max_digit_bits, pass_bits);
+    int shift = 0;
+    for (int p = 0; p < passes; ++p) {
+        if (small_blocks)
+            sort_pass_bits<KeyT, GSR_SORT_ITEMS_SMALL / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1],
+                                                                    n, shift, hist, digit_total, nblocks, st);
+        else
+            sort_pass_bits<KeyT, GSR_SORT_ITEMS / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n,
+                                                              shift, hist, digit_total, nblocks, st);
+        shift += pass_bits[p];
+        cur ^= 1;
+    }
+    return cur;
 }
 
 }  // namespace
@@ -269,21 +291,11 @@ int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits) {
 
 int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
                          uint32_t* digit_total, bool small_blocks, hipStream_t st) {
-    int cur = 0;
-    if (n <= 0) return cur;
-    const int nblocks = (int)gsr_sort_blocks(n, small_blocks);
-    int pass_bits[8];
-    const int passes = gsr_sort_plan(nbits, max_digit_bits, pass_bits);
-    int shift = 0;
-    for (int p = 0; p < passes; ++p) {
-        if (small_blocks)
-            sort_pass_bits<GSR_SORT_ITEMS_SMALL / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n,
-                                                              shift, hist, digit_total, nblocks, st);
-        else
-            sort_pass_bits<GSR_SORT_ITEMS / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift,
-                                                        hist, digit_total, nblocks, st);
-        shift += pass_bits[p];
-        cur ^= 1;
-    }
-    return cur;
+    return sort_pairs_t<uint32_t>(keys, vals, n, nbits, max_digit_bits, hist, digit_total, small_blocks, st);
+}
+
+// 16-bit keys (tile ids when the frame has <= 65536 tiles): 25 % less traffic per pass than 32-bit keys
+int gsr_radix_sort_pairs_k16(uint16_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
+                             uint32_t* digit_total, bool small_blocks, hipStream_t st) {
+    return sort_pairs_t<uint16_t>(keys, vals, n, nbits, max_digit_bits, hist, digit_total, small_blocks, st);
 }
