@@ -81,10 +81,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the product path)"
+    # Test hook (tests/test_gpu_next_rows.py): GSR_BENCH_SHARED_GPU=1 + GSR_BENCH_BACKEND=gloo run the N-rank code path
+    # with all ranks on device 0 of a single-GPU box (RCCL refuses two ranks on one device).  Never set by the driver.
+    shared_gpu = os.environ.get("GSR_BENCH_SHARED_GPU") == "1"
+    backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from gsr_synth import make_camera, make_scene

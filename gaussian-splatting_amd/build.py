@@ -34,6 +34,7 @@ UNITS = [
     ("render_bwd.hip", ["-ffp-contract=fast"]),
     ("adam.hip", ["-ffp-contract=off"]),
     ("ssim.hip", ["-ffp-contract=fast"]),
+    ("knn.hip", ["-ffp-contract=off"]),
     ("gsr_api.cpp", ["-x", "hip"]),
 ]
 

@@ -49,7 +49,37 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
     }
 }
 
+// Sparse variant (SparseGaussianAdam.step(visibility, N), train.py:180-183): the tensor is N rows of M elements; rows of
+// Gaussians that were not visible in this iteration are skipped entirely -- parameter AND both moments stay untouched.
+// [RECALLED, un-vendored source] the reference's kernel applies no bias correction:
+//   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g g;  p += -lr m / (sqrt(v) + eps)
+__global__ void __launch_bounds__(256)
+sparse_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                   const uint8_t* __restrict__ visible, int64_t N, int64_t M, float lr, float b1, float om_b1, float b2,
+                   float om_b2, float eps) {
+    const int64_t n = N * M;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (!visible[i / M]) continue;
+        const float gg = g[i];
+        const float mm = b1 * m[i] + om_b1 * gg;
+        const float vv = b2 * v[i] + om_b2 * gg * gg;
+        p[i] += -lr * mm / (sqrtf(vv) + eps);
+        m[i] = mm;
+        v[i] = vv;
+    }
+}
+
 }  // namespace
+
+void gsr_launch_sparse_adam(float* p, const float* g, float* m, float* v, const uint8_t* visible, int64_t N, int64_t M,
+                            double lr, double beta1, double beta2, double eps, hipStream_t st) {
+    const int64_t n = N * M;
+    if (n <= 0) return;
+    int64_t nb = (n + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(sparse_adam_kernel, dim3((int)nb), dim3(256), 0, st, p, g, m, v, visible, N, M, (float)lr, (float)beta1,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps);
+}
 
 void gsr_launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
                      int step, hipStream_t st) {

@@ -102,6 +102,8 @@ int make_cam(const GsrRasterSettings* s, int M, GsrCamDev& c) {
     c.proj = s->projmatrix;
     c.campos = s->campos;
     c.bg = s->bg;
+    c.sh_dc = s->sh_dc;
+    c.dL_dsh_dc = s->dL_dsh_dc;
     return GSR_OK;
 }
 
@@ -120,6 +122,15 @@ int check_inputs(int P, int M, const float* means3D, const float* shs, const flo
         if (M <= 0 || M > 16) return fail(GSR_ERR_UNSUPPORTED, "SH coefficient count M must be 1..16");
         if ((sh_degree + 1) * (sh_degree + 1) > M) return fail(GSR_ERR_INVALID_ARG, "sh_degree needs more coefficients than M");
     }
+    return GSR_OK;
+}
+
+// split SH form (settings->sh_dc): coefficient 0 in sh_dc[P,1,3], coefficients 1..M-1 in shs[P,M-1,3]
+int check_split_sh(const GsrRasterSettings* s, int P, int M, const float* shs, bool backward) {
+    if (!s->sh_dc || P == 0) return GSR_OK;
+    if (!shs) return fail(GSR_ERR_INVALID_ARG, "sh_dc given without shs (the coefficients 1..M-1)");
+    if (M < 2) return fail(GSR_ERR_UNSUPPORTED, "split SH form needs M >= 2 (pass the DC term as shs with M = 1 instead)");
+    if (backward && !s->dL_dsh_dc) return fail(GSR_ERR_INVALID_ARG, "sh_dc given but dL_dsh_dc is NULL");
     return GSR_OK;
 }
 
@@ -256,6 +267,8 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
     int rc = make_cam(settings, M, cam);
     if (rc != GSR_OK) return rc;
     rc = check_inputs(P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, cam.sh_degree);
+    if (rc != GSR_OK) return rc;
+    rc = check_split_sh(settings, P, M, shs, false);
     if (rc != GSR_OK) return rc;
     if (!out_color || !num_rendered) return fail(GSR_ERR_INVALID_ARG, "out_color / num_rendered are NULL");
     const size_t npix = (size_t)cam.W * cam.H;
@@ -409,7 +422,7 @@ int gsr_backward_blend(const GsrRasterSettings* settings, int P, int32_t num_ren
     STAGE_CHECK("render backward blend");
     if (g_render_bwd_variant != 1 && num_rendered > 0) {
         StageTimer t(GSR_STAGE_GATHER_BWD, st);
-        gsr_launch_reduce_instances(P, g.vals[depth_order_buffer_index()], g.offsets, g.tiles, w.inst_grads, w.inst_flag, sg, st);
+        gsr_launch_reduce_instances(P, g.vals[depth_order_buffer_index()], g.offsets, g.splats, w.inst_grads, w.inst_flag, sg, st);
     }
     STAGE_CHECK("render backward reduce");
     HIP_OK(hipGetLastError());
@@ -427,6 +440,8 @@ int gsr_backward_preprocess(const GsrRasterSettings* settings, int P, int M, con
     int rc = make_cam(settings, M, cam);
     if (rc != GSR_OK) return rc;
     rc = check_inputs(P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, cam.sh_degree);
+    if (rc != GSR_OK) return rc;
+    rc = check_split_sh(settings, P, M, shs, true);
     if (rc != GSR_OK) return rc;
     if (P == 0) return GSR_OK;
     if (!radii || !geom_buffer || !splat_grads) return fail(GSR_ERR_INVALID_ARG, "radii / geometry buffer / splat_grads are NULL");
@@ -469,6 +484,27 @@ int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
     if (n == 0) return GSR_OK;
     if (!param || !grad || !exp_avg || !exp_avg_sq) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
     gsr_launch_adam(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, (hipStream_t)stream);
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_sparse_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* visible,
+                         int64_t N, int64_t M, double lr, double beta1, double beta2, double eps, void* stream) {
+    if (N < 0 || M < 0) return fail(GSR_ERR_INVALID_ARG, "N < 0 or M < 0");
+    if (N == 0 || M == 0) return GSR_OK;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !visible) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
+    gsr_launch_sparse_adam(param, grad, exp_avg, exp_avg_sq, visible, N, M, lr, beta1, beta2, eps, (hipStream_t)stream);
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
+}
+
+size_t gsr_knn_scratch_bytes(int N) { return gsr_knn_scratch_bytes_impl(N); }
+
+int gsr_knn_mean_dist2(int N, const float* points, float* mean_dist2, void* scratch, void* stream) {
+    if (N < 0) return fail(GSR_ERR_INVALID_ARG, "N < 0");
+    if (N == 0) return GSR_OK;
+    if (!points || !mean_dist2 || !scratch) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
+    gsr_launch_knn(N, points, mean_dist2, scratch, (hipStream_t)stream);
     HIP_OK(hipGetLastError());
     return GSR_OK;
 }

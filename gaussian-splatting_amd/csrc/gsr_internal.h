@@ -15,6 +15,8 @@ struct GsrCamDev {
     const float* proj;
     const float* campos;
     const float* bg;
+    const float* sh_dc;      // split SH form (GsrRasterSettings.sh_dc), else NULL
+    float* dL_dsh_dc;
 };
 
 // ---- scratch layouts (GeometryState / BinningState / ImageState), 128-byte aligned carve ----
@@ -105,7 +107,7 @@ void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const
                                 const float4* splats, const float* final_T, const uint32_t* n_contrib,
                                 const float* dL_dpix, const float* dL_dinvdepth, float* splat_grads /*[P,12] variant 1*/,
                                 float* inst_grads /*[R,12] variant 0*/, uint8_t* inst_flag /*[R]*/, int variant, hipStream_t st);
-void gsr_launch_reduce_instances(int P, const uint32_t* order, const uint32_t* offsets, const uint32_t* tiles,
+void gsr_launch_reduce_instances(int P, const uint32_t* order, const uint32_t* offsets, const float4* splats,
                                  const float* inst_grads, const uint8_t* inst_flag, float* splat_grads, hipStream_t st);
 
 // backward scratch (caller-owned, gsr_backward_scratch_bytes): per-Gaussian record, per-instance records, maps
@@ -126,3 +128,10 @@ void gsr_launch_ssim_forward(int planes, int H, int W, const float* img1, const 
                              float* dm_dex2, float* dm_dexy, hipStream_t st);
 void gsr_launch_ssim_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dmap,
                               const float* dm_dmu1, const float* dm_dex2, const float* dm_dexy, float* dL_dimg1, hipStream_t st);
+
+// adam.hip: sparse step (rows of M elements, skipped entirely when visible[row] == 0)
+void gsr_launch_sparse_adam(float* p, const float* g, float* m, float* v, const uint8_t* visible, int64_t N, int64_t M,
+                            double lr, double beta1, double beta2, double eps, hipStream_t st);
+// knn.hip
+size_t gsr_knn_scratch_bytes_impl(int N);
+void gsr_launch_knn(int N, const float* points, float* out, void* scratch, hipStream_t st);

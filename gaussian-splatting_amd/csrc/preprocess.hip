@@ -56,6 +56,125 @@ __device__ __forceinline__ void wave_store_sh16(float* __restrict__ dst_all, int
     __builtin_amdgcn_wave_barrier();
 }
 
+// "separate_sh" call form (gaussian_renderer/__init__.py:82-100): coefficient 0 lives in dc[P,1,3], coefficients 1..15
+// in rest[P,15,3].  Both blocks of the wave's 64 Gaussians are contiguous (768 B and 11520 B) and are moved with
+// 16-byte accesses; the LDS row has the same layout as in the fused case (dc in floats 0..2, rest in 3..47).
+__device__ __forceinline__ void wave_load_sh_split(const float* __restrict__ dc, const float* __restrict__ rest, int64_t i0,
+                                                   int P, uint64_t rows, int lane, float* tile) {
+    const int nrow = (int)((P - i0) < 64 ? (P - i0) : 64);
+    const float* src = rest + i0 * 45;
+    const int nrest = nrow * 45;
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        const int f = (it * 64 + lane) * 4;
+        if (f < nrest) {
+            const int g0 = f / 45, g1 = (f + 3) / 45 < nrow ? (f + 3) / 45 : nrow - 1;
+            if (((rows >> g0) | (rows >> g1)) & 1ull) {
+                float v[4];
+                if (f + 3 < nrest) {
+                    const float4 t = *reinterpret_cast<const float4*>(src + f);
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = f + c < nrest ? src[f + c] : 0.f;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int ff = f + c;
+                    if (ff < nrest) {
+                        const int g = ff / 45;
+                        tile[g * SH_ROW + 3 + (ff - g * 45)] = v[c];
+                    }
+                }
+            }
+        }
+    }
+    {
+        const float* sdc = dc + i0 * 3;
+        const int ndc = nrow * 3, f = lane * 4;
+        if (f < ndc) {
+            float v[4];
+            if (f + 3 < ndc) {
+                const float4 t = *reinterpret_cast<const float4*>(sdc + f);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = f + c < ndc ? sdc[f + c] : 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ff = f + c;
+                if (ff < ndc) {
+                    const int g = ff / 3;
+                    tile[g * SH_ROW + (ff - g * 3)] = v[c];
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void wave_store_sh_split(float* __restrict__ d_dc, float* __restrict__ d_rest, int64_t i0, int P,
+                                                    int lane, const float* tile) {
+    const int nrow = (int)((P - i0) < 64 ? (P - i0) : 64);
+    float* dst = d_rest + i0 * 45;
+    const int nrest = nrow * 45;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        const int f = (it * 64 + lane) * 4;
+        if (f < nrest) {
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ff = f + c < nrest ? f + c : nrest - 1;
+                const int g = ff / 45;
+                v[c] = tile[g * SH_ROW + 3 + (ff - g * 45)];
+            }
+            if (f + 3 < nrest) {
+                *reinterpret_cast<float4*>(dst + f) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (f + c < nrest) dst[f + c] = v[c];
+            }
+        }
+    }
+    {
+        float* ddc = d_dc + i0 * 3;
+        const int ndc = nrow * 3, f = lane * 4;
+        if (f < ndc) {
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ff = f + c < ndc ? f + c : ndc - 1;
+                const int g = ff / 3;
+                v[c] = tile[g * SH_ROW + (ff - g * 3)];
+            }
+            if (f + 3 < ndc) {
+                *reinterpret_cast<float4*>(ddc + f) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (f + c < ndc) ddc[f + c] = v[c];
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+// un-staged fallback of the split form (M != 16 or unaligned pointers): assemble the record in registers / scratch
+__device__ __forceinline__ void gather_sh_split(const float* __restrict__ dc, const float* __restrict__ rest, int64_t i, int M,
+                                                float* rec) {
+    rec[0] = dc[i * 3 + 0]; rec[1] = dc[i * 3 + 1]; rec[2] = dc[i * 3 + 2];
+    const float* r = rest + i * (int64_t)(M - 1) * 3;
+    for (int k = 3; k < M * 3; ++k) rec[k] = r[k - 3];
+}
+__device__ __forceinline__ void scatter_sh_split(float* __restrict__ d_dc, float* __restrict__ d_rest, int64_t i, int M,
+                                                 const float* rec) {
+    d_dc[i * 3 + 0] = rec[0]; d_dc[i * 3 + 1] = rec[1]; d_dc[i * 3 + 2] = rec[2];
+    float* r = d_rest + i * (int64_t)(M - 1) * 3;
+    for (int k = 3; k < M * 3; ++k) r[k - 3] = rec[k];
+}
+
 __global__ void __launch_bounds__(256)
 preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
                       const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -68,7 +187,8 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
     load_cam(camd, cam);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* tile = s_sh[wv];
-    const bool staged_sh = shs != nullptr && cam.M == 16;
+    const float* dc = camd.sh_dc;          // non-NULL: split form, `shs` holds coefficients 1..M-1
+    const bool staged_sh = shs != nullptr && cam.M == 16 && (dc == nullptr || ((((uintptr_t)dc) | ((uintptr_t)shs)) & 15) == 0);
     // wave-uniform trip count: every lane of a wave runs the same iterations (lanes past P idle inside)
     for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < P; i0 += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = i0 + lane;
@@ -96,7 +216,10 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         const bool need_color = vis && sp.tiles > 0;
         if (staged_sh) {
             const uint64_t rows = __ballot(need_color);
-            if (rows) wave_load_sh16(shs, i0, P, rows, lane, tile);
+            if (rows) {
+                if (dc) wave_load_sh_split(dc, shs, i0, P, rows, lane, tile);
+                else wave_load_sh16(shs, i0, P, rows, lane, tile);
+            }
         }
         if (!in_range) continue;
         uint32_t clampbits = 0;
@@ -109,6 +232,10 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
                 rgb[0] = colors_precomp[i * 3 + 0]; rgb[1] = colors_precomp[i * 3 + 1]; rgb[2] = colors_precomp[i * 3 + 2];
             } else if (staged_sh) {
                 gsr_sh_to_rgb(cam.sh_degree, 16, tile + lane * SH_ROW, mean, cam.campos, rgb, clampbits);
+            } else if (dc) {
+                __attribute__((aligned(16))) float rec[48];
+                gather_sh_split(dc, shs, i, cam.M, rec);
+                gsr_sh_to_rgb(cam.sh_degree, cam.M, rec, mean, cam.campos, rgb, clampbits);
             } else {
                 gsr_sh_to_rgb(cam.sh_degree, cam.M, shs + i * (int64_t)cam.M * 3, mean, cam.campos, rgb, clampbits);
             }
@@ -150,7 +277,10 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
     const int M = cam.M;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* tile = s_sh[wv];
-    const bool staged_sh = shs != nullptr && M == 16;
+    const float* dc = camd.sh_dc;          // split form: `shs` / dL_dsh hold coefficients 1..M-1, dc / dL_ddc coefficient 0
+    float* dL_ddc = camd.dL_dsh_dc;
+    const bool staged_sh = shs != nullptr && M == 16 &&
+                           (dc == nullptr || ((((uintptr_t)dc) | ((uintptr_t)shs) | ((uintptr_t)dL_ddc) | ((uintptr_t)dL_dsh)) & 15) == 0);
     for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < P; i0 += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = i0 + lane;
         const bool in_range = i < P;
@@ -164,7 +294,10 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         const bool vis = in_range && radii[i] > 0;
         if (staged_sh) {
             const uint64_t rows = __ballot(vis);
-            if (rows) wave_load_sh16(shs, i0, P, rows, lane, tile);
+            if (rows) {
+                if (dc) wave_load_sh_split(dc, shs, i0, P, rows, lane, tile);
+                else wave_load_sh16(shs, i0, P, rows, lane, tile);
+            }
         }
         if (vis) {
             const float4 g0 = grads[i * 3 + 0], g1 = grads[i * 3 + 1], g2 = grads[i * 3 + 2];
@@ -200,6 +333,12 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
                     gsr_sh_to_rgb(cam.sh_degree, 16, tile + lane * SH_ROW, mean, cam.campos, rgb_unused, clampbits);
                     gsr_sh_backward(cam.sh_degree, 16, tile + lane * SH_ROW, mean, cam.campos, clampbits, drgb,
                                     tile + lane * SH_ROW, dmean);
+                } else if (dc) {
+                    __attribute__((aligned(16))) float rec[48];
+                    gather_sh_split(dc, shs, i, M, rec);
+                    gsr_sh_to_rgb(cam.sh_degree, M, rec, mean, cam.campos, rgb_unused, clampbits);
+                    gsr_sh_backward(cam.sh_degree, M, rec, mean, cam.campos, clampbits, drgb, rec, dmean);
+                    scatter_sh_split(dL_ddc, dL_dsh, i, M, rec);
                 } else {
                     gsr_sh_to_rgb(cam.sh_degree, M, shs + i * (int64_t)M * 3, mean, cam.campos, rgb_unused, clampbits);
                     gsr_sh_backward(cam.sh_degree, M, shs + i * (int64_t)M * 3, mean, cam.campos, clampbits, drgb,
@@ -210,12 +349,19 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             if (staged_sh) {
 #pragma unroll
                 for (int k = 0; k < 12; ++k) *reinterpret_cast<float4*>(tile + lane * SH_ROW + k * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if (in_range && dc) {
+                dL_ddc[i * 3 + 0] = 0.f; dL_ddc[i * 3 + 1] = 0.f; dL_ddc[i * 3 + 2] = 0.f;
+                float* o = dL_dsh + i * (int64_t)(M - 1) * 3;
+                for (int k = 0; k < (M - 1) * 3; ++k) o[k] = 0.f;
             } else if (in_range) {
                 float* o = dL_dsh + i * (int64_t)M * 3;
                 for (int k = 0; k < M * 3; ++k) o[k] = 0.f;
             }
         }
-        if (staged_sh) wave_store_sh16(dL_dsh, i0, P, lane, tile);
+        if (staged_sh) {
+            if (dc) wave_store_sh_split(dL_ddc, dL_dsh, i0, P, lane, tile);
+            else wave_store_sh16(dL_dsh, i0, P, lane, tile);
+        }
         if (!in_range) continue;
         dL_dmeans2D[i * 3 + 0] = dm2x; dL_dmeans2D[i * 3 + 1] = dm2y; dL_dmeans2D[i * 3 + 2] = 0.f;
         dL_dcolors[i * 3 + 0] = drgb[0]; dL_dcolors[i * 3 + 1] = drgb[1]; dL_dcolors[i * 3 + 2] = drgb[2];

@@ -69,6 +69,17 @@ __device__ __forceinline__ float reduce4(float a, float b, float c, float d) {
     return v;
 }
 
+// Two values summed over the wave: lane 31 -> sum(a), lane 63 -> sum(b)
+__device__ __forceinline__ float reduce2(float a, float b) {
+    float v = fold32(a, b);
+    v = dpp_add<0x111, 0xf>(v);
+    v = dpp_add<0x112, 0xf>(v);
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3
+    return v;
+}
+
 __device__ __forceinline__ float min_q_over_box(float mx, float my, float A, float B, float C, float x0, float x1,
                                                 float y0, float y1) {
     const float lx = x0 - mx, hx = x1 - mx, ly = y0 - my, hy = y1 - my;
@@ -93,48 +104,57 @@ __device__ __forceinline__ float bcast(float v, int srclane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
 }
 
-// per-pixel running state of the back-to-front walk (Appendix A.5)
+// per-pixel running state of the back-to-front walk (Appendix A.5).  The reference keeps one running colour per channel
+// ("accum_rec") and dots (c - accum) with dL/dpixel afterwards; both are linear in the channel, so the walk here carries
+// the already-dotted scalars: accD = <accum, dL/dpix>, lastD = <last colour, dL/dpix> -- 2 VALU ops per step instead of 12.
 struct BwdPix {
-    float T, acc_r, acc_g, acc_b, acc_d, last_alpha, last_r, last_g, last_b, last_d;
+    float T, accD, lastD, last_alpha;
 };
 
-// One (pixel, Gaussian) step.  Conic is given both plain (A,B,C) and log2-scaled (a2,b2,c2).  Outputs are zero when the
-// pixel does not take part (hard masks: behind n_contrib, power > 0, alpha < 1/255).
-__device__ __forceinline__ bool bwd_step(BwdPix& s, bool take, float pxf, float pyf, float T_final, float bg_dot, float dLr,
-                                         float dLg, float dLb, float dLd, float gx_, float gy_, float A, float B, float C,
-                                         float a2, float b2, float c2, float op, float cr, float cg, float cb, float idp,
-                                         float& g_px, float& g_py, float& g_A, float& g_B, float& g_C, float& g_op,
-                                         float& g_r, float& g_g, float& g_b, float& g_d) {
+// One (pixel, Gaussian) step.  Outputs are zero when the pixel does not take part (hard masks: behind n_contrib,
+// power > 0, alpha < 1/255).  The five geometric outputs are the raw MOMENTS of m = dL/dG * G over the pixel offsets,
+//     mx = m dx, my = m dy, mxx = m dx^2, mxy = m dx dy, myy = m dy^2,
+// not the derivatives themselves: the derivatives are linear in the moments with per-Gaussian coefficients
+//     dL/dpx = -A mx - B my,  dL/dpy = -C my - B mx,  dL/dA = -mxx/2,  dL/dB = -mxy,  dL/dC = -myy/2
+// so that multiplication is done ONCE per Gaussian after all sums (bwd_reduce_instances) instead of per pair.
+__device__ __forceinline__ bool bwd_step(BwdPix& s, bool take, float pxf, float pyf, float Tf_bg, float dLr, float dLg,
+                                         float dLb, float dLd, float gx_, float gy_, float a2, float b2, float c2, float op,
+                                         float cr, float cg, float cb, float idp, float& mx, float& my, float& mxx,
+                                         float& mxy, float& myy, float& g_op, float& g_r, float& g_g, float& g_b,
+                                         float& g_d) {
     const float dx = gx_ - pxf, dy = gy_ - pyf;
     const float t = fmaf(b2, dy, a2 * dx);
     const float p2 = fmaf(dx, t, (c2 * dy) * dy);
     const float G = __builtin_amdgcn_exp2f(p2);
     const float alpha = fminf(GSR_ALPHA_MAX, op * G);
     const bool active = take & (p2 <= 0.0f) & (alpha >= GSR_ALPHA_MIN);
-    g_px = g_py = g_A = g_B = g_C = g_op = g_r = g_g = g_b = g_d = 0.0f;
+    const float cD = fmaf(idp, dLd, fmaf(cb, dLb, fmaf(cg, dLg, cr * dLr)));
+    float w = 0.0f, dL_dalpha = 0.0f;
     if (active) {
         const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
         s.T = s.T * inv1ma;
-        const float w = alpha * s.T;
-        s.acc_r = fmaf(s.last_alpha, s.last_r - s.acc_r, s.acc_r);
-        s.acc_g = fmaf(s.last_alpha, s.last_g - s.acc_g, s.acc_g);
-        s.acc_b = fmaf(s.last_alpha, s.last_b - s.acc_b, s.acc_b);
-        s.acc_d = fmaf(s.last_alpha, s.last_d - s.acc_d, s.acc_d);
-        s.last_r = cr; s.last_g = cg; s.last_b = cb; s.last_d = idp;
-        float dL_dalpha = (cr - s.acc_r) * dLr + (cg - s.acc_g) * dLg + (cb - s.acc_b) * dLb + (idp - s.acc_d) * dLd;
-        g_r = w * dLr; g_g = w * dLg; g_b = w * dLb; g_d = w * dLd;
-        dL_dalpha = fmaf(dL_dalpha, s.T, (-T_final * inv1ma) * bg_dot);
+        w = alpha * s.T;
+        s.accD = fmaf(s.last_alpha, s.lastD - s.accD, s.accD);
+        s.lastD = cD;
         s.last_alpha = alpha;
-        const float dL_dG = op * dL_dalpha;
-        const float gdx = G * dx, gdy = G * dy;
-        g_px = dL_dG * (-gdx * A - gdy * B);
-        g_py = dL_dG * (-gdy * C - gdx * B);
-        g_A = -0.5f * gdx * dx * dL_dG;
-        g_B = -gdx * dy * dL_dG;
-        g_C = -0.5f * gdy * dy * dL_dG;
-        g_op = G * dL_dalpha;
+        dL_dalpha = fmaf(cD - s.accD, s.T, Tf_bg * inv1ma);      // Tf_bg = -T_final * <bg, dL/dpix>
     }
+    g_r = w * dLr; g_g = w * dLg; g_b = w * dLb; g_d = w * dLd;
+    g_op = G * dL_dalpha;
+    const float m = op * g_op;
+    mx = m * dx; my = m * dy;
+    mxx = mx * dx; mxy = mx * dy; myy = my * dy;
     return active;
+}
+
+// per-Gaussian conversion of the summed moments into the derivatives (record layout of the file header)
+__device__ __forceinline__ void moments_to_grads(float A, float B, float C, float4& u0, float4& u1) {
+    const float mx = u0.x, my = u0.y, mxx = u0.z, mxy = u0.w, myy = u1.x;
+    u0.x = -A * mx - B * my;
+    u0.y = -C * my - B * mx;
+    u0.z = -0.5f * mxx;
+    u0.w = -mxy;
+    u1.x = -0.5f * myy;
 }
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -145,7 +165,7 @@ __device__ __forceinline__ uint32_t emission_index(const float4 q3, uint32_t tx,
     const uint32_t minx = rx & 0xFFFFu, w = (rx >> 16) - minx, miny = ry & 0xFFFFu;
     return goff + (ty - miny) * w + (tx - minx);
 }
-constexpr int REC_STRIDE = 5;      // float4 per staged entry (80 B: conflict-free per-lane ds_read_b128)
+constexpr int REC_STRIDE = 3;      // float4 per staged entry (48 B: 12-word stride, 3 coprime to 16 -> per-lane ds_read_b128 is conflict-free)
 
 // ------------------------------------------------------------------------------------------------
 // default: workgroup per tile, per-instance gradient records, no global atomics
@@ -161,7 +181,7 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
                 const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                 const float* __restrict__ dL_dinvdepth, float4* __restrict__ inst_grads,
                 uint8_t* __restrict__ inst_flag) {
-    __shared__ float4 s_rec[SB * REC_STRIDE];   // 20 KB
+    __shared__ float4 s_rec[SB * REC_STRIDE];   // 12 KB
     __shared__ float s_grad[SB * 12];           // 12 KB
     __shared__ uint32_t s_k[SB];                // emission index of every staged entry
     __shared__ uint32_t s_touch[SB];            // entry received a contribution from some wave of the tile
@@ -187,7 +207,7 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
     const float dLg = inside ? dL_dpix[HW + pix] : 0.f;
     const float dLb = inside ? dL_dpix[2 * HW + pix] : 0.f;
     const float dLd = (inside && dL_dinvdepth) ? dL_dinvdepth[pix] : 0.f;
-    const float bg_dot = cam.bg[0] * dLr + cam.bg[1] * dLg + cam.bg[2] * dLb;
+    const float Tf_bg = -T_final * (cam.bg[0] * dLr + cam.bg[1] * dLg + cam.bg[2] * dLb);
 
     uint32_t mx = last_contrib;
 #pragma unroll
@@ -203,7 +223,7 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
     // rectangle and goffset read from the 4th quad of the 64-byte splat record.
     if (end == 0) return;
 
-    BwdPix s = {T_final, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    BwdPix s = {T_final, 0.f, 0.f, 0.f};
     float4* s_grad4 = reinterpret_cast<float4*>(s_grad);
 
     for (int sb = (int)((end - 1) / SB) * SB; sb >= 0; sb -= SB) {
@@ -214,10 +234,11 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
             const float4 q0 = splats[id * 4 +0];
             const float4 q1 = splats[id * 4 +1];
             const float4 q2 = splats[id * 4 +2];
-            s_rec[tid * REC_STRIDE + 0] = q0;                                           // x, y, A, B
-            s_rec[tid * REC_STRIDE + 1] = q1;                                           // C, opacity, r, g
-            s_rec[tid * REC_STRIDE + 2] = make_float4(q2.x, q2.w, -0.5f * LOG2E * q0.z, -LOG2E * q0.w);   // b, 1/depth, a2, b2
-            s_rec[tid * REC_STRIDE + 3] = make_float4(-0.5f * LOG2E * q1.x, q2.z, 0.f, 0.f);              // c2, tau
+            // staged entry: (x, y, a2, b2 | c2, opacity, r, g | b, 1/depth, tau, -) with the log2-scaled conic
+            // a2 = -0.5 log2(e) A, b2 = -log2(e) B, c2 = -0.5 log2(e) C (power in base 2 = a2 dx^2 + b2 dx dy + c2 dy^2)
+            s_rec[tid * REC_STRIDE + 0] = make_float4(q0.x, q0.y, -0.5f * LOG2E * q0.z, -LOG2E * q0.w);
+            s_rec[tid * REC_STRIDE + 1] = make_float4(-0.5f * LOG2E * q1.x, q1.y, q1.z, q1.w);
+            s_rec[tid * REC_STRIDE + 2] = make_float4(q2.x, q2.w, q2.z, 0.f);
             s_k[tid] = emission_index(splats[id * 4 + 3], (uint32_t)tx, (uint32_t)ty);
         }
         for (int i = tid; i < SB * 3; i += 256) s_grad4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -230,10 +251,12 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
                 bool keep = false;
                 if (e < n) {
                     const float4 r0 = s_rec[e * REC_STRIDE + 0];
-                    const float4 r3 = s_rec[e * REC_STRIDE + 3];
-                    const float C = s_rec[e * REC_STRIDE + 1].x;
-                    const float qmin = min_q_over_box(r0.x, r0.y, r0.z, r0.w, C, x0, x1, y0, y1);
-                    keep = !(qmin > r3.y);
+                    const float c2e = s_rec[e * REC_STRIDE + 1].x;
+                    const float tau = s_rec[e * REC_STRIDE + 2].z;
+                    // plain conic back from the scaled one (the test has a 0.01 margin in tau: the extra rounding is harmless)
+                    const float qmin = min_q_over_box(r0.x, r0.y, r0.z * (-2.0f / LOG2E), r0.w * (-1.0f / LOG2E),
+                                                      c2e * (-2.0f / LOG2E), x0, x1, y0, y1);
+                    keep = !(qmin > tau);
                 }
                 uint64_t mask = __ballot(keep);
                 while (mask) {
@@ -243,13 +266,12 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
                     const uint32_t pos0 = (uint32_t)sb + entry;          // 0-based list position
                     const float4 r0 = s_rec[entry * REC_STRIDE + 0];
                     const float4 r1 = s_rec[entry * REC_STRIDE + 1];
-                    const float4 r2 = s_rec[entry * REC_STRIDE + 2];
-                    const float c2 = s_rec[entry * REC_STRIDE + 3].x;
-                    float g_px, g_py, g_A, g_B, g_C, g_op, g_r, g_g, g_b, g_d;
-                    const bool active = bwd_step(s, pos0 < last_contrib, pxf, pyf, T_final, bg_dot, dLr, dLg, dLb, dLd, r0.x,
-                                                 r0.y, r0.z, r0.w, r1.x, r2.z, r2.w, c2, r1.y, r1.z, r1.w, r2.x, r2.y, g_px,
-                                                 g_py, g_A, g_B, g_C, g_op, g_r, g_g, g_b, g_d);
-                    if (__ballot(active) == 0ull) continue;
+                    const float2 r2 = *reinterpret_cast<const float2*>(&s_rec[entry * REC_STRIDE + 2]);
+                    float g_px, g_py, g_A, g_B, g_C, g_op, g_r, g_g, g_b, g_d;     // g_px .. g_C hold the raw moments
+                    const bool active = bwd_step(s, pos0 < last_contrib, pxf, pyf, Tf_bg, dLr, dLg, dLb, dLd, r0.x, r0.y, r0.z,
+                                                 r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, g_px, g_py, g_A, g_B, g_C, g_op,
+                                                 g_r, g_g, g_b, g_d);
+                    if (__builtin_amdgcn_ballot_w64(active) == 0ull) continue;
                     if (ABLATE >= 1) {
                         asm volatile("" ::"v"(g_px), "v"(g_py), "v"(g_A), "v"(g_B), "v"(g_C), "v"(g_op), "v"(g_r), "v"(g_g), "v"(g_b), "v"(g_d));
                         if (lane == 15) s_touch[entry] = 1u;
@@ -258,12 +280,12 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
                     // slots in lanes 15 / 31 / 47 / 63 = first / third / second / fourth argument
                     const float v0 = reduce4(g_px, g_A, g_py, g_B);     // -> slots 0,1,2,3
                     const float v1 = reduce4(g_C, g_r, g_op, g_g);      // -> slots 4,5,6,7
-                    const float v2 = reduce4(g_b, 0.f, g_d, 0.f);       // -> slots 8,9
+                    const float v2 = reduce2(g_b, g_d);                 // -> slots 8 (lane 31), 9 (lane 63)
                     if ((lane & 15) == 15) {
                         float* o = s_grad + entry * 12 + (lane >> 4);
                         atomicAdd(o, v0);
                         atomicAdd(o + 4, v1);
-                        if (lane < 32) atomicAdd(o + 8, v2);
+                        if (lane & 16) atomicAdd(s_grad + entry * 12 + 8 + (lane >> 5), v2);
                         if (lane == 15) s_touch[entry] = 1u;
                     }
                 }
@@ -294,7 +316,7 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
 __global__ void __launch_bounds__(256)
 bwd_reduce_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
                      const float4* __restrict__ inst_grads, const uint8_t* __restrict__ inst_flag,
-                     float4* __restrict__ splat_grads) {
+                     const float4* __restrict__ splats, float4* __restrict__ splat_grads) {
     __shared__ float s_acc[4][64 * 12];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -352,8 +374,12 @@ bwd_reduce_instances(int P, const uint32_t* __restrict__ order, const uint32_t* 
     if (j < P) {
         const uint32_t g = order[j];
         const float4* a4 = reinterpret_cast<const float4*>(acc + lane * 12);
-        splat_grads[(int64_t)g * 3 + 0] = a4[0];
-        splat_grads[(int64_t)g * 3 + 1] = a4[1];
+        float4 u0 = a4[0], u1 = a4[1];
+        // the instance records carry moments (see bwd_step): turn the sums into derivatives with this Gaussian's conic
+        const float4 q0 = splats[(int64_t)g * 4 + 0];
+        moments_to_grads(q0.z, q0.w, splats[(int64_t)g * 4 + 1].x, u0, u1);
+        splat_grads[(int64_t)g * 3 + 0] = u0;
+        splat_grads[(int64_t)g * 3 + 1] = u1;
         splat_grads[(int64_t)g * 3 + 2] = a4[2];
     }
 }
@@ -391,13 +417,13 @@ render_bwd_wave(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
     const float dLg = inside ? dL_dpix[HW + pix] : 0.f;
     const float dLb = inside ? dL_dpix[2 * HW + pix] : 0.f;
     const float dLd = (inside && dL_dinvdepth) ? dL_dinvdepth[pix] : 0.f;
-    const float bg_dot = cam.bg[0] * dLr + cam.bg[1] * dLg + cam.bg[2] * dLb;
+    const float Tf_bg = -T_final * (cam.bg[0] * dLr + cam.bg[1] * dLg + cam.bg[2] * dLb);
     uint32_t max_contrib = last_contrib;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) max_contrib = max(max_contrib, (uint32_t)__shfl_xor((int)max_contrib, off, 64));
     const uint32_t end = min(range.y - range.x, max_contrib);
     if (end == 0) return;
-    BwdPix s = {T_final, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    BwdPix s = {T_final, 0.f, 0.f, 0.f};
     for (int bstart = (int)((end - 1) & ~63u); bstart >= 0; bstart -= 64) {
         const uint32_t n = min(64u, end - (uint32_t)bstart);
         float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
@@ -423,10 +449,10 @@ render_bwd_wave(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
             const float cb = bcast(colb, j), idp = bcast(invd, j);
             const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, j);
             float g_px, g_py, g_A, g_B, g_C, g_op, g_r, g_g, g_b, g_d;
-            const bool active = bwd_step(s, pos0 < last_contrib, pxf, pyf, T_final, bg_dot, dLr, dLg, dLb, dLd, gx_, gy_, cA, cB,
-                                         cC, -0.5f * LOG2E * cA, -LOG2E * cB, -0.5f * LOG2E * cC, op, cr, cg, cb, idp, g_px, g_py,
+            const bool active = bwd_step(s, pos0 < last_contrib, pxf, pyf, Tf_bg, dLr, dLg, dLb, dLd, gx_, gy_,
+                                         -0.5f * LOG2E * cA, -LOG2E * cB, -0.5f * LOG2E * cC, op, cr, cg, cb, idp, g_px, g_py,
                                          g_A, g_B, g_C, g_op, g_r, g_g, g_b, g_d);
-            if (__ballot(active) == 0ull) continue;
+            if (__builtin_amdgcn_ballot_w64(active) == 0ull) continue;
             g_px = wave_sum_to_lane63(g_px); g_py = wave_sum_to_lane63(g_py);
             g_A = wave_sum_to_lane63(g_A); g_B = wave_sum_to_lane63(g_B); g_C = wave_sum_to_lane63(g_C);
             g_op = wave_sum_to_lane63(g_op);
@@ -434,8 +460,10 @@ render_bwd_wave(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
             g_d = wave_sum_to_lane63(g_d);
             if (lane == 63) {
                 float* o = grads + (int64_t)gid * 12;
-                atomicAdd(o + 0, g_px); atomicAdd(o + 1, g_py);
-                atomicAdd(o + 2, g_A); atomicAdd(o + 3, g_B); atomicAdd(o + 4, g_C);
+                float4 u0 = make_float4(g_px, g_py, g_A, g_B), u1 = make_float4(g_C, 0.f, 0.f, 0.f);
+                moments_to_grads(cA, cB, cC, u0, u1);
+                atomicAdd(o + 0, u0.x); atomicAdd(o + 1, u0.y);
+                atomicAdd(o + 2, u0.z); atomicAdd(o + 3, u0.w); atomicAdd(o + 4, u1.x);
                 atomicAdd(o + 5, g_op);
                 atomicAdd(o + 6, g_r); atomicAdd(o + 7, g_g); atomicAdd(o + 8, g_b);
                 atomicAdd(o + 9, g_d);
@@ -475,10 +503,9 @@ void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const
     }
 }
 
-void gsr_launch_reduce_instances(int P, const uint32_t* order, const uint32_t* offsets, const uint32_t* tiles,
+void gsr_launch_reduce_instances(int P, const uint32_t* order, const uint32_t* offsets, const float4* splats,
                                  const float* inst_grads, const uint8_t* inst_flag, float* splat_grads, hipStream_t st) {
-    (void)tiles;
     const int64_t waves = ((int64_t)P + 63) / 64;
     hipLaunchKernelGGL(bwd_reduce_instances, dim3((int)((waves + 3) / 4)), dim3(256), 0, st, P, order, offsets,
-                       reinterpret_cast<const float4*>(inst_grads), inst_flag, reinterpret_cast<float4*>(splat_grads));
+                       reinterpret_cast<const float4*>(inst_grads), inst_flag, splats, reinterpret_cast<float4*>(splat_grads));
 }

@@ -6,9 +6,11 @@ keyword call (gaussian_renderer/__init__.py:102-110), the same 3-tuple return `(
 invdepth[1,H,W])` and the same autograd contract (gradients to means3D, means2D (NDC-scaled dummy, read at
 scene/gaussian_model.py:472), shs / colors_precomp, opacities, scales, rotations / cov3D_precomp).
 
-It deliberately does NOT export `SparseGaussianAdam`, so train.py:37-41 falls back to the plain call form
-(SURVEY.md 8(b)).  All compute goes through the C ABI of libgsr_hip.so (include/gsr.h, hand-written gfx950
-HIP kernels); there is no CPU or eager-PyTorch fallback -- a missing library raises.
+It also exports `SparseGaussianAdam` (train.py:37-41, scene/gaussian_model.py:24-27), which makes the reference
+use the "separate_sh" call form -- `rasterizer(dc=features_dc, shs=features_rest, ...)`,
+gaussian_renderer/__init__.py:82-100 -- supported here without concatenating the two tensors.
+All compute goes through the C ABI of libgsr_hip.so (include/gsr.h, hand-written gfx950 HIP kernels); there is no
+CPU or eager-PyTorch fallback -- a missing library raises.
 """
 from __future__ import annotations
 
@@ -21,7 +23,7 @@ import torch.nn as nn
 from . import _lib
 from ._lib import GsrError, GsrRasterSettings, RESIZE_FN  # noqa: F401
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "GsrError"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "SparseGaussianAdam", "rasterize_gaussians", "GsrError"]
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -108,7 +110,7 @@ def _require_cuda(t: torch.Tensor, name: str):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, tile_rows, grad_sync):
+                raster_settings, tile_rows, grad_sync, dc):
         lib = _lib.load()
         _require_cuda(means3D, "means3D")
         device = means3D.device
@@ -116,12 +118,22 @@ class _RasterizeGaussians(torch.autograd.Function):
         H, W = int(raster_settings.image_height), int(raster_settings.image_width)
         means3D_c, sh_c, col_c = _f32c(means3D), _f32c(sh), _f32c(colors_precomp)
         op_c, sc_c, rot_c, cov_c = _f32c(opacities), _f32c(scales), _f32c(rotations), _f32c(cov3Ds_precomp)
+        dc_c = _f32c(dc)
+        # split form: dc[P,1,3] + sh[P,M-1,3].  A model with max_sh_degree 0 has an empty `sh`: the DC tensor then IS the
+        # fused [P,1,3] form and its gradient is routed back to `dc`.
+        ctx.dc_as_sh = dc_c is not None and (sh_c is None or sh_c.numel() == 0 or sh_c.shape[1] == 0)
+        if ctx.dc_as_sh:
+            sh_c, dc_c = dc_c.view(P, 1, 3), None
         M = int(sh_c.shape[1]) if sh_c is not None and sh_c.dim() == 3 else 0
+        if dc_c is not None:
+            M += 1
         keep: list = []
         with torch.cuda.device(device):
             # inside autograd.Function.forward grad mode is off; needs_input_grad tells whether a backward can follow
-            no_backward = not any(ctx.needs_input_grad[:8])
+            no_backward = not (any(ctx.needs_input_grad[:8]) or ctx.needs_input_grad[11])
             s = _make_settings(raster_settings, keep, tile_rows, no_backward)
+            if dc_c is not None:
+                s.sh_dc = dc_c.data_ptr()
             color = torch.empty(3, H, W, dtype=torch.float32, device=device)
             invdepth = torch.empty(1, H, W, dtype=torch.float32, device=device)
             if tile_rows is not None:   # rows outside the band are not written by the kernels
@@ -151,21 +163,25 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.M = M
         ctx.op_shape = tuple(opacities.shape)
         ctx.has_means2D = means2D is not None
-        ctx.flags = (sh is not None, colors_precomp is not None, scales is not None, rotations is not None,
+        ctx.flags = (sh_c is not None, colors_precomp is not None, scales is not None, rotations is not None,
                      cov3Ds_precomp is not None)
+        ctx.has_dc = dc_c is not None
+        ctx.sh_given = sh is not None
+        ctx.dc_shape = tuple(dc.shape) if dc is not None else None
         ctx.save_for_backward(means3D_c, sh_c if sh_c is not None else means3D_c.new_empty(0),
                               col_c if col_c is not None else means3D_c.new_empty(0), op_c,
                               sc_c if sc_c is not None else means3D_c.new_empty(0),
                               rot_c if rot_c is not None else means3D_c.new_empty(0),
                               cov_c if cov_c is not None else means3D_c.new_empty(0),
-                              radii, geom.t, binning.t, img.t)
+                              radii, geom.t, binning.t, img.t,
+                              dc_c if dc_c is not None else means3D_c.new_empty(0))
         ctx.mark_non_differentiable(radii)
         return color, radii, invdepth
 
     @staticmethod
     def backward(ctx, grad_out_color, grad_radii, grad_out_depth):
         lib = _lib.load()
-        (means3D, sh, col, op, sc, rot, cov, radii, geom, binning, img) = ctx.saved_tensors
+        (means3D, sh, col, op, sc, rot, cov, radii, geom, binning, img, dc) = ctx.saved_tensors
         has_sh, has_col, has_sc, has_rot, has_cov = ctx.flags
         rs = ctx.raster_settings
         device = means3D.device
@@ -177,7 +193,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         dL_dopacity = torch.empty(P, 1, **f)
         dL_dmeans3D = torch.empty(P, 3, **f)
         dL_dcov3D = torch.empty(P, 6, **f)
-        dL_dsh = torch.empty(P, M, 3, **f) if has_sh else None
+        has_dc = ctx.has_dc
+        dL_dsh = torch.empty(P, M - 1 if has_dc else M, 3, **f) if has_sh else None
+        dL_ddc = torch.empty(P, 1, 3, **f) if has_dc else None
         dL_dscales = torch.empty(P, 3, **f) if has_sc else None
         dL_drot = torch.empty(P, 4, **f) if has_rot else None
         if P > 0:
@@ -187,6 +205,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             keep: list = []
             with torch.cuda.device(device):
                 s = _make_settings(rs, keep, ctx.tile_rows)
+                if has_dc:
+                    s.sh_dc = dc.data_ptr()
+                    s.dL_dsh_dc = dL_ddc.data_ptr()
                 st = _stream_ptr(device)
                 inputs = (_ptr(means3D), _ptr(sh) if has_sh else None, _ptr(col) if has_col else None, _ptr(op),
                           _ptr(sc) if has_sc else None, _ptr(rot) if has_rot else None, _ptr(cov) if has_cov else None,
@@ -223,8 +244,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                 else:
                     _run()
         dL_dopacity = dL_dopacity.view(ctx.op_shape)
+        if ctx.dc_as_sh:      # the DC tensor travelled as the fused [P,1,3] form
+            dL_ddc = dL_dsh.view(ctx.dc_shape)
+            dL_dsh = dL_dsh.new_zeros(P, 0, 3) if ctx.sh_given else None
+        elif has_dc:
+            dL_ddc = dL_ddc.view(ctx.dc_shape)
         return (dL_dmeans3D, dL_dmeans2D if ctx.has_means2D else None, dL_dsh, dL_dcolors if has_col else None, dL_dopacity, dL_dscales, dL_drot,
-                dL_dcov3D if has_cov else None, None, None, None)
+                dL_dcov3D if has_cov else None, None, None, None, dL_ddc)
 
 
 def _cpu_copy(args):
@@ -232,13 +258,14 @@ def _cpu_copy(args):
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings, tile_rows: Optional[Tuple[int, int]] = None, grad_sync=None):
+                        raster_settings, tile_rows: Optional[Tuple[int, int]] = None, grad_sync=None, dc=None):
     """Functional form.  `grad_sync(records[P,12])`, if given, is called between the blend backward and the
     per-Gaussian backward (multi-GPU: all-reduce of the 48-byte gradient records, parallel.py).
     `tile_rows=(y0, y1)` (extension) restricts binning + blending to that
-    band of 16-pixel tile rows; pixels outside the band come back as zeros."""
+    band of 16-pixel tile rows; pixels outside the band come back as zeros.  `dc` (the reference's separate_sh
+    form): SH coefficient 0 as [P,1,3]; `sh` then holds coefficients 1.. as [P,M-1,3]."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, tile_rows, grad_sync)
+                                     cov3Ds_precomp, raster_settings, tile_rows, grad_sync, dc)
 
 
 class GaussianRasterizer(nn.Module):
@@ -259,12 +286,58 @@ class GaussianRasterizer(nn.Module):
                                             _stream_ptr(pos.device)), "gsr_mark_visible")
         return present.bool()
 
-    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+    def forward(self, means3D, means2D, opacities, dc=None, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None):
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if dc is not None and shs is None:
+            raise Exception('dc (SH coefficient 0) was given without shs (the remaining coefficients)!')
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   self.raster_settings, getattr(self, "tile_rows", None))
+                                   self.raster_settings, getattr(self, "tile_rows", None), None, dc)
+
+
+class SparseGaussianAdam(torch.optim.Adam):
+    """`SparseGaussianAdam(params, lr, eps).step(visibility, N)` (scene/gaussian_model.py:194-196, train.py:180-183):
+    Adam that updates only the rows of Gaussians that were visible in this iteration; parameter and both moments of the
+    others stay untouched.  One fused HIP kernel per parameter group (gsr_sparse_adam_step).  State layout
+    (`step`, `exp_avg`, `exp_avg_sq`) is torch.optim.Adam's, so the optimizer-state surgery of
+    scene/gaussian_model.py:316-405 (prune / cat / replace) works unchanged.
+    [RECALLED -- the accelerated rasterizer's source is not vendored] betas are fixed at (0.9, 0.999) and there is no
+    bias correction; parity for this class is unpinned."""
+
+    def __init__(self, params, lr, eps):
+        super().__init__(params=params, lr=lr, eps=eps)
+
+    @torch.no_grad()
+    def step(self, visibility, N):
+        lib = _lib.load()
+        N = int(N)
+        vis = visibility.reshape(-1)
+        if vis.dtype != torch.uint8:
+            vis = vis.to(torch.uint8)
+        vis = vis.contiguous()
+        for group in self.param_groups:
+            lr, eps = group["lr"], group["eps"]
+            assert len(group["params"]) == 1, "more than one tensor in group"
+            param = group["params"][0]
+            if param.grad is None:
+                continue
+            _require_cuda(param, "parameter")
+            if param.dtype != torch.float32 or not param.is_contiguous():
+                raise GsrError("SparseGaussianAdam needs contiguous fp32 parameters")
+            state = self.state[param]
+            if len(state) == 0:
+                state["step"] = torch.tensor(0.0, dtype=torch.float32)
+                state["exp_avg"] = torch.zeros_like(param, memory_format=torch.preserve_format)
+                state["exp_avg_sq"] = torch.zeros_like(param, memory_format=torch.preserve_format)
+            M = param.numel() // N if N > 0 else 0
+            if N > 0 and (param.numel() != N * M or vis.numel() != N):
+                raise GsrError(f"parameter of {param.numel()} elements / visibility of {vis.numel()} do not match N = {N}")
+            g = param.grad if param.grad.is_contiguous() else param.grad.contiguous()
+            with torch.cuda.device(param.device):
+                _lib.check(lib.gsr_sparse_adam_step(_ptr(param), _ptr(g), _ptr(state["exp_avg"]), _ptr(state["exp_avg_sq"]),
+                                                    _ptr(vis), N, M, float(lr), 0.9, 0.999, float(eps),
+                                                    _stream_ptr(param.device)), "gsr_sparse_adam_step")

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgsr_hip.so")
 
 GSR_OK = 0
+ABI_VERSION = 2
 STAGES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "render", "render_bwd", "preprocess_bwd",
           "gather_bwd"]
 
@@ -28,6 +29,7 @@ class GsrRasterSettings(C.Structure):
         ("sh_degree", C.c_int32), ("campos", C.c_void_p),
         ("prefiltered", C.c_int32), ("debug", C.c_int32), ("antialiasing", C.c_int32),
         ("tile_y0", C.c_int32), ("tile_y1", C.c_int32), ("no_backward", C.c_int32),
+        ("sh_dc", C.c_void_p), ("dL_dsh_dc", C.c_void_p),
     ]
 
 
@@ -43,7 +45,8 @@ EXPORTS = [
     "gsr_abi_version", "gsr_last_error", "gsr_geometry_bytes", "gsr_binning_bytes", "gsr_image_bytes",
     "gsr_backward_scratch_bytes",
     "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_backward_blend", "gsr_backward_preprocess",
-    "gsr_mark_visible", "gsr_forward_views", "gsr_adam_step", "gsr_ssim_forward", "gsr_ssim_backward",
+    "gsr_mark_visible", "gsr_forward_views", "gsr_adam_step", "gsr_sparse_adam_step", "gsr_ssim_forward", "gsr_ssim_backward",
+    "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2",
     "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_set_option",
 ]
 
@@ -104,6 +107,13 @@ def load() -> C.CDLL:
                                             vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_adam_step.restype = C.c_int
     lib.gsr_adam_step.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, vp]
+    lib.gsr_sparse_adam_step.restype = C.c_int
+    lib.gsr_sparse_adam_step.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                         C.c_double, vp]
+    lib.gsr_knn_scratch_bytes.restype = C.c_size_t
+    lib.gsr_knn_scratch_bytes.argtypes = [C.c_int]
+    lib.gsr_knn_mean_dist2.restype = C.c_int
+    lib.gsr_knn_mean_dist2.argtypes = [C.c_int, vp, vp, vp, vp]
     lib.gsr_ssim_forward.restype = C.c_int
     lib.gsr_ssim_forward.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_ssim_backward.restype = C.c_int
@@ -119,8 +129,8 @@ def load() -> C.CDLL:
     lib.gsr_profile_read.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int]
     lib.gsr_set_option.restype = C.c_int
     lib.gsr_set_option.argtypes = [C.c_char_p, C.c_int]
-    if lib.gsr_abi_version() != 1:
-        raise GsrError(f"{path}: ABI version {lib.gsr_abi_version()} != 1")
+    if lib.gsr_abi_version() != ABI_VERSION:
+        raise GsrError(f"{path}: ABI version {lib.gsr_abi_version()} != {ABI_VERSION}")
     _lib = lib
     return lib
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 1
+#define GSR_ABI_VERSION 2
 
 typedef enum GsrStatus {
     GSR_OK = 0,
@@ -69,6 +69,14 @@ typedef struct GsrRasterSettings {
     /* Extension: 1 = the caller will not run the backward for this forward (inference / torch.no_grad()): state that only
      * the backward reads (final_T, n_contrib, first-emission indices) is not written.  0 = reference behaviour. */
     int32_t no_backward;
+    /* Extension -- the "separate_sh" call form the reference uses when its accelerated rasterizer is installed
+     * (gaussian_renderer/__init__.py:82-100: rasterizer(dc = features_dc, shs = features_rest, ...)): when sh_dc is
+     * non-NULL, SH coefficient 0 is read from sh_dc[P,1,3] and `shs` holds coefficients 1..M-1 as [P,M-1,3] (M still
+     * counts ALL coefficients, M >= 2).  In the backward dL_dsh then receives [P,M-1,3] and dL_dsh_dc[P,1,3] the
+     * gradient of the DC term.  This avoids the torch.cat of the two parameter tensors (scene/gaussian_model.py:121-125)
+     * and the split of its gradient in every iteration.  Both NULL = fused [P,M,3] form. */
+    const float* sh_dc;
+    float* dL_dsh_dc;
 } GsrRasterSettings;
 
 /* Resize callback: make the buffer at least `bytes` long and return its (device) base address,
@@ -157,6 +165,25 @@ int gsr_backward_preprocess(const GsrRasterSettings* settings, int P, int M,
  */
 int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   double lr, double beta1, double beta2, double eps, int32_t step, void* stream);
+
+/*
+ * Sparse Adam step: replaces `_C.adamUpdate` behind `SparseGaussianAdam.step(visibility, N)` of the
+ * reference's accelerated rasterizer (imported at train.py:37-41 and scene/gaussian_model.py:24-27, stepped at
+ * train.py:180-183).  The tensor is N rows of M elements; rows with visible[row] == 0 are skipped entirely (parameter and
+ * both moments untouched).  [RECALLED -- the source is an un-vendored submodule] no bias correction:
+ *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr m / (sqrt(v) + eps).   visible is uint8 / bool [N].
+ */
+int gsr_sparse_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* visible,
+                         int64_t N, int64_t M, double lr, double beta1, double beta2, double eps, void* stream);
+
+/*
+ * Replaces `simple_knn._C.distCUDA2` (un-vendored submodule submodules/simple-knn, .gitmodules:1-3; called once per
+ * scene at scene/gaussian_model.py:159): mean_dist2[i] = mean of the squared Euclidean distances
+ * from points[i] to its 3 nearest OTHER points (exact; coincident points count with distance 0; fewer than 4 points
+ * leaves FLT_MAX terms in the mean, as in the reference).  points[N,3] fp32, scratch of gsr_knn_scratch_bytes(N) bytes.
+ */
+size_t gsr_knn_scratch_bytes(int N);
+int gsr_knn_mean_dist2(int N, const float* points, float* mean_dist2, void* scratch, void* stream);
 
 /*
  * Fused SSIM map: replaces the un-vendored `fused_ssim` extension (train.py:31-35,122; its

@@ -24,12 +24,12 @@ def lib():
 
 def test_header_symbols_are_exported(lib):
     hdr = open(os.path.join(ROOT, "include", "gsr.h")).read()
-    declared = set(re.findall(r"\b(gsr_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(gsr_[a-z0-9_]+)\s*\(", hdr))
     from diff_gaussian_rasterization import _lib
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gsr.h but not exported"
-    assert lib.gsr_abi_version() == 1
+    assert lib.gsr_abi_version() == 2
 
 
 def test_scratch_sizes(lib):
@@ -83,12 +83,12 @@ def test_package_surface_matches_reference_call_site():
     """What gaussian_renderer/__init__.py:14,36-52,102-110 needs from the package."""
     import inspect
     import diff_gaussian_rasterization as d
-    assert not hasattr(d, "SparseGaussianAdam")                     # train.py:37-41 must fall back
+    assert hasattr(d, "SparseGaussianAdam")                         # train.py:37-41 -> separate_sh call form (dc=, shs=)
     fields = d.GaussianRasterizationSettings._fields
     assert fields == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix",
                       "projmatrix", "sh_degree", "campos", "prefiltered", "debug", "antialiasing")
     sig = inspect.signature(d.GaussianRasterizer.forward)
-    assert list(sig.parameters)[1:] == ["means3D", "means2D", "opacities", "shs", "colors_precomp", "scales",
+    assert list(sig.parameters)[1:] == ["means3D", "means2D", "opacities", "dc", "shs", "colors_precomp", "scales",
                                         "rotations", "cov3D_precomp"]
     ref = "/root/reference/gaussian_renderer/__init__.py"
     if os.path.exists(ref):   # build container only: every keyword the reference passes must be accepted

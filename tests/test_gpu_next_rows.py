@@ -1,0 +1,218 @@
+"""GPU tests of the rows next to the operator: the split-SH ("separate_sh") call form and
+SparseGaussianAdam (N2), and the simple_knn.distCUDA2 provider (N3).  All calls go through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_camera, make_scene, oracle_settings
+from test_gpu_parity import gpu_settings
+
+pytestmark = pytest.mark.gpu
+
+
+def _grads(fn, tensors):
+    for t in tensors:
+        t.grad = None
+    fn().backward()
+    return [t.grad.detach().clone() for t in tensors]
+
+
+@pytest.mark.parametrize("P,W,H,deg,Mstore", [(1000, 256, 256, 3, 16), (5003, 320, 200, 3, 16), (2500, 160, 96, 1, 4),
+                                               (777, 128, 128, 2, 9)])
+def test_split_sh_equals_fused_form(P, W, H, deg, Mstore):
+    """rasterizer(dc=, shs=) (gaussian_renderer/__init__.py:91-100) must give the very same image and gradients as the
+    fused [P,M,3] tensor: same arithmetic, only the memory layout of the SH record differs."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    cam = make_camera(W, H)
+    sc = make_scene(P, cam, seed=21, s_med=0.03).to(dev)
+    s = oracle_settings(cam, sh_degree=deg)
+    rast = GaussianRasterizer(gpu_settings(s, dev))
+    sh_full = sc.shs[:, :Mstore].contiguous()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    wgt = torch.rand(3, H, W, generator=g).to(dev)
+    wd = torch.rand(1, H, W, generator=g).to(dev)
+
+    means = sc.means3D.clone().requires_grad_(True)
+    opac = sc.opacities.clone().requires_grad_(True)
+    scal = sc.scales.clone().requires_grad_(True)
+    rots = sc.rotations.clone().requires_grad_(True)
+    fused = sh_full.clone().requires_grad_(True)
+    dc = sh_full[:, :1].clone().contiguous().requires_grad_(True)
+    rest = sh_full[:, 1:].clone().contiguous().requires_grad_(True)
+
+    def loss_of(img, radii, invd):
+        return (img * wgt).sum() + (invd * wd).sum()
+
+    def run_fused():
+        return loss_of(*rast(means3D=means, means2D=None, shs=fused, colors_precomp=None, opacities=opac, scales=scal,
+                             rotations=rots, cov3D_precomp=None))
+
+    def run_split():
+        return loss_of(*rast(means3D=means, means2D=None, dc=dc, shs=rest, colors_precomp=None, opacities=opac,
+                             scales=scal, rotations=rots, cov3D_precomp=None))
+
+    with torch.no_grad():
+        a = rast(means3D=means, means2D=None, shs=fused, colors_precomp=None, opacities=opac, scales=scal, rotations=rots,
+                 cov3D_precomp=None)
+        b = rast(means3D=means, means2D=None, dc=dc, shs=rest, colors_precomp=None, opacities=opac, scales=scal,
+                 rotations=rots, cov3D_precomp=None)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+    gf = _grads(run_fused, [means, opac, scal, rots, fused])
+    gs = _grads(run_split, [means, opac, scal, rots, dc, rest])
+    # the blend backward sums four waves' LDS atomics in arrival order: identical up to fp32 reassociation
+    for x, y in zip(gf[:4], gs[:4]):
+        assert torch.allclose(x, y, rtol=1e-4, atol=1e-6 * float(x.abs().max()))
+    full = torch.cat([gs[4], gs[5]], dim=1)
+    assert full.shape == gf[4].shape
+    assert torch.allclose(gf[4], full, rtol=1e-4, atol=1e-6 * float(gf[4].abs().max()))
+    assert float(gs[4].abs().max()) > 0 and (Mstore == 1 or deg == 0 or float(gs[5].abs().max()) > 0)
+
+
+def test_split_sh_degree0_model_with_empty_rest():
+    """max_sh_degree = 0: features_rest is [P,0,3]; the DC tensor alone is the SH record."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    cam = make_camera(128, 96)
+    sc = make_scene(600, cam, seed=2, s_med=0.04).to(dev)
+    s = oracle_settings(cam, sh_degree=0)
+    rast = GaussianRasterizer(gpu_settings(s, dev))
+    dc = sc.shs[:, :1].clone().contiguous().requires_grad_(True)
+    rest = torch.zeros(600, 0, 3, device=dev, requires_grad=True)
+    fused = sc.shs[:, :1].clone().contiguous().requires_grad_(True)
+    kw = dict(means3D=sc.means3D, means2D=None, colors_precomp=None, opacities=sc.opacities, scales=sc.scales,
+              rotations=sc.rotations, cov3D_precomp=None)
+    a = rast(shs=fused, **kw)[0]
+    b = rast(dc=dc, shs=rest, **kw)[0]
+    assert torch.equal(a, b)
+    a.sum().backward()
+    b.sum().backward()
+    assert torch.allclose(dc.grad, fused.grad, rtol=1e-4, atol=1e-7)
+    assert rest.grad is not None and rest.grad.shape == (600, 0, 3)
+
+
+def test_sparse_gaussian_adam_updates_only_visible_rows():
+    """SparseGaussianAdam(params, lr, eps).step(visibility, N) (train.py:180-183): rows of invisible Gaussians keep
+    parameter and moments; visible rows follow m = b1 m + (1-b1) g, v = b2 v + (1-b2) g^2, p -= lr m / (sqrt(v) + eps)."""
+    from diff_gaussian_rasterization import SparseGaussianAdam
+    dev = torch.device("cuda:0")
+    N = 10007
+    g = torch.Generator(device="cpu").manual_seed(0)
+    shapes = {"xyz": (N, 3), "f_dc": (N, 1, 3), "f_rest": (N, 15, 3), "opacity": (N, 1), "rotation": (N, 4)}
+    params = {k: torch.randn(*shp, generator=g).to(dev).requires_grad_(True) for k, shp in shapes.items()}
+    lrs = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 1.25e-4, "opacity": 0.025, "rotation": 1e-3}
+    groups = [{"params": [params[k]], "lr": lrs[k], "name": k} for k in shapes]
+    opt = SparseGaussianAdam(groups, lr=0.0, eps=1e-15)
+    ref_p = {k: v.detach().double().clone() for k, v in params.items()}
+    ref_m = {k: torch.zeros_like(v) for k, v in ref_p.items()}
+    ref_v = {k: torch.zeros_like(v) for k, v in ref_p.items()}
+    for it in range(3):
+        vis = (torch.rand(N, generator=g) < 0.6).to(dev)
+        for k, p in params.items():
+            p.grad = torch.randn(*shapes[k], generator=g).to(dev) * (10.0 ** (it - 1))
+        opt.step(vis, N)
+        for k, p in params.items():
+            gg = p.grad.double()
+            mask = vis.view(N, *([1] * (p.dim() - 1))).expand_as(p)
+            m = 0.9 * ref_m[k] + 0.1 * gg
+            v = 0.999 * ref_v[k] + 0.001 * gg * gg
+            step = lrs[k] * m / (v.sqrt() + 1e-15)
+            ref_m[k] = torch.where(mask, m, ref_m[k])
+            ref_v[k] = torch.where(mask, v, ref_v[k])
+            ref_p[k] = torch.where(mask, ref_p[k] - step, ref_p[k])
+    torch.cuda.synchronize()
+    for k, p in params.items():
+        st = opt.state[p]
+        assert torch.allclose(p.detach().double(), ref_p[k], rtol=2e-6, atol=1e-7), k
+        assert torch.allclose(st["exp_avg"].double(), ref_m[k], rtol=2e-6, atol=1e-12), k
+        assert torch.allclose(st["exp_avg_sq"].double(), ref_v[k], rtol=2e-6, atol=1e-12), k
+    # rows never visible are bit-identical to their initial value
+    opt2_p = torch.randn(N, 3, generator=g).to(dev).requires_grad_(True)
+    init = opt2_p.detach().clone()
+    opt2 = SparseGaussianAdam([{"params": [opt2_p], "lr": 0.1, "name": "xyz"}], lr=0.0, eps=1e-15)
+    opt2_p.grad = torch.ones_like(opt2_p)
+    vis = torch.zeros(N, dtype=torch.bool, device=dev)
+    vis[::7] = True
+    opt2.step(vis, N)
+    assert torch.equal(opt2_p.detach()[~vis], init[~vis])
+    assert not torch.equal(opt2_p.detach()[vis], init[vis])
+    assert torch.count_nonzero(opt2.state[opt2_p]["exp_avg"][~vis]) == 0
+
+
+def _clouds():
+    rng = np.random.default_rng(7)
+    out = {}
+    out["normal_5k"] = rng.normal(size=(5000, 3)).astype(np.float32)
+    # SfM-like: dense clusters + far outliers that stretch the bounding box, plus exact duplicates
+    cl = np.concatenate([rng.normal(loc=c, scale=s, size=(n, 3)) for c, s, n in
+                         [((0, 0, 0), 0.05, 1500), ((3, 1, -2), 0.5, 1200), ((-40, 25, 90), 0.01, 300)]])
+    cl = np.concatenate([cl, rng.uniform(-500, 500, size=(40, 3)), cl[:25]]).astype(np.float32)
+    out["clustered_dups"] = cl
+    out["plane"] = np.concatenate([rng.uniform(-1, 1, size=(3000, 2)), np.zeros((3000, 1))], axis=1).astype(np.float32)
+    out["line_x"] = np.stack([np.linspace(0, 1, 700), np.zeros(700), np.zeros(700)], axis=1).astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("name", ["normal_5k", "clustered_dups", "plane", "line_x"])
+def test_distcuda2_matches_brute_force(name):
+    from simple_knn._C import distCUDA2
+    from oracle import knn_oracle as K
+    pts = _clouds()[name]
+    got = distCUDA2(torch.from_numpy(pts).cuda()).cpu().double().numpy()
+    want = K.dist2_mean3(pts)
+    scale = np.maximum(want, 1e-30)
+    assert np.all(np.abs(got - want) <= 4e-6 * scale + 1e-12), float((np.abs(got - want) / scale).max())
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 64, 255, 256, 257, 1025])
+def test_distcuda2_small_and_ragged_sizes(n):
+    from simple_knn._C import distCUDA2
+    from oracle import knn_oracle as K
+    pts = np.random.default_rng(n).normal(size=(n, 3)).astype(np.float32)
+    got = distCUDA2(torch.from_numpy(pts).cuda()).cpu().double().numpy()
+    want = K.dist2_mean3(pts)
+    if n < 4:      # fewer than three other points: FLT_MAX terms dominate (overflow to inf is the reference's behaviour too)
+        assert np.all(got > 1e37)
+    else:
+        assert np.allclose(got, want, rtol=4e-6, atol=1e-12)
+
+
+def test_distcuda2_large_cloud_and_init_scales():
+    """200 k points against scipy's exact k-d tree, then the use the reference makes of it
+    (scene/gaussian_model.py:159-160)."""
+    from simple_knn._C import distCUDA2
+    from oracle import knn_oracle as K
+    rng = np.random.default_rng(11)
+    pts = (rng.normal(size=(200_000, 3)) * np.array([3.0, 1.0, 0.2])).astype(np.float32)
+    d = distCUDA2(torch.from_numpy(pts).cuda())
+    want = K.dist2_mean3_tree(pts)
+    got = d.cpu().double().numpy()
+    assert np.allclose(got, want, rtol=4e-6, atol=1e-12)
+    scales = torch.log(torch.sqrt(torch.clamp_min(d, 0.0000001)))[..., None].repeat(1, 3)
+    assert scales.shape == (200_000, 3) and bool(torch.isfinite(scales).all())
+    assert distCUDA2(torch.empty(0, 3, device="cuda")).shape == (0,)
+    with pytest.raises(Exception):
+        distCUDA2(torch.zeros(10, 3))
+
+
+def test_bench_two_rank_path_on_one_gpu():
+    """bench.py's N > 1 code path (band plan, strip all-gather, record all-reduce, max-over-ranks timing) with two
+    ranks sharing this box's single GPU over gloo -- RCCL itself needs one device per rank and is exercised by the
+    driver's multi-GPU run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT
+    env = dict(os.environ, GSR_BENCH_SHARED_GPU="1", GSR_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--P", "60000", "--width", "640", "--height", "368", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["train_iters_per_s"] > 0 and d["scaling"] == "strong"
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
