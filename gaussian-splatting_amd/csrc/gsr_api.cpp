@@ -129,7 +129,8 @@ int check_inputs(int P, int M, const float* means3D, const float* shs, const flo
 int check_split_sh(const GsrRasterSettings* s, int P, int M, const float* shs, bool backward) {
     if (!s->sh_dc || P == 0) return GSR_OK;
     if (!shs) return fail(GSR_ERR_INVALID_ARG, "sh_dc given without shs (the coefficients 1..M-1)");
-    if (M < 2) return fail(GSR_ERR_UNSUPPORTED, "split SH form needs M >= 2 (pass the DC term as shs with M = 1 instead)");
+    if (M != 16) return fail(GSR_ERR_UNSUPPORTED, "split SH form needs M == 16 (degree-3 storage); concatenate smaller records");
+    if ((((uintptr_t)s->sh_dc) | ((uintptr_t)shs)) & 15) return fail(GSR_ERR_UNSUPPORTED, "split SH form needs 16-byte aligned sh_dc / shs");
     if (backward && !s->dL_dsh_dc) return fail(GSR_ERR_INVALID_ARG, "sh_dc given but dL_dsh_dc is NULL");
     return GSR_OK;
 }
@@ -448,6 +449,8 @@ int gsr_backward_preprocess(const GsrRasterSettings* settings, int P, int M, con
     if (!dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D)
         return fail(GSR_ERR_INVALID_ARG, "gradient outputs are NULL");
     if (shs && !dL_dsh) return fail(GSR_ERR_INVALID_ARG, "dL_dsh is NULL");
+    if (settings->sh_dc && ((((uintptr_t)dL_dsh) | ((uintptr_t)settings->dL_dsh_dc)) & 15))
+        return fail(GSR_ERR_UNSUPPORTED, "split SH form needs 16-byte aligned dL_dsh / dL_dsh_dc");
     if (scales && (!dL_dscales || !dL_drotations)) return fail(GSR_ERR_INVALID_ARG, "dL_dscales / dL_drotations are NULL");
     GsrGeom g = gsr_carve_geom((char*)geom_buffer, P);
     {   StageTimer t(GSR_STAGE_PREPROCESS_BWD, st);

@@ -64,7 +64,7 @@ __device__ __forceinline__ void wave_load_sh_split(const float* __restrict__ dc,
     const int nrow = (int)((P - i0) < 64 ? (P - i0) : 64);
     const float* src = rest + i0 * 45;
     const int nrest = nrow * 45;
-#pragma unroll
+#pragma unroll 3
     for (int it = 0; it < 12; ++it) {
         const int f = (it * 64 + lane) * 4;
         if (f < nrest) {
@@ -119,7 +119,7 @@ __device__ __forceinline__ void wave_store_sh_split(float* __restrict__ d_dc, fl
     float* dst = d_rest + i0 * 45;
     const int nrest = nrow * 45;
     __builtin_amdgcn_wave_barrier();
-#pragma unroll
+#pragma unroll 3
     for (int it = 0; it < 12; ++it) {
         const int f = (it * 64 + lane) * 4;
         if (f < nrest) {
@@ -161,20 +161,8 @@ __device__ __forceinline__ void wave_store_sh_split(float* __restrict__ d_dc, fl
     }
     __builtin_amdgcn_wave_barrier();
 }
-// un-staged fallback of the split form (M != 16 or unaligned pointers): assemble the record in registers / scratch
-__device__ __forceinline__ void gather_sh_split(const float* __restrict__ dc, const float* __restrict__ rest, int64_t i, int M,
-                                                float* rec) {
-    rec[0] = dc[i * 3 + 0]; rec[1] = dc[i * 3 + 1]; rec[2] = dc[i * 3 + 2];
-    const float* r = rest + i * (int64_t)(M - 1) * 3;
-    for (int k = 3; k < M * 3; ++k) rec[k] = r[k - 3];
-}
-__device__ __forceinline__ void scatter_sh_split(float* __restrict__ d_dc, float* __restrict__ d_rest, int64_t i, int M,
-                                                 const float* rec) {
-    d_dc[i * 3 + 0] = rec[0]; d_dc[i * 3 + 1] = rec[1]; d_dc[i * 3 + 2] = rec[2];
-    float* r = d_rest + i * (int64_t)(M - 1) * 3;
-    for (int k = 3; k < M * 3; ++k) r[k - 3] = rec[k];
-}
-
+// SPLIT = the separate dc / rest form (always staged: the C ABI accepts it only for M == 16 and 16-byte aligned pointers)
+template <bool SPLIT>
 __global__ void __launch_bounds__(256)
 preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
                       const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -187,8 +175,8 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
     load_cam(camd, cam);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* tile = s_sh[wv];
-    const float* dc = camd.sh_dc;          // non-NULL: split form, `shs` holds coefficients 1..M-1
-    const bool staged_sh = shs != nullptr && cam.M == 16 && (dc == nullptr || ((((uintptr_t)dc) | ((uintptr_t)shs)) & 15) == 0);
+    const float* dc = SPLIT ? camd.sh_dc : nullptr;          // split form: `shs` holds coefficients 1..15
+    const bool staged_sh = shs != nullptr && cam.M == 16;
     // wave-uniform trip count: every lane of a wave runs the same iterations (lanes past P idle inside)
     for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < P; i0 += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = i0 + lane;
@@ -217,7 +205,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         if (staged_sh) {
             const uint64_t rows = __ballot(need_color);
             if (rows) {
-                if (dc) wave_load_sh_split(dc, shs, i0, P, rows, lane, tile);
+                if (SPLIT) wave_load_sh_split(dc, shs, i0, P, rows, lane, tile);
                 else wave_load_sh16(shs, i0, P, rows, lane, tile);
             }
         }
@@ -232,11 +220,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
                 rgb[0] = colors_precomp[i * 3 + 0]; rgb[1] = colors_precomp[i * 3 + 1]; rgb[2] = colors_precomp[i * 3 + 2];
             } else if (staged_sh) {
                 gsr_sh_to_rgb(cam.sh_degree, 16, tile + lane * SH_ROW, mean, cam.campos, rgb, clampbits);
-            } else if (dc) {
-                __attribute__((aligned(16))) float rec[48];
-                gather_sh_split(dc, shs, i, cam.M, rec);
-                gsr_sh_to_rgb(cam.sh_degree, cam.M, rec, mean, cam.campos, rgb, clampbits);
-            } else {
+            } else if (!SPLIT) {
                 gsr_sh_to_rgb(cam.sh_degree, cam.M, shs + i * (int64_t)cam.M * 3, mean, cam.campos, rgb, clampbits);
             }
             q0 = make_float4(sp.px, sp.py, sp.conA, sp.conB);
@@ -262,6 +246,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
     }
 }
 
+template <bool SPLIT>
 __global__ void __launch_bounds__(256)
 preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
                       const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -277,10 +262,9 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
     const int M = cam.M;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* tile = s_sh[wv];
-    const float* dc = camd.sh_dc;          // split form: `shs` / dL_dsh hold coefficients 1..M-1, dc / dL_ddc coefficient 0
-    float* dL_ddc = camd.dL_dsh_dc;
-    const bool staged_sh = shs != nullptr && M == 16 &&
-                           (dc == nullptr || ((((uintptr_t)dc) | ((uintptr_t)shs) | ((uintptr_t)dL_ddc) | ((uintptr_t)dL_dsh)) & 15) == 0);
+    const float* dc = SPLIT ? camd.sh_dc : nullptr;     // split form: `shs` / dL_dsh hold coefficients 1..15, dc / dL_ddc coefficient 0
+    float* dL_ddc = SPLIT ? camd.dL_dsh_dc : nullptr;
+    const bool staged_sh = shs != nullptr && M == 16;
     for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < P; i0 += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = i0 + lane;
         const bool in_range = i < P;
@@ -295,7 +279,7 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         if (staged_sh) {
             const uint64_t rows = __ballot(vis);
             if (rows) {
-                if (dc) wave_load_sh_split(dc, shs, i0, P, rows, lane, tile);
+                if (SPLIT) wave_load_sh_split(dc, shs, i0, P, rows, lane, tile);
                 else wave_load_sh16(shs, i0, P, rows, lane, tile);
             }
         }
@@ -333,13 +317,7 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
                     gsr_sh_to_rgb(cam.sh_degree, 16, tile + lane * SH_ROW, mean, cam.campos, rgb_unused, clampbits);
                     gsr_sh_backward(cam.sh_degree, 16, tile + lane * SH_ROW, mean, cam.campos, clampbits, drgb,
                                     tile + lane * SH_ROW, dmean);
-                } else if (dc) {
-                    __attribute__((aligned(16))) float rec[48];
-                    gather_sh_split(dc, shs, i, M, rec);
-                    gsr_sh_to_rgb(cam.sh_degree, M, rec, mean, cam.campos, rgb_unused, clampbits);
-                    gsr_sh_backward(cam.sh_degree, M, rec, mean, cam.campos, clampbits, drgb, rec, dmean);
-                    scatter_sh_split(dL_ddc, dL_dsh, i, M, rec);
-                } else {
+                } else if (!SPLIT) {
                     gsr_sh_to_rgb(cam.sh_degree, M, shs + i * (int64_t)M * 3, mean, cam.campos, rgb_unused, clampbits);
                     gsr_sh_backward(cam.sh_degree, M, shs + i * (int64_t)M * 3, mean, cam.campos, clampbits, drgb,
                                     dL_dsh + i * (int64_t)M * 3, dmean);
@@ -349,17 +327,13 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             if (staged_sh) {
 #pragma unroll
                 for (int k = 0; k < 12; ++k) *reinterpret_cast<float4*>(tile + lane * SH_ROW + k * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-            } else if (in_range && dc) {
-                dL_ddc[i * 3 + 0] = 0.f; dL_ddc[i * 3 + 1] = 0.f; dL_ddc[i * 3 + 2] = 0.f;
-                float* o = dL_dsh + i * (int64_t)(M - 1) * 3;
-                for (int k = 0; k < (M - 1) * 3; ++k) o[k] = 0.f;
-            } else if (in_range) {
+            } else if (in_range && !SPLIT) {
                 float* o = dL_dsh + i * (int64_t)M * 3;
                 for (int k = 0; k < M * 3; ++k) o[k] = 0.f;
             }
         }
         if (staged_sh) {
-            if (dc) wave_store_sh_split(dL_ddc, dL_dsh, i0, P, lane, tile);
+            if (SPLIT) wave_store_sh_split(dL_ddc, dL_dsh, i0, P, lane, tile);
             else wave_store_sh16(dL_dsh, i0, P, lane, tile);
         }
         if (!in_range) continue;
@@ -398,9 +372,14 @@ void gsr_launch_preprocess(const GsrCamDev& cam, int P, const float* means3D, co
                            const float* colors_precomp, const float* opacities, const float* scales,
                            const float* rotations, const float* cov3D_precomp, GsrGeom g, int32_t* radii,
                            hipStream_t st) {
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs,
-                       colors_precomp, opacities, scales, rotations, cov3D_precomp, g.splats, g.rect, g.tiles,
-                       g.clamped, g.keys[0], g.vals[0], radii);
+    if (cam.sh_dc)
+        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs,
+                           colors_precomp, opacities, scales, rotations, cov3D_precomp, g.splats, g.rect, g.tiles,
+                           g.clamped, g.keys[0], g.vals[0], radii);
+    else
+        hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs,
+                           colors_precomp, opacities, scales, rotations, cov3D_precomp, g.splats, g.rect, g.tiles,
+                           g.clamped, g.keys[0], g.vals[0], radii);
 }
 
 void gsr_launch_preprocess_backward(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
@@ -409,10 +388,16 @@ void gsr_launch_preprocess_backward(const GsrCamDev& cam, int P, const float* me
                                     GsrGeom g, const float* splat_grads, float* dL_dmeans2D, float* dL_dcolors,
                                     float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                                     float* dL_dscales, float* dL_drotations, hipStream_t st) {
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs,
-                       colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g.clamped,
-                       reinterpret_cast<const float4*>(splat_grads), dL_dmeans2D, dL_dcolors, dL_dopacity,
-                       dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
+    if (cam.sh_dc)
+        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs,
+                           colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g.clamped,
+                           reinterpret_cast<const float4*>(splat_grads), dL_dmeans2D, dL_dcolors, dL_dopacity,
+                           dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
+    else
+        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs,
+                           colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g.clamped,
+                           reinterpret_cast<const float4*>(splat_grads), dL_dmeans2D, dL_dcolors, dL_dopacity,
+                           dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
 }
 
 void gsr_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st) {

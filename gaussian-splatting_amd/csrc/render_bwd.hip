@@ -331,10 +331,14 @@ bwd_reduce_instances(int P, const uint32_t* __restrict__ order, const uint32_t* 
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc[lane * 12 + i] = 0.f;
     const float4* stream = inst_grads + (int64_t)base * 3;
+    // the flag of the NEXT chunk is requested before the current chunk's records: the walk is a chain of dependent
+    // loads (flag -> record) and this takes one of the two latencies off every step
+    uint8_t flag_next = (uint32_t)lane < total ? inst_flag[(int64_t)base + lane] : (uint8_t)0;
     for (uint32_t c0 = 0; c0 < total; c0 += 64) {
         const uint32_t r = c0 + lane;
         const bool valid = r < total;
-        const bool has_rec = valid && inst_flag[(int64_t)base + r] != 0;     // untouched instances have no record
+        const bool has_rec = valid && flag_next != 0;     // untouched instances have no record
+        flag_next = (r + 64u) < total ? inst_flag[(int64_t)base + r + 64u] : (uint8_t)0;
         if (__ballot(has_rec) == 0ull) continue;     // e.g. far Gaussians that every pixel terminated in front of
         int lo = 0, hi = last;
 #pragma unroll

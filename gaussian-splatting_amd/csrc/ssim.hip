@@ -18,6 +18,12 @@ namespace {
 constexpr int TS = 16;            // output tile
 constexpr int HALO = 5;
 constexpr int TW = TS + 2 * HALO; // 26
+// LDS row strides (floats).  In both passes a wave covers 4 consecutive rows x 16 columns: with a 48-float stride the
+// four rows start 16 banks apart (48 r mod 64 = 0, 48, 32, 16), with 16 they are simply consecutive -- every ds_read /
+// ds_write of the two passes is conflict-free (the former 27 / 17 strides measured 2.3 conflict cycles per LDS
+// instruction issue cycle, profiles/r01_pmc_sq_per_kernel.csv).
+constexpr int SW = 48;            // staged halo rows
+constexpr int SHW = 16;           // horizontally filtered rows
 constexpr float C1 = 0.01f * 0.01f;
 constexpr float C2 = 0.03f * 0.03f;
 
@@ -29,9 +35,9 @@ __constant__ float c_win[11] = {1.0283801239e-03f, 7.5987582095e-03f, 3.60007733
 __global__ void __launch_bounds__(256)
 ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2, float* __restrict__ ssim_map,
                 float* __restrict__ dm_dmu1, float* __restrict__ dm_dex2, float* __restrict__ dm_dexy) {
-    __shared__ float s_x[TW][TW + 1];
-    __shared__ float s_y[TW][TW + 1];
-    __shared__ float s_h[5][TW][TS + 1];
+    __shared__ float s_x[TW][SW];
+    __shared__ float s_y[TW][SW];
+    __shared__ float s_h[5][TW][SHW];
     const int tid = threadIdx.x;
     const int plane = blockIdx.z;                       // b * C + c
     const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
@@ -86,8 +92,8 @@ __global__ void __launch_bounds__(256)
 ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
                 const float* __restrict__ dL_dmap, const float* __restrict__ dm_dmu1, const float* __restrict__ dm_dex2,
                 const float* __restrict__ dm_dexy, float* __restrict__ dL_dimg1) {
-    __shared__ float s_in[3][TW][TW + 1];
-    __shared__ float s_h[3][TW][TS + 1];
+    __shared__ float s_in[3][TW][SW];
+    __shared__ float s_h[3][TW][SHW];
     const int tid = threadIdx.x;
     const int plane = blockIdx.z;
     const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;

@@ -119,11 +119,20 @@ class _RasterizeGaussians(torch.autograd.Function):
         means3D_c, sh_c, col_c = _f32c(means3D), _f32c(sh), _f32c(colors_precomp)
         op_c, sc_c, rot_c, cov_c = _f32c(opacities), _f32c(scales), _f32c(rotations), _f32c(cov3Ds_precomp)
         dc_c = _f32c(dc)
-        # split form: dc[P,1,3] + sh[P,M-1,3].  A model with max_sh_degree 0 has an empty `sh`: the DC tensor then IS the
-        # fused [P,1,3] form and its gradient is routed back to `dc`.
-        ctx.dc_as_sh = dc_c is not None and (sh_c is None or sh_c.numel() == 0 or sh_c.shape[1] == 0)
-        if ctx.dc_as_sh:
-            sh_c, dc_c = dc_c.view(P, 1, 3), None
+        # split form: dc[P,1,3] + sh[P,M-1,3].  The kernels take it natively for degree-3 storage (M == 16).  A model
+        # with max_sh_degree 0 has an empty `sh`: the DC tensor then IS the fused [P,1,3] record ("as_sh").  Other small
+        # records (M = 4, 9) or unaligned views are concatenated like the reference's own get_features
+        # (scene/gaussian_model.py:121-125) and the gradient is split again in backward ("cat").
+        ctx.dc_mode = "none"
+        if dc_c is not None:
+            if sh_c is None or sh_c.numel() == 0 or sh_c.shape[1] == 0:
+                ctx.dc_mode = "as_sh"
+                sh_c, dc_c = dc_c.view(P, 1, 3), None
+            elif sh_c.shape[1] + 1 != 16 or dc_c.data_ptr() % 16 or sh_c.data_ptr() % 16:
+                ctx.dc_mode = "cat"
+                sh_c, dc_c = torch.cat([dc_c.view(P, 1, 3), sh_c], dim=1), None
+            else:
+                ctx.dc_mode = "split"
         M = int(sh_c.shape[1]) if sh_c is not None and sh_c.dim() == 3 else 0
         if dc_c is not None:
             M += 1
@@ -244,9 +253,12 @@ class _RasterizeGaussians(torch.autograd.Function):
                 else:
                     _run()
         dL_dopacity = dL_dopacity.view(ctx.op_shape)
-        if ctx.dc_as_sh:      # the DC tensor travelled as the fused [P,1,3] form
+        if ctx.dc_mode == "as_sh":      # the DC tensor travelled as the fused [P,1,3] form
             dL_ddc = dL_dsh.view(ctx.dc_shape)
             dL_dsh = dL_dsh.new_zeros(P, 0, 3) if ctx.sh_given else None
+        elif ctx.dc_mode == "cat":
+            dL_ddc = dL_dsh[:, :1].reshape(ctx.dc_shape)
+            dL_dsh = dL_dsh[:, 1:]
         elif has_dc:
             dL_ddc = dL_ddc.view(ctx.dc_shape)
         return (dL_dmeans3D, dL_dmeans2D if ctx.has_means2D else None, dL_dsh, dL_dcolors if has_col else None, dL_dopacity, dL_dscales, dL_drot,

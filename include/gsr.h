@@ -72,7 +72,8 @@ typedef struct GsrRasterSettings {
     /* Extension -- the "separate_sh" call form the reference uses when its accelerated rasterizer is installed
      * (gaussian_renderer/__init__.py:82-100: rasterizer(dc = features_dc, shs = features_rest, ...)): when sh_dc is
      * non-NULL, SH coefficient 0 is read from sh_dc[P,1,3] and `shs` holds coefficients 1..M-1 as [P,M-1,3] (M still
-     * counts ALL coefficients, M >= 2).  In the backward dL_dsh then receives [P,M-1,3] and dL_dsh_dc[P,1,3] the
+     * counts ALL coefficients; supported for degree-3 storage, M == 16, with 16-byte aligned pointers -- else
+     * GSR_ERR_UNSUPPORTED and the caller concatenates).  In the backward dL_dsh then receives [P,M-1,3] and dL_dsh_dc[P,1,3] the
      * gradient of the DC term.  This avoids the torch.cat of the two parameter tensors (scene/gaussian_model.py:121-125)
      * and the split of its gradient in every iteration.  Both NULL = fused [P,M,3] form. */
     const float* sh_dc;

@@ -124,9 +124,10 @@ def test_sparse_gaussian_adam_updates_only_visible_rows():
     torch.cuda.synchronize()
     for k, p in params.items():
         st = opt.state[p]
-        assert torch.allclose(p.detach().double(), ref_p[k], rtol=2e-6, atol=1e-7), k
-        assert torch.allclose(st["exp_avg"].double(), ref_m[k], rtol=2e-6, atol=1e-12), k
-        assert torch.allclose(st["exp_avg_sq"].double(), ref_v[k], rtol=2e-6, atol=1e-12), k
+        # fp32 kernel against an fp64 restatement: a few ulp of the largest term of each sum
+        assert torch.allclose(p.detach().double(), ref_p[k], rtol=2e-6, atol=2e-6 * float(ref_p[k].abs().max())), k
+        assert torch.allclose(st["exp_avg"].double(), ref_m[k], rtol=2e-6, atol=1e-6 * float(ref_m[k].abs().max())), k
+        assert torch.allclose(st["exp_avg_sq"].double(), ref_v[k], rtol=2e-6, atol=1e-6 * float(ref_v[k].abs().max())), k
     # rows never visible are bit-identical to their initial value
     opt2_p = torch.randn(N, 3, generator=g).to(dev).requires_grad_(True)
     init = opt2_p.detach().clone()
