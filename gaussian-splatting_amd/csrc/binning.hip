@@ -179,8 +179,9 @@ void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offse
                            (uint32_t*)inst_keys, inst_vals, splats);
 }
 
-void gsr_launch_ranges(int64_t R, int n_tiles, const void* sorted_keys, bool key16, uint2* ranges, hipStream_t st) {
-    (void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)n_tiles, st);
+void gsr_launch_ranges(int64_t R, int n_tiles, const void* sorted_keys, bool key16, uint2* ranges, bool already_zeroed,
+                       hipStream_t st) {
+    if (!already_zeroed) (void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)n_tiles, st);
     if (R <= 0) return;
     int64_t nb = (R + 255) / 256;
     if (nb > 2048) nb = 2048;

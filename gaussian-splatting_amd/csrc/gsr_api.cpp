@@ -313,6 +313,9 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
     }
     const int n_tiles = cam.gx * cam.gy;
     char* ibase = (char*)image_resize(image_user, gsr_image_bytes(cam.W, cam.H));
+    // the tile-range table is cleared here, in the shadow of the R read-back (the stream is otherwise idle while the
+    // host waits), instead of in front of the range kernel
+    if (ibase) HIP_OK(hipMemsetAsync(gsr_carve_image(ibase, cam.W, cam.H).ranges, 0, sizeof(uint2) * (size_t)n_tiles, st));
     char* bbase = nullptr;
     size_t spec_bytes = 0;
     const int64_t last_R = g_last_R.load();
@@ -366,7 +369,7 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
         STAGE_CHECK("tile sort");
     }
     {   StageTimer t(GSR_STAGE_RANGES, st);
-        gsr_launch_ranges(R, n_tiles, b.keys[list_buf], n_tiles <= 65536, im.ranges, st);
+        gsr_launch_ranges(R, n_tiles, b.keys[list_buf], n_tiles <= 65536, im.ranges, /*already_zeroed=*/true, st);
     }
     STAGE_CHECK("ranges");
     {   StageTimer t(GSR_STAGE_RENDER, st);

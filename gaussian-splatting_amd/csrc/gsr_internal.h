@@ -97,7 +97,8 @@ void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles, 
 void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect,
                      void* inst_keys, bool key16, uint32_t* inst_vals, float4* splats /*NULL: skip the goffset write*/,
                      hipStream_t st);
-void gsr_launch_ranges(int64_t R, int n_tiles, const void* sorted_keys, bool key16, uint2* ranges, hipStream_t st);
+void gsr_launch_ranges(int64_t R, int n_tiles, const void* sorted_keys, bool key16, uint2* ranges, bool already_zeroed,
+                       hipStream_t st);
 
 // render_fwd.hip / render_bwd.hip
 void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,

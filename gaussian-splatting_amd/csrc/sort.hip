@@ -10,7 +10,7 @@
 // One pass = three launches (a chained-scan "onesweep" pass was rejected: a cross-workgroup hop costs
 // 1-3 us under load on this part, MI355X_MICROARCH.md handoff rows, and the look-back chain is serial):
 //   rs_hist    : per-workgroup digit histogram                          (reads keys)
-//   rs_scan    : one workgroup per digit scans its row over workgroups  (tiny)
+//   rs_scan    : one wave per digit scans its row over workgroups       (tiny)
 //   rs_scatter : wave64 ballot-match ranking, stable; items are re-ordered in LDS first so that every
 //                digit's run leaves the CU as one contiguous store burst (reads keys+vals, writes both)
 // Ranking idiom: each wave owns a contiguous run of the workgroup's items and walks it 64 at a time; the
@@ -38,16 +38,70 @@ rs_hist(const KeyT* __restrict__ keys, int64_t n, int shift, uint32_t* __restric
     constexpr int NB = 1 << BITS;
     constexpr int NCOPY = (NB <= 256) ? RS_WAVES : 1;     // per-wave copies only when they are cheap
     __shared__ uint32_t h[NCOPY][NB];
-    const int tid = threadIdx.x, w = tid >> 6;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     for (int d = tid; d < NB; d += RS_THREADS)
 #pragma unroll
         for (int i = 0; i < NCOPY; ++i) h[i][d] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * (RS_THREADS * IPT);
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    // a histogram does not care about item order: every thread takes its keys in 16-byte (or IPT-key) vectors, so one
+    // wave-wide load moves 1 KB instead of the 128 B of a 16-bit scalar load
+    constexpr int VB = (IPT * (int)sizeof(KeyT) >= 16) ? 16 : IPT * (int)sizeof(KeyT);
+    constexpr int VEC = VB / (int)sizeof(KeyT), NV = IPT / VEC, NW = VB / 4;
+    static_assert(VB >= 4 && NV * VEC == IPT, "vector layout");
+    uint32_t word[NV][NW];
 #pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-        const int64_t idx = base + i * RS_THREADS + tid;
-        if (idx < n) atomicAdd(&h[NCOPY == 1 ? 0 : w][((uint32_t)keys[idx] >> shift) & (NB - 1)], 1u);
+    for (int v = 0; v < NV; ++v) {
+        const int64_t e0 = base + ((int64_t)v * RS_THREADS + tid) * VEC;
+        if (e0 + VEC <= n) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(keys + e0);
+            if (NW == 4) {
+                const uint4 t = *reinterpret_cast<const uint4*>(src);
+                word[v][0] = t.x; word[v][1] = t.y; word[v][2 % NW] = t.z; word[v][3 % NW] = t.w;
+            } else if (NW == 2) {
+                const uint2 t = *reinterpret_cast<const uint2*>(src);
+                word[v][0] = t.x; word[v][1 % NW] = t.y;
+            } else {
+                word[v][0] = src[0];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NW; ++j) word[v][j] = 0u;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                if (e0 + j < n) {
+                    const uint32_t k = (uint32_t)keys[e0 + j];
+                    if (sizeof(KeyT) == 2) word[v][j / 2] |= k << (16 * (j & 1));
+                    else word[v][j % NW] = k;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int64_t e0 = base + ((int64_t)v * RS_THREADS + tid) * VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const bool valid = e0 + j < n;
+            const uint32_t k = sizeof(KeyT) == 2 ? ((word[v][j / 2] >> (16 * (j & 1))) & 0xFFFFu) : word[v][j % NW];
+            const uint32_t d = valid ? ((k >> shift) & (NB - 1)) : 0u;
+            if (BITS <= 8) {
+                // Neighbouring keys often share the digit (tile ids of one splat, the high digit above all): 64 lanes
+                // bumping one LDS counter serialise.  Match the digits across the wave with BITS ballots instead and
+                // let the lowest lane of every group add the group's size once.
+                uint64_t mask = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < BITS; ++b) {
+                    const bool bit = (d >> b) & 1u;
+                    const uint64_t bal = __ballot(bit);
+                    mask &= bit ? bal : ~bal;
+                }
+                if (valid && (mask & lt_mask) == 0ull) atomicAdd(&h[NCOPY == 1 ? 0 : w][d], (uint32_t)__popcll(mask));
+            } else {
+                if (valid) atomicAdd(&h[NCOPY == 1 ? 0 : w][d], 1u);
+            }
+        }
     }
     __syncthreads();
     for (int d = tid; d < NB; d += RS_THREADS) {
@@ -58,32 +112,34 @@ rs_hist(const KeyT* __restrict__ keys, int64_t n, int shift, uint32_t* __restric
     }
 }
 
-// grid = number of digits (one workgroup per digit).  In place: row[b] <- sum_{b' < b} row[b'];  digit_total[d] = row sum.
+// grid = ceil(digits / 4) workgroups, ONE WAVE per digit row: the row (one count per workgroup of the pass) is scanned
+// 64 entries at a time with a running carry -- no LDS, no workgroup barrier.  In place: row[b] <- sum_{b' < b} row[b'];
+// digit_total[d] = row sum.
 __global__ void __launch_bounds__(RS_THREADS)
-rs_scan(uint32_t* __restrict__ block_hist, int nblocks, uint32_t* __restrict__ digit_total) {
-    __shared__ uint32_t wsum[RS_WAVES];
-    __shared__ uint32_t carry_s;
-    uint32_t* row = block_hist + (int64_t)blockIdx.x * nblocks;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < nblocks; base += RS_THREADS) {
-        const int i = base + tid;
-        const uint32_t v = i < nblocks ? row[i] : 0u;
-        const uint32_t incl = wave_incl_scan_u32(v, lane);
-        if (lane == 63) wsum[w] = incl;
-        __syncthreads();
-        uint32_t wbase = 0;
+rs_scan(uint32_t* __restrict__ block_hist, int nblocks, int ndigits, uint32_t* __restrict__ digit_total) {
+    const int lane = threadIdx.x & 63;
+    const int d = blockIdx.x * RS_WAVES + (threadIdx.x >> 6);
+    if (d >= ndigits) return;
+    uint32_t* row = block_hist + (int64_t)d * nblocks;
+    uint32_t carry = 0;
+    for (int base = 0; base < nblocks; base += 256) {
+        // four independent 64-entry segments per trip keep four loads in flight
+        uint32_t v[4], incl[4];
 #pragma unroll
-        for (int k = 0; k < RS_WAVES; ++k)
-            if (k < w) wbase += wsum[k];
-        const uint32_t carry = carry_s;
-        if (i < nblocks) row[i] = carry + wbase + incl - v;
-        __syncthreads();
-        if (tid == RS_THREADS - 1) carry_s = carry + wbase + incl;
-        __syncthreads();
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + k * 64 + lane;
+            v[k] = i < nblocks ? row[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) incl[k] = wave_incl_scan_u32(v[k], lane);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + k * 64 + lane;
+            if (i < nblocks) row[i] = carry + incl[k] - v[k];
+            carry += (uint32_t)__shfl((int)incl[k], 63, 64);
+        }
     }
-    if (tid == 0) digit_total[blockIdx.x] = carry_s;
+    if (lane == 0) digit_total[d] = carry;
 }
 
 // Exclusive scan of NB values held DPT per thread (thread t owns digits t*DPT .. t*DPT+DPT-1); returns the exclusive
@@ -231,7 +287,8 @@ template <typename KeyT, int IPT, int BITS>
 void sort_pass(KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vout, int64_t n, int shift, uint32_t* hist,
                uint32_t* digit_total, int nblocks, hipStream_t st) {
     hipLaunchKernelGGL((rs_hist<KeyT, IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, n, shift, hist, nblocks);
-    hipLaunchKernelGGL(rs_scan, dim3(1 << BITS), dim3(RS_THREADS), 0, st, hist, nblocks, digit_total);
+    hipLaunchKernelGGL(rs_scan, dim3(((1 << BITS) + RS_WAVES - 1) / RS_WAVES), dim3(RS_THREADS), 0, st, hist, nblocks, 1 << BITS,
+                       digit_total);
     hipLaunchKernelGGL((rs_scatter<KeyT, IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, vin, kout, vout, n, shift, hist,
                        digit_total, nblocks);
 }
