@@ -10,7 +10,7 @@
 // One pass = three launches (a chained-scan "onesweep" pass was rejected: a cross-workgroup hop costs
 // 1-3 us under load on this part, MI355X_MICROARCH.md handoff rows, and the look-back chain is serial):
 //   rs_hist    : per-workgroup digit histogram                          (reads keys)
-//   rs_scan    : one wave per digit scans its row over workgroups       (tiny)
+//   rs_scan    : one workgroup per digit scans its row over workgroups  (tiny)
 //   rs_scatter : wave64 ballot-match ranking, stable; items are re-ordered in LDS first so that every
 //                digit's run leaves the CU as one contiguous store burst (reads keys+vals, writes both)
 // Ranking idiom: each wave owns a contiguous run of the workgroup's items and walks it 64 at a time; the
@@ -38,13 +38,12 @@ rs_hist(const KeyT* __restrict__ keys, int64_t n, int shift, uint32_t* __restric
     constexpr int NB = 1 << BITS;
     constexpr int NCOPY = (NB <= 256) ? RS_WAVES : 1;     // per-wave copies only when they are cheap
     __shared__ uint32_t h[NCOPY][NB];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, w = tid >> 6;
     for (int d = tid; d < NB; d += RS_THREADS)
 #pragma unroll
         for (int i = 0; i < NCOPY; ++i) h[i][d] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * (RS_THREADS * IPT);
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
     // a histogram does not care about item order: every thread takes its keys in 16-byte (or IPT-key) vectors, so one
     // wave-wide load moves 1 KB instead of the 128 B of a 16-bit scalar load
     constexpr int VB = (IPT * (int)sizeof(KeyT) >= 16) ? 16 : IPT * (int)sizeof(KeyT);
@@ -86,21 +85,9 @@ rs_hist(const KeyT* __restrict__ keys, int64_t n, int shift, uint32_t* __restric
             const bool valid = e0 + j < n;
             const uint32_t k = sizeof(KeyT) == 2 ? ((word[v][j / 2] >> (16 * (j & 1))) & 0xFFFFu) : word[v][j % NW];
             const uint32_t d = valid ? ((k >> shift) & (NB - 1)) : 0u;
-            if (BITS <= 8) {
-                // Neighbouring keys often share the digit (tile ids of one splat, the high digit above all): 64 lanes
-                // bumping one LDS counter serialise.  Match the digits across the wave with BITS ballots instead and
-                // let the lowest lane of every group add the group's size once.
-                uint64_t mask = __ballot(valid);
-#pragma unroll
-                for (int b = 0; b < BITS; ++b) {
-                    const bool bit = (d >> b) & 1u;
-                    const uint64_t bal = __ballot(bit);
-                    mask &= bit ? bal : ~bal;
-                }
-                if (valid && (mask & lt_mask) == 0ull) atomicAdd(&h[NCOPY == 1 ? 0 : w][d], (uint32_t)__popcll(mask));
-            } else {
-                if (valid) atomicAdd(&h[NCOPY == 1 ? 0 : w][d], 1u);
-            }
+            // plain LDS atomics: matching equal digits across the wave with ballots first (one add per group) measured
+            // SLOWER (25 vs 14 us on 11.3 M 16-bit keys) -- the kernel waits on memory, not on the LDS adder
+            if (valid) atomicAdd(&h[NCOPY == 1 ? 0 : w][d], 1u);
         }
     }
     __syncthreads();
@@ -112,34 +99,34 @@ rs_hist(const KeyT* __restrict__ keys, int64_t n, int shift, uint32_t* __restric
     }
 }
 
-// grid = ceil(digits / 4) workgroups, ONE WAVE per digit row: the row (one count per workgroup of the pass) is scanned
-// 64 entries at a time with a running carry -- no LDS, no workgroup barrier.  In place: row[b] <- sum_{b' < b} row[b'];
-// digit_total[d] = row sum.
+// grid = number of digits, one workgroup per digit row (one count per workgroup of the pass).  Every thread owns a
+// CONTIGUOUS chunk of the row: chunk sums -> one workgroup scan of the 256 sums -> second sweep writes the exclusive
+// prefixes.  Two rounds of independent loads instead of nblocks/256 dependent trips (the trip version measured 6.4 us
+// per launch, almost all of it load latency).  In place: row[b] <- sum_{b' < b} row[b'];  digit_total[d] = row sum.
 __global__ void __launch_bounds__(RS_THREADS)
-rs_scan(uint32_t* __restrict__ block_hist, int nblocks, int ndigits, uint32_t* __restrict__ digit_total) {
-    const int lane = threadIdx.x & 63;
-    const int d = blockIdx.x * RS_WAVES + (threadIdx.x >> 6);
-    if (d >= ndigits) return;
-    uint32_t* row = block_hist + (int64_t)d * nblocks;
-    uint32_t carry = 0;
-    for (int base = 0; base < nblocks; base += 256) {
-        // four independent 64-entry segments per trip keep four loads in flight
-        uint32_t v[4], incl[4];
+rs_scan(uint32_t* __restrict__ block_hist, int nblocks, uint32_t* __restrict__ digit_total) {
+    __shared__ uint32_t wsum[RS_WAVES];
+    uint32_t* row = block_hist + (int64_t)blockIdx.x * nblocks;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int chunk = (nblocks + RS_THREADS - 1) / RS_THREADS;
+    const int lo = min(tid * chunk, nblocks), hi = min(lo + chunk, nblocks);
+    uint32_t sum = 0;
+#pragma unroll 4
+    for (int i = lo; i < hi; ++i) sum += row[i];
+    const uint32_t incl = wave_incl_scan_u32(sum, lane);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = base + k * 64 + lane;
-            v[k] = i < nblocks ? row[i] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) incl[k] = wave_incl_scan_u32(v[k], lane);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = base + k * 64 + lane;
-            if (i < nblocks) row[i] = carry + incl[k] - v[k];
-            carry += (uint32_t)__shfl((int)incl[k], 63, 64);
-        }
+    for (int k = 0; k < RS_WAVES; ++k)
+        if (k < w) run += wsum[k];
+    if (tid == RS_THREADS - 1) digit_total[blockIdx.x] = run + sum;
+#pragma unroll 4
+    for (int i = lo; i < hi; ++i) {
+        const uint32_t v = row[i];
+        row[i] = run;
+        run += v;
     }
-    if (lane == 0) digit_total[d] = carry;
 }
 
 // Exclusive scan of NB values held DPT per thread (thread t owns digits t*DPT .. t*DPT+DPT-1); returns the exclusive
@@ -287,8 +274,7 @@ template <typename KeyT, int IPT, int BITS>
 void sort_pass(KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vout, int64_t n, int shift, uint32_t* hist,
                uint32_t* digit_total, int nblocks, hipStream_t st) {
     hipLaunchKernelGGL((rs_hist<KeyT, IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, n, shift, hist, nblocks);
-    hipLaunchKernelGGL(rs_scan, dim3(((1 << BITS) + RS_WAVES - 1) / RS_WAVES), dim3(RS_THREADS), 0, st, hist, nblocks, 1 << BITS,
-                       digit_total);
+    hipLaunchKernelGGL(rs_scan, dim3(1 << BITS), dim3(RS_THREADS), 0, st, hist, nblocks, digit_total);
     hipLaunchKernelGGL((rs_scatter<KeyT, IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, vin, kout, vout, n, shift, hist,
                        digit_total, nblocks);
 }
