@@ -16,6 +16,23 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
     p = p - step_size * (m / denom);
 }
 
+__device__ __forceinline__ void adam4(float4& p, const float4& g, float4& m, float4& v, float om_b1, float b2, float om_b2,
+                                      float step_size, float inv_bc2_sqrt, float eps) {
+    adam1(p.x, g.x, m.x, v.x, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
+    adam1(p.y, g.y, m.y, v.y, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
+    adam1(p.z, g.z, m.z, v.z, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
+    adam1(p.w, g.w, m.w, v.w, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
+}
+typedef float float4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ntload4(const float4* p) {
+    const float4v t = __builtin_nontemporal_load(reinterpret_cast<const float4v*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void ntstore4(float4* p, const float4& v) {
+    float4v t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<float4v*>(p));
+}
+
 __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
             float om_b1, float b2, float om_b2, float step_size, float inv_bc2_sqrt, float eps, int vec) {
@@ -26,14 +43,25 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
         const float4* g4 = reinterpret_cast<const float4*>(g);
         float4* m4 = reinterpret_cast<float4*>(m);
         float4* v4 = reinterpret_cast<float4*>(v);
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-            float4 pp = p4[i], mm = m4[i], vv = v4[i];
-            const float4 gg = g4[i];
-            adam1(pp.x, gg.x, mm.x, vv.x, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
-            adam1(pp.y, gg.y, mm.y, vv.y, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
-            adam1(pp.z, gg.z, mm.z, vv.z, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
-            adam1(pp.w, gg.w, mm.w, vv.w, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
-            p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        // two independent 64-byte groups per trip (8 x 16-byte loads in flight per lane), streamed past the caches:
+        // every element is touched exactly once per step
+        int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; i + stride < n4; i += 2 * stride) {
+            const int64_t k = i + stride;
+            float4 pa = ntload4(p4 + i), ma = ntload4(m4 + i), va = ntload4(v4 + i);
+            const float4 ga = ntload4(g4 + i);
+            float4 pb = ntload4(p4 + k), mb = ntload4(m4 + k), vb = ntload4(v4 + k);
+            const float4 gb = ntload4(g4 + k);
+            adam4(pa, ga, ma, va, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
+            adam4(pb, gb, mb, vb, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
+            ntstore4(p4 + i, pa); ntstore4(m4 + i, ma); ntstore4(v4 + i, va);
+            ntstore4(p4 + k, pb); ntstore4(m4 + k, mb); ntstore4(v4 + k, vb);
+        }
+        for (; i < n4; i += stride) {
+            float4 pp = ntload4(p4 + i), mm = ntload4(m4 + i), vv = ntload4(v4 + i);
+            const float4 gg = ntload4(g4 + i);
+            adam4(pp, gg, mm, vv, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
+            ntstore4(p4 + i, pp); ntstore4(m4 + i, mm); ntstore4(v4 + i, vv);
         }
         for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
             float pp = p[i], mm = m[i], vv = v[i];
