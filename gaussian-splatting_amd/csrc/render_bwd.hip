@@ -259,31 +259,17 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
                     keep = !(qmin > tau);
                 }
                 uint64_t mask = __ballot(keep);
-                // software pipeline over the survivors: the record of the NEXT survivor is requested from LDS before
-                // the current one is processed, so its ds_read latency overlaps ~80 VALU instructions
-                int jn = mask ? 63 - __builtin_clzll(mask) : -1;
-                float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0;
-                float2 n2 = make_float2(0.f, 0.f);
-                if (jn >= 0) {
-                    const uint32_t en = (uint32_t)sub * 64 + jn;
-                    n0 = s_rec[en * REC_STRIDE + 0];
-                    n1 = s_rec[en * REC_STRIDE + 1];
-                    n2 = *reinterpret_cast<const float2*>(&s_rec[en * REC_STRIDE + 2]);
-                }
-                while (jn >= 0) {
-                    const int j = jn;
-                    const float4 r0 = n0, r1 = n1;
-                    const float2 r2 = n2;
+                // (requesting the NEXT survivor's record before processing the current one -- a software pipeline over
+                // the ds_reads -- measured 8 % slower: 0.517 vs 0.477 ms; LDS returns in order, so the early read also
+                // queues behind this survivor's ds_adds)
+                while (mask) {
+                    const int j = 63 - __builtin_clzll(mask);
                     mask &= ~(1ull << j);
-                    jn = mask ? 63 - __builtin_clzll(mask) : -1;
-                    if (jn >= 0) {
-                        const uint32_t en = (uint32_t)sub * 64 + jn;
-                        n0 = s_rec[en * REC_STRIDE + 0];
-                        n1 = s_rec[en * REC_STRIDE + 1];
-                        n2 = *reinterpret_cast<const float2*>(&s_rec[en * REC_STRIDE + 2]);
-                    }
                     const uint32_t entry = (uint32_t)sub * 64 + j;
                     const uint32_t pos0 = (uint32_t)sb + entry;          // 0-based list position
+                    const float4 r0 = s_rec[entry * REC_STRIDE + 0];
+                    const float4 r1 = s_rec[entry * REC_STRIDE + 1];
+                    const float2 r2 = *reinterpret_cast<const float2*>(&s_rec[entry * REC_STRIDE + 2]);
                     float g_px, g_py, g_A, g_B, g_C, g_op, g_r, g_g, g_b, g_d;     // g_px .. g_C hold the raw moments
                     const bool active = bwd_step(s, pos0 < last_contrib, pxf, pyf, Tf_bg, dLr, dLg, dLb, dLd, r0.x, r0.y, r0.z,
                                                  r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, g_px, g_py, g_A, g_B, g_C, g_op,
