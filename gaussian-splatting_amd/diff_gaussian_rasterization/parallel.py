@@ -73,25 +73,46 @@ def _world(group) -> int:
     return dist.get_world_size(group) if dist.is_initialized() else 1
 
 
-def gather_strips(local: torch.Tensor, plan: BandPlan, H: int, group=None) -> torch.Tensor:
-    """local: [C,H,W] with only this rank's rows valid.  Returns the full [C,H,W] image on every rank.
-    Strips have different heights, so each rank contributes a max-height padded strip to ONE all_gather."""
+class StripGather:
+    """An all-gather of image strips in flight (gather_strips_async).  wait() returns the full [C,H,W] image."""
+
+    def __init__(self, local, recv, rows, work):
+        self._local, self._recv, self._rows, self._work = local, recv, rows, work
+
+    def wait(self) -> torch.Tensor:
+        if self._work is None:
+            return self._local
+        self._work.wait()          # RCCL: the current stream waits for the collective; the host does not block
+        recv, rows = self._recv, self._rows
+        # one concatenation instead of one copy per rank; padding rows of the shorter strips are dropped
+        full = torch.cat([recv[g, :, : gb - ga] for g, (ga, gb) in enumerate(rows)], dim=1)
+        self._work = None
+        self._local = full
+        return full
+
+
+def gather_strips_async(local: torch.Tensor, plan: BandPlan, H: int, group=None) -> StripGather:
+    """local: [C,H,W] with only this rank's rows valid.  Starts ONE all_gather of max-height padded strips (strips have
+    different heights under a balanced plan) and returns a handle; the collective runs on the backend's own stream, so
+    work enqueued afterwards (the next frame's rasterization) overlaps it."""
     world = _world(group)
     if world == 1:
-        return local
+        return StripGather(local, None, None, None)
     rank = dist.get_rank(group)
     C, _, W = local.shape
     rows = [plan.pixel_rows(g, H) for g in range(world)]
     hmax = max(1, max(b - a for a, b in rows))
     a, b = rows[rank]
-    send = local.new_zeros(C, hmax, W)
+    send = local.new_empty(C, hmax, W)          # padding rows are never read back
     send[:, : b - a] = local[:, a:b]
     recv = local.new_empty(world, C, hmax, W)
-    dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)   # flat: concat semantics on every backend
-    full = torch.empty_like(local)
-    for g, (ga, gb) in enumerate(rows):
-        full[:, ga:gb] = recv[g, :, : gb - ga]
-    return full
+    work = dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group, async_op=True)   # flat: concat semantics on every backend
+    return StripGather(local, recv, rows, work)
+
+
+def gather_strips(local: torch.Tensor, plan: BandPlan, H: int, group=None) -> torch.Tensor:
+    """Blocking form: the full [C,H,W] image on every rank."""
+    return gather_strips_async(local, plan, H, group).wait()
 
 
 class _GatherStrips(torch.autograd.Function):

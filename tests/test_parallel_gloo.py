@@ -101,3 +101,43 @@ def test_sharded_render_equals_single_device(world, balanced):
     for a, b in zip(res["grads"], [t.grad for t in leaves] + [m2.grad]):
         # fp32 partial sums are combined in a different order across bands: compare against the gradient's scale
         assert (a - b).abs().max().item() <= 3e-5 * b.abs().max().item()
+
+
+def _pipeline_worker(rank, world, port, path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from diff_gaussian_rasterization.parallel import BandPlan, gather_strips_async
+    H, W, gy = 70, 37, 5                              # last tile row is partial (70 = 4*16 + 6)
+    plan = BandPlan([0, 1, 2, 5]) if world == 3 else BandPlan.uniform(gy, world)      # uneven strips incl. a short one
+    frames = [torch.arange(3 * H * W, dtype=torch.float32).view(3, H, W) * (f + 1) for f in range(3)]
+    a, b = plan.pixel_rows(rank, H)
+    handles = []
+    for f in frames:                                  # three gathers in flight before the first wait (bench.py keeps two)
+        local = torch.full_like(f, -1.0)
+        local[:, a:b] = f[:, a:b]
+        handles.append(gather_strips_async(local, plan, H))
+    outs = [h.wait() for h in handles]
+    ok = all(torch.equal(o, f) for o, f in zip(outs, frames)) and torch.equal(handles[0].wait(), frames[0])
+    if rank == 0:
+        torch.save({"ok": ok}, path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_async_strip_gathers_in_flight(world):
+    """Several strip all-gathers issued back to back (the frame pipeline of bench.py --gpus N) complete in order and
+    assemble the right frames, with uneven band heights and a partial last tile row."""
+    import tempfile
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "ok.pt")
+        procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, path)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        assert torch.load(path)["ok"]
