@@ -541,3 +541,35 @@ def test_fused_ssim_matches_reference_formula(shape):
     assert d <= 2e-5 * a2.grad.abs().max().item(), d
     with torch.no_grad():                      # inference form: no derivative maps kept
         assert abs(fused_ssim(a.to(dev), b.to(dev), train=False).item() - v2.item()) < 2e-6
+
+
+def test_more_than_65536_tiles_uses_32bit_tile_keys():
+    """4112 x 4112 pixels = 257 x 257 = 66 049 tiles: tile ids no longer fit 16 bits, so the binning switches to
+    32-bit keys and a 3-pass tile sort.  Bins against the oracle bit-for-bit; the image on the tiles that hold splats."""
+    W = H = 4112
+    cam = make_camera(W, H)
+    sc = make_scene(3000, cam, seed=41, s_med=0.004)
+    s = oracle_settings(cam)
+    out = run_gpu(s, sc)
+    with torch.no_grad():
+        pre = O.preprocess(sc.means3D, sc.opacities, s, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+        bins = O.bin_and_sort(pre)
+    assert pre["grid"] == (257, 257)
+    assert torch.equal(out["radii"].cpu(), pre["radii"].to(torch.int32))
+    assert out["R"] == bins["R"] and bins["R"] > 3000
+    assert torch.equal(out["point_list"].cpu().long(), bins["point_list"])
+    assert torch.equal(out["ranges"].cpu().long(), bins["ranges"])
+    # tiles beyond id 65535 must be populated, otherwise the case proves nothing
+    assert int(bins["tile_counts"][65536:].sum()) > 0
+    busy = torch.nonzero(bins["tile_counts"] > 0).flatten()
+    sample = busy[:: max(1, busy.numel() // 40)].tolist()
+    col, invd, fT, ncon, frag = O.render_tiles(pre, bins, s, tiles=sample, want_fragile=True)
+    gx = 257
+    gcol = out["color"].cpu()
+    for t in sample:
+        y0, x0 = (t // gx) * 16, (t % gx) * 16
+        ys, xs = slice(y0, min(y0 + 16, H)), slice(x0, min(x0 + 16, W))
+        ok = ~frag[ys, xs]
+        d = (gcol[:, ys, xs] - col[:, ys, xs]).abs().max(0).values
+        assert float(d[ok].max() if ok.any() else 0.0) <= IMG_TOL
+    assert torch.isfinite(out["color"]).all()
