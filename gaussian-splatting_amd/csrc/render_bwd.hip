@@ -117,18 +117,23 @@ struct BwdPix {
 // not the derivatives themselves: the derivatives are linear in the moments with per-Gaussian coefficients
 //     dL/dpx = -A mx - B my,  dL/dpy = -C my - B mx,  dL/dA = -mxx/2,  dL/dB = -mxy,  dL/dC = -myy/2
 // so that multiplication is done ONCE per Gaussian after all sums (bwd_reduce_instances) instead of per pair.
+typedef float v2f __attribute__((ext_vector_type(2)));      // pairs that the compiler turns into v_pk_*_f32
+
 __device__ __forceinline__ bool bwd_step(BwdPix& s, bool take, float pxf, float pyf, float Tf_bg, float dLr, float dLg,
                                          float dLb, float dLd, float gx_, float gy_, float a2, float b2, float c2, float op,
                                          float cr, float cg, float cb, float idp, float& mx, float& my, float& mxx,
                                          float& mxy, float& myy, float& g_op, float& g_r, float& g_g, float& g_b,
                                          float& g_d) {
-    const float dx = gx_ - pxf, dy = gy_ - pyf;
+    const v2f d = (v2f){gx_, gy_} - (v2f){pxf, pyf};
+    const float dx = d.x, dy = d.y;
     const float t = fmaf(b2, dy, a2 * dx);
     const float p2 = fmaf(dx, t, (c2 * dy) * dy);
     const float G = __builtin_amdgcn_exp2f(p2);
     const float alpha = fminf(GSR_ALPHA_MAX, op * G);
     const bool active = take & (p2 <= 0.0f) & (alpha >= GSR_ALPHA_MIN);
-    const float cD = fmaf(idp, dLd, fmaf(cb, dLb, fmaf(cg, dLg, cr * dLr)));
+    const v2f dL01 = {dLr, dLg}, dL23 = {dLb, dLd};
+    const v2f cd = (v2f){cr, cg} * dL01 + (v2f){cb, idp} * dL23;
+    const float cD = cd.x + cd.y;
     float w = 0.0f, dL_dalpha = 0.0f;
     if (active) {
         const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
@@ -139,11 +144,15 @@ __device__ __forceinline__ bool bwd_step(BwdPix& s, bool take, float pxf, float 
         s.last_alpha = alpha;
         dL_dalpha = fmaf(cD - s.accD, s.T, Tf_bg * inv1ma);      // Tf_bg = -T_final * <bg, dL/dpix>
     }
-    g_r = w * dLr; g_g = w * dLg; g_b = w * dLb; g_d = w * dLd;
+    const v2f g01 = w * dL01, g23 = w * dL23;
+    g_r = g01.x; g_g = g01.y; g_b = g23.x; g_d = g23.y;
     g_op = G * dL_dalpha;
     const float m = op * g_op;
-    mx = m * dx; my = m * dy;
-    mxx = mx * dx; mxy = mx * dy; myy = my * dy;
+    const v2f md = m * d;                // (m dx, m dy)
+    const v2f mxd = md.x * d;            // (m dx^2, m dx dy)
+    mx = md.x; my = md.y;
+    mxx = mxd.x; mxy = mxd.y;
+    myy = md.y * dy;
     return active;
 }
 
