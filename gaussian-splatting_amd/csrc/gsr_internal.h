@@ -136,3 +136,10 @@ void gsr_launch_sparse_adam(float* p, const float* g, float* m, float* v, const 
 // knn.hip
 size_t gsr_knn_scratch_bytes_impl(int N);
 void gsr_launch_knn(int N, const float* points, float* out, void* scratch, hipStream_t st);
+// ssim.hip: mean-SSIM form (no map round trip)
+int64_t gsr_ssim_partial_count_impl(int planes, int H, int W);
+void gsr_launch_ssim_mean_forward(int planes, int H, int W, const float* img1, const float* img2, float* partials,
+                                  float* mean_out, float* dm_dmu1, float* dm_dex2, float* dm_dexy, hipStream_t st);
+void gsr_launch_ssim_mean_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dmean,
+                                   const float* dm_dmu1, const float* dm_dex2, const float* dm_dexy, float* dL_dimg1,
+                                   hipStream_t st);

@@ -256,6 +256,7 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
 
         if (quad_alive) {
             for (int sub = (int)((n - 1) >> 6); sub >= 0; --sub) {
+                if ((uint32_t)sb + (uint32_t)sub * 64u >= mx) continue;      // wholly behind this quadrant's last contributor
                 const uint32_t e = (uint32_t)sub * 64 + lane;
                 bool keep = false;
                 if (e < n) {
@@ -265,7 +266,9 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
                     // plain conic back from the scaled one (the test has a 0.01 margin in tau: the extra rounding is harmless)
                     const float qmin = min_q_over_box(r0.x, r0.y, r0.z * (-2.0f / LOG2E), r0.w * (-1.0f / LOG2E),
                                                       c2e * (-2.0f / LOG2E), x0, x1, y0, y1);
-                    keep = !(qmin > tau);
+                    // entries at or behind the quadrant's own last contributor touch none of its pixels either (the
+                    // super-batch runs to the TILE's last contributor, which another quadrant may set much deeper)
+                    keep = !(qmin > tau) && ((uint32_t)sb + e < mx);
                 }
                 uint64_t mask = __ballot(keep);
                 // (requesting the NEXT survivor's record before processing the current one -- a software pipeline over

@@ -32,9 +32,13 @@ __constant__ float c_win[11] = {1.0283801239e-03f, 7.5987582095e-03f, 3.60007733
                                 2.1300552785e-01f, 2.6601171494e-01f, 2.1300552785e-01f, 1.0936068743e-01f,
                                 3.6000773311e-02f, 7.5987582095e-03f, 1.0283801239e-03f};
 
+// MEAN: instead of the SSIM map the workgroup writes the SUM of its tile's SSIM values (partials[plane][tile]); a second
+// one-workgroup kernel adds the partials in fixed order -> mean (deterministic, no 25 MB map round trip, no torch reduce)
+template <bool MEAN>
 __global__ void __launch_bounds__(256)
 ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2, float* __restrict__ ssim_map,
                 float* __restrict__ dm_dmu1, float* __restrict__ dm_dex2, float* __restrict__ dm_dexy) {
+    __shared__ float s_part[4];
     __shared__ float s_x[TW][SW];
     __shared__ float s_y[TW][SW];
     __shared__ float s_h[5][TW][SHW];
@@ -64,6 +68,7 @@ ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __res
     __syncthreads();
     const int ty = tid / TS, tx = tid - ty * TS;
     const int gy = y0 + ty, gx = x0 + tx;
+    float m_own = 0.f;
     if (gy < H && gx < W) {
         float mu1 = 0.f, mu2 = 0.f, ex2 = 0.f, ey2 = 0.f, exy = 0.f;
 #pragma unroll
@@ -79,19 +84,47 @@ ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __res
         const float inv_AB = 1.f / (A * B);
         const float m = Cc * D * inv_AB;
         const int64_t o = (int64_t)plane * H * W + (int64_t)gy * W + gx;
-        ssim_map[o] = m;
+        m_own = m;
+        if (!MEAN) ssim_map[o] = m;
         if (dm_dmu1) {
             dm_dmu1[o] = 2.f * mu2 * (D - Cc) * inv_AB - 2.f * mu1 * m / A + 2.f * mu1 * m / B;
             dm_dex2[o] = -m / B;
             dm_dexy[o] = 2.f * Cc * inv_AB;
         }
     }
+    if (MEAN) {
+        float v = m_own;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((tid & 63) == 0) s_part[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0)
+            ssim_map[((int64_t)plane * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    }
 }
 
+// one workgroup: mean = (sum of the per-tile partial sums, fixed order) / count
+__global__ void __launch_bounds__(256)
+ssim_mean_kernel(const float* __restrict__ partials, int n, float inv_count, float* __restrict__ mean_out) {
+    __shared__ float s_part[4];
+    const int tid = threadIdx.x;
+    const int chunk = (n + 255) / 256;
+    const int lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+    float v = 0.f;
+    for (int i = lo; i < hi; ++i) v += partials[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((tid & 63) == 0) s_part[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) mean_out[0] = ((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])) * inv_count;
+}
+
+// MEAN: dL/dmap is the same for every pixel, dL/dmean / count, read from one device scalar
+template <bool MEAN>
 __global__ void __launch_bounds__(256)
 ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
-                const float* __restrict__ dL_dmap, const float* __restrict__ dm_dmu1, const float* __restrict__ dm_dex2,
-                const float* __restrict__ dm_dexy, float* __restrict__ dL_dimg1) {
+                const float* __restrict__ dL_dmap, float inv_count, const float* __restrict__ dm_dmu1,
+                const float* __restrict__ dm_dex2, const float* __restrict__ dm_dexy, float* __restrict__ dL_dimg1) {
     __shared__ float s_in[3][TW][SW];
     __shared__ float s_h[3][TW][SHW];
     const int tid = threadIdx.x;
@@ -103,7 +136,7 @@ ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __res
         const int gy = y0 + r - HALO, gx = x0 + c - HALO;
         const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
         const int64_t o = pbase + (int64_t)gy * W + gx;
-        const float g = in ? dL_dmap[o] : 0.f;
+        const float g = in ? (MEAN ? dL_dmap[0] * inv_count : dL_dmap[o]) : 0.f;
         s_in[0][r][c] = in ? g * dm_dmu1[o] : 0.f;
         s_in[1][r][c] = in ? g * dm_dex2[o] : 0.f;
         s_in[2][r][c] = in ? g * dm_dexy[o] : 0.f;
@@ -139,11 +172,34 @@ ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __res
 void gsr_launch_ssim_forward(int planes, int H, int W, const float* img1, const float* img2, float* ssim_map, float* dm_dmu1,
                              float* dm_dex2, float* dm_dexy, hipStream_t st) {
     const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, planes);
-    hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, st, H, W, img1, img2, ssim_map, dm_dmu1, dm_dex2, dm_dexy);
+    hipLaunchKernelGGL(ssim_fwd_kernel<false>, grid, dim3(256), 0, st, H, W, img1, img2, ssim_map, dm_dmu1, dm_dex2, dm_dexy);
+}
+
+int64_t gsr_ssim_partial_count_impl(int planes, int H, int W) {
+    return (int64_t)planes * ((W + TS - 1) / TS) * ((H + TS - 1) / TS);
+}
+
+void gsr_launch_ssim_mean_forward(int planes, int H, int W, const float* img1, const float* img2, float* partials,
+                                  float* mean_out, float* dm_dmu1, float* dm_dex2, float* dm_dexy, hipStream_t st) {
+    const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, planes);
+    hipLaunchKernelGGL(ssim_fwd_kernel<true>, grid, dim3(256), 0, st, H, W, img1, img2, partials, dm_dmu1, dm_dex2, dm_dexy);
+    const double count = (double)planes * H * W;
+    hipLaunchKernelGGL(ssim_mean_kernel, dim3(1), dim3(256), 0, st, partials, (int)gsr_ssim_partial_count_impl(planes, H, W),
+                       (float)(1.0 / count), mean_out);
+}
+
+void gsr_launch_ssim_mean_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dmean,
+                                   const float* dm_dmu1, const float* dm_dex2, const float* dm_dexy, float* dL_dimg1,
+                                   hipStream_t st) {
+    const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, planes);
+    const double count = (double)planes * H * W;
+    hipLaunchKernelGGL(ssim_bwd_kernel<true>, grid, dim3(256), 0, st, H, W, img1, img2, dL_dmean, (float)(1.0 / count), dm_dmu1,
+                       dm_dex2, dm_dexy, dL_dimg1);
 }
 
 void gsr_launch_ssim_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dmap,
                               const float* dm_dmu1, const float* dm_dex2, const float* dm_dexy, float* dL_dimg1, hipStream_t st) {
     const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, planes);
-    hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, st, H, W, img1, img2, dL_dmap, dm_dmu1, dm_dex2, dm_dexy, dL_dimg1);
+    hipLaunchKernelGGL(ssim_bwd_kernel<false>, grid, dim3(256), 0, st, H, W, img1, img2, dL_dmap, 0.f, dm_dmu1, dm_dex2, dm_dexy,
+                       dL_dimg1);
 }

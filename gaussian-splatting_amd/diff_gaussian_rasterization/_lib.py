@@ -46,7 +46,7 @@ EXPORTS = [
     "gsr_backward_scratch_bytes",
     "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_backward_blend", "gsr_backward_preprocess",
     "gsr_mark_visible", "gsr_forward_views", "gsr_adam_step", "gsr_sparse_adam_step", "gsr_ssim_forward", "gsr_ssim_backward",
-    "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2",
+    "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_ssim_partial_count", "gsr_ssim_mean_forward", "gsr_ssim_mean_backward",
     "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_set_option",
 ]
 
@@ -116,6 +116,12 @@ def load() -> C.CDLL:
     lib.gsr_knn_mean_dist2.argtypes = [C.c_int, vp, vp, vp, vp]
     lib.gsr_ssim_forward.restype = C.c_int
     lib.gsr_ssim_forward.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_ssim_partial_count.restype = C.c_int64
+    lib.gsr_ssim_partial_count.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.gsr_ssim_mean_forward.restype = C.c_int
+    lib.gsr_ssim_mean_forward.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_ssim_mean_backward.restype = C.c_int
+    lib.gsr_ssim_mean_backward.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_ssim_backward.restype = C.c_int
     lib.gsr_ssim_backward.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_mark_visible.restype = C.c_int

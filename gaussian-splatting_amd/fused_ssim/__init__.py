@@ -14,7 +14,7 @@ import torch
 
 from diff_gaussian_rasterization import _lib
 
-__all__ = ["fused_ssim", "FusedSSIMMap"]
+__all__ = ["fused_ssim", "FusedSSIMMap", "FusedSSIMMean"]
 
 
 def _p(t):
@@ -61,9 +61,55 @@ class FusedSSIMMap(torch.autograd.Function):
         return out, None, None
 
 
+class FusedSSIMMean(torch.autograd.Function):
+    """mean(SSIM map) without materialising the map: per-tile partial sums in the forward kernel, one device scalar
+    dL/dmean into the backward kernel (gsr_ssim_mean_forward / gsr_ssim_mean_backward)."""
+
+    @staticmethod
+    def forward(ctx, img1, img2, train=True):
+        lib = _lib.load()
+        if not img1.is_cuda or not img2.is_cuda:
+            raise _lib.GsrError("fused_ssim needs HIP tensors ('cuda'); there is no CPU path")
+        a = img1.contiguous().float()
+        b = img2.contiguous().float()
+        Bn, Cn, H, W = a.shape
+        planes = Bn * Cn
+        need = train and img1.requires_grad
+        d1 = torch.empty_like(a) if need else None
+        d2 = torch.empty_like(a) if need else None
+        d3 = torch.empty_like(a) if need else None
+        partials = torch.empty(int(lib.gsr_ssim_partial_count(planes, H, W)), dtype=torch.float32, device=a.device)
+        mean = torch.empty((), dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            st = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+            _lib.check(lib.gsr_ssim_mean_forward(planes, H, W, _p(a), _p(b), _p(partials), _p(mean), _p(d1), _p(d2), _p(d3), st),
+                       "gsr_ssim_mean_forward")
+        if need:
+            ctx.save_for_backward(a, b, d1, d2, d3)
+        ctx.need = need
+        return mean
+
+    @staticmethod
+    def backward(ctx, dL_dmean):
+        if not ctx.need:
+            return None, None, None
+        lib = _lib.load()
+        a, b, d1, d2, d3 = ctx.saved_tensors
+        Bn, Cn, H, W = a.shape
+        g = dL_dmean.contiguous().float().reshape(1)
+        out = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            st = C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+            _lib.check(lib.gsr_ssim_mean_backward(Bn * Cn, H, W, _p(a), _p(b), _p(g), _p(d1), _p(d2), _p(d3), _p(out), st),
+                       "gsr_ssim_mean_backward")
+        return out, None, None
+
+
 def fused_ssim(img1, img2, padding="same", train=True):
     if padding != "same":
         raise NotImplementedError("only padding='same' (the reference's call form) is implemented")
     if img1.dim() == 3:
         img1, img2 = img1.unsqueeze(0), img2.unsqueeze(0)
-    return FusedSSIMMap.apply(img1, img2, train).mean()
+    if img1.numel() == 0:
+        return FusedSSIMMap.apply(img1, img2, train).mean()
+    return FusedSSIMMean.apply(img1, img2, train)

@@ -199,6 +199,19 @@ int gsr_ssim_backward(int planes, int H, int W, const float* img1, const float* 
                       const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
                       float* dL_dimg1, void* stream);
 
+/*
+ * Mean-SSIM form of the same kernels -- what `fused_ssim(img1, img2)` returns (train.py:122): the forward writes one
+ * partial sum per 16x16 tile into `partials` (gsr_ssim_partial_count floats) and their mean, added in fixed order, into
+ * mean_out[1]; the backward takes dL/dmean as ONE device scalar.  Saves the SSIM-map round trip and the framework's
+ * reduction / broadcast kernels; results equal gsr_ssim_forward + mean up to fp32 summation order.
+ */
+int64_t gsr_ssim_partial_count(int planes, int H, int W);
+int gsr_ssim_mean_forward(int planes, int H, int W, const float* img1, const float* img2, float* partials, float* mean_out,
+                          float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream);
+int gsr_ssim_mean_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dmean,
+                           const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1,
+                           void* stream);
+
 /* Replaces _C.mark_visible: present[i] = 1 iff Gaussian i is in front of the 0.2 near plane. */
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);

@@ -541,6 +541,13 @@ def test_fused_ssim_matches_reference_formula(shape):
     assert d <= 2e-5 * a2.grad.abs().max().item(), d
     with torch.no_grad():                      # inference form: no derivative maps kept
         assert abs(fused_ssim(a.to(dev), b.to(dev), train=False).item() - v2.item()) < 2e-6
+    # the map-returning form (gsr_ssim_forward / backward) agrees with the mean form (gsr_ssim_mean_*)
+    from fused_ssim import FusedSSIMMap
+    a3 = a.clone().to(dev).requires_grad_(True)
+    m3 = FusedSSIMMap.apply(a3, b.to(dev)).mean()
+    assert abs(m3.item() - v1.item()) < 1e-6
+    (m3 * 3.0).backward()
+    assert (a3.grad - a1.grad).abs().max().item() <= 1e-6 * a1.grad.abs().max().item()
 
 
 def test_more_than_65536_tiles_uses_32bit_tile_keys():
