@@ -54,6 +54,18 @@ def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return t.contiguous()
 
 
+def _bucket(nbytes: int) -> int:
+    """Round a scratch size up to one of 8 sizes per octave (<= 12.5 % slack).  The R-sized buffers (binning state,
+    backward scratch) change by a few hundred KB from frame to frame as the Gaussians move; handing the caching
+    allocator a different size every iteration makes it hipMalloc a fresh block now and then (tens of ms on ROCm --
+    seen as one-off stalls of ~75 ms in bench.py's train legs).  Bucketed sizes hit the same cached block."""
+    nbytes = int(nbytes)
+    if nbytes <= (1 << 20):
+        return nbytes
+    step = 1 << (nbytes.bit_length() - 4)
+    return (nbytes + step - 1) // step * step
+
+
 class _Buffer:
     """A growable uint8 device tensor handed to the library through a resize callback (the reference's
     resizeFunctional lambda)."""
@@ -63,7 +75,7 @@ class _Buffer:
 
         def _resize(_user, nbytes):
             if self.t.numel() < nbytes:
-                self.t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+                self.t = torch.empty(_bucket(nbytes), dtype=torch.uint8, device=device)
             return self.t.data_ptr()
 
         self.cb = RESIZE_FN(_resize)
@@ -210,7 +222,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if P > 0:
             g_color = _f32c(grad_out_color)
             g_depth = _f32c(grad_out_depth) if grad_out_depth is not None else None
-            scratch = torch.empty(int(lib.gsr_backward_scratch_bytes(P, ctx.num_rendered)), dtype=torch.uint8, device=device)
+            scratch = torch.empty(_bucket(lib.gsr_backward_scratch_bytes(P, ctx.num_rendered)), dtype=torch.uint8, device=device)
             keep: list = []
             with torch.cuda.device(device):
                 s = _make_settings(rs, keep, ctx.tile_rows)

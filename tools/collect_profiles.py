@@ -1,0 +1,69 @@
+"""Turn the output of tools/gpu_profile.sh (gpurun_out/p_bench_default.log, prof_stats/, prof_fetch/, prof_write/) into the
+committed summaries under profiles/:
+    rNN_bench_default.json        the default `python bench.py` JSON line
+    rNN_kernel_stats.csv          rocprofv3 --kernel-trace --stats per-kernel table
+    rNN_pmc_per_kernel.csv        FETCH_SIZE / WRITE_SIZE per kernel and launch (separate passes)
+    pmc_latest.json               the same, keyed by kernel name -- bench.py reads roofline.traffic from here
+Usage: python tools/collect_profiles.py r01"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def short(n):
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    return re.sub(r"\(.*", "", n)
+
+
+line = [ln for ln in open(os.path.join(G, "p_bench_default.log")) if ln.startswith("{")][-1]
+json.loads(line)
+open(os.path.join(ROOT, "profiles", f"{tag}_bench_default.json"), "w").write(line)
+
+stats = glob.glob(os.path.join(G, "prof_stats", "**", "*kernel_stats.csv"), recursive=True)[0]
+rows = list(csv.DictReader(open(stats)))
+with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+    for r in rows:
+        w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+
+agg = collections.defaultdict(lambda: {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]})
+for d in ("prof_fetch", "prof_write"):
+    for fcsv in glob.glob(os.path.join(G, d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(fcsv)):
+            c = r["Counter_Name"]
+            if c in ("FETCH_SIZE", "WRITE_SIZE"):
+                a = agg[short(r["Kernel_Name"])][c]
+                a[0] += 1
+                a[1] += float(r["Counter_Value"])
+kern = {}
+for k, v in agg.items():
+    if k.startswith("at::") or k.startswith("__amd") or not v["FETCH_SIZE"][0] or not v["WRITE_SIZE"][0]:
+        continue
+    fk = v["FETCH_SIZE"][1] / v["FETCH_SIZE"][0]
+    wk = v["WRITE_SIZE"][1] / v["WRITE_SIZE"][0]
+    kern[k] = {"FETCH_SIZE_KB_per_launch": round(fk, 1), "launches_FETCH_SIZE": v["FETCH_SIZE"][0],
+               "WRITE_SIZE_KB_per_launch": round(wk, 1), "launches_WRITE_SIZE": v["WRITE_SIZE"][0],
+               "hbm_bytes_corrected": int((2 * fk + wk) * 1024)}
+out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 10 --warmup 2 "
+                 "--train-steps 5; correction per MI355X_MICROARCH.md HBM section: bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                 "(FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950; gather-heavy kernels are over-corrected by up "
+                 "to 2x on the read side)",
+       "kernels": kern}
+json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
+with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_per_kernel.csv"), "w") as f:
+    f.write("kernel,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch,hbm_bytes_per_launch_corrected\n")
+    for k in sorted(kern, key=lambda k: -kern[k]["hbm_bytes_corrected"]):
+        f.write(f"\"{k}\",{kern[k]['FETCH_SIZE_KB_per_launch']},{kern[k]['WRITE_SIZE_KB_per_launch']},{kern[k]['hbm_bytes_corrected']}\n")
+print("bench:", json.loads(line)["value"], "Mpix/s;", len(rows), "kernels in stats;", len(kern), "kernels with PMC")
+for k in ("render_fwd_wave_bf<true, 1>", "render_bwd_tile<256, 0>", "preprocess_fwd_kernel<false>", "adam_kernel"):
+    if k in kern:
+        print(" ", k, kern[k]["hbm_bytes_corrected"] / 1e6, "MB/launch")
