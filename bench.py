@@ -181,7 +181,7 @@ def main():
     #   "ssim_torch": same loss through utils/loss_utils.py-style torch conv2d ops (the reference's un-fused fallback)
     #   "l1"     : L1 only (isolates the rasterizer + optimizer)
     #   "l1_torch_adam": as "l1" but with torch.optim.Adam instead of the fused HIP Adam (gsr_optim.FusedAdam)
-    train = {}
+    train, train_gap = {}, {}
     tsteps = a.steps if a.train_steps < 0 else a.train_steps
     if tsteps > 0:
         from diff_gaussian_rasterization.parallel import render_sharded, hip_band_renderer
@@ -217,10 +217,13 @@ def main():
                 train_step()
             sync_all()
             t0 = time.perf_counter()
+            stamps = [t0]
             for _ in range(tsteps):
                 train_step()
+                stamps.append(time.perf_counter())      # host paced by the per-frame R read-back: gaps show one-off stalls
             sync_all()
             tdt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            train_gap[leg] = max(b - a for a, b in zip(stamps[:-1], stamps[1:])) * 1e3
             if world > 1:
                 dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
             train[leg] = float(tdt.item()) / tsteps * 1e3
@@ -323,6 +326,7 @@ def main():
             "whole_forward": {"algorithmic_bytes": int(ab["total"]), "achieved_GBs": round(whole, 2),
                               "frac_of_8TBs": round(whole / HBM_PEAK_GBS, 5),
                               "roofline_predicted_Mpix_s": round(npix / (ab["total"] / (HBM_PEAK_GBS * 1e9)) / 1e6, 1)},
+            "train_max_step_gap_ms": {k: round(v, 3) for k, v in train_gap.items()},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": roof,
             "cpu_baseline": cpu_baseline,

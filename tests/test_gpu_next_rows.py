@@ -217,3 +217,80 @@ def test_bench_two_rank_path_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["train_iters_per_s"] > 0 and d["scaling"] == "strong"
     assert d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
+
+
+def test_view_sequence_with_changing_instance_counts():
+    """Real training changes the camera every iteration, so R (and with it every R-sized buffer) jumps up and down:
+    the speculative binning-buffer size, the second resize when it was too small, and the bucketed scratch sizes must
+    all hold.  Invariants per frame: sum(tiles_touched) == R, finite image and gradients."""
+    from diff_gaussian_rasterization import GaussianRasterizer, GaussianRasterizationSettings
+    from diff_gaussian_rasterization.debug import forward_with_views
+    from helpers import look_at_camera
+    dev = torch.device("cuda:0")
+    cam0 = make_camera(320, 240)
+    sc = make_scene(30000, cam0, seed=8, s_med=0.03).to(dev)
+    views = [look_at_camera(320, 240, eye, (0.0, 0.0, 4.0)) for eye in
+             [(0.0, 0.0, -1.0), (0.0, 0.0, 3.2), (3.0, 0.5, 0.0), (0.0, 0.0, -30.0), (0.0, 0.0, 0.5), (0.0, 0.0, 3.2)]]
+    Rs = []
+    params = [t.clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+    for cam in views:
+        s = oracle_settings(cam)
+        rs = gpu_settings(s, dev)
+        with torch.no_grad():
+            v = forward_with_views(rs, sc.means3D, sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+        assert int(v["tiles_touched"].long().sum()) == v["R"]
+        Rs.append(v["R"])
+        for p in params:
+            p.grad = None
+        img, radii, invd = GaussianRasterizer(rs)(means3D=params[0], means2D=None, shs=params[1], colors_precomp=None,
+                                                   opacities=params[2], scales=params[3], rotations=params[4],
+                                                   cov3D_precomp=None)
+        (img.sum() + invd.sum()).backward()
+        assert torch.isfinite(img).all() and all(torch.isfinite(p.grad).all() for p in params)
+        assert int((radii > 0).sum()) == int((v["radii"] > 0).sum())
+    assert max(Rs) > 2 * max(1, min(Rs)), Rs       # the sequence really exercised growth and shrinkage
+
+
+@pytest.mark.parametrize("optimizer", ["fused", "sparse"])
+def test_short_optimisation_reduces_the_reference_loss(optimizer):
+    """End to end on the drop-in pieces only (rasterizer with the split-SH call form, fused SSIM, FusedAdam /
+    SparseGaussianAdam): a perturbed copy of a scene is pulled back towards the target render by the reference's
+    loss (train.py:119-126) and learning rates (arguments/__init__.py)."""
+    from diff_gaussian_rasterization import GaussianRasterizer, SparseGaussianAdam
+    from fused_ssim import fused_ssim
+    from gsr_optim import FusedAdam
+    dev = torch.device("cuda:0")
+    cam = make_camera(160, 128)
+    sc = make_scene(4000, cam, seed=12, s_med=0.05).to(dev)
+    s = oracle_settings(cam)
+    rast = GaussianRasterizer(gpu_settings(s, dev))
+    kw0 = dict(means2D=None, colors_precomp=None, cov3D_precomp=None)
+    with torch.no_grad():
+        gt = rast(means3D=sc.means3D, dc=sc.shs[:, :1].contiguous(), shs=sc.shs[:, 1:].contiguous(), opacities=sc.opacities,
+                  scales=sc.scales, rotations=sc.rotations, **kw0)[0]
+    g = torch.Generator(device="cpu").manual_seed(1)
+    noise = lambda t, a: (t + a * torch.randn(t.shape, generator=g).to(dev)).detach().clone().requires_grad_(True)  # noqa: E731
+    xyz, dc, rest = noise(sc.means3D, 0.01), noise(sc.shs[:, :1].contiguous(), 0.1), noise(sc.shs[:, 1:].contiguous(), 0.02)
+    # raw (pre-activation) parameters like GaussianModel: opacity through a sigmoid, scale through exp
+    op_raw = torch.logit(sc.opacities.clamp(1e-4, 1 - 1e-4)).detach().clone().requires_grad_(True)
+    sc_raw = noise(torch.log(sc.scales), 0.1)
+    rot = noise(sc.rotations, 0.05)
+    groups = [{"params": [xyz], "lr": 1.6e-4, "name": "xyz"}, {"params": [dc], "lr": 2.5e-3, "name": "f_dc"},
+              {"params": [rest], "lr": 2.5e-3 / 20, "name": "f_rest"}, {"params": [op_raw], "lr": 0.025, "name": "opacity"},
+              {"params": [sc_raw], "lr": 5e-3, "name": "scaling"}, {"params": [rot], "lr": 1e-3, "name": "rotation"}]
+    opt = SparseGaussianAdam(groups, lr=0.0, eps=1e-15) if optimizer == "sparse" else FusedAdam(groups, lr=0.0, eps=1e-15)
+    losses = []
+    for it in range(60):
+        img, radii, _ = rast(means3D=xyz, dc=dc, shs=rest, opacities=torch.sigmoid(op_raw), scales=torch.exp(sc_raw),
+                             rotations=torch.nn.functional.normalize(rot), **kw0)
+        l1 = (img - gt).abs().mean()
+        loss = 0.8 * l1 + 0.2 * (1.0 - fused_ssim(img.unsqueeze(0), gt.unsqueeze(0)))
+        loss.backward()
+        if optimizer == "sparse":
+            opt.step(radii > 0, radii.shape[0])
+        else:
+            opt.step()
+        opt.zero_grad(set_to_none=True)
+        losses.append(float(loss.detach()))
+    assert all(map(lambda v: v == v, losses))                       # no NaN
+    assert losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
