@@ -86,8 +86,10 @@ scan_finish(int P, const uint32_t* __restrict__ order, const uint32_t* __restric
 // fastest).  (One wave per group measured 48 us on the 1 M / 1080p frame: depth order packs the largest splats --
 // hundreds of tiles each -- into the same few groups, and a lone wave walks their ~200 chunks as one chain of
 // dependent cross-lane searches.)
+constexpr int EMIT_WAVES = 8;        // waves per 64-Gaussian group
+
 template <typename KeyT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(EMIT_WAVES * 64)
 emit_instances(int P, int gx, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
                const uint2* __restrict__ rect, KeyT* __restrict__ inst_keys, uint32_t* __restrict__ inst_vals,
                float4* __restrict__ splats) {
@@ -115,7 +117,7 @@ emit_instances(int P, int gx, const uint32_t* __restrict__ order, const uint32_t
     // first emission index of this Gaussian -> 4th quad of its splat record (the blend backward writes its
     // per-instance gradient records at emission indices, see render_bwd.hip)
     if (splats && wv == 0 && j < P) reinterpret_cast<uint32_t*>(splats + (int64_t)id * 4 + 3)[2] = base + excl_self;
-    for (uint32_t k0 = (uint32_t)wv * 64u; k0 < total; k0 += 256u) {
+    for (uint32_t k0 = (uint32_t)wv * 64u; k0 < total; k0 += EMIT_WAVES * 64u) {
         const uint32_t k = k0 + lane;
         int lo = 0, hi = last;
 #pragma unroll
@@ -174,10 +176,10 @@ void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offse
                      void* inst_keys, bool key16, uint32_t* inst_vals, float4* splats, hipStream_t st) {
     const int nb = (int)(((int64_t)P + 63) / 64);        // one workgroup per 64 Gaussians of the depth order
     if (key16)
-        hipLaunchKernelGGL(emit_instances<uint16_t>, dim3(nb), dim3(256), 0, st, P, gx, order, offsets, rect,
+        hipLaunchKernelGGL(emit_instances<uint16_t>, dim3(nb), dim3(EMIT_WAVES * 64), 0, st, P, gx, order, offsets, rect,
                            (uint16_t*)inst_keys, inst_vals, splats);
     else
-        hipLaunchKernelGGL(emit_instances<uint32_t>, dim3(nb), dim3(256), 0, st, P, gx, order, offsets, rect,
+        hipLaunchKernelGGL(emit_instances<uint32_t>, dim3(nb), dim3(EMIT_WAVES * 64), 0, st, P, gx, order, offsets, rect,
                            (uint32_t*)inst_keys, inst_vals, splats);
 }
 

@@ -323,18 +323,20 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
 
 // splat_grads[g] = sum of the instance records of Gaussian g.  In emission (= depth) order a Gaussian's records are one
 // contiguous run, and the runs of 64 consecutive Gaussians of the depth order form one contiguous stream.  One
-// WORKGROUP per 64 Gaussians: its four waves take the stream's 64-record chunks round-robin (lane = record, fully
+// WORKGROUP per 64 Gaussians: its RED_WAVES waves take the stream's 64-record chunks round-robin (lane = record, fully
 // coalesced), find each record's owner with the same 6-step cross-lane binary search as emit_instances, sum records
 // of the same owner with a SEGMENTED inclusive scan across the lanes, and the last lane of each segment adds the
-// segment total into the owner's row of the wave's private LDS accumulator; the four accumulators are added in
+// segment total into the owner's row of the wave's private LDS accumulator; the accumulators are added in
 // fixed order at the end (deterministic).  History on the 1 M / 1080p frame: lane-per-Gaussian loop 0.49 ms (the wave
 // waits for its largest splat), one wave per 64 Gaussians 0.17 ms (depth order puts the largest splats -- hundreds of
 // tiles each -- into the same few waves, whose serial flag -> record chain sets the kernel time).
-__global__ void __launch_bounds__(256)
+constexpr int RED_WAVES = 8;        // waves per 64-Gaussian group
+
+__global__ void __launch_bounds__(RED_WAVES * 64)
 bwd_reduce_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
                      const float4* __restrict__ inst_grads, const uint8_t* __restrict__ inst_flag,
                      const float4* __restrict__ splats, float4* __restrict__ splat_grads) {
-    __shared__ float s_acc[4][64 * 12];
+    __shared__ float s_acc[RED_WAVES][64 * 12];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t j0 = (int64_t)blockIdx.x * 64;
     if (j0 >= P) return;
@@ -351,11 +353,11 @@ bwd_reduce_instances(int P, const uint32_t* __restrict__ order, const uint32_t* 
     // dependent loads (flag -> record) and this takes one of the two latencies off every step
     const uint32_t first = (uint32_t)wv * 64u + (uint32_t)lane;
     uint8_t flag_next = first < total ? inst_flag[(int64_t)base + first] : (uint8_t)0;
-    for (uint32_t c0 = (uint32_t)wv * 64u; c0 < total; c0 += 256u) {
+    for (uint32_t c0 = (uint32_t)wv * 64u; c0 < total; c0 += RED_WAVES * 64u) {
         const uint32_t r = c0 + lane;
         const bool valid = r < total;
         const bool has_rec = valid && flag_next != 0;     // untouched instances have no record
-        flag_next = (r + 256u) < total ? inst_flag[(int64_t)base + r + 256u] : (uint8_t)0;
+        flag_next = (r + RED_WAVES * 64u) < total ? inst_flag[(int64_t)base + r + RED_WAVES * 64u] : (uint8_t)0;
         if (__ballot(has_rec) == 0ull) continue;     // e.g. far Gaussians that every pixel terminated in front of
         int lo = 0, hi = last;
 #pragma unroll
@@ -398,12 +400,13 @@ bwd_reduce_instances(int P, const uint32_t* __restrict__ order, const uint32_t* 
         float4 t[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            const float4 a0 = *reinterpret_cast<const float4*>(&s_acc[0][lane * 12 + q * 4]);
-            const float4 a1 = *reinterpret_cast<const float4*>(&s_acc[1][lane * 12 + q * 4]);
-            const float4 a2 = *reinterpret_cast<const float4*>(&s_acc[2][lane * 12 + q * 4]);
-            const float4 a3 = *reinterpret_cast<const float4*>(&s_acc[3][lane * 12 + q * 4]);
-            t[q] = make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y, ((a0.z + a1.z) + a2.z) + a3.z,
-                               ((a0.w + a1.w) + a2.w) + a3.w);
+            float4 a = *reinterpret_cast<const float4*>(&s_acc[0][lane * 12 + q * 4]);
+#pragma unroll
+            for (int k = 1; k < RED_WAVES; ++k) {       // fixed order: deterministic
+                const float4 b = *reinterpret_cast<const float4*>(&s_acc[k][lane * 12 + q * 4]);
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            t[q] = a;
         }
         // the instance records carry moments (see bwd_step): turn the sums into derivatives with this Gaussian's conic
         const float4 q0 = splats[(int64_t)g * 4 + 0];
@@ -536,6 +539,6 @@ void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const
 void gsr_launch_reduce_instances(int P, const uint32_t* order, const uint32_t* offsets, const float4* splats,
                                  const float* inst_grads, const uint8_t* inst_flag, float* splat_grads, hipStream_t st) {
     const int64_t groups = ((int64_t)P + 63) / 64;       // one workgroup per 64 Gaussians of the depth order
-    hipLaunchKernelGGL(bwd_reduce_instances, dim3((int)groups), dim3(256), 0, st, P, order, offsets,
+    hipLaunchKernelGGL(bwd_reduce_instances, dim3((int)groups), dim3(RED_WAVES * 64), 0, st, P, order, offsets,
                        reinterpret_cast<const float4*>(inst_grads), inst_flag, splats, reinterpret_cast<float4*>(splat_grads));
 }
