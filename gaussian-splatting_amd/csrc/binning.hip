@@ -86,7 +86,7 @@ scan_finish(int P, const uint32_t* __restrict__ order, const uint32_t* __restric
 // fastest).  (One wave per group measured 48 us on the 1 M / 1080p frame: depth order packs the largest splats --
 // hundreds of tiles each -- into the same few groups, and a lone wave walks their ~200 chunks as one chain of
 // dependent cross-lane searches.)
-constexpr int EMIT_WAVES = 8;        // waves per 64-Gaussian group
+constexpr int EMIT_WAVES = 4;        // waves per 64-Gaussian group (1: 48 us, 4: 39 us, 8: 49 us on the bench frame)
 
 template <typename KeyT>
 __global__ void __launch_bounds__(EMIT_WAVES * 64)

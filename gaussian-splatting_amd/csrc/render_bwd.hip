@@ -330,7 +330,7 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
 // fixed order at the end (deterministic).  History on the 1 M / 1080p frame: lane-per-Gaussian loop 0.49 ms (the wave
 // waits for its largest splat), one wave per 64 Gaussians 0.17 ms (depth order puts the largest splats -- hundreds of
 // tiles each -- into the same few waves, whose serial flag -> record chain sets the kernel time).
-constexpr int RED_WAVES = 8;        // waves per 64-Gaussian group
+constexpr int RED_WAVES = 4;        // waves per 64-Gaussian group (1: 170 us, 4: 93 us, 8: 117 us on the bench frame)
 
 __global__ void __launch_bounds__(RED_WAVES * 64)
 bwd_reduce_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
