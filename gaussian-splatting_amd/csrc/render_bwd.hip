@@ -345,9 +345,14 @@ bwd_reduce_instances(int P, const uint32_t* __restrict__ order, const uint32_t* 
     const uint32_t incl = j < P ? offsets[j] - base : 0xFFFFFFFFu;
     const int last = (int)((P - j0) < 64 ? (P - j0 - 1) : 63);
     const uint32_t total = __shfl(incl, last, 64);
+    // most groups have fewer than 64 records: waves without a chunk only wait at the barrier, and the final sum reads
+    // the accumulators of the working waves only
+    const int nwork = (int)min((uint32_t)RED_WAVES, (total + 63u) >> 6);
     float* acc = s_acc[wv];
+    if (wv < nwork) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) acc[lane * 12 + i] = 0.f;
+        for (int i = 0; i < 12; ++i) acc[lane * 12 + i] = 0.f;
+    }
     const float4* stream = inst_grads + (int64_t)base * 3;
     // the flag of the wave's NEXT chunk is requested before the current chunk's records: the walk is a chain of
     // dependent loads (flag -> record) and this takes one of the two latencies off every step
@@ -400,9 +405,8 @@ bwd_reduce_instances(int P, const uint32_t* __restrict__ order, const uint32_t* 
         float4 t[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            float4 a = *reinterpret_cast<const float4*>(&s_acc[0][lane * 12 + q * 4]);
-#pragma unroll
-            for (int k = 1; k < RED_WAVES; ++k) {       // fixed order: deterministic
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < nwork; ++k) {       // fixed order: deterministic
                 const float4 b = *reinterpret_cast<const float4*>(&s_acc[k][lane * 12 + q * 4]);
                 a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
             }
