@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--cpu-tiles", type=int, default=1200, help="tiles blended by the CPU baseline sample")
     ap.add_argument("--uniform-bands", action="store_true")
     ap.add_argument("--compare-torch-adam", action="store_true", help="also time the train step with torch.optim.Adam")
+    ap.add_argument("--sort-items", type=int, default=0, help="keys per workgroup of the large radix passes (1024 / 2048 / 4096; 0 = library default)")
     ap.add_argument("--bwd-variant", type=int, default=0, help="render_bwd_variant (0 default, 1 atomics baseline, 2 128-entry super-batches)")
     return ap.parse_args()
 
@@ -105,6 +106,8 @@ def main():
     _lib.load()
     _lib.set_option("render_fwd_variant", a.variant)
     _lib.set_option("render_bwd_variant", a.bwd_variant)
+    if a.sort_items:
+        _lib.set_option("sort_items_large", a.sort_items)
     W, H, P = a.width, a.height, a.P
     cam = make_camera(W, H)
     scene_cpu = make_scene(P, cam, seed=a.seed, s_med=a.s_med)

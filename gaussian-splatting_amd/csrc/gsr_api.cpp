@@ -141,7 +141,9 @@ thread_local uint32_t g_host_seq = 0;
 std::atomic<int64_t> g_last_R{0};
 
 int64_t g_small_block_threshold = (int64_t)2 * 1024 * 1024;   // below this a radix pass uses 1024-item workgroups
+int g_sort_items_large = GSR_SORT_ITEMS;                      // keys per workgroup above the threshold (1024 / 2048 / 4096)
 bool use_small_blocks(int64_t n) { return n < g_small_block_threshold; }
+int sort_items(int64_t n) { return use_small_blocks(n) ? GSR_SORT_ITEMS_SMALL : g_sort_items_large; }
 
 }  // namespace
 
@@ -227,6 +229,11 @@ int gsr_set_option(const char* name, int value) {
     if (!strcmp(name, "render_fwd_variant")) { g_render_fwd_variant = value; return GSR_OK; }
     if (!strcmp(name, "render_bwd_variant")) { g_render_bwd_variant = value; return GSR_OK; }
     if (!strcmp(name, "sort_small_block_threshold")) { g_small_block_threshold = value; return GSR_OK; }
+    if (!strcmp(name, "sort_items_large")) {
+        if (value != 1024 && value != 2048 && value != 4096) return fail(GSR_ERR_INVALID_ARG, "sort_items_large must be 1024, 2048 or 4096");
+        g_sort_items_large = value;
+        return GSR_OK;
+    }
     if (!strcmp(name, "depth_digit_bits")) { g_depth_digit_bits = (value > 8) ? 11 : 8; return GSR_OK; }
     return fail(GSR_ERR_INVALID_ARG, std::string("unknown option ") + name);
 }
@@ -294,7 +301,7 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
     {   StageTimer t(GSR_STAGE_DEPTH_SORT, st);
         // 11-bit digits need the large (4096-item) workgroups to keep the 2048-row histogram table small
         order_buf = gsr_radix_sort_pairs(g.keys, g.vals, P, 32, g_depth_digit_bits, g.sort_hist, g.digit_total,
-                                         g_depth_digit_bits > 8 ? false : use_small_blocks(P), st);
+                                         g_depth_digit_bits > 8 ? GSR_SORT_ITEMS : sort_items(P), st);
     }
     STAGE_CHECK("depth sort");
     // R = number of (Gaussian, tile) instances sizes the binning buffer, so the host must learn it mid-pipeline (the
@@ -360,10 +367,10 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
             if (key16) {
                 uint16_t* k16[2] = {(uint16_t*)b.keys[0], (uint16_t*)b.keys[1]};
                 list_buf = gsr_radix_sort_pairs_k16(k16, b.vals, R, bits_for((uint32_t)n_tiles), GSR_TILE_DIGIT_BITS, b.sort_hist,
-                                                    b.digit_total, use_small_blocks(R), st);
+                                                    b.digit_total, sort_items(R), st);
             } else {
                 list_buf = gsr_radix_sort_pairs(b.keys, b.vals, R, bits_for((uint32_t)n_tiles), GSR_TILE_DIGIT_BITS, b.sort_hist,
-                                                b.digit_total, use_small_blocks(R), st);
+                                                b.digit_total, sort_items(R), st);
             }
         }
         STAGE_CHECK("tile sort");

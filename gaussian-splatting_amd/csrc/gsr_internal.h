@@ -75,11 +75,12 @@ void gsr_launch_preprocess_backward(const GsrCamDev& cam, int P, const float* me
 void gsr_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st);
 
 // sort.hip: LSD radix sort of (u32 key, u32 value) pairs on bits [0, nbits); returns the index (0/1) of the
-// ping-pong buffer that holds the result.  n is known on the host.
+// ping-pong buffer that holds the result.  n is known on the host.  items = keys per workgroup: 1024, 2048 or 4096
+// (hist must hold 2^digit_bits * ceil(n / items) counters).
 int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
-                         uint32_t* digit_total, bool small_blocks, hipStream_t st);
+                         uint32_t* digit_total, int items, hipStream_t st);
 int gsr_radix_sort_pairs_k16(uint16_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
-                             uint32_t* digit_total, bool small_blocks, hipStream_t st);
+                             uint32_t* digit_total, int items, hipStream_t st);
 // pass plan shared by the sorter and by code that must know which ping-pong buffer holds the result
 int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits /*[8]*/);
 #define GSR_DEPTH_DIGIT_BITS 8      // 32-bit depth keys: 4 passes of 8 bits (3 x 11 bits measured slower: 113 vs 91 us)

@@ -238,8 +238,8 @@ void gsr_launch_knn(int N, const float* points, float* out, void* scratch, hipSt
     hipLaunchKernelGGL(knn_bbox_init, dim3(1), dim3(64), 0, st, s.bbox);
     hipLaunchKernelGGL(knn_bbox, dim3(grid_for(N)), dim3(256), 0, st, N, points, s.bbox);
     hipLaunchKernelGGL(knn_morton, dim3(grid_for(N)), dim3(256), 0, st, N, points, s.bbox, s.keys[0], s.vals[0]);
-    const bool small_blocks = N < (1 << 18);
-    const int cur = gsr_radix_sort_pairs(s.keys, s.vals, N, 30, 8, s.sort_hist, s.digit_total, small_blocks, st);
+    const int cur = gsr_radix_sort_pairs(s.keys, s.vals, N, 30, 8, s.sort_hist, s.digit_total,
+                                         N < (1 << 21) ? GSR_SORT_ITEMS_SMALL : GSR_SORT_ITEMS, st);
     hipLaunchKernelGGL(knn_boxes, dim3(n_boxes), dim3(KNN_BOX), 0, st, N, points, s.vals[cur], s.sorted, s.box_lo, s.box_hi);
     hipLaunchKernelGGL(knn_query, dim3(n_boxes), dim3(KNN_BOX), 0, st, N, n_boxes, s.sorted, s.box_lo, s.box_hi, out);
 }

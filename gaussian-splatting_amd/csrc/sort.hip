@@ -294,20 +294,23 @@ void sort_pass_bits(int bits, KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vo
 
 template <typename KeyT>
 int sort_pairs_t(KeyT* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
-                 uint32_t* digit_total, bool small_blocks, hipStream_t st) {
+                 uint32_t* digit_total, int items, hipStream_t st) {
     int cur = 0;
     if (n <= 0) return cur;
-    const int nblocks = (int)gsr_sort_blocks(n, small_blocks);
+    const int nblocks = (int)((n + items - 1) / items);
     int pass_bits[8];
     const int passes = gsr_sort_plan(nbits, max_digit_bits, pass_bits);
     int shift = 0;
     for (int p = 0; p < passes; ++p) {
-        if (small_blocks)
-            sort_pass_bits<KeyT, GSR_SORT_ITEMS_SMALL / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1],
-                                                                    n, shift, hist, digit_total, nblocks, st);
+        if (items == 1024)
+            sort_pass_bits<KeyT, 1024 / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
+                                                    digit_total, nblocks, st);
+        else if (items == 2048)
+            sort_pass_bits<KeyT, 2048 / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
+                                                    digit_total, nblocks, st);
         else
-            sort_pass_bits<KeyT, GSR_SORT_ITEMS / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n,
-                                                              shift, hist, digit_total, nblocks, st);
+            sort_pass_bits<KeyT, 4096 / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
+                                                    digit_total, nblocks, st);
         shift += pass_bits[p];
         cur ^= 1;
     }
@@ -333,12 +336,12 @@ int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits) {
 }
 
 int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
-                         uint32_t* digit_total, bool small_blocks, hipStream_t st) {
-    return sort_pairs_t<uint32_t>(keys, vals, n, nbits, max_digit_bits, hist, digit_total, small_blocks, st);
+                         uint32_t* digit_total, int items, hipStream_t st) {
+    return sort_pairs_t<uint32_t>(keys, vals, n, nbits, max_digit_bits, hist, digit_total, items, st);
 }
 
 // 16-bit keys (tile ids when the frame has <= 65536 tiles): 25 % less traffic per pass than 32-bit keys
 int gsr_radix_sort_pairs_k16(uint16_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
-                             uint32_t* digit_total, bool small_blocks, hipStream_t st) {
-    return sort_pairs_t<uint16_t>(keys, vals, n, nbits, max_digit_bits, hist, digit_total, small_blocks, st);
+                             uint32_t* digit_total, int items, hipStream_t st) {
+    return sort_pairs_t<uint16_t>(keys, vals, n, nbits, max_digit_bits, hist, digit_total, items, st);
 }
