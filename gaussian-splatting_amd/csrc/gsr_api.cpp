@@ -230,7 +230,8 @@ int gsr_set_option(const char* name, int value) {
     if (!strcmp(name, "render_bwd_variant")) { g_render_bwd_variant = value; return GSR_OK; }
     if (!strcmp(name, "sort_small_block_threshold")) { g_small_block_threshold = value; return GSR_OK; }
     if (!strcmp(name, "sort_items_large")) {
-        if (value != 1024 && value != 2048 && value != 4096) return fail(GSR_ERR_INVALID_ARG, "sort_items_large must be 1024, 2048 or 4096");
+        if (value != 1024 && value != 2048 && value != 4096 && value != 8192)
+            return fail(GSR_ERR_INVALID_ARG, "sort_items_large must be 1024, 2048, 4096 or 8192");
         g_sort_items_large = value;
         return GSR_OK;
     }

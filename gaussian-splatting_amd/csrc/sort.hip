@@ -308,6 +308,9 @@ int sort_pairs_t(KeyT* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max
         else if (items == 2048)
             sort_pass_bits<KeyT, 2048 / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
                                                     digit_total, nblocks, st);
+        else if (items == 8192)
+            sort_pass_bits<KeyT, 8192 / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
+                                                    digit_total, nblocks, st);
         else
             sort_pass_bits<KeyT, 4096 / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
                                                     digit_total, nblocks, st);

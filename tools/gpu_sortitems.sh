@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-for it in 4096 2048 1024; do
+for it in 4096 8192; do
   python bench.py --steps 40 --warmup 5 --no-cpu-baseline --train-steps 0 --sort-items $it > gpurun_out/s_$it.log 2>&1
   python - <<PY
 import json
