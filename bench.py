@@ -187,29 +187,31 @@ def main():
     train, train_gap = {}, {}
     tsteps = a.steps if a.train_steps < 0 else a.train_steps
     if tsteps > 0:
-        from diff_gaussian_rasterization.parallel import render_sharded, hip_band_renderer
         from gsr_optim import FusedAdam
         from gsr_synth.losses import train_loss, l1_loss
         from fused_ssim import fused_ssim
 
         def fused_train_loss(image, gt_image, lambda_dssim=0.2):      # train.py:119-126 with FUSED_SSIM_AVAILABLE
             return (1.0 - lambda_dssim) * l1_loss(image, gt_image) + lambda_dssim * (1.0 - fused_ssim(image[None], gt_image[None]))
-        band_renderer = hip_band_renderer(rs)
         gt = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
         legs = [("ssim", FusedAdam, fused_train_loss), ("l1", FusedAdam, l1_loss)]
         if a.compare_torch_adam:
             legs.append(("l1_torch_adam", torch.optim.Adam, l1_loss))
             legs.append(("ssim_torch", FusedAdam, train_loss))
+        from diff_gaussian_rasterization.parallel import render_two_axis, padded_shard_size
+        # N > 1: two-axis sharding -- rank g owns Gaussians [lo, hi) (parameters + Adam state) and a band of
+        # tile rows; 64-byte splat records are all-gathered forward, 48-byte gradient records reduce-scattered backward
+        lo, hi = (P * rank) // world, (P * (rank + 1)) // world
+        P_pad = padded_shard_size(hi - lo) if world > 1 else P
         for leg, opt_cls, loss_fn in legs:
-            params = [t.detach().clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+            params = [t[lo:hi].detach().clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
             opt = opt_cls(params, lr=1e-5, eps=1e-15)
 
             def train_step():
                 opt.zero_grad(set_to_none=True)
                 m, sh, o, s_, r_ = params
                 if world > 1:
-                    # own band -> strips all-gathered; backward: 48-byte per-Gaussian records all-reduced (parallel.py)
-                    color, radii, invd = render_sharded(band_renderer, params, plan, reduce="records")
+                    color, radii, invd = render_two_axis(rs, m, sh, o, s_, r_, plan, P_pad)
                 else:
                     color, radii, invd = rasterize_gaussians(m, None, sh, None, o, s_, r_, None, rs, None)
                 loss = loss_fn(color, gt)
@@ -322,7 +324,9 @@ def main():
             "train_iters_per_s": None if train_ips is None else round(train_ips, 3),
             "train_ms_per_iter": None if train_ms is None else round(train_ms, 4),
             "train_step": "forward + loss 0.8 L1 + 0.2 (1-SSIM) (train.py:119-126; fused HIP SSIM) + backward + fused HIP Adam over "
-                          "all 59 floats/Gaussian; *_l1 = L1 loss only; *_ssim_torch = SSIM through torch conv2d ops",
+                          "all 59 floats/Gaussian; *_l1 = L1 loss only; *_ssim_torch = SSIM through torch conv2d ops" +
+                          ("" if world == 1 else "; N > 1: Gaussians AND tile rows sharded (record all-gather / gradient "
+                                                  "reduce-scatter), loss replicated on the all-gathered image"),
             "train_iters_per_s_ssim_torch": None if "ssim_torch" not in train else round(1e3 / train["ssim_torch"], 3),
             "train_iters_per_s_l1": None if "l1" not in train else round(1e3 / train["l1"], 3),
             "train_iters_per_s_l1_torch_adam": None if "l1_torch_adam" not in train else round(1e3 / train["l1_torch_adam"], 3),

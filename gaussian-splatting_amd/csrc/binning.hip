@@ -162,7 +162,43 @@ tile_ranges(int64_t R, const KeyT* __restrict__ keys, uint2* __restrict__ ranges
     }
 }
 
+// Two-axis sharding: the splat records of ALL Gaussians arrive from an all-gather, each produced by the
+// rank that owns the Gaussian with the FULL-frame tile rectangle in its 4th quad.  This kernel copies them into the
+// geometry state and derives what the binning stages need for THIS rank's band of tile rows: band-clamped rectangle,
+// tile count, depth-sort key (culled / out-of-band Gaussians sort last) -- the same values preprocess_fwd_kernel writes
+// when it runs with the band itself.
+__global__ void __launch_bounds__(256)
+splat_ingest(int P, const float4* __restrict__ records, int y0, int y1, float4* __restrict__ splats, uint2* __restrict__ rect,
+             uint32_t* __restrict__ tiles, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 q0 = records[i * 4 + 0], q1 = records[i * 4 + 1], q2 = records[i * 4 + 2], q3 = records[i * 4 + 3];
+        const uint32_t rx = __float_as_uint(q3.x), ry = __float_as_uint(q3.y), full = __float_as_uint(q3.w);
+        const int minx = (int)(rx & 0xFFFFu), maxx = (int)(rx >> 16), miny = (int)(ry & 0xFFFFu), maxy = (int)(ry >> 16);
+        const int bminy = miny < y0 ? y0 : (miny > y1 ? y1 : miny);
+        const int bmaxy = maxy < y0 ? y0 : (maxy > y1 ? y1 : maxy);
+        const uint32_t t = full ? (uint32_t)((maxx - minx) * (bmaxy - bminy)) : 0u;
+        const uint2 rc = make_uint2((uint32_t)minx | ((uint32_t)maxx << 16), (uint32_t)bminy | ((uint32_t)bmaxy << 16));
+        splats[i * 4 + 0] = q0;
+        splats[i * 4 + 1] = q1;
+        splats[i * 4 + 2] = q2;
+        splats[i * 4 + 3] = make_float4(__uint_as_float(rc.x), __uint_as_float(rc.y), 0.f, __uint_as_float(t));
+        rect[i] = rc;
+        tiles[i] = t;
+        keys[i] = t ? __float_as_uint(q2.y) : 0xFFFFFFFFu;      // q2.y = view-space depth
+        vals[i] = (uint32_t)i;
+    }
+}
+
 }  // namespace
+
+void gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
+                             uint32_t* keys, uint32_t* vals, hipStream_t st) {
+    int64_t nb = ((int64_t)P + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(splat_ingest, dim3((int)nb), dim3(256), 0, st, P, reinterpret_cast<const float4*>(records), y0, y1, splats,
+                       rect, tiles, keys, vals);
+}
 
 void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles, uint32_t* offsets,
                            uint32_t* block_sums, uint32_t* num_rendered, uint32_t* host_word, uint32_t seq, hipStream_t st) {

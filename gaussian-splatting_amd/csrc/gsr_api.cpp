@@ -266,38 +266,11 @@ int gsr_profile_read(float* ms_out, int32_t* count_out, int n) {
     return GSR_OK;
 }
 
-int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const float* means3D, const float* shs,
-                          const float* colors_precomp, const float* opacities, const float* scales,
-                          const float* rotations, const float* cov3D_precomp, GsrResizeFn geom_resize, void* geom_user,
+// Everything after the per-Gaussian preprocess: depth sort, scan, R read-back, emission, tile sort, ranges, blend.
+// `g` holds the splat records, band-clamped rectangles / tile counts and the depth keys of all P Gaussians.
+static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& cam, int P, GsrGeom& g,
                           GsrResizeFn binning_resize, void* binning_user, GsrResizeFn image_resize, void* image_user,
-                          float* out_color, float* out_invdepth, int32_t* radii, int32_t* num_rendered, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    GsrCamDev cam;
-    int rc = make_cam(settings, M, cam);
-    if (rc != GSR_OK) return rc;
-    rc = check_inputs(P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, cam.sh_degree);
-    if (rc != GSR_OK) return rc;
-    rc = check_split_sh(settings, P, M, shs, false);
-    if (rc != GSR_OK) return rc;
-    if (!out_color || !num_rendered) return fail(GSR_ERR_INVALID_ARG, "out_color / num_rendered are NULL");
-    const size_t npix = (size_t)cam.W * cam.H;
-    *num_rendered = 0;
-    if (P == 0) {   // reference behaviour: zero image (not background), nothing else touched
-        HIP_OK(hipMemsetAsync(out_color, 0, npix * 3 * sizeof(float), st));
-        if (out_invdepth) HIP_OK(hipMemsetAsync(out_invdepth, 0, npix * sizeof(float), st));
-        return GSR_OK;
-    }
-    if (!radii) return fail(GSR_ERR_INVALID_ARG, "radii is NULL");
-    if (!geom_resize || !binning_resize || !image_resize) return fail(GSR_ERR_INVALID_ARG, "resize callbacks are NULL");
-
-    char* gbase = (char*)geom_resize(geom_user, gsr_geometry_bytes(P));
-    if (!gbase) return fail(GSR_ERR_ALLOC, "geometry buffer resize returned NULL");
-    GsrGeom g = gsr_carve_geom(gbase, P);
-
-    {   StageTimer t(GSR_STAGE_PREPROCESS, st);
-        gsr_launch_preprocess(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, st);
-    }
-    STAGE_CHECK("preprocess");
+                          float* out_color, float* out_invdepth, int32_t* num_rendered, hipStream_t st) {
     int order_buf;
     {   StageTimer t(GSR_STAGE_DEPTH_SORT, st);
         // 11-bit digits need the large (4096-item) workgroups to keep the 2048-row histogram table small
@@ -390,6 +363,101 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
     return GSR_OK;
 }
 
+
+int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const float* means3D, const float* shs,
+                          const float* colors_precomp, const float* opacities, const float* scales,
+                          const float* rotations, const float* cov3D_precomp, GsrResizeFn geom_resize, void* geom_user,
+                          GsrResizeFn binning_resize, void* binning_user, GsrResizeFn image_resize, void* image_user,
+                          float* out_color, float* out_invdepth, int32_t* radii, int32_t* num_rendered, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    GsrCamDev cam;
+    int rc = make_cam(settings, M, cam);
+    if (rc != GSR_OK) return rc;
+    rc = check_inputs(P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, cam.sh_degree);
+    if (rc != GSR_OK) return rc;
+    rc = check_split_sh(settings, P, M, shs, false);
+    if (rc != GSR_OK) return rc;
+    if (!out_color || !num_rendered) return fail(GSR_ERR_INVALID_ARG, "out_color / num_rendered are NULL");
+    const size_t npix = (size_t)cam.W * cam.H;
+    *num_rendered = 0;
+    if (P == 0) {   // reference behaviour: zero image (not background), nothing else touched
+        HIP_OK(hipMemsetAsync(out_color, 0, npix * 3 * sizeof(float), st));
+        if (out_invdepth) HIP_OK(hipMemsetAsync(out_invdepth, 0, npix * sizeof(float), st));
+        return GSR_OK;
+    }
+    if (!radii) return fail(GSR_ERR_INVALID_ARG, "radii is NULL");
+    if (!geom_resize || !binning_resize || !image_resize) return fail(GSR_ERR_INVALID_ARG, "resize callbacks are NULL");
+
+    char* gbase = (char*)geom_resize(geom_user, gsr_geometry_bytes(P));
+    if (!gbase) return fail(GSR_ERR_ALLOC, "geometry buffer resize returned NULL");
+    GsrGeom g = gsr_carve_geom(gbase, P);
+
+    {   StageTimer t(GSR_STAGE_PREPROCESS, st);
+        gsr_launch_preprocess(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, st);
+    }
+    STAGE_CHECK("preprocess");
+    return bin_and_render(settings, cam, P, g, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
+                          num_rendered, st);
+}
+
+int gsr_preprocess_forward(const GsrRasterSettings* settings, int P, int M, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
+                           const float* cov3D_precomp, void* geom_scratch, int32_t* radii, float* splat_records,
+                           void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    GsrCamDev cam;
+    int rc = make_cam(settings, M, cam);
+    if (rc != GSR_OK) return rc;
+    rc = check_inputs(P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, cam.sh_degree);
+    if (rc != GSR_OK) return rc;
+    rc = check_split_sh(settings, P, M, shs, false);
+    if (rc != GSR_OK) return rc;
+    if (P == 0) return GSR_OK;
+    if (!geom_scratch || !radii || !splat_records) return fail(GSR_ERR_INVALID_ARG, "geom_scratch / radii / splat_records are NULL");
+    if ((uintptr_t)splat_records & 15) return fail(GSR_ERR_INVALID_ARG, "splat_records must be 16-byte aligned");
+    // the records leave this rank: rectangles and tile counts are those of the FULL frame, whatever band the settings name
+    cam.tile_y0 = 0;
+    cam.tile_y1 = cam.gy;
+    GsrGeom g = gsr_carve_geom((char*)geom_scratch, P);
+    g.splats = reinterpret_cast<float4*>(splat_records);
+    {   StageTimer t(GSR_STAGE_PREPROCESS, st);
+        gsr_launch_preprocess(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, st);
+    }
+    STAGE_CHECK("preprocess (shard)");
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_rasterize_from_splats(const GsrRasterSettings* settings, int P, const float* splat_records, GsrResizeFn geom_resize,
+                              void* geom_user, GsrResizeFn binning_resize, void* binning_user, GsrResizeFn image_resize,
+                              void* image_user, float* out_color, float* out_invdepth, int32_t* num_rendered, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    GsrCamDev cam;
+    int rc = make_cam(settings, 0, cam);
+    if (rc != GSR_OK) return rc;
+    if (P < 0) return fail(GSR_ERR_INVALID_ARG, "P < 0");
+    if (!out_color || !num_rendered) return fail(GSR_ERR_INVALID_ARG, "out_color / num_rendered are NULL");
+    const size_t npix = (size_t)cam.W * cam.H;
+    *num_rendered = 0;
+    if (P == 0) {
+        HIP_OK(hipMemsetAsync(out_color, 0, npix * 3 * sizeof(float), st));
+        if (out_invdepth) HIP_OK(hipMemsetAsync(out_invdepth, 0, npix * sizeof(float), st));
+        return GSR_OK;
+    }
+    if (!splat_records) return fail(GSR_ERR_INVALID_ARG, "splat_records is NULL");
+    if ((uintptr_t)splat_records & 15) return fail(GSR_ERR_INVALID_ARG, "splat_records must be 16-byte aligned");
+    if (!geom_resize || !binning_resize || !image_resize) return fail(GSR_ERR_INVALID_ARG, "resize callbacks are NULL");
+    char* gbase = (char*)geom_resize(geom_user, gsr_geometry_bytes(P));
+    if (!gbase) return fail(GSR_ERR_ALLOC, "geometry buffer resize returned NULL");
+    GsrGeom g = gsr_carve_geom(gbase, P);
+    {   StageTimer t(GSR_STAGE_PREPROCESS, st);
+        gsr_launch_splat_ingest(P, splat_records, cam.tile_y0, cam.tile_y1, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], st);
+    }
+    STAGE_CHECK("splat ingest");
+    return bin_and_render(settings, cam, P, g, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
+                          num_rendered, st);
+}
+
 static int list_buffer_index(int n_tiles) {
     int pb[8];
     return gsr_sort_plan(bits_for((uint32_t)n_tiles), GSR_TILE_DIGIT_BITS, pb) & 1;
@@ -456,14 +524,15 @@ int gsr_backward_preprocess(const GsrRasterSettings* settings, int P, int M, con
     rc = check_split_sh(settings, P, M, shs, true);
     if (rc != GSR_OK) return rc;
     if (P == 0) return GSR_OK;
-    if (!radii || !geom_buffer || !splat_grads) return fail(GSR_ERR_INVALID_ARG, "radii / geometry buffer / splat_grads are NULL");
+    (void)geom_buffer;      // the colour clamp bits are recomputed; a NULL geometry buffer is accepted (Gaussian-sharded backward)
+    if (!radii || !splat_grads) return fail(GSR_ERR_INVALID_ARG, "radii / splat_grads are NULL");
     if (!dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D)
         return fail(GSR_ERR_INVALID_ARG, "gradient outputs are NULL");
     if (shs && !dL_dsh) return fail(GSR_ERR_INVALID_ARG, "dL_dsh is NULL");
     if (settings->sh_dc && ((((uintptr_t)dL_dsh) | ((uintptr_t)settings->dL_dsh_dc)) & 15))
         return fail(GSR_ERR_UNSUPPORTED, "split SH form needs 16-byte aligned dL_dsh / dL_dsh_dc");
     if (scales && (!dL_dscales || !dL_drotations)) return fail(GSR_ERR_INVALID_ARG, "dL_dscales / dL_drotations are NULL");
-    GsrGeom g = gsr_carve_geom((char*)geom_buffer, P);
+    GsrGeom g = gsr_carve_geom(geom_buffer ? (char*)geom_buffer : nullptr, P);
     {   StageTimer t(GSR_STAGE_PREPROCESS_BWD, st);
         gsr_launch_preprocess_backward(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                        radii, g, splat_grads, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D,

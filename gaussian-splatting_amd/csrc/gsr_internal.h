@@ -144,3 +144,6 @@ void gsr_launch_ssim_mean_forward(int planes, int H, int W, const float* img1, c
 void gsr_launch_ssim_mean_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dmean,
                                    const float* dm_dmu1, const float* dm_dex2, const float* dm_dexy, float* dL_dimg1,
                                    hipStream_t st);
+// binning.hip: gathered splat records -> geometry state of this rank's band (two-axis sharding)
+void gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
+                             uint32_t* keys, uint32_t* vals, hipStream_t st);

@@ -45,6 +45,7 @@ EXPORTS = [
     "gsr_abi_version", "gsr_last_error", "gsr_geometry_bytes", "gsr_binning_bytes", "gsr_image_bytes",
     "gsr_backward_scratch_bytes",
     "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_backward_blend", "gsr_backward_preprocess",
+    "gsr_preprocess_forward", "gsr_rasterize_from_splats",
     "gsr_mark_visible", "gsr_forward_views", "gsr_adam_step", "gsr_sparse_adam_step", "gsr_ssim_forward", "gsr_ssim_backward",
     "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_ssim_partial_count", "gsr_ssim_mean_forward", "gsr_ssim_mean_backward",
     "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_set_option",
@@ -105,6 +106,11 @@ def load() -> C.CDLL:
     lib.gsr_backward_preprocess.argtypes = [C.POINTER(GsrRasterSettings), C.c_int, C.c_int,
                                             vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                             vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_preprocess_forward.restype = C.c_int
+    lib.gsr_preprocess_forward.argtypes = [C.POINTER(GsrRasterSettings), C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_rasterize_from_splats.restype = C.c_int
+    lib.gsr_rasterize_from_splats.argtypes = [C.POINTER(GsrRasterSettings), C.c_int, vp, RESIZE_FN, vp, RESIZE_FN, vp,
+                                              RESIZE_FN, vp, vp, vp, C.POINTER(C.c_int32), vp]
     lib.gsr_adam_step.restype = C.c_int
     lib.gsr_adam_step.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, vp]
     lib.gsr_sparse_adam_step.restype = C.c_int

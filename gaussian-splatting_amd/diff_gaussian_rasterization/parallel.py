@@ -1,22 +1,25 @@
-"""Screen-tile sharding of the rasterizer across the GPUs of one node (net-new: the reference
-has no multi-GPU code).  One process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm,
-"gloo" in the CPU tests).
+"""Sharding of the rasterizer across the GPUs of one node (net-new: the reference has no
+multi-GPU code).  One process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm, "gloo" in the CPU
+tests).  Two modes:
 
-Partitioning
-  * pixel axis: rank g owns a contiguous band of 16-pixel tile ROWS [y0_g, y1_g).  Bands are balanced by the
-    per-row instance counts of the previous frame (uniform rows are imbalanced on real scenes), see BandPlan.
-  * Gaussian axis: parameters are replicated; every rank runs the HBM-streaming preprocess on all P (SH colours
-    are evaluated only for Gaussians that touch the rank's band) -- cheaper than all-gathering 64-byte splat
-    records over xGMI at these sizes and one collective fewer on the critical path.
-Exchange steps
-  * forward : ONE all_gather of the rendered strips (colour + inverse depth stacked: 4*H*W*4 bytes in total);
-  * backward: every rank back-propagates only its own band's dL/dpixel through the blend backward, which yields
-    the dense per-Gaussian 2-D gradient record [P,12] (48 B/Gaussian); the records are summed across ranks with
-    ONE all_reduce and the per-Gaussian backward (59 floats/Gaussian of output) then runs replicated -- 5x less
-    traffic than reducing the parameter gradients themselves.  (`reduce="params"` does the latter; it is what a
-    band renderer without a record hook -- the CPU oracle in the gloo tests -- uses.)
-The band renderer is injected (`render_band`) so the index math and collectives are testable on CPU with gloo;
-`hip_band_renderer` is the product's renderer.
+A. TWO-AXIS (training; `render_two_axis`, SURVEY 8(e) as specified)
+  * Gaussian axis: rank g owns P/G Gaussians -- parameters, optimizer state, the per-Gaussian forward
+    (gsr_preprocess_forward) and backward (gsr_backward_preprocess) -- nothing of size O(59 P) ever crosses ranks;
+  * pixel axis: rank g owns a contiguous band of 16-pixel tile ROWS [y0_g, y1_g), balanced by the per-row instance
+    counts (BandPlan), and runs binning + blending on it (gsr_rasterize_from_splats, gsr_backward_blend);
+  * forward : all-gather of the 64-byte splat records, then ONE all-gather of the rendered strips;
+  * backward: the blend backward yields per-Gaussian 48-byte gradient records for ALL Gaussians from the own band;
+    reduce-scatter (sum) hands every rank the totals of its own shard.
+
+B. REPLICATED PARAMETERS, BANDS ONLY (forward-only rendering; `render_sharded`, bench.py's forward metric)
+  * every rank holds all parameters and runs the HBM-streaming preprocess on all P (SH colours are evaluated only for
+    Gaussians that touch the rank's band): for a forward-only frame re-running the preprocess (0.085 ms at 1 M) is
+    cheaper than all-gathering 64 MB of records and takes one collective off the critical path;
+  * forward: ONE all_gather of the rendered strips (asynchronous form: gather_strips_async, frames pipelined);
+  * backward (optional): ONE all_reduce of the [P,12] records, per-Gaussian backward replicated.
+
+The band renderer / the two stages are injectable, so the index math and the collectives are tested on CPU with gloo
+and the oracle (tests/test_parallel_gloo.py); `hip_band_renderer` and `_TwoAxisHip` are the product's.
 """
 from __future__ import annotations
 
@@ -185,3 +188,176 @@ def row_costs_from_ranges(ranges: torch.Tensor, gx: int, gy: int, group=None, ba
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
     # every row also costs a fixed amount (pixels to write)
     return (cnt + 256.0 * gx * 0.05).tolist()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Two-axis sharding: Gaussian axis for the per-Gaussian stages, pixel axis for binning + blending.
+# ------------------------------------------------------------------------------------------------------------------
+def padded_shard_size(P_local: int, group=None) -> int:
+    """Rows every rank contributes to the record all-gather: the largest shard, so that all_gather_into_tensor /
+    reduce_scatter_tensor see equal chunks (smaller shards pad with zero rows = records without tiles)."""
+    if _world(group) == 1:
+        return int(P_local)
+    t = torch.tensor([int(P_local)], dtype=torch.int64)
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
+class _AllGatherRows(torch.autograd.Function):
+    """[P_pad, k] per rank -> [world * P_pad, k] on every rank; backward = reduce-scatter (sum) of the gradient rows.
+    The generic (autograd) form of the record exchange -- the CPU oracle path of the gloo tests uses it; the HIP path
+    (_TwoAxisHip) issues the same two collectives around its fused kernels."""
+
+    @staticmethod
+    def forward(ctx, rows, group):
+        ctx.group = group
+        world = _world(group)
+        if world == 1:
+            return rows
+        out = rows.new_empty(world * rows.shape[0], *rows.shape[1:])
+        dist.all_gather_into_tensor(out.view(-1), rows.contiguous().view(-1), group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        world = _world(ctx.group)
+        if world == 1:
+            return g, None
+        g = g.contiguous()
+        out = g.new_empty(g.shape[0] // world, *g.shape[1:])
+        if dist.get_backend(ctx.group) == "gloo":      # gloo has no reduce_scatter: all-reduce + slice (tests only)
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+            r = dist.get_rank(ctx.group)
+            out.copy_(g[r * out.shape[0]:(r + 1) * out.shape[0]])
+        else:
+            dist.reduce_scatter_tensor(out.view(-1), g.view(-1), op=dist.ReduceOp.SUM, group=ctx.group)
+        return out, None
+
+
+def all_gather_rows(rows: torch.Tensor, group=None) -> torch.Tensor:
+    return _AllGatherRows.apply(rows, group)
+
+
+def _reduce_scatter_rows(full: torch.Tensor, out: torch.Tensor, group) -> None:
+    """out[P_pad, k] <- sum over ranks of full[rank * P_pad : (rank + 1) * P_pad]."""
+    world = _world(group)
+    if world == 1:
+        out.copy_(full)
+    elif dist.get_backend(group) == "gloo":
+        tmp = full.clone()
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
+        r = dist.get_rank(group)
+        out.copy_(tmp[r * out.shape[0]:(r + 1) * out.shape[0]])
+    else:
+        dist.reduce_scatter_tensor(out.view(-1), full.view(-1), op=dist.ReduceOp.SUM, group=group)
+
+
+class _TwoAxisHip(torch.autograd.Function):
+    """The product's two-axis renderer for one rank: local shard of Gaussians in, the rank's band of the image out.
+    forward : gsr_preprocess_forward (shard) -> all-gather of 64-byte records -> gsr_rasterize_from_splats (band)
+    backward: gsr_backward_blend (band; records of all Gaussians) -> reduce-scatter of 48-byte records ->
+              gsr_backward_preprocess (shard)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, raster_settings, band, P_pad, group, dc):
+        import ctypes as C
+        from . import _lib, _Buffer, _bucket, _f32c, _make_settings, _ptr, _stream_ptr, _require_cuda
+        lib = _lib.load()
+        _require_cuda(means3D, "means3D")
+        device = means3D.device
+        P = int(means3D.shape[0])
+        world = _world(group)
+        H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+        m_c, sh_c, op_c, sc_c, rot_c, dc_c = (_f32c(t) for t in (means3D, sh, opacities, scales, rotations, dc))
+        M = int(sh_c.shape[1]) + (1 if dc_c is not None else 0)
+        if dc_c is not None and (M != 16 or dc_c.data_ptr() % 16 or sh_c.data_ptr() % 16):
+            raise _lib.GsrError("two-axis renderer: the split SH form needs degree-3 storage (dc[P,1,3] + shs[P,15,3])")
+        keep: list = []
+        with torch.cuda.device(device):
+            st = _stream_ptr(device)
+            s = _make_settings(raster_settings, keep, band, False)
+            if dc_c is not None:
+                s.sh_dc = dc_c.data_ptr()
+            records = torch.zeros(int(P_pad), 16, dtype=torch.float32, device=device)     # padding rows: no tiles
+            radii = torch.empty(P, dtype=torch.int32, device=device)
+            scratch = torch.empty(_bucket(lib.gsr_geometry_bytes(P)), dtype=torch.uint8, device=device)
+            _lib.check(lib.gsr_preprocess_forward(C.byref(s), P, M, _ptr(m_c), _ptr(sh_c), None, _ptr(op_c), _ptr(sc_c),
+                                                  _ptr(rot_c), None, _ptr(scratch), _ptr(radii), _ptr(records), st),
+                       "gsr_preprocess_forward")
+            if world > 1:
+                all_records = torch.empty(world * int(P_pad), 16, dtype=torch.float32, device=device)
+                dist.all_gather_into_tensor(all_records.view(-1), records.view(-1), group=group)
+            else:
+                all_records = records
+            P_all = int(all_records.shape[0])
+            color = torch.zeros(3, H, W, dtype=torch.float32, device=device)
+            invdepth = torch.zeros(1, H, W, dtype=torch.float32, device=device)
+            geom, binning, img = _Buffer(device), _Buffer(device), _Buffer(device)
+            nr = C.c_int32(0)
+            _lib.check(lib.gsr_rasterize_from_splats(C.byref(s), P_all, _ptr(all_records), geom.cb, None, binning.cb, None,
+                                                     img.cb, None, _ptr(color), _ptr(invdepth), C.byref(nr), st),
+                       "gsr_rasterize_from_splats")
+        ctx.raster_settings, ctx.band, ctx.group, ctx.P_pad, ctx.P_all, ctx.M = raster_settings, band, group, int(P_pad), P_all, M
+        ctx.num_rendered = int(nr.value)
+        ctx.has_means2D = means2D is not None
+        ctx.has_dc = dc_c is not None
+        ctx.op_shape = tuple(opacities.shape)
+        ctx.dc_shape = tuple(dc.shape) if dc is not None else None
+        ctx.save_for_backward(m_c, sh_c, op_c, sc_c, rot_c, radii, geom.t, binning.t, img.t,
+                              dc_c if dc_c is not None else m_c.new_empty(0))
+        ctx.mark_non_differentiable(radii)
+        return color, radii, invdepth
+
+    @staticmethod
+    def backward(ctx, g_color, g_radii, g_depth):
+        import ctypes as C
+        from . import _lib, _bucket, _f32c, _make_settings, _ptr, _stream_ptr
+        lib = _lib.load()
+        m, sh, op, sc, rot, radii, geom, binning, img, dc = ctx.saved_tensors
+        device = m.device
+        P, P_pad, P_all, M = int(m.shape[0]), ctx.P_pad, ctx.P_all, ctx.M
+        f = dict(dtype=torch.float32, device=device)
+        d_m2, d_col, d_op = torch.empty(P, 3, **f), torch.empty(P, 3, **f), torch.empty(P, 1, **f)
+        d_m3, d_cov = torch.empty(P, 3, **f), torch.empty(P, 6, **f)
+        d_sh = torch.empty(P, M - 1 if ctx.has_dc else M, 3, **f)
+        d_dc = torch.empty(P, 1, 3, **f) if ctx.has_dc else None
+        d_sc, d_rot = torch.empty(P, 3, **f), torch.empty(P, 4, **f)
+        keep: list = []
+        with torch.cuda.device(device):
+            st = _stream_ptr(device)
+            s = _make_settings(ctx.raster_settings, keep, ctx.band)
+            if ctx.has_dc:
+                s.sh_dc, s.dL_dsh_dc = dc.data_ptr(), d_dc.data_ptr()
+            scratch = torch.empty(_bucket(lib.gsr_backward_scratch_bytes(P_all, ctx.num_rendered)), dtype=torch.uint8, device=device)
+            rec_ptr = C.c_void_p(0)
+            gc = _f32c(g_color)
+            gd = _f32c(g_depth) if g_depth is not None else None
+            _lib.check(lib.gsr_backward_blend(C.byref(s), P_all, ctx.num_rendered, _ptr(geom), _ptr(binning), _ptr(img), _ptr(gc),
+                                              _ptr(gd), _ptr(scratch), C.byref(rec_ptr), st), "gsr_backward_blend")
+            off = int(rec_ptr.value) - scratch.data_ptr()
+            full = scratch[off:off + P_all * 48].view(torch.float32).view(P_all, 12)
+            mine = torch.empty(P_pad, 12, **f)
+            _reduce_scatter_rows(full, mine, ctx.group)
+            if P > 0:
+                _lib.check(lib.gsr_backward_preprocess(C.byref(s), P, M, _ptr(m), _ptr(sh), None, _ptr(op), _ptr(sc), _ptr(rot),
+                                                       None, _ptr(radii), None, _ptr(mine), _ptr(d_m2), _ptr(d_col), _ptr(d_op),
+                                                       _ptr(d_m3), _ptr(d_cov), _ptr(d_sh), _ptr(d_sc), _ptr(d_rot), st),
+                           "gsr_backward_preprocess")
+        return (d_m3, d_m2 if ctx.has_means2D else None, d_sh, d_op.view(ctx.op_shape), d_sc, d_rot, None, None, None, None,
+                d_dc.view(ctx.dc_shape) if ctx.has_dc else None)
+
+
+def render_two_axis(raster_settings, means3D, sh, opacities, scales, rotations, plan: BandPlan, P_pad: Optional[int] = None,
+                    group=None, means2D=None, dc=None):
+    """Two-axis sharded render of one frame: this rank's shard of Gaussians in, the FULL image (strips all-gathered)
+    out.  Returns (color[3,H,W], radii[P_local], invdepth[1,H,W]); gradients flow to the rank's own shard only."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if P_pad is None:
+        P_pad = padded_shard_size(means3D.shape[0], group)
+    color, radii, invdepth = _TwoAxisHip.apply(means3D, means2D, sh, opacities, scales, rotations, raster_settings,
+                                               plan.band(rank), P_pad, group, dc)
+    H = color.shape[1]
+    both = _GatherStrips.apply(torch.cat([color, invdepth], dim=0), plan, H, group)
+    return both[:3], radii, both[3:4]

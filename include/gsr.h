@@ -160,6 +160,32 @@ int gsr_backward_preprocess(const GsrRasterSettings* settings, int P, int M,
                             float* dL_dscales, float* dL_drotations, void* stream);
 
 /*
+ * Two-axis sharding (no reference counterpart): the per-Gaussian stages are sharded over the GAUSSIAN
+ * axis (every rank owns P/G Gaussians, their parameters and optimizer state), binning + blending over the PIXEL axis
+ * (bands of tile rows).  Forward: gsr_preprocess_forward on the own shard -> all-gather of the 64-byte splat records ->
+ * gsr_rasterize_from_splats on the own band.  Backward: gsr_backward_blend on the own band (records of ALL Gaussians)
+ * -> reduce-scatter (sum) of the 48-byte gradient records -> gsr_backward_preprocess on the own shard (geom_buffer may
+ * be NULL there).  No parameter or parameter-gradient ever crosses ranks.
+ *
+ * gsr_preprocess_forward: projects the P Gaussians of the shard; writes radii[P] and splat_records[P,16] floats
+ *   (x,y,conA,conB | conC,opacity,r,g | b,depth,tau,1/depth | rect.x,rect.y,0,tiles as bits) with the FULL-frame tile
+ *   rectangle (tile_y0/tile_y1 of the settings are ignored).  geom_scratch: gsr_geometry_bytes(P) bytes.
+ * gsr_rasterize_from_splats: bins and blends P gathered records inside the band the settings name; the records are
+ *   copied into the geometry buffer (obtained through the callback), so the caller's array is not modified.  Buffers
+ *   and outputs as gsr_rasterize_forward; a record whose tile count is 0 (culled, or a zero padding row) is ignored.
+ */
+int gsr_preprocess_forward(const GsrRasterSettings* settings, int P, int M,
+                           const float* means3D, const float* shs, const float* colors_precomp,
+                           const float* opacities, const float* scales, const float* rotations,
+                           const float* cov3D_precomp, void* geom_scratch, int32_t* radii, float* splat_records,
+                           void* stream);
+int gsr_rasterize_from_splats(const GsrRasterSettings* settings, int P, const float* splat_records,
+                              GsrResizeFn geom_resize, void* geom_user,
+                              GsrResizeFn binning_resize, void* binning_user,
+                              GsrResizeFn image_resize, void* image_user,
+                              float* out_color, float* out_invdepth, int32_t* num_rendered, void* stream);
+
+/*
  * Fused dense Adam step on one fp32 tensor of n elements (the optimizer step of train.py:177-186).
  * Same arithmetic as torch.optim.Adam(betas, eps) without weight decay / amsgrad; `step` is the 1-based step count
  * AFTER incrementing; state tensors exp_avg / exp_avg_sq are updated in place.

@@ -294,3 +294,105 @@ def test_short_optimisation_reduces_the_reference_loss(optimizer):
         losses.append(float(loss.detach()))
     assert all(map(lambda v: v == v, losses))                       # no NaN
     assert losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
+
+
+def _fused_reference(rs, sc, wgt, wd, dev):
+    from diff_gaussian_rasterization import rasterize_gaussians
+    L = [t.detach().clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+    m2 = torch.zeros(sc.P, 3, device=dev, requires_grad=True)
+    col, radii, invd = rasterize_gaussians(L[0], m2, L[1], None, L[2], L[3], L[4], None, rs)
+    ((col * wgt).sum() + (invd * wd).sum()).backward()
+    return col.detach(), radii, invd.detach(), [t.grad for t in L] + [m2.grad]
+
+
+def test_two_axis_renderer_single_rank_equals_fused_operator():
+    """render_two_axis with one rank (no collective): gsr_preprocess_forward + gsr_rasterize_from_splats +
+    gsr_backward_blend + gsr_backward_preprocess must reproduce gsr_rasterize_forward / _backward."""
+    from diff_gaussian_rasterization.parallel import BandPlan, render_two_axis
+    dev = torch.device("cuda:0")
+    cam = make_camera(320, 208)
+    sc = make_scene(6000, cam, seed=31, s_med=0.03).to(dev)
+    rs = gpu_settings(oracle_settings(cam, bg=torch.tensor([0.1, 0.3, 0.2])), dev)
+    g = torch.Generator().manual_seed(3)
+    wgt, wd = torch.randn(3, 208, 320, generator=g).to(dev), torch.randn(1, 208, 320, generator=g).to(dev)
+    col, radii, invd, ref = _fused_reference(rs, sc, wgt, wd, dev)
+    L = [t.detach().clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+    m2 = torch.zeros(sc.P, 3, device=dev, requires_grad=True)
+    c2, r2, d2 = render_two_axis(rs, L[0], L[1], L[2], L[3], L[4], BandPlan.uniform(13, 1), means2D=m2)
+    assert torch.equal(c2, col) and torch.equal(r2, radii) and torch.equal(d2, invd)
+    ((c2 * wgt).sum() + (d2 * wd).sum()).backward()
+    for got, want in zip([t.grad for t in L] + [m2.grad], ref):
+        assert (got - want).abs().max().item() <= 5e-5 * want.abs().max().item()
+
+
+def test_two_axis_pieces_two_shards_two_bands_on_one_gpu():
+    """The per-rank pieces of the two-axis scheme driven by hand for 2 Gaussian shards x 2 pixel bands (the collectives
+    replaced by a concatenation and a sum): padded record rows, band clamp in splat_ingest, per-band gradient records,
+    shard-local gsr_backward_preprocess without a geometry buffer."""
+    import ctypes as C
+    from diff_gaussian_rasterization import _lib, _Buffer, _make_settings, _ptr, _stream_ptr
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    W, H = 336, 200
+    cam = make_camera(W, H)
+    sc = make_scene(5001, cam, seed=17, s_med=0.03).to(dev)
+    rs = gpu_settings(oracle_settings(cam), dev)
+    g = torch.Generator().manual_seed(9)
+    wgt, wd = torch.randn(3, H, W, generator=g).to(dev), torch.randn(1, H, W, generator=g).to(dev)
+    col, radii, invd, ref = _fused_reference(rs, sc, wgt, wd, dev)
+    cuts, P_pad, bands, gy = [0, 1900, 5001], 3101, [(0, 5), (5, 13)], 13
+    st = _stream_ptr(dev)
+    keep = []
+    shards = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        P = b - a
+        t = [x[a:b].contiguous() for x in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+        rec = torch.zeros(P_pad, 16, device=dev)
+        rad = torch.empty(P, dtype=torch.int32, device=dev)
+        scratch = torch.empty(int(lib.gsr_geometry_bytes(P)), dtype=torch.uint8, device=dev)
+        s = _make_settings(rs, keep, None)
+        _lib.check(lib.gsr_preprocess_forward(C.byref(s), P, 16, _ptr(t[0]), _ptr(t[1]), None, _ptr(t[2]), _ptr(t[3]), _ptr(t[4]),
+                                              None, _ptr(scratch), _ptr(rad), _ptr(rec), st), "gsr_preprocess_forward")
+        assert torch.equal(rad, radii[a:b])
+        shards.append((t, rec, rad))
+    records = torch.cat([sh_[1] for sh_ in shards], dim=0)            # = the all-gather
+    P_all = records.shape[0]
+    before = records.clone()
+    image = torch.zeros(3, H, W, device=dev)
+    depth = torch.zeros(1, H, W, device=dev)
+    grad_records = torch.zeros(P_all, 12, device=dev)
+    for band in bands:
+        s = _make_settings(rs, keep, band)
+        color = torch.zeros(3, H, W, device=dev)
+        invdp = torch.zeros(1, H, W, device=dev)
+        geom, binning, img = _Buffer(dev), _Buffer(dev), _Buffer(dev)
+        nr = C.c_int32(0)
+        _lib.check(lib.gsr_rasterize_from_splats(C.byref(s), P_all, _ptr(records), geom.cb, None, binning.cb, None, img.cb, None,
+                                                 _ptr(color), _ptr(invdp), C.byref(nr), st), "gsr_rasterize_from_splats")
+        rows = slice(band[0] * 16, min(band[1] * 16, H))
+        image[:, rows], depth[:, rows] = color[:, rows], invdp[:, rows]
+        gc, gd = torch.zeros_like(wgt), torch.zeros_like(wd)
+        gc[:, rows], gd[:, rows] = wgt[:, rows], wd[:, rows]
+        scr = torch.empty(int(lib.gsr_backward_scratch_bytes(P_all, nr.value)), dtype=torch.uint8, device=dev)
+        rp = C.c_void_p(0)
+        _lib.check(lib.gsr_backward_blend(C.byref(s), P_all, nr.value, _ptr(geom.t), _ptr(binning.t), _ptr(img.t), _ptr(gc), _ptr(gd),
+                                          _ptr(scr), C.byref(rp), st), "gsr_backward_blend")
+        off = int(rp.value) - scr.data_ptr()
+        grad_records += scr[off:off + P_all * 48].view(torch.float32).view(P_all, 12)      # = the reduce-scatter's sum
+    torch.cuda.synchronize()
+    assert torch.equal(records, before)                                 # the gathered records are not modified
+    assert torch.equal(image, col) and torch.equal(depth, invd)
+    for k, ((a, b), (t, rec, rad)) in enumerate(zip(zip(cuts[:-1], cuts[1:]), shards)):
+        P = b - a
+        mine = grad_records[k * P_pad:k * P_pad + P].contiguous()
+        assert float(grad_records[k * P_pad + P:(k + 1) * P_pad].abs().max()) == 0.0 if P < P_pad else True
+        f = dict(dtype=torch.float32, device=dev)
+        outs = [torch.empty(P, 3, **f), torch.empty(P, 3, **f), torch.empty(P, 1, **f), torch.empty(P, 3, **f), torch.empty(P, 6, **f),
+                torch.empty(P, 16, 3, **f), torch.empty(P, 3, **f), torch.empty(P, 4, **f)]
+        s = _make_settings(rs, keep, None)
+        _lib.check(lib.gsr_backward_preprocess(C.byref(s), P, 16, _ptr(t[0]), _ptr(t[1]), None, _ptr(t[2]), _ptr(t[3]), _ptr(t[4]), None,
+                                               _ptr(rad), None, _ptr(mine), *[_ptr(o) for o in outs], st), "gsr_backward_preprocess")
+        torch.cuda.synchronize()
+        d_m2, _, d_op, d_m3, _, d_sh, d_sc, d_rot = outs
+        for got, want in zip([d_m3, d_sh, d_op, d_sc, d_rot, d_m2], ref):
+            assert (got.view(-1) - want[a:b].reshape(-1)).abs().max().item() <= 5e-5 * want.abs().max().item()

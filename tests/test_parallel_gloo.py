@@ -141,3 +141,96 @@ def test_async_strip_gathers_in_flight(world):
             p.join(120)
             assert p.exitcode == 0
         assert torch.load(path)["ok"]
+
+
+def _oracle_two_axis(leaves, m2, s, plan, rank, world, P_pad, gy):
+    """The two-axis flow with the oracle as both stages: local preprocess -> all_gather_rows (differentiable; backward
+    = reduce-scatter) -> band clamp -> bin + blend on the own band -> strips."""
+    from diff_gaussian_rasterization.parallel import all_gather_rows, _GatherStrips
+    m, sh, o, scl, rot = leaves
+    pre = O.preprocess(m, o, s, shs=sh, scales=scl, rotations=rot, means2D=m2)              # full frame
+    P = m.shape[0]
+    diff = torch.cat([pre["means2D"], pre["conic"], pre["opacity"][:, None], pre["rgb"], pre["depths"][:, None]], dim=1)
+    ints = torch.cat([pre["rect"].to(diff.dtype), pre["tiles_touched"][:, None].to(diff.dtype),
+                      pre["radii"][:, None].to(diff.dtype)], dim=1)
+    rows = torch.cat([diff, ints], dim=1)
+    rows = torch.cat([rows, rows.new_zeros(P_pad - P, rows.shape[1])], dim=0)               # padding: no tiles
+    allr = all_gather_rows(rows)
+    y0, y1 = plan.band(rank)
+    rect = allr[:, 10:14].detach().to(torch.int64)
+    full_tiles = allr[:, 14].detach().to(torch.int64)
+    bminy, bmaxy = rect[:, 1].clamp(y0, y1), rect[:, 3].clamp(y0, y1)
+    tiles = torch.where(full_tiles > 0, (rect[:, 2] - rect[:, 0]) * (bmaxy - bminy), torch.zeros_like(full_tiles))
+    pre_all = {"means2D": allr[:, 0:2], "conic": allr[:, 2:5], "opacity": allr[:, 5], "rgb": allr[:, 6:9], "depths": allr[:, 9],
+               "radii": allr[:, 15].detach().to(torch.int32), "tiles_touched": tiles,
+               "rect": torch.stack([rect[:, 0], bminy, rect[:, 2], bmaxy], dim=1), "grid": pre["grid"], "band": (y0, y1)}
+    # padding rows have depth 0 -> 1/depth = inf in the oracle's per-Gaussian table; they are never listed
+    pre_all["depths"] = torch.where(full_tiles > 0, pre_all["depths"], torch.ones_like(pre_all["depths"]))
+    bins = O.bin_and_sort(pre_all)
+    color, invd, *_ = O.render_tiles(pre_all, bins, s)
+    H = color.shape[1]
+    both = _GatherStrips.apply(torch.cat([color, invd], dim=0), plan, H, None)
+    return both[:3], pre["radii"], both[3:4]
+
+
+def _two_axis_worker(rank, world, port, path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from diff_gaussian_rasterization.parallel import BandPlan, padded_shard_size
+    cam = make_camera(112, 96)
+    sc = make_edge_scene(500, cam, seed=33)
+    s = oracle_settings(cam, bg=torch.tensor([0.2, 0.4, 0.6]))
+    gy = 6
+    plan = BandPlan([0, 2, 6]) if world == 2 else BandPlan([0, 1, 4, 6])
+    cuts = [0, 230, 500] if world == 2 else [0, 100, 333, 500]           # uneven shards -> padding rows
+    a, b = cuts[rank], cuts[rank + 1]
+    leaves = [t[a:b].clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+    m2 = torch.zeros(b - a, 3, requires_grad=True)
+    P_pad = padded_shard_size(b - a)
+    color, radii, invd = _oracle_two_axis(leaves, m2, s, plan, rank, world, P_pad, gy)
+    g = torch.Generator().manual_seed(7)
+    wc, wd = torch.randn(3, 96, 112, generator=g), torch.randn(1, 96, 112, generator=g)
+    ((color * wc).sum() + (invd * wd).sum()).backward()
+    torch.save({"color": color.detach(), "invd": invd.detach(), "radii": radii, "P_pad": P_pad, "cut": (a, b),
+                "grads": [t.grad for t in leaves] + [m2.grad]}, path % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_axis_sharding_equals_single_device(world):
+    """Gaussian-sharded preprocess + record all-gather + band blend + gradient reduce-scatter against the
+    single-device oracle: same image on every rank, and each rank's parameter gradients equal its slice of the
+    single-device gradients."""
+    import tempfile
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "rank%d.pt")
+        procs = [ctx.Process(target=_two_axis_worker, args=(r, world, port, path)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        outs = [torch.load(path % r) for r in range(world)]
+    cam = make_camera(112, 96)
+    sc = make_edge_scene(500, cam, seed=33)
+    s = oracle_settings(cam, bg=torch.tensor([0.2, 0.4, 0.6]))
+    leaves = [t.clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+    m2 = torch.zeros(sc.P, 3, requires_grad=True)
+    color, radii, invd = O.rasterize(leaves[0], m2, leaves[2], s, shs=leaves[1], scales=leaves[3], rotations=leaves[4])
+    g = torch.Generator().manual_seed(7)
+    wc, wd = torch.randn(3, 96, 112, generator=g), torch.randn(1, 96, 112, generator=g)
+    ((color * wc).sum() + (invd * wd).sum()).backward()
+    ref = [t.grad for t in leaves] + [m2.grad]
+    assert outs[0]["P_pad"] == max(o["cut"][1] - o["cut"][0] for o in outs)
+    for o in outs:
+        a, b = o["cut"]
+        assert torch.equal(o["radii"], radii[a:b])
+        assert (o["color"] - color.detach()).abs().max().item() <= 3e-6 and (o["invd"] - invd.detach()).abs().max().item() <= 3e-6
+        for got, want in zip(o["grads"], ref):
+            scale = want.abs().max().item() + 1e-30
+            assert (got - want[a:b]).abs().max().item() <= 3e-5 * scale
