@@ -4,27 +4,31 @@
 // The reference issues ~10 global float atomics per contributing (pixel, Gaussian) pair.  On MI355X device-scope
 // float atomics are resolved at the memory side (8 non-coherent XCD L2s), and even one atomic set per
 // (8x8 block, Gaussian) -- the first design here, kept as variant 1 -- measured 2.46 ms on the 1 M / 1080p frame,
-// 7x the forward blend.  The default design has NO global atomics and is deterministic:
+// 7x the forward blend.  The default design has NO global atomics (the only run-to-run variation left is the order of
+// the four waves' ds_add_f32 into one LDS table: fp32 reassociation noise):
 //
 //  render_bwd_tile     one 256-thread workgroup per 16x16 tile, wave w = 8x8 quadrant w.  The tile's list is walked
 //                      BACK TO FRONT in super-batches of 256 entries staged once in LDS (record + log2-scaled conic).
 //                      Each wave box-tests 64 entries at a time against its quadrant (same exact test as the forward:
 //                      a culled entry contributed to no pixel of the box, so its gradient from this box is zero),
-//                      walks the survivors (s_flbit), every lane computes its pixel's 10 partial derivatives, and the
+//                      walks the survivors (s_flbit), every lane computes its pixel's 10 per-pair values (five MOMENTS
+//                      of the pixel offset, see bwd_step, plus opacity / colour / inverse-depth terms), and the
 //                      10 values are summed over the 64 lanes with a transpose-reduce: v_permlane32_swap +
 //                      v_permlane16_swap butterflies fold four values into one register (one value per 16-lane row),
-//                      DPP row shifts finish each row -- 28 VALU ops for 10 values instead of 60 -- and lanes 15/31/
+//                      DPP row shifts finish each row -- ~27 VALU ops for 10 values instead of 60 -- and lanes 15/31/
 //                      47/63 add the row totals into the super-batch's LDS gradient table (ds_add_f32).  After the
 //                      super-batch the table (256 x 48 B) is written out as per-INSTANCE gradient records.
 //                      Each record is written at the instance's EMISSION index k = goffset[g] + (ty-miny)*w + (tx-minx)
 //                      (rectangle and goffset ride in the 4th quad of the 64-byte splat record): in emission order a
 //                      Gaussian's instances are contiguous.
-//  bwd_reduce_instances  streams each Gaussian's contiguous run of records and writes the per-Gaussian 2-D gradient
-//                      record ("splat_grads") that preprocess.hip's fused per-Gaussian backward consumes.
+//  bwd_reduce_instances  streams each Gaussian's contiguous run of records, turns the summed moments into derivatives
+//                      with the Gaussian's conic, and writes the per-Gaussian 2-D gradient record ("splat_grads")
+//                      that preprocess.hip's fused per-Gaussian backward consumes.
 //
-// Instance record layout (float[12]): 0 dL/dpx 1 dL/dpy (pixel units) 2 dL/dA 3 dL/dB 4 dL/dC (plain derivatives
-// of the conic entries, power = -0.5(A dx^2 + C dy^2) - B dx dy) 5 dL/d(opacity*aa) 6,7,8 dL/d(rgb) 9 dL/d(1/depth)
-// 10,11 pad.  The per-Gaussian record ("splat_grads", variant 1 and the multi-GPU exchange) has the same layout.
+// Per-Gaussian record layout ("splat_grads", float[12]; also variant 1 and the multi-GPU exchange): 0 dL/dpx 1 dL/dpy
+// (pixel units) 2 dL/dA 3 dL/dB 4 dL/dC (plain derivatives of the conic entries, power = -0.5(A dx^2 + C dy^2) - B dx dy)
+// 5 dL/d(opacity*aa) 6,7,8 dL/d(rgb) 9 dL/d(1/depth) 10,11 pad.  Instance records hold the raw moments
+// (sum m dx, sum m dy, sum m dx^2, sum m dx dy, sum m dy^2) in slots 0..4 instead.
 #include "gsr_internal.h"
 
 namespace {
