@@ -55,8 +55,9 @@ def parse():
     ap.add_argument("--cpu-tiles", type=int, default=1200, help="tiles blended by the CPU baseline sample")
     ap.add_argument("--uniform-bands", action="store_true")
     ap.add_argument("--compare-torch-adam", action="store_true", help="also time the train step with torch.optim.Adam")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams the forward frames alternate on (N = 1 GPU): 1 = strictly "
-                                                          "one frame after the other (frame latency), 2 = double-buffered frames")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the forward frames alternate on (N = 1 GPU): 1 = strictly "
+                                                          "one frame after the other (default), 2 = double-buffered frames -- "
+                                                          "measured 2.5x SLOWER on MI355X / ROCm 7.2 (1.29 vs 0.52 ms per frame), kept for A/B only")
     ap.add_argument("--sort-items", type=int, default=0, help="keys per workgroup of the large radix passes (1024 / 2048 / 4096; 0 = library default)")
     ap.add_argument("--bwd-variant", type=int, default=0, help="render_bwd_variant (0 default, 1 atomics baseline, 2 128-entry super-batches)")
     return ap.parse_args()
