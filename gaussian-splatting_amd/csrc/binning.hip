@@ -17,17 +17,22 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
     return v;
 }
 
-// pass 1: per-workgroup totals of tiles[order[j]]
+// pass 1: per-workgroup totals of tiles[order[j]]; the gathered counts are also written out in depth order
+// (tiles_sorted), so that pass 2 streams them instead of repeating the 4-byte random gather
 __global__ void __launch_bounds__(SC_THREADS)
 scan_block_sums(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
-                uint32_t* __restrict__ block_sums) {
+                uint32_t* __restrict__ tiles_sorted, uint32_t* __restrict__ block_sums) {
     __shared__ uint32_t wsum[SC_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * GSR_SCAN_ITEMS + tid * SC_IPT;
     uint32_t s = 0;
 #pragma unroll
     for (int k = 0; k < SC_IPT; ++k)
-        if (base + k < P) s += tiles[order[base + k]];
+        if (base + k < P) {
+            const uint32_t t = tiles[order[base + k]];
+            tiles_sorted[base + k] = t;
+            s += t;
+        }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if (lane == 0) wsum[w] = s;
@@ -38,7 +43,7 @@ scan_block_sums(int P, const uint32_t* __restrict__ order, const uint32_t* __res
 // pass 2: every workgroup sums the totals of the workgroups before it (a few KB from L2), then scans its
 // own 1024 items.  offsets[j] = inclusive prefix in depth order; the last workgroup publishes R.
 __global__ void __launch_bounds__(SC_THREADS)
-scan_finish(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
+scan_finish(int P, const uint32_t* __restrict__ tiles_sorted,
             const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ offsets, uint32_t* __restrict__ num_rendered,
             uint32_t* host_word, uint32_t seq) {
     __shared__ uint32_t wsum[SC_THREADS / 64];
@@ -54,7 +59,7 @@ scan_finish(int P, const uint32_t* __restrict__ order, const uint32_t* __restric
     uint32_t s = 0;
 #pragma unroll
     for (int k = 0; k < SC_IPT; ++k) {
-        v[k] = (base + k < P) ? tiles[order[base + k]] : 0u;
+        v[k] = (base + k < P) ? tiles_sorted[base + k] : 0u;
         s += v[k];
     }
     const uint32_t incl = wave_incl_scan(s, lane);
@@ -143,22 +148,45 @@ emit_instances(int P, int gx, const uint32_t* __restrict__ order, const uint32_t
     }
 }
 
-// ranges[t] = [first, last+1) of tile t's run in the sorted instance list; untouched tiles stay (0,0)
+// ranges[t] = [first, last+1) of tile t's run in the sorted instance list; untouched tiles stay (0,0).
+// Every lane takes 16 bytes of keys (8 x u16 / 4 x u32) in one load; the key before its first one comes from the
+// neighbouring lane (ds_bpermute) -- one wave-wide load moves 1 KB instead of the 128 B of a 16-bit scalar load.
 template <typename KeyT>
 __global__ void __launch_bounds__(256)
 tile_ranges(int64_t R, const KeyT* __restrict__ keys, uint2* __restrict__ ranges) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t t = keys[i];
-        if (i == 0) {
-            ranges[t].x = 0;
+    constexpr int VEC = 16 / (int)sizeof(KeyT);
+    const int lane = threadIdx.x & 63;
+    const int64_t nvec = (R + VEC - 1) / VEC;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t v0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x - lane; v0 < nvec; v0 += stride) {   // wave-uniform trips
+        const int64_t v = v0 + lane, base = v * VEC;
+        uint32_t k[VEC];
+        if (base + VEC <= R) {
+            const uint4 t = *reinterpret_cast<const uint4*>(keys + base);
+            const uint32_t wd[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                k[j] = sizeof(KeyT) == 2 ? ((wd[j / 2] >> (16 * (j & 1))) & 0xFFFFu) : wd[j % 4];
         } else {
-            const uint32_t p = keys[i - 1];
-            if (p != t) {
-                ranges[p].y = (uint32_t)i;
-                ranges[t].x = (uint32_t)i;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) k[j] = base + j < R ? (uint32_t)keys[base + j] : 0u;
+        }
+        uint32_t prev = (uint32_t)__shfl_up((int)k[VEC - 1], 1, 64);
+        if (lane == 0 && base > 0 && base < R) prev = (uint32_t)keys[base - 1];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int64_t i = base + j;
+            if (i < R) {
+                const uint32_t t = k[j], p = j ? k[j - 1] : prev;
+                if (i == 0) {
+                    ranges[t].x = 0;
+                } else if (p != t) {
+                    ranges[p].y = (uint32_t)i;
+                    ranges[t].x = (uint32_t)i;
+                }
+                if (i == R - 1) ranges[t].y = (uint32_t)R;
             }
         }
-        if (i == R - 1) ranges[t].y = (uint32_t)R;
     }
 }
 
@@ -200,11 +228,11 @@ void gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4
                        rect, tiles, keys, vals);
 }
 
-void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles, uint32_t* offsets,
+void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles, uint32_t* tiles_sorted, uint32_t* offsets,
                            uint32_t* block_sums, uint32_t* num_rendered, uint32_t* host_word, uint32_t seq, hipStream_t st) {
     const int nb = (P + GSR_SCAN_ITEMS - 1) / GSR_SCAN_ITEMS;
-    hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(SC_THREADS), 0, st, P, order, tiles, block_sums);
-    hipLaunchKernelGGL(scan_finish, dim3(nb), dim3(SC_THREADS), 0, st, P, order, tiles, block_sums, offsets, num_rendered,
+    hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(SC_THREADS), 0, st, P, order, tiles, tiles_sorted, block_sums);
+    hipLaunchKernelGGL(scan_finish, dim3(nb), dim3(SC_THREADS), 0, st, P, tiles_sorted, block_sums, offsets, num_rendered,
                        host_word, seq);
 }
 
@@ -223,7 +251,7 @@ void gsr_launch_ranges(int64_t R, int n_tiles, const void* sorted_keys, bool key
                        hipStream_t st) {
     if (!already_zeroed) (void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)n_tiles, st);
     if (R <= 0) return;
-    int64_t nb = (R + 255) / 256;
+    int64_t nb = (R / (key16 ? 8 : 4) + 255) / 256 + 1;
     if (nb > 2048) nb = 2048;
     if (key16)
         hipLaunchKernelGGL(tile_ranges<uint16_t>, dim3((int)nb), dim3(256), 0, st, R, (const uint16_t*)sorted_keys, ranges);

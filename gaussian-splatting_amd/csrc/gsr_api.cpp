@@ -290,7 +290,9 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     }
     const uint32_t seq = ++g_host_seq;
     {   StageTimer t(GSR_STAGE_SCAN, st);
-        gsr_launch_scan_tiles(P, g.vals[order_buf], g.tiles, g.offsets, g.block_sums, g.num_rendered, g_host_word_dev, seq, st);
+        // the depth keys are not needed after the sort: the other half of their ping-pong pair holds the tile counts in depth order
+        gsr_launch_scan_tiles(P, g.vals[order_buf], g.tiles, g.keys[order_buf ^ 1], g.offsets, g.block_sums, g.num_rendered,
+                              g_host_word_dev, seq, st);
     }
     const int n_tiles = cam.gx * cam.gy;
     char* ibase = (char*)image_resize(image_user, gsr_image_bytes(cam.W, cam.H));

@@ -91,7 +91,7 @@ static inline int64_t gsr_sort_blocks(int64_t n, bool small_blocks) {
 }
 
 // binning.hip: scan of tiles_touched in depth order, instance emission, tile ranges
-void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles, uint32_t* offsets,
+void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles, uint32_t* tiles_sorted /*[P] scratch*/, uint32_t* offsets,
                            uint32_t* block_sums, uint32_t* num_rendered, uint32_t* host_word /*mapped pinned, may be NULL*/,
                            uint32_t seq, hipStream_t st);
 // key16: tile ids are stored as uint16_t (frames with <= 65536 tiles), else uint32_t
