@@ -55,10 +55,7 @@ def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 
 def _bucket(nbytes: int) -> int:
-    """Round a scratch size up to one of 8 sizes per octave (<= 12.5 % slack).  The R-sized buffers (binning state,
-    backward scratch) change by a few hundred KB from frame to frame as the Gaussians move; handing the caching
-    allocator a different size every iteration makes it hipMalloc a fresh block now and then (tens of ms on ROCm --
-    seen as one-off stalls of ~75 ms in bench.py's train legs).  Bucketed sizes hit the same cached block."""
+    """Round a scratch size up to one of 8 sizes per octave (<= 12.5 % slack)."""
     nbytes = int(nbytes)
     if nbytes <= (1 << 20):
         return nbytes
@@ -66,16 +63,36 @@ def _bucket(nbytes: int) -> int:
     return (nbytes + step - 1) // step * step
 
 
+_last_size: dict = {}
+
+
+def _sized(kind: str, device, nbytes: int) -> int:
+    """Allocation size for an R-sized scratch buffer (binning state, backward scratch).  R changes by a fraction of a
+    percent from frame to frame as the Gaussians move; handing the caching allocator a different size every iteration
+    makes it hipMalloc a fresh block now and then, which costs tens of ms on ROCm (seen as one-off 75 ms stalls in
+    bench.py's train legs whenever the size crossed a rounding boundary).  So sizes are sticky: the last size of this
+    kind is reused while it fits (and is not more than twice too big); when it does not, the new size jumps 12.5 %
+    ahead of the need and is rounded to 8 steps per octave -- a training run re-allocates once per ~12 % growth."""
+    nbytes = int(nbytes)
+    key = (kind, getattr(device, "index", None))
+    last = _last_size.get(key, 0)
+    if nbytes <= last <= 2 * max(nbytes, 1 << 20):
+        return last
+    new = _bucket(nbytes + nbytes // 8)
+    _last_size[key] = new
+    return new
+
+
 class _Buffer:
     """A growable uint8 device tensor handed to the library through a resize callback (the reference's
     resizeFunctional lambda)."""
 
-    def __init__(self, device):
+    def __init__(self, device, kind: str = "state"):
         self.t = torch.empty(0, dtype=torch.uint8, device=device)
 
         def _resize(_user, nbytes):
             if self.t.numel() < nbytes:
-                self.t = torch.empty(_bucket(nbytes), dtype=torch.uint8, device=device)
+                self.t = torch.empty(_sized(kind, device, nbytes), dtype=torch.uint8, device=device)
             return self.t.data_ptr()
 
         self.cb = RESIZE_FN(_resize)
@@ -161,7 +178,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 color.zero_()
                 invdepth.zero_()
             radii = torch.empty(P, dtype=torch.int32, device=device)
-            geom, binning, img = _Buffer(device), _Buffer(device), _Buffer(device)
+            geom, binning, img = _Buffer(device, "geom"), _Buffer(device, "binning"), _Buffer(device, "image")
             nr = C.c_int32(0)
             args = (C.byref(s), P, M, _ptr(means3D_c), _ptr(sh_c), _ptr(col_c), _ptr(op_c), _ptr(sc_c), _ptr(rot_c),
                     _ptr(cov_c), geom.cb, None, binning.cb, None, img.cb, None, _ptr(color), _ptr(invdepth),
@@ -222,7 +239,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         if P > 0:
             g_color = _f32c(grad_out_color)
             g_depth = _f32c(grad_out_depth) if grad_out_depth is not None else None
-            scratch = torch.empty(_bucket(lib.gsr_backward_scratch_bytes(P, ctx.num_rendered)), dtype=torch.uint8, device=device)
+            scratch = torch.empty(_sized("bwd", device, lib.gsr_backward_scratch_bytes(P, ctx.num_rendered)), dtype=torch.uint8,
+                                  device=device)
             keep: list = []
             with torch.cuda.device(device):
                 s = _make_settings(rs, keep, ctx.tile_rows)

@@ -263,7 +263,7 @@ class _TwoAxisHip(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, raster_settings, band, P_pad, group, dc):
         import ctypes as C
-        from . import _lib, _Buffer, _bucket, _f32c, _make_settings, _ptr, _stream_ptr, _require_cuda
+        from . import _lib, _Buffer, _sized, _f32c, _make_settings, _ptr, _stream_ptr, _require_cuda
         lib = _lib.load()
         _require_cuda(means3D, "means3D")
         device = means3D.device
@@ -282,7 +282,7 @@ class _TwoAxisHip(torch.autograd.Function):
                 s.sh_dc = dc_c.data_ptr()
             records = torch.zeros(int(P_pad), 16, dtype=torch.float32, device=device)     # padding rows: no tiles
             radii = torch.empty(P, dtype=torch.int32, device=device)
-            scratch = torch.empty(_bucket(lib.gsr_geometry_bytes(P)), dtype=torch.uint8, device=device)
+            scratch = torch.empty(_sized("geom_shard", device, lib.gsr_geometry_bytes(P)), dtype=torch.uint8, device=device)
             _lib.check(lib.gsr_preprocess_forward(C.byref(s), P, M, _ptr(m_c), _ptr(sh_c), None, _ptr(op_c), _ptr(sc_c),
                                                   _ptr(rot_c), None, _ptr(scratch), _ptr(radii), _ptr(records), st),
                        "gsr_preprocess_forward")
@@ -294,7 +294,7 @@ class _TwoAxisHip(torch.autograd.Function):
             P_all = int(all_records.shape[0])
             color = torch.zeros(3, H, W, dtype=torch.float32, device=device)
             invdepth = torch.zeros(1, H, W, dtype=torch.float32, device=device)
-            geom, binning, img = _Buffer(device), _Buffer(device), _Buffer(device)
+            geom, binning, img = _Buffer(device, "geom"), _Buffer(device, "binning"), _Buffer(device, "image")
             nr = C.c_int32(0)
             _lib.check(lib.gsr_rasterize_from_splats(C.byref(s), P_all, _ptr(all_records), geom.cb, None, binning.cb, None,
                                                      img.cb, None, _ptr(color), _ptr(invdepth), C.byref(nr), st),
@@ -313,7 +313,7 @@ class _TwoAxisHip(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_color, g_radii, g_depth):
         import ctypes as C
-        from . import _lib, _bucket, _f32c, _make_settings, _ptr, _stream_ptr
+        from . import _lib, _sized, _f32c, _make_settings, _ptr, _stream_ptr
         lib = _lib.load()
         m, sh, op, sc, rot, radii, geom, binning, img, dc = ctx.saved_tensors
         device = m.device
@@ -330,7 +330,7 @@ class _TwoAxisHip(torch.autograd.Function):
             s = _make_settings(ctx.raster_settings, keep, ctx.band)
             if ctx.has_dc:
                 s.sh_dc, s.dL_dsh_dc = dc.data_ptr(), d_dc.data_ptr()
-            scratch = torch.empty(_bucket(lib.gsr_backward_scratch_bytes(P_all, ctx.num_rendered)), dtype=torch.uint8, device=device)
+            scratch = torch.empty(_sized("bwd", device, lib.gsr_backward_scratch_bytes(P_all, ctx.num_rendered)), dtype=torch.uint8, device=device)
             rec_ptr = C.c_void_p(0)
             gc = _f32c(g_color)
             gd = _f32c(g_depth) if g_depth is not None else None
