@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--cpu-tiles", type=int, default=1200, help="tiles blended by the CPU baseline sample")
     ap.add_argument("--uniform-bands", action="store_true")
     ap.add_argument("--compare-torch-adam", action="store_true", help="also time the train step with torch.optim.Adam")
+    ap.add_argument("--min-warm-seconds", type=float, default=1.5, help="the untimed warm-up lasts at least this long (wall clock)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the forward frames alternate on (N = 1 GPU): 1 = strictly "
                                                           "one frame after the other (default), 2 = double-buffered frames -- "
                                                           "measured 2.5x SLOWER on MI355X / ROCm 7.2 (1.29 vs 0.52 ms per frame), kept for A/B only")
@@ -155,19 +156,45 @@ def main():
             torch.cuda.synchronize()
 
     # ---- timed forward ----
-    def timed_forward(step):
-        for _ in range(a.warmup):
-            step()
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            step()
-        sync_all()
-        dt = time.perf_counter() - t0
+    # One-off stalls: on a fresh box a single ~75 ms pause of the whole GPU shows up once, a few hundred ms into the first
+    # sustained activity of the process (seen at a fixed wall-clock offset, in whichever loop happened to be running; not
+    # tied to any kernel or allocation of this code).  Two guards keep it out of the numbers without hiding anything:
+    # the untimed warm-up runs for at least --min-warm-seconds of wall clock, and a timed loop whose host-side step stamps
+    # (the host is paced by the per-frame R read-back) show a gap of more than STALL_MS is timed again, once; the JSON
+    # line reports how often that happened ("retimed").
+    STALL_MS = 20.0
+    retimed = {}
+
+    def timed_loop(step, n, name):
+        for attempt in range(2):
+            sync_all()
+            t0 = time.perf_counter()
+            stamps = [t0]
+            for _ in range(n):
+                step()
+                stamps.append(time.perf_counter())
+            sync_all()
+            dt = time.perf_counter() - t0
+            gaps = [b - a for a, b in zip(stamps[:-1], stamps[1:])]
+            gmax = max(gaps) * 1e3 if gaps else 0.0
+            flag = torch.tensor([1.0 if gmax > STALL_MS else 0.0], device=dev)
+            if world > 1:
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)       # all ranks take the same decision
+            if float(flag.item()) == 0.0 or attempt == 1:
+                break
+            retimed[name] = retimed.get(name, 0) + 1
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        return float(tmax.item())
+        return float(tmax.item()), gmax, int(max(range(len(gaps)), key=gaps.__getitem__)) if gaps else 0
+
+    def timed_forward(step):
+        t_w = time.perf_counter()
+        for _ in range(a.warmup):
+            step()
+        while time.perf_counter() - t_w < a.min_warm_seconds:      # extended untimed warm-up (see above)
+            step()
+        return timed_loop(step, a.steps, "forward")[0]
 
     dt = timed_forward(forward_step)                 # one frame after the other on one stream
     latency_ms = dt / a.steps * 1e3
@@ -247,18 +274,10 @@ def main():
 
             for _ in range(max(2, a.warmup // 2)):
                 train_step()
-            sync_all()
-            t0 = time.perf_counter()
-            stamps = [t0]
-            for _ in range(tsteps):
-                train_step()
-                stamps.append(time.perf_counter())      # host paced by the per-frame R read-back: gaps show one-off stalls
-            sync_all()
-            tdt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-            train_gap[leg] = max(b - a for a, b in zip(stamps[:-1], stamps[1:])) * 1e3
-            if world > 1:
-                dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-            train[leg] = float(tdt.item()) / tsteps * 1e3
+            tdt_s, gmax, gat = timed_loop(train_step, tsteps, "train_" + leg)
+            train_gap[leg] = gmax
+            train_gap[leg + "_at_step"] = gat
+            train[leg] = tdt_s / tsteps * 1e3
             if leg == "l1":
                 _lib.profile_reset()
                 _lib.profile_enable(True)
@@ -366,6 +385,7 @@ def main():
                               "frac_of_8TBs": round(whole / HBM_PEAK_GBS, 5),
                               "roofline_predicted_Mpix_s": round(npix / (ab["total"] / (HBM_PEAK_GBS * 1e9)) / 1e6, 1)},
             "train_max_step_gap_ms": {k: round(v, 3) for k, v in train_gap.items()},
+            "retimed": retimed,
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": roof,
             "cpu_baseline": cpu_baseline,
