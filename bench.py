@@ -192,8 +192,14 @@ def main():
         t_w = time.perf_counter()
         for _ in range(a.warmup):
             step()
-        while time.perf_counter() - t_w < a.min_warm_seconds:      # extended untimed warm-up (see above)
-            step()
+        while True:                                                # extended untimed warm-up (see above)
+            more = torch.tensor([1.0 if time.perf_counter() - t_w < a.min_warm_seconds else 0.0], device=dev)
+            if world > 1:
+                dist.all_reduce(more, op=dist.ReduceOp.MAX)            # every rank must issue the same number of collectives
+            if float(more.item()) == 0.0:
+                break
+            for _ in range(10):
+                step()
         return timed_loop(step, a.steps, "forward")[0]
 
     dt = timed_forward(forward_step)                 # one frame after the other on one stream

@@ -209,8 +209,8 @@ def test_bench_two_rank_path_on_one_gpu():
     env = dict(os.environ, GSR_BENCH_SHARED_GPU="1", GSR_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--P", "60000", "--width", "640", "--height", "368", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+           "--P", "60000", "--width", "640", "--height", "368", "--no-cpu-baseline", "--min-warm-seconds", "0.2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
