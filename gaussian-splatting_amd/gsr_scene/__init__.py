@@ -19,6 +19,7 @@ import torch
 from plyfile import PlyData, PlyElement
 
 __all__ = ["gaussian_attribute_names", "save_gaussians_ply", "load_gaussians_ply", "store_points_ply", "fetch_points_ply"]
+# adaptive density control (clone / split / prune as one repack): gsr_scene.densify
 
 
 def gaussian_attribute_names(n_rest: int, n_scale: int = 3, n_rot: int = 4):

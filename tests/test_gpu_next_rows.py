@@ -396,3 +396,61 @@ def test_two_axis_pieces_two_shards_two_bands_on_one_gpu():
         d_m2, _, d_op, d_m3, _, d_sh, d_sc, d_rot = outs
         for got, want in zip([d_m3, d_sh, d_op, d_sc, d_rot, d_m2], ref):
             assert (got.view(-1) - want[a:b].reshape(-1)).abs().max().item() <= 5e-5 * want.abs().max().item()
+
+
+def test_training_loop_with_density_control():
+    """train.py:111-186 in miniature on the drop-in pieces: render (split-SH form), reference loss, backward, density
+    statistics from the operator's means2D gradient and radii, FusedAdam step, clone / split / prune every 50 iterations
+    (gsr_scene.densify), opacity reset once.  The set must grow, the optimizer state must follow it, the loss must fall."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from fused_ssim import fused_ssim
+    from gsr_optim import FusedAdam
+    from gsr_scene.densify import DensifyStats, densify_and_prune, reset_opacity
+    dev = torch.device("cuda:0")
+    cam = make_camera(160, 128)
+    target = make_scene(3000, cam, seed=21, s_med=0.06).to(dev)
+    s = oracle_settings(cam)
+    rast = GaussianRasterizer(gpu_settings(s, dev))
+    kw0 = dict(colors_precomp=None, cov3D_precomp=None)
+    with torch.no_grad():
+        gt = rast(means3D=target.means3D, means2D=None, dc=target.shs[:, :1].contiguous(), shs=target.shs[:, 1:].contiguous(),
+                  opacities=target.opacities, scales=target.scales, rotations=target.rotations, **kw0)[0]
+    # start from a sparse, blurry subset: every 4th Gaussian, twice as large, so that density control has work to do
+    sub = slice(0, None, 4)
+    P0 = target.means3D[sub].shape[0]
+    mk = lambda t: nn_param(t)  # noqa: E731
+    import torch.nn as nn
+
+    def nn_param(t):
+        return nn.Parameter(t.detach().clone().contiguous().requires_grad_(True))
+    params = {"xyz": mk(target.means3D[sub]), "f_dc": mk(target.shs[sub, :1]), "f_rest": mk(target.shs[sub, 1:] * 0.0),
+              "opacity": mk(torch.logit(target.opacities[sub].clamp(0.05, 0.95))), "scaling": mk(torch.log(target.scales[sub] * 2.0)),
+              "rotation": mk(target.rotations[sub])}
+    lrs = {"xyz": 1.6e-3, "f_dc": 2.5e-3, "f_rest": 2.5e-3 / 20, "opacity": 0.025, "scaling": 5e-3, "rotation": 1e-3}
+    opt = FusedAdam([{"params": [params[k]], "lr": lrs[k], "name": k} for k in params], lr=0.0, eps=1e-15)
+    stats = DensifyStats.zeros(P0, dev)
+    losses, sizes = [], []
+    for it in range(1, 201):
+        m2 = torch.zeros(params["xyz"].shape[0], 3, device=dev, requires_grad=True)
+        img, radii, _ = rast(means3D=params["xyz"], means2D=m2, dc=params["f_dc"], shs=params["f_rest"],
+                             opacities=torch.sigmoid(params["opacity"]), scales=torch.exp(params["scaling"]),
+                             rotations=torch.nn.functional.normalize(params["rotation"]), **kw0)
+        loss = 0.8 * (img - gt).abs().mean() + 0.2 * (1.0 - fused_ssim(img.unsqueeze(0), gt.unsqueeze(0)))
+        loss.backward()
+        with torch.no_grad():
+            stats.add(m2.grad, radii > 0, radii)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        losses.append(float(loss.detach()))
+        if it % 50 == 0 and it < 200:
+            params, stats, _ = densify_and_prune(opt, stats, max_grad=0.0002, min_opacity=0.005, extent=6.0,
+                                                 max_screen_size=20 if it > 100 else None, radii=radii)
+            if it == 100:
+                params["opacity"] = reset_opacity(opt, 0.05)
+            sizes.append(params["xyz"].shape[0])
+            for k, p in params.items():
+                st = opt.state[p]
+                assert st["exp_avg"].shape == p.shape and st["exp_avg_sq"].shape == p.shape and p.is_contiguous(), k
+    assert all(v == v for v in losses)
+    assert max(sizes) > P0, (P0, sizes)                              # density control added Gaussians
+    assert min(losses[-10:]) < 0.8 * losses[0], (losses[0], losses[-10:])
