@@ -146,31 +146,39 @@ struct PixAcc {
     uint32_t last;
 };
 
-__device__ __forceinline__ void blend_step_bf(PixAcc& s, bool& done, float pxf, float pyf, float gx_, float gy_, float a2,
+// One (pixel, Gaussian) step of the wave kernels, branch-free.  Instead of a separate "done" flag the lane carries TWO
+// transmittances: s.T, the value the outputs need (frozen at termination, composites the background), and Tl, the LIVE
+// one that the recurrence uses and that is set to 0 when the pixel terminates (or lies outside the image).  With Tl = 0
+// every later entry sees test = 0 < 1e-4, is classified as the terminator again and contributes nothing -- so the
+// three conditions need no "not done yet" term, and termination costs one select instead of a flag update and a test.
+// Arithmetic on the contributing path is unchanged (w = alpha * T, T' = T - alpha * T): results are bit-identical.
+// TRACK: the contributor index is only needed by the backward (n_contrib); inference builds drop it.
+template <bool TRACK>
+__device__ __forceinline__ void blend_step_bf(PixAcc& s, float& Tl, float pxf, float pyf, float gx_, float gy_, float a2,
                                               float b2, float c2, float op, float r, float g, float b, float invd,
                                               uint32_t pos) {
     const float dx = gx_ - pxf, dy = gy_ - pyf;
     const float t = fmaf(b2, dy, a2 * dx);
     const float p2 = fmaf(dx, t, (c2 * dy) * dy);           // log2(e) * power
     const float alpha = fminf(GSR_ALPHA_MAX, op * __builtin_amdgcn_exp2f(p2));
-    const bool valid = (!done) & (p2 <= 0.0f) & (alpha >= GSR_ALPHA_MIN);
-    const float testT = fmaf(-alpha, s.T, s.T);              // T (1 - alpha)
+    const bool valid = (p2 <= 0.0f) & (alpha >= GSR_ALPHA_MIN);
+    const float testT = fmaf(-alpha, Tl, Tl);                // T (1 - alpha)
     const bool term = valid & (testT < GSR_T_EPS);
     const bool contrib = valid & (!term);
-    const float w = contrib ? alpha * s.T : 0.0f;
+    const float w = contrib ? alpha * Tl : 0.0f;
     s.C0 = fmaf(r, w, s.C0);
     s.C1 = fmaf(g, w, s.C1);
     s.C2 = fmaf(b, w, s.C2);
     s.D = fmaf(invd, w, s.D);
     s.T = contrib ? testT : s.T;
-    s.last = contrib ? pos : s.last;
-    done = done | term;
+    Tl = term ? 0.0f : s.T;
+    if (TRACK) s.last = contrib ? pos : s.last;
 }
 
 // WPB = waves per workgroup: 1 -> one 64-thread workgroup per 8x8 block (workgroup ids arranged so that the four blocks
 // of a tile land on one XCD); 4 -> one 256-thread workgroup per tile whose four waves run independently (no barriers),
 // which lifts the resident-wave count when the per-CU workgroup limit, not registers/LDS, caps occupancy.
-template <bool USE_LDS, int WPB>
+template <bool USE_LDS, int WPB, bool TRACK>
 __global__ void __launch_bounds__(64 * WPB)
 render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ranges,
                    const uint32_t* __restrict__ point_list, const float4* __restrict__ splats,
@@ -203,7 +211,7 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
     const float y0 = (float)by0, y1 = (float)min(by0 + 7, cam.H - 1);
     const uint2 range = ranges[tile];
     PixAcc s = {1.0f, 0.f, 0.f, 0.f, 0.f, 0u};
-    bool done = !inside;
+    float Tl = inside ? 1.0f : 0.0f;          // live transmittance (0 = this lane takes no further entries)
     constexpr float LOG2E = 1.4426950408889634f;
 
     // Software pipeline over the batches of 64 list entries: every batch needs two dependent global loads (list id ->
@@ -247,20 +255,20 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
                 const float4 r0 = s_rec[j * 3 + 0];
                 const float4 r1 = s_rec[j * 3 + 1];
                 const float2 r2 = *reinterpret_cast<const float2*>(&s_rec[j * 3 + 2]);
-                blend_step_bf(s, done, pxf, pyf, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, pos_base + j);
+                blend_step_bf<TRACK>(s, Tl, pxf, pyf, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, pos_base + j);
             } else {
                 const float gx_ = bcast(q0.x, j), gy_ = bcast(q0.y, j), a2 = bcast(q0.z, j), b2 = bcast(q0.w, j);
                 const float c2 = bcast(q1.x, j), op = bcast(q1.y, j), cr = bcast(q1.z, j), cg = bcast(q1.w, j);
                 const float cb = bcast(colb, j), id_ = bcast(invd, j);
-                blend_step_bf(s, done, pxf, pyf, gx_, gy_, a2, b2, c2, op, cr, cg, cb, id_, pos_base + j);
+                blend_step_bf<TRACK>(s, Tl, pxf, pyf, gx_, gy_, a2, b2, c2, op, cr, cg, cb, id_, pos_base + j);
             }
         }
-        if (__ballot(!done) == 0ull) break;
+        if (__ballot(Tl != 0.0f) == 0ull) break;
     }
     if (inside) {
         const int64_t pix = (int64_t)py * cam.W + px;
         const int64_t HW = (int64_t)cam.H * cam.W;
-        if (final_T) {      // NULL in inference mode: only the backward reads these
+        if (TRACK) {        // inference builds (final_T == NULL) do not track: only the backward reads these
             final_T[pix] = s.T;
             n_contrib[pix] = s.last;
         }
@@ -283,14 +291,22 @@ void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const 
                            final_T, n_contrib, out_color, out_invdepth);
     } else {
         const int groups = (n_band_tiles + 7) / 8;
+        const bool track = final_T != nullptr && n_contrib != nullptr;
+#define GSR_LAUNCH_BF(USE_LDS_, WPB_, GRID_, BLOCK_)                                                                              \
+    do {                                                                                                                          \
+        if (track)                                                                                                                \
+            hipLaunchKernelGGL((render_fwd_wave_bf<USE_LDS_, WPB_, true>), dim3(GRID_), dim3(BLOCK_), 0, st, cam, n_band_tiles,    \
+                               ranges, point_list, splats, final_T, n_contrib, out_color, out_invdepth);                         \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((render_fwd_wave_bf<USE_LDS_, WPB_, false>), dim3(GRID_), dim3(BLOCK_), 0, st, cam, n_band_tiles,   \
+                               ranges, point_list, splats, final_T, n_contrib, out_color, out_invdepth);                         \
+    } while (0)
         if (variant == 2)
-            hipLaunchKernelGGL((render_fwd_wave_bf<false, 1>), dim3(groups * 32), dim3(64), 0, st, cam, n_band_tiles, ranges,
-                               point_list, splats, final_T, n_contrib, out_color, out_invdepth);
+            GSR_LAUNCH_BF(false, 1, groups * 32, 64);
         else if (variant == 3)
-            hipLaunchKernelGGL((render_fwd_wave_bf<true, 4>), dim3(n_band_tiles), dim3(256), 0, st, cam, n_band_tiles, ranges,
-                               point_list, splats, final_T, n_contrib, out_color, out_invdepth);
+            GSR_LAUNCH_BF(true, 4, n_band_tiles, 256);
         else
-            hipLaunchKernelGGL((render_fwd_wave_bf<true, 1>), dim3(groups * 32), dim3(64), 0, st, cam, n_band_tiles, ranges,
-                               point_list, splats, final_T, n_contrib, out_color, out_invdepth);
+            GSR_LAUNCH_BF(true, 1, groups * 32, 64);
+#undef GSR_LAUNCH_BF
     }
 }
