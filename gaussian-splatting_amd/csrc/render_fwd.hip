@@ -171,7 +171,7 @@ __device__ __forceinline__ void blend_step_bf(PixAcc& s, float& Tl, float pxf, f
     s.C2 = fmaf(b, w, s.C2);
     s.D = fmaf(invd, w, s.D);
     s.T = contrib ? testT : s.T;
-    Tl = term ? 0.0f : s.T;
+    Tl = contrib ? testT : (term ? 0.0f : Tl);               // an invalid entry must leave a terminated lane at 0
     if (TRACK) s.last = contrib ? pos : s.last;
 }
 
