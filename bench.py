@@ -347,7 +347,7 @@ def main():
             pmc_traffic, pmc_note = None, None
             try:
                 pk = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"]
-                kn = {0: "render_fwd_wave_bf<true, 1>", 1: "render_fwd_block", 2: "render_fwd_wave_bf<false, 1>"}.get(a.variant)
+                kn = {0: "render_fwd_wave_bf<true, 1, false>", 1: "render_fwd_block", 2: "render_fwd_wave_bf<false, 1, false>"}.get(a.variant)
                 if world == 1 and kn in pk and (P, W, H) == (1_000_000, 1920, 1080):
                     pmc_traffic = int(pk[kn]["hbm_bytes_corrected"])
                     pmc_note = "profiles/pmc_latest.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"

@@ -64,6 +64,6 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_per_kernel.csv"), "w") as f
     for k in sorted(kern, key=lambda k: -kern[k]["hbm_bytes_corrected"]):
         f.write(f"\"{k}\",{kern[k]['FETCH_SIZE_KB_per_launch']},{kern[k]['WRITE_SIZE_KB_per_launch']},{kern[k]['hbm_bytes_corrected']}\n")
 print("bench:", json.loads(line)["value"], "Mpix/s;", len(rows), "kernels in stats;", len(kern), "kernels with PMC")
-for k in ("render_fwd_wave_bf<true, 1>", "render_bwd_tile<256, 0>", "preprocess_fwd_kernel<false>", "adam_kernel"):
+for k in ("render_fwd_wave_bf<true, 1, false>", "render_fwd_wave_bf<true, 1, true>", "render_bwd_tile<256, 0>", "preprocess_fwd_kernel<false>", "adam_kernel"):
     if k in kern:
         print(" ", k, kern[k]["hbm_bytes_corrected"] / 1e6, "MB/launch")
