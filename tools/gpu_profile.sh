@@ -6,11 +6,11 @@ export TMPDIR=/tmp
 R="$PWD"
 ( time timeout 900 python bench.py ) > gpurun_out/p_bench_default.log 2>&1
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_stats" -o r1 -- python "$R/bench.py" --steps 30 --warmup 5 --no-cpu-baseline --train-steps 15 > "$R/gpurun_out/p_prof_stats.log" 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$R/gpurun_out/prof_fetch" -o r1 -- python "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --train-steps 5 > "$R/gpurun_out/p_prof_fetch.log" 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$R/gpurun_out/prof_write" -o r1 -- python "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --train-steps 5 > "$R/gpurun_out/p_prof_write.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_stats" -o r1 -- python "$R/bench.py" --steps 30 --warmup 5 --no-cpu-baseline --train-steps 15 --min-warm-seconds 0.2 > "$R/gpurun_out/p_prof_stats.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$R/gpurun_out/prof_fetch" -o r1 -- python "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --train-steps 5 --min-warm-seconds 0.2 > "$R/gpurun_out/p_prof_fetch.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$R/gpurun_out/prof_write" -o r1 -- python "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --train-steps 5 --min-warm-seconds 0.2 > "$R/gpurun_out/p_prof_write.log" 2>&1
 cd "$R"
 tail -4 gpurun_out/p_bench_default.log
 ls gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write
 # keep the merged-back volume small: drop the per-dispatch traces of the PMC runs except the counter csv
-find gpurun_out/prof_fetch gpurun_out/prof_write -name "*kernel_trace*" -delete
+find gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write -name "*kernel_trace*" -delete
