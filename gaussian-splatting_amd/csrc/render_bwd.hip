@@ -538,6 +538,9 @@ void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const
     } else if (variant == 2) {
         hipLaunchKernelGGL(render_bwd_tile<128>, dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats,
                            final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads), inst_flag);
+    } else if (variant == 3) {      // 192-entry super-batches: 20 KB of LDS -> 8 workgroups per CU
+        hipLaunchKernelGGL(render_bwd_tile<192>, dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats,
+                           final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads), inst_flag);
     } else {
         hipLaunchKernelGGL(render_bwd_tile<256>, dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats,
                            final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads), inst_flag);
