@@ -16,8 +16,11 @@
 //                        (contributor numbering is by list position).
 //  variant 1  "block"    : one 256-thread workgroup per 16x16 tile, list staged through LDS 256 entries at a time,
 //                        every lane evaluates every entry, workgroup-wide "all done" vote.  The classic structure;
-//                        A/B baseline (measured 0.408 ms vs 0.161 ms for variant 0 on the 1 M / 1080p frame).
+//                        A/B baseline (measured 0.408 ms vs 0.151 ms for variant 0 on the 1 M / 1080p frame).
 //  variant 2  "wave/readlane": as variant 0 but the record is broadcast with v_readlane into SGPRs (0.291 ms).
+//  variant 3  as variant 0 in 256-thread workgroups of four independent waves (0.165-0.173 ms).
+// The wave kernels are additionally templated on TRACK: the contributor index and final transmittance are produced
+// only when the caller will run the backward (inference launches drop two VALU instructions per entry).
 //
 // Numerics: fp32, FMA contraction allowed, exp through v_exp_f32 (__expf).  Image parity with the oracle is
 // <= 1e-5 except at pixels where a hard threshold (alpha<1/255, T<1e-4, power>0) is within rounding noise
