@@ -62,6 +62,7 @@ def parse():
                                                           "measured 2.5x SLOWER on MI355X / ROCm 7.2 (1.29 vs 0.52 ms per frame), kept for A/B only")
     ap.add_argument("--sort-items", type=int, default=0, help="keys per workgroup of the large radix passes (1024 / 2048 / 4096; 0 = library default)")
     ap.add_argument("--bwd-variant", type=int, default=0, help="render_bwd_variant (0 default, 1 atomics baseline, 2 128-entry super-batches)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="gsr_set_option(NAME, VALUE) before timing (A/B switches)")
     return ap.parse_args()
 
 
@@ -113,6 +114,9 @@ def main():
     _lib.set_option("render_bwd_variant", a.bwd_variant)
     if a.sort_items:
         _lib.set_option("sort_items_large", a.sort_items)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        _lib.set_option(k, int(v))
     W, H, P = a.width, a.height, a.P
     cam = make_camera(W, H)
     scene_cpu = make_scene(P, cam, seed=a.seed, s_med=a.s_med)

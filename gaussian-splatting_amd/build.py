@@ -30,6 +30,7 @@ UNITS = [
     ("preprocess.hip", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]),
     ("sort.hip", []),
     ("binning.hip", []),
+    ("tilesort.hip", []),
     ("render_fwd.hip", ["-ffp-contract=fast"]),
     ("render_bwd.hip", ["-ffp-contract=fast"]),
     ("adam.hip", ["-ffp-contract=off"]),

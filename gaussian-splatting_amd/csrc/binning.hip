@@ -2,6 +2,7 @@
 // (K3 duplicateWithKeys) and per-tile ranges (K5 identifyTileRanges) of the reference rasterizer,
 // redesigned for wave64 (algorithm: SURVEY.md Appendix A.3).
 #include "gsr_internal.h"
+#include "gsr_wave.h"
 
 namespace {
 
@@ -17,67 +18,97 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
     return v;
 }
 
-// pass 1: per-workgroup totals of tiles[order[j]]; the gathered counts are also written out in depth order
-// (tiles_sorted), so that pass 2 streams them instead of repeating the 4-byte random gather
+__device__ __forceinline__ uint32_t rect_tiles(const uint2 r) {
+    return ((r.x >> 16) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.y & 0xFFFFu));      // <= 2^24 (make_cam limits the grid)
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, off, 64);
+        const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), off, 64);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+
+// pass 1: per-workgroup totals of the tile counts in depth order.  The count of a Gaussian is the area of its
+// (band-clamped) tile rectangle; the gathered rectangles are written out in depth order (rect_sorted), so that pass 2
+// and the emission stream them instead of repeating the 8-byte random gather.  Sums are 64-bit: a total beyond
+// 2^31 - 1 must be DETECTED on the host, not wrapped.
 __global__ void __launch_bounds__(SC_THREADS)
-scan_block_sums(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles,
-                uint32_t* __restrict__ tiles_sorted, uint32_t* __restrict__ block_sums) {
-    __shared__ uint32_t wsum[SC_THREADS / 64];
+scan_block_sums(int P, const uint32_t* __restrict__ order, const uint2* __restrict__ rect,
+                uint2* __restrict__ rect_sorted, uint64_t* __restrict__ block_sums) {
+    __shared__ uint64_t wsum[SC_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * GSR_SCAN_ITEMS + tid * SC_IPT;
-    uint32_t s = 0;
+    uint64_t s = 0;
 #pragma unroll
     for (int k = 0; k < SC_IPT; ++k)
         if (base + k < P) {
-            const uint32_t t = tiles[order[base + k]];
-            tiles_sorted[base + k] = t;
-            s += t;
+            const uint2 r = rect[order[base + k]];
+            rect_sorted[base + k] = r;
+            s += rect_tiles(r);
         }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    s = wave_sum_u64(s);
     if (lane == 0) wsum[w] = s;
     __syncthreads();
     if (tid == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 // pass 2: every workgroup sums the totals of the workgroups before it (a few KB from L2), then scans its
-// own 1024 items.  offsets[j] = inclusive prefix in depth order; the last workgroup publishes R.
+// own 1024 items.  offsets[j] = inclusive prefix in depth order (low 32 bits); the last workgroup publishes R (64-bit).
+// Also fills the per-block table of the fused emission (tilesort.hip): block_first[k] = depth-order index of the
+// Gaussian that owns instance k * GSR_TS_ITEMS, and, one past the last block, the last Gaussian with tiles.
 __global__ void __launch_bounds__(SC_THREADS)
-scan_finish(int P, const uint32_t* __restrict__ tiles_sorted,
-            const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ offsets, uint32_t* __restrict__ num_rendered,
-            uint32_t* host_word, uint32_t seq) {
-    __shared__ uint32_t wsum[SC_THREADS / 64];
-    __shared__ uint32_t wtot[SC_THREADS / 64];
+scan_finish(int P, const uint2* __restrict__ rect_sorted, const uint64_t* __restrict__ block_sums,
+            uint32_t* __restrict__ offsets, uint32_t* __restrict__ block_first, uint32_t block_first_cap,
+            uint32_t* __restrict__ num_rendered, uint32_t* host_word, uint32_t seq) {
+    __shared__ uint64_t wsum[SC_THREADS / 64];
+    __shared__ uint64_t wtot[SC_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    uint32_t pre = 0;
+    uint64_t pre = 0;
     for (int b = tid; b < (int)blockIdx.x; b += SC_THREADS) pre += block_sums[b];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off, 64);
+    pre = wave_sum_u64(pre);
     if (lane == 0) wsum[w] = pre;
     const int64_t base = (int64_t)blockIdx.x * GSR_SCAN_ITEMS + tid * SC_IPT;
-    uint32_t v[SC_IPT];
-    uint32_t s = 0;
+    uint32_t v[SC_IPT + 1];
+    uint64_t s = 0;
 #pragma unroll
-    for (int k = 0; k < SC_IPT; ++k) {
-        v[k] = (base + k < P) ? tiles_sorted[base + k] : 0u;
-        s += v[k];
+    for (int k = 0; k <= SC_IPT; ++k) {
+        v[k] = (base + k < P) ? rect_tiles(rect_sorted[base + k]) : 0u;     // v[SC_IPT]: the next thread's first count
+        if (k < SC_IPT) s += v[k];
     }
-    const uint32_t incl = wave_incl_scan(s, lane);
+    const uint64_t incl = gsrw::wave_incl_scan_u64(s, lane);
     if (lane == 63) wtot[w] = incl;
     __syncthreads();
-    uint32_t run = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    uint64_t run = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 #pragma unroll
     for (int k = 0; k < SC_THREADS / 64; ++k)
         if (k < w) run += wtot[k];
     run += incl - s;
+    constexpr uint64_t IT = GSR_TS_ITEMS;
 #pragma unroll
     for (int k = 0; k < SC_IPT; ++k) {
+        const uint64_t excl = run;
         run += v[k];
-        if (base + k < P) offsets[base + k] = run;
+        if (base + k < P) {
+            offsets[base + k] = (uint32_t)run;
+            if (v[k] && run <= 0x7FFFFFFFull) {
+                for (uint64_t b = (excl + IT - 1) / IT; b <= (run - 1) / IT; ++b)
+                    if (b < block_first_cap) block_first[b] = (uint32_t)(base + k);
+                if (v[k + 1] == 0u) {     // counts are non-zero exactly on a prefix of the depth order: this is the last one
+                    const uint64_t b = (run + IT - 1) / IT;
+                    if (b < block_first_cap) block_first[b] = (uint32_t)(base + k);
+                }
+            }
+        }
         if (base + k == (int64_t)P - 1) {
-            num_rendered[0] = run;
+            num_rendered[0] = (uint32_t)run;
+            num_rendered[1] = (uint32_t)(run >> 32);
             if (host_word) {   // publish R to the spinning host: value first, then the sequence number (system-scope release)
-                __hip_atomic_store(&host_word[0], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&host_word[0], (uint32_t)run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&host_word[2], (uint32_t)(run >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(&host_word[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
@@ -96,7 +127,7 @@ constexpr int EMIT_WAVES = 4;        // waves per 64-Gaussian group (1: 48 us, 4
 template <typename KeyT>
 __global__ void __launch_bounds__(EMIT_WAVES * 64)
 emit_instances(int P, int gx, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
-               const uint2* __restrict__ rect, KeyT* __restrict__ inst_keys, uint32_t* __restrict__ inst_vals,
+               const uint2* __restrict__ rect_sorted, KeyT* __restrict__ inst_keys, uint32_t* __restrict__ inst_vals,
                float4* __restrict__ splats) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t j0 = (int64_t)blockIdx.x * 64;
@@ -111,7 +142,7 @@ emit_instances(int P, int gx, const uint32_t* __restrict__ order, const uint32_t
     if (j < P) {
         id = order[j];
         incl = offsets[j] - base;
-        const uint2 r = rect[id];
+        const uint2 r = rect_sorted[j];
         minx = r.x & 0xFFFFu;
         w = (r.x >> 16) - minx;
         miny = r.y & 0xFFFFu;
@@ -228,12 +259,13 @@ void gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4
                        rect, tiles, keys, vals);
 }
 
-void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles, uint32_t* tiles_sorted, uint32_t* offsets,
-                           uint32_t* block_sums, uint32_t* num_rendered, uint32_t* host_word, uint32_t seq, hipStream_t st) {
+void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint2* rect, uint2* rect_sorted, uint32_t* offsets,
+                           uint64_t* block_sums, uint32_t* block_first, uint32_t block_first_cap, uint32_t* num_rendered,
+                           uint32_t* host_word, uint32_t seq, hipStream_t st) {
     const int nb = (P + GSR_SCAN_ITEMS - 1) / GSR_SCAN_ITEMS;
-    hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(SC_THREADS), 0, st, P, order, tiles, tiles_sorted, block_sums);
-    hipLaunchKernelGGL(scan_finish, dim3(nb), dim3(SC_THREADS), 0, st, P, tiles_sorted, block_sums, offsets, num_rendered,
-                       host_word, seq);
+    hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(SC_THREADS), 0, st, P, order, rect, rect_sorted, block_sums);
+    hipLaunchKernelGGL(scan_finish, dim3(nb), dim3(SC_THREADS), 0, st, P, rect_sorted, block_sums, offsets, block_first,
+                       block_first_cap, num_rendered, host_word, seq);
 }
 
 void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect,

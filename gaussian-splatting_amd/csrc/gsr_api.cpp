@@ -31,7 +31,7 @@ int fail(int code, const std::string& msg) {
 // ---- options / profiling ----
 int g_render_fwd_variant = 0;
 int g_render_bwd_variant = 0;
-int g_depth_digit_bits = GSR_DEPTH_DIGIT_BITS;
+int g_tile_sort_mode = 0;       // 0 = fused emission + two-level sort (tilesort.hip), 1 = legacy emit + LSD passes (A/B)
 
 struct PendingEvent { int stage; hipEvent_t a, b; };
 std::mutex g_prof_mu;
@@ -82,6 +82,8 @@ int make_cam(const GsrRasterSettings* s, int M, GsrCamDev& c) {
     c.gx = (c.W + GSR_TILE - 1) / GSR_TILE;
     c.gy = (c.H + GSR_TILE - 1) / GSR_TILE;
     if (c.gx > 65535 || c.gy > 65535) return fail(GSR_ERR_UNSUPPORTED, "more than 65535 tiles per axis");
+    // a Gaussian's tile count (rectangle area) and the tile ids must stay well inside 32 bits
+    if ((int64_t)c.gx * c.gy > (1ll << 24)) return fail(GSR_ERR_UNSUPPORTED, "more than 2^24 tiles");
     // fp32 host arithmetic, same expression as oracle/torch_oracle.py:preprocess
     c.focal_x = (float)c.W / (2.0f * s->tanfovx);
     c.focal_y = (float)c.H / (2.0f * s->tanfovy);
@@ -135,10 +137,21 @@ int check_split_sh(const GsrRasterSettings* s, int P, int M, const float* shs, b
     return GSR_OK;
 }
 
-thread_local uint32_t* g_host_word = nullptr;       // mapped pinned host memory: [0] = R, [1] = sequence number
-thread_local uint32_t* g_host_word_dev = nullptr;   // its device-side address
-thread_local uint32_t g_host_seq = 0;
-std::atomic<int64_t> g_last_R{0};
+// R read-back word: mapped + portable + coherent pinned host memory, one per (thread, device): [0] = R low word,
+// [1] = sequence number, [2] = R high word.  64 bytes each, intentionally not freed (calling into the HIP runtime from a
+// thread_local destructor at process exit is not safe); the runtime releases them with the context.
+constexpr int GSR_MAX_DEVICES = 64;
+struct HostWord { uint32_t* host = nullptr; uint32_t* dev = nullptr; uint32_t seq = 0; };
+thread_local HostWord g_host_word[GSR_MAX_DEVICES];
+std::atomic<int64_t> g_last_R[GSR_MAX_DEVICES];      // per device: sizes the speculative binning buffer of the next frame
+
+#if defined(__x86_64__) || defined(__i386__)
+#define GSR_CPU_RELAX() __builtin_ia32_pause()
+#elif defined(__aarch64__)
+#define GSR_CPU_RELAX() asm volatile("yield" ::: "memory")
+#else
+#define GSR_CPU_RELAX() do { } while (0)
+#endif
 
 int64_t g_small_block_threshold = (int64_t)2 * 1024 * 1024;   // below this a radix pass uses 1024-item workgroups
 int g_sort_items_large = GSR_SORT_ITEMS;                      // keys per workgroup above the threshold (1024 / 2048 / 4096)
@@ -161,13 +174,12 @@ GsrGeom gsr_carve_geom(char* base, int P) {
     g.keys[1] = (uint32_t*)take(n * 4);
     g.vals[0] = (uint32_t*)take(n * 4);
     g.vals[1] = (uint32_t*)take(n * 4);
+    g.rect_sorted = (uint2*)take(n * 8);
     g.offsets = (uint32_t*)take(n * 4);
-    g.block_sums = (uint32_t*)take(((n + GSR_SCAN_ITEMS - 1) / GSR_SCAN_ITEMS) * 4);
-    {   // worst case over the two layouts the depth sort may use: 256 bins x small workgroups, 2048 bins x large ones
-        const size_t a = (size_t)256 * (size_t)gsr_sort_blocks((int64_t)n, true), b2 = (size_t)2048 * (size_t)gsr_sort_blocks((int64_t)n, false);
-        g.sort_hist = (uint32_t*)take((a > b2 ? a : b2) * 4);
-    }
-    g.digit_total = (uint32_t*)take(2048 * 4);
+    g.block_sums = (uint64_t*)take(((n + GSR_SCAN_ITEMS - 1) / GSR_SCAN_ITEMS) * 8);
+    g.block_first = (uint32_t*)take(gsr_block_first_cap(P) * 4);
+    g.sort_hist = (uint32_t*)take((size_t)256 * (size_t)gsr_sort_blocks((int64_t)n, true) * 4);   // small workgroups: worst case
+    g.digit_total = (uint32_t*)take(256 * 4);
     g.num_rendered = (uint32_t*)take(128);
     g.bytes = off;
     return g;
@@ -178,12 +190,21 @@ GsrBinning gsr_carve_binning(char* base, int64_t R) {
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off = gsr_align128(off + bytes); return p; };
     const size_t n = (size_t)(R > 0 ? R : 1);
-    b.keys[0] = (uint32_t*)take(n * 4);
-    b.keys[1] = (uint32_t*)take(n * 4);
+    {   // one contiguous 8n-byte region: the two key buffers of the LSD sort, or the packed words of the fused sort
+        char* wk = take(gsr_align128(n * 4) * 2);
+        b.keys[0] = (uint32_t*)wk;
+        b.keys[1] = (uint32_t*)(wk ? wk + gsr_align128(n * 4) : nullptr);
+    }
     b.vals[0] = (uint32_t*)take(n * 4);
     b.vals[1] = (uint32_t*)take(n * 4);
     b.sort_hist = (uint32_t*)take((size_t)256 * (size_t)gsr_sort_blocks((int64_t)n, true) * 4);   // worst case
+    const size_t nblk = (n + GSR_TS_ITEMS - 1) / GSR_TS_ITEMS;
+    b.hist2 = (uint32_t*)take((nblk + 256) * 256 * 4);
     b.digit_total = (uint32_t*)take(256 * 4);
+    b.bucket_base = (uint32_t*)take(257 * 4);
+    b.blk2_start = (uint32_t*)take(257 * 4);
+    b.tile_base = (uint32_t*)take(65536 * 4);
+    b.block_first = (uint32_t*)take((nblk + 2) * 4);
     b.meta = (uint32_t*)take(128);
     b.bytes = off;
     return b;
@@ -235,7 +256,11 @@ int gsr_set_option(const char* name, int value) {
         g_sort_items_large = value;
         return GSR_OK;
     }
-    if (!strcmp(name, "depth_digit_bits")) { g_depth_digit_bits = (value > 8) ? 11 : 8; return GSR_OK; }
+    if (!strcmp(name, "tile_sort_mode")) {
+        if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "tile_sort_mode must be 0 (fused) or 1 (legacy LSD)");
+        g_tile_sort_mode = value;
+        return GSR_OK;
+    }
     return fail(GSR_ERR_INVALID_ARG, std::string("unknown option ") + name);
 }
 
@@ -273,9 +298,7 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
                           float* out_color, float* out_invdepth, int32_t* num_rendered, hipStream_t st) {
     int order_buf;
     {   StageTimer t(GSR_STAGE_DEPTH_SORT, st);
-        // 11-bit digits need the large (4096-item) workgroups to keep the 2048-row histogram table small
-        order_buf = gsr_radix_sort_pairs(g.keys, g.vals, P, 32, g_depth_digit_bits, g.sort_hist, g.digit_total,
-                                         g_depth_digit_bits > 8 ? GSR_SORT_ITEMS : sort_items(P), st);
+        order_buf = gsr_radix_sort_pairs(g.keys, g.vals, P, 32, GSR_DEPTH_DIGIT_BITS, g.sort_hist, g.digit_total, sort_items(P), st);
     }
     STAGE_CHECK("depth sort");
     // R = number of (Gaussian, tile) instances sizes the binning buffer, so the host must learn it mid-pipeline (the
@@ -283,66 +306,97 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     // number straight into mapped pinned host memory (system-scope release) and the host spins on it instead of going
     // through hipMemcpyAsync + hipStreamSynchronize; (2) the image buffer and a speculative binning buffer (last R + 25 %)
     // are obtained through the callbacks WHILE the GPU is still working, so in steady state no callback sits in the bubble.
-    if (!g_host_word) {
-        HIP_OK(hipHostMalloc((void**)&g_host_word, 64, hipHostMallocMapped));
-        HIP_OK(hipHostGetDevicePointer((void**)&g_host_word_dev, g_host_word, 0));
-        g_host_word[0] = g_host_word[1] = 0;
+    int dev_id = 0;
+    HIP_OK(hipGetDevice(&dev_id));
+    if (dev_id < 0 || dev_id >= GSR_MAX_DEVICES) return fail(GSR_ERR_UNSUPPORTED, "device ordinal out of range");
+    HostWord& hw_slot = g_host_word[dev_id];
+    if (!hw_slot.host) {
+        HIP_OK(hipHostMalloc((void**)&hw_slot.host, 64, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent));
+        HIP_OK(hipHostGetDevicePointer((void**)&hw_slot.dev, hw_slot.host, 0));
+        hw_slot.host[0] = hw_slot.host[1] = hw_slot.host[2] = 0;
     }
-    const uint32_t seq = ++g_host_seq;
+    const uint32_t seq = ++hw_slot.seq;
+    const uint32_t bf_cap = (uint32_t)gsr_block_first_cap(P);
     {   StageTimer t(GSR_STAGE_SCAN, st);
-        // the depth keys are not needed after the sort: the other half of their ping-pong pair holds the tile counts in depth order
-        gsr_launch_scan_tiles(P, g.vals[order_buf], g.tiles, g.keys[order_buf ^ 1], g.offsets, g.block_sums, g.num_rendered,
-                              g_host_word_dev, seq, st);
+        gsr_launch_scan_tiles(P, g.vals[order_buf], g.rect, g.rect_sorted, g.offsets, g.block_sums, g.block_first, bf_cap,
+                              g.num_rendered, hw_slot.dev, seq, st);
     }
     const int n_tiles = cam.gx * cam.gy;
+    GsrTileSortPlan plan;
+    gsr_tile_sort_plan(n_tiles, P, &plan);
+    if (g_tile_sort_mode == 1) plan.fused = false;
     char* ibase = (char*)image_resize(image_user, gsr_image_bytes(cam.W, cam.H));
-    // the tile-range table is cleared here, in the shadow of the R read-back (the stream is otherwise idle while the
-    // host waits), instead of in front of the range kernel
-    if (ibase) HIP_OK(hipMemsetAsync(gsr_carve_image(ibase, cam.W, cam.H).ranges, 0, sizeof(uint2) * (size_t)n_tiles, st));
+    // legacy path: the tile-range table is cleared here, in the shadow of the R read-back (the stream is otherwise idle
+    // while the host waits); the fused path writes every entry of the table itself
+    if (ibase && !plan.fused)
+        HIP_OK(hipMemsetAsync(gsr_carve_image(ibase, cam.W, cam.H).ranges, 0, sizeof(uint2) * (size_t)n_tiles, st));
     char* bbase = nullptr;
     size_t spec_bytes = 0;
-    const int64_t last_R = g_last_R.load();
+    const int64_t last_R = g_last_R[dev_id].load();
     if (last_R > 0) {
         spec_bytes = gsr_binning_bytes(last_R + last_R / 4 + 4096, n_tiles);
         bbase = (char*)binning_resize(binning_user, spec_bytes);
     }
     {
-        volatile uint32_t* hw = g_host_word;
+        volatile uint32_t* hw = hw_slot.host;
         bool got = false;
         for (uint64_t spin = 0; spin < (1ull << 26); ++spin) {
             if (hw[1] == seq) { got = true; break; }
-            __builtin_ia32_pause();
+            GSR_CPU_RELAX();
         }
         if (!got) {   // kernel fault or a very slow queue: fall back to the blocking path, which also surfaces errors
             HIP_OK(hipStreamSynchronize(st));
             if (hw[1] != seq) {
-                HIP_OK(hipMemcpy((void*)g_host_word, g.num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost));
+                uint32_t r2[2] = {0, 0};
+                HIP_OK(hipMemcpy(r2, g.num_rendered, sizeof(r2), hipMemcpyDeviceToHost));
+                hw_slot.host[0] = r2[0];
+                hw_slot.host[2] = r2[1];
             }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
-    const int64_t R = (int64_t)g_host_word[0];
-    if (R > 0x7FFFFFFFll) return fail(GSR_ERR_UNSUPPORTED, "more than 2^31-1 tile instances");
+    const uint64_t R64 = ((uint64_t)hw_slot.host[2] << 32) | (uint64_t)hw_slot.host[0];
+    if (R64 > 0x7FFFFFFFull) return fail(GSR_ERR_UNSUPPORTED, "more than 2^31-1 tile instances");
+    const int64_t R = (int64_t)R64;
     *num_rendered = (int32_t)R;
-    g_last_R.store(R);
+    g_last_R[dev_id].store(R);
     const size_t need_bytes = gsr_binning_bytes(R, n_tiles);
     if (!bbase || need_bytes > spec_bytes) bbase = (char*)binning_resize(binning_user, need_bytes);
     if (!bbase || !ibase) return fail(GSR_ERR_ALLOC, "binning / image buffer resize returned NULL");
     GsrBinning b = gsr_carve_binning(bbase, R);
     GsrImage im = gsr_carve_image(ibase, cam.W, cam.H);
+    float4* goffset_splats = settings->no_backward ? nullptr : g.splats;
 
     int list_buf = 0;
-    if (R > 0) {
-        const bool key16 = n_tiles <= 65536;     // tile ids fit 16 bits: 25 % less sort traffic
+    if (R > 0 && plan.fused) {
+        const uint32_t* block_first = g.block_first;
+        const int64_t nblk = (R + GSR_TS_ITEMS - 1) / GSR_TS_ITEMS;
         {   StageTimer t(GSR_STAGE_EMIT, st);
-            gsr_launch_emit(P, cam.gx, g.vals[order_buf], g.offsets, g.rect, b.keys[0], key16, b.vals[0],
-                            settings->no_backward ? nullptr : g.splats, st);
+            if ((uint64_t)nblk + 1 > (uint64_t)bf_cap) {      // more than ~64 tiles per Gaussian: table sized by R instead
+                gsr_launch_fill_block_first(P, g.offsets, b.block_first, (uint32_t)(nblk + 2), st);
+                block_first = b.block_first;
+            }
+            gsr_launch_tile_sort_level1(plan, R, cam.gx, block_first, g.offsets, g.rect_sorted, g.vals[order_buf], b.keys[0],
+                                        b.sort_hist, b.digit_total, b.bucket_base, b.blk2_start, goffset_splats, st);
+        }
+        STAGE_CHECK("emit + level-1 sort");
+        {   StageTimer t(GSR_STAGE_TILE_SORT, st);
+            gsr_launch_tile_sort_level2(plan, R, n_tiles, b.keys[0], b.vals[0], b.bucket_base, b.blk2_start, b.hist2, b.tile_base,
+                                        im.ranges, st);
+        }
+        STAGE_CHECK("level-2 sort + ranges");
+    } else if (R > 0) {
+        const bool key16 = n_tiles <= 65536;     // (only reachable through the A/B option: <= 65536 tiles normally take the fused path)
+        {   StageTimer t(GSR_STAGE_EMIT, st);
+            gsr_launch_emit(P, cam.gx, g.vals[order_buf], g.offsets, g.rect_sorted, b.keys[0], key16, b.vals[0], goffset_splats, st);
         }
         STAGE_CHECK("emit");
         {   StageTimer t(GSR_STAGE_TILE_SORT, st);
             if (key16) {
                 uint16_t* k16[2] = {(uint16_t*)b.keys[0], (uint16_t*)b.keys[1]};
-                list_buf = gsr_radix_sort_pairs_k16(k16, b.vals, R, bits_for((uint32_t)n_tiles), GSR_TILE_DIGIT_BITS, b.sort_hist,
+                // always two passes (zero high bits sort harmlessly), so that the list lands in vals[0] like the fused path's
+                const int kb = bits_for((uint32_t)n_tiles) < 9 ? 9 : bits_for((uint32_t)n_tiles);
+                list_buf = gsr_radix_sort_pairs_k16(k16, b.vals, R, kb, GSR_TILE_DIGIT_BITS, b.sort_hist,
                                                     b.digit_total, sort_items(R), st);
             } else {
                 list_buf = gsr_radix_sort_pairs(b.keys, b.vals, R, bits_for((uint32_t)n_tiles), GSR_TILE_DIGIT_BITS, b.sort_hist,
@@ -350,11 +404,13 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
             }
         }
         STAGE_CHECK("tile sort");
+        {   StageTimer t(GSR_STAGE_RANGES, st);
+            gsr_launch_ranges(R, n_tiles, b.keys[list_buf], key16, im.ranges, /*already_zeroed=*/true, st);
+        }
+        STAGE_CHECK("ranges");
+    } else if (plan.fused) {
+        HIP_OK(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)n_tiles, st));
     }
-    {   StageTimer t(GSR_STAGE_RANGES, st);
-        gsr_launch_ranges(R, n_tiles, b.keys[list_buf], n_tiles <= 65536, im.ranges, /*already_zeroed=*/true, st);
-    }
-    STAGE_CHECK("ranges");
     {   StageTimer t(GSR_STAGE_RENDER, st);
         gsr_launch_render_forward(cam, im.ranges, b.vals[list_buf], g.splats, settings->no_backward ? nullptr : im.final_T,
                                   settings->no_backward ? nullptr : im.n_contrib, out_color, out_invdepth,
@@ -460,13 +516,17 @@ int gsr_rasterize_from_splats(const GsrRasterSettings* settings, int P, const fl
                           num_rendered, st);
 }
 
+// Which ping-pong buffer holds the sorted list / the depth order is a pure function of the frame geometry (never of a
+// run-time option), so the backward finds the forward's results without any state passed between the two calls:
+// <= 65536 tiles: vals[0] (fused sort writes it; the legacy LSD sort takes 2 passes); more: 3 LSD passes -> vals[1].
 static int list_buffer_index(int n_tiles) {
+    if (n_tiles <= 65536) return 0;
     int pb[8];
     return gsr_sort_plan(bits_for((uint32_t)n_tiles), GSR_TILE_DIGIT_BITS, pb) & 1;
 }
 static int depth_order_buffer_index() {
     int pb[8];
-    return gsr_sort_plan(32, g_depth_digit_bits, pb) & 1;
+    return gsr_sort_plan(32, GSR_DEPTH_DIGIT_BITS, pb) & 1;
 }
 
 int gsr_backward_blend(const GsrRasterSettings* settings, int P, int32_t num_rendered, const void* geom_buffer,

@@ -25,6 +25,10 @@ static inline size_t gsr_align128(size_t x) { return (x + 127) & ~(size_t)127; }
 #define GSR_SORT_ITEMS 4096      // items per workgroup in a radix pass (256 threads x 16)
 #define GSR_SORT_ITEMS_SMALL 1024
 #define GSR_SCAN_ITEMS 1024      // items per workgroup in the tiles_touched scan
+#define GSR_TS_ITEMS 4096        // instances per workgroup of the fused emission / tile sort (tilesort.hip)
+// capacity of the per-block "first Gaussian" table the scan kernel fills: enough for 64 tiles per Gaussian on average;
+// frames beyond that get the table from a fallback kernel once R is known (gsr_launch_fill_block_first)
+static inline size_t gsr_block_first_cap(int P) { return (size_t)(P > 0 ? P : 1) / 64 + 66; }
 
 struct GsrGeom {                 // P-sized
     float4* splats;              // [4P]  (x,y,conA,conB) (conC,opacity,r,g) (b,depth,tau,1/depth) (rect.x,rect.y,goffset,tiles as bits)
@@ -32,9 +36,11 @@ struct GsrGeom {                 // P-sized
     uint32_t* tiles;             // [P]   tiles_touched
     uint32_t* clamped;           // [P]   colour clamp bits
     uint32_t* keys[2];           // [P]x2 depth-sort keys (ping-pong)
-    uint32_t* vals[2];           // [P]x2 Gaussian ids   (ping-pong); vals[order_buf] = depth order
+    uint32_t* vals[2];           // [P]x2 Gaussian ids   (ping-pong); vals[0] = depth order (4 passes: even)
+    uint2* rect_sorted;          // [P]   tile rectangles in depth order (written by the scan)
     uint32_t* offsets;           // [P]   inclusive scan of tiles_touched in depth order
-    uint32_t* block_sums;        // [ceil(P/GSR_SCAN_ITEMS)]
+    uint64_t* block_sums;        // [ceil(P/GSR_SCAN_ITEMS)]
+    uint32_t* block_first;       // [gsr_block_first_cap(P)] first Gaussian (depth-order index) of every 4096-instance block
     uint32_t* sort_hist;         // [256 * nblocks_small(P)] radix block histograms
     uint32_t* digit_total;       // [256]
     uint32_t* num_rendered;      // [1] (+ order_buf index in [1])
@@ -43,11 +49,19 @@ struct GsrGeom {                 // P-sized
 GsrGeom gsr_carve_geom(char* base, int P);
 
 struct GsrBinning {              // R-sized
-    uint32_t* keys[2];           // [R]x2 tile ids (ping-pong)
-    uint32_t* vals[2];           // [R]x2 Gaussian ids (ping-pong); final sorted list = point_list
-    uint32_t* sort_hist;         // [256 * nblocks(R)]
+    // > 65536 tiles (LSD sort, sort.hip): keys[2] tile ids / vals[2] Gaussian ids, ping-pong; list = vals[passes & 1]
+    // <= 65536 tiles (fused emission + two-level sort, tilesort.hip): words = keys[0] (8R bytes, contiguous with
+    //   keys[1]) holds the packed level-1 output, vals[0] the final point_list
+    uint32_t* keys[2];
+    uint32_t* vals[2];
+    uint32_t* sort_hist;         // LSD: [256 * nblocks_small(R)]; fused: level-1 table [nb1 * nblk]
+    uint32_t* hist2;             // fused: level-2 table [(nblk + 256) * 256]
     uint32_t* digit_total;       // [256]
-    uint32_t* meta;              // [4]: [0] = index of the buffer holding the sorted list
+    uint32_t* bucket_base;       // [257]
+    uint32_t* blk2_start;        // [257]
+    uint32_t* tile_base;         // [65536]
+    uint32_t* block_first;       // [ceil(R / GSR_TS_ITEMS) + 2]  (fallback table, see gsr_block_first_cap)
+    uint32_t* meta;
     size_t bytes;
 };
 GsrBinning gsr_carve_binning(char* base, int64_t R);
@@ -91,13 +105,28 @@ static inline int64_t gsr_sort_blocks(int64_t n, bool small_blocks) {
 }
 
 // binning.hip: scan of tiles_touched in depth order, instance emission, tile ranges
-void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles, uint32_t* tiles_sorted /*[P] scratch*/, uint32_t* offsets,
-                           uint32_t* block_sums, uint32_t* num_rendered, uint32_t* host_word /*mapped pinned, may be NULL*/,
-                           uint32_t seq, hipStream_t st);
-// key16: tile ids are stored as uint16_t (frames with <= 65536 tiles), else uint32_t
-void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect,
+// host_word (mapped pinned, may be NULL): [0] = R low word, [2] = R high word, [1] = seq (stored last)
+void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint2* rect, uint2* rect_sorted /*[P]*/, uint32_t* offsets,
+                           uint64_t* block_sums, uint32_t* block_first, uint32_t block_first_cap, uint32_t* num_rendered,
+                           uint32_t* host_word, uint32_t seq, hipStream_t st);
+// legacy emission (frames with more than 65536 tiles): 32-bit tile ids
+void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect_sorted,
                      void* inst_keys, bool key16, uint32_t* inst_vals, float4* splats /*NULL: skip the goffset write*/,
                      hipStream_t st);
+
+// tilesort.hip: fused emission + two-level stable tile sort + ranges (frames with <= 65536 tiles)
+struct GsrTileSortPlan { bool fused; int lb, hb; bool word64; };
+void gsr_tile_sort_plan(int n_tiles, int P, GsrTileSortPlan* plan);
+void gsr_launch_fill_block_first(int P, const uint32_t* offsets, uint32_t* block_first, uint32_t cap, hipStream_t st);
+void gsr_launch_tile_sort_level1(const GsrTileSortPlan& plan, int64_t R, int gx, const uint32_t* block_first,
+                                 const uint32_t* offsets, const uint2* rect_sorted, const uint32_t* order, void* words,
+                                 uint32_t* hist1, uint32_t* digit_total, uint32_t* bucket_base, uint32_t* blk2_start,
+                                 float4* splats /*NULL: inference*/, hipStream_t st);
+void gsr_launch_tile_sort_level2(const GsrTileSortPlan& plan, int64_t R, int n_tiles, const void* words, uint32_t* point_list,
+                                 const uint32_t* bucket_base, const uint32_t* blk2_start, uint32_t* hist2, uint32_t* tile_base,
+                                 uint2* ranges, hipStream_t st);
+// sort.hip: in-place exclusive scan of every digit row of a [ndigits][nblocks] block-histogram table + row totals
+void gsr_launch_rs_scan(uint32_t* block_hist, int nblocks, int ndigits, uint32_t* digit_total, hipStream_t st);
 void gsr_launch_ranges(int64_t R, int n_tiles, const void* sorted_keys, bool key16, uint2* ranges, bool already_zeroed,
                        hipStream_t st);
 

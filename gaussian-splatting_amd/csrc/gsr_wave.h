@@ -1,0 +1,70 @@
+// wave64 / workgroup primitives shared by the binning and sorting kernels (device only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gsrw {
+
+constexpr int WG_THREADS = 256;
+constexpr int WG_WAVES = WG_THREADS / 64;
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, off, 64);
+        const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), off, 64);
+        if (lane >= off) v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+
+// Exclusive scan over the 256 threads of a workgroup of the per-thread totals of DPT values (thread t owns entries
+// t*DPT .. t*DPT+DPT-1); returns the exclusive prefix of the thread's first entry.  wsum: 4-entry LDS scratch; two barriers.
+template <int DPT>
+__device__ __forceinline__ uint32_t block_excl_scan(const uint32_t (&v)[DPT], uint32_t* wsum, int lane, int w) {
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) tsum += v[i];
+    const uint32_t incl = wave_incl_scan_u32(tsum, lane);
+    __syncthreads();
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+#pragma unroll
+    for (int k = 0; k < WG_WAVES; ++k)
+        if (k < w) wbase += wsum[k];
+    return wbase + incl - tsum;
+}
+
+// a / b and the remainder for a < 2^24, 0 < b < 2^16 with a quotient < 2^16: one v_rcp_f32 and a +-1 correction instead
+// of the ~30-instruction integer division sequence
+__device__ __forceinline__ uint32_t div_small(uint32_t a, uint32_t b, uint32_t& rem) {
+    uint32_t q = (uint32_t)((float)a * __builtin_amdgcn_rcpf((float)b));
+    int r = (int)a - (int)(q * b);
+    if (r < 0) { --q; r += (int)b; }
+    else if (r >= (int)b) { ++q; r -= (int)b; }
+    rem = (uint32_t)r;
+    return q;
+}
+
+// 64-bit mask of the lanes whose `digit` (low `bits` bits significant) equals this lane's, among the lanes in `valid_mask`
+__device__ __forceinline__ uint64_t match_digit(uint32_t digit, int bits, uint64_t valid_mask) {
+    uint64_t mask = valid_mask;
+    for (int b = 0; b < bits; ++b) {            // wave-uniform trip count
+        const bool bit = (digit >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        mask &= bit ? bal : ~bal;
+    }
+    return mask;
+}
+
+}  // namespace gsrw

@@ -322,6 +322,10 @@ int sort_pairs_t(KeyT* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max
 
 }  // namespace
 
+void gsr_launch_rs_scan(uint32_t* block_hist, int nblocks, int ndigits, uint32_t* digit_total, hipStream_t st) {
+    hipLaunchKernelGGL(rs_scan, dim3(ndigits), dim3(RS_THREADS), 0, st, block_hist, nblocks, digit_total);
+}
+
 int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits) {
     // number of passes and bits per pass: ceil(nbits / max) passes of (almost) equal width, each in {4..8, 11}
     int passes = (nbits + max_digit_bits - 1) / max_digit_bits;

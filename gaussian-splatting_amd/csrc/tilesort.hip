@@ -1,0 +1,448 @@
+// Instance emission + stable sort by tile for frames with <= 65536 tiles -- replaces duplicateWithKeys, the
+// 64-bit-key cub::DeviceRadixSort::SortPairs call and identifyTileRanges of the un-vendored reference rasterizer
+// (algorithm SURVEY.md Appendix A.3; reached from gaussian_renderer/__init__.py:91-110).
+//
+// Input: the Gaussians in DEPTH ORDER (depth sort on P keys, sort.hip) with the inclusive scan of their tile counts
+// (binning.hip).  The (Gaussian, tile) instances in emission order -- depth order, then y-major / x-fastest inside the
+// Gaussian's rectangle -- only need a STABLE sort by tile id to reach the reference's (tile, depth, index) order.
+// That sort is a two-level MSD radix sort on the tile id split into a high digit ("bucket", ~ one tile row) and a low
+// digit, with the emission FUSED into the first level:
+//
+//   level 1  emit_hist     block = 4096 consecutive instances (found through a per-block table of first Gaussians that
+//                          the scan kernel writes); instances are generated in registers, the block's bucket
+//                          histogram is written                                    (no instance ever stored unsorted)
+//            rs_scan       (sort.hip) bucket totals + per-block offsets
+//            emit_scatter  instances generated again, ranked with wave64 ballot matching (stable, no atomics), staged
+//                          in LDS in bucket order and written as ONE packed word per instance
+//                          (id << LB | low tile digit; 4 bytes when P << LB fits 32 bits, else 8)
+//   level 2  bucket_hist   blocks are assigned per bucket (table written by emit_scatter's block 0): histogram of the
+//                          low digit
+//            bucket_scan   one workgroup per bucket: per-block offsets, and -- because (bucket, low digit) IS the tile --
+//                          the per-tile [start, end) RANGES directly (no range kernel, no sorted key array)
+//            bucket_scatter stable ranking by low digit, ids written in final order = the reference's point_list
+//
+// HBM traffic: 4R (level-1 write) + 4R + 4R (level-2 hist / scatter reads) + 4R (point list) = 16 R bytes, against
+// 6R (emit) + 2 x (2R + 6R + 6R) (two LSD passes on u16 key / u32 id pairs) + 2R (ranges) = 36 R for the previous
+// design (sort.hip, still used above 65536 tiles) and >= 144 R for a 64-bit-key LSD sort.  8 -> 6 launches.
+#include "gsr_internal.h"
+#include "gsr_wave.h"
+
+using namespace gsrw;
+
+namespace {
+
+constexpr int TS_ITEMS = GSR_TS_ITEMS;              // instances per workgroup
+constexpr int TS_IPT = TS_ITEMS / WG_THREADS;       // 16 per thread
+constexpr int TS_MAXBINS = 256;
+
+template <typename WordT> struct Pack;
+template <> struct Pack<uint32_t> {
+    static __device__ __forceinline__ uint32_t make(uint32_t id, uint32_t lo, int lb) { return (id << lb) | lo; }
+    static __device__ __forceinline__ uint32_t id(uint32_t w, int lb) { return w >> lb; }
+    static __device__ __forceinline__ uint32_t lo(uint32_t w, uint32_t mask) { return w & mask; }
+};
+template <> struct Pack<uint64_t> {
+    static __device__ __forceinline__ uint64_t make(uint32_t id, uint32_t lo, int) { return ((uint64_t)id << 32) | lo; }
+    static __device__ __forceinline__ uint32_t id(uint64_t w, int) { return (uint32_t)(w >> 32); }
+    static __device__ __forceinline__ uint32_t lo(uint64_t w, uint32_t mask) { return (uint32_t)w & mask; }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Generation of the workgroup's 4096 instances.  Wave w owns the contiguous run [w*1024, w*1024+1024) of the block's
+// slots, item r of a lane is slot w*1024 + r*64 + lane (so ranking in (r, lane) order is emission order).
+// s_incl: LDS, inclusive tile-count prefixes of the block's Gaussians [j_lo, j_hi].
+// Returns in tile[r] the tile id, in gj[r] the depth-order index of the owning Gaussian, vmask bit r = slot < R.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void generate_instances(uint32_t R, int gx, const uint32_t* __restrict__ block_first,
+                                                   const uint32_t* __restrict__ offsets, const uint2* __restrict__ rect_sorted,
+                                                   uint32_t* s_incl, uint32_t& j_lo_out, int& nG_out, uint32_t& base_excl_out,
+                                                   uint32_t (&tile)[TS_IPT], uint32_t (&gj)[TS_IPT], uint32_t& vmask) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t b = blockIdx.x;
+    const uint32_t j_lo = block_first[b], j_hi = block_first[b + 1];
+    const int nG = (int)(j_hi - j_lo) + 1;                       // <= TS_ITEMS + 1
+    const uint32_t base_excl = j_lo ? offsets[j_lo - 1] : 0u;    // instances emitted before Gaussian j_lo
+    for (int i = tid; i < nG; i += WG_THREADS) s_incl[i] = offsets[j_lo + i];
+    __syncthreads();
+    const uint32_t s0 = b * (uint32_t)TS_ITEMS + (uint32_t)w * (64u * TS_IPT) + (uint32_t)lane;
+    const int steps = nG > 1 ? 32 - __clz(nG - 1) : 0;           // wave-uniform
+    uint32_t kk[TS_IPT];
+    int lo[TS_IPT], hi[TS_IPT];
+    vmask = 0;
+#pragma unroll
+    for (int r = 0; r < TS_IPT; ++r) {
+        const uint32_t k = s0 + (uint32_t)r * 64u;
+        if (k < R) vmask |= 1u << r;
+        kk[r] = k < R ? k : R - 1u;
+        lo[r] = 0;
+        hi[r] = nG - 1;
+    }
+    // owner = first Gaussian whose inclusive prefix exceeds the slot index: 16 independent binary searches per lane,
+    // one LDS read per step each (the reads of a step are all in flight together)
+    for (int s = 0; s < steps; ++s) {
+#pragma unroll
+        for (int r = 0; r < TS_IPT; ++r) {
+            const int mid = (lo[r] + hi[r]) >> 1;
+            if (s_incl[mid] > kk[r]) hi[r] = mid; else lo[r] = mid + 1;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < TS_IPT; ++r) {
+        const int i = lo[r] < nG ? lo[r] : nG - 1;
+        const uint32_t excl = i ? s_incl[i - 1] : base_excl;
+        const uint2 rc = rect_sorted[j_lo + i];
+        const uint32_t minx = rc.x & 0xFFFFu, wd = (rc.x >> 16) - minx, miny = rc.y & 0xFFFFu;
+        uint32_t rx;
+        const uint32_t ry = div_small(kk[r] - excl, wd ? wd : 1u, rx);
+        tile[r] = (miny + ry) * (uint32_t)gx + minx + rx;
+        gj[r] = j_lo + (uint32_t)i;
+    }
+    j_lo_out = j_lo;
+    nG_out = nG;
+    base_excl_out = base_excl;
+}
+
+// level 1 histogram: hist[d * nblk + block] = instances of the block whose tile id >> lb == d
+__global__ void __launch_bounds__(WG_THREADS)
+emit_hist(uint32_t R, int gx, int lb, int nb1, const uint32_t* __restrict__ block_first, const uint32_t* __restrict__ offsets,
+          const uint2* __restrict__ rect_sorted, uint32_t* __restrict__ hist, int nblk) {
+    __shared__ uint32_t s_incl[TS_ITEMS + 1];
+    __shared__ uint32_t h[TS_MAXBINS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < nb1) h[tid] = 0;        // (the barrier inside generate_instances orders this before the adds)
+    uint32_t tile[TS_IPT], gj[TS_IPT], vmask, j_lo, base_excl;
+    int nG;
+    generate_instances(R, gx, block_first, offsets, rect_sorted, s_incl, j_lo, nG, base_excl, tile, gj, vmask);
+    // consecutive slots are consecutive tiles of one rectangle row: they share the bucket, so equal-bucket RUNS are
+    // added with one LDS atomic at the run head instead of one per instance
+#pragma unroll
+    for (int r = 0; r < TS_IPT; ++r) {
+        const bool valid = (vmask >> r) & 1u;
+        const uint32_t d = valid ? (tile[r] >> lb) : 0xFFFFFFFFu;
+        const uint32_t prev = (uint32_t)__shfl_up((int)d, 1, 64);
+        const bool head = lane == 0 || prev != d;
+        const uint64_t hm = __ballot(head);
+        const uint64_t above = lane == 63 ? 0ull : (hm >> (lane + 1)) << (lane + 1);
+        const int next = above ? __builtin_ctzll(above) : 64;
+        if (head && valid) atomicAdd(&h[d], (uint32_t)(next - lane));
+    }
+    __syncthreads();
+    if (tid < nb1) hist[(int64_t)tid * nblk + blockIdx.x] = h[tid];
+}
+
+// Stable scatter of the workgroup's items by `digit` (< nbins <= 256, `bits` significant bits): returns through LDS
+// the items in workgroup-local sorted order (s_word / s_dig) and the global base of every digit (digit_base, already
+// offset so that global position = digit_base[d] + local index).  ranks: wave64 ballot matching, no atomics.
+template <typename WordT>
+__device__ __forceinline__ void local_stable_sort(const WordT (&word)[TS_IPT], const uint32_t (&digit)[TS_IPT], uint32_t vmask,
+                                                  int bits, int nbins, uint32_t my_digit_base /*thread d: global base of digit d*/,
+                                                  uint32_t (*wave_cnt)[TS_MAXBINS], uint32_t* digit_base, uint32_t* wsum,
+                                                  WordT* s_word, uint8_t* s_dig) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < nbins) {
+        digit_base[tid] = my_digit_base;
+#pragma unroll
+        for (int k = 0; k < WG_WAVES; ++k) wave_cnt[k][tid] = 0;
+    }
+    __syncthreads();
+    uint32_t rank[TS_IPT];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < TS_IPT; ++r) {
+        const bool valid = (vmask >> r) & 1u;
+        const uint32_t d = digit[r];
+        const uint64_t mask = match_digit(d, bits, __ballot(valid));
+        const uint32_t prior = valid ? wave_cnt[w][d] : 0u;
+        rank[r] = prior + (uint32_t)__popcll(mask & lt_mask);
+        if (valid && (mask & lt_mask) == 0ull) wave_cnt[w][d] = prior + (uint32_t)__popcll(mask);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {
+        uint32_t tot[1] = {0u};
+        if (tid < nbins) {
+#pragma unroll
+            for (int k = 0; k < WG_WAVES; ++k) tot[0] += wave_cnt[k][tid];
+        }
+        const uint32_t lbase = block_excl_scan<1>(tot, wsum, lane, w);
+        if (tid < nbins) {
+            uint32_t run = lbase;
+#pragma unroll
+            for (int k = 0; k < WG_WAVES; ++k) {
+                const uint32_t t = wave_cnt[k][tid];
+                wave_cnt[k][tid] = run;
+                run += t;
+            }
+            digit_base[tid] -= lbase;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < TS_IPT; ++r) {
+        if ((vmask >> r) & 1u) {
+            const uint32_t lp = wave_cnt[w][digit[r]] + rank[r];
+            s_word[lp] = word[r];
+            s_dig[lp] = (uint8_t)digit[r];
+        }
+    }
+    __syncthreads();
+}
+
+// level 1 scatter (+ first-emission indices for the backward, + the bucket tables of level 2 from block 0)
+template <typename WordT>
+__global__ void __launch_bounds__(WG_THREADS)
+emit_scatter(uint32_t R, int gx, int lb, int hb, const uint32_t* __restrict__ block_first, const uint32_t* __restrict__ offsets,
+             const uint2* __restrict__ rect_sorted, const uint32_t* __restrict__ order, const uint32_t* __restrict__ hist,
+             const uint32_t* __restrict__ digit_total, int nblk, WordT* __restrict__ words_out,
+             uint32_t* __restrict__ bucket_base /*[nb1+1]*/, uint32_t* __restrict__ blk2_start /*[nb1+1]*/,
+             float4* __restrict__ splats /*NULL: inference, no first-emission write*/) {
+    __shared__ uint32_t s_incl[TS_ITEMS + 1];
+    __shared__ uint32_t wave_cnt[WG_WAVES][TS_MAXBINS];
+    __shared__ uint32_t digit_base[TS_MAXBINS];
+    __shared__ uint32_t wsum[WG_WAVES];
+    __shared__ WordT s_word[TS_ITEMS];
+    __shared__ uint8_t s_dig[TS_ITEMS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nb1 = 1 << hb;
+    uint32_t tile[TS_IPT], gj[TS_IPT], vmask, j_lo, base_excl;
+    int nG;
+    generate_instances(R, gx, block_first, offsets, rect_sorted, s_incl, j_lo, nG, base_excl, tile, gj, vmask);
+    if (splats) {
+        // first emission index of every Gaussian whose first instance lies in this block -> 4th quad of its splat record
+        // (the blend backward writes its per-instance gradient records at emission indices, render_bwd.hip)
+        const uint32_t b0 = blockIdx.x * (uint32_t)TS_ITEMS;
+        for (int i = tid; i < nG; i += WG_THREADS) {
+            const uint32_t excl = i ? s_incl[i - 1] : base_excl;
+            if (excl >= b0 && excl - b0 < (uint32_t)TS_ITEMS && s_incl[i] > excl)
+                reinterpret_cast<uint32_t*>(splats + (int64_t)order[j_lo + i] * 4 + 3)[2] = excl;
+        }
+    }
+    // global base of bucket d for this block = exclusive scan of the bucket totals + instances of earlier blocks
+    uint32_t tot[1] = {tid < nb1 ? digit_total[tid] : 0u};
+    const uint32_t bbase = block_excl_scan<1>(tot, wsum, lane, w);
+    if (blockIdx.x == 0) {
+        // level-2 plan: bucket d occupies [bucket_base[d], bucket_base[d+1]) of the word array and gets
+        // ceil(size / TS_ITEMS) workgroups starting at blk2_start[d]
+        uint32_t nb[1] = {(tot[0] + (uint32_t)TS_ITEMS - 1u) / (uint32_t)TS_ITEMS};
+        const uint32_t bstart = block_excl_scan<1>(nb, wsum, lane, w);
+        if (tid < nb1) {
+            bucket_base[tid] = bbase;
+            blk2_start[tid] = bstart;
+            if (tid == nb1 - 1) {
+                bucket_base[nb1] = bbase + tot[0];
+                blk2_start[nb1] = bstart + nb[0];
+            }
+        }
+    }
+    const uint32_t my_base = tid < nb1 ? bbase + hist[(int64_t)tid * nblk + blockIdx.x] : 0u;
+    WordT word[TS_IPT];
+    uint32_t digit[TS_IPT];
+    const uint32_t lomask = (1u << lb) - 1u;
+#pragma unroll
+    for (int r = 0; r < TS_IPT; ++r) {
+        const bool valid = (vmask >> r) & 1u;
+        const uint32_t id = valid ? order[gj[r]] : 0u;
+        word[r] = Pack<WordT>::make(id, tile[r] & lomask, lb);
+        digit[r] = valid ? (tile[r] >> lb) : 0u;
+    }
+    local_stable_sort<WordT>(word, digit, vmask, hb, nb1, my_base, wave_cnt, digit_base, wsum, s_word, s_dig);
+    const uint32_t b0 = blockIdx.x * (uint32_t)TS_ITEMS;
+    const uint32_t nvalid = R - b0 < (uint32_t)TS_ITEMS ? R - b0 : (uint32_t)TS_ITEMS;
+#pragma unroll
+    for (int r = 0; r < TS_IPT; ++r) {
+        const uint32_t i = (uint32_t)r * WG_THREADS + tid;
+        if (i < nvalid) words_out[digit_base[s_dig[i]] + i] = s_word[i];
+    }
+}
+
+// level 2: workgroup B2 -> (bucket h, chunk c).  Returns false when B2 is past the last planned workgroup.
+__device__ __forceinline__ bool bucket_block(int nb1, const uint32_t* __restrict__ bucket_base, const uint32_t* __restrict__ blk2_start,
+                                             int* s_h, uint32_t& h, uint32_t& begin, uint32_t& end) {
+    const int tid = threadIdx.x;
+    const uint32_t B2 = blockIdx.x;
+    if (tid == 0) *s_h = -1;
+    __syncthreads();
+    if (tid < nb1 && blk2_start[tid] <= B2 && B2 < blk2_start[tid + 1]) *s_h = tid;      // at most one bucket matches
+    __syncthreads();
+    const int hh = *s_h;
+    if (hh < 0) return false;
+    h = (uint32_t)hh;
+    const uint32_t c = B2 - blk2_start[hh];
+    begin = bucket_base[hh] + c * (uint32_t)TS_ITEMS;
+    const uint32_t bend = bucket_base[hh + 1];
+    end = bend - begin < (uint32_t)TS_ITEMS ? bend : begin + (uint32_t)TS_ITEMS;
+    return true;
+}
+
+template <typename WordT>
+__global__ void __launch_bounds__(WG_THREADS)
+bucket_hist(int lb, int hb, const WordT* __restrict__ words, const uint32_t* __restrict__ bucket_base,
+            const uint32_t* __restrict__ blk2_start, uint32_t* __restrict__ hist2 /*[blocks][nb2]*/) {
+    __shared__ uint32_t hcnt[WG_WAVES][TS_MAXBINS];
+    __shared__ int s_h;
+    const int tid = threadIdx.x, w = tid >> 6;
+    const int nb1 = 1 << hb, nb2 = 1 << lb;
+    uint32_t h, begin, end;
+    if (!bucket_block(nb1, bucket_base, blk2_start, &s_h, h, begin, end)) return;
+    if (tid < nb2) {
+#pragma unroll
+        for (int k = 0; k < WG_WAVES; ++k) hcnt[k][tid] = 0;
+    }
+    __syncthreads();
+    const uint32_t lomask = (uint32_t)nb2 - 1u;
+    // inside a bucket consecutive words belong to unrelated tiles: plain LDS atomics, one table per wave
+    WordT wd[TS_IPT];
+#pragma unroll
+    for (int r = 0; r < TS_IPT; ++r) {          // all loads first: 16 independent requests in flight per lane
+        const uint32_t i = begin + (uint32_t)r * WG_THREADS + tid;
+        wd[r] = i < end ? words[i] : (WordT)0;
+    }
+#pragma unroll
+    for (int r = 0; r < TS_IPT; ++r) {
+        const uint32_t i = begin + (uint32_t)r * WG_THREADS + tid;
+        if (i < end) atomicAdd(&hcnt[w][Pack<WordT>::lo(wd[r], lomask)], 1u);
+    }
+    __syncthreads();
+    if (tid < nb2) hist2[(int64_t)blockIdx.x * nb2 + tid] = hcnt[0][tid] + hcnt[1][tid] + hcnt[2][tid] + hcnt[3][tid];
+}
+
+// one workgroup per bucket: per-block exclusive offsets of every low digit (in place), the per-tile bases and the
+// tile ranges (tile = bucket << lb | low digit)
+__global__ void __launch_bounds__(WG_THREADS)
+bucket_scan(int lb, int n_tiles, const uint32_t* __restrict__ bucket_base, const uint32_t* __restrict__ blk2_start,
+            uint32_t* __restrict__ hist2, uint32_t* __restrict__ tile_base /*[nb1 * nb2]*/, uint2* __restrict__ ranges) {
+    __shared__ uint32_t wsum[WG_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nb2 = 1 << lb;
+    const uint32_t h = blockIdx.x;
+    const uint32_t s = blk2_start[h], e = blk2_start[h + 1];
+    uint32_t tot[1] = {0u};
+    if (tid < nb2) {
+        uint32_t run = 0;
+        uint32_t* col = hist2 + tid;
+#pragma unroll 4
+        for (uint32_t b = s; b < e; ++b) {
+            const uint32_t v = col[(int64_t)b * nb2];
+            col[(int64_t)b * nb2] = run;
+            run += v;
+        }
+        tot[0] = run;
+    }
+    const uint32_t excl = block_excl_scan<1>(tot, wsum, lane, w);
+    if (tid < nb2) {
+        const uint32_t base = bucket_base[h] + excl;
+        tile_base[h * (uint32_t)nb2 + tid] = base;
+        const uint32_t tile = (h << lb) | (uint32_t)tid;
+        if (tile < (uint32_t)n_tiles) ranges[tile] = tot[0] ? make_uint2(base, base + tot[0]) : make_uint2(0u, 0u);
+    }
+}
+
+template <typename WordT>
+__global__ void __launch_bounds__(WG_THREADS)
+bucket_scatter(int lb, int hb, const WordT* __restrict__ words, const uint32_t* __restrict__ bucket_base,
+               const uint32_t* __restrict__ blk2_start, const uint32_t* __restrict__ hist2,
+               const uint32_t* __restrict__ tile_base, uint32_t* __restrict__ point_list) {
+    __shared__ uint32_t wave_cnt[WG_WAVES][TS_MAXBINS];
+    __shared__ uint32_t digit_base[TS_MAXBINS];
+    __shared__ uint32_t wsum[WG_WAVES];
+    __shared__ uint32_t s_id[TS_ITEMS];
+    __shared__ uint8_t s_dig[TS_ITEMS];
+    __shared__ int s_h;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nb1 = 1 << hb, nb2 = 1 << lb;
+    uint32_t h, begin, end;
+    if (!bucket_block(nb1, bucket_base, blk2_start, &s_h, h, begin, end)) return;
+    const uint32_t lomask = (uint32_t)nb2 - 1u;
+    uint32_t id[TS_IPT], digit[TS_IPT], vmask = 0;
+    const uint32_t wbase = begin + (uint32_t)w * (64u * TS_IPT) + (uint32_t)lane;
+#pragma unroll
+    for (int r = 0; r < TS_IPT; ++r) {
+        const uint32_t i = wbase + (uint32_t)r * 64u;
+        const bool valid = i < end;
+        const WordT wd = valid ? words[i] : (WordT)0;
+        id[r] = Pack<WordT>::id(wd, lb);
+        digit[r] = Pack<WordT>::lo(wd, lomask);
+        if (valid) vmask |= 1u << r;
+    }
+    const uint32_t my_base = tid < nb2 ? tile_base[h * (uint32_t)nb2 + tid] + hist2[(int64_t)blockIdx.x * nb2 + tid] : 0u;
+    local_stable_sort<uint32_t>(id, digit, vmask, lb, nb2, my_base, wave_cnt, digit_base, wsum, s_id, s_dig);
+    const uint32_t nvalid = end - begin;
+#pragma unroll
+    for (int r = 0; r < TS_IPT; ++r) {
+        const uint32_t i = (uint32_t)r * WG_THREADS + tid;
+        if (i < nvalid) point_list[digit_base[s_dig[i]] + i] = s_id[i];
+    }
+}
+
+// Fallback for frames whose instance count exceeds the capacity of the per-block table the scan kernel fills
+// (more than 64 tiles per Gaussian on average): the same table, sized by R, from the finished offsets.
+__global__ void __launch_bounds__(WG_THREADS)
+fill_block_first(int P, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ block_first, uint32_t cap) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < P; j += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t incl = offsets[j], excl = j ? offsets[j - 1] : 0u;
+        if (incl == excl) continue;
+        for (uint32_t k = (excl + TS_ITEMS - 1u) / TS_ITEMS; k <= (incl - 1u) / TS_ITEMS; ++k)
+            if (k < cap) block_first[k] = (uint32_t)j;
+        if (j == (int64_t)P - 1 || offsets[j + 1] == incl) {
+            const uint32_t k = (incl + TS_ITEMS - 1u) / TS_ITEMS;
+            if (k < cap) block_first[k] = (uint32_t)j;
+        }
+    }
+}
+
+}  // namespace
+
+void gsr_tile_sort_plan(int n_tiles, int P, GsrTileSortPlan* plan) {
+    int nbits = 1;
+    while (nbits < 32 && (1ll << nbits) < (long long)n_tiles) ++nbits;
+    plan->fused = n_tiles <= 65536;
+    plan->lb = (nbits + 1) / 2;
+    plan->hb = nbits - plan->lb;
+    plan->word64 = ((unsigned long long)(P > 0 ? P : 1) << plan->lb) > (1ull << 32);
+}
+
+void gsr_launch_fill_block_first(int P, const uint32_t* offsets, uint32_t* block_first, uint32_t cap, hipStream_t st) {
+    int64_t nb = ((int64_t)P + WG_THREADS - 1) / WG_THREADS;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(fill_block_first, dim3((int)nb), dim3(WG_THREADS), 0, st, P, offsets, block_first, cap);
+}
+
+void gsr_launch_tile_sort_level1(const GsrTileSortPlan& plan, int64_t R, int gx, const uint32_t* block_first,
+                                 const uint32_t* offsets, const uint2* rect_sorted, const uint32_t* order, void* words,
+                                 uint32_t* hist1, uint32_t* digit_total, uint32_t* bucket_base, uint32_t* blk2_start,
+                                 float4* splats, hipStream_t st) {
+    const int nblk = (int)((R + TS_ITEMS - 1) / TS_ITEMS);
+    const int nb1 = 1 << plan.hb;
+    const uint32_t R32 = (uint32_t)R;
+    hipLaunchKernelGGL(emit_hist, dim3(nblk), dim3(WG_THREADS), 0, st, R32, gx, plan.lb, nb1, block_first, offsets, rect_sorted,
+                       hist1, nblk);
+    gsr_launch_rs_scan(hist1, nblk, nb1, digit_total, st);
+    if (plan.word64)
+        hipLaunchKernelGGL(emit_scatter<uint64_t>, dim3(nblk), dim3(WG_THREADS), 0, st, R32, gx, plan.lb, plan.hb, block_first,
+                           offsets, rect_sorted, order, hist1, digit_total, nblk, (uint64_t*)words, bucket_base, blk2_start, splats);
+    else
+        hipLaunchKernelGGL(emit_scatter<uint32_t>, dim3(nblk), dim3(WG_THREADS), 0, st, R32, gx, plan.lb, plan.hb, block_first,
+                           offsets, rect_sorted, order, hist1, digit_total, nblk, (uint32_t*)words, bucket_base, blk2_start, splats);
+}
+
+void gsr_launch_tile_sort_level2(const GsrTileSortPlan& plan, int64_t R, int n_tiles, const void* words, uint32_t* point_list,
+                                 const uint32_t* bucket_base, const uint32_t* blk2_start, uint32_t* hist2, uint32_t* tile_base,
+                                 uint2* ranges, hipStream_t st) {
+    const int nblk = (int)((R + TS_ITEMS - 1) / TS_ITEMS);
+    const int nb1 = 1 << plan.hb;
+    const int nblk2 = nblk + nb1;       // upper bound of the level-2 workgroups (every bucket rounds up once)
+    if (plan.word64)
+        hipLaunchKernelGGL(bucket_hist<uint64_t>, dim3(nblk2), dim3(WG_THREADS), 0, st, plan.lb, plan.hb, (const uint64_t*)words,
+                           bucket_base, blk2_start, hist2);
+    else
+        hipLaunchKernelGGL(bucket_hist<uint32_t>, dim3(nblk2), dim3(WG_THREADS), 0, st, plan.lb, plan.hb, (const uint32_t*)words,
+                           bucket_base, blk2_start, hist2);
+    hipLaunchKernelGGL(bucket_scan, dim3(nb1), dim3(WG_THREADS), 0, st, plan.lb, n_tiles, bucket_base, blk2_start, hist2, tile_base,
+                       ranges);
+    if (plan.word64)
+        hipLaunchKernelGGL(bucket_scatter<uint64_t>, dim3(nblk2), dim3(WG_THREADS), 0, st, plan.lb, plan.hb, (const uint64_t*)words,
+                           bucket_base, blk2_start, hist2, tile_base, point_list);
+    else
+        hipLaunchKernelGGL(bucket_scatter<uint32_t>, dim3(nblk2), dim3(WG_THREADS), 0, st, plan.lb, plan.hb, (const uint32_t*)words,
+                           bucket_base, blk2_start, hist2, tile_base, point_list);
+}

@@ -19,7 +19,10 @@ def _view(buf: torch.Tensor, ptr: int, nbytes: int, dtype) -> torch.Tensor:
 
 
 def forward_with_views(rs: GaussianRasterizationSettings, means3D, opacities, shs=None, colors_precomp=None,
-                       scales=None, rotations=None, cov3D_precomp=None, tile_rows=None, want_invdepth=True):
+                       scales=None, rotations=None, cov3D_precomp=None, tile_rows=None, want_invdepth=True,
+                       no_backward=False):
+    """no_backward=True runs the INFERENCE instantiation (what a torch.no_grad() render and bench.py's forward metric
+    use): final_T / n_contrib / first-emission indices are not written, so those views are omitted."""
     lib = _lib.load()
     device = means3D.device
     P = int(means3D.shape[0])
@@ -28,7 +31,7 @@ def forward_with_views(rs: GaussianRasterizationSettings, means3D, opacities, sh
     M = int(t[1].shape[1]) if t[1] is not None else 0
     keep: list = []
     with torch.cuda.device(device):
-        s = _make_settings(rs, keep, tile_rows)
+        s = _make_settings(rs, keep, tile_rows, no_backward)
         color = torch.zeros(3, H, W, dtype=torch.float32, device=device)
         invdepth = torch.zeros(1, H, W, dtype=torch.float32, device=device) if want_invdepth else None
         radii = torch.empty(P, dtype=torch.int32, device=device)
@@ -53,6 +56,7 @@ def forward_with_views(rs: GaussianRasterizationSettings, means3D, opacities, sh
         out["point_list"] = (_view(binning.t, v.point_list, R * 4, torch.int32) if R > 0
                              else torch.empty(0, dtype=torch.int32, device=device))
         out["ranges"] = _view(img.t, v.ranges, gx * gy * 8, torch.int32).view(gx * gy, 2)
-        out["final_T"] = _view(img.t, v.final_T, H * W * 4, torch.float32).view(H, W)
-        out["n_contrib"] = _view(img.t, v.n_contrib, H * W * 4, torch.int32).view(H, W)
+        if not no_backward:
+            out["final_T"] = _view(img.t, v.final_T, H * W * 4, torch.float32).view(H, W)
+            out["n_contrib"] = _view(img.t, v.n_contrib, H * W * 4, torch.int32).view(H, W)
     return out
