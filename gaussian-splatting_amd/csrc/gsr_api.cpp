@@ -216,8 +216,8 @@ GsrBwdScratch gsr_carve_bwd(char* base, int P, int64_t R) {
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off = gsr_align128(off + bytes); return p; };
     const size_t np = (size_t)(P > 0 ? P : 1), nr = (size_t)(R > 0 ? R : 1);
     b.splat_grads = (float*)take(np * 48);
-    b.inst_grads = (float*)take(nr * 48);
-    b.inst_flag = (uint8_t*)take(nr);
+    b.inst_grads = (float*)take(nr * 48 * 4);
+    b.inst_flag = (uint32_t*)take(nr * 4);
     b.bytes = off;
     return b;
 }
@@ -247,8 +247,16 @@ size_t gsr_backward_scratch_bytes(int P, int64_t R) { return gsr_carve_bwd(nullp
 
 int gsr_set_option(const char* name, int value) {
     if (!name) return fail(GSR_ERR_INVALID_ARG, "option name is NULL");
-    if (!strcmp(name, "render_fwd_variant")) { g_render_fwd_variant = value; return GSR_OK; }
-    if (!strcmp(name, "render_bwd_variant")) { g_render_bwd_variant = value; return GSR_OK; }
+    if (!strcmp(name, "render_fwd_variant")) {
+        if (!gsr_render_forward_variant_available(value)) return fail(GSR_ERR_UNSUPPORTED, "render_fwd_variant not in this build (A/B variants need -DGSR_AB_VARIANTS)");
+        g_render_fwd_variant = value;
+        return GSR_OK;
+    }
+    if (!strcmp(name, "render_bwd_variant")) {
+        if (!gsr_render_backward_variant_available(value)) return fail(GSR_ERR_UNSUPPORTED, "render_bwd_variant not in this build (A/B variants need -DGSR_AB_VARIANTS)");
+        g_render_bwd_variant = value;
+        return GSR_OK;
+    }
     if (!strcmp(name, "sort_small_block_threshold")) { g_small_block_threshold = value; return GSR_OK; }
     if (!strcmp(name, "sort_items_large")) {
         if (value != 1024 && value != 2048 && value != 4096 && value != 8192)
@@ -552,19 +560,20 @@ int gsr_backward_blend(const GsrRasterSettings* settings, int P, int32_t num_ren
             HIP_OK(hipMemsetAsync(sg, 0, (size_t)P * 12 * sizeof(float), st));
             if (num_rendered > 0)
                 gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib,
-                                           dL_dout_color, dL_dout_invdepth, sg, nullptr, nullptr, 1, st);
+                                           dL_dout_color, dL_dout_invdepth, sg, nullptr, nullptr, num_rendered, 1, st);
         } else {
-            // instances that contributed nowhere get no record: only their 1-byte valid flags are cleared
-            HIP_OK(hipMemsetAsync(w.inst_flag, 0, (size_t)num_rendered, st));
+            // instances that contributed nowhere get no record: only their flag words are cleared
+            HIP_OK(hipMemsetAsync(w.inst_flag, 0, (size_t)num_rendered * 4, st));
             gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib,
-                                       dL_dout_color, dL_dout_invdepth, nullptr, w.inst_grads, w.inst_flag,
+                                       dL_dout_color, dL_dout_invdepth, nullptr, w.inst_grads, w.inst_flag, num_rendered,
                                        g_render_bwd_variant, st);
         }
     }
     STAGE_CHECK("render backward blend");
     if (g_render_bwd_variant != 1 && num_rendered > 0) {
         StageTimer t(GSR_STAGE_GATHER_BWD, st);
-        gsr_launch_reduce_instances(P, g.vals[depth_order_buffer_index()], g.offsets, g.splats, w.inst_grads, w.inst_flag, sg, st);
+        gsr_launch_reduce_instances(P, num_rendered, g.vals[depth_order_buffer_index()], g.offsets, g.splats, w.inst_grads,
+                                    w.inst_flag, sg, st);
     }
     STAGE_CHECK("render backward reduce");
     HIP_OK(hipGetLastError());

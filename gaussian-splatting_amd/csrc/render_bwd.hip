@@ -2,28 +2,32 @@
 // rasterizer (algorithm SURVEY.md Appendix A.5; reached through loss.backward(), train.py:142).
 //
 // The reference issues ~10 global float atomics per contributing (pixel, Gaussian) pair.  On MI355X device-scope
-// float atomics are resolved at the memory side (8 non-coherent XCD L2s), and even one atomic set per
-// (8x8 block, Gaussian) -- the first design here, kept as variant 1 -- measured 2.46 ms on the 1 M / 1080p frame,
-// 7x the forward blend.  The default design has NO global atomics (the only run-to-run variation left is the order of
-// the four waves' ds_add_f32 into one LDS table: fp32 reassociation noise):
+// float atomics are resolved at the memory side (8 non-coherent XCD L2s): one atomic set per (8x8 block, Gaussian) -- the
+// first design here, kept as A/B variant 1 -- measured 2.46 ms on the 1 M / 1080p frame, 7x the forward blend.  The
+// default design has NO atomics of any kind, no barriers, and is BIT-REPRODUCIBLE:
 //
-//  render_bwd_tile     one 256-thread workgroup per 16x16 tile, wave w = 8x8 quadrant w.  The tile's list is walked
-//                      BACK TO FRONT in super-batches of 256 entries staged once in LDS (record + log2-scaled conic).
-//                      Each wave box-tests 64 entries at a time against its quadrant (same exact test as the forward:
-//                      a culled entry contributed to no pixel of the box, so its gradient from this box is zero),
-//                      walks the survivors (s_flbit), every lane computes its pixel's 10 per-pair values (five MOMENTS
-//                      of the pixel offset, see bwd_step, plus opacity / colour / inverse-depth terms), and the
-//                      10 values are summed over the 64 lanes with a transpose-reduce: v_permlane32_swap +
-//                      v_permlane16_swap butterflies fold four values into one register (one value per 16-lane row),
-//                      DPP row shifts finish each row -- ~27 VALU ops for 10 values instead of 60 -- and lanes 15/31/
-//                      47/63 add the row totals into the super-batch's LDS gradient table (ds_add_f32).  After the
-//                      super-batch the table (256 x 48 B) is written out as per-INSTANCE gradient records.
-//                      Each record is written at the instance's EMISSION index k = goffset[g] + (ty-miny)*w + (tx-minx)
-//                      (rectangle and goffset ride in the 4th quad of the 64-byte splat record): in emission order a
-//                      Gaussian's instances are contiguous.
-//  bwd_reduce_instances  streams each Gaussian's contiguous run of records, turns the summed moments into derivatives
-//                      with the Gaussian's conic, and writes the per-Gaussian 2-D gradient record ("splat_grads")
-//                      that preprocess.hip's fused per-Gaussian backward consumes.
+//  render_bwd_quad     one wave64 per 8x8 pixel QUADRANT of a tile, fully independent of the other three quadrants (no
+//                      workgroup barrier: round 1's workgroup-per-tile kernel, A/B variant 4, spent 35 % of its wave time
+//                      waiting for the slowest quadrant at every super-batch, and its four waves added into one LDS table
+//                      in arrival order).  The quadrant's list is walked BACK TO FRONT from its own last contributor in
+//                      batches of 64 entries: the lanes first act as Gaussian lanes (coalesced id read, 64-byte record
+//                      gather -- ids two batches ahead, records one batch ahead, as in the forward --, the same exact
+//                      box test as the forward: a culled entry contributed to no pixel of the box, so its gradient from
+//                      this box is zero), park the batch in the wave's private LDS, then walk the survivors (s_flbit);
+//                      every lane computes its pixel's 10 per-pair values (five MOMENTS of the pixel offset, see
+//                      bwd_step, plus opacity / colour / inverse-depth terms), and the 10 values are summed over the 64
+//                      lanes with a transpose-reduce: v_permlane32_swap + v_permlane16_swap butterflies fold four values
+//                      into one register (one value per 16-lane row), DPP row shifts finish each row -- ~27 VALU ops for
+//                      10 values instead of 60.  Lanes 15/31/47/63 store the row totals into the batch's LDS record
+//                      table (plain stores: a (quadrant, entry) pair is visited exactly once).  After the batch every
+//                      touched entry's 48-byte record goes to the quadrant's SLOT of the instance's EMISSION index
+//                      k = goffset[g] + (ty-miny)*w + (tx-minx) (rectangle and goffset ride in the 4th quad of the
+//                      64-byte splat record), plus one flag byte: slot_grads[quadrant][k], flags[k] byte `quadrant`.
+//  bwd_reduce_instances  in emission order a Gaussian's instances are contiguous: streams the flag words, adds the up
+//                      to four quadrant records of every instance in FIXED order, sums the runs of each Gaussian with a
+//                      segmented scan, turns the summed moments into derivatives with the Gaussian's conic, and writes
+//                      the per-Gaussian 2-D gradient record ("splat_grads") that preprocess.hip's fused per-Gaussian
+//                      backward consumes.  Every sum has a fixed association order -> two runs agree bit for bit.
 //
 // Per-Gaussian record layout ("splat_grads", float[12]; also variant 1 and the multi-GPU exchange): 0 dL/dpx 1 dL/dpy
 // (pixel units) 2 dL/dA 3 dL/dB 4 dL/dC (plain derivatives of the conic entries, power = -0.5(A dx^2 + C dy^2) - B dx dy)
@@ -181,13 +185,127 @@ __device__ __forceinline__ uint32_t emission_index(const float4 q3, uint32_t tx,
 constexpr int REC_STRIDE = 3;      // float4 per staged entry (48 B: 12-word stride, 3 coprime to 16 -> per-lane ds_read_b128 is conflict-free)
 
 // ------------------------------------------------------------------------------------------------
-// default: workgroup per tile, per-instance gradient records, no global atomics
+// default: one independent wave per 8x8 quadrant, per-(quadrant, instance) gradient records, no atomics, no barriers
 // ------------------------------------------------------------------------------------------------
-// SB = super-batch: list entries staged in LDS at a time (256: one per thread; 128 halves the LDS footprint -> more
-// resident workgroups)
-// ABLATE (measurement only, results are wrong when != 0): 1 = no cross-lane reduction / LDS adds, 2 = additionally no
-// per-pixel gradient math after the alpha evaluation
-template <int SB, int ABLATE = 0>
+__global__ void __launch_bounds__(64)
+render_bwd_quad(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                const float4* __restrict__ splats, const float* __restrict__ final_T,
+                const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                const float* __restrict__ dL_dinvdepth, float4* __restrict__ slot_grads /*[4][R] records of 3 float4*/,
+                uint8_t* __restrict__ slot_flags /*[R][4]*/, int64_t R) {
+    __shared__ float4 s_rec[64 * REC_STRIDE];   // the batch: (x, y, a2, b2 | c2, opacity, r, g | b, 1/depth, -, -)
+    __shared__ float s_grad[64 * 12];           // this quadrant's record of every entry of the batch
+    // XCD-aware mapping as in the forward: the four quadrants of a tile get workgroup ids b, b+8, b+16, b+24 -> same XCD
+    const int b = blockIdx.x;
+    const int grp = b >> 5, r32 = b & 31;
+    const int tile_local = grp * 8 + (r32 & 7);
+    const int quad = r32 >> 3;
+    if (tile_local >= n_band_tiles) return;
+    const int tile = cam.tile_y0 * cam.gx + tile_local;
+    const int tx = tile % cam.gx, ty = tile / cam.gx;
+    const int lane = threadIdx.x;
+    const int bx0 = tx * GSR_TILE + (quad & 1) * 8, by0 = ty * GSR_TILE + (quad >> 1) * 8;
+    if (bx0 >= cam.W || by0 >= cam.H) return;
+    const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
+    const bool inside = px < cam.W && py < cam.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float x0 = (float)bx0, x1 = (float)min(bx0 + 7, cam.W - 1);
+    const float y0 = (float)by0, y1 = (float)min(by0 + 7, cam.H - 1);
+    const uint2 range = ranges[tile];
+    const int64_t pix = (int64_t)py * cam.W + px;
+    const int64_t HW = (int64_t)cam.H * cam.W;
+    const float T_final = inside ? final_T[pix] : 0.f;
+    const uint32_t last_contrib = inside ? n_contrib[pix] : 0u;
+    const float dLr = inside ? dL_dpix[pix] : 0.f;
+    const float dLg = inside ? dL_dpix[HW + pix] : 0.f;
+    const float dLb = inside ? dL_dpix[2 * HW + pix] : 0.f;
+    const float dLd = (inside && dL_dinvdepth) ? dL_dinvdepth[pix] : 0.f;
+    const float Tf_bg = -T_final * (cam.bg[0] * dLr + cam.bg[1] * dLg + cam.bg[2] * dLb);
+    uint32_t mx = last_contrib;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+    // entries at list positions >= end contributed to no pixel of this quadrant: no record, flag byte stays 0
+    const uint32_t end = min(range.y - range.x, mx);
+    if (end == 0) return;
+
+    BwdPix s = {T_final, 0.f, 0.f, 0.f};
+    float4* s_grad4 = reinterpret_cast<float4*>(s_grad);
+    float4* slot = slot_grads + (int64_t)quad * R * 3;
+    const int nbatch = (int)((end + 63u) >> 6);
+    // software pipeline over the batches (each needs two dependent global loads, list id -> 64-byte record): ids are
+    // fetched two batches ahead, records one batch ahead; the survivor loop in between touches only LDS
+    auto load_id = [&](int bi) -> uint32_t {
+        const uint32_t e = (uint32_t)bi * 64u + (uint32_t)lane;
+        return (bi >= 0 && e < end) ? point_list[range.x + e] : 0xFFFFFFFFu;
+    };
+    uint32_t id_n = load_id(nbatch - 1);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 n0 = zero4, n1 = zero4, n2 = zero4, n3 = zero4;
+    if (id_n != 0xFFFFFFFFu) { n0 = splats[id_n * 4 + 0]; n1 = splats[id_n * 4 + 1]; n2 = splats[id_n * 4 + 2]; n3 = splats[id_n * 4 + 3]; }
+    id_n = load_id(nbatch - 2);
+    for (int bi = nbatch - 1; bi >= 0; --bi) {
+        const uint32_t base = (uint32_t)bi * 64u;
+        const uint32_t n = min(64u, end - base);
+        const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
+        if (id_n != 0xFFFFFFFFu) { n0 = splats[id_n * 4 + 0]; n1 = splats[id_n * 4 + 1]; n2 = splats[id_n * 4 + 2]; n3 = splats[id_n * 4 + 3]; }
+        id_n = load_id(bi - 2);
+        bool keep = false;
+        uint32_t k_emit = 0;
+        if ((uint32_t)lane < n) {
+            keep = !(min_q_over_box(q0.x, q0.y, q0.z, q0.w, q1.x, x0, x1, y0, y1) > q2.z);     // q2.z = tau
+            k_emit = emission_index(q3, (uint32_t)tx, (uint32_t)ty);
+            // staged entry with the log2-scaled conic: a2 = -0.5 log2(e) A, b2 = -log2(e) B, c2 = -0.5 log2(e) C
+            s_rec[lane * REC_STRIDE + 0] = make_float4(q0.x, q0.y, -0.5f * LOG2E * q0.z, -LOG2E * q0.w);
+            s_rec[lane * REC_STRIDE + 1] = make_float4(-0.5f * LOG2E * q1.x, q1.y, q1.z, q1.w);
+            s_rec[lane * REC_STRIDE + 2] = make_float4(q2.x, q2.w, 0.f, 0.f);
+        }
+        uint64_t mask = __ballot(keep);
+        uint64_t touched = 0ull;
+        while (mask) {
+            const int j = 63 - __builtin_clzll(mask);
+            mask &= ~(1ull << j);
+            const uint32_t pos0 = base + (uint32_t)j;          // 0-based list position
+            const float4 r0 = s_rec[j * REC_STRIDE + 0];
+            const float4 r1 = s_rec[j * REC_STRIDE + 1];
+            const float2 r2 = *reinterpret_cast<const float2*>(&s_rec[j * REC_STRIDE + 2]);
+            float g_px, g_py, g_A, g_B, g_C, g_op, g_r, g_g, g_b, g_d;     // g_px .. g_C hold the raw moments
+            const bool active = bwd_step(s, pos0 < last_contrib, pxf, pyf, Tf_bg, dLr, dLg, dLb, dLd, r0.x, r0.y, r0.z,
+                                         r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, g_px, g_py, g_A, g_B, g_C, g_op,
+                                         g_r, g_g, g_b, g_d);
+            if (__builtin_amdgcn_ballot_w64(active) == 0ull) continue;
+            // slots in lanes 15 / 31 / 47 / 63 = first / third / second / fourth argument
+            const float v0 = reduce4(g_px, g_A, g_py, g_B);     // -> slots 0,1,2,3
+            const float v1 = reduce4(g_C, g_r, g_op, g_g);      // -> slots 4,5,6,7
+            const float v2 = reduce2(g_b, g_d);                 // -> slots 8 (lane 31), 9 (lane 63)
+            if ((lane & 15) == 15) {
+                float* o = s_grad + j * 12 + (lane >> 4);
+                o[0] = v0;
+                o[4] = v1;
+                if (lane & 16) s_grad[j * 12 + 8 + (lane >> 5)] = v2;
+            }
+            touched |= 1ull << j;
+        }
+        // flush: the touched entries' records go to this quadrant's slot of their instance (emission index) + flag byte
+        if (touched) {
+            __builtin_amdgcn_wave_barrier();
+            if ((touched >> lane) & 1ull) {
+                float4* dst = slot + (int64_t)k_emit * 3;
+                dst[0] = s_grad4[lane * 3 + 0];
+                dst[1] = s_grad4[lane * 3 + 1];
+                dst[2] = s_grad4[lane * 3 + 2];
+                slot_flags[(int64_t)k_emit * 4 + quad] = 1;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+#ifdef GSR_AB_VARIANTS
+// ------------------------------------------------------------------------------------------------
+// A/B variant 4 (round 1's default): workgroup per tile, per-instance gradient records, no global atomics
+// ------------------------------------------------------------------------------------------------
+// SB = super-batch: list entries staged in LDS at a time (256: one per thread)
+template <int SB>
 __global__ void __launch_bounds__(256)
 render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                 const float4* __restrict__ splats, const float* __restrict__ final_T,
@@ -291,11 +409,6 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
                                                  r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, g_px, g_py, g_A, g_B, g_C, g_op,
                                                  g_r, g_g, g_b, g_d);
                     if (__builtin_amdgcn_ballot_w64(active) == 0ull) continue;
-                    if (ABLATE >= 1) {
-                        asm volatile("" ::"v"(g_px), "v"(g_py), "v"(g_A), "v"(g_B), "v"(g_C), "v"(g_op), "v"(g_r), "v"(g_g), "v"(g_b), "v"(g_d));
-                        if (lane == 15) s_touch[entry] = 1u;
-                        continue;
-                    }
                     // slots in lanes 15 / 31 / 47 / 63 = first / third / second / fourth argument
                     const float v0 = reduce4(g_px, g_A, g_py, g_B);     // -> slots 0,1,2,3
                     const float v1 = reduce4(g_C, g_r, g_op, g_g);      // -> slots 4,5,6,7
@@ -318,12 +431,14 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
             const uint32_t e = i / 3, part = i - e * 3;
             if (s_touch[e]) {
                 inst_grads[(int64_t)s_k[e] * 3 + part] = s_grad4[i];
-                if (part == 0) inst_flag[s_k[e]] = 1;
+                if (part == 0) inst_flag[(int64_t)s_k[e] * 4] = 1;      // quadrant slot 0 holds the whole tile's record
             }
         }
         __syncthreads();
     }
 }
+
+#endif  // GSR_AB_VARIANTS
 
 // splat_grads[g] = sum of the instance records of Gaussian g.  In emission (= depth) order a Gaussian's records are one
 // contiguous run, and the runs of 64 consecutive Gaussians of the depth order form one contiguous stream.  One
@@ -337,8 +452,8 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
 constexpr int RED_WAVES = 4;        // waves per 64-Gaussian group (1: 170 us, 4: 93 us, 8: 117 us on the bench frame)
 
 __global__ void __launch_bounds__(RED_WAVES * 64)
-bwd_reduce_instances(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
-                     const float4* __restrict__ inst_grads, const uint8_t* __restrict__ inst_flag,
+bwd_reduce_instances(int P, int64_t R, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
+                     const float4* __restrict__ slot_grads /*[4][R] records*/, const uint32_t* __restrict__ inst_flag /*[R], byte q = quadrant q*/,
                      const float4* __restrict__ splats, float4* __restrict__ splat_grads) {
     __shared__ float s_acc[RED_WAVES][64 * 12];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -357,16 +472,17 @@ bwd_reduce_instances(int P, const uint32_t* __restrict__ order, const uint32_t* 
 #pragma unroll
         for (int i = 0; i < 12; ++i) acc[lane * 12 + i] = 0.f;
     }
-    const float4* stream = inst_grads + (int64_t)base * 3;
-    // the flag of the wave's NEXT chunk is requested before the current chunk's records: the walk is a chain of
+    const float4* stream = slot_grads + (int64_t)base * 3;
+    // the flag word of the wave's NEXT chunk is requested before the current chunk's records: the walk is a chain of
     // dependent loads (flag -> record) and this takes one of the two latencies off every step
     const uint32_t first = (uint32_t)wv * 64u + (uint32_t)lane;
-    uint8_t flag_next = first < total ? inst_flag[(int64_t)base + first] : (uint8_t)0;
+    uint32_t flag_next = first < total ? inst_flag[(int64_t)base + first] : 0u;
     for (uint32_t c0 = (uint32_t)wv * 64u; c0 < total; c0 += RED_WAVES * 64u) {
         const uint32_t r = c0 + lane;
         const bool valid = r < total;
-        const bool has_rec = valid && flag_next != 0;     // untouched instances have no record
-        flag_next = (r + RED_WAVES * 64u) < total ? inst_flag[(int64_t)base + r + RED_WAVES * 64u] : (uint8_t)0;
+        const uint32_t flags = valid ? flag_next : 0u;
+        const bool has_rec = flags != 0u;                 // untouched instances have no record
+        flag_next = (r + RED_WAVES * 64u) < total ? inst_flag[(int64_t)base + r + RED_WAVES * 64u] : 0u;
         if (__ballot(has_rec) == 0ull) continue;     // e.g. far Gaussians that every pixel terminated in front of
         int lo = 0, hi = last;
 #pragma unroll
@@ -377,13 +493,17 @@ bwd_reduce_instances(int P, const uint32_t* __restrict__ order, const uint32_t* 
         }
         const int s = valid ? (lo > last ? last : lo) : 64 + lane;     // invalid lanes never merge
         float v[10];
-        if (has_rec) {
-            const float4 u0 = stream[(int64_t)r * 3 + 0], u1 = stream[(int64_t)r * 3 + 1], u2 = stream[(int64_t)r * 3 + 2];
-            v[0] = u0.x; v[1] = u0.y; v[2] = u0.z; v[3] = u0.w; v[4] = u1.x; v[5] = u1.y; v[6] = u1.z; v[7] = u1.w;
-            v[8] = u2.x; v[9] = u2.y;
-        } else {
 #pragma unroll
-            for (int i = 0; i < 10; ++i) v[i] = 0.f;
+        for (int i = 0; i < 10; ++i) v[i] = 0.f;
+        // the up to four quadrant records of the instance, added in fixed order (quadrant 0, 1, 2, 3)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if ((flags >> (8 * q)) & 0xFFu) {
+                const float4* rec = stream + ((int64_t)q * R + (int64_t)r) * 3;
+                const float4 u0 = rec[0], u1 = rec[1], u2 = rec[2];
+                v[0] += u0.x; v[1] += u0.y; v[2] += u0.z; v[3] += u0.w; v[4] += u1.x; v[5] += u1.y; v[6] += u1.z; v[7] += u1.w;
+                v[8] += u2.x; v[9] += u2.y;
+            }
         }
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -425,6 +545,7 @@ bwd_reduce_instances(int P, const uint32_t* __restrict__ order, const uint32_t* 
     }
 }
 
+#ifdef GSR_AB_VARIANTS
 // ------------------------------------------------------------------------------------------------
 // variant 1 (A/B baseline): wave per 8x8 block, DPP full-wave reductions, one global atomic set per (block, Gaussian)
 // into the per-Gaussian record
@@ -513,43 +634,47 @@ render_bwd_wave(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
     }
 }
 
-inline int stream_grid(int64_t n) {
-    int64_t b = (n + 255) / 256;
-    if (b > 4096) b = 4096;
-    if (b < 1) b = 1;
-    return (int)b;
-}
+#endif  // GSR_AB_VARIANTS
 
 }  // namespace
+
+int gsr_render_backward_variant_available(int variant) {
+#ifdef GSR_AB_VARIANTS
+    return variant == 0 || variant == 1 || variant == 4;
+#else
+    return variant == 0;
+#endif
+}
 
 void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,
                                 const float4* splats, const float* final_T, const uint32_t* n_contrib,
                                 const float* dL_dpix, const float* dL_dinvdepth, float* splat_grads, float* inst_grads,
-                                uint8_t* inst_flag, int variant, hipStream_t st) {
+                                uint32_t* inst_flag, int64_t R, int variant, hipStream_t st) {
     const int n_band_tiles = cam.gx * (cam.tile_y1 - cam.tile_y0);
     if (n_band_tiles <= 0) return;
+    const int groups = (n_band_tiles + 7) / 8;
+#ifdef GSR_AB_VARIANTS
     if (variant == 1) {
-        const int groups = (n_band_tiles + 7) / 8;
         hipLaunchKernelGGL(render_bwd_wave, dim3(groups * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list,
                            splats, final_T, n_contrib, dL_dpix, dL_dinvdepth, splat_grads);
-    } else if (variant == 11) {
-        hipLaunchKernelGGL((render_bwd_tile<256, 1>), dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats,
-                           final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads), inst_flag);
-    } else if (variant == 2) {
-        hipLaunchKernelGGL(render_bwd_tile<128>, dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats,
-                           final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads), inst_flag);
-    } else if (variant == 3) {      // 192-entry super-batches: 20 KB of LDS -> 8 workgroups per CU
-        hipLaunchKernelGGL(render_bwd_tile<192>, dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats,
-                           final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads), inst_flag);
-    } else {
-        hipLaunchKernelGGL(render_bwd_tile<256>, dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats,
-                           final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads), inst_flag);
+        return;
     }
+    if (variant == 4) {
+        hipLaunchKernelGGL(render_bwd_tile<256>, dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats,
+                           final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads),
+                           reinterpret_cast<uint8_t*>(inst_flag));
+        return;
+    }
+#endif
+    (void)variant; (void)splat_grads;
+    hipLaunchKernelGGL(render_bwd_quad, dim3(groups * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list, splats,
+                       final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads),
+                       reinterpret_cast<uint8_t*>(inst_flag), R);
 }
 
-void gsr_launch_reduce_instances(int P, const uint32_t* order, const uint32_t* offsets, const float4* splats,
-                                 const float* inst_grads, const uint8_t* inst_flag, float* splat_grads, hipStream_t st) {
+void gsr_launch_reduce_instances(int P, int64_t R, const uint32_t* order, const uint32_t* offsets, const float4* splats,
+                                 const float* inst_grads, const uint32_t* inst_flag, float* splat_grads, hipStream_t st) {
     const int64_t groups = ((int64_t)P + 63) / 64;       // one workgroup per 64 Gaussians of the depth order
-    hipLaunchKernelGGL(bwd_reduce_instances, dim3((int)groups), dim3(RED_WAVES * 64), 0, st, P, order, offsets,
+    hipLaunchKernelGGL(bwd_reduce_instances, dim3((int)groups), dim3(RED_WAVES * 64), 0, st, P, R, order, offsets,
                        reinterpret_cast<const float4*>(inst_grads), inst_flag, splats, reinterpret_cast<float4*>(splat_grads));
 }

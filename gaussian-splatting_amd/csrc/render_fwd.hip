@@ -29,6 +29,7 @@
 
 namespace {
 
+#ifdef GSR_AB_VARIANTS
 struct PixState {
     float T, C0, C1, C2, D;
     uint32_t last;
@@ -103,6 +104,8 @@ render_fwd_block(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t
         if (out_invdepth) out_invdepth[pix] = s.D;
     }
 }
+
+#endif  // GSR_AB_VARIANTS
 
 // ------------------------------------------------------------------------------------------------
 // wave per 8x8 pixel block: helpers (exact box test, cross-lane broadcast)
@@ -284,17 +287,21 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
 
 }  // namespace
 
+int gsr_render_forward_variant_available(int variant) {
+#ifdef GSR_AB_VARIANTS
+    return variant >= 0 && variant <= 3;
+#else
+    return variant == 0;
+#endif
+}
+
 void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,
                                const float4* splats, float* final_T, uint32_t* n_contrib, float* out_color,
                                float* out_invdepth, int variant, hipStream_t st) {
     const int n_band_tiles = cam.gx * (cam.tile_y1 - cam.tile_y0);
     if (n_band_tiles <= 0) return;
-    if (variant == 1) {
-        hipLaunchKernelGGL(render_fwd_block, dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats,
-                           final_T, n_contrib, out_color, out_invdepth);
-    } else {
-        const int groups = (n_band_tiles + 7) / 8;
-        const bool track = final_T != nullptr && n_contrib != nullptr;
+    const int groups = (n_band_tiles + 7) / 8;
+    const bool track = final_T != nullptr && n_contrib != nullptr;
 #define GSR_LAUNCH_BF(USE_LDS_, WPB_, GRID_, BLOCK_)                                                                              \
     do {                                                                                                                          \
         if (track)                                                                                                                \
@@ -304,12 +311,16 @@ void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const 
             hipLaunchKernelGGL((render_fwd_wave_bf<USE_LDS_, WPB_, false>), dim3(GRID_), dim3(BLOCK_), 0, st, cam, n_band_tiles,   \
                                ranges, point_list, splats, final_T, n_contrib, out_color, out_invdepth);                         \
     } while (0)
-        if (variant == 2)
-            GSR_LAUNCH_BF(false, 1, groups * 32, 64);
-        else if (variant == 3)
-            GSR_LAUNCH_BF(true, 4, n_band_tiles, 256);
-        else
-            GSR_LAUNCH_BF(true, 1, groups * 32, 64);
-#undef GSR_LAUNCH_BF
+#ifdef GSR_AB_VARIANTS
+    if (variant == 1) {
+        hipLaunchKernelGGL(render_fwd_block, dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats,
+                           final_T, n_contrib, out_color, out_invdepth);
+        return;
     }
+    if (variant == 2) { GSR_LAUNCH_BF(false, 1, groups * 32, 64); return; }
+    if (variant == 3) { GSR_LAUNCH_BF(true, 4, n_band_tiles, 256); return; }
+#endif
+    (void)variant;
+    GSR_LAUNCH_BF(true, 1, groups * 32, 64);
+#undef GSR_LAUNCH_BF
 }

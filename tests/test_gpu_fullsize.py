@@ -210,8 +210,9 @@ def test_config1_1M_1080p_backward_on_sampled_tiles():
         assert float(a.reshape(P, -1)[zero_b].abs().max()) == 0.0, f"{k}: non-zero gradient for an untouched Gaussian"
         nz = dd.reshape(P, -1)[~zero_b].flatten()
         res[k] = {"max": float(dd.max()), "p99.9": float(torch.quantile(nz[:8_000_000], 0.999)) if nz.numel() else 0.0}
-        assert res[k]["max"] < 2e-3, f"{k}: max err {res[k]['max']:.3e} (rel. to max |grad|)"
-        assert res[k]["p99.9"] < 1e-4, f"{k}: 99.9th pct err {res[k]['p99.9']:.3e}"
+        # bar: 2e-4 of max |grad| on every entry, 1e-5 at the 99.9th percentile (measured: <= 8e-6 / 4e-7)
+        assert res[k]["max"] < 2e-4, f"{k}: max err {res[k]['max']:.3e} (rel. to max |grad|)"
+        assert res[k]["p99.9"] < 1e-5, f"{k}: 99.9th pct err {res[k]['p99.9']:.3e}"
     _report("configs[1] 1M@1080p/backward", tiles=len(sample), oracle_seconds=round(t_oracle, 1),
             **{f"{k}_{m}": f"{v:.2e}" for k, r in res.items() for m, v in r.items()})
 
