@@ -62,7 +62,7 @@ scan_block_sums(int P, const uint32_t* __restrict__ order, const uint2* __restri
 // Gaussian that owns instance k * GSR_TS_ITEMS, and, one past the last block, the last Gaussian with tiles.
 __global__ void __launch_bounds__(SC_THREADS)
 scan_finish(int P, const uint2* __restrict__ rect_sorted, const uint64_t* __restrict__ block_sums,
-            uint32_t* __restrict__ offsets, uint32_t* __restrict__ block_first, uint32_t block_first_cap,
+            uint32_t* __restrict__ offsets, uint2* __restrict__ block_first, uint32_t block_first_cap,
             uint32_t* __restrict__ num_rendered, uint32_t* host_word, uint32_t seq) {
     __shared__ uint64_t wsum[SC_THREADS / 64];
     __shared__ uint64_t wtot[SC_THREADS / 64];
@@ -96,10 +96,10 @@ scan_finish(int P, const uint2* __restrict__ rect_sorted, const uint64_t* __rest
             offsets[base + k] = (uint32_t)run;
             if (v[k] && run <= 0x7FFFFFFFull) {
                 for (uint64_t b = (excl + IT - 1) / IT; b <= (run - 1) / IT; ++b)
-                    if (b < block_first_cap) block_first[b] = (uint32_t)(base + k);
+                    if (b < block_first_cap) block_first[b] = make_uint2((uint32_t)(base + k), (uint32_t)excl);
                 if (v[k + 1] == 0u) {     // counts are non-zero exactly on a prefix of the depth order: this is the last one
                     const uint64_t b = (run + IT - 1) / IT;
-                    if (b < block_first_cap) block_first[b] = (uint32_t)(base + k);
+                    if (b < block_first_cap) block_first[b] = make_uint2((uint32_t)(base + k), (uint32_t)excl);
                 }
             }
         }
@@ -260,7 +260,7 @@ void gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4
 }
 
 void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint2* rect, uint2* rect_sorted, uint32_t* offsets,
-                           uint64_t* block_sums, uint32_t* block_first, uint32_t block_first_cap, uint32_t* num_rendered,
+                           uint64_t* block_sums, uint2* block_first, uint32_t block_first_cap, uint32_t* num_rendered,
                            uint32_t* host_word, uint32_t seq, hipStream_t st) {
     const int nb = (P + GSR_SCAN_ITEMS - 1) / GSR_SCAN_ITEMS;
     hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(SC_THREADS), 0, st, P, order, rect, rect_sorted, block_sums);

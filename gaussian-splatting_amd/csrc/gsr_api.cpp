@@ -177,7 +177,7 @@ GsrGeom gsr_carve_geom(char* base, int P) {
     g.rect_sorted = (uint2*)take(n * 8);
     g.offsets = (uint32_t*)take(n * 4);
     g.block_sums = (uint64_t*)take(((n + GSR_SCAN_ITEMS - 1) / GSR_SCAN_ITEMS) * 8);
-    g.block_first = (uint32_t*)take(gsr_block_first_cap(P) * 4);
+    g.block_first = (uint2*)take(gsr_block_first_cap(P) * 8);
     g.sort_hist = (uint32_t*)take((size_t)256 * (size_t)gsr_sort_blocks((int64_t)n, true) * 4);   // small workgroups: worst case
     g.digit_total = (uint32_t*)take(256 * 4);
     g.num_rendered = (uint32_t*)take(128);
@@ -204,7 +204,7 @@ GsrBinning gsr_carve_binning(char* base, int64_t R) {
     b.bucket_base = (uint32_t*)take(257 * 4);
     b.blk2_start = (uint32_t*)take(257 * 4);
     b.tile_base = (uint32_t*)take(65536 * 4);
-    b.block_first = (uint32_t*)take((nblk + 2) * 4);
+    b.block_first = (uint2*)take((nblk + 2) * 8);
     b.meta = (uint32_t*)take(128);
     b.bytes = off;
     return b;
@@ -377,7 +377,7 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
 
     int list_buf = 0;
     if (R > 0 && plan.fused) {
-        const uint32_t* block_first = g.block_first;
+        const uint2* block_first = g.block_first;
         const int64_t nblk = (R + GSR_TS_ITEMS - 1) / GSR_TS_ITEMS;
         {   StageTimer t(GSR_STAGE_EMIT, st);
             if ((uint64_t)nblk + 1 > (uint64_t)bf_cap) {      // more than ~64 tiles per Gaussian: table sized by R instead

@@ -40,7 +40,7 @@ struct GsrGeom {                 // P-sized
     uint2* rect_sorted;          // [P]   tile rectangles in depth order (written by the scan)
     uint32_t* offsets;           // [P]   inclusive scan of tiles_touched in depth order
     uint64_t* block_sums;        // [ceil(P/GSR_SCAN_ITEMS)]
-    uint32_t* block_first;       // [gsr_block_first_cap(P)] first Gaussian (depth-order index) of every 4096-instance block
+    uint2* block_first;          // [gsr_block_first_cap(P)] per 4096-instance block: (depth-order index of its first Gaussian, instances before it)
     uint32_t* sort_hist;         // [256 * nblocks_small(P)] radix block histograms
     uint32_t* digit_total;       // [256]
     uint32_t* num_rendered;      // [1] (+ order_buf index in [1])
@@ -60,7 +60,7 @@ struct GsrBinning {              // R-sized
     uint32_t* bucket_base;       // [257]
     uint32_t* blk2_start;        // [257]
     uint32_t* tile_base;         // [65536]
-    uint32_t* block_first;       // [ceil(R / GSR_TS_ITEMS) + 2]  (fallback table, see gsr_block_first_cap)
+    uint2* block_first;          // [ceil(R / GSR_TS_ITEMS) + 2]  (fallback table, see gsr_block_first_cap)
     uint32_t* meta;
     size_t bytes;
 };
@@ -107,7 +107,7 @@ static inline int64_t gsr_sort_blocks(int64_t n, bool small_blocks) {
 // binning.hip: scan of tiles_touched in depth order, instance emission, tile ranges
 // host_word (mapped pinned, may be NULL): [0] = R low word, [2] = R high word, [1] = seq (stored last)
 void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint2* rect, uint2* rect_sorted /*[P]*/, uint32_t* offsets,
-                           uint64_t* block_sums, uint32_t* block_first, uint32_t block_first_cap, uint32_t* num_rendered,
+                           uint64_t* block_sums, uint2* block_first, uint32_t block_first_cap, uint32_t* num_rendered,
                            uint32_t* host_word, uint32_t seq, hipStream_t st);
 // legacy emission (frames with more than 65536 tiles): 32-bit tile ids
 void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect_sorted,
@@ -117,8 +117,8 @@ void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offse
 // tilesort.hip: fused emission + two-level stable tile sort + ranges (frames with <= 65536 tiles)
 struct GsrTileSortPlan { bool fused; int lb, hb; bool word64; };
 void gsr_tile_sort_plan(int n_tiles, int P, GsrTileSortPlan* plan);
-void gsr_launch_fill_block_first(int P, const uint32_t* offsets, uint32_t* block_first, uint32_t cap, hipStream_t st);
-void gsr_launch_tile_sort_level1(const GsrTileSortPlan& plan, int64_t R, int gx, const uint32_t* block_first,
+void gsr_launch_fill_block_first(int P, const uint32_t* offsets, uint2* block_first, uint32_t cap, hipStream_t st);
+void gsr_launch_tile_sort_level1(const GsrTileSortPlan& plan, int64_t R, int gx, const uint2* block_first,
                                  const uint32_t* offsets, const uint2* rect_sorted, const uint32_t* order, void* words,
                                  uint32_t* hist1, uint32_t* digit_total, uint32_t* bucket_base, uint32_t* blk2_start,
                                  float4* splats /*NULL: inference*/, hipStream_t st);

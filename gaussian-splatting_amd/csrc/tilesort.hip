@@ -50,19 +50,32 @@ template <> struct Pack<uint64_t> {
 // ---------------------------------------------------------------------------------------------------------------
 // Generation of the workgroup's 4096 instances.  Wave w owns the contiguous run [w*1024, w*1024+1024) of the block's
 // slots, item r of a lane is slot w*1024 + r*64 + lane (so ranking in (r, lane) order is emission order).
-// s_incl: LDS, inclusive tile-count prefixes of the block's Gaussians [j_lo, j_hi].
-// Returns in tile[r] the tile id, in gj[r] the depth-order index of the owning Gaussian, vmask bit r = slot < R.
+// The block's Gaussians [j_lo, j_hi] come from the per-block table the scan kernel writes (first Gaussian + the number of
+// instances emitted before it); their inclusive prefixes, rectangles and (WANT_ID) ids are staged in LDS with coalesced
+// loads, so the only dependent global round trips of the kernel are table -> staging (the first version gathered
+// rectangle and id per instance after the search: two more dependent trips, and the kernel was latency-bound).
+// Returns in tile[r] the tile id, in id[r] the Gaussian id (WANT_ID), vmask bit r = slot < R.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void generate_instances(uint32_t R, int gx, const uint32_t* __restrict__ block_first,
+constexpr int TS_NGCAP = 1024;      // Gaussians per block whose rectangle / id are staged in LDS (beyond: global gather)
+
+template <bool WANT_ID>
+__device__ __forceinline__ void generate_instances(uint32_t R, int gx, const uint2* __restrict__ block_first,
                                                    const uint32_t* __restrict__ offsets, const uint2* __restrict__ rect_sorted,
-                                                   uint32_t* s_incl, uint32_t& j_lo_out, int& nG_out, uint32_t& base_excl_out,
-                                                   uint32_t (&tile)[TS_IPT], uint32_t (&gj)[TS_IPT], uint32_t& vmask) {
+                                                   const uint32_t* __restrict__ order, uint32_t* s_incl, uint2* s_rect,
+                                                   uint32_t* s_id, uint32_t& j_lo_out, int& nG_out, uint32_t& base_excl_out,
+                                                   uint32_t (&tile)[TS_IPT], uint32_t (&id)[TS_IPT], uint32_t& vmask) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t b = blockIdx.x;
-    const uint32_t j_lo = block_first[b], j_hi = block_first[b + 1];
+    const uint2 d0 = block_first[b];
+    const uint32_t j_lo = d0.x, base_excl = d0.y, j_hi = block_first[b + 1].x;
     const int nG = (int)(j_hi - j_lo) + 1;                       // <= TS_ITEMS + 1
-    const uint32_t base_excl = j_lo ? offsets[j_lo - 1] : 0u;    // instances emitted before Gaussian j_lo
-    for (int i = tid; i < nG; i += WG_THREADS) s_incl[i] = offsets[j_lo + i];
+    for (int i = tid; i < nG; i += WG_THREADS) {
+        s_incl[i] = offsets[j_lo + i];
+        if (i < TS_NGCAP) {
+            s_rect[i] = rect_sorted[j_lo + i];
+            if (WANT_ID) s_id[i] = order[j_lo + i];
+        }
+    }
     __syncthreads();
     const uint32_t s0 = b * (uint32_t)TS_ITEMS + (uint32_t)w * (64u * TS_IPT) + (uint32_t)lane;
     const int steps = nG > 1 ? 32 - __clz(nG - 1) : 0;           // wave-uniform
@@ -90,12 +103,12 @@ __device__ __forceinline__ void generate_instances(uint32_t R, int gx, const uin
     for (int r = 0; r < TS_IPT; ++r) {
         const int i = lo[r] < nG ? lo[r] : nG - 1;
         const uint32_t excl = i ? s_incl[i - 1] : base_excl;
-        const uint2 rc = rect_sorted[j_lo + i];
+        const uint2 rc = i < TS_NGCAP ? s_rect[i] : rect_sorted[j_lo + i];
+        if (WANT_ID) id[r] = i < TS_NGCAP ? s_id[i] : order[j_lo + i];
         const uint32_t minx = rc.x & 0xFFFFu, wd = (rc.x >> 16) - minx, miny = rc.y & 0xFFFFu;
         uint32_t rx;
         const uint32_t ry = div_small(kk[r] - excl, wd ? wd : 1u, rx);
         tile[r] = (miny + ry) * (uint32_t)gx + minx + rx;
-        gj[r] = j_lo + (uint32_t)i;
     }
     j_lo_out = j_lo;
     nG_out = nG;
@@ -104,15 +117,17 @@ __device__ __forceinline__ void generate_instances(uint32_t R, int gx, const uin
 
 // level 1 histogram: hist[d * nblk + block] = instances of the block whose tile id >> lb == d
 __global__ void __launch_bounds__(WG_THREADS)
-emit_hist(uint32_t R, int gx, int lb, int nb1, const uint32_t* __restrict__ block_first, const uint32_t* __restrict__ offsets,
+emit_hist(uint32_t R, int gx, int lb, int nb1, const uint2* __restrict__ block_first, const uint32_t* __restrict__ offsets,
           const uint2* __restrict__ rect_sorted, uint32_t* __restrict__ hist, int nblk) {
     __shared__ uint32_t s_incl[TS_ITEMS + 1];
+    __shared__ uint2 s_rect[TS_NGCAP];
     __shared__ uint32_t h[TS_MAXBINS];
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid < nb1) h[tid] = 0;        // (the barrier inside generate_instances orders this before the adds)
-    uint32_t tile[TS_IPT], gj[TS_IPT], vmask, j_lo, base_excl;
+    uint32_t tile[TS_IPT], unused_id[TS_IPT], vmask, j_lo, base_excl;
     int nG;
-    generate_instances(R, gx, block_first, offsets, rect_sorted, s_incl, j_lo, nG, base_excl, tile, gj, vmask);
+    generate_instances<false>(R, gx, block_first, offsets, rect_sorted, nullptr, s_incl, s_rect, nullptr, j_lo, nG, base_excl, tile,
+                              unused_id, vmask);
     // consecutive slots are consecutive tiles of one rectangle row: they share the bucket, so equal-bucket RUNS are
     // added with one LDS atomic at the run head instead of one per instance
 #pragma unroll
@@ -191,34 +206,48 @@ __device__ __forceinline__ void local_stable_sort(const WordT (&word)[TS_IPT], c
 // level 1 scatter (+ first-emission indices for the backward, + the bucket tables of level 2 from block 0)
 template <typename WordT>
 __global__ void __launch_bounds__(WG_THREADS)
-emit_scatter(uint32_t R, int gx, int lb, int hb, const uint32_t* __restrict__ block_first, const uint32_t* __restrict__ offsets,
+emit_scatter(uint32_t R, int gx, int lb, int hb, const uint2* __restrict__ block_first, const uint32_t* __restrict__ offsets,
              const uint2* __restrict__ rect_sorted, const uint32_t* __restrict__ order, const uint32_t* __restrict__ hist,
              const uint32_t* __restrict__ digit_total, int nblk, WordT* __restrict__ words_out,
              uint32_t* __restrict__ bucket_base /*[nb1+1]*/, uint32_t* __restrict__ blk2_start /*[nb1+1]*/,
              float4* __restrict__ splats /*NULL: inference, no first-emission write*/) {
-    __shared__ uint32_t s_incl[TS_ITEMS + 1];
+    // LDS: the generation phase (prefixes, rectangles, ids of the block's Gaussians) and the sorting phase (words staged
+    // in bucket order) never overlap in time, so they share one region
+    constexpr int GEN_BYTES = ((TS_ITEMS + 1) * 4 + 15) / 16 * 16 + TS_NGCAP * 8 + TS_NGCAP * 4;
+    constexpr int SORT_BYTES = TS_ITEMS * (int)sizeof(WordT) + TS_ITEMS;
+    constexpr int SMEM_BYTES = GEN_BYTES > SORT_BYTES ? GEN_BYTES : SORT_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
     __shared__ uint32_t wave_cnt[WG_WAVES][TS_MAXBINS];
     __shared__ uint32_t digit_base[TS_MAXBINS];
     __shared__ uint32_t wsum[WG_WAVES];
-    __shared__ WordT s_word[TS_ITEMS];
-    __shared__ uint8_t s_dig[TS_ITEMS];
+    uint32_t* s_incl = reinterpret_cast<uint32_t*>(smem);
+    uint2* s_rect = reinterpret_cast<uint2*>(smem + ((TS_ITEMS + 1) * 4 + 15) / 16 * 16);
+    uint32_t* s_id = reinterpret_cast<uint32_t*>(s_rect + TS_NGCAP);
+    WordT* s_word = reinterpret_cast<WordT*>(smem);
+    uint8_t* s_dig = smem + TS_ITEMS * sizeof(WordT);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nb1 = 1 << hb;
-    uint32_t tile[TS_IPT], gj[TS_IPT], vmask, j_lo, base_excl;
+    // independent of everything else: requested first
+    const uint32_t my_total = tid < nb1 ? digit_total[tid] : 0u;
+    const uint32_t my_hist = tid < nb1 ? hist[(int64_t)tid * nblk + blockIdx.x] : 0u;
+    uint32_t tile[TS_IPT], id[TS_IPT], vmask, j_lo, base_excl;
     int nG;
-    generate_instances(R, gx, block_first, offsets, rect_sorted, s_incl, j_lo, nG, base_excl, tile, gj, vmask);
+    generate_instances<true>(R, gx, block_first, offsets, rect_sorted, order, s_incl, s_rect, s_id, j_lo, nG, base_excl, tile, id,
+                             vmask);
     if (splats) {
         // first emission index of every Gaussian whose first instance lies in this block -> 4th quad of its splat record
         // (the blend backward writes its per-instance gradient records at emission indices, render_bwd.hip)
         const uint32_t b0 = blockIdx.x * (uint32_t)TS_ITEMS;
         for (int i = tid; i < nG; i += WG_THREADS) {
             const uint32_t excl = i ? s_incl[i - 1] : base_excl;
-            if (excl >= b0 && excl - b0 < (uint32_t)TS_ITEMS && s_incl[i] > excl)
-                reinterpret_cast<uint32_t*>(splats + (int64_t)order[j_lo + i] * 4 + 3)[2] = excl;
+            if (excl >= b0 && excl - b0 < (uint32_t)TS_ITEMS && s_incl[i] > excl) {
+                const uint32_t gid = i < TS_NGCAP ? s_id[i] : order[j_lo + i];
+                reinterpret_cast<uint32_t*>(splats + (int64_t)gid * 4 + 3)[2] = excl;
+            }
         }
     }
     // global base of bucket d for this block = exclusive scan of the bucket totals + instances of earlier blocks
-    uint32_t tot[1] = {tid < nb1 ? digit_total[tid] : 0u};
+    uint32_t tot[1] = {my_total};
     const uint32_t bbase = block_excl_scan<1>(tot, wsum, lane, w);
     if (blockIdx.x == 0) {
         // level-2 plan: bucket d occupies [bucket_base[d], bucket_base[d+1]) of the word array and gets
@@ -234,18 +263,18 @@ emit_scatter(uint32_t R, int gx, int lb, int hb, const uint32_t* __restrict__ bl
             }
         }
     }
-    const uint32_t my_base = tid < nb1 ? bbase + hist[(int64_t)tid * nblk + blockIdx.x] : 0u;
     WordT word[TS_IPT];
     uint32_t digit[TS_IPT];
     const uint32_t lomask = (1u << lb) - 1u;
 #pragma unroll
     for (int r = 0; r < TS_IPT; ++r) {
         const bool valid = (vmask >> r) & 1u;
-        const uint32_t id = valid ? order[gj[r]] : 0u;
-        word[r] = Pack<WordT>::make(id, tile[r] & lomask, lb);
+        word[r] = Pack<WordT>::make(valid ? id[r] : 0u, tile[r] & lomask, lb);
         digit[r] = valid ? (tile[r] >> lb) : 0u;
     }
-    local_stable_sort<WordT>(word, digit, vmask, hb, nb1, my_base, wave_cnt, digit_base, wsum, s_word, s_dig);
+    // (the barriers at the top of local_stable_sort separate the last read of the generation arrays from the first write
+    // of the word staging that shares their LDS)
+    local_stable_sort<WordT>(word, digit, vmask, hb, nb1, bbase + my_hist, wave_cnt, digit_base, wsum, s_word, s_dig);
     const uint32_t b0 = blockIdx.x * (uint32_t)TS_ITEMS;
     const uint32_t nvalid = R - b0 < (uint32_t)TS_ITEMS ? R - b0 : (uint32_t)TS_ITEMS;
 #pragma unroll
@@ -377,15 +406,15 @@ bucket_scatter(int lb, int hb, const WordT* __restrict__ words, const uint32_t* 
 // Fallback for frames whose instance count exceeds the capacity of the per-block table the scan kernel fills
 // (more than 64 tiles per Gaussian on average): the same table, sized by R, from the finished offsets.
 __global__ void __launch_bounds__(WG_THREADS)
-fill_block_first(int P, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ block_first, uint32_t cap) {
+fill_block_first(int P, const uint32_t* __restrict__ offsets, uint2* __restrict__ block_first, uint32_t cap) {
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < P; j += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t incl = offsets[j], excl = j ? offsets[j - 1] : 0u;
         if (incl == excl) continue;
         for (uint32_t k = (excl + TS_ITEMS - 1u) / TS_ITEMS; k <= (incl - 1u) / TS_ITEMS; ++k)
-            if (k < cap) block_first[k] = (uint32_t)j;
+            if (k < cap) block_first[k] = make_uint2((uint32_t)j, excl);
         if (j == (int64_t)P - 1 || offsets[j + 1] == incl) {
             const uint32_t k = (incl + TS_ITEMS - 1u) / TS_ITEMS;
-            if (k < cap) block_first[k] = (uint32_t)j;
+            if (k < cap) block_first[k] = make_uint2((uint32_t)j, excl);
         }
     }
 }
@@ -401,13 +430,13 @@ void gsr_tile_sort_plan(int n_tiles, int P, GsrTileSortPlan* plan) {
     plan->word64 = ((unsigned long long)(P > 0 ? P : 1) << plan->lb) > (1ull << 32);
 }
 
-void gsr_launch_fill_block_first(int P, const uint32_t* offsets, uint32_t* block_first, uint32_t cap, hipStream_t st) {
+void gsr_launch_fill_block_first(int P, const uint32_t* offsets, uint2* block_first, uint32_t cap, hipStream_t st) {
     int64_t nb = ((int64_t)P + WG_THREADS - 1) / WG_THREADS;
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(fill_block_first, dim3((int)nb), dim3(WG_THREADS), 0, st, P, offsets, block_first, cap);
 }
 
-void gsr_launch_tile_sort_level1(const GsrTileSortPlan& plan, int64_t R, int gx, const uint32_t* block_first,
+void gsr_launch_tile_sort_level1(const GsrTileSortPlan& plan, int64_t R, int gx, const uint2* block_first,
                                  const uint32_t* offsets, const uint2* rect_sorted, const uint32_t* order, void* words,
                                  uint32_t* hist1, uint32_t* digit_total, uint32_t* bucket_base, uint32_t* blk2_start,
                                  float4* splats, hipStream_t st) {
