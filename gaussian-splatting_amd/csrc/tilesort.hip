@@ -48,86 +48,114 @@ template <> struct Pack<uint64_t> {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// Generation of the workgroup's 4096 instances.  Wave w owns the contiguous run [w*1024, w*1024+1024) of the block's
-// slots, item r of a lane is slot w*1024 + r*64 + lane (so ranking in (r, lane) order is emission order).
+// Generation of the workgroup's 4096 instances (a load-balanced expansion of the block's Gaussians).
+// Wave w owns the contiguous run [w*1024, w*1024+1024) of the block's slots, item r of a lane is slot
+// w*1024 + r*64 + lane (so ranking in (r, lane) order is emission order).
 // The block's Gaussians [j_lo, j_hi] come from the per-block table the scan kernel writes (first Gaussian + the number of
-// instances emitted before it); their inclusive prefixes, rectangles and (WANT_ID) ids are staged in LDS with coalesced
-// loads, so the only dependent global round trips of the kernel are table -> staging (the first version gathered
-// rectangle and id per instance after the search: two more dependent trips, and the kernel was latency-bound).
+// instances emitted before it).  Every Gaussian marks the slot of its first instance with its local index; a workgroup
+// MAX-SCAN over the 4096 slots then gives every slot its owner (the first version ran a 12-step binary search per
+// instance: 960 VALU instructions per lane against ~100 here -- the level-1 kernels were VALU-bound on it).  The owner's
+// (first slot, rectangle, id) record is staged in LDS with coalesced loads, so the only dependent global round trips of
+// the kernel are table -> staging.
 // Returns in tile[r] the tile id, in id[r] the Gaussian id (WANT_ID), vmask bit r = slot < R.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int TS_NGCAP = 1024;      // Gaussians per block whose rectangle / id are staged in LDS (beyond: global gather)
+constexpr int TS_NGCAP = 1024;      // Gaussians per block whose record is staged in LDS (beyond: global fetch)
 
 template <bool WANT_ID>
 __device__ __forceinline__ void generate_instances(uint32_t R, int gx, const uint2* __restrict__ block_first,
                                                    const uint32_t* __restrict__ offsets, const uint2* __restrict__ rect_sorted,
-                                                   const uint32_t* __restrict__ order, uint32_t* s_incl, uint2* s_rect,
-                                                   uint32_t* s_id, uint32_t& j_lo_out, int& nG_out, uint32_t& base_excl_out,
+                                                   const uint32_t* __restrict__ order, uint16_t* s_own /*[TS_ITEMS]*/,
+                                                   uint4* s_g4 /*[TS_NGCAP]*/, uint32_t* wsum /*[4]*/, float4* splats,
                                                    uint32_t (&tile)[TS_IPT], uint32_t (&id)[TS_IPT], uint32_t& vmask) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t b = blockIdx.x;
     const uint2 d0 = block_first[b];
     const uint32_t j_lo = d0.x, base_excl = d0.y, j_hi = block_first[b + 1].x;
     const int nG = (int)(j_hi - j_lo) + 1;                       // <= TS_ITEMS + 1
+    const uint32_t b0 = b * (uint32_t)TS_ITEMS;
+    uint4* own4 = reinterpret_cast<uint4*>(s_own);               // thread t scans slots [16t, 16t+16) = own4[2t], own4[2t+1]
+    own4[2 * tid] = make_uint4(0u, 0u, 0u, 0u);
+    own4[2 * tid + 1] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
     for (int i = tid; i < nG; i += WG_THREADS) {
-        s_incl[i] = offsets[j_lo + i];
-        if (i < TS_NGCAP) {
-            s_rect[i] = rect_sorted[j_lo + i];
-            if (WANT_ID) s_id[i] = order[j_lo + i];
+        const uint32_t excl = i ? offsets[j_lo + i - 1] : base_excl;
+        const uint2 rc = rect_sorted[j_lo + i];
+        const uint32_t gid = (WANT_ID || splats) ? order[j_lo + i] : 0u;
+        if (i < TS_NGCAP) s_g4[i] = make_uint4(excl, rc.x, rc.y, gid);
+        const uint32_t pos = excl > b0 ? excl - b0 : 0u;         // only the first Gaussian can start before the block
+        if (pos < (uint32_t)TS_ITEMS) {
+            s_own[pos] = (uint16_t)i;
+            // first emission index of every Gaussian whose first instance lies in this block -> 4th quad of its splat
+            // record (the blend backward writes its per-instance gradient records at emission indices, render_bwd.hip)
+            if (splats && excl >= b0) reinterpret_cast<uint32_t*>(splats + (int64_t)gid * 4 + 3)[2] = excl;
         }
     }
     __syncthreads();
-    const uint32_t s0 = b * (uint32_t)TS_ITEMS + (uint32_t)w * (64u * TS_IPT) + (uint32_t)lane;
-    const int steps = nG > 1 ? 32 - __clz(nG - 1) : 0;           // wave-uniform
-    uint32_t kk[TS_IPT];
-    int lo[TS_IPT], hi[TS_IPT];
+    {   // inclusive max-scan of the owner marks over the block's 4096 slots
+        const uint4 a0 = own4[2 * tid], a1 = own4[2 * tid + 1];
+        const uint32_t a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        uint32_t m[16];
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            run = max(run, a[k] & 0xFFFFu); m[2 * k] = run;
+            run = max(run, a[k] >> 16); m[2 * k + 1] = run;
+        }
+        uint32_t incl = run;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64);
+            if (lane >= off) incl = max(incl, t);
+        }
+        if (lane == 63) wsum[w] = incl;
+        uint32_t pre = (uint32_t)__shfl_up((int)incl, 1, 64);
+        if (lane == 0) pre = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < WG_WAVES; ++k)
+            if (k < w) pre = max(pre, wsum[k]);
+        uint32_t o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = max(pre, m[2 * k]) | (max(pre, m[2 * k + 1]) << 16);
+        own4[2 * tid] = make_uint4(o[0], o[1], o[2], o[3]);
+        own4[2 * tid + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+    __syncthreads();
+    const uint32_t s0 = (uint32_t)w * (64u * TS_IPT) + (uint32_t)lane;     // slot of item 0 inside the block
     vmask = 0;
 #pragma unroll
     for (int r = 0; r < TS_IPT; ++r) {
-        const uint32_t k = s0 + (uint32_t)r * 64u;
+        const uint32_t slot = s0 + (uint32_t)r * 64u;
+        const uint32_t k = b0 + slot;
         if (k < R) vmask |= 1u << r;
-        kk[r] = k < R ? k : R - 1u;
-        lo[r] = 0;
-        hi[r] = nG - 1;
-    }
-    // owner = first Gaussian whose inclusive prefix exceeds the slot index: 16 independent binary searches per lane,
-    // one LDS read per step each (the reads of a step are all in flight together)
-    for (int s = 0; s < steps; ++s) {
-#pragma unroll
-        for (int r = 0; r < TS_IPT; ++r) {
-            const int mid = (lo[r] + hi[r]) >> 1;
-            if (s_incl[mid] > kk[r]) hi[r] = mid; else lo[r] = mid + 1;
+        const uint32_t i = s_own[slot];
+        uint4 g;
+        if (i < (uint32_t)TS_NGCAP) {
+            g = s_g4[i];
+        } else {
+            const uint2 rc = rect_sorted[j_lo + i];
+            g = make_uint4(offsets[j_lo + i - 1], rc.x, rc.y, WANT_ID ? order[j_lo + i] : 0u);
         }
-    }
-#pragma unroll
-    for (int r = 0; r < TS_IPT; ++r) {
-        const int i = lo[r] < nG ? lo[r] : nG - 1;
-        const uint32_t excl = i ? s_incl[i - 1] : base_excl;
-        const uint2 rc = i < TS_NGCAP ? s_rect[i] : rect_sorted[j_lo + i];
-        if (WANT_ID) id[r] = i < TS_NGCAP ? s_id[i] : order[j_lo + i];
-        const uint32_t minx = rc.x & 0xFFFFu, wd = (rc.x >> 16) - minx, miny = rc.y & 0xFFFFu;
+        if (WANT_ID) id[r] = g.w;
+        const uint32_t minx = g.y & 0xFFFFu, wd = (g.y >> 16) - minx, miny = g.z & 0xFFFFu;
         uint32_t rx;
-        const uint32_t ry = div_small(kk[r] - excl, wd ? wd : 1u, rx);
+        const uint32_t ry = div_small((k < R ? k : R - 1u) - g.x, wd ? wd : 1u, rx);
         tile[r] = (miny + ry) * (uint32_t)gx + minx + rx;
     }
-    j_lo_out = j_lo;
-    nG_out = nG;
-    base_excl_out = base_excl;
 }
 
 // level 1 histogram: hist[d * nblk + block] = instances of the block whose tile id >> lb == d
 __global__ void __launch_bounds__(WG_THREADS)
 emit_hist(uint32_t R, int gx, int lb, int nb1, const uint2* __restrict__ block_first, const uint32_t* __restrict__ offsets,
           const uint2* __restrict__ rect_sorted, uint32_t* __restrict__ hist, int nblk) {
-    __shared__ uint32_t s_incl[TS_ITEMS + 1];
-    __shared__ uint2 s_rect[TS_NGCAP];
+    __shared__ __attribute__((aligned(16))) uint16_t s_own[TS_ITEMS];
+    __shared__ uint4 s_g4[TS_NGCAP];
+    __shared__ uint32_t wsum[WG_WAVES];
     __shared__ uint32_t h[TS_MAXBINS];
     const int tid = threadIdx.x, lane = tid & 63;
-    if (tid < nb1) h[tid] = 0;        // (the barrier inside generate_instances orders this before the adds)
-    uint32_t tile[TS_IPT], unused_id[TS_IPT], vmask, j_lo, base_excl;
-    int nG;
-    generate_instances<false>(R, gx, block_first, offsets, rect_sorted, nullptr, s_incl, s_rect, nullptr, j_lo, nG, base_excl, tile,
-                              unused_id, vmask);
+    if (tid < nb1) h[tid] = 0;        // (the barriers inside generate_instances order this before the adds)
+    uint32_t tile[TS_IPT], unused_id[TS_IPT], vmask;
+    generate_instances<false>(R, gx, block_first, offsets, rect_sorted, nullptr, s_own, s_g4, wsum, nullptr, tile, unused_id, vmask);
     // consecutive slots are consecutive tiles of one rectangle row: they share the bucket, so equal-bucket RUNS are
     // added with one LDS atomic at the run head instead of one per instance
 #pragma unroll
@@ -211,18 +239,17 @@ emit_scatter(uint32_t R, int gx, int lb, int hb, const uint2* __restrict__ block
              const uint32_t* __restrict__ digit_total, int nblk, WordT* __restrict__ words_out,
              uint32_t* __restrict__ bucket_base /*[nb1+1]*/, uint32_t* __restrict__ blk2_start /*[nb1+1]*/,
              float4* __restrict__ splats /*NULL: inference, no first-emission write*/) {
-    // LDS: the generation phase (prefixes, rectangles, ids of the block's Gaussians) and the sorting phase (words staged
-    // in bucket order) never overlap in time, so they share one region
-    constexpr int GEN_BYTES = ((TS_ITEMS + 1) * 4 + 15) / 16 * 16 + TS_NGCAP * 8 + TS_NGCAP * 4;
+    // LDS: the generation phase (owner marks, records of the block's Gaussians) and the sorting phase (words staged in
+    // bucket order) never overlap in time, so they share one region
+    constexpr int GEN_BYTES = TS_ITEMS * 2 + TS_NGCAP * 16;
     constexpr int SORT_BYTES = TS_ITEMS * (int)sizeof(WordT) + TS_ITEMS;
     constexpr int SMEM_BYTES = GEN_BYTES > SORT_BYTES ? GEN_BYTES : SORT_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
     __shared__ uint32_t wave_cnt[WG_WAVES][TS_MAXBINS];
     __shared__ uint32_t digit_base[TS_MAXBINS];
     __shared__ uint32_t wsum[WG_WAVES];
-    uint32_t* s_incl = reinterpret_cast<uint32_t*>(smem);
-    uint2* s_rect = reinterpret_cast<uint2*>(smem + ((TS_ITEMS + 1) * 4 + 15) / 16 * 16);
-    uint32_t* s_id = reinterpret_cast<uint32_t*>(s_rect + TS_NGCAP);
+    uint16_t* s_own = reinterpret_cast<uint16_t*>(smem);
+    uint4* s_g4 = reinterpret_cast<uint4*>(smem + TS_ITEMS * 2);
     WordT* s_word = reinterpret_cast<WordT*>(smem);
     uint8_t* s_dig = smem + TS_ITEMS * sizeof(WordT);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -230,22 +257,8 @@ emit_scatter(uint32_t R, int gx, int lb, int hb, const uint2* __restrict__ block
     // independent of everything else: requested first
     const uint32_t my_total = tid < nb1 ? digit_total[tid] : 0u;
     const uint32_t my_hist = tid < nb1 ? hist[(int64_t)tid * nblk + blockIdx.x] : 0u;
-    uint32_t tile[TS_IPT], id[TS_IPT], vmask, j_lo, base_excl;
-    int nG;
-    generate_instances<true>(R, gx, block_first, offsets, rect_sorted, order, s_incl, s_rect, s_id, j_lo, nG, base_excl, tile, id,
-                             vmask);
-    if (splats) {
-        // first emission index of every Gaussian whose first instance lies in this block -> 4th quad of its splat record
-        // (the blend backward writes its per-instance gradient records at emission indices, render_bwd.hip)
-        const uint32_t b0 = blockIdx.x * (uint32_t)TS_ITEMS;
-        for (int i = tid; i < nG; i += WG_THREADS) {
-            const uint32_t excl = i ? s_incl[i - 1] : base_excl;
-            if (excl >= b0 && excl - b0 < (uint32_t)TS_ITEMS && s_incl[i] > excl) {
-                const uint32_t gid = i < TS_NGCAP ? s_id[i] : order[j_lo + i];
-                reinterpret_cast<uint32_t*>(splats + (int64_t)gid * 4 + 3)[2] = excl;
-            }
-        }
-    }
+    uint32_t tile[TS_IPT], id[TS_IPT], vmask;
+    generate_instances<true>(R, gx, block_first, offsets, rect_sorted, order, s_own, s_g4, wsum, splats, tile, id, vmask);
     // global base of bucket d for this block = exclusive scan of the bucket totals + instances of earlier blocks
     uint32_t tot[1] = {my_total};
     const uint32_t bbase = block_excl_scan<1>(tot, wsum, lane, w);
@@ -349,8 +362,18 @@ bucket_scan(int lb, int n_tiles, const uint32_t* __restrict__ bucket_base, const
     if (tid < nb2) {
         uint32_t run = 0;
         uint32_t* col = hist2 + tid;
-#pragma unroll 4
-        for (uint32_t b = s; b < e; ++b) {
+        uint32_t b = s;
+        for (; b + 8 <= e; b += 8) {        // eight independent loads in flight, then the eight prefixes
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = col[(int64_t)(b + k) * nb2];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                col[(int64_t)(b + k) * nb2] = run;
+                run += v[k];
+            }
+        }
+        for (; b < e; ++b) {
             const uint32_t v = col[(int64_t)b * nb2];
             col[(int64_t)b * nb2] = run;
             run += v;
