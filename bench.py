@@ -12,9 +12,17 @@ frame is split into N bands of tile rows (strong scaling), every rank renders it
 all-gathered over RCCL; value = W*H / (max-over-ranks time per frame).
 
 The JSON line also carries
-  train_iters_per_s : forward + L1 loss + backward + Adam on all parameters (same scene), steps/s
-  roofline          : the dominant kernel (forward blend), algorithmic bytes / its mean duration from HIP events
-                      recorded on the launch stream by the library (gsr_profile_*), against the 8 TB/s HBM peak
+  train_iters_per_s : forward + loss + backward + Adam on all parameters, a NEW CAMERA EVERY ITERATION (train.py:96-102:
+                      --views synthetic cameras around the generating one, cycled), steps/s; legs for the dense fused Adam,
+                      for the reference's accelerated call form (SparseGaussianAdam + separate SH tensors,
+                      train.py:37-41,180-183) and for L1 only
+  stages            : every pipeline stage with its mean HIP-event duration, algorithmic bytes (SURVEY.md 8(d) terms) and
+                      the GB/s / fraction of 8 TB/s that gives
+  roofline          : the dominant kernel of the forward (the blend).  It is fp32-VALU bound (SQ counters: VALU issue, not
+                      memory, limits it), so `bound` = "valu": achieved = evaluated (pixel, Gaussian) pair-steps counted by
+                      the kernel itself x 25 FLOP / its HIP-event duration, against the 157.3 TFLOP/s fp32
+                      vector peak; the HBM view (algorithmic bytes, GB/s, PMC traffic) rides along under "hbm"
+  roofline_train    : the same for the dominant kernel of the train step (the blend backward)
   cpu_baseline      : the pure-PyTorch CPU oracle on this host's cores, on a bounded sample of the same frame
 """
 from __future__ import annotations
@@ -63,21 +71,42 @@ def parse():
     ap.add_argument("--sort-items", type=int, default=0, help="keys per workgroup of the large radix passes (1024 / 2048 / 4096; 0 = library default)")
     ap.add_argument("--bwd-variant", type=int, default=0, help="render_bwd_variant (0 default, 1 atomics baseline, 2 128-entry super-batches)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="gsr_set_option(NAME, VALUE) before timing (A/B switches)")
+    ap.add_argument("--views", type=int, default=32, help="training views cycled by the train legs (1 = the static camera of round 1)")
     return ap.parse_args()
 
 
-def algorithmic_bytes(P, V, R, T, npix, M=16):
-    """B_fwd, inference layout, sort counted as one read + one write of 12-byte pairs."""
-    pre_in = 12 * P + V * (32 + 12 * M)
-    pre_out = 8 * P + 40 * V
+def algorithmic_bytes(P, V, R, T, npix, M=16, track=False):
+    """SURVEY.md 8(d) B_fwd, term by term (inference layout unless track; sort counted as one read + one write of 12-byte
+    pairs), mapped onto the stages of this pipeline."""
+    pre = 12 * P + V * (32 + 12 * M) + 8 * P + 40 * V + (27 * V if track else 0)
     scan = 8 * P
-    dup_in = 8 * P + 16 * V
-    dup_out = 12 * R
+    dup = 8 * P + 16 * V + 12 * R
     sort = 24 * R
     ranges = 8 * R + 8 * T
-    blend = 44 * R + 24 * npix
-    return {"total": pre_in + pre_out + scan + dup_in + dup_out + sort + ranges + blend, "blend": blend,
-            "preprocess": pre_in + pre_out, "sort": sort + dup_out}
+    blend = 44 * R + (24 if track else 16) * npix
+    return {"total": pre + scan + dup + sort + ranges + blend, "blend": blend, "preprocess": pre, "scan": scan,
+            "emit": dup, "tile_sort": sort + ranges, "depth_sort": 0}
+
+
+def algorithmic_bytes_bwd(P, V, R, npix, M=16):
+    """SURVEY.md 8(d) B_bwd terms + Adam."""
+    return {"render_bwd": 44 * R + 32 * npix, "gather_bwd": 40 * R, "preprocess_bwd": 136 * V + V * (48 + 27 + 32 + 12 * M) + V * (40 + 12 * M),
+            "adam": 7 * 4 * 59 * P}
+
+
+FWD_FLOP_PER_PAIR = 25      # SURVEY 8(d): ~12 FLOP quadratic form + exp + ~8 FLOP blend per (pixel, Gaussian) pair
+BWD_FLOP_PER_PAIR = 60      # bwd_step: ~49 FLOP per pair (alpha, T / accumulator recurrences, 10 gradient terms) + ~10 adds of the cross-lane sums
+
+
+def make_views(make_camera, look_at_camera, W, H, n):
+    """Camera 0 is the generating camera of the scene; the others sit on a small circle around it and look at
+    the middle of the cloud, so every view sees most of the scene but R, the lists and the scratch sizes change per frame."""
+    cams = [make_camera(W, H)]
+    for k in range(1, n):
+        ang = 2 * math.pi * k / max(1, n - 1)
+        r = 0.25 + 0.35 * ((k * 7) % 5) / 4.0
+        cams.append(look_at_camera(W, H, (r * math.cos(ang), r * math.sin(ang), -0.2 * ((k % 3) - 1)), (0.0, 0.0, 7.0)))
+    return cams
 
 
 def main():
@@ -104,7 +133,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
-    from gsr_synth import make_camera, make_scene
+    from gsr_synth import look_at_camera, make_camera, make_scene
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _lib, rasterize_gaussians
     from diff_gaussian_rasterization.debug import forward_with_views
     from diff_gaussian_rasterization.parallel import BandPlan, gather_strips_async, row_costs_from_ranges
@@ -235,55 +264,113 @@ def main():
     # ---- per-stage HIP-event timing (separate pass: event pairs around every stage perturb the pipeline) ----
     _lib.profile_reset()
     _lib.profile_enable(True)
+    _lib.profile_counters(reset=True)
     for _ in range(a.steps):
         forward_step()
     while in_flight:
         in_flight.pop(0).wait()
     torch.cuda.synchronize()
     stages = _lib.profile_read()
+    fwd_counters = _lib.profile_counters(reset=True)
     _lib.profile_enable(False)
     stage_ms = {k: (v["ms"] / max(1, v["launches"])) for k, v in stages.items() if v["launches"]}
+    fwd_steps_per_launch = fwd_counters["fwd_steps"] / max(1, a.steps)
+    fwd_batches_per_launch = fwd_counters["fwd_batches"] / max(1, a.steps)
 
-    # ---- train leg: forward + loss + backward + Adam over all parameters (train.py:111-186 without densification) ----
-    #   "ssim"   : the reference's loss, 0.8 L1 + 0.2 (1 - SSIM)  (train.py:119-126) with the fused HIP SSIM (fused_ssim package)
-    #   "ssim_torch": same loss through utils/loss_utils.py-style torch conv2d ops (the reference's un-fused fallback)
-    #   "l1"     : L1 only (isolates the rasterizer + optimizer)
-    #   "l1_torch_adam": as "l1" but with torch.optim.Adam instead of the fused HIP Adam (gsr_optim.FusedAdam)
+    # the TRACKING build of the forward (what a training iteration runs: final_T / n_contrib / first-emission indices are
+    # written for the backward), timed beside the inference build the headline uses
+    track_ms = None
+    if world == 1:
+        req = [t.detach().clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+
+        def forward_track():
+            rasterize_gaussians(req[0], None, req[1], None, req[2], req[3], req[4], None, rs, None)
+        for _ in range(5):
+            forward_track()
+        track_ms = timed_loop(forward_track, a.steps, "forward_track")[0] / a.steps * 1e3
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        for _ in range(min(10, a.steps)):
+            forward_track()
+        torch.cuda.synchronize()
+        tr = _lib.profile_read()
+        _lib.profile_counters(reset=True)
+        _lib.profile_enable(False)
+        stage_ms["render_track"] = tr["render"]["ms"] / max(1, tr["render"]["launches"])
+        del req
+
+    # ---- train legs: forward + loss + backward + optimizer over all parameters (train.py:111-186 without densification; the
+    # full loop with density control on the reference's schedule is tools/train_run.py).  A NEW CAMERA EVERY ITERATION
+    # (train.py:96-102): --views synthetic cameras, cycled, each with its own target image.
+    #   "ssim"        : the reference's loss, 0.8 L1 + 0.2 (1 - SSIM) (train.py:119-126) with the fused HIP SSIM, dense fused Adam
+    #   "sparse_adam" : same loss, the reference's accelerated call form: dc= / shs= separate SH tensors + SparseGaussianAdam
+    #                   stepping only the visible Gaussians (train.py:37-41,180-183; gaussian_renderer/__init__.py:82-100)
+    #   "l1"          : L1 only with the dense fused Adam (isolates the rasterizer + optimizer)
+    #   "l1_torch_adam" / "ssim_torch": torch.optim.Adam / un-fused torch SSIM (--compare-torch-adam)
     train, train_gap = {}, {}
+    bwd_counters = None
     tsteps = a.steps if a.train_steps < 0 else a.train_steps
     if tsteps > 0:
         from gsr_optim import FusedAdam
         from gsr_synth.losses import train_loss, l1_loss
         from fused_ssim import fused_ssim
+        from diff_gaussian_rasterization import SparseGaussianAdam
 
         def fused_train_loss(image, gt_image, lambda_dssim=0.2):      # train.py:119-126 with FUSED_SSIM_AVAILABLE
             return (1.0 - lambda_dssim) * l1_loss(image, gt_image) + lambda_dssim * (1.0 - fused_ssim(image[None], gt_image[None]))
-        gt = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
-        legs = [("ssim", FusedAdam, fused_train_loss), ("l1", FusedAdam, l1_loss)]
+        views = make_views(make_camera, look_at_camera, W, H, max(1, a.views))
+        rs_views, gts = [], []
+        for i, vc in enumerate(views):
+            vd = vc.to(dev)
+            rs_views.append(GaussianRasterizationSettings(H, W, vc.tanfovx, vc.tanfovy, bg, 1.0, vd.world_view_transform,
+                                                          vd.full_proj_transform, 3, vd.camera_center, False, False, False))
+            gts.append(torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(1 + i)))
+        legs = [("ssim", "dense", fused_train_loss), ("sparse_adam", "sparse", fused_train_loss), ("l1", "dense", l1_loss)]
         if a.compare_torch_adam:
-            legs.append(("l1_torch_adam", torch.optim.Adam, l1_loss))
-            legs.append(("ssim_torch", FusedAdam, train_loss))
+            legs.append(("l1_torch_adam", "torch", l1_loss))
+            legs.append(("ssim_torch", "dense", train_loss))
+        if world > 1:
+            legs = [l for l in legs if l[1] != "sparse"]      # the sharded path keeps the fused [P,16,3] SH tensor
         from diff_gaussian_rasterization.parallel import render_two_axis, padded_shard_size
         # N > 1: two-axis sharding -- rank g owns Gaussians [lo, hi) (parameters + Adam state) and a band of
         # tile rows; 64-byte splat records are all-gathered forward, 48-byte gradient records reduce-scattered backward
         lo, hi = (P * rank) // world, (P * (rank + 1)) // world
         P_pad = padded_shard_size(hi - lo) if world > 1 else P
-        for leg, opt_cls, loss_fn in legs:
-            params = [t[lo:hi].detach().clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
-            opt = opt_cls(params, lr=1e-5, eps=1e-15)
+        for leg, opt_kind, loss_fn in legs:
+            if opt_kind == "sparse":
+                src = (sc.means3D, sc.shs[:, :1].contiguous(), sc.shs[:, 1:].contiguous(), sc.opacities, sc.scales, sc.rotations)
+            else:
+                src = (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)
+            params = [t[lo:hi].detach().clone().requires_grad_(True) for t in src]
+            if opt_kind == "sparse":
+                opt = SparseGaussianAdam([{"params": [p_], "lr": 1e-5} for p_ in params], lr=1e-5, eps=1e-15)
+            elif opt_kind == "torch":
+                opt = torch.optim.Adam(params, lr=1e-5, eps=1e-15)
+            else:
+                opt = FusedAdam(params, lr=1e-5, eps=1e-15)
+            it_no = [0]
 
             def train_step():
+                vi = it_no[0] % len(rs_views)
+                it_no[0] += 1
                 opt.zero_grad(set_to_none=True)
-                m, sh, o, s_, r_ = params
-                if world > 1:
-                    color, radii, invd = render_two_axis(rs, m, sh, o, s_, r_, plan, P_pad)
+                if opt_kind == "sparse":
+                    m, dc, rest, o, s_, r_ = params
+                    color, radii, invd = rasterize_gaussians(m, None, rest, None, o, s_, r_, None, rs_views[vi], None, None, dc)
+                elif world > 1:
+                    m, sh, o, s_, r_ = params
+                    color, radii, invd = render_two_axis(rs_views[vi], m, sh, o, s_, r_, plan, P_pad)
                 else:
-                    color, radii, invd = rasterize_gaussians(m, None, sh, None, o, s_, r_, None, rs, None)
-                loss = loss_fn(color, gt)
+                    m, sh, o, s_, r_ = params
+                    color, radii, invd = rasterize_gaussians(m, None, sh, None, o, s_, r_, None, rs_views[vi], None)
+                loss = loss_fn(color, gts[vi])
                 loss.backward()
-                opt.step()
+                if opt_kind == "sparse":
+                    opt.step(radii > 0, radii.shape[0])
+                else:
+                    opt.step()
 
-            for _ in range(max(2, a.warmup // 2)):
+            for _ in range(max(len(rs_views) if world == 1 else 2, a.warmup // 2)):     # every view once: scratch sizes settle
                 train_step()
             tdt_s, gmax, gat = timed_loop(train_step, tsteps, "train_" + leg)
             train_gap[leg] = gmax
@@ -292,10 +379,13 @@ def main():
             if leg == "l1":
                 _lib.profile_reset()
                 _lib.profile_enable(True)
-                for _ in range(min(10, tsteps)):
+                _lib.profile_counters(reset=True)
+                nprof = min(10, tsteps)
+                for _ in range(nprof):
                     train_step()
                 torch.cuda.synchronize()
                 tstages = _lib.profile_read()
+                bwd_counters = {k: v / nprof for k, v in _lib.profile_counters(reset=True).items()}
                 _lib.profile_enable(False)
                 for k in ("render_bwd", "gather_bwd", "preprocess_bwd"):
                     if tstages[k]["launches"]:
@@ -337,42 +427,78 @@ def main():
 
     if rank == 0:
         ab = algorithmic_bytes(P, V, R, gx * gy, npix)
-        render_ms = stage_ms.get("render")
-        roof = None
-        if render_ms:
-            # per-launch algorithmic bytes of the blend kernel on THIS rank's band: 44 B per instance + 24 B per pixel
-            frac_rows = 1.0 if world == 1 else (plan.band(0)[1] - plan.band(0)[0]) / gy
-            blend_bytes = ab["blend"] if world == 1 else ab["blend"] * frac_rows
-            ach = blend_bytes / (render_ms * 1e-3) / 1e9
-            pairs = 256.0 * R * (frac_rows if world > 1 else 1.0)
-            # HBM traffic of this kernel cannot be collected in-process: it comes from the committed rocprofv3 --pmc passes
-            # of this same command (profiles/pmc_latest.json: FETCH_SIZE and WRITE_SIZE in separate runs, bytes =
-            # (2*FETCH + WRITE)*1024 per MI355X_MICROARCH.md); null when the file or the kernel is missing
-            pmc_traffic, pmc_note = None, None
+        abb = algorithmic_bytes_bwd(P, V, R, npix)
+        frac_rows = 1.0 if world == 1 else (plan.band(0)[1] - plan.band(0)[0]) / gy
+
+        def pmc(kernel_names):
+            """HBM traffic / VALU instruction counts cannot be collected in-process: they come from the committed rocprofv3
+            --pmc passes of this same command (profiles/pmc_latest.json; FETCH_SIZE and WRITE_SIZE in separate runs, bytes =
+            (2*FETCH + WRITE)*1024 per MI355X_MICROARCH.md; SQ_INSTS_VALU from the SQ pass).  None when unavailable."""
             try:
                 pk = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"]
-                kn = {0: "render_fwd_wave_bf<true, 1, false>", 1: "render_fwd_block", 2: "render_fwd_wave_bf<false, 1, false>"}.get(a.variant)
-                if world == 1 and kn in pk and (P, W, H) == (1_000_000, 1920, 1080):
-                    pmc_traffic = int(pk[kn]["hbm_bytes_corrected"])
-                    pmc_note = "profiles/pmc_latest.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)"
+                if world == 1 and (P, W, H) == (1_000_000, 1920, 1080):
+                    for kn in kernel_names:
+                        if kn in pk:
+                            return pk[kn]
             except Exception:
                 pass
-            roof = {"bound": "hbm", "kernel": {0: "render_fwd_wave_bf<LDS>", 1: "render_fwd_block", 2: "render_fwd_wave_bf<readlane>"}.get(a.variant, "?"),
-                    "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                    "frac_of_measured_achievable_6.29TBs": round(ach / HBM_ACHIEVABLE_GBS, 5),
-                    "traffic": pmc_traffic, "traffic_source": pmc_note, "kernel_ms": round(render_ms, 4),
-                    "algorithmic_bytes_per_launch": int(blend_bytes),
-                    "note": "blend is fp32-VALU/exp bound, not HBM bound (SURVEY 8(d)); listed (pixel,Gaussian) pairs = 256*R per "
-                            "launch; most are never evaluated (early termination + exact box culling, DESIGN.md 3.3)",
-                    "listed_pairs_per_s": round(pairs / (render_ms * 1e-3), 1),
-                                        }
+            return None
+
+        def blend_roofline(kernel, ms, steps, flop_per_pair, hbm_bytes, pmc_entry, what):
+            if not ms:
+                return None
+            flops = steps * 64.0 * flop_per_pair
+            ach = flops / (ms * 1e-3) / 1e12
+            gbs = hbm_bytes / (ms * 1e-3) / 1e9
+            r = {"bound": "valu", "kernel": kernel, "achieved": round(ach, 3), "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
+                 "frac": round(ach / FP32_VALU_PEAK_TF, 5), "kernel_ms": round(ms, 4),
+                 "evaluated_pair_steps_per_launch": int(steps * 64), "flop_per_pair": flop_per_pair,
+                 "counted": what,
+                 "traffic": None if not pmc_entry else int(pmc_entry.get("hbm_bytes_corrected", 0)) or None,
+                 "traffic_source": None if not pmc_entry else "profiles/pmc_latest.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)",
+                 "hbm": {"algorithmic_bytes_per_launch": int(hbm_bytes), "achieved_GBs": round(gbs, 2),
+                         "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 5), "frac_of_6.29TBs": round(gbs / HBM_ACHIEVABLE_GBS, 5)},
+                 "note": "fp32-VALU bound, not HBM bound (SURVEY 8(d); SQ counters: waves wait for VALU issue, measured HBM traffic is a "
+                         "fraction of the algorithmic bytes because the splat records stay in L2 / Infinity Cache and early "
+                         "termination ends the walks); FLOPs counted = pairs the kernel actually evaluates (whole waves: 64 pixels "
+                         "per surviving list entry), not the 256*R listed pairs"}
+            if pmc_entry and pmc_entry.get("SQ_INSTS_VALU"):
+                lane_ops = pmc_entry["SQ_INSTS_VALU"] * 64.0 / (ms * 1e-3) / 1e12
+                r["valu_lane_ops_T_per_s"] = round(lane_ops, 2)
+                r["valu_issue_frac"] = round(lane_ops / (FP32_VALU_PEAK_TF / 2.0), 4)     # peak: one lane-op per lane and clock
+            return r
+
+        roof = blend_roofline("render_fwd_wave_bf<LDS, inference>", stage_ms.get("render"), fwd_steps_per_launch, FWD_FLOP_PER_PAIR,
+                              ab["blend"] * frac_rows, pmc(["render_fwd_wave_bf<true, 1, false>"]),
+                              "wave-level (8x8 pixel block, list entry) pairs that survive the exact box test and are blended, counted by the kernel")
+        roof_train = None
+        if bwd_counters:
+            roof_train = blend_roofline("render_bwd_quad", stage_ms.get("render_bwd"), bwd_counters["bwd_steps"], BWD_FLOP_PER_PAIR,
+                                        abb["render_bwd"] * frac_rows, pmc(["render_bwd_quad"]),
+                                        "wave-level (8x8 quadrant, list entry) pairs stepped by the backward walk, counted by the kernel")
+        # every stage: HIP-event ms, algorithmic bytes (SURVEY 8(d) term of the stage), GB/s
+        stage_tab = {}
+        sbytes = {"preprocess": ab["preprocess"], "scan": ab["scan"], "emit": ab["emit"], "tile_sort": ab["tile_sort"], "render": ab["blend"],
+                  "render_track": algorithmic_bytes(P, V, R, gx * gy, npix, track=True)["blend"],
+                  "render_bwd": abb["render_bwd"], "gather_bwd": abb["gather_bwd"], "preprocess_bwd": abb["preprocess_bwd"]}
+        design = {"depth_sort": 80 * P, "emit": 16 * P + 4 * R, "tile_sort": 12 * R + 8 * gx * gy}
+        for k, ms in stage_ms.items():
+            e = {"ms": round(ms, 4)}
+            if k in sbytes:
+                e["algorithmic_bytes"] = int(sbytes[k])
+                e["GBs"] = round(sbytes[k] / (ms * 1e-3) / 1e9, 1)
+                e["frac_of_8TBs"] = round(sbytes[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            if k in design:
+                e["design_bytes"] = int(design[k])      # what this pipeline's kernels move by design for the stage
+                e["design_GBs"] = round(design[k] / (ms * 1e-3) / 1e9, 1)
+            stage_tab[k] = e
         whole = ab["total"] / (ms_per_step * 1e-3) / 1e9
         out = {
             "metric": "Mpix/s forward (1 M Gaussians @1080p); train iters/s alongside",
             "value": round(mpix_s, 2), "unit": "Mpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "frame_latency_ms": round(latency_ms, 4),
             "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "parity": "oracle-only (the reference rasterizer is an un-vendored submodule)",
             "config": {"workload": "configs[1] stand-in: 1M random Gaussians (SURVEY 8(d) generator, seed %d, s_med %.4g), "
                                    "%dx%d forward render, SH degree 3" % (a.seed, a.s_med, W, H),
                        "P": P, "visible": V, "num_rendered": R, "tiles": gx * gy,
@@ -384,23 +510,38 @@ def main():
                        "frame_streams_note": "value = frames / time with consecutive frames alternating between HIP streams "
                                              "(double-buffered); frame_latency_ms = one frame after the other on one stream"
                                              if n_streams > 1 else "one frame after the other on one stream"},
+            "forward_builds_ms": {"inference (value; torch.no_grad(): no final_T / n_contrib / first-emission writes)": round(ms_per_step, 4),
+                                  "tracking (what a training iteration runs)": None if track_ms is None else round(track_ms, 4)},
             "train_iters_per_s": None if train_ips is None else round(train_ips, 3),
             "train_ms_per_iter": None if train_ms is None else round(train_ms, 4),
             "train_step": "forward + loss 0.8 L1 + 0.2 (1-SSIM) (train.py:119-126; fused HIP SSIM) + backward + fused HIP Adam over "
-                          "all 59 floats/Gaussian; *_l1 = L1 loss only; *_ssim_torch = SSIM through torch conv2d ops" +
+                          "all 59 floats/Gaussian, a new camera every iteration (%d views cycled, train.py:96-102); *_sparse_adam = the "
+                          "reference's accelerated call form (separate dc / rest SH tensors + SparseGaussianAdam on visible rows, "
+                          "train.py:180-183); *_l1 = L1 loss only; *_ssim_torch = SSIM through torch conv2d ops; full loop with density "
+                          "control: tools/train_run.py" % max(1, a.views) +
                           ("" if world == 1 else "; N > 1: Gaussians AND tile rows sharded (record all-gather / gradient "
                                                   "reduce-scatter), loss replicated on the all-gathered image"),
+            "train_iters_per_s_sparse_adam": None if "sparse_adam" not in train else round(1e3 / train["sparse_adam"], 3),
             "train_iters_per_s_ssim_torch": None if "ssim_torch" not in train else round(1e3 / train["ssim_torch"], 3),
             "train_iters_per_s_l1": None if "l1" not in train else round(1e3 / train["l1"], 3),
             "train_iters_per_s_l1_torch_adam": None if "l1_torch_adam" not in train else round(1e3 / train["l1_torch_adam"], 3),
             "whole_forward": {"algorithmic_bytes": int(ab["total"]), "achieved_GBs": round(whole, 2),
                               "frac_of_8TBs": round(whole / HBM_PEAK_GBS, 5),
                               "frac_of_6.29TBs": round(whole / HBM_ACHIEVABLE_GBS, 5),
-                              "roofline_predicted_Mpix_s": round(npix / (ab["total"] / (HBM_PEAK_GBS * 1e9)) / 1e6, 1)},
+                              "roofline_predicted_Mpix_s": round(npix / (ab["total"] / (HBM_PEAK_GBS * 1e9)) / 1e6, 1),
+                              "note": "HBM roofline of SURVEY 8(d)'s B_fwd; structurally out of reach because the blend is VALU-bound "
+                                      "(its %.3f ms alone exceed the %.3f ms the whole B_fwd takes at 8 TB/s)" %
+                                      (stage_ms.get("render", 0.0), ab["total"] / (HBM_PEAK_GBS * 1e9) * 1e3)},
             "train_max_step_gap_ms": {k: round(v, 3) for k, v in train_gap.items()},
             "retimed": retimed,
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "stages": stage_tab,
+            "blend_work": {"fwd_pair_steps_per_launch": int(fwd_steps_per_launch), "fwd_batches_per_launch": int(fwd_batches_per_launch),
+                           "bwd_pair_steps_per_launch": None if not bwd_counters else int(bwd_counters["bwd_steps"]),
+                           "bwd_batches_per_launch": None if not bwd_counters else int(bwd_counters["bwd_batches"]),
+                           "listed_instance_blocks": 4 * R},
             "roofline": roof,
+            "roofline_train": roof_train,
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out), flush=True)

@@ -40,6 +40,7 @@ std::vector<PendingEvent> g_pending;
 std::vector<hipEvent_t> g_pool;
 double g_stage_ms[GSR_STAGE_COUNT] = {0};
 int g_stage_n[GSR_STAGE_COUNT] = {0};
+unsigned long long* g_counters = nullptr;     // device: work counters of the blend kernels, allocated by gsr_profile_enable(1)
 
 hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
@@ -272,7 +273,25 @@ int gsr_set_option(const char* name, int value) {
     return fail(GSR_ERR_INVALID_ARG, std::string("unknown option ") + name);
 }
 
-int gsr_profile_enable(int on) { std::lock_guard<std::mutex> l(g_prof_mu); g_prof_on = on != 0; return GSR_OK; }
+int gsr_profile_enable(int on) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    if (on && !g_counters) {      // measurement only: the product path never allocates
+        if (hipMalloc((void**)&g_counters, GSR_COUNTER_COUNT * sizeof(unsigned long long)) != hipSuccess) g_counters = nullptr;
+        else (void)hipMemset(g_counters, 0, GSR_COUNTER_COUNT * sizeof(unsigned long long));
+    }
+    g_prof_on = on != 0;
+    return GSR_OK;
+}
+int gsr_profile_counters(uint64_t* out, int n, int reset) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    unsigned long long host[GSR_COUNTER_COUNT] = {0};
+    if (g_counters) {
+        if (hipMemcpy(host, g_counters, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return fail(GSR_ERR_HIP, "counter read-back failed");
+        if (reset) (void)hipMemset(g_counters, 0, sizeof(host));
+    }
+    for (int i = 0; i < n && i < GSR_COUNTER_COUNT; ++i) out[i] = host[i];
+    return GSR_OK;
+}
 int gsr_profile_reset(void) {
     std::lock_guard<std::mutex> l(g_prof_mu);
     for (auto& p : g_pending) { (void)hipEventSynchronize(p.b); g_pool.push_back(p.a); g_pool.push_back(p.b); }
@@ -422,7 +441,7 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     {   StageTimer t(GSR_STAGE_RENDER, st);
         gsr_launch_render_forward(cam, im.ranges, b.vals[list_buf], g.splats, settings->no_backward ? nullptr : im.final_T,
                                   settings->no_backward ? nullptr : im.n_contrib, out_color, out_invdepth,
-                                  g_render_fwd_variant, st);
+                                  g_render_fwd_variant, g_prof_on ? g_counters : nullptr, st);
     }
     STAGE_CHECK("render");
     HIP_OK(hipGetLastError());
@@ -560,13 +579,13 @@ int gsr_backward_blend(const GsrRasterSettings* settings, int P, int32_t num_ren
             HIP_OK(hipMemsetAsync(sg, 0, (size_t)P * 12 * sizeof(float), st));
             if (num_rendered > 0)
                 gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib,
-                                           dL_dout_color, dL_dout_invdepth, sg, nullptr, nullptr, num_rendered, 1, st);
+                                           dL_dout_color, dL_dout_invdepth, sg, nullptr, nullptr, num_rendered, 1, nullptr, st);
         } else {
             // instances that contributed nowhere get no record: only their flag words are cleared
             HIP_OK(hipMemsetAsync(w.inst_flag, 0, (size_t)num_rendered * 4, st));
             gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib,
                                        dL_dout_color, dL_dout_invdepth, nullptr, w.inst_grads, w.inst_flag, num_rendered,
-                                       g_render_bwd_variant, st);
+                                       g_render_bwd_variant, g_prof_on ? g_counters : nullptr, st);
         }
     }
     STAGE_CHECK("render backward blend");

@@ -133,7 +133,8 @@ void gsr_launch_ranges(int64_t R, int n_tiles, const void* sorted_keys, bool key
 // render_fwd.hip / render_bwd.hip
 void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,
                                const float4* splats, float* final_T, uint32_t* n_contrib, float* out_color,
-                               float* out_invdepth, int variant, hipStream_t st);
+                               float* out_invdepth, int variant, unsigned long long* counters /*NULL or [4] work counters*/,
+                               hipStream_t st);
 // variant: 0 = default (independent quadrant waves); 1 (global atomics) and 4 (round 1's workgroup-per-tile kernel) exist
 // only in builds with -DGSR_AB_VARIANTS
 int gsr_render_backward_variant_available(int variant);
@@ -141,7 +142,8 @@ int gsr_render_forward_variant_available(int variant);
 void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,
                                 const float4* splats, const float* final_T, const uint32_t* n_contrib,
                                 const float* dL_dpix, const float* dL_dinvdepth, float* splat_grads /*[P,12] variant 1*/,
-                                float* inst_grads /*[4][R,12]*/, uint32_t* inst_flag /*[R]*/, int64_t R, int variant, hipStream_t st);
+                                float* inst_grads /*[4][R,12]*/, uint32_t* inst_flag /*[R]*/, int64_t R, int variant,
+                                unsigned long long* counters, hipStream_t st);
 void gsr_launch_reduce_instances(int P, int64_t R, const uint32_t* order, const uint32_t* offsets, const float4* splats,
                                  const float* inst_grads, const uint32_t* inst_flag, float* splat_grads, hipStream_t st);
 

@@ -192,7 +192,7 @@ render_bwd_quad(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
                 const float4* __restrict__ splats, const float* __restrict__ final_T,
                 const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                 const float* __restrict__ dL_dinvdepth, float4* __restrict__ slot_grads /*[4][R] records of 3 float4*/,
-                uint8_t* __restrict__ slot_flags /*[R][4]*/, int64_t R) {
+                uint8_t* __restrict__ slot_flags /*[R][4]*/, int64_t R, unsigned long long* __restrict__ counters /*NULL unless profiling*/) {
     __shared__ float4 s_rec[64 * REC_STRIDE];   // the batch: (x, y, a2, b2 | c2, opacity, r, g | b, 1/depth, -, -)
     __shared__ float s_grad[64 * 12];           // this quadrant's record of every entry of the batch
     // XCD-aware mapping as in the forward: the four quadrants of a tile get workgroup ids b, b+8, b+16, b+24 -> same XCD
@@ -243,6 +243,7 @@ render_bwd_quad(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
     float4 n0 = zero4, n1 = zero4, n2 = zero4, n3 = zero4;
     if (id_n != 0xFFFFFFFFu) { n0 = splats[id_n * 4 + 0]; n1 = splats[id_n * 4 + 1]; n2 = splats[id_n * 4 + 2]; n3 = splats[id_n * 4 + 3]; }
     id_n = load_id(nbatch - 2);
+    uint32_t nsteps = 0;        // wave-uniform work counter, reported only while profiling
     for (int bi = nbatch - 1; bi >= 0; --bi) {
         const uint32_t base = (uint32_t)bi * 64u;
         const uint32_t n = min(64u, end - base);
@@ -260,6 +261,7 @@ render_bwd_quad(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
             s_rec[lane * REC_STRIDE + 2] = make_float4(q2.x, q2.w, 0.f, 0.f);
         }
         uint64_t mask = __ballot(keep);
+        nsteps += (uint32_t)__popcll(mask);
         uint64_t touched = 0ull;
         while (mask) {
             const int j = 63 - __builtin_clzll(mask);
@@ -297,6 +299,10 @@ render_bwd_quad(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
             }
             __builtin_amdgcn_wave_barrier();
         }
+    }
+    if (counters && lane == 0) {     // [2] (quadrant, entry) pairs stepped by all 64 lanes, [3] batches of 64 entries box-tested
+        atomicAdd(counters + 2, (unsigned long long)nsteps);
+        atomicAdd(counters + 3, (unsigned long long)nbatch);
     }
 }
 
@@ -649,7 +655,7 @@ int gsr_render_backward_variant_available(int variant) {
 void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,
                                 const float4* splats, const float* final_T, const uint32_t* n_contrib,
                                 const float* dL_dpix, const float* dL_dinvdepth, float* splat_grads, float* inst_grads,
-                                uint32_t* inst_flag, int64_t R, int variant, hipStream_t st) {
+                                uint32_t* inst_flag, int64_t R, int variant, unsigned long long* counters, hipStream_t st) {
     const int n_band_tiles = cam.gx * (cam.tile_y1 - cam.tile_y0);
     if (n_band_tiles <= 0) return;
     const int groups = (n_band_tiles + 7) / 8;
@@ -669,7 +675,7 @@ void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const
     (void)variant; (void)splat_grads;
     hipLaunchKernelGGL(render_bwd_quad, dim3(groups * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list, splats,
                        final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads),
-                       reinterpret_cast<uint8_t*>(inst_flag), R);
+                       reinterpret_cast<uint8_t*>(inst_flag), R, counters);
 }
 
 void gsr_launch_reduce_instances(int P, int64_t R, const uint32_t* order, const uint32_t* offsets, const float4* splats,

@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(64 * WPB)
 render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ranges,
                    const uint32_t* __restrict__ point_list, const float4* __restrict__ splats,
                    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-                   float* __restrict__ out_invdepth) {
+                   float* __restrict__ out_invdepth, unsigned long long* __restrict__ counters /*NULL unless profiling*/) {
     __shared__ float4 s_rec_all[USE_LDS ? WPB * 64 * 3 : 1];
     float4* s_rec = s_rec_all + (USE_LDS ? (threadIdx.x >> 6) * 64 * 3 : 0);
     int tile_local, quad;
@@ -224,6 +224,7 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
     // 64-byte record gather), ~1-2 us under load, while a wave walks only a handful of batches before its pixels
     // terminate -- un-pipelined the kernel was latency-bound on that chain.  Ids are fetched two batches ahead and
     // records one batch ahead; the survivor loop in between touches only LDS, so the loads stay in flight across it.
+    uint32_t nsteps = 0, nbatches = 0;      // wave-uniform work counters (SGPRs), reported only while profiling
     auto load_id = [&](uint32_t b) -> uint32_t { return (b + lane < range.y) ? point_list[b + lane] : 0xFFFFFFFFu; };
     uint32_t id_n1 = load_id(range.x);                    // ids of the batch whose records are fetched next
     float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
@@ -253,6 +254,8 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
             s_rec[lane * 3 + 2] = make_float4(colb, invd, 0.f, 0.f);
         }
         uint64_t mask = __ballot(keep);
+        nsteps += (uint32_t)__popcll(mask);
+        ++nbatches;
         const uint32_t pos_base = base - range.x + 1;
         while (mask) {
             const int j = __builtin_ctzll(mask);
@@ -270,6 +273,10 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
             }
         }
         if (__ballot(Tl != 0.0f) == 0ull) break;
+    }
+    if (counters && lane == 0) {     // [0] (8x8 block, entry) pairs blended by all 64 lanes, [1] batches of 64 entries box-tested
+        atomicAdd(counters + 0, (unsigned long long)nsteps);
+        atomicAdd(counters + 1, (unsigned long long)nbatches);
     }
     if (inside) {
         const int64_t pix = (int64_t)py * cam.W + px;
@@ -297,7 +304,7 @@ int gsr_render_forward_variant_available(int variant) {
 
 void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,
                                const float4* splats, float* final_T, uint32_t* n_contrib, float* out_color,
-                               float* out_invdepth, int variant, hipStream_t st) {
+                               float* out_invdepth, int variant, unsigned long long* counters, hipStream_t st) {
     const int n_band_tiles = cam.gx * (cam.tile_y1 - cam.tile_y0);
     if (n_band_tiles <= 0) return;
     const int groups = (n_band_tiles + 7) / 8;
@@ -306,10 +313,10 @@ void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const 
     do {                                                                                                                          \
         if (track)                                                                                                                \
             hipLaunchKernelGGL((render_fwd_wave_bf<USE_LDS_, WPB_, true>), dim3(GRID_), dim3(BLOCK_), 0, st, cam, n_band_tiles,    \
-                               ranges, point_list, splats, final_T, n_contrib, out_color, out_invdepth);                         \
+                               ranges, point_list, splats, final_T, n_contrib, out_color, out_invdepth, counters);               \
         else                                                                                                                      \
             hipLaunchKernelGGL((render_fwd_wave_bf<USE_LDS_, WPB_, false>), dim3(GRID_), dim3(BLOCK_), 0, st, cam, n_band_tiles,   \
-                               ranges, point_list, splats, final_T, n_contrib, out_color, out_invdepth);                         \
+                               ranges, point_list, splats, final_T, n_contrib, out_color, out_invdepth, counters);               \
     } while (0)
 #ifdef GSR_AB_VARIANTS
     if (variant == 1) {

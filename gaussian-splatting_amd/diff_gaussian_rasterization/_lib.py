@@ -48,7 +48,7 @@ EXPORTS = [
     "gsr_preprocess_forward", "gsr_rasterize_from_splats",
     "gsr_mark_visible", "gsr_forward_views", "gsr_adam_step", "gsr_sparse_adam_step", "gsr_ssim_forward", "gsr_ssim_backward",
     "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_ssim_partial_count", "gsr_ssim_mean_forward", "gsr_ssim_mean_backward",
-    "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_set_option",
+    "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_profile_counters", "gsr_set_option",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -139,6 +139,8 @@ def load() -> C.CDLL:
     lib.gsr_profile_reset.restype = C.c_int
     lib.gsr_profile_read.restype = C.c_int
     lib.gsr_profile_read.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int]
+    lib.gsr_profile_counters.restype = C.c_int
+    lib.gsr_profile_counters.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.c_int]
     lib.gsr_set_option.restype = C.c_int
     lib.gsr_set_option.argtypes = [C.c_char_p, C.c_int]
     if lib.gsr_abi_version() != ABI_VERSION:
@@ -163,6 +165,12 @@ def profile_enable(on: bool) -> None:
 
 def profile_reset() -> None:
     load().gsr_profile_reset()
+
+
+def profile_counters(reset: bool = True) -> dict:
+    out = (C.c_uint64 * 4)()
+    check(load().gsr_profile_counters(out, 4, 1 if reset else 0), "gsr_profile_counters")
+    return {"fwd_steps": int(out[0]), "fwd_batches": int(out[1]), "bwd_steps": int(out[2]), "bwd_batches": int(out[3])}
 
 
 def profile_read() -> dict:

@@ -278,6 +278,11 @@ int gsr_profile_enable(int on);
 int gsr_profile_reset(void);
 /* Resolves pending events (synchronises them) and returns accumulated ms and launch counts per stage. */
 int gsr_profile_read(float* ms_out, int32_t* count_out, int n);
+/* Work counters of the blend kernels, accumulated over the launches made while profiling is enabled (bench.py turns them
+ * into achieved FLOP/s): [0] forward (8x8 pixel block, list entry) pairs blended by a whole wave, [1] forward batches of
+ * 64 entries box-tested, [2] / [3] the same for the blend backward.  reset != 0 clears them after reading. */
+#define GSR_COUNTER_COUNT 4
+int gsr_profile_counters(uint64_t* out, int n, int reset);
 
 /* Variant selection for A/B measurement of the render kernels (0 = default). */
 int gsr_set_option(const char* name, int value);

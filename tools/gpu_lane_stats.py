@@ -75,10 +75,18 @@ for t in tiles:
     nc[inside] = ncon[py[inside], px[inside]]
     pos = torch.arange(N, device=dev)
     contrib = valid & (pos[None, None, :] < nc[:, :, None])        # backward's active (pixel, entry) pairs
-    # forward: a pixel evaluates entries until it terminates; termination position ~ n_contrib (+1 for the terminator) if final_T small
-    done_at = torch.where(torch.zeros_like(nc, dtype=torch.bool), nc, nc)
-    fwd_pair = valid & (pos[None, None, :] <= nc[:, :, None])
+    # forward: a pixel evaluates entries until it terminates (T (1 - alpha) < 1e-4 on a valid entry); p_term = position of
+    # the terminating entry, N if the pixel never terminates (then its wave walks the whole list)
+    a_eff = torch.where(valid, alpha, torch.zeros_like(alpha)).double()
+    Tincl = torch.cumprod(1.0 - a_eff, dim=2)
+    term = valid & (Tincl < 1e-4)
+    has_term = term.any(dim=2)
+    p_term = torch.where(has_term, torch.argmax(term.to(torch.int8), dim=2), torch.full_like(nc, N))
+    p_term = torch.where(inside, p_term, torch.zeros_like(p_term) - 1)      # pixels outside the image never hold the wave
+    fwd_pair = valid & (pos[None, None, :] < p_term[:, :, None])
     touched_any = torch.zeros(N, dtype=torch.bool, device=dev)
+    surv_b = [None] * 4
+    surv_f = [None] * 4
     for q in range(4):
         qy, qx = (q >> 1) * 8, (q & 1) * 8
         bx0, by0 = tx * 16 + qx, ty * 16 + qy
@@ -88,19 +96,15 @@ for t in tiles:
         keep8 = ~(min_q_box(mx, my, A, B, C, float(bx0), x1, float(by0), y1) > tau)
         ncq = nc[qy:qy + 8, qx:qx + 8]
         mxq = int(ncq.max())
-        # forward walk depth of the quadrant: until all pixels terminated; pixels that never terminate walk the whole list
-        fTq = torch.ones(8, 8, device=dev)
-        ins = inside[qy:qy + 8, qx:qx + 8]
-        fTq[ins] = fT[py[qy:qy + 8, qx:qx + 8][ins], px[qy:qy + 8, qx:qx + 8][ins]]
-        # a pixel is "done" only by termination (T(1-a) < 1e-4); unfinished pixels keep the wave walking to the end of the list
-        unfinished = bool(((fTq >= 1e-4 * 1.0) & ins).any())       # conservative: final_T >= 1e-4 means never terminated
-        fdepth = N if unfinished else min(N, mxq + 1)
+        # forward walk depth of the quadrant: until every pixel has met its terminating entry (batches of 64 are ignored)
+        fdepth = min(N, int(p_term[qy:qy + 8, qx:qx + 8].max()) + 1)
         live_f = pos < fdepth
         live_b = pos < mxq
         acc["fwd_live8"] += int(live_f.sum()); acc["bwd_live8"] += int(live_b.sum())
         s8f = keep8 & live_f
         s8b = keep8 & live_b
         acc["fwd_s8"] += int(s8f.sum()); acc["bwd_s8"] += int(s8b.sum())
+        surv_b[q], surv_f[q] = s8b, s8f
         cq = contrib[qy:qy + 8, qx:qx + 8]
         acc["bwd_pairs"] += int(cq.sum())
         acc["fwd_pairs"] += int(fwd_pair[qy:qy + 8, qx:qx + 8].sum())
@@ -116,22 +120,30 @@ for t in tiles:
             keep4 = ~(min_q_box(mx, my, A, B, C, float(sx0), float(min(sx0 + 3, W - 1)), float(sy0), float(min(sy0 + 3, H - 1))) > tau)
             ncr = nc[ry:ry + 4, rx:rx + 4]
             mxr = int(ncr.max())
-            insr = inside[ry:ry + 4, rx:rx + 4]
-            fTr = torch.ones(4, 4, device=dev)
-            fTr[insr] = fT[py[ry:ry + 4, rx:rx + 4][insr], px[ry:ry + 4, rx:rx + 4][insr]]
-            unf = bool(((fTr >= 1e-4) & insr).any())
-            fd = N if unf else min(N, mxr + 1)
+            fd = min(N, int(p_term[ry:ry + 4, rx:rx + 4].max()) + 1)
             n4f = int((keep4 & (pos < fd)).sum()); n4b = int((keep4 & (pos < mxr)).sum())
             acc["fwd_s4sum"] += n4f; acc["bwd_s4sum"] += n4b
             rowmax_f = max(rowmax_f, n4f); rowmax_b = max(rowmax_b, n4b)
         acc["fwd_rowmax"] += rowmax_f; acc["bwd_rowmax"] += rowmax_b
     acc["bwd_touched_inst"] += int(touched_any.sum())
+    # two quadrants per wave (2 pixels per lane): steps = union of the two survivor sets
+    for (qa, qb), key in (((0, 1), "h"), ((2, 3), "h"), ((0, 2), "v"), ((1, 3), "v")):
+        if surv_b[qa] is None or surv_b[qb] is None:
+            continue
+        acc["bwd_pair_" + key] = acc.get("bwd_pair_" + key, 0) + int((surv_b[qa] | surv_b[qb]).sum())
+        acc["bwd_pairsum_" + key] = acc.get("bwd_pairsum_" + key, 0) + int(surv_b[qa].sum()) + int(surv_b[qb].sum())
+        acc["fwd_pair_" + key] = acc.get("fwd_pair_" + key, 0) + int((surv_f[qa] | surv_f[qb]).sum())
+        acc["fwd_pairsum_" + key] = acc.get("fwd_pairsum_" + key, 0) + int(surv_f[qa].sum()) + int(surv_f[qb].sum())
 
 f = lambda a, b: f"{a / max(1, b):.3f}"
 print(f"s_med {s_med}, {len(tiles)} tiles sampled")
 print(f"FWD: live (8x8,entry) {acc['fwd_live8']}  survivors8 {acc['fwd_s8']} ({f(acc['fwd_s8'], acc['fwd_live8'])})  lane efficiency "
       f"{f(acc['fwd_pairs'], 64 * acc['fwd_s8'])}  row-independent steps (max of 4 rows) {acc['fwd_rowmax']} = {f(acc['fwd_rowmax'], acc['fwd_s8'])} x current; "
       f"sum of 4x4 survivors {acc['fwd_s4sum']} ({f(acc['fwd_s4sum'], 4 * acc['fwd_s8'])} of 4 x s8)")
+for d in ("fwd", "bwd"):
+    for key in ("h", "v"):
+        print(f"{d.upper()} two quadrants per wave ({'16x8' if key == 'h' else '8x16'}): union / sum of survivor steps = "
+              f"{f(acc.get(d + '_pair_' + key, 0), acc.get(d + '_pairsum_' + key, 0))}")
 print(f"BWD: live (8x8,entry) {acc['bwd_live8']}  survivors8 {acc['bwd_s8']} ({f(acc['bwd_s8'], acc['bwd_live8'])})  lane efficiency "
       f"{f(acc['bwd_pairs'], 64 * acc['bwd_s8'])}  row-independent steps {acc['bwd_rowmax']} = {f(acc['bwd_rowmax'], acc['bwd_s8'])} x current; "
       f"sum of 4x4 survivors {acc['bwd_s4sum']} ({f(acc['bwd_s4sum'], 4 * acc['bwd_s8'])} of 4 x s8); quadrant records {acc['bwd_quad_records']} "

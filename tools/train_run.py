@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""BASELINE.json configs[2] stand-in: the reference's FULL training loop (forward + loss + backward + density control +
+optimizer), 30 000 iterations on its own schedule, on the drop-in packages of this repo.
+
+    python tools/train_run.py [--iters 30000] [--P0 100000] [--P-target 1000000] [--cams 32] [--dense-adam]
+
+What is mirrored from the reference (train.py:73-190, arguments/__init__.py:72-100, scene/gaussian_model.py):
+  * a new camera every iteration, drawn without replacement from the training set (train.py:96-102) -- here `--cams`
+    synthetic views of a synthetic target scene (no dataset ships with this repo; SURVEY.md 8(d) generator);
+  * render through `GaussianRasterizer` in the separate-SH call form with `SparseGaussianAdam` (what the reference selects
+    when the accelerated rasterizer is importable, train.py:37-41,180-183) or `--dense-adam` for the default optimizer;
+  * loss 0.8 L1 + 0.2 (1 - SSIM) with the fused SSIM (train.py:119-126);
+  * SH degree + 1 every 1000 iterations (train.py:92-94), exponential position learning-rate schedule
+    (utils/general_utils.py:get_expon_lr_func; position_lr 1.6e-4 -> 1.6e-6 over 30 000 steps, scaled by the scene extent);
+  * density statistics every iteration and clone / split / prune every 100 iterations from 500 to 15 000 with gradient
+    threshold 0.0002, opacity floor 0.005, screen-size pruning after iteration 3000, opacity reset every 3000 iterations
+    (train.py:160-174, arguments/__init__.py:91-95).
+Reported: iterations/s (whole run and per 5000-iteration window), the Gaussian count over time, peak device memory, the
+largest R-sized scratch buffers.  One JSON line on stdout (also written to gpurun_out/train_run.json)."""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, "gaussian-splatting_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+
+def expon_lr(step, lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """utils/general_utils.py:get_expon_lr_func"""
+    if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+        return 0.0
+    if lr_delay_steps > 0:
+        delay_rate = lr_delay_mult + (1 - lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / lr_delay_steps, 0), 1))
+    else:
+        delay_rate = 1.0
+    t = min(max(step / max_steps, 0), 1)
+    return delay_rate * math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=30000)
+    ap.add_argument("--P0", type=int, default=100_000)
+    ap.add_argument("--P-target", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--cams", type=int, default=32)
+    ap.add_argument("--dense-adam", action="store_true")
+    ap.add_argument("--extent", type=float, default=4.0, help="scene extent (cameras_extent of the reference)")
+    ap.add_argument("--max-P", type=int, default=4_000_000, help="densification stops growing the set beyond this (memory guard)")
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+
+    from gsr_synth import look_at_camera, make_camera, make_scene
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, SparseGaussianAdam
+    import diff_gaussian_rasterization as dgr
+    from fused_ssim import fused_ssim
+    from gsr_optim import FusedAdam
+    from gsr_scene.densify import DensifyStats, densify_and_prune, reset_opacity
+
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    random.seed(a.seed)
+    torch.manual_seed(a.seed)
+    W, H = a.width, a.height
+    cam0 = make_camera(W, H)
+    target = make_scene(a.P_target, cam0, seed=a.seed, s_med=0.012).to(dev)
+    # training views: eyes on a small circle around the generating camera, all looking at the middle of the cloud
+    cams = [cam0]
+    for k in range(1, a.cams):
+        ang = 2 * math.pi * k / max(1, a.cams - 1)
+        r = 0.25 + 0.35 * ((k * 7) % 5) / 4.0
+        cams.append(look_at_camera(W, H, (r * math.cos(ang), r * math.sin(ang), -0.2 * ((k % 3) - 1)), (0.0, 0.0, 7.0)))
+    bg = torch.zeros(3, device=dev)
+
+    def settings(cam, deg):
+        c = cam.to(dev)
+        return GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, bg, 1.0, c.world_view_transform, c.full_proj_transform,
+                                             deg, c.camera_center, False, False, False)
+
+    with torch.no_grad():
+        gts = []
+        for cam in cams:
+            img = GaussianRasterizer(settings(cam, 3))(means3D=target.means3D, means2D=None, dc=target.shs[:, :1].contiguous(),
+                                                       shs=target.shs[:, 1:].contiguous(), opacities=target.opacities,
+                                                       scales=target.scales, rotations=target.rotations)[0]
+            gts.append(img.clone())
+    # initial model: a sparse, blurry subset of the target (the role of the SfM point cloud, scene/gaussian_model.py:147-173)
+    step = max(1, a.P_target // a.P0)
+    sub = slice(0, None, step)
+
+    def par(t):
+        return nn.Parameter(t.detach().clone().contiguous().requires_grad_(True))
+    P0 = target.means3D[sub].shape[0]
+    params = {"xyz": par(target.means3D[sub]), "f_dc": par(target.shs[sub, :1]), "f_rest": par(target.shs[sub, 1:] * 0.0),
+              "opacity": par(torch.full((P0, 1), math.log(0.1 / 0.9), device=dev)),
+              "scaling": par(torch.log(target.scales[sub] * 2.0)), "rotation": par(target.rotations[sub])}
+    del target
+    torch.cuda.empty_cache()
+    ext = a.extent
+    lrs = {"xyz": 0.00016 * ext, "f_dc": 0.0025, "f_rest": 0.0025 / 20.0, "opacity": 0.025, "scaling": 0.005, "rotation": 0.001}
+    groups = [{"params": [params[k]], "lr": lrs[k], "name": k} for k in params]
+    opt = FusedAdam(groups, lr=0.0, eps=1e-15) if a.dense_adam else SparseGaussianAdam(groups, lr=0.0, eps=1e-15)
+    stats = DensifyStats.zeros(P0, dev)
+    deg = 0
+    stack = []
+    sizes, window_t, losses = [], [], []
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    t_start = t_win = time.perf_counter()
+    for it in range(1, a.iters + 1):
+        lr_xyz = expon_lr(it, 0.00016 * ext, 0.0000016 * ext, 0, 0.01, 30000)
+        for g in opt.param_groups:
+            if g["name"] == "xyz":
+                g["lr"] = lr_xyz
+        if it % 1000 == 0 and deg < 3:
+            deg += 1
+        if not stack:
+            stack = list(range(len(cams)))
+        ci = stack.pop(random.randint(0, len(stack) - 1))
+        P = params["xyz"].shape[0]
+        m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
+        img, radii, _ = GaussianRasterizer(settings(cams[ci], deg))(
+            means3D=params["xyz"], means2D=m2, dc=params["f_dc"], shs=params["f_rest"], opacities=torch.sigmoid(params["opacity"]),
+            scales=torch.exp(params["scaling"]), rotations=torch.nn.functional.normalize(params["rotation"]))
+        gt = gts[ci]
+        loss = 0.8 * (img - gt).abs().mean() + 0.2 * (1.0 - fused_ssim(img.unsqueeze(0), gt.unsqueeze(0)))
+        loss.backward()
+        with torch.no_grad():
+            if it < 15000:
+                stats.add(m2.grad, radii > 0, radii)
+                if it > 500 and it % 100 == 0:
+                    grow = params["xyz"].shape[0] < a.max_P
+                    params, stats, _ = densify_and_prune(opt, stats, max_grad=0.0002 if grow else 1e30, min_opacity=0.005, extent=ext,
+                                                         max_screen_size=20 if it > 3000 else None, radii=radii)
+                if it % 3000 == 0:
+                    params["opacity"] = reset_opacity(opt, 0.01)
+            if it < a.iters:
+                if a.dense_adam:
+                    opt.step()
+                else:
+                    opt.step(radii > 0, radii.shape[0])
+                opt.zero_grad(set_to_none=True)
+        if it % 5000 == 0 or it == a.iters:
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            window_t.append({"until_iter": it, "iters_per_s": round((5000 if it % 5000 == 0 else it % 5000) / (now - t_win), 2),
+                             "P": int(params["xyz"].shape[0]), "loss": round(float(loss.detach()), 5)})
+            t_win = now
+        if it % 1000 == 0:
+            sizes.append(int(params["xyz"].shape[0]))
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t_start
+    out = {"metric": "train iters/s, full loop (fwd + loss + bwd + density control + optimizer), reference schedule",
+           "value": round(a.iters / total, 2), "unit": "it/s", "iterations": a.iters, "seconds": round(total, 2),
+           "config": {"workload": f"configs[2] stand-in: P0 {P0} -> densified, {W}x{H}, {len(cams)} synthetic views cycled without "
+                                  f"replacement, target scene {a.P_target} Gaussians (SURVEY 8(d) generator, seed {a.seed})",
+                      "optimizer": "FusedAdam (dense)" if a.dense_adam else "SparseGaussianAdam + separate_sh call form",
+                      "schedule": "densify 500..15000 every 100 (grad 0.0002, opacity 0.005, size 20 after 3000), opacity reset / 3000, "
+                                  "SH degree +1 / 1000, position lr 1.6e-4 -> 1.6e-6 x extent", "extent": ext},
+           "final_P": int(params["xyz"].shape[0]), "max_P": max(sizes + [P0]), "P_every_1000_iters": sizes,
+           "windows": window_t, "peak_device_memory_bytes": int(torch.cuda.max_memory_allocated()),
+           "peak_scratch_bytes": {f"{k[0]}": int(v) for k, v in dgr._last_size.items()},
+           "data": "synthetic", "dtype": "f32"}
+    print(json.dumps(out), flush=True)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        tag = "dense" if a.dense_adam else "sparse"
+        json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"train_run_{tag}.json"), "w"), indent=1)
+    except Exception:
+        pass
+
+
+if __name__ == "__main__":
+    main()
