@@ -36,6 +36,8 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 // (band-clamped) tile rectangle; the gathered rectangles are written out in depth order (rect_sorted), so that pass 2
 // and the emission stream them instead of repeating the 8-byte random gather.  Sums are 64-bit: a total beyond
 // 2^31 - 1 must be DETECTED on the host, not wrapped.
+// GATHER = false: rect_sorted was already filled by the last pass of the depth sort (sort.hip, os_pass<LAST>)
+template <bool GATHER>
 __global__ void __launch_bounds__(SC_THREADS)
 scan_block_sums(int P, const uint32_t* __restrict__ order, const uint2* __restrict__ rect,
                 uint2* __restrict__ rect_sorted, uint64_t* __restrict__ block_sums) {
@@ -46,8 +48,13 @@ scan_block_sums(int P, const uint32_t* __restrict__ order, const uint2* __restri
 #pragma unroll
     for (int k = 0; k < SC_IPT; ++k)
         if (base + k < P) {
-            const uint2 r = rect[order[base + k]];
-            rect_sorted[base + k] = r;
+            uint2 r;
+            if (GATHER) {
+                r = rect[order[base + k]];
+                rect_sorted[base + k] = r;
+            } else {
+                r = rect_sorted[base + k];
+            }
             s += rect_tiles(r);
         }
     s = wave_sum_u64(s);
@@ -63,7 +70,7 @@ scan_block_sums(int P, const uint32_t* __restrict__ order, const uint2* __restri
 __global__ void __launch_bounds__(SC_THREADS)
 scan_finish(int P, const uint2* __restrict__ rect_sorted, const uint64_t* __restrict__ block_sums,
             uint32_t* __restrict__ offsets, uint2* __restrict__ block_first, uint32_t block_first_cap,
-            uint32_t* __restrict__ num_rendered, uint32_t* host_word, uint32_t seq) {
+            uint32_t* __restrict__ num_rendered, uint32_t* host_word, uint32_t seq, const uint32_t* __restrict__ sort_err) {
     __shared__ uint64_t wsum[SC_THREADS / 64];
     __shared__ uint64_t wtot[SC_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -104,6 +111,7 @@ scan_finish(int P, const uint2* __restrict__ rect_sorted, const uint64_t* __rest
             }
         }
         if (base + k == (int64_t)P - 1) {
+            if (sort_err && *sort_err) run = ~0ull;      // the depth sort reported a spin time-out: the host must not go on
             num_rendered[0] = (uint32_t)run;
             num_rendered[1] = (uint32_t)(run >> 32);
             if (host_word) {   // publish R to the spinning host: value first, then the sequence number (system-scope release)
@@ -261,11 +269,14 @@ void gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4
 
 void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint2* rect, uint2* rect_sorted, uint32_t* offsets,
                            uint64_t* block_sums, uint2* block_first, uint32_t block_first_cap, uint32_t* num_rendered,
-                           uint32_t* host_word, uint32_t seq, hipStream_t st) {
+                           uint32_t* host_word, uint32_t seq, bool rect_already_sorted, const uint32_t* sort_err, hipStream_t st) {
     const int nb = (P + GSR_SCAN_ITEMS - 1) / GSR_SCAN_ITEMS;
-    hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(SC_THREADS), 0, st, P, order, rect, rect_sorted, block_sums);
+    if (rect_already_sorted)
+        hipLaunchKernelGGL(scan_block_sums<false>, dim3(nb), dim3(SC_THREADS), 0, st, P, order, rect, rect_sorted, block_sums);
+    else
+        hipLaunchKernelGGL(scan_block_sums<true>, dim3(nb), dim3(SC_THREADS), 0, st, P, order, rect, rect_sorted, block_sums);
     hipLaunchKernelGGL(scan_finish, dim3(nb), dim3(SC_THREADS), 0, st, P, rect_sorted, block_sums, offsets, block_first,
-                       block_first_cap, num_rendered, host_word, seq);
+                       block_first_cap, num_rendered, host_word, seq, sort_err);
 }
 
 void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect,

@@ -31,11 +31,14 @@ int fail(int code, const std::string& msg) {
 // ---- options / profiling ----
 int g_render_fwd_variant = 0;
 int g_render_bwd_variant = 0;
+int g_depth_sort_mode = 0;      // 0 = hist / scan / scatter per pass, 1 = one kernel per pass ("onesweep", sort.hip)
 int g_tile_sort_mode = 0;       // 0 = fused emission + two-level sort (tilesort.hip), 1 = legacy emit + LSD passes (A/B)
 
 struct PendingEvent { int stage; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
+bool g_count_on = false;      // work counters of the blend kernels (bit 1 of gsr_profile_enable): they serialise on two global words
+                              // and slow the kernels several times over, so they are never on while stages are being timed
 std::vector<PendingEvent> g_pending;
 std::vector<hipEvent_t> g_pool;
 double g_stage_ms[GSR_STAGE_COUNT] = {0};
@@ -181,6 +184,7 @@ GsrGeom gsr_carve_geom(char* base, int P) {
     g.block_first = (uint2*)take(gsr_block_first_cap(P) * 8);
     g.sort_hist = (uint32_t*)take((size_t)256 * (size_t)gsr_sort_blocks((int64_t)n, true) * 4);   // small workgroups: worst case
     g.digit_total = (uint32_t*)take(256 * 4);
+    g.os_scratch = (uint32_t*)take(gsr_onesweep_scratch_bytes((int64_t)n));
     g.num_rendered = (uint32_t*)take(128);
     g.bytes = off;
     return g;
@@ -265,6 +269,11 @@ int gsr_set_option(const char* name, int value) {
         g_sort_items_large = value;
         return GSR_OK;
     }
+    if (!strcmp(name, "depth_sort_mode")) {
+        if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "depth_sort_mode must be 0 (three kernels per pass) or 1 (onesweep)");
+        g_depth_sort_mode = value;
+        return GSR_OK;
+    }
     if (!strcmp(name, "tile_sort_mode")) {
         if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "tile_sort_mode must be 0 (fused) or 1 (legacy LSD)");
         g_tile_sort_mode = value;
@@ -275,11 +284,12 @@ int gsr_set_option(const char* name, int value) {
 
 int gsr_profile_enable(int on) {
     std::lock_guard<std::mutex> l(g_prof_mu);
-    if (on && !g_counters) {      // measurement only: the product path never allocates
+    g_count_on = (on & 2) != 0;
+    if (g_count_on && !g_counters) {      // measurement only: the product path never allocates
         if (hipMalloc((void**)&g_counters, GSR_COUNTER_COUNT * sizeof(unsigned long long)) != hipSuccess) g_counters = nullptr;
         else (void)hipMemset(g_counters, 0, GSR_COUNTER_COUNT * sizeof(unsigned long long));
     }
-    g_prof_on = on != 0;
+    g_prof_on = (on & 1) != 0;
     return GSR_OK;
 }
 int gsr_profile_counters(uint64_t* out, int n, int reset) {
@@ -324,8 +334,15 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
                           GsrResizeFn binning_resize, void* binning_user, GsrResizeFn image_resize, void* image_user,
                           float* out_color, float* out_invdepth, int32_t* num_rendered, hipStream_t st) {
     int order_buf;
+    uint32_t* sort_err = nullptr;
+    const bool onesweep = g_depth_sort_mode == 1;
     {   StageTimer t(GSR_STAGE_DEPTH_SORT, st);
-        order_buf = gsr_radix_sort_pairs(g.keys, g.vals, P, 32, GSR_DEPTH_DIGIT_BITS, g.sort_hist, g.digit_total, sort_items(P), st);
+        if (onesweep) {
+            gsr_onesweep_depth_sort(g.keys, g.vals, P, g.os_scratch, g.rect, g.rect_sorted, &sort_err, st);
+            order_buf = 0;
+        } else {
+            order_buf = gsr_radix_sort_pairs(g.keys, g.vals, P, 32, GSR_DEPTH_DIGIT_BITS, g.sort_hist, g.digit_total, sort_items(P), st);
+        }
     }
     STAGE_CHECK("depth sort");
     // R = number of (Gaussian, tile) instances sizes the binning buffer, so the host must learn it mid-pipeline (the
@@ -346,7 +363,7 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     const uint32_t bf_cap = (uint32_t)gsr_block_first_cap(P);
     {   StageTimer t(GSR_STAGE_SCAN, st);
         gsr_launch_scan_tiles(P, g.vals[order_buf], g.rect, g.rect_sorted, g.offsets, g.block_sums, g.block_first, bf_cap,
-                              g.num_rendered, hw_slot.dev, seq, st);
+                              g.num_rendered, hw_slot.dev, seq, onesweep, sort_err, st);
     }
     const int n_tiles = cam.gx * cam.gy;
     GsrTileSortPlan plan;
@@ -383,6 +400,7 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
     const uint64_t R64 = ((uint64_t)hw_slot.host[2] << 32) | (uint64_t)hw_slot.host[0];
+    if (R64 == ~0ull) return fail(GSR_ERR_HIP, "depth sort: a workgroup timed out waiting for its predecessors");
     if (R64 > 0x7FFFFFFFull) return fail(GSR_ERR_UNSUPPORTED, "more than 2^31-1 tile instances");
     const int64_t R = (int64_t)R64;
     *num_rendered = (int32_t)R;
@@ -441,7 +459,7 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     {   StageTimer t(GSR_STAGE_RENDER, st);
         gsr_launch_render_forward(cam, im.ranges, b.vals[list_buf], g.splats, settings->no_backward ? nullptr : im.final_T,
                                   settings->no_backward ? nullptr : im.n_contrib, out_color, out_invdepth,
-                                  g_render_fwd_variant, g_prof_on ? g_counters : nullptr, st);
+                                  g_render_fwd_variant, g_count_on ? g_counters : nullptr, st);
     }
     STAGE_CHECK("render");
     HIP_OK(hipGetLastError());
@@ -585,7 +603,7 @@ int gsr_backward_blend(const GsrRasterSettings* settings, int P, int32_t num_ren
             HIP_OK(hipMemsetAsync(w.inst_flag, 0, (size_t)num_rendered * 4, st));
             gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib,
                                        dL_dout_color, dL_dout_invdepth, nullptr, w.inst_grads, w.inst_flag, num_rendered,
-                                       g_render_bwd_variant, g_prof_on ? g_counters : nullptr, st);
+                                       g_render_bwd_variant, g_count_on ? g_counters : nullptr, st);
         }
     }
     STAGE_CHECK("render backward blend");

@@ -43,7 +43,8 @@ struct GsrGeom {                 // P-sized
     uint2* block_first;          // [gsr_block_first_cap(P)] per 4096-instance block: (depth-order index of its first Gaussian, instances before it)
     uint32_t* sort_hist;         // [256 * nblocks_small(P)] radix block histograms
     uint32_t* digit_total;       // [256]
-    uint32_t* num_rendered;      // [1] (+ order_buf index in [1])
+    uint32_t* os_scratch;        // gsr_onesweep_scratch_bytes(P): tables / descriptor words of the one-kernel-per-pass depth sort
+    uint32_t* num_rendered;      // [2] R as 64 bits
     size_t bytes;
 };
 GsrGeom gsr_carve_geom(char* base, int P);
@@ -95,6 +96,10 @@ int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nb
                          uint32_t* digit_total, int items, hipStream_t st);
 int gsr_radix_sort_pairs_k16(uint16_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
                              uint32_t* digit_total, int items, hipStream_t st);
+// one-kernel-per-pass depth sort (4 x 8 bits) with the rectangle gather fused into the last pass; result in vals[0]
+size_t gsr_onesweep_scratch_bytes(int64_t n);
+void gsr_onesweep_depth_sort(uint32_t* keys[2], uint32_t* vals[2], int64_t n, uint32_t* scratch, const uint2* rect,
+                             uint2* rect_sorted, uint32_t** err_word_dev, hipStream_t st);
 // pass plan shared by the sorter and by code that must know which ping-pong buffer holds the result
 int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits /*[8]*/);
 #define GSR_DEPTH_DIGIT_BITS 8      // 32-bit depth keys: 4 passes of 8 bits (3 x 11 bits measured slower: 113 vs 91 us)
@@ -108,7 +113,8 @@ static inline int64_t gsr_sort_blocks(int64_t n, bool small_blocks) {
 // host_word (mapped pinned, may be NULL): [0] = R low word, [2] = R high word, [1] = seq (stored last)
 void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint2* rect, uint2* rect_sorted /*[P]*/, uint32_t* offsets,
                            uint64_t* block_sums, uint2* block_first, uint32_t block_first_cap, uint32_t* num_rendered,
-                           uint32_t* host_word, uint32_t seq, hipStream_t st);
+                           uint32_t* host_word, uint32_t seq, bool rect_already_sorted, const uint32_t* sort_err /*device, may be NULL*/,
+                           hipStream_t st);
 // legacy emission (frames with more than 65536 tiles): 32-bit tile ids
 void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect_sorted,
                      void* inst_keys, bool key16, uint32_t* inst_vals, float4* splats /*NULL: skip the goffset write*/,

@@ -270,6 +270,218 @@ rs_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_i
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// "onesweep" pass for the depth sort (P keys, 8-bit digits): ONE kernel per pass instead of hist + scan + scatter.
+// Every workgroup ranks its 4096 keys locally, PUBLISHES its per-digit counts as flagged 32-bit words
+// (agent-scope stores: the word is data and flag at once -- cdna_hip_programming.md G16 form R2, no fences), then sums the
+// counts of ALL its predecessors (a column sum, not a serial look-back chain: with <= a few hundred workgroups that start
+// together every predecessor publishes at about the same time, and a serial chain of ~1 us hops would dominate) and
+// scatters.  Workgroups beyond 256 are chained through per-group inclusive prefixes.  Order of arrival is made explicit
+// with a TICKET (atomicAdd): a workgroup only ever waits for lower tickets, which have started by construction, so the
+// protocol cannot deadlock whatever the dispatch order or residency.  Every spin is bounded; on expiry an error word is
+// set (the host then reports an error instead of hanging).  Digit totals of all four passes come from one up-front
+// histogram kernel (digit histograms do not depend on the order of the keys).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int OS_IPT = 16;
+constexpr int OS_ITEMS = RS_THREADS * OS_IPT;      // 4096 keys per workgroup
+constexpr int OS_GROUP = 256;                      // workgroups per look-back group
+constexpr uint32_t OS_FLAG = 0x80000000u;
+constexpr uint32_t OS_SPIN_LIMIT = 1u << 22;
+
+typedef __attribute__((address_space(1))) uint32_t os_gu32;
+
+__device__ __forceinline__ void os_publish(uint32_t* p, uint32_t v) {
+    __hip_atomic_store((os_gu32*)p, v | OS_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t os_peek(const uint32_t* p) {
+    return __hip_atomic_load((os_gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// sum of the published words col[b * 256] for b in [b0, b1)
+__device__ __forceinline__ uint32_t os_column_sum(const uint32_t* col, int b0, int b1, uint32_t* err) {
+    uint32_t sum = 0;
+    for (int b = b0; b < b1; b += 8) {
+        uint32_t spins = 0;
+        for (;;) {
+            uint32_t v[8];
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                v[k] = (b + k < b1) ? os_peek(col + (int64_t)(b + k) * 256) : OS_FLAG;
+                ok &= (v[k] & OS_FLAG) != 0u;
+            }
+            if (ok) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sum += v[k] & ~OS_FLAG;
+                break;
+            }
+            if (++spins > OS_SPIN_LIMIT) { *err = 1u; return sum; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return sum;
+}
+
+// Digit histograms of all four passes of every workgroup's 4096 keys: table[(pass * 256 + d) * nblk + blk].
+// Also resets the state of the four passes (descriptor words, group prefixes, tickets, error word).
+__global__ void __launch_bounds__(RS_THREADS)
+os_hist_all(const uint32_t* __restrict__ keys, int64_t n, uint32_t* __restrict__ table, int nblk, uint32_t* __restrict__ desc,
+            uint32_t* __restrict__ group_incl, int ngroups, uint32_t* __restrict__ tickets) {
+    __shared__ uint32_t h[4][256];
+    const int tid = threadIdx.x, lane = tid & 63;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) h[p][tid] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * OS_ITEMS;
+    uint32_t k[OS_IPT];
+#pragma unroll
+    for (int r = 0; r < OS_IPT; ++r) {
+        const int64_t idx = base + (int64_t)r * RS_THREADS + tid;
+        k[r] = idx < n ? keys[idx] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < OS_IPT; ++r) {
+        const int64_t idx = base + (int64_t)r * RS_THREADS + tid;
+        const bool valid = idx < n;
+        const uint64_t vm = __ballot(valid);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t d = (k[r] >> (8 * p)) & 255u;
+            // the high digits of depth keys are nearly constant: a wave whose valid lanes all agree adds once
+            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+            const uint64_t same = __ballot(valid && d == d0);
+            if (same == vm) {
+                if (lane == 0 && vm) atomicAdd(&h[p][d0], (uint32_t)__popcll(vm));
+            } else if (valid) {
+                atomicAdd(&h[p][d], 1u);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        table[((int64_t)p * 256 + tid) * nblk + blockIdx.x] = h[p][tid];
+        desc[((int64_t)p * nblk + blockIdx.x) * 256 + tid] = 0u;
+        if ((int)blockIdx.x < ngroups) group_incl[((int64_t)p * ngroups + blockIdx.x) * 256 + tid] = 0u;
+    }
+    if (blockIdx.x == 0 && tid < 8) tickets[tid] = 0u;     // [0..3] tickets, [4] error word
+}
+
+// grid = 4 (one workgroup per pass): digit_start[pass][d] = number of keys whose digit of that pass is < d
+__global__ void __launch_bounds__(RS_THREADS)
+os_hist_reduce(const uint32_t* __restrict__ table, int nblk, uint32_t* __restrict__ digit_start) {
+    __shared__ uint32_t wsum[RS_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t* row = table + ((int64_t)blockIdx.x * 256 + tid) * nblk;
+    uint32_t v[1] = {0u};
+    int b = 0;
+    for (; b + 4 <= nblk; b += 4) v[0] += row[b] + row[b + 1] + row[b + 2] + row[b + 3];
+    for (; b < nblk; ++b) v[0] += row[b];
+    digit_start[blockIdx.x * 256 + tid] = block_excl_scan<1>(v, wsum, lane, w);
+}
+
+// FIRST: values are the item indices (not read); LAST: keys are not written (nobody reads them after the sort) and the
+// tile rectangle of every Gaussian is gathered into depth order (rect_sorted) -- the 8-byte random gather the scan kernel
+// used to do, here hidden behind the other workgroups' ranking.
+template <bool FIRST, bool LAST>
+__global__ void __launch_bounds__(RS_THREADS)
+os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+        uint32_t* __restrict__ vals_out, int64_t n, int shift, const uint32_t* __restrict__ digit_start /*[256] of this pass*/,
+        uint32_t* desc /*[nblk][256]*/, uint32_t* group_incl /*[ngroups][256]*/, uint32_t* ticket, uint32_t* err,
+        const uint2* __restrict__ rect, uint2* __restrict__ rect_sorted) {
+    __shared__ uint32_t wave_cnt[RS_WAVES][256];
+    __shared__ uint32_t digit_base[256];
+    __shared__ uint32_t wsum[RS_WAVES];
+    __shared__ uint32_t s_key[OS_ITEMS];
+    __shared__ uint32_t s_val[OS_ITEMS];
+    __shared__ uint32_t s_vb;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_vb = atomicAdd(ticket, 1u);
+#pragma unroll
+    for (int k = 0; k < RS_WAVES; ++k) wave_cnt[k][tid] = 0;
+    const uint32_t dstart = digit_start[tid];
+    __syncthreads();
+    const int vb = (int)s_vb;                      // virtual workgroup id = arrival order
+    const int64_t wave_base = (int64_t)vb * OS_ITEMS + (int64_t)w * (64 * OS_IPT);
+    uint32_t key[OS_IPT], val[OS_IPT], rank[OS_IPT];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < OS_IPT; ++r) {
+        const int64_t idx = wave_base + r * 64 + lane;
+        const bool valid = idx < n;
+        key[r] = valid ? keys_in[idx] : 0u;
+        val[r] = FIRST ? (uint32_t)idx : (valid ? vals_in[idx] : 0u);
+    }
+#pragma unroll
+    for (int r = 0; r < OS_IPT; ++r) {
+        const int64_t idx = wave_base + r * 64 + lane;
+        const bool valid = idx < n;
+        const uint32_t d = (key[r] >> shift) & 255u;
+        uint64_t mask = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            mask &= bit ? bal : ~bal;
+        }
+        const uint32_t prior = wave_cnt[w][d];
+        rank[r] = prior + (uint32_t)__popcll(mask & lt_mask);
+        if (valid && (mask & lt_mask) == 0ull) wave_cnt[w][d] = prior + (uint32_t)__popcll(mask);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // this workgroup's count of digit `tid`, published at once; local offsets while the others publish
+    uint32_t tot[1] = {wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid]};
+    os_publish(desc + (int64_t)vb * 256 + tid, tot[0]);
+    const uint32_t lbase = block_excl_scan<1>(tot, wsum, lane, w);
+    {
+        uint32_t run = lbase;
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; ++k) {
+            const uint32_t t = wave_cnt[k][tid];
+            wave_cnt[k][tid] = run;
+            run += t;
+        }
+    }
+    // keys with digit `tid` in the workgroups before this one
+    const int g = vb / OS_GROUP, g0 = g * OS_GROUP;
+    uint32_t before = os_column_sum(desc + tid, g0, vb, err);
+    if (g > 0) {
+        uint32_t spins = 0, v;
+        while (((v = os_peek(group_incl + (int64_t)(g - 1) * 256 + tid)) & OS_FLAG) == 0u) {
+            if (++spins > OS_SPIN_LIMIT) { *err = 1u; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        before += v & ~OS_FLAG;
+    }
+    if (vb == g0 + OS_GROUP - 1) os_publish(group_incl + (int64_t)g * 256 + tid, before + tot[0]);   // last of its group
+    digit_base[tid] = dstart + before - lbase;        // global position = digit_base[d] + local slot
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < OS_IPT; ++r) {
+        const int64_t idx = wave_base + r * 64 + lane;
+        if (idx < n) {
+            const uint32_t d = (key[r] >> shift) & 255u;
+            const uint32_t lp = wave_cnt[w][d] + rank[r];
+            s_key[lp] = key[r];
+            s_val[lp] = val[r];
+        }
+    }
+    __syncthreads();
+    const int64_t block_base = (int64_t)vb * OS_ITEMS;
+    const uint32_t nvalid = (uint32_t)((n - block_base) < (int64_t)OS_ITEMS ? (n - block_base) : OS_ITEMS);
+#pragma unroll
+    for (int r = 0; r < OS_IPT; ++r) {
+        const uint32_t i = (uint32_t)r * RS_THREADS + tid;
+        if (i < nvalid) {
+            const uint32_t k = s_key[i], v = s_val[i];
+            const uint32_t pos = digit_base[(k >> shift) & 255u] + i;
+            if (!LAST) keys_out[pos] = k;
+            vals_out[pos] = v;
+            if (LAST) rect_sorted[pos] = rect[v];
+        }
+    }
+}
+
 template <typename KeyT, int IPT, int BITS>
 void sort_pass(KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vout, int64_t n, int shift, uint32_t* hist,
                uint32_t* digit_total, int nblocks, hipStream_t st) {
@@ -321,6 +533,36 @@ int sort_pairs_t(KeyT* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max
 }
 
 }  // namespace
+
+size_t gsr_onesweep_scratch_bytes(int64_t n) {
+    const size_t nblk = (size_t)((n + OS_ITEMS - 1) / OS_ITEMS), ngroups = (nblk + OS_GROUP - 1) / OS_GROUP;
+    return (4 * 256 * nblk /*table*/ + 4 * nblk * 256 /*desc*/ + 4 * ngroups * 256 /*group prefixes*/ + 4 * 256 /*digit_start*/ + 64) * 4;
+}
+
+// Depth sort of n (key, index) pairs, 4 onesweep passes of 8 bits: keys[0] in, vals[0] out (even pass count); vals need not
+// be initialised.  rect / rect_sorted: see os_pass<LAST>.  *err_word_dev receives the device address of the error word
+// (non-zero after a spin time-out).
+void gsr_onesweep_depth_sort(uint32_t* keys[2], uint32_t* vals[2], int64_t n, uint32_t* scratch, const uint2* rect,
+                             uint2* rect_sorted, uint32_t** err_word_dev, hipStream_t st) {
+    const int nblk = (int)((n + OS_ITEMS - 1) / OS_ITEMS), ngroups = (nblk + OS_GROUP - 1) / OS_GROUP;
+    uint32_t* table = scratch;
+    uint32_t* desc = table + (size_t)4 * 256 * nblk;
+    uint32_t* group_incl = desc + (size_t)4 * nblk * 256;
+    uint32_t* digit_start = group_incl + (size_t)4 * ngroups * 256;
+    uint32_t* tickets = digit_start + 4 * 256;
+    if (err_word_dev) *err_word_dev = tickets + 4;
+    hipLaunchKernelGGL(os_hist_all, dim3(nblk), dim3(RS_THREADS), 0, st, keys[0], n, table, nblk, desc, group_incl, ngroups, tickets);
+    hipLaunchKernelGGL(os_hist_reduce, dim3(4), dim3(RS_THREADS), 0, st, table, nblk, digit_start);
+#define GSR_OS_PASS(FIRST_, LAST_, P_, IN_, OUT_)                                                                                   \
+    hipLaunchKernelGGL((os_pass<FIRST_, LAST_>), dim3(nblk), dim3(RS_THREADS), 0, st, keys[IN_], vals[IN_], keys[OUT_], vals[OUT_], n,  \
+                       8 * P_, digit_start + 256 * P_, desc + (size_t)P_ * nblk * 256, group_incl + (size_t)P_ * ngroups * 256,       \
+                       tickets + P_, tickets + 4, rect, rect_sorted)
+    GSR_OS_PASS(true, false, 0, 0, 1);
+    GSR_OS_PASS(false, false, 1, 1, 0);
+    GSR_OS_PASS(false, false, 2, 0, 1);
+    GSR_OS_PASS(false, true, 3, 1, 0);
+#undef GSR_OS_PASS
+}
 
 void gsr_launch_rs_scan(uint32_t* block_hist, int nblocks, int ndigits, uint32_t* digit_total, hipStream_t st) {
     hipLaunchKernelGGL(rs_scan, dim3(ndigits), dim3(RS_THREADS), 0, st, block_hist, nblocks, digit_total);

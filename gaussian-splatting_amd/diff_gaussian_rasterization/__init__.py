@@ -64,6 +64,8 @@ def _bucket(nbytes: int) -> int:
 
 
 _last_size: dict = {}
+_last_R = 0          # num_rendered of the most recent forward (diagnostics: tools/train_run.py)
+_max_R = 0
 
 
 def _sized(kind: str, device, nbytes: int) -> int:
@@ -198,6 +200,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.tile_rows = tile_rows
         ctx.grad_sync = grad_sync
         ctx.num_rendered = int(nr.value)
+        global _last_R, _max_R
+        _last_R = ctx.num_rendered
+        _max_R = max(_max_R, _last_R)
         ctx.M = M
         ctx.op_shape = tuple(opacities.shape)
         ctx.has_means2D = means2D is not None

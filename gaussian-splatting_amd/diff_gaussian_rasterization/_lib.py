@@ -146,6 +146,11 @@ def load() -> C.CDLL:
     if lib.gsr_abi_version() != ABI_VERSION:
         raise GsrError(f"{path}: ABI version {lib.gsr_abi_version()} != {ABI_VERSION}")
     _lib = lib
+    # measurement hook: GSR_OPTIONS="name=value,name=value" applies gsr_set_option switches at load time (A/B runs of the
+    # test-suite and of bench.py without editing them); unknown names raise
+    for kv in filter(None, os.environ.get("GSR_OPTIONS", "").split(",")):
+        k, v = kv.split("=")
+        check(lib.gsr_set_option(k.strip().encode(), int(v)), f"GSR_OPTIONS {kv}")
     return lib
 
 
@@ -159,8 +164,9 @@ def set_option(name: str, value: int) -> None:
     check(load().gsr_set_option(name.encode(), int(value)), "gsr_set_option")
 
 
-def profile_enable(on: bool) -> None:
-    load().gsr_profile_enable(1 if on else 0)
+def profile_enable(on, counters: bool = False) -> None:
+    """on: per-stage HIP events; counters: the blend kernels' work counters (they slow the kernels: use a separate pass)."""
+    load().gsr_profile_enable((1 if on else 0) | (2 if counters else 0))
 
 
 def profile_reset() -> None:

@@ -274,7 +274,7 @@ enum {
     GSR_STAGE_GATHER_BWD = 9,
     GSR_STAGE_COUNT = 10
 };
-int gsr_profile_enable(int on);
+int gsr_profile_enable(int on);      /* bit 0: per-stage events; bit 1: work counters (slow the blend kernels: count in a separate pass) */
 int gsr_profile_reset(void);
 /* Resolves pending events (synchronises them) and returns accumulated ms and launch counts per stage. */
 int gsr_profile_read(float* ms_out, int32_t* count_out, int n);

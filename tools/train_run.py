@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--extent", type=float, default=4.0, help="scene extent (cameras_extent of the reference)")
     ap.add_argument("--max-P", type=int, default=4_000_000, help="densification stops growing the set beyond this (memory guard)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--grad-threshold", type=float, default=0.0002, help="densify_grad_threshold (arguments/__init__.py:95)")
+    ap.add_argument("--tag", default="")
     a = ap.parse_args()
 
     from gsr_synth import look_at_camera, make_camera, make_scene
@@ -142,7 +144,7 @@ def main():
                 stats.add(m2.grad, radii > 0, radii)
                 if it > 500 and it % 100 == 0:
                     grow = params["xyz"].shape[0] < a.max_P
-                    params, stats, _ = densify_and_prune(opt, stats, max_grad=0.0002 if grow else 1e30, min_opacity=0.005, extent=ext,
+                    params, stats, _ = densify_and_prune(opt, stats, max_grad=a.grad_threshold if grow else 1e30, min_opacity=0.005, extent=ext,
                                                          max_screen_size=20 if it > 3000 else None, radii=radii)
                 if it % 3000 == 0:
                     params["opacity"] = reset_opacity(opt, 0.01)
@@ -156,7 +158,9 @@ def main():
             torch.cuda.synchronize()
             now = time.perf_counter()
             window_t.append({"until_iter": it, "iters_per_s": round((5000 if it % 5000 == 0 else it % 5000) / (now - t_win), 2),
-                             "P": int(params["xyz"].shape[0]), "loss": round(float(loss.detach()), 5)})
+                             "P": int(params["xyz"].shape[0]), "loss": round(float(loss.detach()), 5),
+                             "num_rendered": int(dgr._last_R) if hasattr(dgr, "_last_R") else None,
+                             "mem_allocated": int(torch.cuda.memory_allocated()), "mem_reserved": int(torch.cuda.memory_reserved())})
             t_win = now
         if it % 1000 == 0:
             sizes.append(int(params["xyz"].shape[0]))
@@ -167,16 +171,16 @@ def main():
            "config": {"workload": f"configs[2] stand-in: P0 {P0} -> densified, {W}x{H}, {len(cams)} synthetic views cycled without "
                                   f"replacement, target scene {a.P_target} Gaussians (SURVEY 8(d) generator, seed {a.seed})",
                       "optimizer": "FusedAdam (dense)" if a.dense_adam else "SparseGaussianAdam + separate_sh call form",
-                      "schedule": "densify 500..15000 every 100 (grad 0.0002, opacity 0.005, size 20 after 3000), opacity reset / 3000, "
+                      "schedule": f"densify 500..15000 every 100 (grad {a.grad_threshold:g}, opacity 0.005, size 20 after 3000), opacity reset / 3000, "
                                   "SH degree +1 / 1000, position lr 1.6e-4 -> 1.6e-6 x extent", "extent": ext},
            "final_P": int(params["xyz"].shape[0]), "max_P": max(sizes + [P0]), "P_every_1000_iters": sizes,
            "windows": window_t, "peak_device_memory_bytes": int(torch.cuda.max_memory_allocated()),
-           "peak_scratch_bytes": {f"{k[0]}": int(v) for k, v in dgr._last_size.items()},
+           "scratch_bytes_last": {f"{k[0]}": int(v) for k, v in dgr._last_size.items()}, "max_num_rendered": int(dgr._max_R),
            "data": "synthetic", "dtype": "f32"}
     print(json.dumps(out), flush=True)
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        tag = "dense" if a.dense_adam else "sparse"
+        tag = ("dense" if a.dense_adam else "sparse") + a.tag
         json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"train_run_{tag}.json"), "w"), indent=1)
     except Exception:
         pass
