@@ -236,7 +236,10 @@ tile_ranges(int64_t R, const KeyT* __restrict__ keys, uint2* __restrict__ ranges
 // when it runs with the band itself.
 __global__ void __launch_bounds__(256)
 splat_ingest(int P, const float4* __restrict__ records, int y0, int y1, float4* __restrict__ splats, uint2* __restrict__ rect,
-             uint32_t* __restrict__ tiles, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+             uint32_t* __restrict__ tiles, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+             uint32_t* __restrict__ sort_state) {
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < GSR_OS_STATE_WORDS; i += 256) sort_state[i] = 0u;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 q0 = records[i * 4 + 0], q1 = records[i * 4 + 1], q2 = records[i * 4 + 2], q3 = records[i * 4 + 3];
         const uint32_t rx = __float_as_uint(q3.x), ry = __float_as_uint(q3.y), full = __float_as_uint(q3.w);
@@ -259,12 +262,12 @@ splat_ingest(int P, const float4* __restrict__ records, int y0, int y1, float4* 
 }  // namespace
 
 void gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
-                             uint32_t* keys, uint32_t* vals, hipStream_t st) {
+                             uint32_t* keys, uint32_t* vals, uint32_t* sort_state, hipStream_t st) {
     int64_t nb = ((int64_t)P + 255) / 256;
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(splat_ingest, dim3((int)nb), dim3(256), 0, st, P, reinterpret_cast<const float4*>(records), y0, y1, splats,
-                       rect, tiles, keys, vals);
+                       rect, tiles, keys, vals, sort_state);
 }
 
 void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint2* rect, uint2* rect_sorted, uint32_t* offsets,

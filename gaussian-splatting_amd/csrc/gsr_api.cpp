@@ -554,7 +554,7 @@ int gsr_rasterize_from_splats(const GsrRasterSettings* settings, int P, const fl
     if (!gbase) return fail(GSR_ERR_ALLOC, "geometry buffer resize returned NULL");
     GsrGeom g = gsr_carve_geom(gbase, P);
     {   StageTimer t(GSR_STAGE_PREPROCESS, st);
-        gsr_launch_splat_ingest(P, splat_records, cam.tile_y0, cam.tile_y1, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], st);
+        gsr_launch_splat_ingest(P, splat_records, cam.tile_y0, cam.tile_y1, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], g.os_scratch, st);
     }
     STAGE_CHECK("splat ingest");
     return bin_and_render(settings, cam, P, g, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,

@@ -80,7 +80,7 @@ GsrImage gsr_carve_image(char* base, int W, int H);
 void gsr_launch_preprocess(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,
                            const float* rotations, const float* cov3D_precomp, GsrGeom g, int32_t* radii,
-                           hipStream_t st);
+                           hipStream_t st);      // also zeroes the first GSR_OS_STATE_WORDS words of g.os_scratch
 void gsr_launch_preprocess_backward(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
                                     const float* colors_precomp, const float* opacities, const float* scales,
                                     const float* rotations, const float* cov3D_precomp, const int32_t* radii,
@@ -96,6 +96,7 @@ int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nb
                          uint32_t* digit_total, int items, hipStream_t st);
 int gsr_radix_sort_pairs_k16(uint16_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
                              uint32_t* digit_total, int items, hipStream_t st);
+#define GSR_OS_STATE_WORDS 1088      // digit totals [4][256] + tickets [4] + error word (+ pad); zeroed by the key-producing kernel
 // one-kernel-per-pass depth sort (4 x 8 bits) with the rectangle gather fused into the last pass; result in vals[0]
 size_t gsr_onesweep_scratch_bytes(int64_t n);
 void gsr_onesweep_depth_sort(uint32_t* keys[2], uint32_t* vals[2], int64_t n, uint32_t* scratch, const uint2* rect,
@@ -187,4 +188,4 @@ void gsr_launch_ssim_mean_backward(int planes, int H, int W, const float* img1, 
                                    hipStream_t st);
 // binning.hip: gathered splat records -> geometry state of this rank's band (two-axis sharding)
 void gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
-                             uint32_t* keys, uint32_t* vals, hipStream_t st);
+                             uint32_t* keys, uint32_t* vals, uint32_t* sort_state /*zeroed, GSR_OS_STATE_WORDS*/, hipStream_t st);

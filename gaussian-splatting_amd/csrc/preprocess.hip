@@ -169,8 +169,11 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
                       const float* __restrict__ scales, const float* __restrict__ rotations,
                       const float* __restrict__ cov3D_precomp, float4* __restrict__ splats,
                       uint2* __restrict__ rect, uint32_t* __restrict__ tiles, uint32_t* __restrict__ clamped_out,
-                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int32_t* __restrict__ radii) {
+                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int32_t* __restrict__ radii,
+                      uint32_t* __restrict__ sort_state /*GSR_OS_STATE_WORDS words zeroed for the depth sort that follows*/) {
     __shared__ __attribute__((aligned(16))) float s_sh[4][64 * SH_ROW];
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < GSR_OS_STATE_WORDS; i += 256) sort_state[i] = 0u;
     GsrCam cam;
     load_cam(camd, cam);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -375,11 +378,11 @@ void gsr_launch_preprocess(const GsrCamDev& cam, int P, const float* means3D, co
     if (cam.sh_dc)
         hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, g.splats, g.rect, g.tiles,
-                           g.clamped, g.keys[0], g.vals[0], radii);
+                           g.clamped, g.keys[0], g.vals[0], radii, g.os_scratch);
     else
         hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, g.splats, g.rect, g.tiles,
-                           g.clamped, g.keys[0], g.vals[0], radii);
+                           g.clamped, g.keys[0], g.vals[0], radii, g.os_scratch);
 }
 
 void gsr_launch_preprocess_backward(const GsrCamDev& cam, int P, const float* means3D, const float* shs,

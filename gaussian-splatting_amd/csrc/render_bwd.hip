@@ -306,6 +306,177 @@ render_bwd_quad(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// variant 6: one wave per 16x8 HALF tile, two pixels per lane (same row, 8 columns apart).
+// The blend backward is VALU-issue bound (SQ counters), so the lever is instructions per (pixel, entry) pair:
+//  * the two pixels of a lane share dy, c2 dy^2 and every wave-uniform operand, and their per-pixel arithmetic is written
+//    on 2-vectors that compile to v_pk_{mul,add,fma}_f32 (one instruction for both pixels);
+//  * their ten gradient terms are added per lane BEFORE the cross-lane transpose-reduce, so the ~27-instruction reduction is
+//    paid once per (half tile, entry) instead of once per (quadrant, entry);
+//  * an instance gets at most two records (one per half) instead of four, which halves the reduce kernel's stream.
+// Price: the survivor list of a wave is the UNION of its two quadrants' lists (measured on the bench frame: 0.58 of their sum).
+// p2 is computed by the forward's exact operation sequence (mul, fma, fma), so the hard masks agree with the forward's.
+// ------------------------------------------------------------------------------------------------
+struct BwdPix2 {
+    v2f T, accD, lastD, last_alpha;
+};
+
+__global__ void __launch_bounds__(64)
+render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                const float4* __restrict__ splats, const float* __restrict__ final_T,
+                const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                const float* __restrict__ dL_dinvdepth, float4* __restrict__ slot_grads /*[4][R] records of 3 float4*/,
+                uint8_t* __restrict__ slot_flags /*[R][4]*/, int64_t R, unsigned long long* __restrict__ counters) {
+    __shared__ float4 s_rec[64 * REC_STRIDE];
+    __shared__ float s_grad[64 * 12];
+    // the two halves of a tile get workgroup ids b and b + 16 -> same XCD -> they share the gathered records in L2
+    const int b = blockIdx.x;
+    const int grp = b >> 5, r32 = b & 31;
+    const int tile_local = grp * 16 + (r32 & 15);
+    const int half = r32 >> 4;
+    if (tile_local >= n_band_tiles) return;
+    const int tile = cam.tile_y0 * cam.gx + tile_local;
+    const int tx = tile % cam.gx, ty = tile / cam.gx;
+    const int lane = threadIdx.x;
+    const int bx0 = tx * GSR_TILE, by0 = ty * GSR_TILE + half * 8;
+    if (by0 >= cam.H) return;
+    const int pxA = bx0 + (lane & 7), pxB = pxA + 8, py = by0 + (lane >> 3);
+    const bool inA = pxA < cam.W && py < cam.H, inB = pxB < cam.W && py < cam.H;
+    const v2f pxf = {(float)pxA, (float)pxB};
+    const float pyf = (float)py;
+    // boxes of the existing pixels of the two quadrants (the right one may be empty at the image border)
+    const float y0 = (float)by0, y1 = (float)min(by0 + 7, cam.H - 1);
+    const float xa0 = (float)bx0, xa1 = (float)min(bx0 + 7, cam.W - 1);
+    const float xb0 = (float)(bx0 + 8), xb1 = (float)min(bx0 + 15, cam.W - 1);
+    const bool quadB_alive = bx0 + 8 < cam.W;
+    const uint2 range = ranges[tile];
+    const int64_t pixA = (int64_t)py * cam.W + pxA, pixB = pixA + 8;
+    const int64_t HW = (int64_t)cam.H * cam.W;
+    const v2f T_final = {inA ? final_T[pixA] : 0.f, inB ? final_T[pixB] : 0.f};
+    const uint32_t lastA = inA ? n_contrib[pixA] : 0u, lastB = inB ? n_contrib[pixB] : 0u;
+    const v2f dLr = {inA ? dL_dpix[pixA] : 0.f, inB ? dL_dpix[pixB] : 0.f};
+    const v2f dLg = {inA ? dL_dpix[HW + pixA] : 0.f, inB ? dL_dpix[HW + pixB] : 0.f};
+    const v2f dLb = {inA ? dL_dpix[2 * HW + pixA] : 0.f, inB ? dL_dpix[2 * HW + pixB] : 0.f};
+    const v2f dLd = {(inA && dL_dinvdepth) ? dL_dinvdepth[pixA] : 0.f, (inB && dL_dinvdepth) ? dL_dinvdepth[pixB] : 0.f};
+    const v2f Tf_bg = -T_final * (cam.bg[0] * dLr + cam.bg[1] * dLg + cam.bg[2] * dLb);
+    uint32_t mxA = lastA, mxB = lastB;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mxA = max(mxA, (uint32_t)__shfl_xor((int)mxA, off, 64));
+        mxB = max(mxB, (uint32_t)__shfl_xor((int)mxB, off, 64));
+    }
+    const uint32_t end = min(range.y - range.x, max(mxA, mxB));
+    if (end == 0) return;
+
+    BwdPix2 s = {T_final, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    float4* s_grad4 = reinterpret_cast<float4*>(s_grad);
+    float4* slot = slot_grads + (int64_t)half * R * 3;
+    const int nbatch = (int)((end + 63u) >> 6);
+    auto load_id = [&](int bi) -> uint32_t {
+        const uint32_t e = (uint32_t)bi * 64u + (uint32_t)lane;
+        return (bi >= 0 && e < end) ? point_list[range.x + e] : 0xFFFFFFFFu;
+    };
+    uint32_t id_n = load_id(nbatch - 1);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 n0 = zero4, n1 = zero4, n2 = zero4, n3 = zero4;
+    if (id_n != 0xFFFFFFFFu) { n0 = splats[id_n * 4 + 0]; n1 = splats[id_n * 4 + 1]; n2 = splats[id_n * 4 + 2]; n3 = splats[id_n * 4 + 3]; }
+    id_n = load_id(nbatch - 2);
+    uint32_t nsteps = 0;
+    for (int bi = nbatch - 1; bi >= 0; --bi) {
+        const uint32_t base = (uint32_t)bi * 64u;
+        const uint32_t n = min(64u, end - base);
+        const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
+        if (id_n != 0xFFFFFFFFu) { n0 = splats[id_n * 4 + 0]; n1 = splats[id_n * 4 + 1]; n2 = splats[id_n * 4 + 2]; n3 = splats[id_n * 4 + 3]; }
+        id_n = load_id(bi - 2);
+        bool keepA = false, keepB = false;
+        uint32_t k_emit = 0;
+        if ((uint32_t)lane < n) {
+            const uint32_t pos = base + (uint32_t)lane;
+            // an entry at or behind a quadrant's own last contributor touches none of its pixels
+            keepA = pos < mxA && !(min_q_over_box(q0.x, q0.y, q0.z, q0.w, q1.x, xa0, xa1, y0, y1) > q2.z);
+            keepB = quadB_alive && pos < mxB && !(min_q_over_box(q0.x, q0.y, q0.z, q0.w, q1.x, xb0, xb1, y0, y1) > q2.z);
+            k_emit = emission_index(q3, (uint32_t)tx, (uint32_t)ty);
+            s_rec[lane * REC_STRIDE + 0] = make_float4(q0.x, q0.y, -0.5f * LOG2E * q0.z, -LOG2E * q0.w);
+            s_rec[lane * REC_STRIDE + 1] = make_float4(-0.5f * LOG2E * q1.x, q1.y, q1.z, q1.w);
+            s_rec[lane * REC_STRIDE + 2] = make_float4(q2.x, q2.w, 0.f, 0.f);
+        }
+        const uint64_t maskA = __ballot(keepA), maskB = __ballot(keepB);
+        uint64_t mask = maskA | maskB;
+        nsteps += (uint32_t)__popcll(mask);
+        uint64_t touched = 0ull;
+        while (mask) {
+            const int j = 63 - __builtin_clzll(mask);
+            mask &= ~(1ull << j);
+            const uint32_t pos0 = base + (uint32_t)j;
+            const bool doA = (maskA >> j) & 1ull, doB = (maskB >> j) & 1ull;      // wave-uniform
+            const float4 r0 = s_rec[j * REC_STRIDE + 0];
+            const float4 r1 = s_rec[j * REC_STRIDE + 1];
+            const float2 r2 = *reinterpret_cast<const float2*>(&s_rec[j * REC_STRIDE + 2]);
+            const float a2 = r0.z, b2 = r0.w, c2 = r1.x, op = r1.y;
+            // ---- geometry: the forward's operation sequence per pixel (mul, fma, fma), two pixels per instruction ----
+            const v2f dx = (v2f){r0.x, r0.x} - pxf;
+            const float dy = r0.y - pyf;
+            const float u = (c2 * dy) * dy;
+            const v2f t = (v2f){b2, b2} * (v2f){dy, dy} + a2 * dx;
+            const v2f p2 = dx * t + (v2f){u, u};
+            const v2f G = {__builtin_amdgcn_exp2f(p2.x), __builtin_amdgcn_exp2f(p2.y)};
+            const v2f opG = op * G;
+            const v2f alpha = {fminf(GSR_ALPHA_MAX, opG.x), fminf(GSR_ALPHA_MAX, opG.y)};
+            const bool actA = doA & (pos0 < lastA) & (p2.x <= 0.0f) & (alpha.x >= GSR_ALPHA_MIN);
+            const bool actB = doB & (pos0 < lastB) & (p2.y <= 0.0f) & (alpha.y >= GSR_ALPHA_MIN);
+            if (__builtin_amdgcn_ballot_w64(actA | actB) == 0ull) continue;
+            // ---- recurrences (Appendix A.5), inactive pixels keep their state and produce zeros ----
+            const v2f cD = r1.z * dLr + r1.w * dLg + r2.x * dLb + r2.y * dLd;
+            const v2f one_m = (v2f){1.0f, 1.0f} - alpha;
+            const v2f inv1ma = {__builtin_amdgcn_rcpf(one_m.x), __builtin_amdgcn_rcpf(one_m.y)};
+            const v2f Tn = s.T * inv1ma;
+            const v2f accn = s.last_alpha * (s.lastD - s.accD) + s.accD;
+            v2f w = alpha * Tn;
+            v2f dL_dalpha = (cD - accn) * Tn + Tf_bg * inv1ma;
+            s.T = (v2f){actA ? Tn.x : s.T.x, actB ? Tn.y : s.T.y};
+            s.accD = (v2f){actA ? accn.x : s.accD.x, actB ? accn.y : s.accD.y};
+            s.lastD = (v2f){actA ? cD.x : s.lastD.x, actB ? cD.y : s.lastD.y};
+            s.last_alpha = (v2f){actA ? alpha.x : s.last_alpha.x, actB ? alpha.y : s.last_alpha.y};
+            w = (v2f){actA ? w.x : 0.0f, actB ? w.y : 0.0f};
+            dL_dalpha = (v2f){actA ? dL_dalpha.x : 0.0f, actB ? dL_dalpha.y : 0.0f};
+            // ---- the ten per-pair terms, the two pixels added per lane ----
+            const v2f gr2 = w * dLr, gg2 = w * dLg, gb2 = w * dLb, gd2 = w * dLd;
+            const v2f gop2 = G * dL_dalpha;
+            const v2f m = op * gop2;
+            const v2f mdx = m * dx;                 // m dx
+            const v2f mdxx = mdx * dx;              // m dx^2
+            const float msum = m.x + m.y, mdxsum = mdx.x + mdx.y;
+            const float g_px = mdxsum, g_py = msum * dy, g_A = mdxx.x + mdxx.y, g_B = mdxsum * dy, g_C = (msum * dy) * dy;
+            const float g_op = gop2.x + gop2.y, g_r = gr2.x + gr2.y, g_g = gg2.x + gg2.y, g_b = gb2.x + gb2.y, g_d = gd2.x + gd2.y;
+            const float v0 = reduce4(g_px, g_A, g_py, g_B);     // -> slots 0,1,2,3
+            const float v1 = reduce4(g_C, g_r, g_op, g_g);      // -> slots 4,5,6,7
+            const float v2 = reduce2(g_b, g_d);                 // -> slots 8 (lane 31), 9 (lane 63)
+            if ((lane & 15) == 15) {
+                float* o = s_grad + j * 12 + (lane >> 4);
+                o[0] = v0;
+                o[4] = v1;
+                if (lane & 16) s_grad[j * 12 + 8 + (lane >> 5)] = v2;
+            }
+            touched |= 1ull << j;
+        }
+        if (touched) {
+            __builtin_amdgcn_wave_barrier();
+            if ((touched >> lane) & 1ull) {
+                float4* dst = slot + (int64_t)k_emit * 3;
+                dst[0] = s_grad4[lane * 3 + 0];
+                dst[1] = s_grad4[lane * 3 + 1];
+                dst[2] = s_grad4[lane * 3 + 2];
+                slot_flags[(int64_t)k_emit * 4 + half] = 1;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (counters && lane == 0) {
+        atomicAdd(counters + 2, (unsigned long long)nsteps);
+        atomicAdd(counters + 3, (unsigned long long)nbatch);
+    }
+}
+
 #ifdef GSR_AB_VARIANTS
 // ------------------------------------------------------------------------------------------------
 // A/B variant 4 (round 1's default): workgroup per tile, per-instance gradient records, no global atomics
@@ -646,9 +817,9 @@ render_bwd_wave(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
 
 int gsr_render_backward_variant_available(int variant) {
 #ifdef GSR_AB_VARIANTS
-    return variant == 0 || variant == 1 || variant == 4;
+    return variant == 0 || variant == 1 || variant == 4 || variant == 6;
 #else
-    return variant == 0;
+    return variant == 0 || variant == 6;
 #endif
 }
 
@@ -672,7 +843,14 @@ void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const
         return;
     }
 #endif
-    (void)variant; (void)splat_grads;
+    (void)splat_grads;
+    if (variant == 6) {
+        const int groups16 = (n_band_tiles + 15) / 16;
+        hipLaunchKernelGGL(render_bwd_half, dim3(groups16 * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list, splats,
+                           final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads),
+                           reinterpret_cast<uint8_t*>(inst_flag), R, counters);
+        return;
+    }
     hipLaunchKernelGGL(render_bwd_quad, dim3(groups * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list, splats,
                        final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads),
                        reinterpret_cast<uint8_t*>(inst_flag), R, counters);

@@ -296,22 +296,23 @@ __device__ __forceinline__ void os_publish(uint32_t* p, uint32_t v) {
 __device__ __forceinline__ uint32_t os_peek(const uint32_t* p) {
     return __hip_atomic_load((os_gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// sum of the published words col[b * 256] for b in [b0, b1)
+// sum of the published words col[b * 256] for b in [b0, b1).  32 independent loads are in flight per trip (the first
+// version waited for 8 at a time: 30 serial round trips of ~1 us made the pass slower than the three kernels it replaces).
 __device__ __forceinline__ uint32_t os_column_sum(const uint32_t* col, int b0, int b1, uint32_t* err) {
+    constexpr int CH = 32;
     uint32_t sum = 0;
-    for (int b = b0; b < b1; b += 8) {
+    for (int b = b0; b < b1; b += CH) {
         uint32_t spins = 0;
         for (;;) {
-            uint32_t v[8];
+            uint32_t v[CH];
             bool ok = true;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                v[k] = (b + k < b1) ? os_peek(col + (int64_t)(b + k) * 256) : OS_FLAG;
-                ok &= (v[k] & OS_FLAG) != 0u;
-            }
+            for (int k = 0; k < CH; ++k) v[k] = (b + k < b1) ? os_peek(col + (int64_t)(b + k) * 256) : OS_FLAG;
+#pragma unroll
+            for (int k = 0; k < CH; ++k) ok &= (v[k] & OS_FLAG) != 0u;
             if (ok) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) sum += v[k] & ~OS_FLAG;
+                for (int k = 0; k < CH; ++k) sum += v[k] & ~OS_FLAG;
                 break;
             }
             if (++spins > OS_SPIN_LIMIT) { *err = 1u; return sum; }
@@ -321,11 +322,11 @@ __device__ __forceinline__ uint32_t os_column_sum(const uint32_t* col, int b0, i
     return sum;
 }
 
-// Digit histograms of all four passes of every workgroup's 4096 keys: table[(pass * 256 + d) * nblk + blk].
-// Also resets the state of the four passes (descriptor words, group prefixes, tickets, error word).
+// Digit totals of all four passes: totals[pass * 256 + d] (zeroed by the kernel that produced the keys) receive one global
+// atomic per non-empty (workgroup, pass, digit) bin.  Also resets the descriptor words / group prefixes of the four passes.
 __global__ void __launch_bounds__(RS_THREADS)
-os_hist_all(const uint32_t* __restrict__ keys, int64_t n, uint32_t* __restrict__ table, int nblk, uint32_t* __restrict__ desc,
-            uint32_t* __restrict__ group_incl, int ngroups, uint32_t* __restrict__ tickets) {
+os_hist_all(const uint32_t* __restrict__ keys, int64_t n, uint32_t* __restrict__ totals, int nblk, uint32_t* __restrict__ desc,
+            uint32_t* __restrict__ group_incl, int ngroups) {
     __shared__ uint32_t h[4][256];
     const int tid = threadIdx.x, lane = tid & 63;
 #pragma unroll
@@ -337,6 +338,11 @@ os_hist_all(const uint32_t* __restrict__ keys, int64_t n, uint32_t* __restrict__
     for (int r = 0; r < OS_IPT; ++r) {
         const int64_t idx = base + (int64_t)r * RS_THREADS + tid;
         k[r] = idx < n ? keys[idx] : 0u;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        desc[((int64_t)p * nblk + blockIdx.x) * 256 + tid] = 0u;
+        if ((int)blockIdx.x < ngroups) group_incl[((int64_t)p * ngroups + blockIdx.x) * 256 + tid] = 0u;
     }
 #pragma unroll
     for (int r = 0; r < OS_IPT; ++r) {
@@ -359,24 +365,9 @@ os_hist_all(const uint32_t* __restrict__ keys, int64_t n, uint32_t* __restrict__
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        table[((int64_t)p * 256 + tid) * nblk + blockIdx.x] = h[p][tid];
-        desc[((int64_t)p * nblk + blockIdx.x) * 256 + tid] = 0u;
-        if ((int)blockIdx.x < ngroups) group_incl[((int64_t)p * ngroups + blockIdx.x) * 256 + tid] = 0u;
+        const uint32_t c = h[p][tid];
+        if (c) atomicAdd(totals + p * 256 + tid, c);
     }
-    if (blockIdx.x == 0 && tid < 8) tickets[tid] = 0u;     // [0..3] tickets, [4] error word
-}
-
-// grid = 4 (one workgroup per pass): digit_start[pass][d] = number of keys whose digit of that pass is < d
-__global__ void __launch_bounds__(RS_THREADS)
-os_hist_reduce(const uint32_t* __restrict__ table, int nblk, uint32_t* __restrict__ digit_start) {
-    __shared__ uint32_t wsum[RS_WAVES];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t* row = table + ((int64_t)blockIdx.x * 256 + tid) * nblk;
-    uint32_t v[1] = {0u};
-    int b = 0;
-    for (; b + 4 <= nblk; b += 4) v[0] += row[b] + row[b + 1] + row[b + 2] + row[b + 3];
-    for (; b < nblk; ++b) v[0] += row[b];
-    digit_start[blockIdx.x * 256 + tid] = block_excl_scan<1>(v, wsum, lane, w);
 }
 
 // FIRST: values are the item indices (not read); LAST: keys are not written (nobody reads them after the sort) and the
@@ -385,7 +376,7 @@ os_hist_reduce(const uint32_t* __restrict__ table, int nblk, uint32_t* __restric
 template <bool FIRST, bool LAST>
 __global__ void __launch_bounds__(RS_THREADS)
 os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
-        uint32_t* __restrict__ vals_out, int64_t n, int shift, const uint32_t* __restrict__ digit_start /*[256] of this pass*/,
+        uint32_t* __restrict__ vals_out, int64_t n, int shift, const uint32_t* __restrict__ totals /*[256] of this pass*/,
         uint32_t* desc /*[nblk][256]*/, uint32_t* group_incl /*[ngroups][256]*/, uint32_t* ticket, uint32_t* err,
         const uint2* __restrict__ rect, uint2* __restrict__ rect_sorted) {
     __shared__ uint32_t wave_cnt[RS_WAVES][256];
@@ -398,8 +389,8 @@ os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_
     if (tid == 0) s_vb = atomicAdd(ticket, 1u);
 #pragma unroll
     for (int k = 0; k < RS_WAVES; ++k) wave_cnt[k][tid] = 0;
-    const uint32_t dstart = digit_start[tid];
-    __syncthreads();
+    uint32_t dtot[1] = {totals[tid]};
+    const uint32_t dstart = block_excl_scan<1>(dtot, wsum, lane, w);      // keys whose digit is smaller (two barriers inside)
     const int vb = (int)s_vb;                      // virtual workgroup id = arrival order
     const int64_t wave_base = (int64_t)vb * OS_ITEMS + (int64_t)w * (64 * OS_IPT);
     uint32_t key[OS_IPT], val[OS_IPT], rank[OS_IPT];
@@ -536,26 +527,25 @@ int sort_pairs_t(KeyT* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max
 
 size_t gsr_onesweep_scratch_bytes(int64_t n) {
     const size_t nblk = (size_t)((n + OS_ITEMS - 1) / OS_ITEMS), ngroups = (nblk + OS_GROUP - 1) / OS_GROUP;
-    return (4 * 256 * nblk /*table*/ + 4 * nblk * 256 /*desc*/ + 4 * ngroups * 256 /*group prefixes*/ + 4 * 256 /*digit_start*/ + 64) * 4;
+    return (4 * nblk * 256 /*desc*/ + 4 * ngroups * 256 /*group prefixes*/ + GSR_OS_STATE_WORDS) * 4;
 }
 
 // Depth sort of n (key, index) pairs, 4 onesweep passes of 8 bits: keys[0] in, vals[0] out (even pass count); vals need not
-// be initialised.  rect / rect_sorted: see os_pass<LAST>.  *err_word_dev receives the device address of the error word
-// (non-zero after a spin time-out).
+// be initialised.  The first GSR_OS_STATE_WORDS words of `scratch` (digit totals [4][256], tickets [4], error word) must
+// have been ZEROED by the kernel that wrote the keys.  rect / rect_sorted: see os_pass<LAST>.  *err_word_dev receives the
+// device address of the error word (non-zero after a spin time-out).
 void gsr_onesweep_depth_sort(uint32_t* keys[2], uint32_t* vals[2], int64_t n, uint32_t* scratch, const uint2* rect,
                              uint2* rect_sorted, uint32_t** err_word_dev, hipStream_t st) {
     const int nblk = (int)((n + OS_ITEMS - 1) / OS_ITEMS), ngroups = (nblk + OS_GROUP - 1) / OS_GROUP;
-    uint32_t* table = scratch;
-    uint32_t* desc = table + (size_t)4 * 256 * nblk;
+    uint32_t* totals = scratch;
+    uint32_t* tickets = scratch + 4 * 256;
+    uint32_t* desc = scratch + GSR_OS_STATE_WORDS;
     uint32_t* group_incl = desc + (size_t)4 * nblk * 256;
-    uint32_t* digit_start = group_incl + (size_t)4 * ngroups * 256;
-    uint32_t* tickets = digit_start + 4 * 256;
     if (err_word_dev) *err_word_dev = tickets + 4;
-    hipLaunchKernelGGL(os_hist_all, dim3(nblk), dim3(RS_THREADS), 0, st, keys[0], n, table, nblk, desc, group_incl, ngroups, tickets);
-    hipLaunchKernelGGL(os_hist_reduce, dim3(4), dim3(RS_THREADS), 0, st, table, nblk, digit_start);
+    hipLaunchKernelGGL(os_hist_all, dim3(nblk), dim3(RS_THREADS), 0, st, keys[0], n, totals, nblk, desc, group_incl, ngroups);
 #define GSR_OS_PASS(FIRST_, LAST_, P_, IN_, OUT_)                                                                                   \
     hipLaunchKernelGGL((os_pass<FIRST_, LAST_>), dim3(nblk), dim3(RS_THREADS), 0, st, keys[IN_], vals[IN_], keys[OUT_], vals[OUT_], n,  \
-                       8 * P_, digit_start + 256 * P_, desc + (size_t)P_ * nblk * 256, group_incl + (size_t)P_ * ngroups * 256,       \
+                       8 * P_, totals + 256 * P_, desc + (size_t)P_ * nblk * 256, group_incl + (size_t)P_ * ngroups * 256,            \
                        tickets + P_, tickets + 4, rect, rect_sorted)
     GSR_OS_PASS(true, false, 0, 0, 1);
     GSR_OS_PASS(false, false, 1, 1, 0);
