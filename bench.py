@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--s-med", type=float, default=0.012)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--variant", type=int, default=0, help="render_fwd_variant (0 wave + LDS broadcast, 1 workgroup-per-tile baseline, 2 wave + readlane)")
+    ap.add_argument("--variant", type=int, default=None, help="render_fwd_variant (0 wave + LDS broadcast, 1 workgroup-per-tile baseline, 2 wave + readlane)")
     ap.add_argument("--train-steps", type=int, default=-1, help="-1: same as --steps; 0 disables the train leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=1200, help="tiles blended by the CPU baseline sample")
@@ -69,7 +69,7 @@ def parse():
                                                           "one frame after the other (default), 2 = double-buffered frames -- "
                                                           "measured 2.5x SLOWER on MI355X / ROCm 7.2 (1.29 vs 0.52 ms per frame), kept for A/B only")
     ap.add_argument("--sort-items", type=int, default=0, help="keys per workgroup of the large radix passes (1024 / 2048 / 4096; 0 = library default)")
-    ap.add_argument("--bwd-variant", type=int, default=0, help="render_bwd_variant (0 default, 1 atomics baseline, 2 128-entry super-batches)")
+    ap.add_argument("--bwd-variant", type=int, default=None, help="render_bwd_variant (0 default, 1 atomics baseline, 2 128-entry super-batches)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="gsr_set_option(NAME, VALUE) before timing (A/B switches)")
     ap.add_argument("--views", type=int, default=32, help="training views cycled by the train legs (1 = the static camera of round 1)")
     return ap.parse_args()
@@ -139,8 +139,10 @@ def main():
     from diff_gaussian_rasterization.parallel import BandPlan, gather_strips_async, row_costs_from_ranges
 
     _lib.load()
-    _lib.set_option("render_fwd_variant", a.variant)
-    _lib.set_option("render_bwd_variant", a.bwd_variant)
+    if a.variant is not None:
+        _lib.set_option("render_fwd_variant", a.variant)
+    if a.bwd_variant is not None:
+        _lib.set_option("render_bwd_variant", a.bwd_variant)
     if a.sort_items:
         _lib.set_option("sort_items_large", a.sort_items)
     for kv in a.opt:
@@ -518,7 +520,7 @@ def main():
                        "parallelism": "tile-row bands x%d%s" % (world, "" if world == 1 else
                                                                 (" (uniform)" if a.uniform_bands else " (instance-balanced)") +
                                                                 ", strip all-gather of frame i overlapped with frame i+1"),
-                       "render_fwd_variant": a.variant,
+                       "render_fwd_variant": a.variant or 0, "options": os.environ.get("GSR_OPTIONS", ""),
                        "frame_streams": n_streams,
                        "frame_streams_note": "value = frames / time with consecutive frames alternating between HIP streams "
                                              "(double-buffered); frame_latency_ms = one frame after the other on one stream"

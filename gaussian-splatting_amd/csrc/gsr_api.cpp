@@ -341,7 +341,8 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
             gsr_onesweep_depth_sort(g.keys, g.vals, P, g.os_scratch, g.rect, g.rect_sorted, &sort_err, st);
             order_buf = 0;
         } else {
-            order_buf = gsr_radix_sort_pairs(g.keys, g.vals, P, 32, GSR_DEPTH_DIGIT_BITS, g.sort_hist, g.digit_total, sort_items(P), st);
+            order_buf = gsr_radix_sort_pairs(g.keys, g.vals, P, 32, GSR_DEPTH_DIGIT_BITS, g.sort_hist, g.digit_total, sort_items(P), st,
+                                             g.rect, g.rect_sorted);
         }
     }
     STAGE_CHECK("depth sort");
@@ -363,7 +364,7 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     const uint32_t bf_cap = (uint32_t)gsr_block_first_cap(P);
     {   StageTimer t(GSR_STAGE_SCAN, st);
         gsr_launch_scan_tiles(P, g.vals[order_buf], g.rect, g.rect_sorted, g.offsets, g.block_sums, g.block_first, bf_cap,
-                              g.num_rendered, hw_slot.dev, seq, onesweep, sort_err, st);
+                              g.num_rendered, hw_slot.dev, seq, /*rect_already_sorted=*/true, sort_err, st);
     }
     const int n_tiles = cam.gx * cam.gy;
     GsrTileSortPlan plan;

@@ -92,8 +92,10 @@ void gsr_launch_mark_visible(int P, const float* means3D, const float* view, uin
 // sort.hip: LSD radix sort of (u32 key, u32 value) pairs on bits [0, nbits); returns the index (0/1) of the
 // ping-pong buffer that holds the result.  n is known on the host.  items = keys per workgroup: 1024, 2048 or 4096
 // (hist must hold 2^digit_bits * ceil(n / items) counters).
+// rect / rect_sorted (optional): the last pass also writes rect_sorted[pos] = rect[value] (depth sort: the tile rectangles
+// in depth order, which the scan and the emission stream afterwards)
 int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
-                         uint32_t* digit_total, int items, hipStream_t st);
+                         uint32_t* digit_total, int items, hipStream_t st, const uint2* rect = nullptr, uint2* rect_sorted = nullptr);
 int gsr_radix_sort_pairs_k16(uint16_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
                              uint32_t* digit_total, int items, hipStream_t st);
 #define GSR_OS_STATE_WORDS 1088      // digit totals [4][256] + tickets [4] + error word (+ pad); zeroed by the key-producing kernel

@@ -43,6 +43,26 @@ __device__ __forceinline__ void wave_load_sh16(const float* __restrict__ shs, in
     }
     __builtin_amdgcn_wave_barrier();
 }
+// Two-step form of the same copy: the 12 coalesced 16-byte loads of the wave's block are ISSUED first (into registers) and
+// written to the LDS tile later, so that their latency overlaps the projection arithmetic instead of following it.
+__device__ __forceinline__ void wave_issue_sh16(const float* __restrict__ shs, int64_t i0, int P, int lane, float4 (&reg)[12]) {
+    const float4* src = reinterpret_cast<const float4*>(shs + i0 * 48);
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        const int idx = it * 64 + lane;
+        const int g = idx / 12;
+        reg[it] = (i0 + g < P) ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ void wave_commit_sh16(const float4 (&reg)[12], uint64_t rows, int lane, float* tile) {
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        const int idx = it * 64 + lane;
+        const int g = idx / 12, part = idx - g * 12;
+        if ((rows >> g) & 1ull) *reinterpret_cast<float4*>(tile + g * SH_ROW + part * 4) = reg[it];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
 // ... and back: every row (all 64, or up to P) is written -- zero rows included.
 __device__ __forceinline__ void wave_store_sh16(float* __restrict__ dst_all, int64_t i0, int P, int lane, const float* tile) {
     float4* dst = reinterpret_cast<float4*>(dst_all + i0 * 48);
@@ -180,6 +200,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
     float* tile = s_sh[wv];
     const float* dc = SPLIT ? camd.sh_dc : nullptr;          // split form: `shs` holds coefficients 1..15
     const bool staged_sh = shs != nullptr && cam.M == 16;
+    const bool speculative = cam.tile_y0 == 0 && cam.tile_y1 == cam.gy;
     // wave-uniform trip count: every lane of a wave runs the same iterations (lanes past P idle inside)
     for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < P; i0 += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = i0 + lane;
@@ -188,19 +209,45 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         sp.radius = 0; sp.tiles = 0; sp.minx = sp.miny = sp.maxx = sp.maxy = 0; sp.depth = 0.f;
         float mean[3] = {0.f, 0.f, 0.f};
         bool vis = false;
+        // full frame on one GPU: nearly every Gaussian needs its colour, so the SH block is requested up front, together
+        // with the geometry, and one memory latency is exposed per iteration instead of two (projection -> visibility ->
+        // SH loads).  The block goes to the LDS tile as soon as it lands -- for all rows, the visibility is not known yet --
+        // so its 48 registers are free again before the projection arithmetic starts.  Under screen sharding only ~1/N of
+        // the rows are needed: there the loads wait for the visibility mask.
+        const bool spec_sh = !SPLIT && staged_sh && speculative;
+        float4 g_rot = make_float4(0.f, 0.f, 0.f, 0.f);
+        float g_s[3] = {0.f, 0.f, 0.f}, g_op = 0.f;
+        if (spec_sh) {
+            float4 shreg[12];
+            wave_issue_sh16(shs, i0, P, lane, shreg);
+            if (in_range) {     // the geometry loads ride in the same latency window
+                mean[0] = means3D[i * 3 + 0]; mean[1] = means3D[i * 3 + 1]; mean[2] = means3D[i * 3 + 2];
+                g_op = opacities[i];
+                if (!cov3D_precomp) {
+                    g_s[0] = scales[i * 3 + 0]; g_s[1] = scales[i * 3 + 1]; g_s[2] = scales[i * 3 + 2];
+                    g_rot = reinterpret_cast<const float4*>(rotations)[i];
+                }
+            }
+            wave_commit_sh16(shreg, ~0ull, lane, tile);
+        }
         if (in_range) {
-            mean[0] = means3D[i * 3 + 0]; mean[1] = means3D[i * 3 + 1]; mean[2] = means3D[i * 3 + 2];
+            if (!spec_sh) {
+                mean[0] = means3D[i * 3 + 0]; mean[1] = means3D[i * 3 + 1]; mean[2] = means3D[i * 3 + 2];
+                g_op = opacities[i];
+            }
             float cov[6];
             if (cov3D_precomp) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) cov[k] = cov3D_precomp[i * 6 + k];
             } else {
-                const float s[3] = {scales[i * 3 + 0], scales[i * 3 + 1], scales[i * 3 + 2]};
-                const float4 q4 = reinterpret_cast<const float4*>(rotations)[i];
-                const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-                gsr_cov3d(s, cam.scale_modifier, q, cov);
+                if (!spec_sh) {
+                    g_s[0] = scales[i * 3 + 0]; g_s[1] = scales[i * 3 + 1]; g_s[2] = scales[i * 3 + 2];
+                    g_rot = reinterpret_cast<const float4*>(rotations)[i];
+                }
+                const float q[4] = {g_rot.x, g_rot.y, g_rot.z, g_rot.w};
+                gsr_cov3d(g_s, cam.scale_modifier, q, cov);
             }
-            vis = gsr_project(cam, mean, cov, opacities[i], sp);
+            vis = gsr_project(cam, mean, cov, g_op, sp);
         }
         // colours are needed only by Gaussians that touch this rank's band of tile rows (all visible ones on one GPU):
         // with the screen sharded over N GPUs each rank streams ~1/N of the SH records
@@ -209,7 +256,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             const uint64_t rows = __ballot(need_color);
             if (rows) {
                 if (SPLIT) wave_load_sh_split(dc, shs, i0, P, rows, lane, tile);
-                else wave_load_sh16(shs, i0, P, rows, lane, tile);
+                else if (!spec_sh) wave_load_sh16(shs, i0, P, rows, lane, tile);
             }
         }
         if (!in_range) continue;

@@ -147,11 +147,14 @@ __device__ __forceinline__ uint32_t block_excl_scan(const uint32_t (&v)[DPT], ui
     return wbase + incl - tsum;
 }
 
+// rect / rect_sorted (depth sort's last pass only, else NULL): the value is a Gaussian id whose tile rectangle is gathered
+// into the sorted order here -- the 8-byte random gather the scan kernel would otherwise run as a pass of its own.
 template <typename KeyT, int IPT, int BITS>
 __global__ void __launch_bounds__(RS_THREADS)
 rs_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
            KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int shift,
-           const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_total, int nblocks) {
+           const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_total, int nblocks,
+           const uint2* __restrict__ rect, uint2* __restrict__ rect_sorted) {
     constexpr int NB = 1 << BITS;
     constexpr int DPT = (NB + RS_THREADS - 1) / RS_THREADS;   // digits per thread (1 for <= 256 bins, 8 for 2048)
     __shared__ uint32_t wave_cnt[RS_WAVES][NB];
@@ -475,29 +478,29 @@ os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_
 
 template <typename KeyT, int IPT, int BITS>
 void sort_pass(KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vout, int64_t n, int shift, uint32_t* hist,
-               uint32_t* digit_total, int nblocks, hipStream_t st) {
+               uint32_t* digit_total, int nblocks, const uint2* rect, uint2* rect_sorted, hipStream_t st) {
     hipLaunchKernelGGL((rs_hist<KeyT, IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, n, shift, hist, nblocks);
     hipLaunchKernelGGL(rs_scan, dim3(1 << BITS), dim3(RS_THREADS), 0, st, hist, nblocks, digit_total);
     hipLaunchKernelGGL((rs_scatter<KeyT, IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, vin, kout, vout, n, shift, hist,
-                       digit_total, nblocks);
+                       digit_total, nblocks, rect, rect_sorted);
 }
 
 template <typename KeyT, int IPT>
 void sort_pass_bits(int bits, KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vout, int64_t n, int shift,
-                    uint32_t* hist, uint32_t* digit_total, int nblocks, hipStream_t st) {
+                    uint32_t* hist, uint32_t* digit_total, int nblocks, const uint2* rect, uint2* rect_sorted, hipStream_t st) {
     switch (bits) {
-        case 11: sort_pass<KeyT, IPT, 11>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
-        case 8: sort_pass<KeyT, IPT, 8>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
-        case 7: sort_pass<KeyT, IPT, 7>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
-        case 6: sort_pass<KeyT, IPT, 6>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
-        case 5: sort_pass<KeyT, IPT, 5>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
-        default: sort_pass<KeyT, IPT, 4>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, st); break;
+        case 11: sort_pass<KeyT, IPT, 11>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st); break;
+        case 8: sort_pass<KeyT, IPT, 8>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st); break;
+        case 7: sort_pass<KeyT, IPT, 7>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st); break;
+        case 6: sort_pass<KeyT, IPT, 6>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st); break;
+        case 5: sort_pass<KeyT, IPT, 5>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st); break;
+        default: sort_pass<KeyT, IPT, 4>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st); break;
     }
 }
 
 template <typename KeyT>
 int sort_pairs_t(KeyT* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
-                 uint32_t* digit_total, int items, hipStream_t st) {
+                 uint32_t* digit_total, int items, const uint2* rect, uint2* rect_sorted, hipStream_t st) {
     int cur = 0;
     if (n <= 0) return cur;
     const int nblocks = (int)((n + items - 1) / items);
@@ -505,18 +508,20 @@ int sort_pairs_t(KeyT* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max
     const int passes = gsr_sort_plan(nbits, max_digit_bits, pass_bits);
     int shift = 0;
     for (int p = 0; p < passes; ++p) {
+        const uint2* rc = p == passes - 1 ? rect : nullptr;          // the gather rides on the last pass only
+        uint2* rcs = p == passes - 1 ? rect_sorted : nullptr;
         if (items == 1024)
             sort_pass_bits<KeyT, 1024 / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
-                                                    digit_total, nblocks, st);
+                                                    digit_total, nblocks, rc, rcs, st);
         else if (items == 2048)
             sort_pass_bits<KeyT, 2048 / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
-                                                    digit_total, nblocks, st);
+                                                    digit_total, nblocks, rc, rcs, st);
         else if (items == 8192)
             sort_pass_bits<KeyT, 8192 / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
-                                                    digit_total, nblocks, st);
+                                                    digit_total, nblocks, rc, rcs, st);
         else
             sort_pass_bits<KeyT, 4096 / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
-                                                    digit_total, nblocks, st);
+                                                    digit_total, nblocks, rc, rcs, st);
         shift += pass_bits[p];
         cur ^= 1;
     }
@@ -575,12 +580,12 @@ int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits) {
 }
 
 int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
-                         uint32_t* digit_total, int items, hipStream_t st) {
-    return sort_pairs_t<uint32_t>(keys, vals, n, nbits, max_digit_bits, hist, digit_total, items, st);
+                         uint32_t* digit_total, int items, hipStream_t st, const uint2* rect, uint2* rect_sorted) {
+    return sort_pairs_t<uint32_t>(keys, vals, n, nbits, max_digit_bits, hist, digit_total, items, rect, rect_sorted, st);
 }
 
 // 16-bit keys (tile ids when the frame has <= 65536 tiles): 25 % less traffic per pass than 32-bit keys
 int gsr_radix_sort_pairs_k16(uint16_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
                              uint32_t* digit_total, int items, hipStream_t st) {
-    return sort_pairs_t<uint16_t>(keys, vals, n, nbits, max_digit_bits, hist, digit_total, items, st);
+    return sort_pairs_t<uint16_t>(keys, vals, n, nbits, max_digit_bits, hist, digit_total, items, nullptr, nullptr, st);
 }
