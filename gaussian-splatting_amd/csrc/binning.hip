@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256)
 splat_ingest(int P, const float4* __restrict__ records, int y0, int y1, float4* __restrict__ splats, uint2* __restrict__ rect,
              uint32_t* __restrict__ tiles, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
              uint32_t* __restrict__ sort_state) {
-    if (blockIdx.x == 0)
+    if (sort_state && blockIdx.x == 0)
         for (int i = threadIdx.x; i < GSR_OS_STATE_WORDS; i += 256) sort_state[i] = 0u;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 q0 = records[i * 4 + 0], q1 = records[i * 4 + 1], q2 = records[i * 4 + 2], q3 = records[i * 4 + 3];

@@ -271,6 +271,7 @@ int gsr_set_option(const char* name, int value) {
     }
     if (!strcmp(name, "depth_sort_mode")) {
         if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "depth_sort_mode must be 0 (three kernels per pass) or 1 (onesweep)");
+        if (value == 1 && !gsr_onesweep_available()) return fail(GSR_ERR_UNSUPPORTED, "depth_sort_mode 1 needs a -DGSR_AB_VARIANTS build");
         g_depth_sort_mode = value;
         return GSR_OK;
     }
@@ -555,7 +556,7 @@ int gsr_rasterize_from_splats(const GsrRasterSettings* settings, int P, const fl
     if (!gbase) return fail(GSR_ERR_ALLOC, "geometry buffer resize returned NULL");
     GsrGeom g = gsr_carve_geom(gbase, P);
     {   StageTimer t(GSR_STAGE_PREPROCESS, st);
-        gsr_launch_splat_ingest(P, splat_records, cam.tile_y0, cam.tile_y1, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], g.os_scratch, st);
+        gsr_launch_splat_ingest(P, splat_records, cam.tile_y0, cam.tile_y1, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], gsr_onesweep_available() ? g.os_scratch : nullptr, st);
     }
     STAGE_CHECK("splat ingest");
     return bin_and_render(settings, cam, P, g, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,

@@ -100,6 +100,7 @@ int gsr_radix_sort_pairs_k16(uint16_t* keys[2], uint32_t* vals[2], int64_t n, in
                              uint32_t* digit_total, int items, hipStream_t st);
 #define GSR_OS_STATE_WORDS 1088      // digit totals [4][256] + tickets [4] + error word (+ pad); zeroed by the key-producing kernel
 // one-kernel-per-pass depth sort (4 x 8 bits) with the rectangle gather fused into the last pass; result in vals[0]
+int gsr_onesweep_available(void);      // measurement builds (-DGSR_AB_VARIANTS) only
 size_t gsr_onesweep_scratch_bytes(int64_t n);
 void gsr_onesweep_depth_sort(uint32_t* keys[2], uint32_t* vals[2], int64_t n, uint32_t* scratch, const uint2* rect,
                              uint2* rect_sorted, uint32_t** err_word_dev, hipStream_t st);

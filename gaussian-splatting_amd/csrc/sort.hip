@@ -268,11 +268,14 @@ rs_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_i
             const uint32_t k = (uint32_t)s_key[i];
             const uint32_t pos = digit_base[(k >> shift) & (NB - 1)] + i;
             keys_out[pos] = (KeyT)k;
-            vals_out[pos] = s_val[i];
+            const uint32_t v = s_val[i];
+            vals_out[pos] = v;
+            if (rect_sorted) rect_sorted[pos] = rect[v];
         }
     }
 }
 
+#ifdef GSR_AB_VARIANTS
 // ------------------------------------------------------------------------------------------------------------------
 // "onesweep" pass for the depth sort (P keys, 8-bit digits): ONE kernel per pass instead of hist + scan + scatter.
 // Every workgroup ranks its 4096 keys locally, PUBLISHES its per-digit counts as flagged 32-bit words
@@ -284,6 +287,10 @@ rs_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_i
 // protocol cannot deadlock whatever the dispatch order or residency.  Every spin is bounded; on expiry an error word is
 // set (the host then reports an error instead of hanging).  Digit totals of all four passes come from one up-front
 // histogram kernel (digit histograms do not depend on the order of the keys).
+// MEASURED AND REJECTED (round 2, 1 M keys, bit-exact results): 31-50 us per pass against 22 us for hist + scan + scatter,
+// whether the look-back waits for 8 or 32 predecessors at a time -- the agent-scope (sc1) descriptor traffic and the
+// ticket / publish / poll chain cost more than the two kernel boundaries they replace (~1.5 us each).  Kept in the
+// measurement build only (-DGSR_AB_VARIANTS, option depth_sort_mode = 1).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int OS_IPT = 16;
 constexpr int OS_ITEMS = RS_THREADS * OS_IPT;      // 4096 keys per workgroup
@@ -476,6 +483,8 @@ os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_
     }
 }
 
+#endif  // GSR_AB_VARIANTS
+
 template <typename KeyT, int IPT, int BITS>
 void sort_pass(KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vout, int64_t n, int shift, uint32_t* hist,
                uint32_t* digit_total, int nblocks, const uint2* rect, uint2* rect_sorted, hipStream_t st) {
@@ -530,6 +539,8 @@ int sort_pairs_t(KeyT* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max
 
 }  // namespace
 
+#ifdef GSR_AB_VARIANTS
+int gsr_onesweep_available(void) { return 1; }
 size_t gsr_onesweep_scratch_bytes(int64_t n) {
     const size_t nblk = (size_t)((n + OS_ITEMS - 1) / OS_ITEMS), ngroups = (nblk + OS_GROUP - 1) / OS_GROUP;
     return (4 * nblk * 256 /*desc*/ + 4 * ngroups * 256 /*group prefixes*/ + GSR_OS_STATE_WORDS) * 4;
@@ -558,6 +569,12 @@ void gsr_onesweep_depth_sort(uint32_t* keys[2], uint32_t* vals[2], int64_t n, ui
     GSR_OS_PASS(false, true, 3, 1, 0);
 #undef GSR_OS_PASS
 }
+
+#else
+int gsr_onesweep_available(void) { return 0; }
+size_t gsr_onesweep_scratch_bytes(int64_t) { return 0; }
+void gsr_onesweep_depth_sort(uint32_t**, uint32_t**, int64_t, uint32_t*, const uint2*, uint2*, uint32_t**, hipStream_t) {}
+#endif  // GSR_AB_VARIANTS
 
 void gsr_launch_rs_scan(uint32_t* block_hist, int nblocks, int ndigits, uint32_t* digit_total, hipStream_t st) {
     hipLaunchKernelGGL(rs_scan, dim3(ndigits), dim3(RS_THREADS), 0, st, block_hist, nblocks, digit_total);
