@@ -221,7 +221,7 @@ GsrBwdScratch gsr_carve_bwd(char* base, int P, int64_t R) {
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off = gsr_align128(off + bytes); return p; };
     const size_t np = (size_t)(P > 0 ? P : 1), nr = (size_t)(R > 0 ? R : 1);
     b.splat_grads = (float*)take(np * 48);
-    b.inst_grads = (float*)take(nr * 48 * 4);
+    b.inst_grads = (float*)take(nr * 48 * GSR_BWD_SLOTS);
     b.inst_flag = (uint32_t*)take(nr * 4);
     b.bytes = off;
     return b;

@@ -158,10 +158,16 @@ void gsr_launch_reduce_instances(int P, int64_t R, const uint32_t* order, const 
                                  const float* inst_grads, const uint32_t* inst_flag, float* splat_grads, hipStream_t st);
 
 // backward scratch (caller-owned, gsr_backward_scratch_bytes): per-Gaussian record, per-instance records, maps
+// record slots per instance: one per 16x8 half tile (the measurement build's per-quadrant kernel needs four)
+#ifdef GSR_AB_VARIANTS
+#define GSR_BWD_SLOTS 4
+#else
+#define GSR_BWD_SLOTS 2
+#endif
 struct GsrBwdScratch {
     float* splat_grads;     // [P,12]
-    float* inst_grads;      // [4][R,12]  one record slot per (tile quadrant, instance), quadrant-major
-    uint32_t* inst_flag;    // [R]  byte q != 0: quadrant q of the instance has a record
+    float* inst_grads;      // [GSR_BWD_SLOTS][R,12]  one record slot per (half tile, instance), slot-major
+    uint32_t* inst_flag;    // [R]  byte q != 0: slot q of the instance has a record
     size_t bytes;
 };
 GsrBwdScratch gsr_carve_bwd(char* base, int P, int64_t R);

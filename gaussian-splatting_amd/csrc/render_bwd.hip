@@ -185,129 +185,7 @@ __device__ __forceinline__ uint32_t emission_index(const float4 q3, uint32_t tx,
 constexpr int REC_STRIDE = 3;      // float4 per staged entry (48 B: 12-word stride, 3 coprime to 16 -> per-lane ds_read_b128 is conflict-free)
 
 // ------------------------------------------------------------------------------------------------
-// default: one independent wave per 8x8 quadrant, per-(quadrant, instance) gradient records, no atomics, no barriers
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
-render_bwd_quad(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                const float4* __restrict__ splats, const float* __restrict__ final_T,
-                const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                const float* __restrict__ dL_dinvdepth, float4* __restrict__ slot_grads /*[4][R] records of 3 float4*/,
-                uint8_t* __restrict__ slot_flags /*[R][4]*/, int64_t R, unsigned long long* __restrict__ counters /*NULL unless profiling*/) {
-    __shared__ float4 s_rec[64 * REC_STRIDE];   // the batch: (x, y, a2, b2 | c2, opacity, r, g | b, 1/depth, -, -)
-    __shared__ float s_grad[64 * 12];           // this quadrant's record of every entry of the batch
-    // XCD-aware mapping as in the forward: the four quadrants of a tile get workgroup ids b, b+8, b+16, b+24 -> same XCD
-    const int b = blockIdx.x;
-    const int grp = b >> 5, r32 = b & 31;
-    const int tile_local = grp * 8 + (r32 & 7);
-    const int quad = r32 >> 3;
-    if (tile_local >= n_band_tiles) return;
-    const int tile = cam.tile_y0 * cam.gx + tile_local;
-    const int tx = tile % cam.gx, ty = tile / cam.gx;
-    const int lane = threadIdx.x;
-    const int bx0 = tx * GSR_TILE + (quad & 1) * 8, by0 = ty * GSR_TILE + (quad >> 1) * 8;
-    if (bx0 >= cam.W || by0 >= cam.H) return;
-    const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
-    const bool inside = px < cam.W && py < cam.H;
-    const float pxf = (float)px, pyf = (float)py;
-    const float x0 = (float)bx0, x1 = (float)min(bx0 + 7, cam.W - 1);
-    const float y0 = (float)by0, y1 = (float)min(by0 + 7, cam.H - 1);
-    const uint2 range = ranges[tile];
-    const int64_t pix = (int64_t)py * cam.W + px;
-    const int64_t HW = (int64_t)cam.H * cam.W;
-    const float T_final = inside ? final_T[pix] : 0.f;
-    const uint32_t last_contrib = inside ? n_contrib[pix] : 0u;
-    const float dLr = inside ? dL_dpix[pix] : 0.f;
-    const float dLg = inside ? dL_dpix[HW + pix] : 0.f;
-    const float dLb = inside ? dL_dpix[2 * HW + pix] : 0.f;
-    const float dLd = (inside && dL_dinvdepth) ? dL_dinvdepth[pix] : 0.f;
-    const float Tf_bg = -T_final * (cam.bg[0] * dLr + cam.bg[1] * dLg + cam.bg[2] * dLb);
-    uint32_t mx = last_contrib;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
-    // entries at list positions >= end contributed to no pixel of this quadrant: no record, flag byte stays 0
-    const uint32_t end = min(range.y - range.x, mx);
-    if (end == 0) return;
-
-    BwdPix s = {T_final, 0.f, 0.f, 0.f};
-    float4* s_grad4 = reinterpret_cast<float4*>(s_grad);
-    float4* slot = slot_grads + (int64_t)quad * R * 3;
-    const int nbatch = (int)((end + 63u) >> 6);
-    // software pipeline over the batches (each needs two dependent global loads, list id -> 64-byte record): ids are
-    // fetched two batches ahead, records one batch ahead; the survivor loop in between touches only LDS
-    auto load_id = [&](int bi) -> uint32_t {
-        const uint32_t e = (uint32_t)bi * 64u + (uint32_t)lane;
-        return (bi >= 0 && e < end) ? point_list[range.x + e] : 0xFFFFFFFFu;
-    };
-    uint32_t id_n = load_id(nbatch - 1);
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 n0 = zero4, n1 = zero4, n2 = zero4, n3 = zero4;
-    if (id_n != 0xFFFFFFFFu) { n0 = splats[id_n * 4 + 0]; n1 = splats[id_n * 4 + 1]; n2 = splats[id_n * 4 + 2]; n3 = splats[id_n * 4 + 3]; }
-    id_n = load_id(nbatch - 2);
-    uint32_t nsteps = 0;        // wave-uniform work counter, reported only while profiling
-    for (int bi = nbatch - 1; bi >= 0; --bi) {
-        const uint32_t base = (uint32_t)bi * 64u;
-        const uint32_t n = min(64u, end - base);
-        const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
-        if (id_n != 0xFFFFFFFFu) { n0 = splats[id_n * 4 + 0]; n1 = splats[id_n * 4 + 1]; n2 = splats[id_n * 4 + 2]; n3 = splats[id_n * 4 + 3]; }
-        id_n = load_id(bi - 2);
-        bool keep = false;
-        uint32_t k_emit = 0;
-        if ((uint32_t)lane < n) {
-            keep = !(min_q_over_box(q0.x, q0.y, q0.z, q0.w, q1.x, x0, x1, y0, y1) > q2.z);     // q2.z = tau
-            k_emit = emission_index(q3, (uint32_t)tx, (uint32_t)ty);
-            // staged entry with the log2-scaled conic: a2 = -0.5 log2(e) A, b2 = -log2(e) B, c2 = -0.5 log2(e) C
-            s_rec[lane * REC_STRIDE + 0] = make_float4(q0.x, q0.y, -0.5f * LOG2E * q0.z, -LOG2E * q0.w);
-            s_rec[lane * REC_STRIDE + 1] = make_float4(-0.5f * LOG2E * q1.x, q1.y, q1.z, q1.w);
-            s_rec[lane * REC_STRIDE + 2] = make_float4(q2.x, q2.w, 0.f, 0.f);
-        }
-        uint64_t mask = __ballot(keep);
-        nsteps += (uint32_t)__popcll(mask);
-        uint64_t touched = 0ull;
-        while (mask) {
-            const int j = 63 - __builtin_clzll(mask);
-            mask &= ~(1ull << j);
-            const uint32_t pos0 = base + (uint32_t)j;          // 0-based list position
-            const float4 r0 = s_rec[j * REC_STRIDE + 0];
-            const float4 r1 = s_rec[j * REC_STRIDE + 1];
-            const float2 r2 = *reinterpret_cast<const float2*>(&s_rec[j * REC_STRIDE + 2]);
-            float g_px, g_py, g_A, g_B, g_C, g_op, g_r, g_g, g_b, g_d;     // g_px .. g_C hold the raw moments
-            const bool active = bwd_step(s, pos0 < last_contrib, pxf, pyf, Tf_bg, dLr, dLg, dLb, dLd, r0.x, r0.y, r0.z,
-                                         r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, g_px, g_py, g_A, g_B, g_C, g_op,
-                                         g_r, g_g, g_b, g_d);
-            if (__builtin_amdgcn_ballot_w64(active) == 0ull) continue;
-            // slots in lanes 15 / 31 / 47 / 63 = first / third / second / fourth argument
-            const float v0 = reduce4(g_px, g_A, g_py, g_B);     // -> slots 0,1,2,3
-            const float v1 = reduce4(g_C, g_r, g_op, g_g);      // -> slots 4,5,6,7
-            const float v2 = reduce2(g_b, g_d);                 // -> slots 8 (lane 31), 9 (lane 63)
-            if ((lane & 15) == 15) {
-                float* o = s_grad + j * 12 + (lane >> 4);
-                o[0] = v0;
-                o[4] = v1;
-                if (lane & 16) s_grad[j * 12 + 8 + (lane >> 5)] = v2;
-            }
-            touched |= 1ull << j;
-        }
-        // flush: the touched entries' records go to this quadrant's slot of their instance (emission index) + flag byte
-        if (touched) {
-            __builtin_amdgcn_wave_barrier();
-            if ((touched >> lane) & 1ull) {
-                float4* dst = slot + (int64_t)k_emit * 3;
-                dst[0] = s_grad4[lane * 3 + 0];
-                dst[1] = s_grad4[lane * 3 + 1];
-                dst[2] = s_grad4[lane * 3 + 2];
-                slot_flags[(int64_t)k_emit * 4 + quad] = 1;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    if (counters && lane == 0) {     // [2] (quadrant, entry) pairs stepped by all 64 lanes, [3] batches of 64 entries box-tested
-        atomicAdd(counters + 2, (unsigned long long)nsteps);
-        atomicAdd(counters + 3, (unsigned long long)nbatch);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// variant 6: one wave per 16x8 HALF tile, two pixels per lane (same row, 8 columns apart).
+// default: one wave per 16x8 HALF tile, two pixels per lane (same row, 8 columns apart), no atomics, no barriers.
 // The blend backward is VALU-issue bound (SQ counters), so the lever is instructions per (pixel, entry) pair:
 //  * the two pixels of a lane share dy, c2 dy^2 and every wave-uniform operand, and their per-pixel arithmetic is written
 //    on 2-vectors that compile to v_pk_{mul,add,fma}_f32 (one instruction for both pixels);
@@ -478,6 +356,128 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
 }
 
 #ifdef GSR_AB_VARIANTS
+// ------------------------------------------------------------------------------------------------
+// A/B variant 5 (first version of round 2): one independent wave per 8x8 quadrant, per-(quadrant, instance) records
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+render_bwd_quad(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                const float4* __restrict__ splats, const float* __restrict__ final_T,
+                const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                const float* __restrict__ dL_dinvdepth, float4* __restrict__ slot_grads /*[4][R] records of 3 float4*/,
+                uint8_t* __restrict__ slot_flags /*[R][4]*/, int64_t R, unsigned long long* __restrict__ counters /*NULL unless profiling*/) {
+    __shared__ float4 s_rec[64 * REC_STRIDE];   // the batch: (x, y, a2, b2 | c2, opacity, r, g | b, 1/depth, -, -)
+    __shared__ float s_grad[64 * 12];           // this quadrant's record of every entry of the batch
+    // XCD-aware mapping as in the forward: the four quadrants of a tile get workgroup ids b, b+8, b+16, b+24 -> same XCD
+    const int b = blockIdx.x;
+    const int grp = b >> 5, r32 = b & 31;
+    const int tile_local = grp * 8 + (r32 & 7);
+    const int quad = r32 >> 3;
+    if (tile_local >= n_band_tiles) return;
+    const int tile = cam.tile_y0 * cam.gx + tile_local;
+    const int tx = tile % cam.gx, ty = tile / cam.gx;
+    const int lane = threadIdx.x;
+    const int bx0 = tx * GSR_TILE + (quad & 1) * 8, by0 = ty * GSR_TILE + (quad >> 1) * 8;
+    if (bx0 >= cam.W || by0 >= cam.H) return;
+    const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
+    const bool inside = px < cam.W && py < cam.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float x0 = (float)bx0, x1 = (float)min(bx0 + 7, cam.W - 1);
+    const float y0 = (float)by0, y1 = (float)min(by0 + 7, cam.H - 1);
+    const uint2 range = ranges[tile];
+    const int64_t pix = (int64_t)py * cam.W + px;
+    const int64_t HW = (int64_t)cam.H * cam.W;
+    const float T_final = inside ? final_T[pix] : 0.f;
+    const uint32_t last_contrib = inside ? n_contrib[pix] : 0u;
+    const float dLr = inside ? dL_dpix[pix] : 0.f;
+    const float dLg = inside ? dL_dpix[HW + pix] : 0.f;
+    const float dLb = inside ? dL_dpix[2 * HW + pix] : 0.f;
+    const float dLd = (inside && dL_dinvdepth) ? dL_dinvdepth[pix] : 0.f;
+    const float Tf_bg = -T_final * (cam.bg[0] * dLr + cam.bg[1] * dLg + cam.bg[2] * dLb);
+    uint32_t mx = last_contrib;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+    // entries at list positions >= end contributed to no pixel of this quadrant: no record, flag byte stays 0
+    const uint32_t end = min(range.y - range.x, mx);
+    if (end == 0) return;
+
+    BwdPix s = {T_final, 0.f, 0.f, 0.f};
+    float4* s_grad4 = reinterpret_cast<float4*>(s_grad);
+    float4* slot = slot_grads + (int64_t)quad * R * 3;
+    const int nbatch = (int)((end + 63u) >> 6);
+    // software pipeline over the batches (each needs two dependent global loads, list id -> 64-byte record): ids are
+    // fetched two batches ahead, records one batch ahead; the survivor loop in between touches only LDS
+    auto load_id = [&](int bi) -> uint32_t {
+        const uint32_t e = (uint32_t)bi * 64u + (uint32_t)lane;
+        return (bi >= 0 && e < end) ? point_list[range.x + e] : 0xFFFFFFFFu;
+    };
+    uint32_t id_n = load_id(nbatch - 1);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 n0 = zero4, n1 = zero4, n2 = zero4, n3 = zero4;
+    if (id_n != 0xFFFFFFFFu) { n0 = splats[id_n * 4 + 0]; n1 = splats[id_n * 4 + 1]; n2 = splats[id_n * 4 + 2]; n3 = splats[id_n * 4 + 3]; }
+    id_n = load_id(nbatch - 2);
+    uint32_t nsteps = 0;        // wave-uniform work counter, reported only while profiling
+    for (int bi = nbatch - 1; bi >= 0; --bi) {
+        const uint32_t base = (uint32_t)bi * 64u;
+        const uint32_t n = min(64u, end - base);
+        const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
+        if (id_n != 0xFFFFFFFFu) { n0 = splats[id_n * 4 + 0]; n1 = splats[id_n * 4 + 1]; n2 = splats[id_n * 4 + 2]; n3 = splats[id_n * 4 + 3]; }
+        id_n = load_id(bi - 2);
+        bool keep = false;
+        uint32_t k_emit = 0;
+        if ((uint32_t)lane < n) {
+            keep = !(min_q_over_box(q0.x, q0.y, q0.z, q0.w, q1.x, x0, x1, y0, y1) > q2.z);     // q2.z = tau
+            k_emit = emission_index(q3, (uint32_t)tx, (uint32_t)ty);
+            // staged entry with the log2-scaled conic: a2 = -0.5 log2(e) A, b2 = -log2(e) B, c2 = -0.5 log2(e) C
+            s_rec[lane * REC_STRIDE + 0] = make_float4(q0.x, q0.y, -0.5f * LOG2E * q0.z, -LOG2E * q0.w);
+            s_rec[lane * REC_STRIDE + 1] = make_float4(-0.5f * LOG2E * q1.x, q1.y, q1.z, q1.w);
+            s_rec[lane * REC_STRIDE + 2] = make_float4(q2.x, q2.w, 0.f, 0.f);
+        }
+        uint64_t mask = __ballot(keep);
+        nsteps += (uint32_t)__popcll(mask);
+        uint64_t touched = 0ull;
+        while (mask) {
+            const int j = 63 - __builtin_clzll(mask);
+            mask &= ~(1ull << j);
+            const uint32_t pos0 = base + (uint32_t)j;          // 0-based list position
+            const float4 r0 = s_rec[j * REC_STRIDE + 0];
+            const float4 r1 = s_rec[j * REC_STRIDE + 1];
+            const float2 r2 = *reinterpret_cast<const float2*>(&s_rec[j * REC_STRIDE + 2]);
+            float g_px, g_py, g_A, g_B, g_C, g_op, g_r, g_g, g_b, g_d;     // g_px .. g_C hold the raw moments
+            const bool active = bwd_step(s, pos0 < last_contrib, pxf, pyf, Tf_bg, dLr, dLg, dLb, dLd, r0.x, r0.y, r0.z,
+                                         r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, g_px, g_py, g_A, g_B, g_C, g_op,
+                                         g_r, g_g, g_b, g_d);
+            if (__builtin_amdgcn_ballot_w64(active) == 0ull) continue;
+            // slots in lanes 15 / 31 / 47 / 63 = first / third / second / fourth argument
+            const float v0 = reduce4(g_px, g_A, g_py, g_B);     // -> slots 0,1,2,3
+            const float v1 = reduce4(g_C, g_r, g_op, g_g);      // -> slots 4,5,6,7
+            const float v2 = reduce2(g_b, g_d);                 // -> slots 8 (lane 31), 9 (lane 63)
+            if ((lane & 15) == 15) {
+                float* o = s_grad + j * 12 + (lane >> 4);
+                o[0] = v0;
+                o[4] = v1;
+                if (lane & 16) s_grad[j * 12 + 8 + (lane >> 5)] = v2;
+            }
+            touched |= 1ull << j;
+        }
+        // flush: the touched entries' records go to this quadrant's slot of their instance (emission index) + flag byte
+        if (touched) {
+            __builtin_amdgcn_wave_barrier();
+            if ((touched >> lane) & 1ull) {
+                float4* dst = slot + (int64_t)k_emit * 3;
+                dst[0] = s_grad4[lane * 3 + 0];
+                dst[1] = s_grad4[lane * 3 + 1];
+                dst[2] = s_grad4[lane * 3 + 2];
+                slot_flags[(int64_t)k_emit * 4 + quad] = 1;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (counters && lane == 0) {     // [2] (quadrant, entry) pairs stepped by all 64 lanes, [3] batches of 64 entries box-tested
+        atomicAdd(counters + 2, (unsigned long long)nsteps);
+        atomicAdd(counters + 3, (unsigned long long)nbatch);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // A/B variant 4 (round 1's default): workgroup per tile, per-instance gradient records, no global atomics
 // ------------------------------------------------------------------------------------------------
@@ -672,9 +672,9 @@ bwd_reduce_instances(int P, int64_t R, const uint32_t* __restrict__ order, const
         float v[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) v[i] = 0.f;
-        // the up to four quadrant records of the instance, added in fixed order (quadrant 0, 1, 2, 3)
+        // the records of the instance (one per half tile; per quadrant in the A/B build), added in fixed slot order
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < GSR_BWD_SLOTS; ++q) {
             if ((flags >> (8 * q)) & 0xFFu) {
                 const float4* rec = stream + ((int64_t)q * R + (int64_t)r) * 3;
                 const float4 u0 = rec[0], u1 = rec[1], u2 = rec[2];
@@ -817,9 +817,9 @@ render_bwd_wave(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
 
 int gsr_render_backward_variant_available(int variant) {
 #ifdef GSR_AB_VARIANTS
-    return variant == 0 || variant == 1 || variant == 4 || variant == 6;
+    return variant == 0 || variant == 1 || variant == 4 || variant == 5;
 #else
-    return variant == 0 || variant == 6;
+    return variant == 0;
 #endif
 }
 
@@ -842,16 +842,16 @@ void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const
                            reinterpret_cast<uint8_t*>(inst_flag));
         return;
     }
-#endif
-    (void)splat_grads;
-    if (variant == 6) {
-        const int groups16 = (n_band_tiles + 15) / 16;
-        hipLaunchKernelGGL(render_bwd_half, dim3(groups16 * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list, splats,
+    if (variant == 5) {
+        hipLaunchKernelGGL(render_bwd_quad, dim3(groups * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list, splats,
                            final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads),
                            reinterpret_cast<uint8_t*>(inst_flag), R, counters);
         return;
     }
-    hipLaunchKernelGGL(render_bwd_quad, dim3(groups * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list, splats,
+#endif
+    (void)variant; (void)splat_grads; (void)groups;
+    const int groups16 = (n_band_tiles + 15) / 16;
+    hipLaunchKernelGGL(render_bwd_half, dim3(groups16 * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list, splats,
                        final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads),
                        reinterpret_cast<uint8_t*>(inst_flag), R, counters);
 }

@@ -285,10 +285,11 @@ def _backward_case(name, n, colors_cov=False, use_depth=True, seed=0):
         assert b.abs().max().item() > 0, f"{k}: oracle gradient is identically zero"
 
 
-@pytest.mark.parametrize("bwd_variant", [0, 1, 4])
+@pytest.mark.parametrize("bwd_variant", [0, 1, 4, 5])
 def test_backward_parity_sh_scale_rot(bwd_variant):
     from diff_gaussian_rasterization import _lib
-    # 0: independent quadrant waves (default); A/B builds only: 1 = global atomics, 4 = round 1's workgroup-per-tile kernel
+    # 0: wave per 16x8 half tile, two pixels per lane (default); A/B builds only: 1 = global atomics, 4 = round 1's
+    # workgroup-per-tile kernel, 5 = wave per 8x8 quadrant
     _set_variant("render_bwd_variant", bwd_variant)
     try:
         _backward_case("c1", 1000)
@@ -320,7 +321,7 @@ def test_backward_is_bit_reproducible_and_variants_agree():
     a, b = grads(0), grads(0)
     for x, y in zip(a, b):
         assert torch.equal(x, y), "default backward is not bit-reproducible"
-    for variant, tol in ((1, 2e-4), (4, 5e-5)):
+    for variant, tol in ((1, 2e-4), (4, 5e-5), (5, 5e-5)):
         try:
             c = grads(variant)
         except _lib.GsrError:
