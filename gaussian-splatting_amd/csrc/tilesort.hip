@@ -144,30 +144,43 @@ __device__ __forceinline__ void generate_instances(uint32_t R, int gx, const uin
     }
 }
 
-// level 1 histogram: hist[d * nblk + block] = instances of the block whose tile id >> lb == d
+// level 1 histogram: hist[d * nblk + block] = instances of the block whose tile id >> lb == d.
+// Counted per rectangle ROW, not per instance: the part of a Gaussian's instance run that falls into the block is a
+// partial first row, whole rows and a partial last row of its rectangle; every row is a run of consecutive tile ids that
+// is cut at the bucket boundaries (usually not at all) and added with one LDS atomic per piece -- ~3.6x fewer items than
+// instances on the bench frame and no owner expansion (the instance-wise version spent 23 us, all VALU).
 __global__ void __launch_bounds__(WG_THREADS)
 emit_hist(uint32_t R, int gx, int lb, int nb1, const uint2* __restrict__ block_first, const uint32_t* __restrict__ offsets,
           const uint2* __restrict__ rect_sorted, uint32_t* __restrict__ hist, int nblk) {
-    __shared__ __attribute__((aligned(16))) uint16_t s_own[TS_ITEMS];
-    __shared__ uint4 s_g4[TS_NGCAP];
-    __shared__ uint32_t wsum[WG_WAVES];
     __shared__ uint32_t h[TS_MAXBINS];
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (tid < nb1) h[tid] = 0;        // (the barriers inside generate_instances order this before the adds)
-    uint32_t tile[TS_IPT], unused_id[TS_IPT], vmask;
-    generate_instances<false>(R, gx, block_first, offsets, rect_sorted, nullptr, s_own, s_g4, wsum, nullptr, tile, unused_id, vmask);
-    // consecutive slots are consecutive tiles of one rectangle row: they share the bucket, so equal-bucket RUNS are
-    // added with one LDS atomic at the run head instead of one per instance
-#pragma unroll
-    for (int r = 0; r < TS_IPT; ++r) {
-        const bool valid = (vmask >> r) & 1u;
-        const uint32_t d = valid ? (tile[r] >> lb) : 0xFFFFFFFFu;
-        const uint32_t prev = (uint32_t)__shfl_up((int)d, 1, 64);
-        const bool head = lane == 0 || prev != d;
-        const uint64_t hm = __ballot(head);
-        const uint64_t above = lane == 63 ? 0ull : (hm >> (lane + 1)) << (lane + 1);
-        const int next = above ? __builtin_ctzll(above) : 64;
-        if (head && valid) atomicAdd(&h[d], (uint32_t)(next - lane));
+    const int tid = threadIdx.x;
+    if (tid < nb1) h[tid] = 0;
+    const uint32_t b = blockIdx.x;
+    const uint2 d0 = block_first[b];
+    const uint32_t j_lo = d0.x, base_excl = d0.y, j_hi = block_first[b + 1].x;
+    const int nG = (int)(j_hi - j_lo) + 1;
+    const uint32_t b0 = b * (uint32_t)TS_ITEMS;
+    const uint32_t b1 = R - b0 < (uint32_t)TS_ITEMS ? R : b0 + (uint32_t)TS_ITEMS;
+    __syncthreads();
+    for (int i = tid; i < nG; i += WG_THREADS) {
+        const uint32_t excl = i ? offsets[j_lo + i - 1] : base_excl, incl = offsets[j_lo + i];
+        const uint2 rc = rect_sorted[j_lo + i];
+        const uint32_t minx = rc.x & 0xFFFFu, wd = (rc.x >> 16) - minx, miny = rc.y & 0xFFFFu;
+        const uint32_t lo = excl > b0 ? excl : b0, hi = incl < b1 ? incl : b1;
+        if (hi <= lo || wd == 0u) continue;
+        const uint32_t ka = lo - excl, kb = hi - excl;          // the Gaussian's local instances [ka, kb) lie in this block
+        uint32_t xa, xl;
+        const uint32_t ra = div_small(ka, wd, xa), rb = div_small(kb - 1u, wd, xl);
+        for (uint32_t r = ra; r <= rb; ++r) {
+            const uint32_t x0 = r == ra ? xa : 0u, x1 = r == rb ? xl + 1u : wd;
+            uint32_t t0 = (miny + r) * (uint32_t)gx + minx + x0;
+            const uint32_t t1 = t0 + (x1 - x0);
+            while (t0 < t1) {                                   // cut the row at bucket boundaries
+                const uint32_t d = t0 >> lb, tend = min(t1, (d + 1u) << lb);
+                atomicAdd(&h[d], tend - t0);
+                t0 = tend;
+            }
+        }
     }
     __syncthreads();
     if (tid < nb1) hist[(int64_t)tid * nblk + blockIdx.x] = h[tid];

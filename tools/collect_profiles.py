@@ -44,6 +44,26 @@ for d in ("prof_fetch", "prof_write"):
                 a = agg[short(r["Kernel_Name"])][c]
                 a[0] += 1
                 a[1] += float(r["Counter_Value"])
+# SQ counters (two passes of tools/gpu_profile.sh): per-kernel means per launch
+sq = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+for d in ("prof_sq", "prof_sq2"):
+    for fcsv in glob.glob(os.path.join(G, d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(fcsv)):
+            a = sq[short(r["Kernel_Name"])][r["Counter_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+SQ_NAMES = ['SQ_WAVES', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM_RD', 'SQ_INSTS_VMEM_WR', 'SQ_WAVE_CYCLES',
+            'SQ_BUSY_CYCLES', 'SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_SCA', 'SQ_ACTIVE_INST_LDS', 'SQ_WAIT_ANY',
+            'SQ_WAIT_INST_ANY', 'SQ_LDS_BANK_CONFLICT']
+if sq:
+    with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_sq_per_kernel.csv"), "w") as f:
+        f.write("kernel," + ",".join(SQ_NAMES) + "\n")
+        key = lambda k: -sq[k].get('SQ_WAVE_CYCLES', [1, 0])[1] / max(1, sq[k].get('SQ_WAVE_CYCLES', [1, 0])[0])
+        for k in sorted(sq, key=key):
+            if k.startswith("at::") or k.startswith("__amd"):
+                continue
+            f.write('"' + k + '",' + ",".join(f"{sq[k][n][1] / sq[k][n][0]:.0f}" if n in sq[k] else "" for n in SQ_NAMES) + "\n")
+
 kern = {}
 for k, v in agg.items():
     if k.startswith("at::") or k.startswith("__amd") or not v["FETCH_SIZE"][0] or not v["WRITE_SIZE"][0]:
@@ -53,6 +73,9 @@ for k, v in agg.items():
     kern[k] = {"FETCH_SIZE_KB_per_launch": round(fk, 1), "launches_FETCH_SIZE": v["FETCH_SIZE"][0],
                "WRITE_SIZE_KB_per_launch": round(wk, 1), "launches_WRITE_SIZE": v["WRITE_SIZE"][0],
                "hbm_bytes_corrected": int((2 * fk + wk) * 1024)}
+    for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
+        if k in sq and n in sq[k]:
+            kern[k][n] = int(sq[k][n][1] / sq[k][n][0])
 out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --steps 10 --warmup 2 "
                  "--train-steps 5; correction per MI355X_MICROARCH.md HBM section: bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                  "(FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950; gather-heavy kernels are over-corrected by up "
@@ -64,6 +87,6 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_per_kernel.csv"), "w") as f
     for k in sorted(kern, key=lambda k: -kern[k]["hbm_bytes_corrected"]):
         f.write(f"\"{k}\",{kern[k]['FETCH_SIZE_KB_per_launch']},{kern[k]['WRITE_SIZE_KB_per_launch']},{kern[k]['hbm_bytes_corrected']}\n")
 print("bench:", json.loads(line)["value"], "Mpix/s;", len(rows), "kernels in stats;", len(kern), "kernels with PMC")
-for k in ("render_fwd_wave_bf<true, 1, false>", "render_fwd_wave_bf<true, 1, true>", "render_bwd_tile<256, 0>", "preprocess_fwd_kernel<false>", "adam_kernel"):
+for k in ("render_fwd_wave_bf<true, 1, false>", "render_fwd_wave_bf<true, 1, true>", "render_bwd_half", "preprocess_fwd_kernel<false>", "adam_kernel"):
     if k in kern:
         print(" ", k, kern[k]["hbm_bytes_corrected"] / 1e6, "MB/launch")
