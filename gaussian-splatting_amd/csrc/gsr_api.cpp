@@ -636,8 +636,9 @@ int gsr_backward_preprocess(const GsrRasterSettings* settings, int P, int M, con
     if (P == 0) return GSR_OK;
     (void)geom_buffer;      // the colour clamp bits are recomputed; a NULL geometry buffer is accepted (Gaussian-sharded backward)
     if (!radii || !splat_grads) return fail(GSR_ERR_INVALID_ARG, "radii / splat_grads are NULL");
-    if (!dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D)
-        return fail(GSR_ERR_INVALID_ARG, "gradient outputs are NULL");
+    if (!dL_dmeans2D || !dL_dopacity || !dL_dmeans3D) return fail(GSR_ERR_INVALID_ARG, "gradient outputs are NULL");
+    if (colors_precomp && !dL_dcolors) return fail(GSR_ERR_INVALID_ARG, "dL_dcolors is NULL");
+    if (cov3D_precomp && !dL_dcov3D) return fail(GSR_ERR_INVALID_ARG, "dL_dcov3D is NULL");
     if (shs && !dL_dsh) return fail(GSR_ERR_INVALID_ARG, "dL_dsh is NULL");
     if (settings->sh_dc && ((((uintptr_t)dL_dsh) | ((uintptr_t)settings->dL_dsh_dc)) & 15))
         return fail(GSR_ERR_UNSUPPORTED, "split SH form needs 16-byte aligned dL_dsh / dL_dsh_dc");

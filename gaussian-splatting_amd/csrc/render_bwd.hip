@@ -650,38 +650,64 @@ bwd_reduce_instances(int P, int64_t R, const uint32_t* __restrict__ order, const
         for (int i = 0; i < 12; ++i) acc[lane * 12 + i] = 0.f;
     }
     const float4* stream = slot_grads + (int64_t)base * 3;
-    // the flag word of the wave's NEXT chunk is requested before the current chunk's records: the walk is a chain of
-    // dependent loads (flag -> record) and this takes one of the two latencies off every step
-    const uint32_t first = (uint32_t)wv * 64u + (uint32_t)lane;
-    uint32_t flag_next = first < total ? inst_flag[(int64_t)base + first] : 0u;
-    for (uint32_t c0 = (uint32_t)wv * 64u; c0 < total; c0 += RED_WAVES * 64u) {
+    // The walk is a chain of dependent loads (offsets -> flag words -> records) over only a few chunks per wave, i.e. pure
+    // memory latency.  Two-deep software pipeline: while chunk c is reduced, the records of chunk c+1 (whose flag words
+    // arrived one trip earlier) and the flag words of chunk c+2 are already in flight.
+    constexpr uint32_t STEP = RED_WAVES * 64u;
+    auto load_flags = [&](uint32_t c0) -> uint32_t {
+        const uint32_t r = c0 + (uint32_t)lane;
+        return (c0 < total && r < total) ? inst_flag[(int64_t)base + r] : 0u;
+    };
+    auto load_recs = [&](uint32_t c0, uint32_t flags, float4 (&u)[GSR_BWD_SLOTS][3]) {
+        const uint32_t r = c0 + (uint32_t)lane;
+#pragma unroll
+        for (int q = 0; q < GSR_BWD_SLOTS; ++q) {
+            if ((flags >> (8 * q)) & 0xFFu) {
+                const float4* rec = stream + ((int64_t)q * R + (int64_t)r) * 3;
+                u[q][0] = rec[0]; u[q][1] = rec[1]; u[q][2] = rec[2];
+            } else {
+                u[q][0] = u[q][1] = u[q][2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    const uint32_t cfirst = (uint32_t)wv * 64u;
+    uint32_t flags_cur = load_flags(cfirst);
+    uint32_t flags_nxt = load_flags(cfirst + STEP);
+    float4 rec_cur[GSR_BWD_SLOTS][3], rec_nxt[GSR_BWD_SLOTS][3];
+    load_recs(cfirst, flags_cur, rec_cur);
+    for (uint32_t c0 = cfirst; c0 < total; c0 += STEP) {
         const uint32_t r = c0 + lane;
         const bool valid = r < total;
-        const uint32_t flags = valid ? flag_next : 0u;
+        const uint32_t flags = flags_cur;
         const bool has_rec = flags != 0u;                 // untouched instances have no record
-        flag_next = (r + RED_WAVES * 64u) < total ? inst_flag[(int64_t)base + r + RED_WAVES * 64u] : 0u;
+        load_recs(c0 + STEP, flags_nxt, rec_nxt);
+        const uint32_t flags_nn = load_flags(c0 + 2 * STEP);
+        float v[10];
+        // the records of the instance (one per half tile; per quadrant in the A/B build), added in fixed slot order
+        {
+            float4 a0 = rec_cur[0][0], a1 = rec_cur[0][1], a2 = rec_cur[0][2];
+#pragma unroll
+            for (int q = 1; q < GSR_BWD_SLOTS; ++q) {
+                a0.x += rec_cur[q][0].x; a0.y += rec_cur[q][0].y; a0.z += rec_cur[q][0].z; a0.w += rec_cur[q][0].w;
+                a1.x += rec_cur[q][1].x; a1.y += rec_cur[q][1].y; a1.z += rec_cur[q][1].z; a1.w += rec_cur[q][1].w;
+                a2.x += rec_cur[q][2].x; a2.y += rec_cur[q][2].y;
+            }
+            v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+            v[8] = a2.x; v[9] = a2.y;
+        }
+        flags_cur = flags_nxt;
+        flags_nxt = flags_nn;
+#pragma unroll
+        for (int q = 0; q < GSR_BWD_SLOTS; ++q) { rec_cur[q][0] = rec_nxt[q][0]; rec_cur[q][1] = rec_nxt[q][1]; rec_cur[q][2] = rec_nxt[q][2]; }
         if (__ballot(has_rec) == 0ull) continue;     // e.g. far Gaussians that every pixel terminated in front of
         int lo = 0, hi = last;
 #pragma unroll
         for (int it = 0; it < 6; ++it) {
             const int mid = (lo + hi) >> 1;
-            const uint32_t v = __shfl(incl, mid, 64);
-            if (v > r) hi = mid; else lo = mid + 1;
+            const uint32_t vv = __shfl(incl, mid, 64);
+            if (vv > r) hi = mid; else lo = mid + 1;
         }
         const int s = valid ? (lo > last ? last : lo) : 64 + lane;     // invalid lanes never merge
-        float v[10];
-#pragma unroll
-        for (int i = 0; i < 10; ++i) v[i] = 0.f;
-        // the records of the instance (one per half tile; per quadrant in the A/B build), added in fixed slot order
-#pragma unroll
-        for (int q = 0; q < GSR_BWD_SLOTS; ++q) {
-            if ((flags >> (8 * q)) & 0xFFu) {
-                const float4* rec = stream + ((int64_t)q * R + (int64_t)r) * 3;
-                const float4 u0 = rec[0], u1 = rec[1], u2 = rec[2];
-                v[0] += u0.x; v[1] += u0.y; v[2] += u0.z; v[3] += u0.w; v[4] += u1.x; v[5] += u1.y; v[6] += u1.z; v[7] += u1.w;
-                v[8] += u2.x; v[9] += u2.y;
-            }
-        }
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const int s_up = __shfl_up(s, off, 64);

@@ -190,7 +190,7 @@ emit_hist(uint32_t R, int gx, int lb, int nb1, const uint2* __restrict__ block_f
 // the items in workgroup-local sorted order (s_word / s_dig) and the global base of every digit (digit_base, already
 // offset so that global position = digit_base[d] + local index).  ranks: wave64 ballot matching, no atomics.
 template <typename WordT>
-__device__ __forceinline__ void local_stable_sort(const WordT (&word)[TS_IPT], const uint32_t (&digit)[TS_IPT], uint32_t vmask,
+__device__ __forceinline__ void local_stable_sort(const WordT (&word)[TS_IPT], uint32_t (&digit)[TS_IPT] /*clobbered*/, uint32_t vmask,
                                                   int bits, int nbins, uint32_t my_digit_base /*thread d: global base of digit d*/,
                                                   uint32_t (*wave_cnt)[TS_MAXBINS], uint32_t* digit_base, uint32_t* wsum,
                                                   WordT* s_word, uint8_t* s_dig) {
@@ -201,7 +201,6 @@ __device__ __forceinline__ void local_stable_sort(const WordT (&word)[TS_IPT], c
         for (int k = 0; k < WG_WAVES; ++k) wave_cnt[k][tid] = 0;
     }
     __syncthreads();
-    uint32_t rank[TS_IPT];
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int r = 0; r < TS_IPT; ++r) {
@@ -209,7 +208,8 @@ __device__ __forceinline__ void local_stable_sort(const WordT (&word)[TS_IPT], c
         const uint32_t d = digit[r];
         const uint64_t mask = match_digit(d, bits, __ballot(valid));
         const uint32_t prior = valid ? wave_cnt[w][d] : 0u;
-        rank[r] = prior + (uint32_t)__popcll(mask & lt_mask);
+        // the item's rank among the wave's items of its digit rides in the upper half of the digit word (rank < 4096)
+        digit[r] = d | ((prior + (uint32_t)__popcll(mask & lt_mask)) << 16);
         if (valid && (mask & lt_mask) == 0ull) wave_cnt[w][d] = prior + (uint32_t)__popcll(mask);
         __builtin_amdgcn_wave_barrier();
     }
@@ -236,9 +236,10 @@ __device__ __forceinline__ void local_stable_sort(const WordT (&word)[TS_IPT], c
 #pragma unroll
     for (int r = 0; r < TS_IPT; ++r) {
         if ((vmask >> r) & 1u) {
-            const uint32_t lp = wave_cnt[w][digit[r]] + rank[r];
+            const uint32_t d = digit[r] & 0xFFFFu;
+            const uint32_t lp = wave_cnt[w][d] + (digit[r] >> 16);
             s_word[lp] = word[r];
-            s_dig[lp] = (uint8_t)digit[r];
+            s_dig[lp] = (uint8_t)d;
         }
     }
     __syncthreads();

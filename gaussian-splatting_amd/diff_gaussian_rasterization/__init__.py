@@ -232,10 +232,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         M = ctx.M
         f = dict(dtype=torch.float32, device=device)
         dL_dmeans2D = torch.empty(P, 3, **f)
-        dL_dcolors = torch.empty(P, 3, **f)
+        dL_dcolors = torch.empty(P, 3, **f) if has_col else None      # intermediates of the kernel unless they are inputs' grads
         dL_dopacity = torch.empty(P, 1, **f)
         dL_dmeans3D = torch.empty(P, 3, **f)
-        dL_dcov3D = torch.empty(P, 6, **f)
+        dL_dcov3D = torch.empty(P, 6, **f) if has_cov else None
         has_dc = ctx.has_dc
         dL_dsh = torch.empty(P, M - 1 if has_dc else M, 3, **f) if has_sh else None
         dL_ddc = torch.empty(P, 1, 3, **f) if has_dc else None

@@ -120,7 +120,8 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M,
  * Outputs (every element is overwritten -- zeros for Gaussians with radii == 0 -- so the caller may pass
  * uninitialised memory; the reference's glue allocates them with torch::zeros):
  *   dL_dmeans2D[P,3]  (x,y in NDC-scaled units = pixel gradient * (0.5 W, 0.5 H); z = 0)
- *   dL_dcolors[P,3], dL_dopacity[P], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dsh[P,M,3] (NULL if no shs),
+ *   dL_dcolors[P,3] (may be NULL unless colors_precomp was given: it is an intermediate otherwise), dL_dopacity[P],
+ *   dL_dmeans3D[P,3], dL_dcov3D[P,6] (may be NULL unless cov3D_precomp was given), dL_dsh[P,M,3] (NULL if no shs),
  *   dL_dscales[P,3], dL_drotations[P,4] (NULL if cov3D_precomp was given).
  *   bwd_scratch: caller-owned scratch of gsr_backward_scratch_bytes(P, num_rendered) bytes (per-instance
  *   gradient records, the emission-order inverse map and the per-Gaussian 2-D gradient record).
