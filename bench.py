@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--sort-items", type=int, default=0, help="keys per workgroup of the large radix passes (1024 / 2048 / 4096; 0 = library default)")
     ap.add_argument("--bwd-variant", type=int, default=None, help="render_bwd_variant (0 default, 1 atomics baseline, 2 128-entry super-batches)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="gsr_set_option(NAME, VALUE) before timing (A/B switches)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short forward measurements of configs[3] (1 M @4K) and configs[4] (6 M @1080p)")
     ap.add_argument("--views", type=int, default=32, help="training views cycled by the train legs (1 = the static camera of round 1)")
     return ap.parse_args()
 
@@ -409,6 +410,42 @@ def main():
     train_ms = train.get("ssim")
     train_ips = None if train_ms is None else 1e3 / train_ms
 
+    # ---- the other GPU configs of BASELINE.json, forward only, same sharding (short: they are not the headline metric) ----
+    #   configs[3] stand-in: 1 M Gaussians @3840x2160;  configs[4] stand-in: 6 M Gaussians @1920x1080
+    other = {}
+    if not a.no_other_configs and (P, W, H) == (1_000_000, 1920, 1080):
+        for oname, oP, oW, oH in (("configs[3] 1M@4K", 1_000_000, 3840, 2160), ("configs[4] 6M@1080p", 6_000_000, 1920, 1080)):
+            ocam = make_camera(oW, oH)
+            osc = make_scene(oP, ocam, seed=a.seed, s_med=a.s_med).to(dev)
+            ocd = ocam.to(dev)
+            ors = GaussianRasterizationSettings(oH, oW, ocam.tanfovx, ocam.tanfovy, bg, 1.0, ocd.world_view_transform,
+                                                ocd.full_proj_transform, 3, ocd.camera_center, False, False, False)
+            ogx, ogy = (oW + 15) // 16, (oH + 15) // 16
+            with torch.no_grad():
+                ov = forward_with_views(ors, osc.means3D, osc.opacities, shs=osc.shs, scales=osc.scales, rotations=osc.rotations)
+                oR = int(ov["R"])
+                orow = row_costs_from_ranges(ov["ranges"].long(), ogx, ogy, banded=False)
+                del ov
+            oplan = BandPlan.uniform(ogy, world) if (a.uniform_bands or world == 1) else BandPlan.balanced(orow, world)
+            oband = None if world == 1 else oplan.band(rank)
+
+            def ostep():
+                with torch.no_grad():
+                    color, _, _ = rasterize_gaussians(osc.means3D, None, osc.shs, None, osc.opacities, osc.scales, osc.rotations,
+                                                      None, ors, oband)
+                    if world > 1:
+                        in_flight.append(gather_strips_async(color, oplan, oH))
+                        if len(in_flight) > 1:
+                            in_flight.pop(0).wait()
+            for _ in range(5):
+                ostep()
+            osteps = max(5, min(20, a.steps))
+            odt = timed_loop(ostep, osteps, "other_" + oname)[0]
+            other[oname] = {"P": oP, "width": oW, "height": oH, "num_rendered": oR, "steps": osteps,
+                            "ms_per_frame": round(odt / osteps * 1e3, 4), "Mpix_s": round(oW * oH / (odt / osteps) / 1e6, 1)}
+            del osc
+            torch.cuda.empty_cache()
+
     # ---- CPU baseline (rank 0, N=1 only): pure-PyTorch oracle on a bounded sample of the same frame ----
     cpu_baseline = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -459,15 +496,15 @@ def main():
                 pass
             return None
 
-        def blend_roofline(kernel, ms, steps, flop_per_pair, hbm_bytes, pmc_entry, what):
+        def blend_roofline(kernel, ms, steps, flop_per_pair, hbm_bytes, pmc_entry, what, pairs_per_step=64.0):
             if not ms:
                 return None
-            flops = steps * 64.0 * flop_per_pair
+            flops = steps * pairs_per_step * flop_per_pair
             ach = flops / (ms * 1e-3) / 1e12
             gbs = hbm_bytes / (ms * 1e-3) / 1e9
             r = {"bound": "valu", "kernel": kernel, "achieved": round(ach, 3), "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
                  "frac": round(ach / FP32_VALU_PEAK_TF, 5), "kernel_ms": round(ms, 4),
-                 "evaluated_pair_steps_per_launch": int(steps * 64), "flop_per_pair": flop_per_pair,
+                 "evaluated_pair_steps_per_launch": int(steps * pairs_per_step), "flop_per_pair": flop_per_pair,
                  "counted": what,
                  "traffic": None if not pmc_entry else int(pmc_entry.get("hbm_bytes_corrected", 0)) or None,
                  "traffic_source": None if not pmc_entry else "profiles/pmc_latest.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)",
@@ -480,7 +517,8 @@ def main():
             if pmc_entry and pmc_entry.get("SQ_INSTS_VALU"):
                 lane_ops = pmc_entry["SQ_INSTS_VALU"] * 64.0 / (ms * 1e-3) / 1e12
                 r["valu_lane_ops_T_per_s"] = round(lane_ops, 2)
-                r["valu_issue_frac"] = round(lane_ops / (FP32_VALU_PEAK_TF / 2.0), 4)     # peak: one lane-op per lane and clock
+                r["valu_issue_frac_of_spec"] = round(lane_ops / (FP32_VALU_PEAK_TF / 2.0), 4)     # spec: one lane-op per lane and clock at 2.4 GHz
+                r["valu_instructions_per_launch"] = int(pmc_entry["SQ_INSTS_VALU"])
             return r
 
         roof = blend_roofline("render_fwd_wave_bf<LDS, inference>", stage_ms.get("render"), fwd_steps_per_launch, FWD_FLOP_PER_PAIR,
@@ -488,9 +526,10 @@ def main():
                               "wave-level (8x8 pixel block, list entry) pairs that survive the exact box test and are blended, counted by the kernel")
         roof_train = None
         if bwd_counters:
-            roof_train = blend_roofline("render_bwd_quad", stage_ms.get("render_bwd"), bwd_counters["bwd_steps"], BWD_FLOP_PER_PAIR,
-                                        abb["render_bwd"] * frac_rows, pmc(["render_bwd_quad"]),
-                                        "wave-level (8x8 quadrant, list entry) pairs stepped by the backward walk, counted by the kernel")
+            roof_train = blend_roofline("render_bwd_half", stage_ms.get("render_bwd"), bwd_counters["bwd_steps"], BWD_FLOP_PER_PAIR,
+                                        abb["render_bwd"] * frac_rows, pmc(["render_bwd_half"]),
+                                        "wave-level (16x8 half tile, list entry) steps of the backward walk x 128 pixels, counted by the kernel",
+                                        pairs_per_step=128.0)
         # every stage: HIP-event ms, algorithmic bytes (SURVEY 8(d) term of the stage), GB/s
         stage_tab = {}
         sbytes = {"preprocess": ab["preprocess"], "scan": ab["scan"], "emit": ab["emit"], "tile_sort": ab["tile_sort"], "render": ab["blend"],
@@ -555,6 +594,7 @@ def main():
                            "bwd_pair_steps_per_launch": None if not bwd_counters else int(bwd_counters["bwd_steps"]),
                            "bwd_batches_per_launch": None if not bwd_counters else int(bwd_counters["bwd_batches"]),
                            "listed_instance_blocks": 4 * R},
+            "other_configs_forward": other,
             "roofline": roof,
             "roofline_train": roof_train,
             "cpu_baseline": cpu_baseline,

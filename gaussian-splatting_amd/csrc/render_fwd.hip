@@ -122,12 +122,12 @@ __device__ __forceinline__ float min_q_over_box(float mx, float my, float A, flo
     if (in_x && in_y) return 0.0f;
     if (!in_x) {
         const float dx = lx > 0.0f ? lx : hx;                 // facing vertical edge
-        const float dy = fminf(hy, fmaxf(ly, -B * dx / C));   // clamped optimum along it
+        const float dy = fminf(hy, fmaxf(ly, -B * dx * __builtin_amdgcn_rcpf(C)));   // clamped optimum along it (tau carries a 0.01 margin: v_rcp_f32's ulp is harmless)
         q = fminf(q, A * dx * dx + 2.0f * B * dx * dy + C * dy * dy);
     }
     if (!in_y) {
         const float dy = ly > 0.0f ? ly : hy;
-        const float dx = fminf(hx, fmaxf(lx, -B * dy / A));
+        const float dx = fminf(hx, fmaxf(lx, -B * dy * __builtin_amdgcn_rcpf(A)));
         q = fminf(q, A * dx * dx + 2.0f * B * dx * dy + C * dy * dy);
     }
     return q;

@@ -87,17 +87,25 @@ def _sized(kind: str, device, nbytes: int) -> int:
 
 class _Buffer:
     """A growable uint8 device tensor handed to the library through a resize callback (the reference's
-    resizeFunctional lambda)."""
+    resizeFunctional lambda).  The callback closes over a one-element list, NOT over the _Buffer: a closure that referenced
+    `self` would form a reference cycle (self -> ctypes callback -> closure -> self) that only the cyclic garbage collector
+    breaks -- and it does not see device memory pressure: a 30 000-iteration training run of round 1's version accumulated
+    > 100 GB of dead scratch buffers between collections."""
 
     def __init__(self, device, kind: str = "state"):
-        self.t = torch.empty(0, dtype=torch.uint8, device=device)
+        holder = [torch.empty(0, dtype=torch.uint8, device=device)]
+        self._holder = holder
 
         def _resize(_user, nbytes):
-            if self.t.numel() < nbytes:
-                self.t = torch.empty(_sized(kind, device, nbytes), dtype=torch.uint8, device=device)
-            return self.t.data_ptr()
+            if holder[0].numel() < nbytes:
+                holder[0] = torch.empty(_sized(kind, device, nbytes), dtype=torch.uint8, device=device)
+            return holder[0].data_ptr()
 
         self.cb = RESIZE_FN(_resize)
+
+    @property
+    def t(self) -> torch.Tensor:
+        return self._holder[0]
 
 
 def _make_settings(rs: GaussianRasterizationSettings, keep: list, tile_rows, no_backward: bool = False) -> GsrRasterSettings:

@@ -70,3 +70,24 @@ def fptr(a):
 
 def np32(t):
     return None if t is None else np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
+
+
+def parity_report(key, **kw):
+    """Measured parity numbers (max errors, fragile fractions) are printed and collected into gpurun_out/parity_report.json
+    (copied to profiles/ by the builder), so that the tolerances are visible, not hidden in asserts."""
+    import json
+    print(f"[parity] {key}: " + ", ".join(f"{k}={v}" for k, v in kw.items()), flush=True)
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "parity_report.json")
+        old = {}
+        if os.path.exists(path):
+            try:
+                old = json.load(open(path))
+            except Exception:
+                old = {}
+        old[key] = kw
+        json.dump(old, open(path, "w"), indent=1, sort_keys=True)
+    except Exception:
+        pass

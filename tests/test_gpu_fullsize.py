@@ -23,31 +23,14 @@ import time
 import pytest
 import torch
 
-from helpers import O, ROOT, make_camera, make_scene, oracle_settings
+from helpers import O, ROOT, make_camera, make_scene, oracle_settings, parity_report
 
 pytestmark = pytest.mark.gpu
 
 IMG_TOL = 1e-5
-REPORT = {}
 
 
-def _report(key, **kw):
-    REPORT[key] = kw
-    print(f"[parity] {key}: " + ", ".join(f"{k}={v}" for k, v in kw.items()), flush=True)
-    try:
-        d = os.path.join(ROOT, "gpurun_out")
-        os.makedirs(d, exist_ok=True)
-        path = os.path.join(d, "parity_report.json")
-        old = {}
-        if os.path.exists(path):
-            try:
-                old = json.load(open(path))
-            except Exception:
-                old = {}
-        old.update(REPORT)
-        json.dump(old, open(path, "w"), indent=1, sort_keys=True)
-    except Exception:
-        pass
+_report = parity_report
 
 
 def _gpu_settings(s, dev, debug=False):

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import O, make_camera, look_at_camera, make_scene, make_edge_scene, oracle_settings
+from helpers import O, make_camera, look_at_camera, make_scene, make_edge_scene, oracle_settings, parity_report
 
 pytestmark = pytest.mark.gpu
 
@@ -275,14 +275,17 @@ def _backward_case(name, n, colors_cov=False, use_depth=True, seed=0):
     gloss.backward()
     torch.cuda.synchronize()
     assert torch.equal(gradii.cpu(), radii)
+    measured = {}
     for k in Lc:
         a, b = Lg[k].grad.cpu().double(), Lc[k].grad.double()
         scale = b.abs().max().item() + 1e-30
         d = (a - b).abs() / scale
+        measured[k] = f"{d.max().item():.2e}/{torch.quantile(d.flatten()[: 4_000_000], 0.999).item():.2e}"
         # discrete threshold flips (fragile pixels) may move a handful of entries; the bulk must be tight
         assert d.max().item() < 2e-3, f"{k}: max err {d.max().item():.3e} (rel. to max |grad|)"
         assert torch.quantile(d.flatten()[: 4_000_000], 0.999).item() < 1e-4, f"{k}: 99.9th pct err too large"
         assert b.abs().max().item() > 0, f"{k}: oracle gradient is identically zero"
+    parity_report(f"small scene {name}/backward (max / p99.9 of |d grad| / max |grad|)", n=int(sc.P), **measured)
 
 
 @pytest.mark.parametrize("bwd_variant", [0, 1, 4, 5])
