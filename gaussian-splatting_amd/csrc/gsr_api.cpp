@@ -33,6 +33,11 @@ int g_render_fwd_variant = 0;
 int g_render_bwd_variant = 0;
 int g_depth_sort_mode = 0;      // 0 = hist / scan / scatter per pass, 1 = one kernel per pass ("onesweep", sort.hip)
 int g_tile_sort_mode = 0;       // 0 = fused emission + two-level sort (tilesort.hip), 1 = legacy emit + LSD passes (A/B)
+int g_first_hist = 0;           // 1 = the preprocess kernel also produces the histogram of the depth sort's first pass (large P).
+                                // Measured (1 M Gaussians): the sort saves 4.3 us, the preprocess -- one workgroup per 1024
+                                // Gaussians instead of a 2048-wide grid -- loses 4.5 us: no gain, off by default.
+int g_color_overlap = 0;        // 0 = one preprocess kernel; 1 = geometry + colour kernels, same stream; 2 = colour kernel on the
+                                // library's second stream, beside the depth sort / scan / tile sort (joined in front of the blend)
 
 struct PendingEvent { int stage; hipEvent_t a, b; };
 std::mutex g_prof_mu;
@@ -148,6 +153,11 @@ constexpr int GSR_MAX_DEVICES = 64;
 struct HostWord { uint32_t* host = nullptr; uint32_t* dev = nullptr; uint32_t seq = 0; };
 thread_local HostWord g_host_word[GSR_MAX_DEVICES];
 std::atomic<int64_t> g_last_R[GSR_MAX_DEVICES];      // per device: sizes the speculative binning buffer of the next frame
+
+// Second stream (lowest priority, non-blocking) + fork / join events of the overlapped colour kernel, one set per (thread,
+// device) like the host word, so that concurrent host threads never share an event.  Not freed, for the same reason.
+struct AuxStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+thread_local AuxStream g_aux[GSR_MAX_DEVICES];
 
 #if defined(__x86_64__) || defined(__i386__)
 #define GSR_CPU_RELAX() __builtin_ia32_pause()
@@ -275,6 +285,17 @@ int gsr_set_option(const char* name, int value) {
         g_depth_sort_mode = value;
         return GSR_OK;
     }
+    if (!strcmp(name, "first_hist_in_preprocess")) {
+        if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "first_hist_in_preprocess must be 0 or 1");
+        g_first_hist = value;
+        return GSR_OK;
+    }
+    if (!strcmp(name, "color_overlap")) {
+        if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARG, "color_overlap must be 0 (fused preprocess), 1 (split, one stream) or 2 (split, colour on a second stream)");
+        if (value && !gsr_preprocess_split_available()) return fail(GSR_ERR_UNSUPPORTED, "color_overlap needs a -DGSR_AB_VARIANTS build");
+        g_color_overlap = value;
+        return GSR_OK;
+    }
     if (!strcmp(name, "tile_sort_mode")) {
         if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "tile_sort_mode must be 0 (fused) or 1 (legacy LSD)");
         g_tile_sort_mode = value;
@@ -333,7 +354,8 @@ int gsr_profile_read(float* ms_out, int32_t* count_out, int n) {
 // `g` holds the splat records, band-clamped rectangles / tile counts and the depth keys of all P Gaussians.
 static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& cam, int P, GsrGeom& g,
                           GsrResizeFn binning_resize, void* binning_user, GsrResizeFn image_resize, void* image_user,
-                          float* out_color, float* out_invdepth, int32_t* num_rendered, hipStream_t st) {
+                          float* out_color, float* out_invdepth, int32_t* num_rendered, hipStream_t st,
+                          hipEvent_t colors_done = nullptr, bool first_hist_ready = false) {
     int order_buf;
     uint32_t* sort_err = nullptr;
     const bool onesweep = g_depth_sort_mode == 1;
@@ -343,7 +365,7 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
             order_buf = 0;
         } else {
             order_buf = gsr_radix_sort_pairs(g.keys, g.vals, P, 32, GSR_DEPTH_DIGIT_BITS, g.sort_hist, g.digit_total, sort_items(P), st,
-                                             g.rect, g.rect_sorted);
+                                             g.rect, g.rect_sorted, first_hist_ready);
         }
     }
     STAGE_CHECK("depth sort");
@@ -458,6 +480,7 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     } else if (plan.fused) {
         HIP_OK(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)n_tiles, st));
     }
+    if (colors_done) HIP_OK(hipStreamWaitEvent(st, colors_done, 0));      // the blend is the first reader of the colours
     {   StageTimer t(GSR_STAGE_RENDER, st);
         gsr_launch_render_forward(cam, im.ranges, b.vals[list_buf], g.splats, settings->no_backward ? nullptr : im.final_T,
                                   settings->no_backward ? nullptr : im.n_contrib, out_color, out_invdepth,
@@ -497,12 +520,53 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
     if (!gbase) return fail(GSR_ERR_ALLOC, "geometry buffer resize returned NULL");
     GsrGeom g = gsr_carve_geom(gbase, P);
 
-    {   StageTimer t(GSR_STAGE_PREPROCESS, st);
-        gsr_launch_preprocess(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, st);
+    if (g_color_overlap == 0 || !shs) {
+        // large P: one preprocess workgroup per workgroup of the depth sort's first pass, which then needs no histogram
+        // kernel of its own (small P keeps the wider grid: a 4-deep loop per workgroup would cost more than the launch)
+        const int items = sort_items(P);
+        const bool first_hist = g_first_hist && g_depth_sort_mode == 0 && GSR_DEPTH_DIGIT_BITS == 8 && ((int64_t)P + items - 1) / items >= 512;
+        {   StageTimer t(GSR_STAGE_PREPROCESS, st);
+            gsr_launch_preprocess(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, st,
+                                  first_hist ? items : 0);
+        }
+        STAGE_CHECK("preprocess");
+        return bin_and_render(settings, cam, P, g, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
+                              num_rendered, st, nullptr, first_hist);
     }
-    STAGE_CHECK("preprocess");
-    return bin_and_render(settings, cam, P, g, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
-                          num_rendered, st);
+    // split form: the binning chain needs only the geometry; the SH evaluation runs beside it on the second stream
+    {   StageTimer t(GSR_STAGE_PREPROCESS, st);
+        gsr_launch_preprocess_geom(cam, P, means3D, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, st);
+    }
+    STAGE_CHECK("preprocess (geometry)");
+    hipEvent_t join = nullptr;
+    hipStream_t cst = st;
+    if (g_color_overlap == 2) {
+        int dev_id = 0;
+        HIP_OK(hipGetDevice(&dev_id));
+        if (dev_id < 0 || dev_id >= GSR_MAX_DEVICES) return fail(GSR_ERR_UNSUPPORTED, "device ordinal out of range");
+        AuxStream& aux = g_aux[dev_id];
+        if (!aux.s) {
+            int least = 0, greatest = 0;
+            HIP_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIP_OK(hipStreamCreateWithPriority(&aux.s, hipStreamNonBlocking, least));
+            HIP_OK(hipEventCreateWithFlags(&aux.fork, hipEventDisableTiming));
+            HIP_OK(hipEventCreateWithFlags(&aux.join, hipEventDisableTiming));
+        }
+        HIP_OK(hipEventRecord(aux.fork, st));
+        HIP_OK(hipStreamWaitEvent(aux.s, aux.fork, 0));
+        cst = aux.s;
+        join = aux.join;
+    }
+    {   StageTimer t(GSR_STAGE_COLOR, cst);
+        gsr_launch_preprocess_color(cam, P, means3D, shs, g, cst);
+    }
+    if (join) HIP_OK(hipEventRecord(join, cst));
+    if (settings->debug && cst != st) HIP_OK(hipStreamSynchronize(cst));
+    rc = bin_and_render(settings, cam, P, g, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
+                        num_rendered, st, join);
+    // an early return leaves the colour kernel un-joined: the caller may release the geometry buffer, so wait for it here
+    if (rc != GSR_OK && cst != st) (void)hipStreamSynchronize(cst);
+    return rc;
 }
 
 int gsr_preprocess_forward(const GsrRasterSettings* settings, int P, int M, const float* means3D, const float* shs,

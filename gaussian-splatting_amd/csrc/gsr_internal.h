@@ -80,7 +80,16 @@ GsrImage gsr_carve_image(char* base, int W, int H);
 void gsr_launch_preprocess(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,
                            const float* rotations, const float* cov3D_precomp, GsrGeom g, int32_t* radii,
-                           hipStream_t st);      // also zeroes the first GSR_OS_STATE_WORDS words of g.os_scratch
+                           hipStream_t st, int first_hist_items = 0);
+// (also zeroes the first GSR_OS_STATE_WORDS words of g.os_scratch in A/B builds; first_hist_items != 0: one workgroup per
+// first_hist_items Gaussians, which also leaves the histogram of the depth sort's first pass in g.sort_hist)
+// A/B builds only -- split form: geometry (everything the binning chain needs) and colour (SH -> RGB into the splat
+// records); the colour kernel may run on another stream beside the depth sort (gsr_api.cpp).  Measured and rejected.
+int gsr_preprocess_split_available(void);
+void gsr_launch_preprocess_geom(const GsrCamDev& cam, int P, const float* means3D, const float* colors_precomp, const float* opacities,
+                                const float* scales, const float* rotations, const float* cov3D_precomp, GsrGeom g, int32_t* radii,
+                                hipStream_t st);
+void gsr_launch_preprocess_color(const GsrCamDev& cam, int P, const float* means3D, const float* shs, GsrGeom g, hipStream_t st);
 void gsr_launch_preprocess_backward(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
                                     const float* colors_precomp, const float* opacities, const float* scales,
                                     const float* rotations, const float* cov3D_precomp, const int32_t* radii,
@@ -95,7 +104,8 @@ void gsr_launch_mark_visible(int P, const float* means3D, const float* view, uin
 // rect / rect_sorted (optional): the last pass also writes rect_sorted[pos] = rect[value] (depth sort: the tile rectangles
 // in depth order, which the scan and the emission stream afterwards)
 int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
-                         uint32_t* digit_total, int items, hipStream_t st, const uint2* rect = nullptr, uint2* rect_sorted = nullptr);
+                         uint32_t* digit_total, int items, hipStream_t st, const uint2* rect = nullptr, uint2* rect_sorted = nullptr,
+                         bool first_hist_ready = false);
 int gsr_radix_sort_pairs_k16(uint16_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
                              uint32_t* digit_total, int items, hipStream_t st);
 #define GSR_OS_STATE_WORDS 1088      // digit totals [4][256] + tickets [4] + error word (+ pad); zeroed by the key-producing kernel

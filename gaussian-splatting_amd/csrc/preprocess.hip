@@ -190,10 +190,17 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
                       const float* __restrict__ cov3D_precomp, float4* __restrict__ splats,
                       uint2* __restrict__ rect, uint32_t* __restrict__ tiles, uint32_t* __restrict__ clamped_out,
                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int32_t* __restrict__ radii,
-                      uint32_t* __restrict__ sort_state /*GSR_OS_STATE_WORDS words zeroed for the depth sort that follows*/) {
+                      uint32_t* __restrict__ sort_state /*GSR_OS_STATE_WORDS words zeroed for the depth sort that follows*/,
+                      uint32_t* __restrict__ first_hist, int hist_items) {
     __shared__ __attribute__((aligned(16))) float s_sh[4][64 * SH_ROW];
+    // first_hist != NULL: workgroup b owns Gaussians [b * hist_items, (b + 1) * hist_items) -- exactly the keys of workgroup
+    // b of the depth sort's first radix pass -- and leaves that pass's digit histogram (low 8 key bits) in
+    // first_hist[d * gridDim.x + b], which saves the pass its histogram kernel (a launch and a read of all keys).
+    __shared__ uint32_t s_hist[256];
+    if (first_hist) s_hist[threadIdx.x] = 0u;
     if (sort_state && blockIdx.x == 0)
         for (int i = threadIdx.x; i < GSR_OS_STATE_WORDS; i += 256) sort_state[i] = 0u;
+    if (first_hist) __syncthreads();
     GsrCam cam;
     load_cam(camd, cam);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -204,7 +211,10 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
     // 0.074 ms speculative for a quarter-frame band at 1 M Gaussians)
     const bool speculative = (cam.tile_y1 - cam.tile_y0) * 4 >= cam.gy;
     // wave-uniform trip count: every lane of a wave runs the same iterations (lanes past P idle inside)
-    for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < P; i0 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i_first = first_hist ? (int64_t)blockIdx.x * hist_items + wv * 64 : ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane;
+    const int64_t i_stride = first_hist ? 256 : (int64_t)gridDim.x * blockDim.x;
+    const int64_t i_limit = first_hist ? min((int64_t)P, ((int64_t)blockIdx.x + 1) * hist_items) : (int64_t)P;
+    for (int64_t i0 = i_first; i0 < i_limit; i0 += i_stride) {
         const int64_t i = i0 + lane;
         const bool in_range = i < P;
         GsrSplat sp;
@@ -295,10 +305,127 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         radii[i] = sp.radius;
         // depth-sort key: positive fp32 bit patterns order like the floats; Gaussians with no tile in
         // the band sort last.
+        const uint32_t key = sp.tiles ? __float_as_uint(sp.depth) : 0xFFFFFFFFu;
+        keys[i] = key;
+        vals[i] = (uint32_t)i;
+        if (first_hist) atomicAdd(&s_hist[key & 255u], 1u);
+    }
+    if (first_hist) {
+        __syncthreads();
+        first_hist[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = s_hist[threadIdx.x];
+    }
+}
+
+#ifdef GSR_AB_VARIANTS
+// ------------------------------------------------------------------------------------------------------------------
+// Split form of the forward preprocess: GEOMETRY (projection, tile rectangle, sort key, splat record without colour) and
+// COLOUR (SH -> RGB into the record).  Only the geometry is on the critical path of the binning chain: the depth sort,
+// scan and tile sort that follow need keys and rectangles, not colours, and they are latency-bound kernels that leave most
+// of the GPU idle -- so the library runs the colour kernel on a second HIP stream BESIDE them (gsr_api.cpp) and joins the
+// two streams in front of the blend.  Same arithmetic as the fused kernel, identical outputs.
+// MEASURED AND REJECTED (round 2, 1 M Gaussians @1080p, parity green in both modes): the two kernels cost 41 + 56 us against
+// 74 us fused (the colour kernel's 12-byte writes into 64-byte records are partial-line stores), and with the colour kernel
+// on the second stream the depth sort beside it slows from 95 to 133 us -- its kernels are latency-bound and lose their
+// CUs / memory queue slots to the streaming kernel -- so the frame gets 0.486 ms instead of 0.467.  Measurement build only
+// (option color_overlap = 1 / 2).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+preprocess_geom_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, const float* __restrict__ colors_precomp,
+                       const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
+                       const float* __restrict__ cov3D_precomp, float4* __restrict__ splats, uint2* __restrict__ rect,
+                       uint32_t* __restrict__ tiles, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                       int32_t* __restrict__ radii, uint32_t* __restrict__ sort_state) {
+    if (sort_state && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < GSR_OS_STATE_WORDS; i += 256) sort_state[i] = 0u;
+    GsrCam cam;
+    load_cam(camd, cam);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        GsrSplat sp;
+        sp.radius = 0; sp.tiles = 0; sp.minx = sp.miny = sp.maxx = sp.maxy = 0; sp.depth = 0.f;
+        const float mean[3] = {means3D[i * 3 + 0], means3D[i * 3 + 1], means3D[i * 3 + 2]};
+        float cov[6];
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) cov[k] = cov3D_precomp[i * 6 + k];
+        } else {
+            const float sc[3] = {scales[i * 3 + 0], scales[i * 3 + 1], scales[i * 3 + 2]};
+            const float4 q4 = reinterpret_cast<const float4*>(rotations)[i];
+            const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+            gsr_cov3d(sc, cam.scale_modifier, q, cov);
+        }
+        const bool vis = gsr_project(cam, mean, cov, opacities[i], sp);
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+        if (vis) {
+            float rgb[3] = {0.f, 0.f, 0.f};
+            if (colors_precomp && sp.tiles > 0) {
+                rgb[0] = colors_precomp[i * 3 + 0]; rgb[1] = colors_precomp[i * 3 + 1]; rgb[2] = colors_precomp[i * 3 + 2];
+            }
+            q0 = make_float4(sp.px, sp.py, sp.conA, sp.conB);
+            q1 = make_float4(sp.conC, sp.opacity, rgb[0], rgb[1]);
+            q2 = make_float4(rgb[2], sp.depth, 2.0f * logf(255.0f * sp.opacity) + 0.01f, 1.0f / sp.depth);
+        }
+        const uint2 rc = make_uint2(sp.minx | (sp.maxx << 16), sp.miny | (sp.maxy << 16));
+        splats[i * 4 + 0] = q0;
+        splats[i * 4 + 1] = q1;
+        splats[i * 4 + 2] = q2;
+        splats[i * 4 + 3] = make_float4(__uint_as_float(rc.x), __uint_as_float(rc.y), 0.f, __uint_as_float(sp.tiles));
+        rect[i] = rc;
+        tiles[i] = sp.tiles;
+        radii[i] = sp.radius;
         keys[i] = sp.tiles ? __float_as_uint(sp.depth) : 0xFFFFFFFFu;
         vals[i] = (uint32_t)i;
     }
 }
+
+// colours of the Gaussians that touch this rank's band (tiles > 0), written into the records the geometry kernel made
+template <bool SPLIT>
+__global__ void __launch_bounds__(256)
+preprocess_color_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
+                        const uint32_t* __restrict__ tiles, float4* __restrict__ splats) {
+    __shared__ __attribute__((aligned(16))) float s_sh[4][64 * SH_ROW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* tile = s_sh[wv];
+    const float* dc = SPLIT ? camd.sh_dc : nullptr;
+    const int M = camd.M, deg = camd.sh_degree;
+    const bool staged_sh = M == 16;
+    const bool speculative = (camd.tile_y1 - camd.tile_y0) * 4 >= camd.gy;
+    const float campos[3] = {camd.campos[0], camd.campos[1], camd.campos[2]};
+    for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < P; i0 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = i0 + lane;
+        const bool in_range = i < P;
+        const bool spec_sh = staged_sh && speculative;
+        float4 shreg[12];
+        if (spec_sh && !SPLIT) wave_issue_sh16(shs, i0, P, lane, shreg);
+        float mean[3] = {0.f, 0.f, 0.f};
+        bool need = false;
+        if (in_range) {
+            need = tiles[i] > 0u;
+            mean[0] = means3D[i * 3 + 0]; mean[1] = means3D[i * 3 + 1]; mean[2] = means3D[i * 3 + 2];
+        }
+        if (staged_sh) {
+            if (spec_sh) {
+                if (SPLIT) wave_load_sh_split(dc, shs, i0, P, ~0ull, lane, tile);
+                else wave_commit_sh16(shreg, ~0ull, lane, tile);
+            } else {
+                const uint64_t rows = __ballot(need);
+                if (rows) {
+                    if (SPLIT) wave_load_sh_split(dc, shs, i0, P, rows, lane, tile);
+                    else wave_load_sh16(shs, i0, P, rows, lane, tile);
+                }
+            }
+        }
+        if (!need) continue;
+        float rgb[3] = {0.f, 0.f, 0.f};
+        uint32_t clampbits = 0;
+        if (staged_sh) gsr_sh_to_rgb(deg, 16, tile + lane * SH_ROW, mean, campos, rgb, clampbits);
+        else if (!SPLIT) gsr_sh_to_rgb(deg, M, shs + i * (int64_t)M * 3, mean, campos, rgb, clampbits);
+        float* rec = reinterpret_cast<float*>(splats + i * 4);
+        *reinterpret_cast<float2*>(rec + 6) = make_float2(rgb[0], rgb[1]);      // q1.zw
+        rec[8] = rgb[2];                                                        // q2.x
+    }
+}
+
+#endif  // GSR_AB_VARIANTS
 
 template <bool SPLIT>
 __global__ void __launch_bounds__(256)
@@ -433,18 +560,45 @@ inline int stream_grid(int64_t n) {
 void gsr_launch_preprocess(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,
                            const float* rotations, const float* cov3D_precomp, GsrGeom g, int32_t* radii,
-                           hipStream_t st) {
+                           hipStream_t st, int first_hist_items) {
+    // first_hist_items != 0: one workgroup per workgroup of the depth sort's first pass (see the kernel)
+    const int grid = first_hist_items ? (int)(((int64_t)P + first_hist_items - 1) / first_hist_items) : stream_grid(P);
+    uint32_t* first_hist = first_hist_items ? g.sort_hist : nullptr;
     if (cam.sh_dc)
-        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs,
+        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(grid), dim3(256), 0, st, cam, P, means3D, shs,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, g.splats, g.rect, g.tiles,
                            /*clamped (recomputed by the backward)*/ nullptr, g.keys[0], g.vals[0], radii,
-                           gsr_onesweep_available() ? g.os_scratch : nullptr);
+                           gsr_onesweep_available() ? g.os_scratch : nullptr, first_hist, first_hist_items);
     else
-        hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs,
+        hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(grid), dim3(256), 0, st, cam, P, means3D, shs,
                            colors_precomp, opacities, scales, rotations, cov3D_precomp, g.splats, g.rect, g.tiles,
                            /*clamped (recomputed by the backward)*/ nullptr, g.keys[0], g.vals[0], radii,
-                           gsr_onesweep_available() ? g.os_scratch : nullptr);
+                           gsr_onesweep_available() ? g.os_scratch : nullptr, first_hist, first_hist_items);
 }
+
+#ifdef GSR_AB_VARIANTS
+int gsr_preprocess_split_available(void) { return 1; }
+void gsr_launch_preprocess_geom(const GsrCamDev& cam, int P, const float* means3D, const float* colors_precomp, const float* opacities,
+                                const float* scales, const float* rotations, const float* cov3D_precomp, GsrGeom g, int32_t* radii,
+                                hipStream_t st) {
+    hipLaunchKernelGGL(preprocess_geom_kernel, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, colors_precomp, opacities, scales,
+                       rotations, cov3D_precomp, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], radii,
+                       gsr_onesweep_available() ? g.os_scratch : nullptr);
+}
+
+void gsr_launch_preprocess_color(const GsrCamDev& cam, int P, const float* means3D, const float* shs, GsrGeom g, hipStream_t st) {
+    if (cam.sh_dc)
+        hipLaunchKernelGGL(preprocess_color_kernel<true>, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs, g.tiles, g.splats);
+    else
+        hipLaunchKernelGGL(preprocess_color_kernel<false>, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs, g.tiles, g.splats);
+}
+
+#else
+int gsr_preprocess_split_available(void) { return 0; }
+void gsr_launch_preprocess_geom(const GsrCamDev&, int, const float*, const float*, const float*, const float*, const float*, const float*,
+                                GsrGeom, int32_t*, hipStream_t) {}
+void gsr_launch_preprocess_color(const GsrCamDev&, int, const float*, const float*, GsrGeom, hipStream_t) {}
+#endif  // GSR_AB_VARIANTS
 
 void gsr_launch_preprocess_backward(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
                                     const float* colors_precomp, const float* opacities, const float* scales,

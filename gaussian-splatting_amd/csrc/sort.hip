@@ -110,9 +110,22 @@ rs_scan(uint32_t* __restrict__ block_hist, int nblocks, uint32_t* __restrict__ d
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int chunk = (nblocks + RS_THREADS - 1) / RS_THREADS;
     const int lo = min(tid * chunk, nblocks), hi = min(lo + chunk, nblocks);
+    // rows of up to 4096 workgroups (the depth sort of <= 4 M Gaussians, 16 M instances at 4096 per workgroup) stay in
+    // registers between the two sweeps: ONE round of loads instead of two (each round is a ~1 us trip, the counts were
+    // just written by other CUs)
+    constexpr int KEEP = 16;
+    const bool keep = chunk <= KEEP;
+    uint32_t v[KEEP];
     uint32_t sum = 0;
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) v[k] = (lo + k < hi) ? row[lo + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) sum += v[k];
+    } else {
 #pragma unroll 4
-    for (int i = lo; i < hi; ++i) sum += row[i];
+        for (int i = lo; i < hi; ++i) sum += row[i];
+    }
     const uint32_t incl = wave_incl_scan_u32(sum, lane);
     if (lane == 63) wsum[w] = incl;
     __syncthreads();
@@ -121,11 +134,19 @@ rs_scan(uint32_t* __restrict__ block_hist, int nblocks, uint32_t* __restrict__ d
     for (int k = 0; k < RS_WAVES; ++k)
         if (k < w) run += wsum[k];
     if (tid == RS_THREADS - 1) digit_total[blockIdx.x] = run + sum;
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            if (lo + k < hi) row[lo + k] = run;
+            run += v[k];
+        }
+    } else {
 #pragma unroll 4
-    for (int i = lo; i < hi; ++i) {
-        const uint32_t v = row[i];
-        row[i] = run;
-        run += v;
+        for (int i = lo; i < hi; ++i) {
+            const uint32_t t = row[i];
+            row[i] = run;
+            run += t;
+        }
     }
 }
 
@@ -164,6 +185,17 @@ rs_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_i
     __shared__ uint32_t s_val[RS_THREADS * IPT];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 
+    // the workgroup's items are requested first: their trip overlaps the digit-base prologue (loads + two barriers) below
+    const int64_t wave_base = (int64_t)blockIdx.x * (RS_THREADS * IPT) + (int64_t)w * (64 * IPT);
+    uint32_t key[IPT], val[IPT], rank[IPT];
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+        const int64_t idx = wave_base + r * 64 + lane;
+        const bool valid = idx < n;
+        key[r] = valid ? (uint32_t)keys_in[idx] : 0u;
+        val[r] = valid ? vals_in[idx] : 0u;
+    }
+
     // digit_base[d] = (exclusive scan of digit totals)[d] + (keys with digit d in earlier workgroups)
     {
         uint32_t v[DPT];
@@ -186,16 +218,7 @@ rs_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_i
     }
     __syncthreads();
 
-    const int64_t wave_base = (int64_t)blockIdx.x * (RS_THREADS * IPT) + (int64_t)w * (64 * IPT);
-    uint32_t key[IPT], val[IPT], rank[IPT];
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int r = 0; r < IPT; ++r) {
-        const int64_t idx = wave_base + r * 64 + lane;
-        const bool valid = idx < n;
-        key[r] = valid ? (uint32_t)keys_in[idx] : 0u;
-        val[r] = valid ? vals_in[idx] : 0u;
-    }
 #pragma unroll
     for (int r = 0; r < IPT; ++r) {
         const int64_t idx = wave_base + r * 64 + lane;
@@ -487,8 +510,9 @@ os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_
 
 template <typename KeyT, int IPT, int BITS>
 void sort_pass(KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vout, int64_t n, int shift, uint32_t* hist,
-               uint32_t* digit_total, int nblocks, const uint2* rect, uint2* rect_sorted, hipStream_t st) {
-    hipLaunchKernelGGL((rs_hist<KeyT, IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, n, shift, hist, nblocks);
+               uint32_t* digit_total, int nblocks, const uint2* rect, uint2* rect_sorted, hipStream_t st, bool hist_ready = false) {
+    if (!hist_ready)      // (the producer of the keys may already have left this pass's histogram in `hist`)
+        hipLaunchKernelGGL((rs_hist<KeyT, IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, n, shift, hist, nblocks);
     hipLaunchKernelGGL(rs_scan, dim3(1 << BITS), dim3(RS_THREADS), 0, st, hist, nblocks, digit_total);
     hipLaunchKernelGGL((rs_scatter<KeyT, IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, vin, kout, vout, n, shift, hist,
                        digit_total, nblocks, rect, rect_sorted);
@@ -496,7 +520,12 @@ void sort_pass(KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vout, int64_t n, 
 
 template <typename KeyT, int IPT>
 void sort_pass_bits(int bits, KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vout, int64_t n, int shift,
-                    uint32_t* hist, uint32_t* digit_total, int nblocks, const uint2* rect, uint2* rect_sorted, hipStream_t st) {
+                    uint32_t* hist, uint32_t* digit_total, int nblocks, const uint2* rect, uint2* rect_sorted, hipStream_t st,
+                    bool hist_ready) {
+    if (hist_ready && bits == 8) {
+        sort_pass<KeyT, IPT, 8>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st, true);
+        return;
+    }
     switch (bits) {
         case 11: sort_pass<KeyT, IPT, 11>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st); break;
         case 8: sort_pass<KeyT, IPT, 8>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st); break;
@@ -509,7 +538,7 @@ void sort_pass_bits(int bits, KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vo
 
 template <typename KeyT>
 int sort_pairs_t(KeyT* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
-                 uint32_t* digit_total, int items, const uint2* rect, uint2* rect_sorted, hipStream_t st) {
+                 uint32_t* digit_total, int items, const uint2* rect, uint2* rect_sorted, hipStream_t st, bool first_hist_ready) {
     int cur = 0;
     if (n <= 0) return cur;
     const int nblocks = (int)((n + items - 1) / items);
@@ -521,16 +550,16 @@ int sort_pairs_t(KeyT* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max
         uint2* rcs = p == passes - 1 ? rect_sorted : nullptr;
         if (items == 1024)
             sort_pass_bits<KeyT, 1024 / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
-                                                    digit_total, nblocks, rc, rcs, st);
+                                                    digit_total, nblocks, rc, rcs, st, first_hist_ready && p == 0);
         else if (items == 2048)
             sort_pass_bits<KeyT, 2048 / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
-                                                    digit_total, nblocks, rc, rcs, st);
+                                                    digit_total, nblocks, rc, rcs, st, first_hist_ready && p == 0);
         else if (items == 8192)
             sort_pass_bits<KeyT, 8192 / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
-                                                    digit_total, nblocks, rc, rcs, st);
+                                                    digit_total, nblocks, rc, rcs, st, first_hist_ready && p == 0);
         else
             sort_pass_bits<KeyT, 4096 / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
-                                                    digit_total, nblocks, rc, rcs, st);
+                                                    digit_total, nblocks, rc, rcs, st, first_hist_ready && p == 0);
         shift += pass_bits[p];
         cur ^= 1;
     }
@@ -597,12 +626,17 @@ int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits) {
 }
 
 int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
-                         uint32_t* digit_total, int items, hipStream_t st, const uint2* rect, uint2* rect_sorted) {
-    return sort_pairs_t<uint32_t>(keys, vals, n, nbits, max_digit_bits, hist, digit_total, items, rect, rect_sorted, st);
+                         uint32_t* digit_total, int items, hipStream_t st, const uint2* rect, uint2* rect_sorted,
+                         bool first_hist_ready) {
+    // first_hist_ready: hist[d * nblocks + b] already holds the first pass's per-workgroup histogram (8-bit digit, same
+    // `items` per workgroup) -- the preprocess kernel counts the low byte of every key it writes
+    int pb[8];
+    if (first_hist_ready && (gsr_sort_plan(nbits, max_digit_bits, pb) < 1 || pb[0] != 8)) first_hist_ready = false;
+    return sort_pairs_t<uint32_t>(keys, vals, n, nbits, max_digit_bits, hist, digit_total, items, rect, rect_sorted, st, first_hist_ready);
 }
 
 // 16-bit keys (tile ids when the frame has <= 65536 tiles): 25 % less traffic per pass than 32-bit keys
 int gsr_radix_sort_pairs_k16(uint16_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
                              uint32_t* digit_total, int items, hipStream_t st) {
-    return sort_pairs_t<uint16_t>(keys, vals, n, nbits, max_digit_bits, hist, digit_total, items, nullptr, nullptr, st);
+    return sort_pairs_t<uint16_t>(keys, vals, n, nbits, max_digit_bits, hist, digit_total, items, nullptr, nullptr, st, false);
 }

@@ -273,7 +273,8 @@ enum {
     GSR_STAGE_RENDER_BWD = 7,
     GSR_STAGE_PREPROCESS_BWD = 8,
     GSR_STAGE_GATHER_BWD = 9,
-    GSR_STAGE_COUNT = 10
+    GSR_STAGE_COLOR = 10,            /* SH -> RGB kernel of the split preprocess (option color_overlap) */
+    GSR_STAGE_COUNT = 11
 };
 int gsr_profile_enable(int on);      /* bit 0: per-stage events; bit 1: work counters (slow the blend kernels: count in a separate pass) */
 int gsr_profile_reset(void);

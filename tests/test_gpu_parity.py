@@ -281,9 +281,9 @@ def _backward_case(name, n, colors_cov=False, use_depth=True, seed=0):
         scale = b.abs().max().item() + 1e-30
         d = (a - b).abs() / scale
         measured[k] = f"{d.max().item():.2e}/{torch.quantile(d.flatten()[: 4_000_000], 0.999).item():.2e}"
-        # discrete threshold flips (fragile pixels) may move a handful of entries; the bulk must be tight
-        assert d.max().item() < 2e-3, f"{k}: max err {d.max().item():.3e} (rel. to max |grad|)"
-        assert torch.quantile(d.flatten()[: 4_000_000], 0.999).item() < 1e-4, f"{k}: 99.9th pct err too large"
+        # measured on MI355X (profiles/r02_parity_report.json): max <= 9.5e-6, p99.9 <= 3.3e-6 over the three scenes
+        assert d.max().item() < 1e-4, f"{k}: max err {d.max().item():.3e} (rel. to max |grad|)"
+        assert torch.quantile(d.flatten()[: 4_000_000], 0.999).item() < 1e-5, f"{k}: 99.9th pct err too large"
         assert b.abs().max().item() > 0, f"{k}: oracle gradient is identically zero"
     parity_report(f"small scene {name}/backward (max / p99.9 of |d grad| / max |grad|)", n=int(sc.P), **measured)
 
