@@ -16,6 +16,13 @@
 
 namespace {
 
+// experiment (measurement build): ask for 3 waves per SIMD in the two per-Gaussian kernels (costs 25-49 spilled registers)
+#if defined(GSR_AB_VARIANTS) && defined(GSR_PRE_WAVES3)
+#define GSR_PRE_OCC __attribute__((amdgpu_waves_per_eu(3, 3)))
+#else
+#define GSR_PRE_OCC
+#endif
+
 constexpr int SH_ROW = 52;        // LDS row stride in floats for a 48-float SH record (52*l mod 64 hits 16 distinct bank quads)
 
 __device__ __forceinline__ void load_cam(const GsrCamDev& c, GsrCam& cam) {
@@ -40,6 +47,34 @@ __device__ __forceinline__ void wave_load_sh16(const float* __restrict__ shs, in
         const int g = idx / 12, part = idx - g * 12;
         if (((rows >> g) & 1ull) && i0 + g < P)
             *reinterpret_cast<float4*>(tile + g * SH_ROW + part * 4) = src[idx];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+// gfx950 form of the same copy: global -> LDS directly (global_load_lds_dwordx4, "LDS DMA"): the wave's 12 KB block lands in
+// the tile in memory order -- row stride 48 floats, no padding -- without passing through registers, so the block costs no
+// VGPRs while it is in flight and can stay in flight across the whole projection arithmetic.  `shs` must be 16-byte aligned.
+// Completion is tracked by vmcnt like any load (the compiler waits before the first LDS read that may alias).
+constexpr int SH_ROW_DMA = 48;
+__device__ __forceinline__ void wave_dma_sh16(const float* __restrict__ shs, int64_t i0, int P, int lane, float* tile) {
+    const int nchunk = (int)((P - i0) < 64 ? (P - i0) : 64) * 12;
+    const char* src = reinterpret_cast<const char*>(shs + i0 * 48);
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        const int idx = it * 64 + lane;
+        if (idx < nchunk)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + idx * 16),
+                                             (__attribute__((address_space(3))) void*)(tile + it * 256), 16, 0, 0);
+    }
+}
+// ... and the dense tile back to global memory (every row up to P, zero rows included)
+__device__ __forceinline__ void wave_store_sh16_dense(float* __restrict__ dst_all, int64_t i0, int P, int lane, const float* tile) {
+    float4* dst = reinterpret_cast<float4*>(dst_all + i0 * 48);
+    const int nchunk = (int)((P - i0) < 64 ? (P - i0) : 64) * 12;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        const int idx = it * 64 + lane;
+        if (idx < nchunk) dst[idx] = *reinterpret_cast<const float4*>(tile + idx * 4);
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -182,8 +217,8 @@ __device__ __forceinline__ void wave_store_sh_split(float* __restrict__ d_dc, fl
     __builtin_amdgcn_wave_barrier();
 }
 // SPLIT = the separate dc / rest form (always staged: the C ABI accepts it only for M == 16 and 16-byte aligned pointers)
-template <bool SPLIT>
-__global__ void __launch_bounds__(256)
+template <bool SPLIT, bool DMA>
+__global__ void __launch_bounds__(256) GSR_PRE_OCC
 preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
                       const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                       const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -210,6 +245,9 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
     // bands of a quarter of the frame or more: still cheaper than a second latency phase (measured: 0.098 ms two-phase vs
     // 0.074 ms speculative for a quarter-frame band at 1 M Gaussians)
     const bool speculative = (cam.tile_y1 - cam.tile_y0) * 4 >= cam.gy;
+    // DMA (chosen by the launcher: fused SH form, M == 16, 16-byte aligned, full-frame band): see wave_dma_sh16
+    constexpr bool dma_sh = DMA && !SPLIT;
+    constexpr int sh_row = dma_sh ? SH_ROW_DMA : SH_ROW;
     // wave-uniform trip count: every lane of a wave runs the same iterations (lanes past P idle inside)
     const int64_t i_first = first_hist ? (int64_t)blockIdx.x * hist_items + wv * 64 : ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane;
     const int64_t i_stride = first_hist ? 256 : (int64_t)gridDim.x * blockDim.x;
@@ -229,7 +267,19 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         const bool spec_sh = staged_sh && speculative;
         float4 g_rot = make_float4(0.f, 0.f, 0.f, 0.f);
         float g_s[3] = {0.f, 0.f, 0.f}, g_op = 0.f;
-        if (spec_sh) {
+        if (dma_sh) {
+            // geometry first, the SH block behind it: vmcnt retires in order, so the projection can start as soon as the
+            // geometry has landed while the 12 KB block is still streaming into the tile
+            if (in_range) {
+                mean[0] = means3D[i * 3 + 0]; mean[1] = means3D[i * 3 + 1]; mean[2] = means3D[i * 3 + 2];
+                g_op = opacities[i];
+                if (!cov3D_precomp) {
+                    g_s[0] = scales[i * 3 + 0]; g_s[1] = scales[i * 3 + 1]; g_s[2] = scales[i * 3 + 2];
+                    g_rot = reinterpret_cast<const float4*>(rotations)[i];
+                }
+            }
+            wave_dma_sh16(shs, i0, P, lane, tile);
+        } else if (spec_sh) {
             float4 shreg[12];
             if (!SPLIT) wave_issue_sh16(shs, i0, P, lane, shreg);
             if (in_range) {     // the geometry loads ride in the same latency window
@@ -244,7 +294,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             else wave_commit_sh16(shreg, ~0ull, lane, tile);
         }
         if (in_range) {
-            if (!spec_sh) {
+            if (!spec_sh && !dma_sh) {
                 mean[0] = means3D[i * 3 + 0]; mean[1] = means3D[i * 3 + 1]; mean[2] = means3D[i * 3 + 2];
                 g_op = opacities[i];
             }
@@ -253,7 +303,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
 #pragma unroll
                 for (int k = 0; k < 6; ++k) cov[k] = cov3D_precomp[i * 6 + k];
             } else {
-                if (!spec_sh) {
+                if (!spec_sh && !dma_sh) {
                     g_s[0] = scales[i * 3 + 0]; g_s[1] = scales[i * 3 + 1]; g_s[2] = scales[i * 3 + 2];
                     g_rot = reinterpret_cast<const float4*>(rotations)[i];
                 }
@@ -265,7 +315,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         // colours are needed only by Gaussians that touch this rank's band of tile rows (all visible ones on one GPU):
         // with the screen sharded over N GPUs each rank streams ~1/N of the SH records
         const bool need_color = vis && sp.tiles > 0;
-        if (staged_sh) {
+        if (staged_sh && !dma_sh) {
             const uint64_t rows = __ballot(need_color);
             if (rows) {
                 if (spec_sh) { /* already staged */ }
@@ -283,7 +333,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             } else if (colors_precomp) {
                 rgb[0] = colors_precomp[i * 3 + 0]; rgb[1] = colors_precomp[i * 3 + 1]; rgb[2] = colors_precomp[i * 3 + 2];
             } else if (staged_sh) {
-                gsr_sh_to_rgb(cam.sh_degree, 16, tile + lane * SH_ROW, mean, cam.campos, rgb, clampbits);
+                gsr_sh_to_rgb(cam.sh_degree, 16, tile + lane * sh_row, mean, cam.campos, rgb, clampbits);
             } else if (!SPLIT) {
                 gsr_sh_to_rgb(cam.sh_degree, cam.M, shs + i * (int64_t)cam.M * 3, mean, cam.campos, rgb, clampbits);
             }
@@ -427,8 +477,8 @@ preprocess_color_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D
 
 #endif  // GSR_AB_VARIANTS
 
-template <bool SPLIT>
-__global__ void __launch_bounds__(256)
+template <bool SPLIT, bool DMA>
+__global__ void __launch_bounds__(256) GSR_PRE_OCC
 preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
                       const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                       const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -446,6 +496,8 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
     const float* dc = SPLIT ? camd.sh_dc : nullptr;     // split form: `shs` / dL_dsh hold coefficients 1..15, dc / dL_ddc coefficient 0
     float* dL_ddc = SPLIT ? camd.dL_dsh_dc : nullptr;
     const bool staged_sh = shs != nullptr && M == 16;
+    constexpr bool dma_sh = DMA && !SPLIT;      // launcher: fused SH form, M == 16, shs / dL_dsh 16-byte aligned
+    constexpr int sh_row = dma_sh ? SH_ROW_DMA : SH_ROW;
     for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < P; i0 += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = i0 + lane;
         const bool in_range = i < P;
@@ -477,6 +529,7 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         }
         if (staged_sh) {
             if (SPLIT) wave_load_sh_split(dc, shs, i0, P, ~0ull, lane, tile);
+            else if (dma_sh) wave_dma_sh16(shs, i0, P, lane, tile);      // streams in behind the geometry, costs no registers
             else wave_load_sh16(shs, i0, P, ~0ull, lane, tile);
         }
         const bool vis = in_range && rad > 0;
@@ -495,6 +548,10 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             dm2x = g.dpx * (0.5f * (float)cam.W);
             dm2y = g.dpy * (0.5f * (float)cam.H);
             if (!cov3D_precomp) gsr_cov3d_backward(s, cam.scale_modifier, q, dcov, dscale, drot);
+        }
+        // the tile is read AND written below (gradient in place, zero rows): the block must have landed for every lane
+        if (dma_sh) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+        if (vis) {
             if (shs) {
                 // The colour clamp mask is recomputed from the SH record (a few hundred FLOPs on data that is loaded anyway)
                 // instead of being read from the forward's array: under screen sharding the forward evaluates colours
@@ -502,9 +559,9 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
                 float rgb_unused[3];
                 uint32_t clampbits = 0;
                 if (staged_sh) {   // in place in the LDS row: each 48-byte group is read before it is overwritten with its gradient
-                    gsr_sh_to_rgb(cam.sh_degree, 16, tile + lane * SH_ROW, mean, cam.campos, rgb_unused, clampbits);
-                    gsr_sh_backward(cam.sh_degree, 16, tile + lane * SH_ROW, mean, cam.campos, clampbits, drgb,
-                                    tile + lane * SH_ROW, dmean);
+                    gsr_sh_to_rgb(cam.sh_degree, 16, tile + lane * sh_row, mean, cam.campos, rgb_unused, clampbits);
+                    gsr_sh_backward(cam.sh_degree, 16, tile + lane * sh_row, mean, cam.campos, clampbits, drgb,
+                                    tile + lane * sh_row, dmean);
                 } else if (!SPLIT) {
                     gsr_sh_to_rgb(cam.sh_degree, M, shs + i * (int64_t)M * 3, mean, cam.campos, rgb_unused, clampbits);
                     gsr_sh_backward(cam.sh_degree, M, shs + i * (int64_t)M * 3, mean, cam.campos, clampbits, drgb,
@@ -514,7 +571,7 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         } else if (shs) {
             if (staged_sh) {
 #pragma unroll
-                for (int k = 0; k < 12; ++k) *reinterpret_cast<float4*>(tile + lane * SH_ROW + k * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k = 0; k < 12; ++k) *reinterpret_cast<float4*>(tile + lane * sh_row + k * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
             } else if (in_range && !SPLIT) {
                 float* o = dL_dsh + i * (int64_t)M * 3;
                 for (int k = 0; k < M * 3; ++k) o[k] = 0.f;
@@ -522,6 +579,7 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         }
         if (staged_sh) {
             if (SPLIT) wave_store_sh_split(dL_ddc, dL_dsh, i0, P, lane, tile);
+            else if (dma_sh) wave_store_sh16_dense(dL_dsh, i0, P, lane, tile);
             else wave_store_sh16(dL_dsh, i0, P, lane, tile);
         }
         if (!in_range) continue;
@@ -548,6 +606,17 @@ mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __res
     }
 }
 
+// option sh_dma (measurement build): SH blocks go global -> LDS directly (global_load_lds_dwordx4) in the forward (bit 0) /
+// backward (bit 1) per-Gaussian kernel.  MEASURED (round 2, 1 M Gaussians, parity green): the forward drops from 187 to 153
+// VGPRs (3 waves/SIMD instead of 2) and gets 2-3 us SLOWER (0.072-0.074 vs 0.069-0.071 ms: the unpadded 192-byte rows cost
+// 4-way LDS bank conflicts and the kernel was not occupancy-bound); the backward gains 1 % (0.137-0.139 vs 0.140 ms).
+// Asking for 3 waves/SIMD with spills (amdgpu_waves_per_eu) loses 35 us in the forward and is a wash in the backward.
+#ifdef GSR_AB_VARIANTS
+int g_sh_dma = 0;
+#else
+constexpr int g_sh_dma = 0;
+#endif
+
 inline int stream_grid(int64_t n) {
     int64_t b = (n + 255) / 256;
     if (b > 2048) b = 2048;
@@ -564,16 +633,21 @@ void gsr_launch_preprocess(const GsrCamDev& cam, int P, const float* means3D, co
     // first_hist_items != 0: one workgroup per workgroup of the depth sort's first pass (see the kernel)
     const int grid = first_hist_items ? (int)(((int64_t)P + first_hist_items - 1) / first_hist_items) : stream_grid(P);
     uint32_t* first_hist = first_hist_items ? g.sort_hist : nullptr;
-    if (cam.sh_dc)
-        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(grid), dim3(256), 0, st, cam, P, means3D, shs,
-                           colors_precomp, opacities, scales, rotations, cov3D_precomp, g.splats, g.rect, g.tiles,
-                           /*clamped (recomputed by the backward)*/ nullptr, g.keys[0], g.vals[0], radii,
-                           gsr_onesweep_available() ? g.os_scratch : nullptr, first_hist, first_hist_items);
-    else
-        hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(grid), dim3(256), 0, st, cam, P, means3D, shs,
-                           colors_precomp, opacities, scales, rotations, cov3D_precomp, g.splats, g.rect, g.tiles,
-                           /*clamped (recomputed by the backward)*/ nullptr, g.keys[0], g.vals[0], radii,
-                           gsr_onesweep_available() ? g.os_scratch : nullptr, first_hist, first_hist_items);
+    // fused SH records of degree-3 storage, 16-byte aligned, full-frame band: the SH block goes global -> LDS directly
+    const bool dma = (g_sh_dma & 1) && !cam.sh_dc && shs && cam.M == 16 && (reinterpret_cast<uintptr_t>(shs) & 15) == 0 &&
+                     (cam.tile_y1 - cam.tile_y0) * 4 >= cam.gy;
+#define GSR_PRE_FWD(SPLIT_, DMA_)                                                                                                     \
+    hipLaunchKernelGGL((preprocess_fwd_kernel<SPLIT_, DMA_>), dim3(grid), dim3(256), 0, st, cam, P, means3D, shs, colors_precomp,        \
+                       opacities, scales, rotations, cov3D_precomp, g.splats, g.rect, g.tiles,                                         \
+                       /*clamped (recomputed by the backward)*/ nullptr, g.keys[0], g.vals[0], radii,                                 \
+                       gsr_onesweep_available() ? g.os_scratch : nullptr, first_hist, first_hist_items)
+    if (cam.sh_dc) GSR_PRE_FWD(true, false);
+#ifdef GSR_AB_VARIANTS
+    else if (dma) GSR_PRE_FWD(false, true);
+#endif
+    else GSR_PRE_FWD(false, false);
+#undef GSR_PRE_FWD
+    (void)dma;
 }
 
 #ifdef GSR_AB_VARIANTS
@@ -606,18 +680,28 @@ void gsr_launch_preprocess_backward(const GsrCamDev& cam, int P, const float* me
                                     GsrGeom g, const float* splat_grads, float* dL_dmeans2D, float* dL_dcolors,
                                     float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                                     float* dL_dscales, float* dL_drotations, hipStream_t st) {
-    if (cam.sh_dc)
-        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs,
-                           colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g.clamped,
-                           reinterpret_cast<const float4*>(splat_grads), dL_dmeans2D, dL_dcolors, dL_dopacity,
-                           dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
-    else
-        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs,
-                           colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g.clamped,
-                           reinterpret_cast<const float4*>(splat_grads), dL_dmeans2D, dL_dcolors, dL_dopacity,
-                           dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
+    const bool dma = (g_sh_dma & 2) && !cam.sh_dc && shs && cam.M == 16 &&
+                     ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(dL_dsh)) & 15) == 0;
+#define GSR_PRE_BWD(SPLIT_, DMA_)                                                                                                     \
+    hipLaunchKernelGGL((preprocess_bwd_kernel<SPLIT_, DMA_>), dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs,             \
+                       colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g.clamped,                                 \
+                       reinterpret_cast<const float4*>(splat_grads), dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D,     \
+                       dL_dsh, dL_dscales, dL_drotations)
+    if (cam.sh_dc) GSR_PRE_BWD(true, false);
+#ifdef GSR_AB_VARIANTS
+    else if (dma) GSR_PRE_BWD(false, true);
+#endif
+    else GSR_PRE_BWD(false, false);
+#undef GSR_PRE_BWD
+    (void)dma;
 }
 
 void gsr_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st) {
     hipLaunchKernelGGL(mark_visible_kernel, dim3(stream_grid(P)), dim3(256), 0, st, P, means3D, view, present);
 }
+
+#ifdef GSR_AB_VARIANTS
+int gsr_set_sh_dma(int mask) { g_sh_dma = mask & 3; return 1; }
+#else
+int gsr_set_sh_dma(int) { return 0; }
+#endif
