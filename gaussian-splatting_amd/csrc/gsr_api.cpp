@@ -292,6 +292,7 @@ int gsr_set_option(const char* name, int value) {
     }
     if (!strcmp(name, "first_hist_in_preprocess")) {
         if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "first_hist_in_preprocess must be 0 or 1");
+        if (value && !gsr_preprocess_split_available()) return fail(GSR_ERR_UNSUPPORTED, "first_hist_in_preprocess needs a -DGSR_AB_VARIANTS build");
         g_first_hist = value;
         return GSR_OK;
     }

@@ -207,7 +207,45 @@ GSR_HD void gsr_st12(float* p, int nf, const float* src) {
 // sh points at this Gaussian's [M][3] block (global or host memory); it is consumed in groups of 4 coefficients
 // (12 floats = three 16-byte loads) so that only one group is live in registers.  Per channel the sum is built
 // left to right exactly as sh_utils writes it: result (+/-) (C * factor ...) * sh[k].
-GSR_HD void gsr_sh_to_rgb(int deg, int M, const float* sh, const float* mean, const float* campos, float* rgb, uint32_t& clamped) {
+// Where a Gaussian's SH record lives.  GsrShRow: M consecutive RGB triples (the fused [P, M, 3] tensor, or an LDS row).
+// GsrShRowSplit: coefficient 0 in dc[3], coefficients 1..15 in rest[45] -- the "separate_sh" call form, whose two blocks are
+// staged in LDS exactly as they lie in memory (rest rows 45 floats apart: odd stride, bank-conflict-free scalar reads).
+// ld / st move the 12 floats of coefficient group k0 .. k0+3.
+struct GsrShRow {
+    const float* p;
+    GSR_HD void ld(int k0, int nf, float* dst) const { gsr_ld12(p + k0 * 3, nf, dst); }
+};
+struct GsrShRowOut {
+    float* p;
+    GSR_HD void st(int k0, int nf, const float* src) const { gsr_st12(p + k0 * 3, nf, src); }
+};
+struct GsrShRowSplit {
+    const float* dc;
+    const float* rest;
+    GSR_HD void ld(int k0, int, float* dst) const {
+        if (k0 == 0) {
+            dst[0] = dc[0]; dst[1] = dc[1]; dst[2] = dc[2];
+            for (int i = 0; i < 9; ++i) dst[3 + i] = rest[i];
+        } else {
+            for (int i = 0; i < 12; ++i) dst[i] = rest[k0 * 3 - 3 + i];
+        }
+    }
+};
+struct GsrShRowSplitOut {
+    float* dc;
+    float* rest;
+    GSR_HD void st(int k0, int, const float* src) const {
+        if (k0 == 0) {
+            dc[0] = src[0]; dc[1] = src[1]; dc[2] = src[2];
+            for (int i = 0; i < 9; ++i) rest[i] = src[3 + i];
+        } else {
+            for (int i = 0; i < 12; ++i) rest[k0 * 3 - 3 + i] = src[i];
+        }
+    }
+};
+
+template <class Row>
+GSR_HD void gsr_sh_to_rgb_row(int deg, int M, const Row& sh, const float* mean, const float* campos, float* rgb, uint32_t& clamped) {
     const float dx = mean[0] - campos[0], dy = mean[1] - campos[1], dz = mean[2] - campos[2];
     const float n = sqrtf(dx * dx + dy * dy + dz * dz);
     const float x = dx / n, y = dy / n, z = dz / n;
@@ -219,7 +257,7 @@ GSR_HD void gsr_sh_to_rgb(int deg, int M, const float* sh, const float* mean, co
     for (int grp = 0; grp < 4; ++grp) {
         const int k0 = grp * 4;
         if (k0 >= ncoef) break;
-        gsr_ld12(sh + k0 * 3, (M - k0 >= 4 ? 4 : M - k0) * 3, s);
+        sh.ld(k0, (M - k0 >= 4 ? 4 : M - k0) * 3, s);
         for (int ch = 0; ch < 3; ++ch) {
             float r = res[ch];
             if (grp == 0) {
@@ -247,6 +285,9 @@ GSR_HD void gsr_sh_to_rgb(int deg, int M, const float* sh, const float* mean, co
         if (result < 0.0f) clamped |= (1u << ch);
         rgb[ch] = fmaxf(result, 0.0f);
     }
+}
+GSR_HD void gsr_sh_to_rgb(int deg, int M, const float* sh, const float* mean, const float* campos, float* rgb, uint32_t& clamped) {
+    gsr_sh_to_rgb_row(deg, M, GsrShRow{sh}, mean, campos, rgb, clamped);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -389,8 +430,9 @@ GSR_HD void gsr_sh_bwd_term(GsrShBwdAcc& a, const float* s3, float* d3, float ba
     a.ddy += by * dot;
     a.ddz += bz * dot;
 }
-GSR_HD void gsr_sh_backward(int deg, int M, const float* sh, const float* mean, const float* campos,
-                            uint32_t clamped, const float* drgb_in, float* dsh, float* dmean) {
+template <class Row, class RowOut>
+GSR_HD void gsr_sh_backward_row(int deg, int M, const Row& sh, const float* mean, const float* campos,
+                                uint32_t clamped, const float* drgb_in, const RowOut& dsh, float* dmean) {
     const float ox = mean[0] - campos[0], oy = mean[1] - campos[1], oz = mean[2] - campos[2];
     const float n = sqrtf(ox * ox + oy * oy + oz * oz);
     const float x = ox / n, y = oy / n, z = oz / n;
@@ -405,7 +447,7 @@ GSR_HD void gsr_sh_backward(int deg, int M, const float* sh, const float* mean, 
         const int nf = (M - k0 >= 4 ? 4 : M - k0) * 3;
         for (int i = 0; i < 12; ++i) d[i] = 0.0f;
         const bool live = (grp == 0) || (grp == 1 && deg > 1) || (grp >= 2 && deg > (grp == 2 ? 1 : 2));
-        if (live) gsr_ld12(sh + k0 * 3, nf, s);
+        if (live) sh.ld(k0, nf, s);
         if (grp == 0) {
             gsr_sh_bwd_term(a, s + 0, d + 0, GSR_SH_C0, 0.0f, 0.0f, 0.0f);
             if (deg > 0) {
@@ -438,7 +480,7 @@ GSR_HD void gsr_sh_backward(int deg, int M, const float* sh, const float* mean, 
             gsr_sh_bwd_term(a, s + 9, d + 9, GSR_SH_C3_6 * x * (xx - 3.0f * yy), GSR_SH_C3_6 * (3.0f * xx - 3.0f * yy),
                             GSR_SH_C3_6 * -6.0f * xy, 0.0f);
         }
-        gsr_st12(dsh + k0 * 3, nf, d);
+        dsh.st(k0, nf, d);
     }
     // d = o / |o|  =>  dL/do = (dL/dd - d (d . dL/dd)) / |o|
     const float dd = x * a.ddx + y * a.ddy + z * a.ddz;
@@ -446,6 +488,10 @@ GSR_HD void gsr_sh_backward(int deg, int M, const float* sh, const float* mean, 
     dmean[0] += (a.ddx - x * dd) * inv;
     dmean[1] += (a.ddy - y * dd) * inv;
     dmean[2] += (a.ddz - z * dd) * inv;
+}
+GSR_HD void gsr_sh_backward(int deg, int M, const float* sh, const float* mean, const float* campos,
+                            uint32_t clamped, const float* drgb_in, float* dsh, float* dmean) {
+    gsr_sh_backward_row(deg, M, GsrShRow{sh}, mean, campos, clamped, drgb_in, GsrShRowOut{dsh}, dmean);
 }
 
 // Sigma3D = (R S)(R S)^T backward: dcov (independent packed entries) -> dscale[3], drot[4]

@@ -112,107 +112,76 @@ __device__ __forceinline__ void wave_store_sh16(float* __restrict__ dst_all, int
 }
 
 // "separate_sh" call form (gaussian_renderer/__init__.py:82-100): coefficient 0 lives in dc[P,1,3], coefficients 1..15
-// in rest[P,15,3].  Both blocks of the wave's 64 Gaussians are contiguous (768 B and 11520 B) and are moved with
-// 16-byte accesses; the LDS row has the same layout as in the fused case (dc in floats 0..2, rest in 3..47).
-__device__ __forceinline__ void wave_load_sh_split(const float* __restrict__ dc, const float* __restrict__ rest, int64_t i0,
-                                                   int P, uint64_t rows, int lane, float* tile) {
+// in rest[P,15,3].  Both blocks of the wave's 64 Gaussians are contiguous (768 B and 11520 B).
+// Both blocks are copied with 16-byte accesses EXACTLY as they lie in memory -- rest rows at tile[g * 45], dc rows at
+// tile[SPLIT_DC + g * 3] -- so the copy needs no per-float address arithmetic (the first version re-laid them out as padded
+// 48-float rows: ~20 VALU instructions per 16 bytes on divisions by 45 plus four 4-byte LDS writes made the split-form
+// forward 117 us against 74 us for the fused form).  Readers go through GsrShRowSplit (gsr_math.h): scalar LDS reads at
+// an odd row stride, bank-conflict-free.
+constexpr int SPLIT_DC = 64 * 45;      // float offset of the dc rows inside the tile (2880 + 192 = 3072 floats <= 64 * SH_ROW)
+__device__ __forceinline__ void wave_load_sh_split_dense(const float* __restrict__ dc, const float* __restrict__ rest, int64_t i0,
+                                                         int P, uint64_t rows, int lane, float* tile) {
     const int nrow = (int)((P - i0) < 64 ? (P - i0) : 64);
     const float* src = rest + i0 * 45;
     const int nrest = nrow * 45;
-#pragma unroll 3
+    float4 v[12];
+#pragma unroll
     for (int it = 0; it < 12; ++it) {
         const int f = (it * 64 + lane) * 4;
-        if (f < nrest) {
-            const int g0 = f / 45, g1 = (f + 3) / 45 < nrow ? (f + 3) / 45 : nrow - 1;
-            if (((rows >> g0) | (rows >> g1)) & 1ull) {
-                float v[4];
-                if (f + 3 < nrest) {
-                    const float4 t = *reinterpret_cast<const float4*>(src + f);
-                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = f + c < nrest ? src[f + c] : 0.f;
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int ff = f + c;
-                    if (ff < nrest) {
-                        const int g = ff / 45;
-                        tile[g * SH_ROW + 3 + (ff - g * 45)] = v[c];
-                    }
-                }
-            }
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (rows != all: screen-sharded ranks fetch only the 16-byte pieces that hold a wanted row)
+        const bool want = rows == ~0ull || ((((rows >> (f / 45)) | (rows >> ((f + 3) / 45 > 63 ? 63 : (f + 3) / 45))) & 1ull) != 0);
+        if (!want) {
+        } else if (f + 3 < nrest) {
+            v[it] = *reinterpret_cast<const float4*>(src + f);
+        } else if (f < nrest) {
+            v[it].x = src[f];
+            if (f + 1 < nrest) v[it].y = src[f + 1];
+            if (f + 2 < nrest) v[it].z = src[f + 2];
         }
     }
-    {
-        const float* sdc = dc + i0 * 3;
-        const int ndc = nrow * 3, f = lane * 4;
-        if (f < ndc) {
-            float v[4];
-            if (f + 3 < ndc) {
-                const float4 t = *reinterpret_cast<const float4*>(sdc + f);
-                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-            } else {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = f + c < ndc ? sdc[f + c] : 0.f;
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int ff = f + c;
-                if (ff < ndc) {
-                    const int g = ff / 3;
-                    tile[g * SH_ROW + (ff - g * 3)] = v[c];
-                }
-            }
-        }
+    float4 vd = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* sdc = dc + i0 * 3;
+    const int ndc = nrow * 3, fd = lane * 4;
+    if (rows == 0ull) {
+    } else if (fd + 3 < ndc) {
+        vd = *reinterpret_cast<const float4*>(sdc + fd);
+    } else if (fd < ndc) {
+        vd.x = sdc[fd];
+        if (fd + 1 < ndc) vd.y = sdc[fd + 1];
+        if (fd + 2 < ndc) vd.z = sdc[fd + 2];
     }
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        const int f = (it * 64 + lane) * 4;
+        if (f < 64 * 45) *reinterpret_cast<float4*>(tile + f) = v[it];
+    }
+    if (fd < 64 * 3) *reinterpret_cast<float4*>(tile + SPLIT_DC + fd) = vd;
     __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ void wave_store_sh_split(float* __restrict__ d_dc, float* __restrict__ d_rest, int64_t i0, int P,
-                                                    int lane, const float* tile) {
+__device__ __forceinline__ void wave_store_sh_split_dense(float* __restrict__ d_dc, float* __restrict__ d_rest, int64_t i0, int P,
+                                                          int lane, const float* tile) {
     const int nrow = (int)((P - i0) < 64 ? (P - i0) : 64);
     float* dst = d_rest + i0 * 45;
     const int nrest = nrow * 45;
     __builtin_amdgcn_wave_barrier();
-#pragma unroll 3
+#pragma unroll
     for (int it = 0; it < 12; ++it) {
         const int f = (it * 64 + lane) * 4;
-        if (f < nrest) {
-            float v[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int ff = f + c < nrest ? f + c : nrest - 1;
-                const int g = ff / 45;
-                v[c] = tile[g * SH_ROW + 3 + (ff - g * 45)];
-            }
-            if (f + 3 < nrest) {
-                *reinterpret_cast<float4*>(dst + f) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (f + c < nrest) dst[f + c] = v[c];
-            }
+        if (f + 3 < nrest) {
+            *reinterpret_cast<float4*>(dst + f) = *reinterpret_cast<const float4*>(tile + f);
+        } else if (f < nrest) {
+            for (int c = 0; c < 3; ++c)
+                if (f + c < nrest) dst[f + c] = tile[f + c];
         }
     }
-    {
-        float* ddc = d_dc + i0 * 3;
-        const int ndc = nrow * 3, f = lane * 4;
-        if (f < ndc) {
-            float v[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int ff = f + c < ndc ? f + c : ndc - 1;
-                const int g = ff / 3;
-                v[c] = tile[g * SH_ROW + (ff - g * 3)];
-            }
-            if (f + 3 < ndc) {
-                *reinterpret_cast<float4*>(ddc + f) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (f + c < ndc) ddc[f + c] = v[c];
-            }
-        }
+    float* ddc = d_dc + i0 * 3;
+    const int ndc = nrow * 3, fd = lane * 4;
+    if (fd + 3 < ndc) {
+        *reinterpret_cast<float4*>(ddc + fd) = *reinterpret_cast<const float4*>(tile + SPLIT_DC + fd);
+    } else if (fd < ndc) {
+        for (int c = 0; c < 3; ++c)
+            if (fd + c < ndc) ddc[fd + c] = tile[SPLIT_DC + fd + c];
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -231,7 +200,14 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
     // first_hist != NULL: workgroup b owns Gaussians [b * hist_items, (b + 1) * hist_items) -- exactly the keys of workgroup
     // b of the depth sort's first radix pass -- and leaves that pass's digit histogram (low 8 key bits) in
     // first_hist[d * gridDim.x + b], which saves the pass its histogram kernel (a launch and a read of all keys).
-    __shared__ uint32_t s_hist[256];
+    // (measurement build only: measured 4.3 us saved in the sort, 4.5 us lost here to the narrower grid)
+#ifdef GSR_AB_VARIANTS
+    constexpr bool HIST = true;
+#else
+    constexpr bool HIST = false;
+#endif
+    __shared__ uint32_t s_hist[HIST ? 256 : 1];
+    if (!HIST) first_hist = nullptr;
     if (first_hist) s_hist[threadIdx.x] = 0u;
     if (sort_state && blockIdx.x == 0)
         for (int i = threadIdx.x; i < GSR_OS_STATE_WORDS; i += 256) sort_state[i] = 0u;
@@ -290,7 +266,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
                     g_rot = reinterpret_cast<const float4*>(rotations)[i];
                 }
             }
-            if (SPLIT) wave_load_sh_split(dc, shs, i0, P, ~0ull, lane, tile);
+            if (SPLIT) wave_load_sh_split_dense(dc, shs, i0, P, ~0ull, lane, tile);
             else wave_commit_sh16(shreg, ~0ull, lane, tile);
         }
         if (in_range) {
@@ -319,7 +295,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             const uint64_t rows = __ballot(need_color);
             if (rows) {
                 if (spec_sh) { /* already staged */ }
-                else if (SPLIT) wave_load_sh_split(dc, shs, i0, P, rows, lane, tile);
+                else if (SPLIT) wave_load_sh_split_dense(dc, shs, i0, P, rows, lane, tile);
                 else wave_load_sh16(shs, i0, P, rows, lane, tile);
             }
         }
@@ -333,7 +309,8 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             } else if (colors_precomp) {
                 rgb[0] = colors_precomp[i * 3 + 0]; rgb[1] = colors_precomp[i * 3 + 1]; rgb[2] = colors_precomp[i * 3 + 2];
             } else if (staged_sh) {
-                gsr_sh_to_rgb(cam.sh_degree, 16, tile + lane * sh_row, mean, cam.campos, rgb, clampbits);
+                if (SPLIT) gsr_sh_to_rgb_row(cam.sh_degree, 16, GsrShRowSplit{tile + SPLIT_DC + lane * 3, tile + lane * 45}, mean, cam.campos, rgb, clampbits);
+                else gsr_sh_to_rgb(cam.sh_degree, 16, tile + lane * sh_row, mean, cam.campos, rgb, clampbits);
             } else if (!SPLIT) {
                 gsr_sh_to_rgb(cam.sh_degree, cam.M, shs + i * (int64_t)cam.M * 3, mean, cam.campos, rgb, clampbits);
             }
@@ -454,12 +431,12 @@ preprocess_color_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D
         }
         if (staged_sh) {
             if (spec_sh) {
-                if (SPLIT) wave_load_sh_split(dc, shs, i0, P, ~0ull, lane, tile);
+                if (SPLIT) wave_load_sh_split_dense(dc, shs, i0, P, ~0ull, lane, tile);
                 else wave_commit_sh16(shreg, ~0ull, lane, tile);
             } else {
                 const uint64_t rows = __ballot(need);
                 if (rows) {
-                    if (SPLIT) wave_load_sh_split(dc, shs, i0, P, rows, lane, tile);
+                    if (SPLIT) wave_load_sh_split_dense(dc, shs, i0, P, rows, lane, tile);
                     else wave_load_sh16(shs, i0, P, rows, lane, tile);
                 }
             }
@@ -467,7 +444,8 @@ preprocess_color_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D
         if (!need) continue;
         float rgb[3] = {0.f, 0.f, 0.f};
         uint32_t clampbits = 0;
-        if (staged_sh) gsr_sh_to_rgb(deg, 16, tile + lane * SH_ROW, mean, campos, rgb, clampbits);
+        if (staged_sh && SPLIT) gsr_sh_to_rgb_row(deg, 16, GsrShRowSplit{tile + SPLIT_DC + lane * 3, tile + lane * 45}, mean, campos, rgb, clampbits);
+        else if (staged_sh) gsr_sh_to_rgb(deg, 16, tile + lane * SH_ROW, mean, campos, rgb, clampbits);
         else if (!SPLIT) gsr_sh_to_rgb(deg, M, shs + i * (int64_t)M * 3, mean, campos, rgb, clampbits);
         float* rec = reinterpret_cast<float*>(splats + i * 4);
         *reinterpret_cast<float2*>(rec + 6) = make_float2(rgb[0], rgb[1]);      // q1.zw
@@ -528,7 +506,7 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             }
         }
         if (staged_sh) {
-            if (SPLIT) wave_load_sh_split(dc, shs, i0, P, ~0ull, lane, tile);
+            if (SPLIT) wave_load_sh_split_dense(dc, shs, i0, P, ~0ull, lane, tile);
             else if (dma_sh) wave_dma_sh16(shs, i0, P, lane, tile);      // streams in behind the geometry, costs no registers
             else wave_load_sh16(shs, i0, P, ~0ull, lane, tile);
         }
@@ -559,9 +537,16 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
                 float rgb_unused[3];
                 uint32_t clampbits = 0;
                 if (staged_sh) {   // in place in the LDS row: each 48-byte group is read before it is overwritten with its gradient
-                    gsr_sh_to_rgb(cam.sh_degree, 16, tile + lane * sh_row, mean, cam.campos, rgb_unused, clampbits);
-                    gsr_sh_backward(cam.sh_degree, 16, tile + lane * sh_row, mean, cam.campos, clampbits, drgb,
-                                    tile + lane * sh_row, dmean);
+                    if (SPLIT) {
+                        const GsrShRowSplit row{tile + SPLIT_DC + lane * 3, tile + lane * 45};
+                        gsr_sh_to_rgb_row(cam.sh_degree, 16, row, mean, cam.campos, rgb_unused, clampbits);
+                        gsr_sh_backward_row(cam.sh_degree, 16, row, mean, cam.campos, clampbits, drgb,
+                                            GsrShRowSplitOut{tile + SPLIT_DC + lane * 3, tile + lane * 45}, dmean);
+                    } else {
+                        gsr_sh_to_rgb(cam.sh_degree, 16, tile + lane * sh_row, mean, cam.campos, rgb_unused, clampbits);
+                        gsr_sh_backward(cam.sh_degree, 16, tile + lane * sh_row, mean, cam.campos, clampbits, drgb,
+                                        tile + lane * sh_row, dmean);
+                    }
                 } else if (!SPLIT) {
                     gsr_sh_to_rgb(cam.sh_degree, M, shs + i * (int64_t)M * 3, mean, cam.campos, rgb_unused, clampbits);
                     gsr_sh_backward(cam.sh_degree, M, shs + i * (int64_t)M * 3, mean, cam.campos, clampbits, drgb,
@@ -571,14 +556,26 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         } else if (shs) {
             if (staged_sh) {
 #pragma unroll
-                for (int k = 0; k < 12; ++k) *reinterpret_cast<float4*>(tile + lane * sh_row + k * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k = 0; k < 12; ++k) {
+                    if (SPLIT) {      // the lane's own 45 + 3 floats, nothing else (rows are not padded)
+                        if (k < 11) {
+                            tile[lane * 45 + k * 4 + 0] = 0.f; tile[lane * 45 + k * 4 + 1] = 0.f;
+                            tile[lane * 45 + k * 4 + 2] = 0.f; tile[lane * 45 + k * 4 + 3] = 0.f;
+                        } else {
+                            tile[lane * 45 + 44] = 0.f;
+                            tile[SPLIT_DC + lane * 3 + 0] = 0.f; tile[SPLIT_DC + lane * 3 + 1] = 0.f; tile[SPLIT_DC + lane * 3 + 2] = 0.f;
+                        }
+                    } else {
+                        *reinterpret_cast<float4*>(tile + lane * sh_row + k * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
             } else if (in_range && !SPLIT) {
                 float* o = dL_dsh + i * (int64_t)M * 3;
                 for (int k = 0; k < M * 3; ++k) o[k] = 0.f;
             }
         }
         if (staged_sh) {
-            if (SPLIT) wave_store_sh_split(dL_ddc, dL_dsh, i0, P, lane, tile);
+            if (SPLIT) wave_store_sh_split_dense(dL_ddc, dL_dsh, i0, P, lane, tile);
             else if (dma_sh) wave_store_sh16_dense(dL_dsh, i0, P, lane, tile);
             else wave_store_sh16(dL_dsh, i0, P, lane, tile);
         }

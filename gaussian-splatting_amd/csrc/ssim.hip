@@ -4,33 +4,43 @@
 // their autograd backward, which measured 10.7 ms per step on MI355X (MIOpen) against 2 ms for everything else in the
 // step.  Here: one kernel per direction, the separable 11-tap Gaussian window (sigma 1.5) applied inside LDS.
 //
-//   forward : per 16x16 output tile, the 26x26 halo of img1 / img2 is staged in LDS (zero outside the image = conv2d's
-//             zero padding 5), a horizontal pass produces the 5 windowed moments (x, y, x^2, y^2, xy) for the 26 halo
-//             rows, a vertical pass finishes them per pixel; the SSIM value and the three partial derivatives
-//             dm/dmu1, dm/dE[x^2], dm/dE[xy] (statistics held, as in the published fused-ssim scheme) are written.
+//   forward : per 64x16 output tile, the 74x26 halo of img1 / img2 is staged in LDS (zero outside the image = conv2d's
+//             zero padding 5); a horizontal pass produces the 5 windowed moments (x, y, x^2, y^2, xy) for the 26 halo
+//             rows -- one thread per 8 adjacent outputs, every input read once and spread over the outputs it feeds from
+//             registers -- a vertical pass finishes them, four vertically adjacent pixels per thread; the SSIM value and
+//             the three partial derivatives dm/dmu1, dm/dE[x^2], dm/dE[xy] (statistics held, as in the published
+//             fused-ssim scheme) are written with row-contiguous 256-byte stores.
 //   backward: dL/dimg1 = G * (dL/dm dm/dmu1) + 2 img1 (G * (dL/dm dm/dE[x^2])) + img2 (G * (dL/dm dm/dE[xy])), the same
 //             separable window applied to three maps.
-// HBM traffic ~0.25 GB per direction at 3x1080x1920 -> streaming-bound by design; arithmetic is a few FMA per byte.
+// Measured (3 x 1080 x 1920, MI355X): 82 us forward + 62 us backward -- THE SAME as round 1's 16x16-tile, one-output-per-thread
+// version (2.6x halo, 91 LDS reads per pixel) although this form reads LDS 14 (horizontal) + 17.5 (vertical) times per pixel
+// and stages a 1.9x halo: the kernel is not LDS- or HBM-bound (0.125 GB per direction = 1.5 TB/s) but sits on the FMA floor
+// of the separable window -- 5 moments x 11 taps x 2 passes x 1.6 (halo rows) = 144 FMA per pixel = ~41 us of VALU issue
+// even with v_pk_fma_f32 -- plus the load -> barrier -> horizontal -> barrier -> vertical phases of only three resident
+// workgroups per CU (50 KB of LDS each).  A barrier-free "marching" form (one wave per column strip, 11-row ring of the
+// horizontal moments in registers) was costed and dropped: at 1080p it has either < 3 waves per SIMD or > 30 % halo rows.
 #include "gsr_internal.h"
 
 namespace {
 
-constexpr int TS = 16;            // output tile
+constexpr int TXO = 64, TYO = 16;      // output tile (x, y)
 constexpr int HALO = 5;
-constexpr int TW = TS + 2 * HALO; // 26
-// LDS row strides (floats).  In both passes a wave covers 4 consecutive rows x 16 columns: with a 48-float stride the
-// four rows start 16 banks apart (48 r mod 64 = 0, 48, 32, 16), with 16 they are simply consecutive -- every ds_read /
-// ds_write of the two passes is conflict-free (the former 27 / 17 strides measured 2.3 conflict cycles per LDS
-// instruction issue cycle, profiles/r01_pmc_sq_per_kernel.csv).
-constexpr int SW = 48;            // staged halo rows
-constexpr int SHW = 16;           // horizontally filtered rows
+constexpr int HX = TXO + 2 * HALO;     // 74 staged columns
+constexpr int HY = TYO + 2 * HALO;     // 26 staged rows
+// LDS row strides (floats), both ODD: in the horizontal pass a wave is 8 rows x 8 tasks whose addresses are
+// r * stride + 8 t + j -- with an odd stride the eight rows start in eight different residues mod 8, so the 64 lanes hit 64
+// different banks; the vertical pass reads 64 consecutive columns of one row.
+constexpr int SW = 77;                 // staged halo rows
+constexpr int SHW = 65;                // horizontally filtered rows
+constexpr int HTASKS = HY * (TXO / 8); // 208 horizontal tasks of 8 outputs
 constexpr float C1 = 0.01f * 0.01f;
 constexpr float C2 = 0.03f * 0.03f;
 
 // normalised 11-tap Gaussian, sigma = 1.5 (utils/loss_utils.py:43-46), rounded from fp64
-__constant__ float c_win[11] = {1.0283801239e-03f, 7.5987582095e-03f, 3.6000773311e-02f, 1.0936068743e-01f,
-                                2.1300552785e-01f, 2.6601171494e-01f, 2.1300552785e-01f, 1.0936068743e-01f,
-                                3.6000773311e-02f, 7.5987582095e-03f, 1.0283801239e-03f};
+#define GSR_WIN(k)                                                                                                        \
+    ((k) == 0 || (k) == 10 ? 1.0283801239e-03f : (k) == 1 || (k) == 9 ? 7.5987582095e-03f                                \
+     : (k) == 2 || (k) == 8 ? 3.6000773311e-02f : (k) == 3 || (k) == 7 ? 1.0936068743e-01f                                \
+     : (k) == 4 || (k) == 6 ? 2.1300552785e-01f : 2.6601171494e-01f)
 
 // MEAN: instead of the SSIM map the workgroup writes the SUM of its tile's SSIM values (partials[plane][tile]); a second
 // one-workgroup kernel adds the partials in fixed order -> mean (deterministic, no 25 MB map round trip, no torch reduce)
@@ -39,57 +49,91 @@ __global__ void __launch_bounds__(256)
 ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2, float* __restrict__ ssim_map,
                 float* __restrict__ dm_dmu1, float* __restrict__ dm_dex2, float* __restrict__ dm_dexy) {
     __shared__ float s_part[4];
-    __shared__ float s_x[TW][SW];
-    __shared__ float s_y[TW][SW];
-    __shared__ float s_h[5][TW][SHW];
+    __shared__ float s_x[HY][SW];
+    __shared__ float s_y[HY][SW];
+    __shared__ float s_h[5][HY][SHW];
     const int tid = threadIdx.x;
     const int plane = blockIdx.z;                       // b * C + c
-    const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+    const int x0 = blockIdx.x * TXO, y0 = blockIdx.y * TYO;
     const float* p1 = img1 + (int64_t)plane * H * W;
     const float* p2 = img2 + (int64_t)plane * H * W;
-    for (int i = tid; i < TW * TW; i += 256) {
-        const int r = i / TW, c = i - r * TW;
+    for (int i = tid; i < HY * HX; i += 256) {
+        const int r = i / HX, c = i - r * HX;
         const int gy = y0 + r - HALO, gx = x0 + c - HALO;
         const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
         s_x[r][c] = in ? p1[(int64_t)gy * W + gx] : 0.f;
         s_y[r][c] = in ? p2[(int64_t)gy * W + gx] : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < TW * TS; i += 256) {          // horizontal pass on the 26 halo rows
-        const int r = i / TS, c = i - r * TS;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+    if (tid < HTASKS) {                                 // horizontal pass: row r, outputs c0 .. c0+7
+        const int r = tid >> 3, c0 = (tid & 7) * 8;
+        float acc[8][5];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float w = c_win[k], x = s_x[r][c + k], y = s_y[r][c + k];
-            a0 += w * x; a1 += w * y; a2 += w * x * x; a3 += w * y * y; a4 += w * x * y;
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int m = 0; m < 5; ++m) acc[i][m] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {                  // input column c0 + j feeds output i with tap j - i
+            const float x = s_x[r][c0 + j], y = s_y[r][c0 + j];
+            const float xx = x * x, yy = y * y, xy = x * y;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = j - i;
+                if (k >= 0 && k <= 10) {
+                    const float w = GSR_WIN(k);
+                    acc[i][0] = fmaf(w, x, acc[i][0]); acc[i][1] = fmaf(w, y, acc[i][1]); acc[i][2] = fmaf(w, xx, acc[i][2]);
+                    acc[i][3] = fmaf(w, yy, acc[i][3]); acc[i][4] = fmaf(w, xy, acc[i][4]);
+                }
+            }
         }
-        s_h[0][r][c] = a0; s_h[1][r][c] = a1; s_h[2][r][c] = a2; s_h[3][r][c] = a3; s_h[4][r][c] = a4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int m = 0; m < 5; ++m) s_h[m][r][c0 + i] = acc[i][m];
     }
     __syncthreads();
-    const int ty = tid / TS, tx = tid - ty * TS;
-    const int gy = y0 + ty, gx = x0 + tx;
-    float m_own = 0.f;
-    if (gy < H && gx < W) {
-        float mu1 = 0.f, mu2 = 0.f, ex2 = 0.f, ey2 = 0.f, exy = 0.f;
+    const int cx = tid & 63, rg = tid >> 6;             // vertical pass: column cx, rows 4 rg .. 4 rg + 3
+    float acc[4][5];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float w = c_win[k];
-            mu1 += w * s_h[0][ty + k][tx]; mu2 += w * s_h[1][ty + k][tx]; ex2 += w * s_h[2][ty + k][tx];
-            ey2 += w * s_h[3][ty + k][tx]; exy += w * s_h[4][ty + k][tx];
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int m = 0; m < 5; ++m) acc[o][m] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+        float v[5];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) v[m] = s_h[m][4 * rg + j][cx];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int k = j - o;
+            if (k >= 0 && k <= 10) {
+                const float w = GSR_WIN(k);
+#pragma unroll
+                for (int m = 0; m < 5; ++m) acc[o][m] = fmaf(w, v[m], acc[o][m]);
+            }
         }
-        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-        const float sigma1_sq = ex2 - mu1_sq, sigma2_sq = ey2 - mu2_sq, sigma12 = exy - mu12;
-        const float A = mu1_sq + mu2_sq + C1, B = sigma1_sq + sigma2_sq + C2;
-        const float Cc = 2.f * mu12 + C1, D = 2.f * sigma12 + C2;
-        const float inv_AB = 1.f / (A * B);
-        const float m = Cc * D * inv_AB;
-        const int64_t o = (int64_t)plane * H * W + (int64_t)gy * W + gx;
-        m_own = m;
-        if (!MEAN) ssim_map[o] = m;
-        if (dm_dmu1) {
-            dm_dmu1[o] = 2.f * mu2 * (D - Cc) * inv_AB - 2.f * mu1 * m / A + 2.f * mu1 * m / B;
-            dm_dex2[o] = -m / B;
-            dm_dexy[o] = 2.f * Cc * inv_AB;
+    }
+    const int gx = x0 + cx;
+    float m_own = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const int gy = y0 + 4 * rg + o;
+        if (gy < H && gx < W) {
+            const float mu1 = acc[o][0], mu2 = acc[o][1], ex2 = acc[o][2], ey2 = acc[o][3], exy = acc[o][4];
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float sigma1_sq = ex2 - mu1_sq, sigma2_sq = ey2 - mu2_sq, sigma12 = exy - mu12;
+            const float A = mu1_sq + mu2_sq + C1, B = sigma1_sq + sigma2_sq + C2;
+            const float Cc = 2.f * mu12 + C1, D = 2.f * sigma12 + C2;
+            const float inv_AB = 1.f / (A * B);
+            const float m = Cc * D * inv_AB;
+            const int64_t oo = (int64_t)plane * H * W + (int64_t)gy * W + gx;
+            m_own += m;
+            if (!MEAN) ssim_map[oo] = m;
+            if (dm_dmu1) {
+                dm_dmu1[oo] = 2.f * mu2 * (D - Cc) * inv_AB - 2.f * mu1 * m / A + 2.f * mu1 * m / B;
+                dm_dex2[oo] = -m / B;
+                dm_dexy[oo] = 2.f * Cc * inv_AB;
+            }
         }
     }
     if (MEAN) {
@@ -125,45 +169,69 @@ __global__ void __launch_bounds__(256)
 ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
                 const float* __restrict__ dL_dmap, float inv_count, const float* __restrict__ dm_dmu1,
                 const float* __restrict__ dm_dex2, const float* __restrict__ dm_dexy, float* __restrict__ dL_dimg1) {
-    __shared__ float s_in[3][TW][SW];
-    __shared__ float s_h[3][TW][SHW];
+    __shared__ float s_in[3][HY][SW];
+    __shared__ float s_h[3][HY][SHW];
     const int tid = threadIdx.x;
     const int plane = blockIdx.z;
-    const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+    const int x0 = blockIdx.x * TXO, y0 = blockIdx.y * TYO;
     const int64_t pbase = (int64_t)plane * H * W;
-    for (int i = tid; i < TW * TW; i += 256) {
-        const int r = i / TW, c = i - r * TW;
+    const float gmean = MEAN ? dL_dmap[0] * inv_count : 0.f;
+    for (int i = tid; i < HY * HX; i += 256) {
+        const int r = i / HX, c = i - r * HX;
         const int gy = y0 + r - HALO, gx = x0 + c - HALO;
         const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
         const int64_t o = pbase + (int64_t)gy * W + gx;
-        const float g = in ? (MEAN ? dL_dmap[0] * inv_count : dL_dmap[o]) : 0.f;
+        const float g = in ? (MEAN ? gmean : dL_dmap[o]) : 0.f;
         s_in[0][r][c] = in ? g * dm_dmu1[o] : 0.f;
         s_in[1][r][c] = in ? g * dm_dex2[o] : 0.f;
         s_in[2][r][c] = in ? g * dm_dexy[o] : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < TW * TS; i += 256) {
-        const int r = i / TS, c = i - r * TS;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (tid < HTASKS) {
+        const int r = tid >> 3, c0 = (tid & 7) * 8;
+        float acc[8][3];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float w = c_win[k];
-            a0 += w * s_in[0][r][c + k]; a1 += w * s_in[1][r][c + k]; a2 += w * s_in[2][r][c + k];
+        for (int i = 0; i < 8; ++i) { acc[i][0] = 0.f; acc[i][1] = 0.f; acc[i][2] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+            const float a = s_in[0][r][c0 + j], b = s_in[1][r][c0 + j], c = s_in[2][r][c0 + j];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = j - i;
+                if (k >= 0 && k <= 10) {
+                    const float w = GSR_WIN(k);
+                    acc[i][0] = fmaf(w, a, acc[i][0]); acc[i][1] = fmaf(w, b, acc[i][1]); acc[i][2] = fmaf(w, c, acc[i][2]);
+                }
+            }
         }
-        s_h[0][r][c] = a0; s_h[1][r][c] = a1; s_h[2][r][c] = a2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s_h[0][r][c0 + i] = acc[i][0]; s_h[1][r][c0 + i] = acc[i][1]; s_h[2][r][c0 + i] = acc[i][2]; }
     }
     __syncthreads();
-    const int ty = tid / TS, tx = tid - ty * TS;
-    const int gy = y0 + ty, gx = x0 + tx;
-    if (gy < H && gx < W) {
-        float a = 0.f, b = 0.f, c = 0.f;
+    const int cx = tid & 63, rg = tid >> 6;
+    float acc[4][3];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float w = c_win[k];
-            a += w * s_h[0][ty + k][tx]; b += w * s_h[1][ty + k][tx]; c += w * s_h[2][ty + k][tx];
+    for (int o = 0; o < 4; ++o) { acc[o][0] = 0.f; acc[o][1] = 0.f; acc[o][2] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+        const float a = s_h[0][4 * rg + j][cx], b = s_h[1][4 * rg + j][cx], c = s_h[2][4 * rg + j][cx];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int k = j - o;
+            if (k >= 0 && k <= 10) {
+                const float w = GSR_WIN(k);
+                acc[o][0] = fmaf(w, a, acc[o][0]); acc[o][1] = fmaf(w, b, acc[o][1]); acc[o][2] = fmaf(w, c, acc[o][2]);
+            }
         }
-        const int64_t o = pbase + (int64_t)gy * W + gx;
-        dL_dimg1[o] = a + 2.f * img1[o] * b + img2[o] * c;
+    }
+    const int gx = x0 + cx;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const int gy = y0 + 4 * rg + o;
+        if (gy < H && gx < W) {
+            const int64_t oo = pbase + (int64_t)gy * W + gx;
+            dL_dimg1[oo] = acc[o][0] + 2.f * img1[oo] * acc[o][1] + img2[oo] * acc[o][2];
+        }
     }
 }
 
@@ -171,17 +239,17 @@ ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __res
 
 void gsr_launch_ssim_forward(int planes, int H, int W, const float* img1, const float* img2, float* ssim_map, float* dm_dmu1,
                              float* dm_dex2, float* dm_dexy, hipStream_t st) {
-    const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, planes);
+    const dim3 grid((W + TXO - 1) / TXO, (H + TYO - 1) / TYO, planes);
     hipLaunchKernelGGL(ssim_fwd_kernel<false>, grid, dim3(256), 0, st, H, W, img1, img2, ssim_map, dm_dmu1, dm_dex2, dm_dexy);
 }
 
 int64_t gsr_ssim_partial_count_impl(int planes, int H, int W) {
-    return (int64_t)planes * ((W + TS - 1) / TS) * ((H + TS - 1) / TS);
+    return (int64_t)planes * ((W + TXO - 1) / TXO) * ((H + TYO - 1) / TYO);
 }
 
 void gsr_launch_ssim_mean_forward(int planes, int H, int W, const float* img1, const float* img2, float* partials,
                                   float* mean_out, float* dm_dmu1, float* dm_dex2, float* dm_dexy, hipStream_t st) {
-    const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, planes);
+    const dim3 grid((W + TXO - 1) / TXO, (H + TYO - 1) / TYO, planes);
     hipLaunchKernelGGL(ssim_fwd_kernel<true>, grid, dim3(256), 0, st, H, W, img1, img2, partials, dm_dmu1, dm_dex2, dm_dexy);
     const double count = (double)planes * H * W;
     hipLaunchKernelGGL(ssim_mean_kernel, dim3(1), dim3(256), 0, st, partials, (int)gsr_ssim_partial_count_impl(planes, H, W),
@@ -191,7 +259,7 @@ void gsr_launch_ssim_mean_forward(int planes, int H, int W, const float* img1, c
 void gsr_launch_ssim_mean_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dmean,
                                    const float* dm_dmu1, const float* dm_dex2, const float* dm_dexy, float* dL_dimg1,
                                    hipStream_t st) {
-    const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, planes);
+    const dim3 grid((W + TXO - 1) / TXO, (H + TYO - 1) / TYO, planes);
     const double count = (double)planes * H * W;
     hipLaunchKernelGGL(ssim_bwd_kernel<true>, grid, dim3(256), 0, st, H, W, img1, img2, dL_dmean, (float)(1.0 / count), dm_dmu1,
                        dm_dex2, dm_dexy, dL_dimg1);
@@ -199,7 +267,7 @@ void gsr_launch_ssim_mean_backward(int planes, int H, int W, const float* img1, 
 
 void gsr_launch_ssim_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dmap,
                               const float* dm_dmu1, const float* dm_dex2, const float* dm_dexy, float* dL_dimg1, hipStream_t st) {
-    const dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, planes);
+    const dim3 grid((W + TXO - 1) / TXO, (H + TYO - 1) / TYO, planes);
     hipLaunchKernelGGL(ssim_bwd_kernel<false>, grid, dim3(256), 0, st, H, W, img1, img2, dL_dmap, 0.f, dm_dmu1, dm_dex2, dm_dexy,
                        dL_dimg1);
 }
