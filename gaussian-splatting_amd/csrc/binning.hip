@@ -45,17 +45,25 @@ scan_block_sums(int P, const uint32_t* __restrict__ order, const uint2* __restri
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * GSR_SCAN_ITEMS + tid * SC_IPT;
     uint64_t s = 0;
+    // Loads are unconditional (index clamped to the last Gaussian) and all issued before the first use: with the load inside
+    // "if (base + k < P)" the compiler emits load -> s_waitcnt vmcnt(0) per element, SC_IPT serial round trips in a kernel
+    // that is nothing but one round trip.
+    uint2 r[SC_IPT];
+    if (GATHER) {
+        uint32_t id[SC_IPT];
+#pragma unroll
+        for (int k = 0; k < SC_IPT; ++k) id[k] = order[min(base + k, (int64_t)P - 1)];
+#pragma unroll
+        for (int k = 0; k < SC_IPT; ++k) r[k] = rect[id[k]];
+    } else {
+#pragma unroll
+        for (int k = 0; k < SC_IPT; ++k) r[k] = rect_sorted[min(base + k, (int64_t)P - 1)];
+    }
 #pragma unroll
     for (int k = 0; k < SC_IPT; ++k)
         if (base + k < P) {
-            uint2 r;
-            if (GATHER) {
-                r = rect[order[base + k]];
-                rect_sorted[base + k] = r;
-            } else {
-                r = rect_sorted[base + k];
-            }
-            s += rect_tiles(r);
+            if (GATHER) rect_sorted[base + k] = r[k];
+            s += rect_tiles(r[k]);
         }
     s = wave_sum_u64(s);
     if (lane == 0) wsum[w] = s;
@@ -74,16 +82,27 @@ scan_finish(int P, const uint2* __restrict__ rect_sorted, const uint64_t* __rest
     __shared__ uint64_t wsum[SC_THREADS / 64];
     __shared__ uint64_t wtot[SC_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * GSR_SCAN_ITEMS + tid * SC_IPT;
+    // every load of the kernel is issued up front, unconditionally (clamped indices): the block sums of the workgroups
+    // before this one (four per thread cover 1024 workgroups = 1 M Gaussians; beyond that a loop) and the thread's items
+    uint2 rr[SC_IPT + 1];
+#pragma unroll
+    for (int k = 0; k <= SC_IPT; ++k) rr[k] = rect_sorted[min(base + k, (int64_t)P - 1)];
+    uint64_t bs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bs[j] = block_sums[min(tid + j * SC_THREADS, (int)blockIdx.x)];      // (entry blockIdx.x exists)
     uint64_t pre = 0;
-    for (int b = tid; b < (int)blockIdx.x; b += SC_THREADS) pre += block_sums[b];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (tid + j * SC_THREADS < (int)blockIdx.x) pre += bs[j];
+    for (int b = tid + 4 * SC_THREADS; b < (int)blockIdx.x; b += SC_THREADS) pre += block_sums[b];
     pre = wave_sum_u64(pre);
     if (lane == 0) wsum[w] = pre;
-    const int64_t base = (int64_t)blockIdx.x * GSR_SCAN_ITEMS + tid * SC_IPT;
     uint32_t v[SC_IPT + 1];
     uint64_t s = 0;
 #pragma unroll
     for (int k = 0; k <= SC_IPT; ++k) {
-        v[k] = (base + k < P) ? rect_tiles(rect_sorted[base + k]) : 0u;     // v[SC_IPT]: the next thread's first count
+        v[k] = (base + k < P) ? rect_tiles(rr[k]) : 0u;     // v[SC_IPT]: the next thread's first count
         if (k < SC_IPT) s += v[k];
     }
     const uint64_t incl = gsrw::wave_incl_scan_u64(s, lane);

@@ -219,6 +219,29 @@ struct GsrShRowOut {
     float* p;
     GSR_HD void st(int k0, int nf, const float* src) const { gsr_st12(p + k0 * 3, nf, src); }
 };
+#if defined(__HIPCC__)
+// Row known to be 16-byte aligned with all 16 coefficients present (the LDS tile rows of the per-Gaussian kernels): three
+// 16-byte accesses per group, unconditionally.  (gsr_ld12's run-time alignment test made the compiler fall back to 4-byte
+// LDS accesses, which at the tile's 52-float row stride are 4-way bank-conflicted: 52 l mod 32 takes 8 values.)
+struct GsrShRowAligned {
+    const float* p;
+    __device__ __forceinline__ void ld(int k0, int, float* dst) const {
+        const float4* q = reinterpret_cast<const float4*>(p + k0 * 3);
+        const float4 v0 = q[0], v1 = q[1], v2 = q[2];
+        dst[0] = v0.x; dst[1] = v0.y; dst[2] = v0.z; dst[3] = v0.w; dst[4] = v1.x; dst[5] = v1.y; dst[6] = v1.z; dst[7] = v1.w;
+        dst[8] = v2.x; dst[9] = v2.y; dst[10] = v2.z; dst[11] = v2.w;
+    }
+};
+struct GsrShRowAlignedOut {
+    float* p;
+    __device__ __forceinline__ void st(int k0, int, const float* src) const {
+        float4* q = reinterpret_cast<float4*>(p + k0 * 3);
+        q[0] = make_float4(src[0], src[1], src[2], src[3]);
+        q[1] = make_float4(src[4], src[5], src[6], src[7]);
+        q[2] = make_float4(src[8], src[9], src[10], src[11]);
+    }
+};
+#endif
 struct GsrShRowSplit {
     const float* dc;
     const float* rest;

@@ -19,6 +19,8 @@ namespace {
 // experiment (measurement build): ask for 3 waves per SIMD in the two per-Gaussian kernels (costs 25-49 spilled registers)
 #if defined(GSR_AB_VARIANTS) && defined(GSR_PRE_WAVES3)
 #define GSR_PRE_OCC __attribute__((amdgpu_waves_per_eu(3, 3)))
+#elif defined(GSR_AB_VARIANTS) && defined(GSR_PRE_WAVES2)
+#define GSR_PRE_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))
 #else
 #define GSR_PRE_OCC
 #endif
@@ -41,12 +43,24 @@ __device__ __forceinline__ void load_cam(const GsrCamDev& c, GsrCam& cam) {
 __device__ __forceinline__ void wave_load_sh16(const float* __restrict__ shs, int64_t i0, int P, uint64_t rows, int lane,
                                                float* tile) {
     const float4* src = reinterpret_cast<const float4*>(shs + i0 * 48);
+    // all twelve loads are issued before the first LDS write: written as "tile[..] = src[idx]" per iteration the compiler
+    // waited for every load before issuing the next one (twelve serial memory round trips per 64 Gaussians -- the fused
+    // backward ran 141 us against 101 us for the split form, whose loader already had this shape)
+    float4 v[12];
 #pragma unroll
     for (int it = 0; it < 12; ++it) {
         const int idx = it * 64 + lane;          // float4 index inside the 64 x 12 block
+        const int g = idx / 12;
+        v[it] = src[(((rows >> g) & 1ull) && i0 + g < P) ? idx : 0];      // (piece 0 is always valid)
+    }
+    __builtin_amdgcn_sched_barrier(0);      // keep the loads together: the scheduler otherwise sinks each one to its LDS write
+    // ... and unconditional LDS writes (a conditional write makes the compiler sink the load into the branch, which brings
+    // the serial round trips back); rows that were not fetched receive piece 0 and are never read
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        const int idx = it * 64 + lane;
         const int g = idx / 12, part = idx - g * 12;
-        if (((rows >> g) & 1ull) && i0 + g < P)
-            *reinterpret_cast<float4*>(tile + g * SH_ROW + part * 4) = src[idx];
+        *reinterpret_cast<float4*>(tile + g * SH_ROW + part * 4) = v[it];
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -123,40 +137,39 @@ __device__ __forceinline__ void wave_load_sh_split_dense(const float* __restrict
                                                          int P, uint64_t rows, int lane, float* tile) {
     const int nrow = (int)((P - i0) < 64 ? (P - i0) : 64);
     const float* src = rest + i0 * 45;
-    const int nrest = nrow * 45;
-    float4 v[12];
-#pragma unroll
-    for (int it = 0; it < 12; ++it) {
-        const int f = (it * 64 + lane) * 4;
-        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        // (rows != all: screen-sharded ranks fetch only the 16-byte pieces that hold a wanted row)
-        const bool want = rows == ~0ull || ((((rows >> (f / 45)) | (rows >> ((f + 3) / 45 > 63 ? 63 : (f + 3) / 45))) & 1ull) != 0);
-        if (!want) {
-        } else if (f + 3 < nrest) {
-            v[it] = *reinterpret_cast<const float4*>(src + f);
-        } else if (f < nrest) {
-            v[it].x = src[f];
-            if (f + 1 < nrest) v[it].y = src[f + 1];
-            if (f + 2 < nrest) v[it].z = src[f + 2];
-        }
-    }
-    float4 vd = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* sdc = dc + i0 * 3;
-    const int ndc = nrow * 3, fd = lane * 4;
-    if (rows == 0ull) {
-    } else if (fd + 3 < ndc) {
-        vd = *reinterpret_cast<const float4*>(sdc + fd);
-    } else if (fd < ndc) {
-        vd.x = sdc[fd];
-        if (fd + 1 < ndc) vd.y = sdc[fd + 1];
-        if (fd + 2 < ndc) vd.z = sdc[fd + 2];
-    }
+    const int nrest = nrow * 45, ndc = nrow * 3;
+    // Branch-free issue of all thirteen 16-byte loads (a piece that is not wanted, or not completely inside the block, reads
+    // the block's first 16 bytes instead -- always valid, always cached): with a branch per piece the compiler waits for
+    // every load before it issues the next one, twelve serial round trips per 64 Gaussians.
+    // rows != all: screen-sharded ranks fetch only the pieces that hold a wanted row.
+    float4 v[12];
+    bool ok[12];      // (kept for the address select only)
 #pragma unroll
     for (int it = 0; it < 12; ++it) {
         const int f = (it * 64 + lane) * 4;
-        if (f < 64 * 45) *reinterpret_cast<float4*>(tile + f) = v[it];
+        const int g0 = f / 45, g1 = (f + 3) / 45;
+        const bool want = rows == ~0ull || ((((rows >> (g0 & 63)) | (rows >> (g1 & 63))) & 1ull) != 0);
+        ok[it] = want && f + 3 < nrest;
+        v[it] = *reinterpret_cast<const float4*>(src + (ok[it] ? f : 0));
     }
-    if (fd < 64 * 3) *reinterpret_cast<float4*>(tile + SPLIT_DC + fd) = vd;
+    const int fd = lane * 4;
+    const bool okd = rows != 0ull && fd + 3 < ndc;
+    const float4 vd = *reinterpret_cast<const float4*>(sdc + (okd ? fd : 0));
+    __builtin_amdgcn_sched_barrier(0);      // keep the loads together: the scheduler otherwise sinks each one to its LDS write
+    // ... and unconditional LDS writes (a conditional write makes the compiler sink the load into the branch, which brings
+    // the serial round trips back): pieces that were not fetched land in rows nobody reads, or -- past the end of the two
+    // blocks -- in the 256 spare floats at the end of the tile
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        const int f = (it * 64 + lane) * 4;
+        *reinterpret_cast<float4*>(tile + (f < 64 * 45 ? f : 64 * 48 + lane * 4)) = v[it];
+    }
+    *reinterpret_cast<float4*>(tile + (fd < 64 * 3 ? SPLIT_DC + fd : 64 * 48 + lane * 4)) = vd;
+    (void)ok; (void)okd;
+    // ragged ends (only when the block is the last one and its float count is not a multiple of four)
+    if (lane < (nrest & 3)) tile[(nrest & ~3) + lane] = src[(nrest & ~3) + lane];
+    if (lane < (ndc & 3)) tile[SPLIT_DC + (ndc & ~3) + lane] = sdc[(ndc & ~3) + lane];
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ void wave_store_sh_split_dense(float* __restrict__ d_dc, float* __restrict__ d_rest, int64_t i0, int P,
@@ -310,7 +323,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
                 rgb[0] = colors_precomp[i * 3 + 0]; rgb[1] = colors_precomp[i * 3 + 1]; rgb[2] = colors_precomp[i * 3 + 2];
             } else if (staged_sh) {
                 if (SPLIT) gsr_sh_to_rgb_row(cam.sh_degree, 16, GsrShRowSplit{tile + SPLIT_DC + lane * 3, tile + lane * 45}, mean, cam.campos, rgb, clampbits);
-                else gsr_sh_to_rgb(cam.sh_degree, 16, tile + lane * sh_row, mean, cam.campos, rgb, clampbits);
+                else gsr_sh_to_rgb_row(cam.sh_degree, 16, GsrShRowAligned{tile + lane * sh_row}, mean, cam.campos, rgb, clampbits);
             } else if (!SPLIT) {
                 gsr_sh_to_rgb(cam.sh_degree, cam.M, shs + i * (int64_t)cam.M * 3, mean, cam.campos, rgb, clampbits);
             }
@@ -445,7 +458,7 @@ preprocess_color_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D
         float rgb[3] = {0.f, 0.f, 0.f};
         uint32_t clampbits = 0;
         if (staged_sh && SPLIT) gsr_sh_to_rgb_row(deg, 16, GsrShRowSplit{tile + SPLIT_DC + lane * 3, tile + lane * 45}, mean, campos, rgb, clampbits);
-        else if (staged_sh) gsr_sh_to_rgb(deg, 16, tile + lane * SH_ROW, mean, campos, rgb, clampbits);
+        else if (staged_sh) gsr_sh_to_rgb_row(deg, 16, GsrShRowAligned{tile + lane * SH_ROW}, mean, campos, rgb, clampbits);
         else if (!SPLIT) gsr_sh_to_rgb(deg, M, shs + i * (int64_t)M * 3, mean, campos, rgb, clampbits);
         float* rec = reinterpret_cast<float*>(splats + i * 4);
         *reinterpret_cast<float2*>(rec + 6) = make_float2(rgb[0], rgb[1]);      // q1.zw
@@ -543,9 +556,10 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
                         gsr_sh_backward_row(cam.sh_degree, 16, row, mean, cam.campos, clampbits, drgb,
                                             GsrShRowSplitOut{tile + SPLIT_DC + lane * 3, tile + lane * 45}, dmean);
                     } else {
-                        gsr_sh_to_rgb(cam.sh_degree, 16, tile + lane * sh_row, mean, cam.campos, rgb_unused, clampbits);
-                        gsr_sh_backward(cam.sh_degree, 16, tile + lane * sh_row, mean, cam.campos, clampbits, drgb,
-                                        tile + lane * sh_row, dmean);
+                        const GsrShRowAligned row{tile + lane * sh_row};
+                        gsr_sh_to_rgb_row(cam.sh_degree, 16, row, mean, cam.campos, rgb_unused, clampbits);
+                        gsr_sh_backward_row(cam.sh_degree, 16, row, mean, cam.campos, clampbits, drgb,
+                                            GsrShRowAlignedOut{tile + lane * sh_row}, dmean);
                     }
                 } else if (!SPLIT) {
                     gsr_sh_to_rgb(cam.sh_degree, M, shs + i * (int64_t)M * 3, mean, cam.campos, rgb_unused, clampbits);

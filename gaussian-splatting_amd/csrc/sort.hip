@@ -39,10 +39,6 @@ rs_hist(const KeyT* __restrict__ keys, int64_t n, int shift, uint32_t* __restric
     constexpr int NCOPY = (NB <= 256) ? RS_WAVES : 1;     // per-wave copies only when they are cheap
     __shared__ uint32_t h[NCOPY][NB];
     const int tid = threadIdx.x, w = tid >> 6;
-    for (int d = tid; d < NB; d += RS_THREADS)
-#pragma unroll
-        for (int i = 0; i < NCOPY; ++i) h[i][d] = 0;
-    __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * (RS_THREADS * IPT);
     // a histogram does not care about item order: every thread takes its keys in 16-byte (or IPT-key) vectors, so one
     // wave-wide load moves 1 KB instead of the 128 B of a 16-bit scalar load
@@ -77,6 +73,11 @@ rs_hist(const KeyT* __restrict__ keys, int64_t n, int shift, uint32_t* __restric
             }
         }
     }
+    // (the keys are requested before the histogram is cleared: their trip overlaps the clear and its barrier)
+    for (int d = tid; d < NB; d += RS_THREADS)
+#pragma unroll
+        for (int i = 0; i < NCOPY; ++i) h[i][d] = 0;
+    __syncthreads();
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const int64_t e0 = base + ((int64_t)v * RS_THREADS + tid) * VEC;
@@ -198,18 +199,19 @@ rs_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_i
 
     // digit_base[d] = (exclusive scan of digit totals)[d] + (keys with digit d in earlier workgroups)
     {
-        uint32_t v[DPT];
+        uint32_t v[DPT], bh[DPT];
 #pragma unroll
         for (int i = 0; i < DPT; ++i) {
             const int d = tid * DPT + i;
             v[i] = d < NB ? digit_total[d] : 0u;
+            bh[i] = block_hist[(int64_t)(d < NB ? d : 0) * nblocks + blockIdx.x];      // same trip as the totals, not one after the scan
         }
         uint32_t run = block_excl_scan<DPT>(v, wsum, lane, w);
 #pragma unroll
         for (int i = 0; i < DPT; ++i) {
             const int d = tid * DPT + i;
             if (d < NB) {
-                digit_base[d] = run + block_hist[(int64_t)d * nblocks + blockIdx.x];
+                digit_base[d] = run + bh[i];
 #pragma unroll
                 for (int k = 0; k < RS_WAVES; ++k) wave_cnt[k][d] = 0;
             }
@@ -284,16 +286,35 @@ rs_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_i
     __syncthreads();
     const int64_t block_base = (int64_t)blockIdx.x * (RS_THREADS * IPT);
     const uint32_t nvalid = (uint32_t)((n - block_base) < (int64_t)(RS_THREADS * IPT) ? (n - block_base) : (RS_THREADS * IPT));
+    uint32_t ok_[IPT], ov_[IPT], opos_[IPT];
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+        const uint32_t i = (uint32_t)r * RS_THREADS + tid;
+        ok_[r] = (uint32_t)s_key[i];
+        ov_[r] = s_val[i];
+        opos_[r] = digit_base[(ok_[r] >> shift) & (NB - 1)] + i;
+    }
+    if (rect_sorted) {
+        // last pass of the depth sort: the rectangle gather.  All IPT gathers are issued before the first store -- written
+        // as "rect_sorted[pos] = rect[v]" inside the store loop each gather was waited for on its own (IPT serial round trips).
+        uint2 rc[IPT];
+#pragma unroll
+        for (int r = 0; r < IPT; ++r) {
+            const uint32_t i = (uint32_t)r * RS_THREADS + tid;
+            rc[r] = rect[i < nvalid ? ov_[r] : 0u];
+        }
+#pragma unroll
+        for (int r = 0; r < IPT; ++r) {
+            const uint32_t i = (uint32_t)r * RS_THREADS + tid;
+            if (i < nvalid) rect_sorted[opos_[r]] = rc[r];
+        }
+    }
 #pragma unroll
     for (int r = 0; r < IPT; ++r) {
         const uint32_t i = (uint32_t)r * RS_THREADS + tid;
         if (i < nvalid) {
-            const uint32_t k = (uint32_t)s_key[i];
-            const uint32_t pos = digit_base[(k >> shift) & (NB - 1)] + i;
-            keys_out[pos] = (KeyT)k;
-            const uint32_t v = s_val[i];
-            vals_out[pos] = v;
-            if (rect_sorted) rect_sorted[pos] = rect[v];
+            keys_out[opos_[r]] = (KeyT)ok_[r];
+            vals_out[opos_[r]] = ov_[r];
         }
     }
 }

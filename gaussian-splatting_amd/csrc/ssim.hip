@@ -33,6 +33,13 @@ constexpr int HY = TYO + 2 * HALO;     // 26 staged rows
 constexpr int SW = 77;                 // staged halo rows
 constexpr int SHW = 65;                // horizontally filtered rows
 constexpr int HTASKS = HY * (TXO / 8); // 208 horizontal tasks of 8 outputs
+// Halo staging: thread t stages elements t, t + 256, ... of the HY x HX halo.  Written as the obvious loop
+// "s[r][c] = inside ? p[..] : 0" the compiler emits load -> s_waitcnt vmcnt(0) -> LDS write per element: 15 serial memory
+// round trips per workgroup in the forward kernel.  So: NSTAGE unrolled, unconditional loads (address 0 when outside the
+// image) into registers first, then unconditional LDS writes -- the last iteration's surplus threads write into
+// STAGE_PAD spare rows nobody reads (a conditional write makes the compiler sink the load back into the branch).
+constexpr int NSTAGE = (HY * HX + 255) / 256;                       // 8
+constexpr int STAGE_PAD = (NSTAGE * 256 + HX - 1) / HX - HY;        // 2 spare rows
 constexpr float C1 = 0.01f * 0.01f;
 constexpr float C2 = 0.03f * 0.03f;
 
@@ -49,20 +56,34 @@ __global__ void __launch_bounds__(256)
 ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2, float* __restrict__ ssim_map,
                 float* __restrict__ dm_dmu1, float* __restrict__ dm_dex2, float* __restrict__ dm_dexy) {
     __shared__ float s_part[4];
-    __shared__ float s_x[HY][SW];
-    __shared__ float s_y[HY][SW];
+    __shared__ float s_x[HY + STAGE_PAD][SW];
+    __shared__ float s_y[HY + STAGE_PAD][SW];
     __shared__ float s_h[5][HY][SHW];
     const int tid = threadIdx.x;
     const int plane = blockIdx.z;                       // b * C + c
     const int x0 = blockIdx.x * TXO, y0 = blockIdx.y * TYO;
     const float* p1 = img1 + (int64_t)plane * H * W;
     const float* p2 = img2 + (int64_t)plane * H * W;
-    for (int i = tid; i < HY * HX; i += 256) {
-        const int r = i / HX, c = i - r * HX;
-        const int gy = y0 + r - HALO, gx = x0 + c - HALO;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        s_x[r][c] = in ? p1[(int64_t)gy * W + gx] : 0.f;
-        s_y[r][c] = in ? p2[(int64_t)gy * W + gx] : 0.f;
+    {   // halo staging: ALL loads are issued before the first LDS write, branch-free (see NSTAGE)
+        float vx[NSTAGE], vy[NSTAGE];
+#pragma unroll
+        for (int k = 0; k < NSTAGE; ++k) {
+            const int i = tid + k * 256;
+            const int r = i / HX, c = i - r * HX;
+            const int gy = y0 + r - HALO, gx = x0 + c - HALO;
+            const bool in = i < HY * HX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int64_t o = in ? (int64_t)gy * W + gx : 0;
+            const float a = p1[o], b = p2[o];
+            vx[k] = in ? a : 0.f;
+            vy[k] = in ? b : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NSTAGE; ++k) {
+            const int i = tid + k * 256;
+            const int r = i / HX, c = i - r * HX;
+            s_x[r][c] = vx[k];
+            s_y[r][c] = vy[k];
+        }
     }
     __syncthreads();
     if (tid < HTASKS) {                                 // horizontal pass: row r, outputs c0 .. c0+7
@@ -169,22 +190,47 @@ __global__ void __launch_bounds__(256)
 ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
                 const float* __restrict__ dL_dmap, float inv_count, const float* __restrict__ dm_dmu1,
                 const float* __restrict__ dm_dex2, const float* __restrict__ dm_dexy, float* __restrict__ dL_dimg1) {
-    __shared__ float s_in[3][HY][SW];
+    __shared__ float s_in[3][HY + STAGE_PAD][SW];
     __shared__ float s_h[3][HY][SHW];
     const int tid = threadIdx.x;
     const int plane = blockIdx.z;
     const int x0 = blockIdx.x * TXO, y0 = blockIdx.y * TYO;
     const int64_t pbase = (int64_t)plane * H * W;
     const float gmean = MEAN ? dL_dmap[0] * inv_count : 0.f;
-    for (int i = tid; i < HY * HX; i += 256) {
-        const int r = i / HX, c = i - r * HX;
-        const int gy = y0 + r - HALO, gx = x0 + c - HALO;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const int64_t o = pbase + (int64_t)gy * W + gx;
-        const float g = in ? (MEAN ? gmean : dL_dmap[o]) : 0.f;
-        s_in[0][r][c] = in ? g * dm_dmu1[o] : 0.f;
-        s_in[1][r][c] = in ? g * dm_dex2[o] : 0.f;
-        s_in[2][r][c] = in ? g * dm_dexy[o] : 0.f;
+    // the two images are only needed by the last expression: requested first, they arrive during the two passes
+    const int cx = tid & 63, rg = tid >> 6;
+    const int gx_out = x0 + cx;
+    float im1[4], im2[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const int gy = y0 + 4 * rg + o;
+        const int64_t oo = (gy < H && gx_out < W) ? pbase + (int64_t)gy * W + gx_out : pbase;
+        im1[o] = img1[oo];
+        im2[o] = img2[oo];
+    }
+    {   // halo staging, all loads before the first LDS write (see NSTAGE)
+        float v0[NSTAGE], v1[NSTAGE], v2[NSTAGE];
+#pragma unroll
+        for (int k = 0; k < NSTAGE; ++k) {
+            const int i = tid + k * 256;
+            const int r = i / HX, c = i - r * HX;
+            const int gy = y0 + r - HALO, gx = x0 + c - HALO;
+            const bool in = i < HY * HX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int64_t o = in ? pbase + (int64_t)gy * W + gx : pbase;
+            const float g = MEAN ? gmean : dL_dmap[o];
+            const float a = dm_dmu1[o], b = dm_dex2[o], c2 = dm_dexy[o];
+            v0[k] = in ? g * a : 0.f;
+            v1[k] = in ? g * b : 0.f;
+            v2[k] = in ? g * c2 : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NSTAGE; ++k) {
+            const int i = tid + k * 256;
+            const int r = i / HX, c = i - r * HX;
+            s_in[0][r][c] = v0[k];
+            s_in[1][r][c] = v1[k];
+            s_in[2][r][c] = v2[k];
+        }
     }
     __syncthreads();
     if (tid < HTASKS) {
@@ -208,7 +254,6 @@ ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __res
         for (int i = 0; i < 8; ++i) { s_h[0][r][c0 + i] = acc[i][0]; s_h[1][r][c0 + i] = acc[i][1]; s_h[2][r][c0 + i] = acc[i][2]; }
     }
     __syncthreads();
-    const int cx = tid & 63, rg = tid >> 6;
     float acc[4][3];
 #pragma unroll
     for (int o = 0; o < 4; ++o) { acc[o][0] = 0.f; acc[o][1] = 0.f; acc[o][2] = 0.f; }
@@ -224,13 +269,12 @@ ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __res
             }
         }
     }
-    const int gx = x0 + cx;
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         const int gy = y0 + 4 * rg + o;
-        if (gy < H && gx < W) {
-            const int64_t oo = pbase + (int64_t)gy * W + gx;
-            dL_dimg1[oo] = acc[o][0] + 2.f * img1[oo] * acc[o][1] + img2[oo] * acc[o][2];
+        if (gy < H && gx_out < W) {
+            const int64_t oo = pbase + (int64_t)gy * W + gx_out;
+            dL_dimg1[oo] = acc[o][0] + 2.f * im1[o] * acc[o][1] + im2[o] * acc[o][2];
         }
     }
 }

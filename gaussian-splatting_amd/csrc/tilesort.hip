@@ -312,20 +312,27 @@ emit_scatter(uint32_t R, int gx, int lb, int hb, const uint2* __restrict__ block
 }
 
 // level 2: workgroup B2 -> (bucket h, chunk c).  Returns false when B2 is past the last planned workgroup.
+// One memory round trip: thread t < nb1 fetches both table rows of bucket t and the (single) matching thread publishes the
+// bucket, its word range and its first workgroup through LDS (the first version looked the bucket up, then read the two
+// tables again for the match: two dependent trips in front of every level-2 kernel's own loads).
 __device__ __forceinline__ bool bucket_block(int nb1, const uint32_t* __restrict__ bucket_base, const uint32_t* __restrict__ blk2_start,
-                                             int* s_h, uint32_t& h, uint32_t& begin, uint32_t& end) {
+                                             int* s_h /*[4]*/, uint32_t& h, uint32_t& begin, uint32_t& end) {
     const int tid = threadIdx.x;
     const uint32_t B2 = blockIdx.x;
-    if (tid == 0) *s_h = -1;
+    const int t = tid < nb1 ? tid : 0;
+    const uint32_t b0 = blk2_start[t], b1 = blk2_start[t + 1], w0 = bucket_base[t], w1 = bucket_base[t + 1];
+    if (tid == 0) s_h[0] = -1;
     __syncthreads();
-    if (tid < nb1 && blk2_start[tid] <= B2 && B2 < blk2_start[tid + 1]) *s_h = tid;      // at most one bucket matches
+    if (tid < nb1 && b0 <= B2 && B2 < b1) {      // at most one bucket matches
+        s_h[0] = tid; s_h[1] = (int)b0; s_h[2] = (int)w0; s_h[3] = (int)w1;
+    }
     __syncthreads();
-    const int hh = *s_h;
+    const int hh = s_h[0];
     if (hh < 0) return false;
     h = (uint32_t)hh;
-    const uint32_t c = B2 - blk2_start[hh];
-    begin = bucket_base[hh] + c * (uint32_t)TS_ITEMS;
-    const uint32_t bend = bucket_base[hh + 1];
+    const uint32_t c = B2 - (uint32_t)s_h[1];
+    begin = (uint32_t)s_h[2] + c * (uint32_t)TS_ITEMS;
+    const uint32_t bend = (uint32_t)s_h[3];
     end = bend - begin < (uint32_t)TS_ITEMS ? bend : begin + (uint32_t)TS_ITEMS;
     return true;
 }
@@ -335,11 +342,11 @@ __global__ void __launch_bounds__(WG_THREADS)
 bucket_hist(int lb, int hb, const WordT* __restrict__ words, const uint32_t* __restrict__ bucket_base,
             const uint32_t* __restrict__ blk2_start, uint32_t* __restrict__ hist2 /*[blocks][nb2]*/) {
     __shared__ uint32_t hcnt[WG_WAVES][TS_MAXBINS];
-    __shared__ int s_h;
+    __shared__ int s_h[4];
     const int tid = threadIdx.x, w = tid >> 6;
     const int nb1 = 1 << hb, nb2 = 1 << lb;
     uint32_t h, begin, end;
-    if (!bucket_block(nb1, bucket_base, blk2_start, &s_h, h, begin, end)) return;
+    if (!bucket_block(nb1, bucket_base, blk2_start, s_h, h, begin, end)) return;
     if (tid < nb2) {
 #pragma unroll
         for (int k = 0; k < WG_WAVES; ++k) hcnt[k][tid] = 0;
@@ -413,11 +420,11 @@ bucket_scatter(int lb, int hb, const WordT* __restrict__ words, const uint32_t* 
     __shared__ uint32_t wsum[WG_WAVES];
     __shared__ uint32_t s_id[TS_ITEMS];
     __shared__ uint8_t s_dig[TS_ITEMS];
-    __shared__ int s_h;
+    __shared__ int s_h[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nb1 = 1 << hb, nb2 = 1 << lb;
     uint32_t h, begin, end;
-    if (!bucket_block(nb1, bucket_base, blk2_start, &s_h, h, begin, end)) return;
+    if (!bucket_block(nb1, bucket_base, blk2_start, s_h, h, begin, end)) return;
     const uint32_t lomask = (uint32_t)nb2 - 1u;
     uint32_t id[TS_IPT], digit[TS_IPT], vmask = 0;
     const uint32_t wbase = begin + (uint32_t)w * (64u * TS_IPT) + (uint32_t)lane;
