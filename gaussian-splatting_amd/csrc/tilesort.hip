@@ -123,24 +123,42 @@ __device__ __forceinline__ void generate_instances(uint32_t R, int gx, const uin
     __syncthreads();
     const uint32_t s0 = (uint32_t)w * (64u * TS_IPT) + (uint32_t)lane;     // slot of item 0 inside the block
     vmask = 0;
-#pragma unroll
-    for (int r = 0; r < TS_IPT; ++r) {
-        const uint32_t slot = s0 + (uint32_t)r * 64u;
-        const uint32_t k = b0 + slot;
-        if (k < R) vmask |= 1u << r;
-        const uint32_t i = s_own[slot];
-        uint4 g;
-        if (i < (uint32_t)TS_NGCAP) {
-            g = s_g4[i];
-        } else {
-            const uint2 rc = rect_sorted[j_lo + i];
-            g = make_uint4(offsets[j_lo + i - 1], rc.x, rc.y, WANT_ID ? order[j_lo + i] : 0u);
-        }
+    auto finish = [&](int r, uint32_t k, const uint4& g) {
         if (WANT_ID) id[r] = g.w;
         const uint32_t minx = g.y & 0xFFFFu, wd = (g.y >> 16) - minx, miny = g.z & 0xFFFFu;
         uint32_t rx;
         const uint32_t ry = div_small((k < R ? k : R - 1u) - g.x, wd ? wd : 1u, rx);
         tile[r] = (miny + ry) * (uint32_t)gx + minx + rx;
+    };
+    // Two separate loops on a workgroup-uniform condition.  Written as one loop with "i < TS_NGCAP ? LDS record : global
+    // fetch" per item, the compiler merged the two sources into a pointer select and FOUR flat_load_dword per item (the LDS
+    // record read through the flat aperture, ~15 address instructions and a full s_waitcnt per item, 16 items per thread).
+    if (nG <= TS_NGCAP) {
+        uint32_t own[TS_IPT];
+#pragma unroll
+        for (int r = 0; r < TS_IPT; ++r) own[r] = s_own[s0 + (uint32_t)r * 64u];
+#pragma unroll
+        for (int r = 0; r < TS_IPT; ++r) {
+            const uint32_t k = b0 + s0 + (uint32_t)r * 64u;
+            if (k < R) vmask |= 1u << r;
+            finish(r, k, s_g4[own[r]]);
+        }
+    } else {            // (more than 1024 Gaussians in 4096 instances: fewer than four tiles each)
+#pragma unroll 1
+        for (int r = 0; r < TS_IPT; ++r) {
+            const uint32_t slot = s0 + (uint32_t)r * 64u;
+            const uint32_t k = b0 + slot;
+            if (k < R) vmask |= 1u << r;
+            const uint32_t i = s_own[slot];
+            uint4 g;
+            if (i < (uint32_t)TS_NGCAP) {
+                g = s_g4[i];
+            } else {
+                const uint2 rc = rect_sorted[j_lo + i];
+                g = make_uint4(offsets[j_lo + i - 1], rc.x, rc.y, WANT_ID ? order[j_lo + i] : 0u);
+            }
+            finish(r, k, g);
+        }
     }
 }
 

@@ -14,7 +14,10 @@ it from perfectly innocent source:
 The cure used throughout csrc/: unconditional loads from a clamped (always valid) address into registers, THEN unconditional
 LDS writes (surplus lanes write into spare rows).  Round 2 found and removed chains of 12 (SH block of the per-Gaussian
 backward: 141 -> 126 us), 15 (SSIM halo staging), 4-6 (scan kernels) and IPT (rectangle gather of the depth sort's last pass).
-The output lists, per kernel: VGPRs, LDS bytes, spilled VGPRs, number of vector loads, and the lengths of all chains >= 3."""
+The output lists, per kernel: VGPRs, LDS bytes, spilled VGPRs, number of vector loads, flat_* instructions (an LDS access and a
+global access merged into one generic-pointer access: emit_scatter read its LDS records with four flat_load_dword per instance
+until the two sources got separate loops) and the lengths of all chains >= 3.
+Caveat: the scan stops at a kernel's first s_endpgm (early-exit paths come first in some kernels)."""
 from __future__ import annotations
 
 import os
@@ -65,7 +68,10 @@ def audit(path: str, flags, extra):
         st = "".join(seq)
         chains = [len(c) // 2 for c in re.findall(r"(?:L0){3,}", st)]
         v, lds, sp = meta.get(m.group(1), (-1, -1, -1))
-        rows.append((demangle_short(m.group(1)), v, lds, sp, st.count("L"), chains))
+        # flat_* = the compiler lost the address space (e.g. it merged an LDS read and a global read into one pointer
+        # select): such a load goes down both memory paths and waits on both counters
+        nflat = len(re.findall(r"^\s+flat_(?:load|store|atomic)", m.group(2), re.M))
+        rows.append((demangle_short(m.group(1)), v, lds, sp, st.count("L"), chains, nflat))
     return rows
 
 
@@ -78,10 +84,11 @@ def main():
     for f in files:
         base = os.path.basename(f)
         print(f"== {base}")
-        for name, v, lds, sp, nl, chains in audit(os.path.join(CSRC, base), UNITS.get(base, []), extra):
+        for name, v, lds, sp, nl, chains, nflat in audit(os.path.join(CSRC, base), UNITS.get(base, []), extra):
             flag = "   <-- serial load chain" if chains else ""
             spill = f" SPILLS {sp}" if sp > 0 else ""
-            print(f"  {name:46s} vgpr {v:3d}  lds {lds:6d}{spill}  loads {nl:3d}  chains {chains}{flag}")
+            flat = f"  FLAT {nflat}" if nflat else ""
+            print(f"  {name:46s} vgpr {v:3d}  lds {lds:6d}{spill}  loads {nl:3d}{flat}  chains {chains}{flag}")
             bad += len(chains)
     print(f"{bad} serial load chain(s) of length >= 3")
 
