@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "gaussian-splatting_amd", "csrc")
 UNITS = {"preprocess.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"], "sort.hip": [], "binning.hip": [],
          "tilesort.hip": [], "render_fwd.hip": ["-ffp-contract=fast"], "render_bwd.hip": ["-ffp-contract=fast"],
-         "adam.hip": ["-ffp-contract=off"], "ssim.hip": ["-ffp-contract=fast"], "knn.hip": ["-ffp-contract=off"]}
+         "adam.hip": ["-ffp-contract=off"], "ssim.hip": ["-ffp-contract=fast", "-fno-slp-vectorize"], "knn.hip": ["-ffp-contract=off"]}
 
 
 def demangle_short(name: str) -> str:
