@@ -16,8 +16,7 @@ LDS writes (surplus lanes write into spare rows).  Round 2 found and removed cha
 backward: 141 -> 126 us), 15 (SSIM halo staging), 4-6 (scan kernels) and IPT (rectangle gather of the depth sort's last pass).
 The output lists, per kernel: VGPRs, LDS bytes, spilled VGPRs, number of vector loads, flat_* instructions (an LDS access and a
 global access merged into one generic-pointer access: emit_scatter read its LDS records with four flat_load_dword per instance
-until the two sources got separate loops) and the lengths of all chains >= 3.
-Caveat: the scan stops at a kernel's first s_endpgm (early-exit paths come first in some kernels)."""
+until the two sources got separate loops) and the lengths of all chains >= 3."""
 from __future__ import annotations
 
 import os
@@ -53,7 +52,7 @@ def audit(path: str, flags, extra):
     for m in re.finditer(r"\.group_segment_fixed_size:\s*(\d+).*?\.name:\s*(\S+).*?\.vgpr_count:\s*(\d+)\s*\n\s*\.vgpr_spill_count:\s*(\d+)", s, re.S):
         meta[m.group(2)] = (int(m.group(3)), int(m.group(1)), int(m.group(4)))
     rows = []
-    for m in re.finditer(r"^(_Z\w+): ; @.*?\n(.*?)s_endpgm", s, re.S | re.M):
+    for m in re.finditer(r"^(_Z\w+): ; @.*?\n(.*?)^\.Lfunc_end", s, re.S | re.M):
         seq = []
         for line in m.group(2).split("\n"):
             t = line.strip().split()
