@@ -395,6 +395,13 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
         gsr_launch_scan_tiles(P, g.vals[order_buf], g.rect, g.rect_sorted, g.offsets, g.block_sums, g.block_first, bf_cap,
                               g.num_rendered, hw_slot.dev, seq, /*rect_already_sorted=*/true, sort_err, st);
     }
+    // (profiling only) the GPU-idle bubble of the R read-back: from the end of the scan to the first launch after the wait
+    hipEvent_t wait_a = nullptr, wait_b = nullptr;
+    if (g_prof_on) {
+        std::lock_guard<std::mutex> l(g_prof_mu);
+        wait_a = get_event(); wait_b = get_event();
+        (void)hipEventRecord(wait_a, st);
+    }
     const int n_tiles = cam.gx * cam.gy;
     GsrTileSortPlan plan;
     gsr_tile_sort_plan(n_tiles, P, &plan);
@@ -440,6 +447,11 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     if (!bbase || !ibase) return fail(GSR_ERR_ALLOC, "binning / image buffer resize returned NULL");
     GsrBinning b = gsr_carve_binning(bbase, R);
     GsrImage im = gsr_carve_image(ibase, cam.W, cam.H);
+    if (wait_a) {
+        (void)hipEventRecord(wait_b, st);
+        std::lock_guard<std::mutex> l(g_prof_mu);
+        g_pending.push_back({GSR_STAGE_R_WAIT, wait_a, wait_b});
+    }
     float4* goffset_splats = settings->no_backward ? nullptr : g.splats;
 
     int list_buf = 0;

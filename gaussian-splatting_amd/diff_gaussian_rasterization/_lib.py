@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgsr_hip.so")
 GSR_OK = 0
 ABI_VERSION = 2
 STAGES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "render", "render_bwd", "preprocess_bwd",
-          "gather_bwd", "color"]
+          "gather_bwd", "color", "r_wait"]
 
 
 class GsrRasterSettings(C.Structure):

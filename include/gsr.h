@@ -274,7 +274,8 @@ enum {
     GSR_STAGE_PREPROCESS_BWD = 8,
     GSR_STAGE_GATHER_BWD = 9,
     GSR_STAGE_COLOR = 10,            /* SH -> RGB kernel of the split preprocess (option color_overlap) */
-    GSR_STAGE_COUNT = 11
+    GSR_STAGE_R_WAIT = 11,           /* GPU idle between the scan (which publishes R) and the first kernel the host launches after reading R */
+    GSR_STAGE_COUNT = 12
 };
 int gsr_profile_enable(int on);      /* bit 0: per-stage events; bit 1: work counters (slow the blend kernels: count in a separate pass) */
 int gsr_profile_reset(void);
