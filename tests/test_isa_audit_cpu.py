@@ -1,0 +1,35 @@
+"""Static properties of the compiled gfx950 code (hipcc cross-compiles here, no GPU): the hot kernels contain no SERIAL
+LOAD CHAIN (load -> s_waitcnt vmcnt(0) per element), no register spills and no flat_* access outside the one
+documented slow path.  These regress silently -- a one-line source change can bring a 12-trip chain back without failing any
+numerical test -- so the property is pinned here."""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+
+# legacy instantiations (16-bit-key LSD passes, > 65536-tile frames only) are not audited
+LEGACY = ("ItLi",)
+
+
+@pytest.mark.parametrize("unit", ["sort.hip", "binning.hip", "tilesort.hip", "render_fwd.hip", "render_bwd.hip", "ssim.hip", "adam.hip",
+                                  "preprocess.hip"])
+def test_no_serial_load_chains_spills_or_stray_flat_accesses(unit):
+    import isa_audit
+    rows = isa_audit.audit(os.path.join(isa_audit.CSRC, unit), isa_audit.UNITS[unit], [])
+    assert rows, "no kernels found in " + unit
+    for name, vgpr, lds, spills, nloads, chains, nflat in rows:
+        if any(t in name for t in LEGACY):
+            continue
+        assert not chains, f"{unit}:{name}: serial load chain(s) {chains} (see tools/isa_audit.py)"
+        assert spills == 0, f"{unit}:{name}: {spills} spilled VGPRs"
+        assert lds <= 160 * 1024 and 0 < vgpr <= 256, (name, vgpr, lds)
+        if name.startswith("emit_scatter"):
+            assert nflat <= 4, f"{name}: {nflat} flat accesses (only the > 1024-Gaussians-per-block fallback loop may have any)"
+        else:
+            assert nflat == 0, f"{unit}:{name}: {nflat} flat_* instructions: an address space was lost"
