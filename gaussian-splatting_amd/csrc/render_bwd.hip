@@ -56,6 +56,18 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
+// one step of a segmented inclusive scan over the wave: lanes whose DPP source lane carries the same segment id add its values
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void seg_scan_step(int seg, float (&v)[10]) {
+    const int src_seg = __builtin_amdgcn_update_dpp(-1, seg, CTRL, ROW_MASK, 0xf, false);
+    const bool take = src_seg == seg;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const float t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), CTRL, ROW_MASK, 0xf, false));
+        if (take) v[i] += t;
+    }
+}
+
 // [a.lo+a.hi | b.lo+b.hi] : lanes 0-31 hold 32 partial sums of a, lanes 32-63 of b
 __device__ __forceinline__ float fold32(float a, float b) {
     const uint2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
@@ -708,16 +720,16 @@ bwd_reduce_instances(int P, int64_t R, const uint32_t* __restrict__ order, const
             if (vv > r) hi = mid; else lo = mid + 1;
         }
         const int s = valid ? (lo > last ? last : lo) : 64 + lane;     // invalid lanes never merge
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int s_up = __shfl_up(s, off, 64);
-            const bool take = (lane >= off) && (s_up == s);
-#pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                const float t = __shfl_up(v[i], off, 64);
-                if (take) v[i] += t;
-            }
-        }
+        // segmented inclusive scan (segments = Gaussians, ids ascending) with DPP moves instead of __shfl_up: four
+        // Hillis-Steele steps inside the 16-lane rows, then the rows are chained with row_bcast:15 / row_bcast:31.  A lane
+        // without a source (row start, masked row) receives the sentinel -1 as segment id and takes nothing.  66 VALU
+        // moves replace 66 ds_bpermute round trips per chunk.
+        seg_scan_step<0x111, 0xf>(s, v);      // row_shr:1
+        seg_scan_step<0x112, 0xf>(s, v);      // row_shr:2
+        seg_scan_step<0x114, 0xf>(s, v);      // row_shr:4
+        seg_scan_step<0x118, 0xf>(s, v);      // row_shr:8
+        seg_scan_step<0x142, 0xa>(s, v);      // row_bcast:15 -> rows 1, 3
+        seg_scan_step<0x143, 0xc>(s, v);      // row_bcast:31 -> rows 2, 3
         const int s_next = __shfl_down(s, 1, 64);
         const bool tail = valid && (lane == 63 || s_next != s);
         if (tail) {
