@@ -9,27 +9,16 @@ namespace {
 constexpr int SC_THREADS = 256;
 constexpr int SC_IPT = GSR_SCAN_ITEMS / SC_THREADS;   // 4 consecutive items per thread
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(v, off, 64);
-        if (lane >= off) v += t;
-    }
-    return v;
-}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) { return gsrw::wave_incl_scan_u32(v, lane); }
 
 __device__ __forceinline__ uint32_t rect_tiles(const uint2 r) {
     return ((r.x >> 16) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.y & 0xFFFFu));      // <= 2^24 (make_cam limits the grid)
 }
 
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, off, 64);
-        const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), off, 64);
-        v += ((uint64_t)hi << 32) | lo;
-    }
-    return v;
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {      // total in every lane: DPP scan, then lane 63's value
+    const uint64_t t = gsrw::wave_incl_scan_u64(v, 0);
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(t >> 32), 63) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)t, 63);
 }
 
 // pass 1: per-workgroup totals of the tile counts in depth order.  The count of a Gaussian is the area of its

@@ -8,22 +8,34 @@ namespace gsrw {
 constexpr int WG_THREADS = 256;
 constexpr int WG_WAVES = WG_THREADS / 64;
 
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)v, off, 64);
-        if (lane >= off) v += t;
-    }
+// Wave-wide inclusive scans with DPP moves (gfx9 family: row_shr inside the 16-lane rows, row_bcast:15 / row_bcast:31
+// across them) instead of __shfl_up: a __shfl_up is a ds_bpermute_b32 -- an LDS-crossbar round trip of ~100 cycles that
+// the next step depends on, six in a row per scan -- while the DPP forms are plain VALU operand modifiers (the compiler
+// fuses most steps into v_add_u32_dpp).  Lanes without a source (row start, masked row) read 0.  All lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_src_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+#define GSR_DPP_SCAN_STEPS(STEP) STEP(0x111, 0xf) STEP(0x112, 0xf) STEP(0x114, 0xf) STEP(0x118, 0xf) STEP(0x142, 0xa) STEP(0x143, 0xc)
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int /*lane*/) {
+#define GSR_STEP(C, M) v += dpp_src_u32<C, M>(v);
+    GSR_DPP_SCAN_STEPS(GSR_STEP)
+#undef GSR_STEP
     return v;
 }
 
-__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, off, 64);
-        const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), off, 64);
-        if (lane >= off) v += ((uint64_t)hi << 32) | lo;
-    }
+__device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t v) {
+#define GSR_STEP(C, M) v = max(v, dpp_src_u32<C, M>(v));
+    GSR_DPP_SCAN_STEPS(GSR_STEP)
+#undef GSR_STEP
+    return v;
+}
+
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int /*lane*/) {
+#define GSR_STEP(C, M) v += ((uint64_t)dpp_src_u32<C, M>((uint32_t)(v >> 32)) << 32) | dpp_src_u32<C, M>((uint32_t)v);
+    GSR_DPP_SCAN_STEPS(GSR_STEP)
+#undef GSR_STEP
     return v;
 }
 

@@ -23,12 +23,18 @@ namespace {
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / 64;
 
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(v, off, 64);
-        if (lane >= off) v += t;
-    }
+// DPP scan (see gsr_wave.h): row_shr 1/2/4/8 inside the 16-lane rows, row_bcast:15 / :31 across them; no ds_bpermute
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_src_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int /*lane*/) {
+    v += dpp_src_u32<0x111, 0xf>(v);
+    v += dpp_src_u32<0x112, 0xf>(v);
+    v += dpp_src_u32<0x114, 0xf>(v);
+    v += dpp_src_u32<0x118, 0xf>(v);
+    v += dpp_src_u32<0x142, 0xa>(v);
+    v += dpp_src_u32<0x143, 0xc>(v);
     return v;
 }
 

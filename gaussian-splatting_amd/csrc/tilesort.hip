@@ -101,15 +101,9 @@ __device__ __forceinline__ void generate_instances(uint32_t R, int gx, const uin
             run = max(run, a[k] & 0xFFFFu); m[2 * k] = run;
             run = max(run, a[k] >> 16); m[2 * k + 1] = run;
         }
-        uint32_t incl = run;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64);
-            if (lane >= off) incl = max(incl, t);
-        }
+        const uint32_t incl = wave_incl_max_u32(run);
         if (lane == 63) wsum[w] = incl;
-        uint32_t pre = (uint32_t)__shfl_up((int)incl, 1, 64);
-        if (lane == 0) pre = 0;
+        uint32_t pre = dpp_src_u32<0x138, 0xf>(incl);      // wave_shr:1 -- the previous lane's inclusive maximum, 0 for lane 0
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < WG_WAVES; ++k)
