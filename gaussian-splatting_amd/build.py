@@ -34,8 +34,9 @@ UNITS = [
     ("sort.hip", []),
     ("binning.hip", []),
     ("tilesort.hip", []),
-    ("render_fwd.hip", ["-ffp-contract=fast"]),
-    ("render_bwd.hip", ["-ffp-contract=fast"]),
+    # -fno-slp-vectorize: automatic v_pk_*_f32 packing costs more issue slots than it saves on gfx950 (forward blend -3 %)
+    ("render_fwd.hip", ["-ffp-contract=fast", "-fno-slp-vectorize"]),
+    ("render_bwd.hip", ["-ffp-contract=fast", "-fno-slp-vectorize"]),
     ("adam.hip", ["-ffp-contract=off"]),
     # no SLP vectorisation: the auto-packed v_pk_fma_f32 and the v_mov shuffles that assemble their operand pairs cost more
     # issue slots than the scalar FMAs they replace (forward 60.2 -> 55.3 us on one box); the per-Gaussian kernels were

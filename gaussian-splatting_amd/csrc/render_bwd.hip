@@ -137,7 +137,16 @@ struct BwdPix {
 // not the derivatives themselves: the derivatives are linear in the moments with per-Gaussian coefficients
 //     dL/dpx = -A mx - B my,  dL/dpy = -C my - B mx,  dL/dA = -mxx/2,  dL/dB = -mxy,  dL/dC = -myy/2
 // so that multiplication is done ONCE per Gaussian after all sums (bwd_reduce_instances) instead of per pair.
-typedef float v2f __attribute__((ext_vector_type(2)));      // pairs that the compiler turns into v_pk_*_f32
+// Pairs of per-pixel values (the two pixels of a lane).  Plain scalars on purpose: written on ext_vector_type(2) floats the
+// compiler emits v_pk_{mul,add,fma}_f32, and on this part a packed op costs MORE than the two scalar ops it replaces
+// (measured on one box, whole kernel: 0.4476 ms packed, 0.4428 ms scalar; the forward blend likewise 0.1481 -> 0.1435 ms
+// once the SLP vectoriser's automatic packing was switched off) -- this file and render_fwd.hip are built -fno-slp-vectorize.
+struct v2f { float x, y; };
+__device__ __forceinline__ v2f operator+(v2f a, v2f b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ v2f operator-(v2f a, v2f b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ v2f operator*(v2f a, v2f b) { return {a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ v2f operator*(float a, v2f b) { return {a * b.x, a * b.y}; }
+__device__ __forceinline__ v2f operator-(v2f a) { return {-a.x, -a.y}; }
 
 __device__ __forceinline__ bool bwd_step(BwdPix& s, bool take, float pxf, float pyf, float Tf_bg, float dLr, float dLg,
                                          float dLb, float dLd, float gx_, float gy_, float a2, float b2, float c2, float op,
@@ -199,8 +208,8 @@ constexpr int REC_STRIDE = 3;      // float4 per staged entry (48 B: 12-word str
 // ------------------------------------------------------------------------------------------------
 // default: one wave per 16x8 HALF tile, two pixels per lane (same row, 8 columns apart), no atomics, no barriers.
 // The blend backward is VALU-issue bound (SQ counters), so the lever is instructions per (pixel, entry) pair:
-//  * the two pixels of a lane share dy, c2 dy^2 and every wave-uniform operand, and their per-pixel arithmetic is written
-//    on 2-vectors that compile to v_pk_{mul,add,fma}_f32 (one instruction for both pixels);
+//  * the two pixels of a lane share dy, c2 dy^2, every wave-uniform operand, the LDS record reads and the loop's scalar work
+//    (their per-pixel arithmetic is written on pairs, v2f -- scalar pairs: packed v_pk_*_f32 forms measured slower);
 //  * their ten gradient terms are added per lane BEFORE the cross-lane transpose-reduce, so the ~27-instruction reduction is
 //    paid once per (half tile, entry) instead of once per (quadrant, entry);
 //  * an instance gets at most two records (one per half) instead of four, which halves the reduce kernel's stream.
