@@ -167,10 +167,16 @@ thread_local AuxStream g_aux[GSR_MAX_DEVICES];
 #define GSR_CPU_RELAX() do { } while (0)
 #endif
 
-int64_t g_small_block_threshold = (int64_t)2 * 1024 * 1024;   // below this a radix pass uses 1024-item workgroups
-int g_sort_items_large = GSR_SORT_ITEMS;                      // keys per workgroup above the threshold (1024 / 2048 / 4096)
-bool use_small_blocks(int64_t n) { return n < g_small_block_threshold; }
-int sort_items(int64_t n) { return use_small_blocks(n) ? GSR_SORT_ITEMS_SMALL : g_sort_items_large; }
+// keys per workgroup of a radix pass: 1024 below 512 K keys, 2048 below 3 M, 4096 above.  Measured on the depth sort of
+// 1 M keys with the round-2 kernels (one box, interleaved): 1024 -> 0.0892 ms, 2048 -> 0.0855 ms, 4096 -> 0.0919 ms.
+int64_t g_small_block_threshold = (int64_t)512 * 1024;
+int64_t g_mid_block_threshold = (int64_t)3 * 1024 * 1024;
+int g_sort_items_large = GSR_SORT_ITEMS;                      // keys per workgroup above the thresholds (1024 / 2048 / 4096 / 8192)
+int sort_items(int64_t n) {
+    if (n < g_small_block_threshold) return GSR_SORT_ITEMS_SMALL;
+    if (n < g_mid_block_threshold) return 2048 < g_sort_items_large ? 2048 : g_sort_items_large;
+    return g_sort_items_large;
+}
 
 }  // namespace
 
@@ -273,6 +279,7 @@ int gsr_set_option(const char* name, int value) {
         return GSR_OK;
     }
     if (!strcmp(name, "sort_small_block_threshold")) { g_small_block_threshold = value; return GSR_OK; }
+    if (!strcmp(name, "sort_mid_block_threshold")) { g_mid_block_threshold = value; return GSR_OK; }
     if (!strcmp(name, "sort_items_large")) {
         if (value != 1024 && value != 2048 && value != 4096 && value != 8192)
             return fail(GSR_ERR_INVALID_ARG, "sort_items_large must be 1024, 2048, 4096 or 8192");

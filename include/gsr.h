@@ -288,7 +288,7 @@ int gsr_profile_read(float* ms_out, int32_t* count_out, int n);
 int gsr_profile_counters(uint64_t* out, int n, int reset);
 
 /* A/B switches for measurement (0 = the product default everywhere).  The product library accepts the tuning knobs
- * sort_small_block_threshold, sort_items_large and tile_sort_mode (0 fused two-level sort, 1 legacy LSD passes) and value 0
+ * sort_small_block_threshold, sort_mid_block_threshold, sort_items_large and tile_sort_mode (0 fused two-level sort, 1 legacy LSD passes) and value 0
  * of everything else; the measurement build (GSR_AB=1 python build.py -> lib_ab/) also compiles:
  *   render_fwd_variant 1..3, render_bwd_variant 1 / 4 / 5, depth_sort_mode 1 (onesweep), color_overlap 1 / 2 (split
  *   preprocess, colour kernel beside the depth sort), first_hist_in_preprocess 1, sh_dma 1..3 (LDS-DMA staging of the SH
