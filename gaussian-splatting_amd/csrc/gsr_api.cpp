@@ -292,6 +292,7 @@ int gsr_set_option(const char* name, int value) {
         g_depth_sort_mode = value;
         return GSR_OK;
     }
+    if (!strcmp(name, "preprocess_grid_cap")) { gsr_set_preprocess_grid_cap(value); return GSR_OK; }
     if (!strcmp(name, "sh_dma")) {
         if (value < 0 || value > 3) return fail(GSR_ERR_INVALID_ARG, "sh_dma must be 0..3 (bit 0: forward, bit 1: backward per-Gaussian kernel)");
         if (!gsr_set_sh_dma(value) && value) return fail(GSR_ERR_UNSUPPORTED, "sh_dma needs a -DGSR_AB_VARIANTS build");

@@ -96,6 +96,7 @@ void gsr_launch_preprocess_backward(const GsrCamDev& cam, int P, const float* me
                                     GsrGeom g, const float* splat_grads /*[P,12]*/, float* dL_dmeans2D,
                                     float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D,
                                     float* dL_dsh, float* dL_dscales, float* dL_drotations, hipStream_t st);
+void gsr_set_preprocess_grid_cap(int cap);      // tuning knob (option preprocess_grid_cap)
 int gsr_set_sh_dma(int mask);     // A/B builds: LDS-DMA staging of the SH block (option sh_dma: bit 0 forward, bit 1 backward); 0 = not in this build
 void gsr_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st);
 

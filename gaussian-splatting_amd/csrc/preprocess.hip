@@ -628,9 +628,11 @@ int g_sh_dma = 0;
 constexpr int g_sh_dma = 0;
 #endif
 
+int g_stream_grid_cap = 2048;      // option preprocess_grid_cap (tuning): workgroups of the grid-stride per-Gaussian kernels
+
 inline int stream_grid(int64_t n) {
     int64_t b = (n + 255) / 256;
-    if (b > 2048) b = 2048;
+    if (b > g_stream_grid_cap) b = g_stream_grid_cap;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -716,3 +718,5 @@ int gsr_set_sh_dma(int mask) { g_sh_dma = mask & 3; return 1; }
 #else
 int gsr_set_sh_dma(int) { return 0; }
 #endif
+
+void gsr_set_preprocess_grid_cap(int cap) { g_stream_grid_cap = cap < 64 ? 64 : cap; }
