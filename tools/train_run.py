@@ -86,8 +86,13 @@ def main():
         cams.append(look_at_camera(W, H, (r * math.cos(ang), r * math.sin(ang), -0.2 * ((k % 3) - 1)), (0.0, 0.0, 7.0)))
     bg = torch.zeros(3, device=dev)
 
+    # the reference's Camera objects keep their matrices on the device (scene/cameras.py): upload once, not per iteration
+    _dev_cams = {}
+
     def settings(cam, deg):
-        c = cam.to(dev)
+        c = _dev_cams.get(id(cam))
+        if c is None:
+            c = _dev_cams[id(cam)] = cam.to(dev)
         return GaussianRasterizationSettings(H, W, cam.tanfovx, cam.tanfovy, bg, 1.0, c.world_view_transform, c.full_proj_transform,
                                              deg, c.camera_center, False, False, False)
 
