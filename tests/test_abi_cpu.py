@@ -77,6 +77,17 @@ def test_argument_validation_without_gpu(lib):
     assert rc == -1 and b"coefficients" in lib.gsr_last_error()
     assert lib.gsr_set_option(b"no_such_option", 1) == -1
     assert lib.gsr_set_option(b"render_fwd_variant", 0) == 0
+    # the product library holds the default kernels only: every A/B switch accepts 0 and rejects the measured-and-rejected
+    # variants (they exist in the GSR_AB=1 build); the tuning knobs are accepted
+    for name in (b"render_fwd_variant", b"render_bwd_variant", b"depth_sort_mode", b"color_overlap", b"first_hist_in_preprocess",
+                 b"sh_dma"):
+        assert lib.gsr_set_option(name, 0) == 0, name
+        assert lib.gsr_set_option(name, 1) != 0, name
+        assert b"GSR_AB_VARIANTS" in lib.gsr_last_error(), (name, lib.gsr_last_error())
+    for name, value in ((b"sort_small_block_threshold", 512 * 1024), (b"sort_mid_block_threshold", 3 * 1024 * 1024),
+                        (b"sort_items_large", 4096), (b"tile_sort_mode", 0), (b"preprocess_grid_cap", 2048)):
+        assert lib.gsr_set_option(name, value) == 0, name
+    assert lib.gsr_set_option(b"sort_items_large", 1000) == -1
 
 
 def test_package_surface_matches_reference_call_site():
