@@ -69,3 +69,58 @@ def test_bins_bit_exact_in_every_structural_regime(name):
         assert torch.equal(out["point_list"].cpu().to(torch.int64), bins["point_list"]), "sorted point list differs"
         assert torch.equal(out["ranges"].cpu().to(torch.int64), bins["ranges"]), "tile ranges differ"
         del out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The backward in the two extreme segment regimes of its gradient reduce (bwd_reduce_instances: a segmented scan over the
+# instances of every Gaussian): one or two instances per Gaussian -- most segments are single lanes, several Gaussians of a
+# group have none -- and hundreds of instances per Gaussian -- segments span many 64-instance chunks and all four waves.
+# Oracle: autograd through O.rasterize (train.py:142 boundary).  Bars as in test_gpu_parity.py.
+# ------------------------------------------------------------------------------------------------------------------
+BWD_CASES = {
+    # name: (P, W, H, s_med, seed)
+    "segments_of_one": (6_000, 320, 192, 0.002, 11),
+    "segments_of_hundreds": (60, 320, 192, 0.6, 12),
+}
+
+
+@pytest.mark.parametrize("name", list(BWD_CASES))
+def test_backward_in_extreme_segment_regimes(name):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    P, W, H, s_med, seed = BWD_CASES[name]
+    dev = torch.device("cuda:0")
+    cam = make_camera(W, H)
+    sc = make_scene(P, cam, seed=seed, s_med=s_med)
+    s = oracle_settings(cam, bg=torch.tensor([0.2, 0.1, 0.3]))
+    g = torch.Generator().manual_seed(seed)
+    wc, wd = torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g) * 0.3
+
+    def leaves(device):
+        L = {k: getattr(sc, k).detach().clone().to(device).requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+        L["means2D"] = torch.zeros(P, 3, device=device, requires_grad=True)
+        return L
+
+    Lc = leaves("cpu")
+    col, radii, invd = O.rasterize(Lc["means3D"], Lc["means2D"], Lc["opacities"], s, shs=Lc["shs"], scales=Lc["scales"],
+                                   rotations=Lc["rotations"])
+    ((col * wc).sum() + (invd * wd).sum()).backward()
+    R = int(O.bin_and_sort(O.preprocess(sc.means3D, sc.opacities, s, shs=sc.shs, scales=sc.scales, rotations=sc.rotations))["R"])
+    V = int((radii > 0).sum())
+    if name == "segments_of_one":
+        assert R / V < 2.5, (R, V)
+    else:
+        assert R / V > 100.0, (R, V)
+    Lg = leaves(dev)
+    rs = GaussianRasterizationSettings(H, W, s.tanfovx, s.tanfovy, s.bg.to(dev), s.scale_modifier, s.viewmatrix.to(dev),
+                                       s.projmatrix.to(dev), s.sh_degree, s.campos.to(dev), False, False, s.antialiasing)
+    gcol, gradii, ginvd = GaussianRasterizer(rs)(means3D=Lg["means3D"], means2D=Lg["means2D"], opacities=Lg["opacities"],
+                                                 shs=Lg["shs"], scales=Lg["scales"], rotations=Lg["rotations"])
+    ((gcol * wc.to(dev)).sum() + (ginvd * wd.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(gradii.cpu(), radii)
+    for k in Lc:
+        a, b = Lg[k].grad.cpu().double(), Lc[k].grad.double()
+        assert b.abs().max().item() > 0, f"{k}: oracle gradient is identically zero"
+        d = (a - b).abs() / (b.abs().max().item() + 1e-30)
+        assert d.max().item() < 1e-4, f"{name}/{k}: max err {d.max().item():.3e} (rel. to max |grad|)"
+        assert torch.quantile(d.flatten()[: 4_000_000], 0.999).item() < 1e-5, f"{name}/{k}: 99.9th percentile too large"
