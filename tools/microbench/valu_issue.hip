@@ -1,0 +1,243 @@
+// Micro-benchmark (measurement tool, not product): how fast can ONE SIMD of a gfx950 CU issue wave64 VALU instructions?
+// DESIGN.md quoted a "VALU issue ceiling" without evidence.  This program measures it:
+//   * streams of independent / dependent v_fma_f32, v_mul+v_add, v_cmp+v_cndmask pairs, v_exp_f32, v_rcp_f32, v_pk_fma_f32,
+//     DPP adds, v_permlane32_swap, and VALU interleaved with SALU, written as inline asm so the instruction mix is exact;
+//   * the forward blend's per-entry body (render_fwd.hip: blend_step_bf<false>) as compiled C++, record read with a
+//     wave-uniform ds_read_b128 exactly like the product kernel (BODY_LDS) or held in SGPRs (BODY_SGPR);
+//   * at 1..8 resident waves per SIMD (occupancy pinned with dynamic LDS: W workgroups of 4 waves per CU, 256 x W workgroups).
+// Per wave: cycles = s_memtime delta (shader clock), ns = s_memrealtime delta (100 MHz) -> sustained clock.
+// Reported: cycles per VALU instruction PER SIMD = mean wave cycles / (W x instructions per wave).  The datasheet rate is 2.0
+// (64 lanes over a SIMD-32: 157.3 TFLOP/s = 256 CU x 4 SIMD x 32 lanes x 2 FLOP x 2.4 GHz).
+//   hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o valu_issue valu_issue.hip && ./valu_issue   (-fno-slp-vectorize as render_fwd.hip is built)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+enum Kind { FMA_IND = 0, FMA_DEP, MULADD_IND, CMP_CNDMASK, EXP_IND, RCP_IND, PK_FMA_IND, DPP_ADD, PERMLANE32, FMA_SALU, BODY_LDS, BODY_SGPR,
+            FMA_EXP_7_1, KIND_COUNT };
+static const char* kind_name[KIND_COUNT] = {
+    "v_fma_f32, 8 independent chains", "v_fma_f32, 1 dependent chain", "v_mul_f32 + v_add_f32 alternating, 8 chains",
+    "v_cmp_gt_f32 + v_cndmask_b32 pairs", "v_exp_f32, 8 independent", "v_rcp_f32, 8 independent",
+    "v_pk_fma_f32, 8 independent (2 lanes' worth each)", "v_add_f32 row_shr:1 (DPP), 8 chains", "v_permlane32_swap, 4 pairs",
+    "v_fma_f32 (8 chains) + 1 s_add_u32 per 2 VALU", "forward blend body, record via uniform ds_read_b128 (product form)",
+    "forward blend body, record in SGPRs (s_load)", "7 v_fma_f32 + 1 v_exp_f32 per 8"};
+// VALU instructions per loop iteration of each kind (BODY kinds: filled from the compiled ISA, see body_valu below)
+static const int kind_valu_per_iter[KIND_COUNT] = {64, 64, 64, 64, 64, 64, 64, 64, 32, 64, 0, 0, 64};
+
+struct WaveOut { unsigned long long cycles, ticks; };
+
+#define REP8(X) X X X X X X X X
+#define ASM_FMA8 asm volatile( \
+    "v_fma_f32 %0, %8, %9, %0\n v_fma_f32 %1, %8, %9, %1\n v_fma_f32 %2, %8, %9, %2\n v_fma_f32 %3, %8, %9, %3\n" \
+    "v_fma_f32 %4, %8, %9, %4\n v_fma_f32 %5, %8, %9, %5\n v_fma_f32 %6, %8, %9, %6\n v_fma_f32 %7, %8, %9, %7\n" \
+    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+#define ASM_FMA_DEP8 asm volatile( \
+    "v_fma_f32 %0, %1, %2, %0\n v_fma_f32 %0, %1, %2, %0\n v_fma_f32 %0, %1, %2, %0\n v_fma_f32 %0, %1, %2, %0\n" \
+    "v_fma_f32 %0, %1, %2, %0\n v_fma_f32 %0, %1, %2, %0\n v_fma_f32 %0, %1, %2, %0\n v_fma_f32 %0, %1, %2, %0\n" \
+    : "+v"(a0) : "v"(b), "v"(c));
+#define ASM_MULADD8 asm volatile( \
+    "v_mul_f32 %0, %8, %0\n v_add_f32 %1, %9, %1\n v_mul_f32 %2, %8, %2\n v_add_f32 %3, %9, %3\n" \
+    "v_mul_f32 %4, %8, %4\n v_add_f32 %5, %9, %5\n v_mul_f32 %6, %8, %6\n v_add_f32 %7, %9, %7\n" \
+    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+#define ASM_CMPSEL8 asm volatile( \
+    "v_cmp_gt_f32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %9, vcc\n v_cmp_gt_f32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %9, vcc\n" \
+    "v_cmp_gt_f32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %9, vcc\n v_cmp_gt_f32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %9, vcc\n" \
+    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+#define ASM_EXP8 asm volatile( \
+    "v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n" \
+    "v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n" \
+    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+#define ASM_RCP8 asm volatile( \
+    "v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n" \
+    "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n" \
+    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+#define ASM_DPP8 asm volatile( \
+    "v_add_f32_dpp %0, %0, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %1, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n" \
+    "v_add_f32_dpp %2, %2, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %3, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n" \
+    "v_add_f32_dpp %4, %4, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %5, %5, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n" \
+    "v_add_f32_dpp %6, %6, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %7, %7, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n" \
+    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+#define PERM1(P_, Q_) { const uint2v r_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(P_), __float_as_uint(Q_), false, false); P_ = __uint_as_float(r_[0]); Q_ = __uint_as_float(r_[1]); }
+#define ASM_PERM4 PERM1(a0, a1) PERM1(a2, a3) PERM1(a4, a5) PERM1(a6, a7) asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+#define ASM_FMA_SALU8 asm volatile( \
+    "v_fma_f32 %0, %9, %10, %0\n v_fma_f32 %1, %9, %10, %1\n s_add_u32 %8, %8, 1\n v_fma_f32 %2, %9, %10, %2\n v_fma_f32 %3, %9, %10, %3\n s_add_u32 %8, %8, 1\n" \
+    "v_fma_f32 %4, %9, %10, %4\n v_fma_f32 %5, %9, %10, %5\n s_add_u32 %8, %8, 1\n v_fma_f32 %6, %9, %10, %6\n v_fma_f32 %7, %9, %10, %7\n s_add_u32 %8, %8, 1\n" \
+    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(sacc) : "v"(b), "v"(c) : "scc");
+#define ASM_FMA7_EXP1 asm volatile( \
+    "v_fma_f32 %0, %8, %9, %0\n v_fma_f32 %1, %8, %9, %1\n v_fma_f32 %2, %8, %9, %2\n v_fma_f32 %3, %8, %9, %3\n" \
+    "v_fma_f32 %4, %8, %9, %4\n v_fma_f32 %5, %8, %9, %5\n v_fma_f32 %6, %8, %9, %6\n v_exp_f32 %7, %7\n" \
+    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+
+template <int KIND>
+__global__ void __launch_bounds__(256) stream_kernel(WaveOut* out, float* sink, int iters, float seed) {
+    extern __shared__ float lds[];
+    float a0 = seed + threadIdx.x * 1e-3f, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    const float b = 0.999f + seed * 1e-6f, c = 1e-4f;
+    unsigned sacc = 0;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+        if (KIND == FMA_IND) { REP8(ASM_FMA8) }
+        if (KIND == FMA_DEP) { REP8(ASM_FMA_DEP8) }
+        if (KIND == MULADD_IND) { REP8(ASM_MULADD8) }
+        if (KIND == CMP_CNDMASK) { REP8(ASM_CMPSEL8) }
+        if (KIND == EXP_IND) { REP8(ASM_EXP8) }
+        if (KIND == RCP_IND) { REP8(ASM_RCP8) }
+        if (KIND == DPP_ADD) { REP8(ASM_DPP8) }
+        if (KIND == PERMLANE32) { REP8(ASM_PERM4) }
+        if (KIND == FMA_SALU) { REP8(ASM_FMA_SALU8) }
+        if (KIND == FMA_EXP_7_1) { REP8(ASM_FMA7_EXP1) }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = {t1 - t0, r1 - r0};
+    const float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)sacc;
+    if (s == 123.456f) sink[0] = s + lds[0];
+}
+
+__global__ void __launch_bounds__(256) pk_kernel(WaveOut* out, float* sink, int iters, float seed) {
+    extern __shared__ float lds[];
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f a0 = {seed, seed + 1}, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    const v2f b = {0.999f, 0.998f}, c = {1e-4f, 2e-4f};
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#define ASM_PK8 asm volatile( \
+    "v_pk_fma_f32 %0, %8, %9, %0\n v_pk_fma_f32 %1, %8, %9, %1\n v_pk_fma_f32 %2, %8, %9, %2\n v_pk_fma_f32 %3, %8, %9, %3\n" \
+    "v_pk_fma_f32 %4, %8, %9, %4\n v_pk_fma_f32 %5, %8, %9, %5\n v_pk_fma_f32 %6, %8, %9, %6\n v_pk_fma_f32 %7, %8, %9, %7\n" \
+    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+        REP8(ASM_PK8)
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = {t1 - t0, r1 - r0};
+    const v2f s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    if (s.x + s.y == 123.456f) sink[0] = s.x + lds[0];
+}
+
+// ---- the forward blend's per-entry body (same expression tree as render_fwd.hip: blend_step_bf<TRACK=false>) ----
+struct PixAcc { float T, C0, C1, C2, D; };
+__device__ __forceinline__ void blend_body(PixAcc& s, float& Tl, float pxf, float pyf, float gx_, float gy_, float a2, float b2, float c2,
+                                           float op, float r, float g, float b, float invd) {
+    const float dx = gx_ - pxf, dy = gy_ - pyf;
+    const float t = fmaf(b2, dy, a2 * dx);
+    const float p2 = fmaf(dx, t, (c2 * dy) * dy);
+    const float alpha = fminf(0.99f, op * __builtin_amdgcn_exp2f(p2));
+    const bool valid = (p2 <= 0.0f) & (alpha >= (1.0f / 255.0f));
+    const float testT = fmaf(-alpha, Tl, Tl);
+    const bool term = valid & (testT < 1e-4f);
+    const bool contrib = valid & (!term);
+    const float w = contrib ? alpha * Tl : 0.0f;
+    s.C0 = fmaf(r, w, s.C0);
+    s.C1 = fmaf(g, w, s.C1);
+    s.C2 = fmaf(b, w, s.C2);
+    s.D = fmaf(invd, w, s.D);
+    s.T = contrib ? testT : s.T;
+    Tl = contrib ? testT : (term ? 0.0f : Tl);
+}
+
+// 64 entries per "batch" like the product kernel; the survivor walk is replaced by a plain loop over all 64 slots (no s_ff1 /
+// mask update: 2 SALU fewer per entry than the product loop), so this is the VALU + DS + loop-control floor of the body.
+template <bool SGPR>
+__global__ void __launch_bounds__(256) body_kernel(WaveOut* out, float* sink, int iters, float seed, const float4* __restrict__ recs) {
+    extern __shared__ float4 s_dyn[];
+    float4* s_rec = s_dyn + (threadIdx.x >> 6) * 64 * 3;
+    const int lane = threadIdx.x & 63;
+    for (int k = 0; k < 3; ++k) s_rec[lane * 3 + k] = recs[lane * 3 + k];
+    PixAcc s = {1.f, 0.f, 0.f, 0.f, 0.f};
+    float Tl = 1.0f;
+    const float pxf = (float)(lane & 7) + seed, pyf = (float)(lane >> 3);
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll 1
+        for (int j = 0; j < 64; ++j) {
+            float4 q0, q1; float2 q2;
+            if (SGPR) {
+                q0 = recs[j * 3 + 0]; q1 = recs[j * 3 + 1]; q2 = *reinterpret_cast<const float2*>(&recs[j * 3 + 2]);
+            } else {
+                q0 = s_rec[j * 3 + 0]; q1 = s_rec[j * 3 + 1]; q2 = *reinterpret_cast<const float2*>(&s_rec[j * 3 + 2]);
+            }
+            blend_body(s, Tl, pxf, pyf, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y);
+        }
+        Tl = Tl < 0.5f ? 1.0f : Tl;     // keep the lanes live so every iteration costs the same
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = {t1 - t0, r1 - r0};
+    const float sum = s.T + s.C0 + s.C1 + s.C2 + s.D + Tl;
+    if (sum == 123.456f) sink[0] = sum;
+}
+
+int main(int argc, char** argv) {
+    // VALU instructions of one blend body + loop control, read off the compiled ISA (tools/isa_audit.py-style disassembly of THIS
+    // file: `hipcc -S`); override with argv when the compiler changes.  Used only to convert cycles/entry into cycles/VALU.
+    int body_valu_lds = argc > 1 ? atoi(argv[1]) : 24, body_valu_sgpr = argc > 2 ? atoi(argv[2]) : 23;
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const int n_cu = prop.multiProcessorCount;
+    printf("device %s, %d CUs, clockRate %d kHz\n", prop.name, n_cu, prop.clockRate);
+    hipStream_t st; CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    WaveOut* d_out; float* d_sink; float4* d_recs;
+    CK(hipMalloc(&d_out, sizeof(WaveOut) * n_cu * 8 * 4)); CK(hipMalloc(&d_sink, 64)); CK(hipMalloc(&d_recs, 64 * 3 * sizeof(float4)));
+    {   // plausible splat records: centres around the 8x8 box, conic ~ 1/(6 px)^2 in log2 units, opacities 0.02..0.6 (few terminate)
+        std::vector<float> h(64 * 12);
+        for (int j = 0; j < 64; ++j) {
+            float* r = &h[j * 12];
+            r[0] = 3.5f + 9.f * sinf(j * 1.3f); r[1] = 3.5f + 9.f * cosf(j * 0.7f); r[2] = -0.02f; r[3] = -0.004f;
+            r[4] = -0.025f; r[5] = 0.02f + 0.009f * j; r[6] = 0.5f; r[7] = 0.3f; r[8] = 0.7f; r[9] = 0.25f; r[10] = r[11] = 0.f;
+        }
+        CK(hipMemcpy(d_recs, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    }
+    const int LDS_TOTAL = 160 * 1024;
+    auto set_lds = [&](const void* f) { CK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL)); };
+    set_lds((const void*)stream_kernel<FMA_IND>); set_lds((const void*)stream_kernel<FMA_DEP>); set_lds((const void*)stream_kernel<MULADD_IND>);
+    set_lds((const void*)stream_kernel<CMP_CNDMASK>); set_lds((const void*)stream_kernel<EXP_IND>); set_lds((const void*)stream_kernel<RCP_IND>);
+    set_lds((const void*)stream_kernel<DPP_ADD>); set_lds((const void*)stream_kernel<PERMLANE32>); set_lds((const void*)stream_kernel<FMA_SALU>);
+    set_lds((const void*)stream_kernel<FMA_EXP_7_1>);
+    set_lds((const void*)pk_kernel); set_lds((const void*)body_kernel<false>); set_lds((const void*)body_kernel<true>);
+
+    printf("%-62s %3s %12s %12s %10s %10s %9s\n", "instruction stream", "W", "cyc/VALU/SIMD", "(max wave)", "GHz", "wall us", "T lane-op/s");
+    for (int kind = 0; kind < KIND_COUNT; ++kind) {
+        for (int W : {1, 2, 3, 4, 5, 6, 8}) {
+            const size_t lds = (size_t)(LDS_TOTAL / W) & ~(size_t)1023;        // W workgroups fill the CU's LDS: at most W resident per CU
+            if (W == 8 && lds * 9 <= (size_t)LDS_TOTAL) continue;
+            const int grid = n_cu * W;
+            const bool body = kind == BODY_LDS || kind == BODY_SGPR;
+            const int iters = body ? 40 : (kind == FMA_DEP ? 200 : 400);
+            const long long valu_per_wave = body ? (long long)iters * 64 * (kind == BODY_LDS ? body_valu_lds : body_valu_sgpr)
+                                                 : (long long)iters * kind_valu_per_iter[kind];
+            float best_ms = 1e30f; double mean_cyc = 0, max_cyc = 0, ghz = 0;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipEventRecord(e0, st));
+                switch (kind) {
+#define LAUNCH_STREAM(K) case K: hipLaunchKernelGGL(stream_kernel<K>, dim3(grid), dim3(256), lds, st, d_out, d_sink, iters, 1.0f + rep); break;
+                    LAUNCH_STREAM(FMA_IND) LAUNCH_STREAM(FMA_DEP) LAUNCH_STREAM(MULADD_IND) LAUNCH_STREAM(CMP_CNDMASK) LAUNCH_STREAM(EXP_IND)
+                    LAUNCH_STREAM(RCP_IND) LAUNCH_STREAM(DPP_ADD) LAUNCH_STREAM(PERMLANE32) LAUNCH_STREAM(FMA_SALU) LAUNCH_STREAM(FMA_EXP_7_1)
+                    case PK_FMA_IND: hipLaunchKernelGGL(pk_kernel, dim3(grid), dim3(256), lds, st, d_out, d_sink, iters, 1.0f + rep); break;
+                    case BODY_LDS: hipLaunchKernelGGL(body_kernel<false>, dim3(grid), dim3(256), lds, st, d_out, d_sink, iters, 0.25f * rep, d_recs); break;
+                    case BODY_SGPR: hipLaunchKernelGGL(body_kernel<true>, dim3(grid), dim3(256), lds, st, d_out, d_sink, iters, 0.25f * rep, d_recs); break;
+                }
+                CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep == 0) continue;      // warm-up
+                if (ms < best_ms) {
+                    best_ms = ms;
+                    std::vector<WaveOut> h(grid * 4);
+                    CK(hipMemcpy(h.data(), d_out, sizeof(WaveOut) * grid * 4, hipMemcpyDeviceToHost));
+                    double sc = 0, mc = 0, sg = 0;
+                    for (auto& w : h) { sc += (double)w.cycles; mc = std::max(mc, (double)w.cycles); sg += (double)w.cycles / ((double)w.ticks * 10.0); }
+                    mean_cyc = sc / h.size(); max_cyc = mc; ghz = sg / h.size();
+                }
+            }
+            const double cpi = mean_cyc / ((double)W * (double)valu_per_wave);
+            const double cpi_max = max_cyc / ((double)W * (double)valu_per_wave);
+            const double lane_ops = (double)valu_per_wave * 64.0 * grid * 4 / (best_ms * 1e-3) / 1e12;
+            printf("%-62s %3d %12.3f %12.3f %10.3f %10.1f %9.2f\n", kind_name[kind], W, cpi, cpi_max, ghz, best_ms * 1e3, lane_ops);
+        }
+    }
+    printf("blend body VALU counts used: LDS form %d, SGPR form %d (per entry, incl. loop control VALU if any)\n", body_valu_lds, body_valu_sgpr);
+    return 0;
+}
