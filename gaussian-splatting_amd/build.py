@@ -34,6 +34,7 @@ UNITS = [
     ("sort.hip", []),
     ("binning.hip", []),
     ("tilesort.hip", []),
+    ("route.hip", []),
     # -fno-slp-vectorize: automatic v_pk_*_f32 packing costs more issue slots than it saves on gfx950 (forward blend -3 %)
     ("render_fwd.hip", ["-ffp-contract=fast", "-fno-slp-vectorize"]),
     ("render_bwd.hip", ["-ffp-contract=fast", "-fno-slp-vectorize"]),

@@ -245,7 +245,7 @@ tile_ranges(int64_t R, const KeyT* __restrict__ keys, uint2* __restrict__ ranges
 __global__ void __launch_bounds__(256)
 splat_ingest(int P, const float4* __restrict__ records, int y0, int y1, float4* __restrict__ splats, uint2* __restrict__ rect,
              uint32_t* __restrict__ tiles, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-             uint32_t* __restrict__ sort_state) {
+             uint32_t* __restrict__ sort_state, uint32_t* key_overflow) {
     if (sort_state && blockIdx.x == 0)
         for (int i = threadIdx.x; i < GSR_OS_STATE_WORDS; i += 256) sort_state[i] = 0u;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
@@ -262,7 +262,17 @@ splat_ingest(int P, const float4* __restrict__ records, int y0, int y1, float4* 
         splats[i * 4 + 3] = make_float4(__uint_as_float(rc.x), __uint_as_float(rc.y), 0.f, __uint_as_float(t));
         rect[i] = rc;
         tiles[i] = t;
-        keys[i] = t ? __float_as_uint(q2.y) : 0xFFFFFFFFu;      // q2.y = view-space depth
+        keys[i] = gsr_depth_key(q2.y, t != 0u, key_overflow);      // q2.y = view-space depth
+        vals[i] = (uint32_t)i;
+    }
+}
+
+// fallback of the 27-bit depth sort (a listed Gaussian deeper than 13 107): the full 32-bit keys of round 2
+__global__ void __launch_bounds__(256)
+rekey_full(int P, const float4* __restrict__ splats, const uint32_t* __restrict__ tiles, uint32_t* __restrict__ keys,
+           uint32_t* __restrict__ vals) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        keys[i] = tiles[i] ? __float_as_uint(splats[i * 4 + 2].y) : 0xFFFFFFFFu;
         vals[i] = (uint32_t)i;
     }
 }
@@ -270,12 +280,19 @@ splat_ingest(int P, const float4* __restrict__ records, int y0, int y1, float4* 
 }  // namespace
 
 void gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
-                             uint32_t* keys, uint32_t* vals, uint32_t* sort_state, hipStream_t st) {
+                             uint32_t* keys, uint32_t* vals, uint32_t* sort_state, uint32_t* key_overflow, hipStream_t st) {
     int64_t nb = ((int64_t)P + 255) / 256;
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(splat_ingest, dim3((int)nb), dim3(256), 0, st, P, reinterpret_cast<const float4*>(records), y0, y1, splats,
-                       rect, tiles, keys, vals, sort_state);
+                       rect, tiles, keys, vals, sort_state, key_overflow);
+}
+
+void gsr_launch_rekey_full(int P, const float4* splats, const uint32_t* tiles, uint32_t* keys, uint32_t* vals, hipStream_t st) {
+    int64_t nb = ((int64_t)P + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(rekey_full, dim3((int)nb), dim3(256), 0, st, P, splats, tiles, keys, vals);
 }
 
 void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint2* rect, uint2* rect_sorted, uint32_t* offsets,

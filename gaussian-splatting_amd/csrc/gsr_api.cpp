@@ -4,7 +4,10 @@
 // depth-sort + stable tile-sort binning pipeline instead of one 64-bit key sort.
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -48,7 +51,8 @@ std::vector<PendingEvent> g_pending;
 std::vector<hipEvent_t> g_pool;
 double g_stage_ms[GSR_STAGE_COUNT] = {0};
 int g_stage_n[GSR_STAGE_COUNT] = {0};
-unsigned long long* g_counters = nullptr;     // device: work counters of the blend kernels, allocated by gsr_profile_enable(1)
+constexpr int GSR_MAX_DEVICES = 64;
+unsigned long long* g_counters_dev[GSR_MAX_DEVICES] = {nullptr};     // per device: work counters of the blend kernels (measurement only)
 
 hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
@@ -146,13 +150,49 @@ int check_split_sh(const GsrRasterSettings* s, int P, int M, const float* shs, b
     return GSR_OK;
 }
 
-// R read-back word: mapped + portable + coherent pinned host memory, one per (thread, device): [0] = R low word,
-// [1] = sequence number, [2] = R high word.  64 bytes each, intentionally not freed (calling into the HIP runtime from a
-// thread_local destructor at process exit is not safe); the runtime releases them with the context.
-constexpr int GSR_MAX_DEVICES = 64;
+// R read-back word: mapped + portable + coherent pinned host memory: [0] = R low word, [1] = sequence number, [2] = R high word,
+// [3] = "a depth key needed more than 27 bits" (set by the key-producing kernel).  Words are LEASED per call from a per-device
+// pool (keyed by device, not by thread -- a host thread that comes and goes leaks nothing, concurrent callers
+// never share a word); 64 bytes each, never freed (the runtime releases them with the context).
 struct HostWord { uint32_t* host = nullptr; uint32_t* dev = nullptr; uint32_t seq = 0; };
-thread_local HostWord g_host_word[GSR_MAX_DEVICES];
+std::mutex g_hw_mu;
+std::vector<HostWord> g_hw_pool[GSR_MAX_DEVICES];
 std::atomic<int64_t> g_last_R[GSR_MAX_DEVICES];      // per device: sizes the speculative binning buffer of the next frame
+struct HostWordLease {
+    int dev = -1;
+    HostWord hw;
+    hipStream_t st = nullptr;
+    bool settled = true;      // false while a kernel that will still write the word may be pending
+    ~HostWordLease() {
+        if (dev < 0) return;
+        if (!settled) (void)hipStreamSynchronize(st);      // error paths only: never hand a word with a pending writer to the next call
+        std::lock_guard<std::mutex> l(g_hw_mu);
+        g_hw_pool[dev].push_back(hw);
+    }
+};
+int lease_host_word(HostWordLease& lease, hipStream_t st) {
+    int dev_id = 0;
+    HIP_OK(hipGetDevice(&dev_id));
+    if (dev_id < 0 || dev_id >= GSR_MAX_DEVICES) return fail(GSR_ERR_UNSUPPORTED, "device ordinal out of range");
+    {
+        std::lock_guard<std::mutex> l(g_hw_mu);
+        if (!g_hw_pool[dev_id].empty()) { lease.hw = g_hw_pool[dev_id].back(); g_hw_pool[dev_id].pop_back(); }
+    }
+    if (!lease.hw.host) {
+        HIP_OK(hipHostMalloc((void**)&lease.hw.host, 64, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent));
+        HIP_OK(hipHostGetDevicePointer((void**)&lease.hw.dev, lease.hw.host, 0));
+        lease.hw.host[0] = lease.hw.host[1] = lease.hw.host[2] = 0;
+    }
+    lease.hw.host[3] = 0;
+    lease.dev = dev_id;
+    lease.st = st;
+    return GSR_OK;
+}
+unsigned long long* counters_for_current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= GSR_MAX_DEVICES) return nullptr;
+    return g_counters_dev[d];
+}
 
 // Second stream (lowest priority, non-blocking) + fork / join events of the overlapped colour kernel, one set per (thread,
 // device) like the host word, so that concurrent host threads never share an event.  Not freed, for the same reason.
@@ -198,10 +238,11 @@ GsrGeom gsr_carve_geom(char* base, int P) {
     g.offsets = (uint32_t*)take(n * 4);
     g.block_sums = (uint64_t*)take(((n + GSR_SCAN_ITEMS - 1) / GSR_SCAN_ITEMS) * 8);
     g.block_first = (uint2*)take(gsr_block_first_cap(P) * 8);
-    g.sort_hist = (uint32_t*)take((size_t)256 * (size_t)gsr_sort_blocks((int64_t)n, true) * 4);   // small workgroups: worst case
-    g.digit_total = (uint32_t*)take(256 * 4);
+    g.sort_hist = (uint32_t*)take((size_t)GSR_SORT_MAX_DIGITS * (size_t)gsr_sort_blocks((int64_t)n, true) * 4);   // small workgroups: worst case
+    g.digit_total = (uint32_t*)take(GSR_SORT_MAX_DIGITS * 4);
     g.os_scratch = (uint32_t*)take(gsr_onesweep_scratch_bytes((int64_t)n));
     g.num_rendered = (uint32_t*)take(128);
+    g.key_overflow = nullptr;
     g.bytes = off;
     return g;
 }
@@ -321,9 +362,11 @@ int gsr_set_option(const char* name, int value) {
 int gsr_profile_enable(int on) {
     std::lock_guard<std::mutex> l(g_prof_mu);
     g_count_on = (on & 2) != 0;
-    if (g_count_on && !g_counters) {      // measurement only: the product path never allocates
-        if (hipMalloc((void**)&g_counters, GSR_COUNTER_COUNT * sizeof(unsigned long long)) != hipSuccess) g_counters = nullptr;
-        else (void)hipMemset(g_counters, 0, GSR_COUNTER_COUNT * sizeof(unsigned long long));
+    int d = 0;
+    if (g_count_on && hipGetDevice(&d) == hipSuccess && d >= 0 && d < GSR_MAX_DEVICES && !g_counters_dev[d]) {
+        // measurement only (the product path never allocates): one counter block per device ordinal, on the CURRENT device
+        if (hipMalloc((void**)&g_counters_dev[d], GSR_COUNTER_COUNT * sizeof(unsigned long long)) != hipSuccess) g_counters_dev[d] = nullptr;
+        else (void)hipMemset(g_counters_dev[d], 0, GSR_COUNTER_COUNT * sizeof(unsigned long long));
     }
     g_prof_on = (on & 1) != 0;
     return GSR_OK;
@@ -331,9 +374,10 @@ int gsr_profile_enable(int on) {
 int gsr_profile_counters(uint64_t* out, int n, int reset) {
     std::lock_guard<std::mutex> l(g_prof_mu);
     unsigned long long host[GSR_COUNTER_COUNT] = {0};
-    if (g_counters) {
-        if (hipMemcpy(host, g_counters, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return fail(GSR_ERR_HIP, "counter read-back failed");
-        if (reset) (void)hipMemset(g_counters, 0, sizeof(host));
+    unsigned long long* ctr = counters_for_current_device();
+    if (ctr) {
+        if (hipMemcpy(host, ctr, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return fail(GSR_ERR_HIP, "counter read-back failed");
+        if (reset) (void)hipMemset(ctr, 0, sizeof(host));
     }
     for (int i = 0; i < n && i < GSR_COUNTER_COUNT; ++i) out[i] = host[i];
     return GSR_OK;
@@ -364,9 +408,72 @@ int gsr_profile_read(float* ms_out, int32_t* count_out, int n) {
     return GSR_OK;
 }
 
+// (profiling only) an event pair that goes back to the pool unless it was handed to g_pending -- ADVICE r02: the early
+// returns of bin_and_render leaked two events per failed frame
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    bool armed = false;
+    void arm(hipStream_t st) {
+        if (!g_prof_on) return;
+        std::lock_guard<std::mutex> l(g_prof_mu);
+        a = get_event(); b = get_event(); armed = true;
+        (void)hipEventRecord(a, st);
+    }
+    void commit(int stage, hipStream_t st) {
+        if (!armed) return;
+        (void)hipEventRecord(b, st);
+        std::lock_guard<std::mutex> l(g_prof_mu);
+        g_pending.push_back({stage, a, b});
+        armed = false;
+    }
+    ~EventPair() {
+        if (!armed) return;
+        std::lock_guard<std::mutex> l(g_prof_mu);
+        g_pool.push_back(a); g_pool.push_back(b);
+    }
+};
+
+// Which ping-pong buffer holds the depth order is a pure function of the build (3 passes of 9 bits -> vals[1]); the 32-bit
+// fallback sort (4 passes -> vals[0]) copies its result there, so the backward finds it without any state.
+static int depth_order_buffer_index() {
+    int pb[8];
+    return gsr_sort_plan(GSR_DEPTH_KEY_BITS, GSR_DEPTH_DIGIT_BITS, pb) & 1;
+}
+
+// Host side of the R read-back: spin on the mapped word.  ADVICE r02: in training the host runs far ahead of the GPU, so the
+// wait can be the whole rest of the previous iteration -- a hard spin would pin a core per rank.  200 us of PAUSE spinning
+// (covers the forward-only case, where the wait is the scan bubble), then polls separated by sched_yield(), after 2 s the
+// blocking path (which also surfaces kernel faults).
+static int wait_for_R(HostWord& hw, uint32_t seq, hipStream_t st, const uint32_t* num_rendered_dev) {
+    volatile uint32_t* w = hw.host;
+    bool got = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spin = 0;; ++spin) {
+        if (w[1] == seq) { got = true; break; }
+        if ((spin & 63) == 63) {
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            if (us > 2.0e6) break;
+            if (us > 200.0) sched_yield();
+        } else {
+            GSR_CPU_RELAX();
+        }
+    }
+    if (!got) {
+        HIP_OK(hipStreamSynchronize(st));
+        if (w[1] != seq) {
+            uint32_t r2[2] = {0, 0};
+            HIP_OK(hipMemcpy(r2, num_rendered_dev, sizeof(r2), hipMemcpyDeviceToHost));
+            hw.host[0] = r2[0];
+            hw.host[2] = r2[1];
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return GSR_OK;
+}
+
 // Everything after the per-Gaussian preprocess: depth sort, scan, R read-back, emission, tile sort, ranges, blend.
 // `g` holds the splat records, band-clamped rectangles / tile counts and the depth keys of all P Gaussians.
-static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& cam, int P, GsrGeom& g,
+static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& cam, int P, GsrGeom& g, HostWordLease& lease,
                           GsrResizeFn binning_resize, void* binning_user, GsrResizeFn image_resize, void* image_user,
                           float* out_color, float* out_invdepth, int32_t* num_rendered, hipStream_t st,
                           hipEvent_t colors_done = nullptr, bool first_hist_ready = false) {
@@ -374,12 +481,12 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     uint32_t* sort_err = nullptr;
     const bool onesweep = g_depth_sort_mode == 1;
     {   StageTimer t(GSR_STAGE_DEPTH_SORT, st);
-        if (onesweep) {
+        if (onesweep) {      // (measurement build) 4 passes of 8 bits on the 27-bit keys; result in vals[0]
             gsr_onesweep_depth_sort(g.keys, g.vals, P, g.os_scratch, g.rect, g.rect_sorted, &sort_err, st);
             order_buf = 0;
         } else {
-            order_buf = gsr_radix_sort_pairs(g.keys, g.vals, P, 32, GSR_DEPTH_DIGIT_BITS, g.sort_hist, g.digit_total, sort_items(P), st,
-                                             g.rect, g.rect_sorted, first_hist_ready);
+            order_buf = gsr_radix_sort_pairs(g.keys, g.vals, P, GSR_DEPTH_KEY_BITS, GSR_DEPTH_DIGIT_BITS, g.sort_hist, g.digit_total,
+                                             sort_items(P), st, g.rect, g.rect_sorted, first_hist_ready);
         }
     }
     STAGE_CHECK("depth sort");
@@ -388,28 +495,18 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     // number straight into mapped pinned host memory (system-scope release) and the host spins on it instead of going
     // through hipMemcpyAsync + hipStreamSynchronize; (2) the image buffer and a speculative binning buffer (last R + 25 %)
     // are obtained through the callbacks WHILE the GPU is still working, so in steady state no callback sits in the bubble.
-    int dev_id = 0;
-    HIP_OK(hipGetDevice(&dev_id));
-    if (dev_id < 0 || dev_id >= GSR_MAX_DEVICES) return fail(GSR_ERR_UNSUPPORTED, "device ordinal out of range");
-    HostWord& hw_slot = g_host_word[dev_id];
-    if (!hw_slot.host) {
-        HIP_OK(hipHostMalloc((void**)&hw_slot.host, 64, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent));
-        HIP_OK(hipHostGetDevicePointer((void**)&hw_slot.dev, hw_slot.host, 0));
-        hw_slot.host[0] = hw_slot.host[1] = hw_slot.host[2] = 0;
-    }
-    const uint32_t seq = ++hw_slot.seq;
+    const int dev_id = lease.dev;
+    HostWord& hw_slot = lease.hw;
+    uint32_t seq = ++hw_slot.seq;
     const uint32_t bf_cap = (uint32_t)gsr_block_first_cap(P);
+    lease.settled = false;
     {   StageTimer t(GSR_STAGE_SCAN, st);
         gsr_launch_scan_tiles(P, g.vals[order_buf], g.rect, g.rect_sorted, g.offsets, g.block_sums, g.block_first, bf_cap,
                               g.num_rendered, hw_slot.dev, seq, /*rect_already_sorted=*/true, sort_err, st);
     }
     // (profiling only) the GPU-idle bubble of the R read-back: from the end of the scan to the first launch after the wait
-    hipEvent_t wait_a = nullptr, wait_b = nullptr;
-    if (g_prof_on) {
-        std::lock_guard<std::mutex> l(g_prof_mu);
-        wait_a = get_event(); wait_b = get_event();
-        (void)hipEventRecord(wait_a, st);
-    }
+    EventPair wait_ev;
+    wait_ev.arm(st);
     const int n_tiles = cam.gx * cam.gy;
     GsrTileSortPlan plan;
     gsr_tile_sort_plan(n_tiles, P, &plan);
@@ -426,23 +523,23 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
         spec_bytes = gsr_binning_bytes(last_R + last_R / 4 + 4096, n_tiles);
         bbase = (char*)binning_resize(binning_user, spec_bytes);
     }
-    {
-        volatile uint32_t* hw = hw_slot.host;
-        bool got = false;
-        for (uint64_t spin = 0; spin < (1ull << 26); ++spin) {
-            if (hw[1] == seq) { got = true; break; }
-            GSR_CPU_RELAX();
-        }
-        if (!got) {   // kernel fault or a very slow queue: fall back to the blocking path, which also surfaces errors
-            HIP_OK(hipStreamSynchronize(st));
-            if (hw[1] != seq) {
-                uint32_t r2[2] = {0, 0};
-                HIP_OK(hipMemcpy(r2, g.num_rendered, sizeof(r2), hipMemcpyDeviceToHost));
-                hw_slot.host[0] = r2[0];
-                hw_slot.host[2] = r2[1];
-            }
-        }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    int rc = wait_for_R(hw_slot, seq, st, g.num_rendered);
+    if (rc != GSR_OK) return rc;
+    lease.settled = true;
+    if (hw_slot.host[3] != 0u && !onesweep) {
+        // a listed Gaussian lies deeper than 0.2 * 2^16: its 27-bit key was clamped and the depth order above is not
+        // trustworthy.  Rare path: full 32-bit keys from the splat records, 4 passes of 8 bits (round 2's sort), result
+        // copied into the buffer the 3-pass sort uses, scan again (R itself does not depend on the order).
+        gsr_launch_rekey_full(P, g.splats, g.tiles, g.keys[0], g.vals[0], st);
+        const int ob = gsr_radix_sort_pairs(g.keys, g.vals, P, 32, 8, g.sort_hist, g.digit_total, sort_items(P), st, g.rect, g.rect_sorted, false);
+        if (ob != order_buf) HIP_OK(hipMemcpyAsync(g.vals[order_buf], g.vals[ob], (size_t)P * 4, hipMemcpyDeviceToDevice, st));
+        seq = ++hw_slot.seq;
+        lease.settled = false;
+        gsr_launch_scan_tiles(P, g.vals[order_buf], g.rect, g.rect_sorted, g.offsets, g.block_sums, g.block_first, bf_cap,
+                              g.num_rendered, hw_slot.dev, seq, true, nullptr, st);
+        rc = wait_for_R(hw_slot, seq, st, g.num_rendered);
+        if (rc != GSR_OK) return rc;
+        lease.settled = true;
     }
     const uint64_t R64 = ((uint64_t)hw_slot.host[2] << 32) | (uint64_t)hw_slot.host[0];
     if (R64 == ~0ull) return fail(GSR_ERR_HIP, "depth sort: a workgroup timed out waiting for its predecessors");
@@ -455,11 +552,7 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     if (!bbase || !ibase) return fail(GSR_ERR_ALLOC, "binning / image buffer resize returned NULL");
     GsrBinning b = gsr_carve_binning(bbase, R);
     GsrImage im = gsr_carve_image(ibase, cam.W, cam.H);
-    if (wait_a) {
-        (void)hipEventRecord(wait_b, st);
-        std::lock_guard<std::mutex> l(g_prof_mu);
-        g_pending.push_back({GSR_STAGE_R_WAIT, wait_a, wait_b});
-    }
+    wait_ev.commit(GSR_STAGE_R_WAIT, st);
     float4* goffset_splats = settings->no_backward ? nullptr : g.splats;
 
     int list_buf = 0;
@@ -510,7 +603,7 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     {   StageTimer t(GSR_STAGE_RENDER, st);
         gsr_launch_render_forward(cam, im.ranges, b.vals[list_buf], g.splats, settings->no_backward ? nullptr : im.final_T,
                                   settings->no_backward ? nullptr : im.n_contrib, out_color, out_invdepth,
-                                  g_render_fwd_variant, g_count_on ? g_counters : nullptr, st);
+                                  g_render_fwd_variant, g_count_on ? counters_for_current_device() : nullptr, st);
     }
     STAGE_CHECK("render");
     HIP_OK(hipGetLastError());
@@ -545,6 +638,10 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
     char* gbase = (char*)geom_resize(geom_user, gsr_geometry_bytes(P));
     if (!gbase) return fail(GSR_ERR_ALLOC, "geometry buffer resize returned NULL");
     GsrGeom g = gsr_carve_geom(gbase, P);
+    HostWordLease lease;
+    rc = lease_host_word(lease, st);
+    if (rc != GSR_OK) return rc;
+    g.key_overflow = lease.hw.dev + 3;
 
     if (g_color_overlap == 0 || !shs) {
         // large P: one preprocess workgroup per workgroup of the depth sort's first pass, which then needs no histogram
@@ -556,7 +653,7 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
                                   first_hist ? items : 0);
         }
         STAGE_CHECK("preprocess");
-        return bin_and_render(settings, cam, P, g, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
+        return bin_and_render(settings, cam, P, g, lease, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
                               num_rendered, st, nullptr, first_hist);
     }
     // split form: the binning chain needs only the geometry; the SH evaluation runs beside it on the second stream
@@ -588,7 +685,7 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
     }
     if (join) HIP_OK(hipEventRecord(join, cst));
     if (settings->debug && cst != st) HIP_OK(hipStreamSynchronize(cst));
-    rc = bin_and_render(settings, cam, P, g, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
+    rc = bin_and_render(settings, cam, P, g, lease, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
                         num_rendered, st, join);
     // an early return leaves the colour kernel un-joined: the caller may release the geometry buffer, so wait for it here
     if (rc != GSR_OK && cst != st) (void)hipStreamSynchronize(cst);
@@ -623,9 +720,10 @@ int gsr_preprocess_forward(const GsrRasterSettings* settings, int P, int M, cons
     return GSR_OK;
 }
 
-int gsr_rasterize_from_splats(const GsrRasterSettings* settings, int P, const float* splat_records, GsrResizeFn geom_resize,
-                              void* geom_user, GsrResizeFn binning_resize, void* binning_user, GsrResizeFn image_resize,
-                              void* image_user, float* out_color, float* out_invdepth, int32_t* num_rendered, void* stream) {
+// shared body of gsr_rasterize_from_splats (64-byte records) / gsr_rasterize_from_packed (48-byte records)
+static int rasterize_from_records(const GsrRasterSettings* settings, int P, const float* records, bool packed, GsrResizeFn geom_resize,
+                                  void* geom_user, GsrResizeFn binning_resize, void* binning_user, GsrResizeFn image_resize,
+                                  void* image_user, float* out_color, float* out_invdepth, int32_t* num_rendered, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     GsrCamDev cam;
     int rc = make_cam(settings, 0, cam);
@@ -639,18 +737,98 @@ int gsr_rasterize_from_splats(const GsrRasterSettings* settings, int P, const fl
         if (out_invdepth) HIP_OK(hipMemsetAsync(out_invdepth, 0, npix * sizeof(float), st));
         return GSR_OK;
     }
-    if (!splat_records) return fail(GSR_ERR_INVALID_ARG, "splat_records is NULL");
-    if ((uintptr_t)splat_records & 15) return fail(GSR_ERR_INVALID_ARG, "splat_records must be 16-byte aligned");
+    if (!records) return fail(GSR_ERR_INVALID_ARG, "records pointer is NULL");
+    if ((uintptr_t)records & 15) return fail(GSR_ERR_INVALID_ARG, "records must be 16-byte aligned");
     if (!geom_resize || !binning_resize || !image_resize) return fail(GSR_ERR_INVALID_ARG, "resize callbacks are NULL");
     char* gbase = (char*)geom_resize(geom_user, gsr_geometry_bytes(P));
     if (!gbase) return fail(GSR_ERR_ALLOC, "geometry buffer resize returned NULL");
     GsrGeom g = gsr_carve_geom(gbase, P);
+    HostWordLease lease;
+    rc = lease_host_word(lease, st);
+    if (rc != GSR_OK) return rc;
+    g.key_overflow = lease.hw.dev + 3;
     {   StageTimer t(GSR_STAGE_PREPROCESS, st);
-        gsr_launch_splat_ingest(P, splat_records, cam.tile_y0, cam.tile_y1, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], gsr_onesweep_available() ? g.os_scratch : nullptr, st);
+        uint32_t* sort_state = gsr_onesweep_available() ? g.os_scratch : nullptr;
+        if (packed) gsr_launch_ingest_packed(P, records, cam.tile_y0, cam.tile_y1, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], sort_state, g.key_overflow, st);
+        else gsr_launch_splat_ingest(P, records, cam.tile_y0, cam.tile_y1, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], sort_state, g.key_overflow, st);
     }
     STAGE_CHECK("splat ingest");
-    return bin_and_render(settings, cam, P, g, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
+    return bin_and_render(settings, cam, P, g, lease, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
                           num_rendered, st);
+}
+
+int gsr_rasterize_from_splats(const GsrRasterSettings* settings, int P, const float* splat_records, GsrResizeFn geom_resize,
+                              void* geom_user, GsrResizeFn binning_resize, void* binning_user, GsrResizeFn image_resize,
+                              void* image_user, float* out_color, float* out_invdepth, int32_t* num_rendered, void* stream) {
+    return rasterize_from_records(settings, P, splat_records, false, geom_resize, geom_user, binning_resize, binning_user, image_resize,
+                                  image_user, out_color, out_invdepth, num_rendered, stream);
+}
+
+int gsr_rasterize_from_packed(const GsrRasterSettings* settings, int P, const float* packed_records, GsrResizeFn geom_resize,
+                              void* geom_user, GsrResizeFn binning_resize, void* binning_user, GsrResizeFn image_resize,
+                              void* image_user, float* out_color, float* out_invdepth, int32_t* num_rendered, void* stream) {
+    return rasterize_from_records(settings, P, packed_records, true, geom_resize, geom_user, binning_resize, binning_user, image_resize,
+                                  image_user, out_color, out_invdepth, num_rendered, stream);
+}
+
+// ---- Gaussian-sharded exchange (route.hip) ----
+static int check_bands(int n_bands, const int32_t* band_bounds) {
+    if (n_bands < 1 || n_bands > GSR_MAX_BANDS) return fail(GSR_ERR_UNSUPPORTED, "n_bands must be 1..64");
+    if (!band_bounds) return fail(GSR_ERR_INVALID_ARG, "band_bounds is NULL");
+    for (int b = 0; b < n_bands; ++b)
+        if (band_bounds[b] > band_bounds[b + 1] || band_bounds[b] < 0) return fail(GSR_ERR_INVALID_ARG, "band_bounds must be non-negative and non-decreasing");
+    return GSR_OK;
+}
+
+size_t gsr_route_scratch_bytes(int P, int n_bands) { return gsr_route_scratch_bytes_impl(P, n_bands < 1 ? 1 : n_bands); }
+
+int gsr_route_count(int P, const float* splat_records, int n_bands, const int32_t* band_bounds, void* scratch, uint32_t* band_counts,
+                    void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int rc = check_bands(n_bands, band_bounds);
+    if (rc != GSR_OK) return rc;
+    if (P < 0) return fail(GSR_ERR_INVALID_ARG, "P < 0");
+    if (!band_counts) return fail(GSR_ERR_INVALID_ARG, "band_counts is NULL");
+    if (P == 0) { HIP_OK(hipMemsetAsync(band_counts, 0, sizeof(uint32_t) * (size_t)n_bands, st)); return GSR_OK; }
+    if (!splat_records || !scratch) return fail(GSR_ERR_INVALID_ARG, "splat_records / scratch are NULL");
+    if ((uintptr_t)splat_records & 15) return fail(GSR_ERR_INVALID_ARG, "splat_records must be 16-byte aligned");
+    gsr_launch_route_count(P, splat_records, n_bands, band_bounds, (uint32_t*)scratch, band_counts, st);
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_route_pack(int P, const float* splat_records, int n_bands, const int32_t* band_bounds, const int64_t* band_offsets,
+                   const void* scratch, float* packed, int32_t* send_ids, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int rc = check_bands(n_bands, band_bounds);
+    if (rc != GSR_OK) return rc;
+    if (P < 0) return fail(GSR_ERR_INVALID_ARG, "P < 0");
+    if (P == 0) return GSR_OK;
+    if (!band_offsets) return fail(GSR_ERR_INVALID_ARG, "band_offsets is NULL");
+    if (band_offsets[n_bands] == band_offsets[0]) return GSR_OK;      // nothing to send
+    if (!splat_records || !scratch || !packed || !send_ids) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
+    if (((uintptr_t)splat_records | (uintptr_t)packed) & 15) return fail(GSR_ERR_INVALID_ARG, "splat_records / packed must be 16-byte aligned");
+    gsr_launch_route_pack(P, splat_records, n_bands, band_bounds, band_offsets, (const uint32_t*)scratch, packed, send_ids, st);
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_route_return(int P, int n_bands, const int64_t* band_offsets, const int32_t* send_ids, const float* returned,
+                     float* splat_grads, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (P < 0 || n_bands < 1 || n_bands > GSR_MAX_BANDS) return fail(GSR_ERR_INVALID_ARG, "bad P / n_bands");
+    if (P == 0) return GSR_OK;
+    if (!band_offsets || !splat_grads) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
+    HIP_OK(hipMemsetAsync(splat_grads, 0, (size_t)P * 48, st));
+    for (int b = 0; b < n_bands; ++b) {      // band order: fixed association order of the <= n_bands terms per Gaussian
+        const int64_t n = band_offsets[b + 1] - band_offsets[b];
+        if (n < 0) return fail(GSR_ERR_INVALID_ARG, "band_offsets must be non-decreasing");
+        if (n == 0) continue;
+        if (!send_ids || !returned) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
+        gsr_launch_route_add_rows(n, send_ids + band_offsets[b], returned + band_offsets[b] * 12, splat_grads, st);
+    }
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
 }
 
 // Which ping-pong buffer holds the sorted list / the depth order is a pure function of the frame geometry (never of a
@@ -660,10 +838,6 @@ static int list_buffer_index(int n_tiles) {
     if (n_tiles <= 65536) return 0;
     int pb[8];
     return gsr_sort_plan(bits_for((uint32_t)n_tiles), GSR_TILE_DIGIT_BITS, pb) & 1;
-}
-static int depth_order_buffer_index() {
-    int pb[8];
-    return gsr_sort_plan(32, GSR_DEPTH_DIGIT_BITS, pb) & 1;
 }
 
 int gsr_backward_blend(const GsrRasterSettings* settings, int P, int32_t num_rendered, const void* geom_buffer,
@@ -695,7 +869,7 @@ int gsr_backward_blend(const GsrRasterSettings* settings, int P, int32_t num_ren
             HIP_OK(hipMemsetAsync(w.inst_flag, 0, (size_t)num_rendered * 4, st));
             gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib,
                                        dL_dout_color, dL_dout_invdepth, nullptr, w.inst_grads, w.inst_flag, num_rendered,
-                                       g_render_bwd_variant, g_count_on ? g_counters : nullptr, st);
+                                       g_render_bwd_variant, g_count_on ? counters_for_current_device() : nullptr, st);
         }
     }
     STAGE_CHECK("render backward blend");
@@ -776,6 +950,7 @@ int gsr_sparse_adam_step(float* param, const float* grad, float* exp_avg, float*
                          int64_t N, int64_t M, double lr, double beta1, double beta2, double eps, void* stream) {
     if (N < 0 || M < 0) return fail(GSR_ERR_INVALID_ARG, "N < 0 or M < 0");
     if (N == 0 || M == 0) return GSR_OK;
+    if (M >= (1ll << 31) || N >= (1ll << 31)) return fail(GSR_ERR_UNSUPPORTED, "sparse Adam: N and M must be below 2^31 (the kernel indexes rows and columns with 32 bits)");
     if (!param || !grad || !exp_avg || !exp_avg_sq || !visible) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
     gsr_launch_sparse_adam(param, grad, exp_avg, exp_avg_sq, visible, N, M, lr, beta1, beta2, eps, (hipStream_t)stream);
     HIP_OK(hipGetLastError());

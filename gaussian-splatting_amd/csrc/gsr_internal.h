@@ -45,9 +45,36 @@ struct GsrGeom {                 // P-sized
     uint32_t* digit_total;       // [256]
     uint32_t* os_scratch;        // gsr_onesweep_scratch_bytes(P): tables / descriptor words of the one-kernel-per-pass depth sort
     uint32_t* num_rendered;      // [2] R as 64 bits
+    uint32_t* key_overflow;      // NOT carved: device address of the host word a kernel sets when a depth key needs > 27 bits (may be NULL)
     size_t bytes;
 };
 GsrGeom gsr_carve_geom(char* base, int P);
+
+// ---- depth-sort keys (round 3): 27 bits instead of 32 -> 3 radix passes of 9 bits instead of 4 of 8 ----
+// Every listed Gaussian passed the near cull view.z > 0.2 (Appendix A.2 step 1), and positive fp32 bit patterns order like the
+// floats, so key = bits(depth) - bits(0.2f) >= 1 orders the listed Gaussians exactly like bits(depth).  27 bits cover
+// 16 octaves: depths below 0.2 * 2^16 = 13 107.  A deeper Gaussian sets *key_overflow (a mapped host word); the host then
+// re-keys with the full 32 bits and repeats the depth sort with 4 passes (gsr_api.cpp) -- bit-identical order either way.
+// Gaussians without a tile in the band sort last (key = 2^27 - 1; stable sort: among themselves in index order).
+#define GSR_DEPTH_KEY_BITS 27
+#define GSR_DEPTH_KEY_BASE 0x3E4CCCCDu
+#define GSR_DEPTH_KEY_CULLED ((1u << GSR_DEPTH_KEY_BITS) - 1u)
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t gsr_depth_key(float depth, bool listed, uint32_t* key_overflow) {
+    if (!listed) return GSR_DEPTH_KEY_CULLED;
+    uint32_t k = __float_as_uint(depth) - GSR_DEPTH_KEY_BASE;
+    if (k >= GSR_DEPTH_KEY_CULLED) {
+        if (key_overflow) __hip_atomic_store(key_overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        k = GSR_DEPTH_KEY_CULLED - 1u;
+    }
+    return k;
+}
+// the two derived fields of a splat record, written by the preprocess and recomputed bit-identically from (opacity, depth) by the
+// receiver of a packed record (route.hip): explicit single roundings, independent of the translation unit's -ffp-contract
+// tau = 2 ln(255 opacity) + slack: a splat reaches alpha >= 1/255 only where its quadratic form is <= tau (box cull of the blend)
+__device__ __forceinline__ float gsr_tau(float opacity) { return __fadd_rn(__fmul_rn(2.0f, logf(__fmul_rn(255.0f, opacity))), 0.01f); }
+__device__ __forceinline__ float gsr_inv_depth(float depth) { return __fdiv_rn(1.0f, depth); }
+#endif
 
 struct GsrBinning {              // R-sized
     // > 65536 tiles (LSD sort, sort.hip): keys[2] tile ids / vals[2] Gaussian ids, ping-pong; list = vals[passes & 1]
@@ -118,7 +145,8 @@ void gsr_onesweep_depth_sort(uint32_t* keys[2], uint32_t* vals[2], int64_t n, ui
                              uint2* rect_sorted, uint32_t** err_word_dev, hipStream_t st);
 // pass plan shared by the sorter and by code that must know which ping-pong buffer holds the result
 int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits /*[8]*/);
-#define GSR_DEPTH_DIGIT_BITS 8      // 32-bit depth keys: 4 passes of 8 bits (3 x 11 bits measured slower: 113 vs 91 us)
+#define GSR_DEPTH_DIGIT_BITS 9      // 27-bit depth keys: 3 passes of 9 bits (round 2: 4 x 8 on 32 bits; 3 x 11 measured slower: 113 vs 91 us)
+#define GSR_SORT_MAX_DIGITS 512     // table rows (digit values) the geometry buffer provides for the depth sort
 #define GSR_TILE_DIGIT_BITS 8       // tile ids: ceil(bits/8) passes of equal width
 static inline int64_t gsr_sort_blocks(int64_t n, bool small_blocks) {
     const int64_t items = small_blocks ? GSR_SORT_ITEMS_SMALL : GSR_SORT_ITEMS;
@@ -209,4 +237,18 @@ void gsr_launch_ssim_mean_backward(int planes, int H, int W, const float* img1, 
                                    hipStream_t st);
 // binning.hip: gathered splat records -> geometry state of this rank's band (two-axis sharding)
 void gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
-                             uint32_t* keys, uint32_t* vals, uint32_t* sort_state /*zeroed, GSR_OS_STATE_WORDS*/, hipStream_t st);
+                             uint32_t* keys, uint32_t* vals, uint32_t* sort_state /*zeroed, GSR_OS_STATE_WORDS*/, uint32_t* key_overflow,
+                             hipStream_t st);
+// binning.hip: full 32-bit depth keys from the splat records (fallback of the 27-bit depth sort)
+void gsr_launch_rekey_full(int P, const float4* splats, const uint32_t* tiles, uint32_t* keys, uint32_t* vals, hipStream_t st);
+
+// route.hip: Gaussian-sharded rendering -- destination-targeted exchange of packed splat records
+#define GSR_MAX_BANDS 64
+size_t gsr_route_scratch_bytes_impl(int P, int n_bands);
+void gsr_launch_route_count(int P, const float* records, int n_bands, const int32_t* bounds, uint32_t* block_counts,
+                            uint32_t* band_counts, hipStream_t st);
+void gsr_launch_route_pack(int P, const float* records, int n_bands, const int32_t* bounds, const int64_t* band_offsets,
+                           const uint32_t* block_offsets, float* packed, int32_t* send_ids, hipStream_t st);
+void gsr_launch_ingest_packed(int P, const float* packed, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
+                              uint32_t* keys, uint32_t* vals, uint32_t* sort_state, uint32_t* key_overflow, hipStream_t st);
+void gsr_launch_route_add_rows(int64_t n, const int32_t* ids, const float* rows, float* out, hipStream_t st);

@@ -208,7 +208,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
                       uint2* __restrict__ rect, uint32_t* __restrict__ tiles, uint32_t* __restrict__ clamped_out,
                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int32_t* __restrict__ radii,
                       uint32_t* __restrict__ sort_state /*GSR_OS_STATE_WORDS words zeroed for the depth sort that follows*/,
-                      uint32_t* __restrict__ first_hist, int hist_items) {
+                      uint32_t* __restrict__ first_hist, int hist_items, uint32_t* key_overflow) {
     __shared__ __attribute__((aligned(16))) float s_sh[4][64 * SH_ROW];
     // first_hist != NULL: workgroup b owns Gaussians [b * hist_items, (b + 1) * hist_items) -- exactly the keys of workgroup
     // b of the depth sort's first radix pass -- and leaves that pass's digit histogram (low 8 key bits) in
@@ -331,7 +331,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             q1 = make_float4(sp.conC, sp.opacity, rgb[0], rgb[1]);
             // tau = 2 ln(255 opacity) + slack: a splat reaches alpha >= 1/255 only where its quadratic form is <= tau
             // (box-cull threshold of the blend kernels); 1/depth feeds the inverse-depth image.
-            q2 = make_float4(rgb[2], sp.depth, 2.0f * logf(255.0f * sp.opacity) + 0.01f, 1.0f / sp.depth);
+            q2 = make_float4(rgb[2], sp.depth, gsr_tau(sp.opacity), gsr_inv_depth(sp.depth));
         }
         const uint2 rc = make_uint2(sp.minx | (sp.maxx << 16), sp.miny | (sp.maxy << 16));
         splats[i * 4 + 0] = q0;
@@ -343,9 +343,8 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         tiles[i] = sp.tiles;
         if (clamped_out) clamped_out[i] = clampbits;
         radii[i] = sp.radius;
-        // depth-sort key: positive fp32 bit patterns order like the floats; Gaussians with no tile in
-        // the band sort last.
-        const uint32_t key = sp.tiles ? __float_as_uint(sp.depth) : 0xFFFFFFFFu;
+        // depth-sort key (gsr_internal.h): 27 bits of bits(depth) - bits(0.2f); Gaussians with no tile in the band sort last.
+        const uint32_t key = gsr_depth_key(sp.depth, sp.tiles != 0u, key_overflow);
         keys[i] = key;
         vals[i] = (uint32_t)i;
         if (first_hist) atomicAdd(&s_hist[key & 255u], 1u);
@@ -374,7 +373,7 @@ preprocess_geom_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D,
                        const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
                        const float* __restrict__ cov3D_precomp, float4* __restrict__ splats, uint2* __restrict__ rect,
                        uint32_t* __restrict__ tiles, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                       int32_t* __restrict__ radii, uint32_t* __restrict__ sort_state) {
+                       int32_t* __restrict__ radii, uint32_t* __restrict__ sort_state, uint32_t* key_overflow) {
     if (sort_state && blockIdx.x == 0)
         for (int i = threadIdx.x; i < GSR_OS_STATE_WORDS; i += 256) sort_state[i] = 0u;
     GsrCam cam;
@@ -402,7 +401,7 @@ preprocess_geom_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D,
             }
             q0 = make_float4(sp.px, sp.py, sp.conA, sp.conB);
             q1 = make_float4(sp.conC, sp.opacity, rgb[0], rgb[1]);
-            q2 = make_float4(rgb[2], sp.depth, 2.0f * logf(255.0f * sp.opacity) + 0.01f, 1.0f / sp.depth);
+            q2 = make_float4(rgb[2], sp.depth, gsr_tau(sp.opacity), gsr_inv_depth(sp.depth));
         }
         const uint2 rc = make_uint2(sp.minx | (sp.maxx << 16), sp.miny | (sp.maxy << 16));
         splats[i * 4 + 0] = q0;
@@ -412,7 +411,7 @@ preprocess_geom_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D,
         rect[i] = rc;
         tiles[i] = sp.tiles;
         radii[i] = sp.radius;
-        keys[i] = sp.tiles ? __float_as_uint(sp.depth) : 0xFFFFFFFFu;
+        keys[i] = gsr_depth_key(sp.depth, sp.tiles != 0u, key_overflow);
         vals[i] = (uint32_t)i;
     }
 }
@@ -653,7 +652,7 @@ void gsr_launch_preprocess(const GsrCamDev& cam, int P, const float* means3D, co
     hipLaunchKernelGGL((preprocess_fwd_kernel<SPLIT_, DMA_>), dim3(grid), dim3(256), 0, st, cam, P, means3D, shs, colors_precomp,        \
                        opacities, scales, rotations, cov3D_precomp, g.splats, g.rect, g.tiles,                                         \
                        /*clamped (recomputed by the backward)*/ nullptr, g.keys[0], g.vals[0], radii,                                 \
-                       gsr_onesweep_available() ? g.os_scratch : nullptr, first_hist, first_hist_items)
+                       gsr_onesweep_available() ? g.os_scratch : nullptr, first_hist, first_hist_items, g.key_overflow)
     if (cam.sh_dc) GSR_PRE_FWD(true, false);
 #ifdef GSR_AB_VARIANTS
     else if (dma) GSR_PRE_FWD(false, true);
@@ -670,7 +669,7 @@ void gsr_launch_preprocess_geom(const GsrCamDev& cam, int P, const float* means3
                                 hipStream_t st) {
     hipLaunchKernelGGL(preprocess_geom_kernel, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, colors_precomp, opacities, scales,
                        rotations, cov3D_precomp, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], radii,
-                       gsr_onesweep_available() ? g.os_scratch : nullptr);
+                       gsr_onesweep_available() ? g.os_scratch : nullptr, g.key_overflow);
 }
 
 void gsr_launch_preprocess_color(const GsrCamDev& cam, int P, const float* means3D, const float* shs, GsrGeom g, hipStream_t st) {

@@ -216,10 +216,20 @@ constexpr int REC_STRIDE = 3;      // float4 per staged entry (48 B: 12-word str
 // Price: the survivor list of a wave is the UNION of its two quadrants' lists (measured on the bench frame: 0.58 of their sum).
 // p2 is computed by the forward's exact operation sequence (mul, fma, fma), so the hard masks agree with the forward's.
 // ------------------------------------------------------------------------------------------------
+// Round 3: the walk carries TWO values per pixel, (T, acc), instead of four.  The reference's lazy pair (last_alpha,
+// last_color) is folded eagerly: after an entry has used acc (= <running colour behind it, dL/dpix>) the entry itself is folded
+// in at once, acc <- fma(alpha, cD - acc, acc) -- the very expression (same operands, same rounding) that the lazy form
+// evaluates one active entry later, so results are bit-identical to round 2's kernel.  An entry that a pixel skips (behind
+// its last contributor, power > 0, alpha < 1/255) takes part with alpha = 0 and G = 0: then 1 - alpha = 1, rcp(1) = 1,
+// T * 1 = T, fma(0, x, acc) = acc and every gradient term is 0 * finite = 0 -- the state needs no select at all, and the
+// per-pixel select count drops from six (T, acc, last colour, last alpha, w, dL/dalpha) to two (alpha, G).
+// HAS_DEPTH = false (no gradient arrives for the inverse-depth image: train.py without depth supervision) drops the
+// 1/depth term of cD, the tenth gradient value and one cross-lane reduction.
 struct BwdPix2 {
-    v2f T, accD, lastD, last_alpha;
+    v2f T, acc;
 };
 
+template <bool HAS_DEPTH>
 __global__ void __launch_bounds__(64)
 render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                 const float4* __restrict__ splats, const float* __restrict__ final_T,
@@ -241,7 +251,7 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
     if (by0 >= cam.H) return;
     const int pxA = bx0 + (lane & 7), pxB = pxA + 8, py = by0 + (lane >> 3);
     const bool inA = pxA < cam.W && py < cam.H, inB = pxB < cam.W && py < cam.H;
-    const v2f pxf = {(float)pxA, (float)pxB};
+    const float pxfA = (float)pxA, pxfB = (float)pxB;
     const float pyf = (float)py;
     // boxes of the existing pixels of the two quadrants (the right one may be empty at the image border)
     const float y0 = (float)by0, y1 = (float)min(by0 + 7, cam.H - 1);
@@ -256,7 +266,8 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
     const v2f dLr = {inA ? dL_dpix[pixA] : 0.f, inB ? dL_dpix[pixB] : 0.f};
     const v2f dLg = {inA ? dL_dpix[HW + pixA] : 0.f, inB ? dL_dpix[HW + pixB] : 0.f};
     const v2f dLb = {inA ? dL_dpix[2 * HW + pixA] : 0.f, inB ? dL_dpix[2 * HW + pixB] : 0.f};
-    const v2f dLd = {(inA && dL_dinvdepth) ? dL_dinvdepth[pixA] : 0.f, (inB && dL_dinvdepth) ? dL_dinvdepth[pixB] : 0.f};
+    v2f dLd = {0.f, 0.f};
+    if (HAS_DEPTH) dLd = (v2f){inA ? dL_dinvdepth[pixA] : 0.f, inB ? dL_dinvdepth[pixB] : 0.f};
     const v2f Tf_bg = -T_final * (cam.bg[0] * dLr + cam.bg[1] * dLg + cam.bg[2] * dLb);
     uint32_t mxA = lastA, mxB = lastB;
 #pragma unroll
@@ -267,7 +278,7 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
     const uint32_t end = min(range.y - range.x, max(mxA, mxB));
     if (end == 0) return;
 
-    BwdPix2 s = {T_final, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    BwdPix2 s = {T_final, {0.f, 0.f}};
     float4* s_grad4 = reinterpret_cast<float4*>(s_grad);
     float4* slot = slot_grads + (int64_t)half * R * 3;
     const int nbatch = (int)((end + 63u) >> 6);
@@ -310,51 +321,63 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
             const bool doA = (maskA >> j) & 1ull, doB = (maskB >> j) & 1ull;      // wave-uniform
             const float4 r0 = s_rec[j * REC_STRIDE + 0];
             const float4 r1 = s_rec[j * REC_STRIDE + 1];
-            const float2 r2 = *reinterpret_cast<const float2*>(&s_rec[j * REC_STRIDE + 2]);
+            float r2x, r2y = 0.f;
+            if (HAS_DEPTH) { const float2 r2 = *reinterpret_cast<const float2*>(&s_rec[j * REC_STRIDE + 2]); r2x = r2.x; r2y = r2.y; }
+            else r2x = s_rec[j * REC_STRIDE + 2].x;
             const float a2 = r0.z, b2 = r0.w, c2 = r1.x, op = r1.y;
-            // ---- geometry: the forward's operation sequence per pixel (mul, fma, fma), two pixels per instruction ----
-            const v2f dx = (v2f){r0.x, r0.x} - pxf;
+            // ---- geometry: the forward's operation sequence per pixel (mul, fma, fma; blend_step_bf in render_fwd.hip), so
+            // that the hard masks agree with the forward's bit for bit ----
+            const float dxA = r0.x - pxfA, dxB = r0.x - pxfB;
             const float dy = r0.y - pyf;
             const float u = (c2 * dy) * dy;
-            const v2f t = (v2f){b2, b2} * (v2f){dy, dy} + a2 * dx;
-            const v2f p2 = dx * t + (v2f){u, u};
-            const v2f G = {__builtin_amdgcn_exp2f(p2.x), __builtin_amdgcn_exp2f(p2.y)};
-            const v2f opG = op * G;
-            const v2f alpha = {fminf(GSR_ALPHA_MAX, opG.x), fminf(GSR_ALPHA_MAX, opG.y)};
-            const bool actA = doA & (pos0 < lastA) & (p2.x <= 0.0f) & (alpha.x >= GSR_ALPHA_MIN);
-            const bool actB = doB & (pos0 < lastB) & (p2.y <= 0.0f) & (alpha.y >= GSR_ALPHA_MIN);
+            const float tA = fmaf(b2, dy, a2 * dxA), tB = fmaf(b2, dy, a2 * dxB);
+            const float p2A = fmaf(dxA, tA, u), p2B = fmaf(dxB, tB, u);
+            const float GA = __builtin_amdgcn_exp2f(p2A), GB = __builtin_amdgcn_exp2f(p2B);
+            const float alA = fminf(GSR_ALPHA_MAX, op * GA), alB = fminf(GSR_ALPHA_MAX, op * GB);
+            const bool actA = doA & (pos0 < lastA) & (p2A <= 0.0f) & (alA >= GSR_ALPHA_MIN);
+            const bool actB = doB & (pos0 < lastB) & (p2B <= 0.0f) & (alB >= GSR_ALPHA_MIN);
             if (__builtin_amdgcn_ballot_w64(actA | actB) == 0ull) continue;
-            // ---- recurrences (Appendix A.5), inactive pixels keep their state and produce zeros ----
-            const v2f cD = r1.z * dLr + r1.w * dLg + r2.x * dLb + r2.y * dLd;
+            // ---- the only selects of the step: a skipped pixel takes part with alpha = 0 and G = 0 ----
+            const v2f alpha = {actA ? alA : 0.0f, actB ? alB : 0.0f};
+            const v2f G = {actA ? GA : 0.0f, actB ? GB : 0.0f};
+            const v2f dx = {dxA, dxB};
+            // ---- recurrences (Appendix A.5) ----
+            v2f cD = r1.z * dLr + r1.w * dLg + r2x * dLb;
+            if (HAS_DEPTH) cD = cD + r2y * dLd;
             const v2f one_m = (v2f){1.0f, 1.0f} - alpha;
             const v2f inv1ma = {__builtin_amdgcn_rcpf(one_m.x), __builtin_amdgcn_rcpf(one_m.y)};
-            const v2f Tn = s.T * inv1ma;
-            const v2f accn = s.last_alpha * (s.lastD - s.accD) + s.accD;
-            v2f w = alpha * Tn;
-            v2f dL_dalpha = (cD - accn) * Tn + Tf_bg * inv1ma;
-            s.T = (v2f){actA ? Tn.x : s.T.x, actB ? Tn.y : s.T.y};
-            s.accD = (v2f){actA ? accn.x : s.accD.x, actB ? accn.y : s.accD.y};
-            s.lastD = (v2f){actA ? cD.x : s.lastD.x, actB ? cD.y : s.lastD.y};
-            s.last_alpha = (v2f){actA ? alpha.x : s.last_alpha.x, actB ? alpha.y : s.last_alpha.y};
-            w = (v2f){actA ? w.x : 0.0f, actB ? w.y : 0.0f};
-            dL_dalpha = (v2f){actA ? dL_dalpha.x : 0.0f, actB ? dL_dalpha.y : 0.0f};
-            // ---- the ten per-pair terms, the two pixels added per lane ----
-            const v2f gr2 = w * dLr, gg2 = w * dLg, gb2 = w * dLb, gd2 = w * dLd;
+            s.T = s.T * inv1ma;
+            const v2f diff = cD - s.acc;
+            const v2f dL_dalpha = diff * s.T + Tf_bg * inv1ma;
+            s.acc = (v2f){fmaf(alpha.x, diff.x, s.acc.x), fmaf(alpha.y, diff.y, s.acc.y)};
+            const v2f w = alpha * s.T;
+            // ---- the per-pair terms, the two pixels added per lane ----
+            const v2f gr2 = w * dLr, gg2 = w * dLg, gb2 = w * dLb;
             const v2f gop2 = G * dL_dalpha;
             const v2f m = op * gop2;
             const v2f mdx = m * dx;                 // m dx
             const v2f mdxx = mdx * dx;              // m dx^2
             const float msum = m.x + m.y, mdxsum = mdx.x + mdx.y;
             const float g_px = mdxsum, g_py = msum * dy, g_A = mdxx.x + mdxx.y, g_B = mdxsum * dy, g_C = (msum * dy) * dy;
-            const float g_op = gop2.x + gop2.y, g_r = gr2.x + gr2.y, g_g = gg2.x + gg2.y, g_b = gb2.x + gb2.y, g_d = gd2.x + gd2.y;
+            const float g_op = gop2.x + gop2.y, g_r = gr2.x + gr2.y, g_g = gg2.x + gg2.y, g_b = gb2.x + gb2.y;
             const float v0 = reduce4(g_px, g_A, g_py, g_B);     // -> slots 0,1,2,3
             const float v1 = reduce4(g_C, g_r, g_op, g_g);      // -> slots 4,5,6,7
-            const float v2 = reduce2(g_b, g_d);                 // -> slots 8 (lane 31), 9 (lane 63)
+            float v2;
+            if (HAS_DEPTH) {
+                const v2f gd2 = w * dLd;
+                v2 = reduce2(g_b, gd2.x + gd2.y);               // -> slots 8 (lane 31), 9 (lane 63)
+            } else {
+                v2 = wave_sum_to_lane63(g_b);                   // -> slot 8 (lane 63); slot 9 stays 0
+            }
             if ((lane & 15) == 15) {
                 float* o = s_grad + j * 12 + (lane >> 4);
                 o[0] = v0;
                 o[4] = v1;
-                if (lane & 16) s_grad[j * 12 + 8 + (lane >> 5)] = v2;
+                if (HAS_DEPTH) {
+                    if (lane & 16) s_grad[j * 12 + 8 + (lane >> 5)] = v2;
+                } else if (lane == 63) {
+                    *reinterpret_cast<float2*>(&s_grad[j * 12 + 8]) = make_float2(v2, 0.0f);
+                }
             }
             touched |= 1ull << j;
         }
@@ -898,9 +921,14 @@ void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const
 #endif
     (void)variant; (void)splat_grads; (void)groups;
     const int groups16 = (n_band_tiles + 15) / 16;
-    hipLaunchKernelGGL(render_bwd_half, dim3(groups16 * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list, splats,
-                       final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads),
-                       reinterpret_cast<uint8_t*>(inst_flag), R, counters);
+    if (dL_dinvdepth)
+        hipLaunchKernelGGL(render_bwd_half<true>, dim3(groups16 * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list, splats,
+                           final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads),
+                           reinterpret_cast<uint8_t*>(inst_flag), R, counters);
+    else
+        hipLaunchKernelGGL(render_bwd_half<false>, dim3(groups16 * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list, splats,
+                           final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads),
+                           reinterpret_cast<uint8_t*>(inst_flag), R, counters);
 }
 
 void gsr_launch_reduce_instances(int P, int64_t R, const uint32_t* order, const uint32_t* offsets, const float4* splats,

@@ -42,7 +42,7 @@ template <typename KeyT, int IPT, int BITS>
 __global__ void __launch_bounds__(RS_THREADS)
 rs_hist(const KeyT* __restrict__ keys, int64_t n, int shift, uint32_t* __restrict__ block_hist, int nblocks) {
     constexpr int NB = 1 << BITS;
-    constexpr int NCOPY = (NB <= 256) ? RS_WAVES : 1;     // per-wave copies only when they are cheap
+    constexpr int NCOPY = (NB <= 512) ? RS_WAVES : 1;     // per-wave copies only when they are cheap (<= 8 KB)
     __shared__ uint32_t h[NCOPY][NB];
     const int tid = threadIdx.x, w = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * (RS_THREADS * IPT);
@@ -555,6 +555,8 @@ void sort_pass_bits(int bits, KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vo
     }
     switch (bits) {
         case 11: sort_pass<KeyT, IPT, 11>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st); break;
+        case 10: sort_pass<KeyT, IPT, 10>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st); break;
+        case 9: sort_pass<KeyT, IPT, 9>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st); break;
         case 8: sort_pass<KeyT, IPT, 8>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st); break;
         case 7: sort_pass<KeyT, IPT, 7>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st); break;
         case 6: sort_pass<KeyT, IPT, 6>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st); break;
@@ -637,13 +639,13 @@ void gsr_launch_rs_scan(uint32_t* block_hist, int nblocks, int ndigits, uint32_t
 }
 
 int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits) {
-    // number of passes and bits per pass: ceil(nbits / max) passes of (almost) equal width, each in {4..8, 11}
+    // number of passes and bits per pass: ceil(nbits / max) passes of (almost) equal width, each in {4..11}
     int passes = (nbits + max_digit_bits - 1) / max_digit_bits;
     if (passes < 1) passes = 1;
     int left = nbits;
     for (int i = 0; i < passes; ++i) {
         int b = (left + (passes - i) - 1) / (passes - i);
-        if (b > 8 && b < 11) b = 11;
+        if (b > 11) b = 11;
         if (b < 4) b = 4;
         pass_bits[i] = b;
         left -= b;

@@ -227,12 +227,19 @@ class _RasterizeGaussians(torch.autograd.Function):
                               radii, geom.t, binning.t, img.t,
                               dc_c if dc_c is not None else means3D_c.new_empty(0))
         ctx.mark_non_differentiable(radii)
+        # an output nobody differentiates through (the inverse-depth image unless depth supervision is on, train.py:130-137)
+        # arrives in backward as None instead of a materialised zero image: the blend backward then runs its build without
+        # the 1/depth terms ("skip the invdepth terms when it is all-zero / None")
+        ctx.set_materialize_grads(False)
         return color, radii, invdepth
 
     @staticmethod
     def backward(ctx, grad_out_color, grad_radii, grad_out_depth):
         lib = _lib.load()
         (means3D, sh, col, op, sc, rot, cov, radii, geom, binning, img, dc) = ctx.saved_tensors
+        if grad_out_color is None:          # only the inverse-depth image was used
+            rs_ = ctx.raster_settings
+            grad_out_color = torch.zeros(3, int(rs_.image_height), int(rs_.image_width), dtype=torch.float32, device=means3D.device)
         has_sh, has_col, has_sc, has_rot, has_cov = ctx.flags
         rs = ctx.raster_settings
         device = means3D.device

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgsr_hip.so")
 
 GSR_OK = 0
-ABI_VERSION = 2
+ABI_VERSION = 3
 STAGES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "render", "render_bwd", "preprocess_bwd",
           "gather_bwd", "color", "r_wait"]
 
@@ -46,6 +46,7 @@ EXPORTS = [
     "gsr_backward_scratch_bytes",
     "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_backward_blend", "gsr_backward_preprocess",
     "gsr_preprocess_forward", "gsr_rasterize_from_splats",
+    "gsr_route_scratch_bytes", "gsr_route_count", "gsr_route_pack", "gsr_rasterize_from_packed", "gsr_route_return",
     "gsr_mark_visible", "gsr_forward_views", "gsr_adam_step", "gsr_sparse_adam_step", "gsr_ssim_forward", "gsr_ssim_backward",
     "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_ssim_partial_count", "gsr_ssim_mean_forward", "gsr_ssim_mean_backward",
     "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_profile_counters", "gsr_set_option",
@@ -79,6 +80,14 @@ def load() -> C.CDLL:
         pass
     lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
     lib.gsr_abi_version.restype = C.c_int
+    # the version is checked BEFORE any other symbol is bound: an older library (tools/build_prev_lib.sh, GSR_LIB=...) fails
+    # with this message instead of an AttributeError on a symbol it does not have yet
+    if lib.gsr_abi_version() != ABI_VERSION and os.environ.get("GSR_ALLOW_ABI_MISMATCH") != "1":
+        raise GsrError(f"{path}: ABI version {lib.gsr_abi_version()} != {ABI_VERSION} (set GSR_ALLOW_ABI_MISMATCH=1 to bind the "
+                       f"symbols both versions share, for A/B runs of an older revision)")
+    missing = [n for n in EXPORTS if not hasattr(lib, n)]
+    if missing and os.environ.get("GSR_ALLOW_ABI_MISMATCH") != "1":
+        raise GsrError(f"{path} does not export {missing}")
     lib.gsr_last_error.restype = C.c_char_p
     lib.gsr_geometry_bytes.restype = C.c_size_t
     lib.gsr_geometry_bytes.argtypes = [C.c_int]
@@ -111,6 +120,19 @@ def load() -> C.CDLL:
     lib.gsr_rasterize_from_splats.restype = C.c_int
     lib.gsr_rasterize_from_splats.argtypes = [C.POINTER(GsrRasterSettings), C.c_int, vp, RESIZE_FN, vp, RESIZE_FN, vp,
                                               RESIZE_FN, vp, vp, vp, C.POINTER(C.c_int32), vp]
+    if not missing or "gsr_route_count" not in missing:
+        i32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        lib.gsr_route_scratch_bytes.restype = C.c_size_t
+        lib.gsr_route_scratch_bytes.argtypes = [C.c_int, C.c_int]
+        lib.gsr_route_count.restype = C.c_int
+        lib.gsr_route_count.argtypes = [C.c_int, vp, C.c_int, i32p, vp, vp, vp]
+        lib.gsr_route_pack.restype = C.c_int
+        lib.gsr_route_pack.argtypes = [C.c_int, vp, C.c_int, i32p, i64p, vp, vp, vp, vp]
+        lib.gsr_rasterize_from_packed.restype = C.c_int
+        lib.gsr_rasterize_from_packed.argtypes = [C.POINTER(GsrRasterSettings), C.c_int, vp, RESIZE_FN, vp, RESIZE_FN, vp,
+                                                  RESIZE_FN, vp, vp, vp, C.POINTER(C.c_int32), vp]
+        lib.gsr_route_return.restype = C.c_int
+        lib.gsr_route_return.argtypes = [C.c_int, C.c_int, i64p, vp, vp, vp, vp]
     lib.gsr_adam_step.restype = C.c_int
     lib.gsr_adam_step.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, vp]
     lib.gsr_sparse_adam_step.restype = C.c_int
@@ -139,12 +161,11 @@ def load() -> C.CDLL:
     lib.gsr_profile_reset.restype = C.c_int
     lib.gsr_profile_read.restype = C.c_int
     lib.gsr_profile_read.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int]
-    lib.gsr_profile_counters.restype = C.c_int
-    lib.gsr_profile_counters.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.c_int]
+    if hasattr(lib, "gsr_profile_counters"):
+        lib.gsr_profile_counters.restype = C.c_int
+        lib.gsr_profile_counters.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.c_int]
     lib.gsr_set_option.restype = C.c_int
     lib.gsr_set_option.argtypes = [C.c_char_p, C.c_int]
-    if lib.gsr_abi_version() != ABI_VERSION:
-        raise GsrError(f"{path}: ABI version {lib.gsr_abi_version()} != {ABI_VERSION}")
     _lib = lib
     # measurement hook: GSR_OPTIONS="name=value,name=value" applies gsr_set_option switches at load time (A/B runs of the
     # test-suite and of bench.py without editing them); unknown names raise

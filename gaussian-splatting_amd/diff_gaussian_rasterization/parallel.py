@@ -18,6 +18,16 @@ B. REPLICATED PARAMETERS, BANDS ONLY (forward-only rendering; `render_sharded`, 
   * forward: ONE all_gather of the rendered strips (asynchronous form: gather_strips_async, frames pipelined);
   * backward (optional): ONE all_reduce of the [P,12] records, per-Gaussian backward replicated.
 
+C. GAUSSIAN-SHARDED WITH A DESTINATION-TARGETED EXCHANGE (round 3; `render_gaussian_sharded`, bench.py --gpus N)
+  * as A, but a projected splat travels only to the ranks whose band its tile rectangle touches: per-band stable
+    compaction into 48-byte packed records (gsr_route_count / gsr_route_pack), ONE variable-size all-to-all
+    (all_to_all_single) instead of the all-gather of every record, and the receiving rank bins + blends
+    (gsr_rasterize_from_packed) only the Gaussians of its band -- depth sort, scan, emission and tile sort shrink with
+    the band, which the replicated / all-gathered forms A and B cannot do;
+  * backward: blend backward on the received set -> the reverse all-to-all of the 48-byte gradient rows ->
+    gsr_route_return adds them into the shard's [P,12] record (band order, no atomics) -> per-Gaussian backward;
+  * one host sync per frame: the G x G count matrix (all-gather of G counters) sizes the exchange buffers.
+
 The band renderer / the two stages are injectable, so the index math and the collectives are tested on CPU with gloo
 and the oracle (tests/test_parallel_gloo.py); `hip_band_renderer` and `_TwoAxisHip` are the product's.
 """
@@ -94,18 +104,44 @@ class StripGather:
         return full
 
 
-def gather_strips_async(local: torch.Tensor, plan: BandPlan, H: int, group=None) -> StripGather:
-    """local: [C,H,W] with only this rank's rows valid.  Starts ONE all_gather of max-height padded strips (strips have
-    different heights under a balanced plan) and returns a handle; the collective runs on the backend's own stream, so
-    work enqueued afterwards (the next frame's rasterization) overlaps it."""
+class _StripGatherList:
+    """Exact-size form of StripGather: one receive buffer per rank (dist.all_gather with unequal sizes)."""
+
+    def __init__(self, bufs, rows, work):
+        self._bufs, self._rows, self._work, self._full = bufs, rows, work, None
+
+    def wait(self) -> torch.Tensor:
+        if self._full is None:
+            self._work.wait()
+            self._full = torch.cat(self._bufs, dim=1)
+            self._work = None
+        return self._full
+
+
+def gather_strips_async(local: torch.Tensor, plan: BandPlan, H: int, group=None, exact: Optional[bool] = None):
+    """local: [C,H,W] with only this rank's rows valid.  Starts ONE all-gather of the strips and returns a handle with
+    .wait(); the collective runs on the backend's own stream, so work enqueued afterwards (the next frame's
+    rasterization) overlaps it.  Strips have different heights under a balanced plan: with RCCL (`exact`, default on
+    for backend "nccl") every strip travels at its exact size (all_gather with unequal tensors = grouped broadcasts);
+    otherwise -- gloo, or if the exact form is refused -- strips are padded to the tallest band."""
     world = _world(group)
     if world == 1:
         return StripGather(local, None, None, None)
     rank = dist.get_rank(group)
     C, _, W = local.shape
     rows = [plan.pixel_rows(g, H) for g in range(world)]
-    hmax = max(1, max(b - a for a, b in rows))
+    heights = [b - a for a, b in rows]
     a, b = rows[rank]
+    if exact is None:
+        exact = dist.get_backend(group) == "nccl"
+    if exact and len(set(heights)) > 1 and min(heights) > 0:
+        try:
+            bufs = [local.new_empty(C, h, W) for h in heights]
+            work = dist.all_gather(bufs, local[:, a:b].contiguous(), group=group, async_op=True)
+            return _StripGatherList(bufs, rows, work)
+        except Exception:      # backend without unequal all_gather: padded form below
+            pass
+    hmax = max(1, max(heights))
     send = local.new_empty(C, hmax, W)          # padding rows are never read back
     send[:, : b - a] = local[:, a:b]
     recv = local.new_empty(world, C, hmax, W)
@@ -361,3 +397,282 @@ def render_two_axis(raster_settings, means3D, sh, opacities, scales, rotations, 
     H = color.shape[1]
     both = _GatherStrips.apply(torch.cat([color, invdepth], dim=0), plan, H, group)
     return both[:3], radii, both[3:4]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# C. Gaussian-sharded rendering with a destination-targeted exchange of packed splat records (round 3)
+# ------------------------------------------------------------------------------------------------------------------
+PACKED_WORDS = 12      # 48-byte packed record: x, y, conA, conB | conC, opacity, r, g | b, depth, rect.x bits, rect.y bits
+
+
+def exchange_counts(counts: torch.Tensor, group=None) -> Tuple[List[int], List[int]]:
+    """counts[G] (this rank's records per destination band, on the collective's device) -> (send_counts, recv_counts) as
+    Python lists: ONE all-gather of the G counters gives every rank the G x G matrix, and its read-back is the single host
+    sync of a Gaussian-sharded frame (all_to_all_single needs the split sizes on the host)."""
+    world = _world(group)
+    if world == 1:
+        n = int(counts.sum().item())
+        return [n], [n]
+    rank = dist.get_rank(group)
+    c = counts.to(torch.int64).contiguous()
+    mat = torch.empty(world * c.numel(), dtype=torch.int64, device=c.device)
+    dist.all_gather_into_tensor(mat, c, group=group)
+    mat = mat.view(world, -1).cpu()
+    return mat[rank].tolist(), mat[:, rank].tolist()
+
+
+def all_to_all_rows(send: torch.Tensor, send_counts: Sequence[int], recv_counts: Sequence[int], group=None, async_op: bool = False):
+    """send[sum(send_counts), K] rows grouped by destination -> recv[sum(recv_counts), K] rows grouped by source rank.
+    Returns (recv, work) -- work is None unless async_op."""
+    world = _world(group)
+    recv = send.new_empty(int(sum(recv_counts)), *send.shape[1:])
+    if world == 1:
+        recv.copy_(send)
+        return recv, None
+    work = dist.all_to_all_single(recv, send.contiguous(), [int(c) for c in recv_counts], [int(c) for c in send_counts],
+                                  group=group, async_op=async_op)
+    return recv, (work if async_op else None)
+
+
+class _ExchangeRows(torch.autograd.Function):
+    """Differentiable all_to_all_rows (the oracle path of the gloo tests; the HIP path issues the same two collectives
+    around its fused kernels): backward = the reverse all-to-all of the gradient rows."""
+
+    @staticmethod
+    def forward(ctx, send, send_counts, recv_counts, group):
+        ctx.meta = (list(send_counts), list(recv_counts), group)
+        return all_to_all_rows(send, send_counts, recv_counts, group)[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        send_counts, recv_counts, group = ctx.meta
+        return all_to_all_rows(g.contiguous(), recv_counts, send_counts, group)[0], None, None, None
+
+
+def exchange_rows(send: torch.Tensor, send_counts, recv_counts, group=None) -> torch.Tensor:
+    return _ExchangeRows.apply(send, send_counts, recv_counts, group)
+
+
+def route_plan_torch(miny: torch.Tensor, maxy: torch.Tensor, tiles: torch.Tensor, bounds: Sequence[int]):
+    """Reference semantics of gsr_route_count / gsr_route_pack in torch (CPU tests; checked against the HIP kernels on the
+    GPU): a record goes to band b iff it has tiles and its tile rows [miny, maxy) intersect [bounds[b], bounds[b+1]).
+    Returns (send_index int64 -- Gaussian indices grouped by band, ascending inside a band -- , counts list)."""
+    idx, counts = [], []
+    for b in range(len(bounds) - 1):
+        m = (tiles > 0) & (miny.clamp_min(bounds[b]) < maxy.clamp_max(bounds[b + 1]))      # (an empty band receives nothing)
+        sel = torch.nonzero(m, as_tuple=False).flatten()
+        idx.append(sel)
+        counts.append(int(sel.numel()))
+    return (torch.cat(idx) if idx else miny.new_zeros(0, dtype=torch.int64)), counts
+
+
+def _i32_array(vals):
+    import ctypes as C
+    return (C.c_int32 * len(vals))(*[int(v) for v in vals])
+
+
+def _i64_array(vals):
+    import ctypes as C
+    return (C.c_int64 * len(vals))(*[int(v) for v in vals])
+
+
+def hip_preprocess_shard(raster_settings, means3D, sh, opacities, scales, rotations, dc=None):
+    """gsr_preprocess_forward on this rank's shard: (records[P,16], radii[P], M, contiguous inputs)."""
+    import ctypes as C
+    from . import _lib, _sized, _f32c, _make_settings, _ptr, _stream_ptr, _require_cuda
+    lib = _lib.load()
+    _require_cuda(means3D, "means3D")
+    device = means3D.device
+    P = int(means3D.shape[0])
+    m_c, sh_c, op_c, sc_c, rot_c, dc_c = (_f32c(t) for t in (means3D, sh, opacities, scales, rotations, dc))
+    M = int(sh_c.shape[1]) + (1 if dc_c is not None else 0)
+    if dc_c is not None and (M != 16 or dc_c.data_ptr() % 16 or sh_c.data_ptr() % 16):
+        raise _lib.GsrError("sharded renderer: the split SH form needs degree-3 storage (dc[P,1,3] + shs[P,15,3])")
+    keep: list = []
+    with torch.cuda.device(device):
+        s = _make_settings(raster_settings, keep, None, False)
+        if dc_c is not None:
+            s.sh_dc = dc_c.data_ptr()
+        records = torch.empty(P, 16, dtype=torch.float32, device=device)
+        radii = torch.empty(P, dtype=torch.int32, device=device)
+        scratch = torch.empty(_sized("geom_shard", device, lib.gsr_geometry_bytes(P)), dtype=torch.uint8, device=device)
+        _lib.check(lib.gsr_preprocess_forward(C.byref(s), P, M, _ptr(m_c), _ptr(sh_c), None, _ptr(op_c), _ptr(sc_c),
+                                              _ptr(rot_c), None, _ptr(scratch), _ptr(radii), _ptr(records), _stream_ptr(device)),
+                   "gsr_preprocess_forward")
+    return records, radii, M, (m_c, sh_c, op_c, sc_c, rot_c, dc_c)
+
+
+def hip_route_count(records: torch.Tensor, bounds: Sequence[int]):
+    """gsr_route_count: (counts int32[G] on the device, scratch) -- no host sync."""
+    import ctypes as C
+    from . import _lib, _ptr, _stream_ptr
+    lib = _lib.load()
+    device = records.device
+    P, G = int(records.shape[0]), len(bounds) - 1
+    with torch.cuda.device(device):
+        scratch = torch.empty(max(128, lib.gsr_route_scratch_bytes(P, G)), dtype=torch.uint8, device=device)
+        counts = torch.empty(G, dtype=torch.int32, device=device)
+        _lib.check(lib.gsr_route_count(P, _ptr(records), G, _i32_array(bounds), _ptr(scratch), _ptr(counts), _stream_ptr(device)),
+                   "gsr_route_count")
+    return counts, scratch
+
+
+def hip_route_pack(records: torch.Tensor, bounds: Sequence[int], send_counts: Sequence[int], scratch: torch.Tensor):
+    """gsr_route_pack: (packed[sum,12], send_ids int32[sum], offsets list of G+1)."""
+    import ctypes as C
+    from . import _lib, _ptr, _stream_ptr
+    lib = _lib.load()
+    device = records.device
+    P, G = int(records.shape[0]), len(bounds) - 1
+    offsets = [0]
+    for c in send_counts:
+        offsets.append(offsets[-1] + int(c))
+    with torch.cuda.device(device):
+        packed = torch.empty(offsets[-1], PACKED_WORDS, dtype=torch.float32, device=device)
+        send_ids = torch.empty(offsets[-1], dtype=torch.int32, device=device)
+        _lib.check(lib.gsr_route_pack(P, _ptr(records), G, _i32_array(bounds), _i64_array(offsets), _ptr(scratch), _ptr(packed),
+                                      _ptr(send_ids), _stream_ptr(device)), "gsr_route_pack")
+    return packed, send_ids, offsets
+
+
+def hip_render_packed(raster_settings, band, recv: torch.Tensor, no_backward: bool):
+    """gsr_rasterize_from_packed on this rank's band: (color[3,H,W], invdepth[1,H,W], state) with only the band's rows
+    written (zeros elsewhere); state = (geom, binning, img, num_rendered) for gsr_backward_blend."""
+    import ctypes as C
+    from . import _lib, _Buffer, _make_settings, _ptr, _stream_ptr
+    lib = _lib.load()
+    device = recv.device
+    H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+    keep: list = []
+    with torch.cuda.device(device):
+        s = _make_settings(raster_settings, keep, band, no_backward)
+        color = torch.zeros(3, H, W, dtype=torch.float32, device=device)
+        invdepth = torch.zeros(1, H, W, dtype=torch.float32, device=device)
+        geom, binning, img = _Buffer(device, "geom"), _Buffer(device, "binning"), _Buffer(device, "image")
+        nr = C.c_int32(0)
+        _lib.check(lib.gsr_rasterize_from_packed(C.byref(s), int(recv.shape[0]), _ptr(recv), geom.cb, None, binning.cb, None,
+                                                 img.cb, None, _ptr(color), _ptr(invdepth), C.byref(nr), _stream_ptr(device)),
+                   "gsr_rasterize_from_packed")
+    return color, invdepth, (geom.t, binning.t, img.t, int(nr.value))
+
+
+class _GaussianShardedHip(torch.autograd.Function):
+    """Mode C for one rank: local shard of Gaussians in, the rank's band of the image out (see the module docstring)."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, raster_settings, plan, group, dc):
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        bounds = list(plan.bounds)
+        records, radii, M, (m_c, sh_c, op_c, sc_c, rot_c, dc_c) = hip_preprocess_shard(raster_settings, means3D, sh, opacities,
+                                                                                      scales, rotations, dc)
+        counts, rscratch = hip_route_count(records, bounds)
+        send_counts, recv_counts = exchange_counts(counts, group)                    # the frame's one host sync
+        packed, send_ids, offsets = hip_route_pack(records, bounds, send_counts, rscratch)
+        recv, _ = all_to_all_rows(packed, send_counts, recv_counts, group)
+        no_backward = not (any(ctx.needs_input_grad[:6]) or ctx.needs_input_grad[9])
+        color, invdepth, (geom, binning, img, nr) = hip_render_packed(raster_settings, plan.band(rank), recv, no_backward)
+        ctx.raster_settings, ctx.band, ctx.group, ctx.M = raster_settings, plan.band(rank), group, M
+        ctx.send_counts, ctx.recv_counts, ctx.offsets = send_counts, recv_counts, offsets
+        ctx.P_recv, ctx.num_rendered = int(recv.shape[0]), nr
+        ctx.has_means2D, ctx.has_dc = means2D is not None, dc_c is not None
+        ctx.op_shape = tuple(opacities.shape)
+        ctx.dc_shape = tuple(dc.shape) if dc is not None else None
+        ctx.save_for_backward(m_c, sh_c, op_c, sc_c, rot_c, radii, geom, binning, img, send_ids,
+                              dc_c if dc_c is not None else m_c.new_empty(0))
+        ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)
+        return color, radii, invdepth
+
+    @staticmethod
+    def backward(ctx, g_color, g_radii, g_depth):
+        import ctypes as C
+        from . import _lib, _sized, _f32c, _make_settings, _ptr, _stream_ptr
+        lib = _lib.load()
+        m, sh, op, sc, rot, radii, geom, binning, img, send_ids, dc = ctx.saved_tensors
+        device = m.device
+        P, P_recv, M = int(m.shape[0]), ctx.P_recv, ctx.M
+        rs = ctx.raster_settings
+        f = dict(dtype=torch.float32, device=device)
+        if g_color is None:
+            g_color = torch.zeros(3, int(rs.image_height), int(rs.image_width), **f)
+        d_m2, d_col, d_op = torch.empty(P, 3, **f), torch.empty(P, 3, **f), torch.empty(P, 1, **f)
+        d_m3, d_cov = torch.empty(P, 3, **f), torch.empty(P, 6, **f)
+        d_sh = torch.empty(P, M - 1 if ctx.has_dc else M, 3, **f)
+        d_dc = torch.empty(P, 1, 3, **f) if ctx.has_dc else None
+        d_sc, d_rot = torch.empty(P, 3, **f), torch.empty(P, 4, **f)
+        keep: list = []
+        with torch.cuda.device(device):
+            st = _stream_ptr(device)
+            s = _make_settings(rs, keep, ctx.band)
+            if ctx.has_dc:
+                s.sh_dc, s.dL_dsh_dc = dc.data_ptr(), d_dc.data_ptr()
+            if P_recv > 0:
+                scratch = torch.empty(_sized("bwd", device, lib.gsr_backward_scratch_bytes(P_recv, ctx.num_rendered)),
+                                      dtype=torch.uint8, device=device)
+                rec_ptr = C.c_void_p(0)
+                gc = _f32c(g_color)
+                gd = _f32c(g_depth) if g_depth is not None else None
+                _lib.check(lib.gsr_backward_blend(C.byref(s), P_recv, ctx.num_rendered, _ptr(geom), _ptr(binning), _ptr(img),
+                                                  _ptr(gc), _ptr(gd), _ptr(scratch), C.byref(rec_ptr), st), "gsr_backward_blend")
+                off = int(rec_ptr.value) - scratch.data_ptr()
+                full = scratch[off:off + P_recv * 48].view(torch.float32).view(P_recv, 12)
+            else:
+                full = torch.empty(0, 12, **f)
+            returned, _ = all_to_all_rows(full, ctx.recv_counts, ctx.send_counts, ctx.group)      # rows back to their owners
+            if P > 0:
+                mine = torch.empty(P, 12, **f)
+                _lib.check(lib.gsr_route_return(P, len(ctx.send_counts), _i64_array(ctx.offsets), _ptr(send_ids), _ptr(returned),
+                                                _ptr(mine), st), "gsr_route_return")
+                _lib.check(lib.gsr_backward_preprocess(C.byref(s), P, M, _ptr(m), _ptr(sh), None, _ptr(op), _ptr(sc), _ptr(rot),
+                                                       None, _ptr(radii), None, _ptr(mine), _ptr(d_m2), _ptr(d_col), _ptr(d_op),
+                                                       _ptr(d_m3), _ptr(d_cov), _ptr(d_sh), _ptr(d_sc), _ptr(d_rot), st),
+                           "gsr_backward_preprocess")
+        return (d_m3, d_m2 if ctx.has_means2D else None, d_sh, d_op.view(ctx.op_shape), d_sc, d_rot, None, None, None,
+                d_dc.view(ctx.dc_shape) if ctx.has_dc else None)
+
+
+def render_gaussian_sharded(raster_settings, means3D, sh, opacities, scales, rotations, plan: BandPlan, group=None,
+                            means2D=None, dc=None, gather_invdepth: bool = True):
+    """Mode C render of one frame: this rank's shard of Gaussians in, the FULL image (strips all-gathered) out.  Shards must
+    be contiguous index ranges in rank order (ties in depth resolve by global index, as on one GPU).  Returns
+    (color[3,H,W], radii[P_local], invdepth[1,H,W]); gradients flow to the rank's own shard only.
+    gather_invdepth=False: only the colour strips are gathered (invdepth then holds this rank's band only) -- what a
+    training step without depth supervision needs; the blend backward then runs its build without the 1/depth terms."""
+    color, radii, invdepth = _GaussianShardedHip.apply(means3D, means2D, sh, opacities, scales, rotations, raster_settings,
+                                                       plan, group, dc)
+    H = color.shape[1]
+    if gather_invdepth:
+        both = _GatherStrips.apply(torch.cat([color, invdepth], dim=0), plan, H, group)
+        return both[:3], radii, both[3:4]
+    return _GatherStrips.apply(color, plan, H, group), radii, invdepth
+
+
+class ShardedFrame:
+    """A forward-only mode-C frame in flight (bench.py's pipelined forward): begin() has projected, routed and launched the
+    all-to-all; finish() waits for it, renders the band and launches the strip all-gather."""
+    __slots__ = ("rs", "plan", "group", "recv", "work", "radii", "keep")
+
+
+def sharded_forward_begin(raster_settings, means3D, sh, opacities, scales, rotations, plan: BandPlan, group=None, dc=None) -> ShardedFrame:
+    fr = ShardedFrame()
+    with torch.no_grad():
+        records, radii, _, keep = hip_preprocess_shard(raster_settings, means3D, sh, opacities, scales, rotations, dc)
+        bounds = list(plan.bounds)
+        counts, rscratch = hip_route_count(records, bounds)
+        send_counts, recv_counts = exchange_counts(counts, group)
+        packed, _, _ = hip_route_pack(records, bounds, send_counts, rscratch)
+        fr.recv, fr.work = all_to_all_rows(packed, send_counts, recv_counts, group, async_op=True)
+        fr.keep = (packed, records)      # alive until the collective has read them
+    fr.rs, fr.plan, fr.group, fr.radii = raster_settings, plan, group, radii
+    return fr
+
+
+def sharded_forward_finish(fr: ShardedFrame):
+    """-> handle with .wait() -> full colour image [3,H,W] on every rank."""
+    rank = dist.get_rank(fr.group) if dist.is_initialized() else 0
+    with torch.no_grad():
+        if fr.work is not None:
+            fr.work.wait()
+        color, _, _ = hip_render_packed(fr.rs, fr.plan.band(rank), fr.recv, True)
+        fr.keep = None
+        return gather_strips_async(color, fr.plan, int(fr.rs.image_height), fr.group)

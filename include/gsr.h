@@ -14,8 +14,9 @@
  *   - plain C: pointers + sizes only, no torch / C++ types; every data pointer is a DEVICE pointer
  *     (tensor.data_ptr()) to contiguous fp32 / int32 data unless stated otherwise.
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream).
- *     gsr_rasterize_forward synchronises that stream once (the 4-byte num_rendered read-back that
- *     sizes the binning buffer -- the reference has the same sync).
+ *     gsr_rasterize_forward learns num_rendered (it sizes the binning buffer) mid-pipeline like the reference, but
+ *     without hipStreamSynchronize: the scan kernel stores the 64-bit count + a sequence number into a mapped, pinned
+ *     host word and the calling thread polls it (200 us of spinning, then sched_yield() between polls).
  *   - return value: GSR_OK (0) or a negative GsrStatus; gsr_last_error() gives the message for the
  *     calling thread.  No exception crosses the ABI.
  *   - no device allocation inside: scratch memory is caller-owned and obtained through the three
@@ -33,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 2
+#define GSR_ABI_VERSION 3
 
 typedef enum GsrStatus {
     GSR_OK = 0,
@@ -185,6 +186,35 @@ int gsr_rasterize_from_splats(const GsrRasterSettings* settings, int P, const fl
                               GsrResizeFn binning_resize, void* binning_user,
                               GsrResizeFn image_resize, void* image_user,
                               float* out_color, float* out_invdepth, int32_t* num_rendered, void* stream);
+
+/*
+ * Gaussian-sharded rendering (round 3; SURVEY.md 8(e), no reference counterpart): like the two-axis form, but the projected
+ * splats are sent only where they are needed.  Rank g projects its P/G Gaussians (gsr_preprocess_forward), finds for every
+ * band of tile rows [band_bounds[b], band_bounds[b+1]) the records whose tile rectangle touches it (gsr_route_count ->
+ * band_counts, which the ranks exchange to size the buffers), packs them STABLY per band as 48-byte records
+ * (x, y, conA, conB | conC, opacity, r, g | b, depth, rect.x bits, rect.y bits) together with their shard-local indices
+ * (gsr_route_pack), and a variable-size all-to-all delivers segment b to rank b.  The receiver concatenates the segments in
+ * rank order (= global Gaussian order when shards are contiguous index ranges, so depth ties resolve as on one GPU) and
+ * calls gsr_rasterize_from_packed on its band: depth sort, scan, emission and tile sort then run on the band's Gaussians
+ * only.  Backward: gsr_backward_blend on the received set -> reverse all-to-all of the [n,12] gradient rows ->
+ * gsr_route_return adds the returned rows into splat_grads[P,12] of the shard (band order, no atomics, deterministic) ->
+ * gsr_backward_preprocess.
+ *   band_bounds : HOST array of n_bands + 1 tile-row indices (n_bands <= 64);  band_counts : DEVICE uint32[n_bands]
+ *   band_offsets: HOST array of n_bands + 1 row offsets into packed / send_ids (exclusive scan of the counts)
+ *   scratch     : gsr_route_scratch_bytes(P, n_bands) bytes, filled by gsr_route_count and read by gsr_route_pack
+ */
+size_t gsr_route_scratch_bytes(int P, int n_bands);
+int gsr_route_count(int P, const float* splat_records, int n_bands, const int32_t* band_bounds, void* scratch,
+                    uint32_t* band_counts, void* stream);
+int gsr_route_pack(int P, const float* splat_records, int n_bands, const int32_t* band_bounds, const int64_t* band_offsets,
+                   const void* scratch, float* packed, int32_t* send_ids, void* stream);
+int gsr_rasterize_from_packed(const GsrRasterSettings* settings, int P, const float* packed_records,
+                              GsrResizeFn geom_resize, void* geom_user,
+                              GsrResizeFn binning_resize, void* binning_user,
+                              GsrResizeFn image_resize, void* image_user,
+                              float* out_color, float* out_invdepth, int32_t* num_rendered, void* stream);
+int gsr_route_return(int P, int n_bands, const int64_t* band_offsets, const int32_t* send_ids, const float* returned,
+                     float* splat_grads, void* stream);
 
 /*
  * Fused dense Adam step on one fp32 tensor of n elements (the optimizer step of train.py:177-186).

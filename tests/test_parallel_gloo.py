@@ -234,3 +234,117 @@ def test_two_axis_sharding_equals_single_device(world):
         for got, want in zip(o["grads"], ref):
             scale = want.abs().max().item() + 1e-30
             assert (got - want[a:b]).abs().max().item() <= 3e-5 * scale
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# mode C: Gaussian-sharded forward with the destination-targeted all-to-all (parallel.render_gaussian_sharded)
+# ------------------------------------------------------------------------------------------------------------------
+def _oracle_gaussian_sharded(leaves, m2, s, plan, rank, gid0):
+    """The mode-C flow with the oracle as both stages: local preprocess -> route (which band needs which record) ->
+    count exchange -> differentiable variable-size all-to-all (backward = the reverse exchange + index_add = the HIP path's
+    gsr_route_return) -> band clamp -> bin + blend on the own band -> strips.  Returns the image, the local radii and the
+    band's bins expressed in GLOBAL Gaussian ids."""
+    from diff_gaussian_rasterization.parallel import exchange_counts, exchange_rows, route_plan_torch, _GatherStrips
+    m, sh, o, scl, rot = leaves
+    pre = O.preprocess(m, o, s, shs=sh, scales=scl, rotations=rot, means2D=m2)              # full frame
+    P = m.shape[0]
+    diff = torch.cat([pre["means2D"], pre["conic"], pre["opacity"][:, None], pre["rgb"], pre["depths"][:, None]], dim=1)
+    gid = (torch.arange(P, dtype=torch.int64) + gid0).to(diff.dtype)
+    ints = torch.cat([pre["rect"].to(diff.dtype), gid[:, None]], dim=1)                       # full-frame rectangle + global id
+    rows = torch.cat([diff, ints], dim=1)
+    send_index, counts = route_plan_torch(pre["rect"][:, 1], pre["rect"][:, 3], pre["tiles_touched"], plan.bounds)
+    send_counts, recv_counts = exchange_counts(torch.tensor(counts, dtype=torch.int64))
+    assert send_counts == counts
+    recv = exchange_rows(rows.index_select(0, send_index), send_counts, recv_counts)
+    y0, y1 = plan.band(rank)
+    rect = recv[:, 10:14].detach().to(torch.int64)
+    bminy, bmaxy = rect[:, 1].clamp(y0, y1), rect[:, 3].clamp(y0, y1)
+    tiles = (rect[:, 2] - rect[:, 0]) * (bmaxy - bminy)
+    assert bool((tiles > 0).all())                                                           # only records that touch the band arrive
+    pre_band = {"means2D": recv[:, 0:2], "conic": recv[:, 2:5], "opacity": recv[:, 5], "rgb": recv[:, 6:9], "depths": recv[:, 9],
+                "tiles_touched": tiles, "rect": torch.stack([rect[:, 0], bminy, rect[:, 2], bmaxy], dim=1),
+                "grid": pre["grid"], "band": (y0, y1)}
+    bins = O.bin_and_sort(pre_band)
+    color, invd, *_ = O.render_tiles(pre_band, bins, s)
+    color = color + 0.0 * recv.sum()      # a rank with an empty band must still take part in the backward's collectives
+    H = color.shape[1]
+    both = _GatherStrips.apply(torch.cat([color, invd], dim=0), plan, H, None)
+    gids = recv[:, 14].detach().to(torch.int64)
+    return both[:3], pre["radii"], both[3:4], {"ranges": bins["ranges"], "point_gid": gids[bins["point_list"]],
+                                                "n_recv": int(recv.shape[0]), "send_counts": send_counts}
+
+
+def _gaussian_sharded_worker(rank, world, port, path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from diff_gaussian_rasterization.parallel import BandPlan
+    cam = make_camera(112, 96)
+    sc = make_edge_scene(500, cam, seed=33)
+    s = oracle_settings(cam, bg=torch.tensor([0.2, 0.4, 0.6]))
+    plan = {2: BandPlan([0, 2, 6]), 3: BandPlan([0, 1, 4, 6]), 4: BandPlan([0, 1, 3, 3, 6])}[world]      # world 4: an EMPTY band
+    cuts = {2: [0, 230, 500], 3: [0, 100, 333, 500], 4: [0, 100, 100, 333, 500]}[world]                   # world 4: an EMPTY shard
+    a, b = cuts[rank], cuts[rank + 1]
+    leaves = [t[a:b].clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+    m2 = torch.zeros(b - a, 3, requires_grad=True)
+    color, radii, invd, band_bins = _oracle_gaussian_sharded(leaves, m2, s, plan, rank, a)
+    g = torch.Generator().manual_seed(7)
+    wc, wd = torch.randn(3, 96, 112, generator=g), torch.randn(1, 96, 112, generator=g)
+    ((color * wc).sum() + (invd * wd).sum()).backward()
+    torch.save({"color": color.detach(), "invd": invd.detach(), "radii": radii, "cut": (a, b), "band": plan.band(rank),
+                "bins": band_bins, "grads": [t.grad for t in leaves] + [m2.grad]}, path % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_gaussian_sharded_equals_single_device(world):
+    """Mode C: Gaussian-sharded preprocess + destination-targeted all-to-all + band blend + reverse
+    exchange of the gradient rows, against the single-device oracle: same image on every rank, each rank's parameter
+    gradients equal its slice of the single-device gradients, and every band's bins (tile ranges + point list in global
+    Gaussian ids) are BIT-EXACT the single-device bins of that band's tiles.  Uneven shards / bands, an empty shard and an
+    empty band (world 4)."""
+    import tempfile
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "rank%d.pt")
+        procs = [ctx.Process(target=_gaussian_sharded_worker, args=(r, world, port, path)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        outs = [torch.load(path % r) for r in range(world)]
+    cam = make_camera(112, 96)
+    sc = make_edge_scene(500, cam, seed=33)
+    s = oracle_settings(cam, bg=torch.tensor([0.2, 0.4, 0.6]))
+    leaves = [t.clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+    m2 = torch.zeros(sc.P, 3, requires_grad=True)
+    color, radii, invd, aux = O.rasterize(leaves[0], m2, leaves[2], s, shs=leaves[1], scales=leaves[3], rotations=leaves[4],
+                                          return_aux=True)
+    g = torch.Generator().manual_seed(7)
+    wc, wd = torch.randn(3, 96, 112, generator=g), torch.randn(1, 96, 112, generator=g)
+    ((color * wc).sum() + (invd * wd).sum()).backward()
+    ref = [t.grad for t in leaves] + [m2.grad]
+    gx = 7
+    visible = int((aux["tiles_touched"] > 0).sum())
+    total_sent = sum(sum(o["bins"]["send_counts"]) for o in outs)
+    assert visible <= total_sent < world * visible                 # targeted: fewer rows than an all-gather of the visible ones
+    for o in outs:
+        a, b = o["cut"]
+        assert torch.equal(o["radii"], radii[a:b])
+        assert (o["color"] - color.detach()).abs().max().item() <= 3e-6 and (o["invd"] - invd.detach()).abs().max().item() <= 3e-6
+        for got, want in zip(o["grads"], ref):
+            scale = want.abs().max().item() + 1e-30
+            assert got.shape == want[a:b].shape
+            if b > a:                                   # (world 4 has an empty shard)
+                assert (got - want[a:b]).abs().max().item() <= 3e-5 * scale
+        # bins of the band, bit-exact: same per-tile counts and the same Gaussians in the same order
+        y0, y1 = o["band"]
+        for t in range(y0 * gx, y1 * gx):
+            ra, rb = (int(v) for v in aux["ranges"][t])
+            ba, bb = (int(v) for v in o["bins"]["ranges"][t])
+            assert rb - ra == bb - ba
+            assert torch.equal(o["bins"]["point_gid"][ba:bb], aux["point_list"][ra:rb])
