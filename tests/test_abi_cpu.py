@@ -29,7 +29,7 @@ def test_header_symbols_are_exported(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gsr.h but not exported"
-    assert lib.gsr_abi_version() == 2
+    assert lib.gsr_abi_version() == 3
 
 
 def test_scratch_sizes(lib):
@@ -157,4 +157,4 @@ int main(void) {
                            str(src), so, "-Wl,-rpath," + os.path.dirname(so), "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
-    assert "abi 2 ok" in out.stdout
+    assert "abi 3 ok" in out.stdout
