@@ -248,6 +248,7 @@ splat_ingest(int P, const float4* __restrict__ records, int y0, int y1, float4* 
              uint32_t* __restrict__ sort_state, uint32_t* key_overflow) {
     if (sort_state && blockIdx.x == 0)
         for (int i = threadIdx.x; i < GSR_OS_STATE_WORDS; i += 256) sort_state[i] = 0u;
+    bool key_ovf = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 q0 = records[i * 4 + 0], q1 = records[i * 4 + 1], q2 = records[i * 4 + 2], q3 = records[i * 4 + 3];
         const uint32_t rx = __float_as_uint(q3.x), ry = __float_as_uint(q3.y), full = __float_as_uint(q3.w);
@@ -262,9 +263,10 @@ splat_ingest(int P, const float4* __restrict__ records, int y0, int y1, float4* 
         splats[i * 4 + 3] = make_float4(__uint_as_float(rc.x), __uint_as_float(rc.y), 0.f, __uint_as_float(t));
         rect[i] = rc;
         tiles[i] = t;
-        keys[i] = gsr_depth_key(q2.y, t != 0u, key_overflow);      // q2.y = view-space depth
+        keys[i] = gsr_depth_key(q2.y, t != 0u, key_ovf);      // q2.y = view-space depth
         vals[i] = (uint32_t)i;
     }
+    gsr_report_key_overflow(key_ovf, key_overflow);
 }
 
 // fallback of the 27-bit depth sort (a listed Gaussian deeper than 13 107): the full 32-bit keys of round 2

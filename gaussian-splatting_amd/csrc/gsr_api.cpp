@@ -1013,6 +1013,32 @@ int gsr_ssim_mean_backward(int planes, int H, int W, const float* img1, const fl
     return GSR_OK;
 }
 
+int gsr_train_loss_forward(int planes, int H, int W, const float* img1, const float* img2, float lambda_dssim, float* partials,
+                           float* loss_out, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream) {
+    if (planes <= 0 || H <= 0 || W <= 0) return fail(GSR_ERR_INVALID_ARG, "bad image size");
+    if (planes > 65535) return fail(GSR_ERR_UNSUPPORTED, "more than 65535 image planes");
+    if (gsr_ssim_partial_count_impl(planes, H, W) > 0x3FFFFFFFll) return fail(GSR_ERR_UNSUPPORTED, "too many tiles");
+    if (!img1 || !img2 || !partials || !loss_out) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
+    if ((dm_dmu1 == nullptr) != (dm_dsigma1_sq == nullptr) || (dm_dmu1 == nullptr) != (dm_dsigma12 == nullptr))
+        return fail(GSR_ERR_INVALID_ARG, "give all three derivative maps or none");
+    gsr_launch_train_loss_forward(planes, H, W, img1, img2, lambda_dssim, partials, loss_out, dm_dmu1, dm_dsigma1_sq, dm_dsigma12,
+                                  (hipStream_t)stream);
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_train_loss_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dloss, float lambda_dssim,
+                            const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1, void* stream) {
+    if (planes <= 0 || H <= 0 || W <= 0) return fail(GSR_ERR_INVALID_ARG, "bad image size");
+    if (planes > 65535) return fail(GSR_ERR_UNSUPPORTED, "more than 65535 image planes");
+    if (!img1 || !img2 || !dL_dloss || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1)
+        return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
+    gsr_launch_train_loss_backward(planes, H, W, img1, img2, dL_dloss, lambda_dssim, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1,
+                                   (hipStream_t)stream);
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
+}
+
 int gsr_ssim_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dmap,
                       const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1, void* stream) {
     if (planes < 0 || H <= 0 || W <= 0) return fail(GSR_ERR_INVALID_ARG, "bad image size");

@@ -60,14 +60,20 @@ GsrGeom gsr_carve_geom(char* base, int P);
 #define GSR_DEPTH_KEY_BASE 0x3E4CCCCDu
 #define GSR_DEPTH_KEY_CULLED ((1u << GSR_DEPTH_KEY_BITS) - 1u)
 #ifdef __HIPCC__
-__device__ __forceinline__ uint32_t gsr_depth_key(float depth, bool listed, uint32_t* key_overflow) {
+// `overflow` is a per-thread flag the caller reports ONCE, after its loop, with gsr_report_key_overflow: a store through the
+// (unrestricted) host-word pointer inside the streaming loop made hipcc serialise the loop's batched loads (ISA audit: the
+// split-SH loader of the preprocess became a 14-long load -> wait chain).
+__device__ __forceinline__ uint32_t gsr_depth_key(float depth, bool listed, bool& overflow) {
     if (!listed) return GSR_DEPTH_KEY_CULLED;
     uint32_t k = __float_as_uint(depth) - GSR_DEPTH_KEY_BASE;
     if (k >= GSR_DEPTH_KEY_CULLED) {
-        if (key_overflow) __hip_atomic_store(key_overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        overflow = true;
         k = GSR_DEPTH_KEY_CULLED - 1u;
     }
     return k;
+}
+__device__ __forceinline__ void gsr_report_key_overflow(bool overflow, uint32_t* key_overflow) {
+    if (overflow && key_overflow) __hip_atomic_store(key_overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // the two derived fields of a splat record, written by the preprocess and recomputed bit-identically from (opacity, depth) by the
 // receiver of a packed record (route.hip): explicit single roundings, independent of the translation unit's -ffp-contract
@@ -235,6 +241,11 @@ void gsr_launch_ssim_mean_forward(int planes, int H, int W, const float* img1, c
 void gsr_launch_ssim_mean_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dmean,
                                    const float* dm_dmu1, const float* dm_dex2, const float* dm_dexy, float* dL_dimg1,
                                    hipStream_t st);
+// ssim.hip: the fused training loss (1 - lambda) L1 + lambda (1 - SSIM) in the SSIM kernels' single pass
+void gsr_launch_train_loss_forward(int planes, int H, int W, const float* img1, const float* img2, float lambda, float* partials,
+                                   float* loss_out, float* dm_dmu1, float* dm_dex2, float* dm_dexy, hipStream_t st);
+void gsr_launch_train_loss_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dloss, float lambda,
+                                    const float* dm_dmu1, const float* dm_dex2, const float* dm_dexy, float* dL_dimg1, hipStream_t st);
 // binning.hip: gathered splat records -> geometry state of this rank's band (two-axis sharding)
 void gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
                              uint32_t* keys, uint32_t* vals, uint32_t* sort_state /*zeroed, GSR_OS_STATE_WORDS*/, uint32_t* key_overflow,

@@ -241,6 +241,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
     const int64_t i_first = first_hist ? (int64_t)blockIdx.x * hist_items + wv * 64 : ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane;
     const int64_t i_stride = first_hist ? 256 : (int64_t)gridDim.x * blockDim.x;
     const int64_t i_limit = first_hist ? min((int64_t)P, ((int64_t)blockIdx.x + 1) * hist_items) : (int64_t)P;
+    bool key_ovf = false;
     for (int64_t i0 = i_first; i0 < i_limit; i0 += i_stride) {
         const int64_t i = i0 + lane;
         const bool in_range = i < P;
@@ -344,11 +345,12 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         if (clamped_out) clamped_out[i] = clampbits;
         radii[i] = sp.radius;
         // depth-sort key (gsr_internal.h): 27 bits of bits(depth) - bits(0.2f); Gaussians with no tile in the band sort last.
-        const uint32_t key = gsr_depth_key(sp.depth, sp.tiles != 0u, key_overflow);
+        const uint32_t key = gsr_depth_key(sp.depth, sp.tiles != 0u, key_ovf);
         keys[i] = key;
         vals[i] = (uint32_t)i;
         if (first_hist) atomicAdd(&s_hist[key & 255u], 1u);
     }
+    gsr_report_key_overflow(key_ovf, key_overflow);
     if (first_hist) {
         __syncthreads();
         first_hist[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = s_hist[threadIdx.x];
@@ -378,6 +380,7 @@ preprocess_geom_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D,
         for (int i = threadIdx.x; i < GSR_OS_STATE_WORDS; i += 256) sort_state[i] = 0u;
     GsrCam cam;
     load_cam(camd, cam);
+    bool key_ovf = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
         GsrSplat sp;
         sp.radius = 0; sp.tiles = 0; sp.minx = sp.miny = sp.maxx = sp.maxy = 0; sp.depth = 0.f;
@@ -411,9 +414,10 @@ preprocess_geom_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D,
         rect[i] = rc;
         tiles[i] = sp.tiles;
         radii[i] = sp.radius;
-        keys[i] = gsr_depth_key(sp.depth, sp.tiles != 0u, key_overflow);
+        keys[i] = gsr_depth_key(sp.depth, sp.tiles != 0u, key_ovf);
         vals[i] = (uint32_t)i;
     }
+    gsr_report_key_overflow(key_ovf, key_overflow);
 }
 
 // colours of the Gaussians that touch this rank's band (tiles > 0), written into the records the geometry kernel made

@@ -107,6 +107,7 @@ ingest_packed(int P, const float4* __restrict__ packed, int y0, int y1, float4* 
               uint32_t* __restrict__ sort_state, uint32_t* key_overflow) {
     if (sort_state && blockIdx.x == 0)
         for (int i = threadIdx.x; i < GSR_OS_STATE_WORDS; i += 256) sort_state[i] = 0u;
+    bool key_ovf = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 q0 = packed[i * 3 + 0], q1 = packed[i * 3 + 1], p2 = packed[i * 3 + 2];
         const uint32_t rx = __float_as_uint(p2.z), ry = __float_as_uint(p2.w);
@@ -122,9 +123,10 @@ ingest_packed(int P, const float4* __restrict__ packed, int y0, int y1, float4* 
         splats[i * 4 + 3] = make_float4(__uint_as_float(rc.x), __uint_as_float(rc.y), 0.f, __uint_as_float(t));
         rect[i] = rc;
         tiles[i] = t;
-        keys[i] = gsr_depth_key(depth, t != 0u, key_overflow);
+        keys[i] = gsr_depth_key(depth, t != 0u, key_ovf);
         vals[i] = (uint32_t)i;
     }
+    gsr_report_key_overflow(key_ovf, key_overflow);
 }
 
 // out[ids[r]] += rows[r] for r in [0, n): ids are distinct within one launch

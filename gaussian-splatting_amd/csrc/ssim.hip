@@ -51,11 +51,15 @@ constexpr float C2 = 0.03f * 0.03f;
 
 // MEAN: instead of the SSIM map the workgroup writes the SUM of its tile's SSIM values (partials[plane][tile]); a second
 // one-workgroup kernel adds the partials in fixed order -> mean (deterministic, no 25 MB map round trip, no torch reduce)
-template <bool MEAN>
+// MODE 0: SSIM map.  MODE 1 (MEAN): per-tile partial sums instead of the map.  MODE 2 (round 3, the training loss of
+// train.py:119-126 in one pass): as MODE 1, and the tile's sum of |img1 - img2| (the L1 term, utils/loss_utils.py:40-41) goes to
+// partials[n_tiles + tile] -- the pixels are already in LDS, so the L1 half of the loss costs no extra read of either image.
+template <int MODE>
 __global__ void __launch_bounds__(256)
 ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2, float* __restrict__ ssim_map,
                 float* __restrict__ dm_dmu1, float* __restrict__ dm_dex2, float* __restrict__ dm_dexy) {
-    __shared__ float s_part[4];
+    constexpr bool MEAN = MODE != 0;
+    __shared__ float s_part[8];
     __shared__ float s_x[HY + STAGE_PAD][SW];
     __shared__ float s_y[HY + STAGE_PAD][SW];
     __shared__ float s_h[5][HY][SHW];
@@ -135,11 +139,12 @@ ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __res
         }
     }
     const int gx = x0 + cx;
-    float m_own = 0.f;
+    float m_own = 0.f, l1_own = 0.f;
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         const int gy = y0 + 4 * rg + o;
         if (gy < H && gx < W) {
+            if (MODE == 2) l1_own += fabsf(s_x[4 * rg + o + HALO][cx + HALO] - s_y[4 * rg + o + HALO][cx + HALO]);
             const float mu1 = acc[o][0], mu2 = acc[o][1], ex2 = acc[o][2], ey2 = acc[o][3], exy = acc[o][4];
             const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
             const float sigma1_sq = ex2 - mu1_sq, sigma2_sq = ey2 - mu2_sq, sigma12 = exy - mu12;
@@ -158,13 +163,41 @@ ssim_fwd_kernel(int H, int W, const float* __restrict__ img1, const float* __res
         }
     }
     if (MEAN) {
-        float v = m_own;
+        float v = m_own, u = l1_own;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if ((tid & 63) == 0) s_part[tid >> 6] = v;
+        for (int off = 32; off > 0; off >>= 1) {
+            v += __shfl_xor(v, off, 64);
+            if (MODE == 2) u += __shfl_xor(u, off, 64);
+        }
+        if ((tid & 63) == 0) { s_part[tid >> 6] = v; s_part[4 + (tid >> 6)] = u; }
         __syncthreads();
-        if (tid == 0)
-            ssim_map[((int64_t)plane * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+        if (tid == 0) {
+            const int64_t t = ((int64_t)plane * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            ssim_map[t] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+            if (MODE == 2) ssim_map[(int64_t)gridDim.z * gridDim.y * gridDim.x + t] = (s_part[4] + s_part[5]) + (s_part[6] + s_part[7]);
+        }
+    }
+}
+
+// one workgroup: out = [loss, L1, SSIM] with loss = (1 - lambda) L1 + lambda (1 - SSIM) (train.py:123), sums in fixed order
+__global__ void __launch_bounds__(256)
+loss_mean_kernel(const float* __restrict__ partials, int n, float inv_count, float lambda, float* __restrict__ out) {
+    __shared__ float s_part[8];
+    const int tid = threadIdx.x;
+    const int chunk = (n + 255) / 256;
+    const int lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+    float v = 0.f, u = 0.f;
+    for (int i = lo; i < hi; ++i) { v += partials[i]; u += partials[n + i]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); u += __shfl_xor(u, off, 64); }
+    if ((tid & 63) == 0) { s_part[tid >> 6] = v; s_part[4 + (tid >> 6)] = u; }
+    __syncthreads();
+    if (tid == 0) {
+        const float ssim = ((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])) * inv_count;
+        const float l1 = ((s_part[4] + s_part[5]) + (s_part[6] + s_part[7])) * inv_count;
+        out[0] = (1.0f - lambda) * l1 + lambda * (1.0f - ssim);
+        out[1] = l1;
+        out[2] = ssim;
     }
 }
 
@@ -185,18 +218,22 @@ ssim_mean_kernel(const float* __restrict__ partials, int n, float inv_count, flo
 }
 
 // MEAN: dL/dmap is the same for every pixel, dL/dmean / count, read from one device scalar
-template <bool MEAN>
+// MODE 2: dL/dmap[0] is dL/dloss of the fused training loss: the SSIM maps are weighted with -lambda dL/dloss / count and
+// (1 - lambda) dL/dloss / count * sign(img1 - img2) -- the L1 term's gradient -- is added in the same store.
+template <int MODE>
 __global__ void __launch_bounds__(256)
 ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
-                const float* __restrict__ dL_dmap, float inv_count, const float* __restrict__ dm_dmu1,
+                const float* __restrict__ dL_dmap, float inv_count, float lambda, const float* __restrict__ dm_dmu1,
                 const float* __restrict__ dm_dex2, const float* __restrict__ dm_dexy, float* __restrict__ dL_dimg1) {
+    constexpr bool MEAN = MODE != 0;
     __shared__ float s_in[3][HY + STAGE_PAD][SW];
     __shared__ float s_h[3][HY][SHW];
     const int tid = threadIdx.x;
     const int plane = blockIdx.z;
     const int x0 = blockIdx.x * TXO, y0 = blockIdx.y * TYO;
     const int64_t pbase = (int64_t)plane * H * W;
-    const float gmean = MEAN ? dL_dmap[0] * inv_count : 0.f;
+    const float gmean = MODE == 2 ? -lambda * dL_dmap[0] * inv_count : (MEAN ? dL_dmap[0] * inv_count : 0.f);
+    const float gl1 = MODE == 2 ? (1.0f - lambda) * dL_dmap[0] * inv_count : 0.f;
     // the two images are only needed by the last expression: requested first, they arrive during the two passes
     const int cx = tid & 63, rg = tid >> 6;
     const int gx_out = x0 + cx;
@@ -274,7 +311,9 @@ ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __res
         const int gy = y0 + 4 * rg + o;
         if (gy < H && gx_out < W) {
             const int64_t oo = pbase + (int64_t)gy * W + gx_out;
-            dL_dimg1[oo] = acc[o][0] + 2.f * im1[o] * acc[o][1] + im2[o] * acc[o][2];
+            float v = acc[o][0] + 2.f * im1[o] * acc[o][1] + im2[o] * acc[o][2];
+            if (MODE == 2) { const float d = im1[o] - im2[o]; v += d > 0.f ? gl1 : (d < 0.f ? -gl1 : 0.f); }      // torch's sign(0) = 0
+            dL_dimg1[oo] = v;
         }
     }
 }
@@ -284,7 +323,7 @@ ssim_bwd_kernel(int H, int W, const float* __restrict__ img1, const float* __res
 void gsr_launch_ssim_forward(int planes, int H, int W, const float* img1, const float* img2, float* ssim_map, float* dm_dmu1,
                              float* dm_dex2, float* dm_dexy, hipStream_t st) {
     const dim3 grid((W + TXO - 1) / TXO, (H + TYO - 1) / TYO, planes);
-    hipLaunchKernelGGL(ssim_fwd_kernel<false>, grid, dim3(256), 0, st, H, W, img1, img2, ssim_map, dm_dmu1, dm_dex2, dm_dexy);
+    hipLaunchKernelGGL(ssim_fwd_kernel<0>, grid, dim3(256), 0, st, H, W, img1, img2, ssim_map, dm_dmu1, dm_dex2, dm_dexy);
 }
 
 int64_t gsr_ssim_partial_count_impl(int planes, int H, int W) {
@@ -294,7 +333,7 @@ int64_t gsr_ssim_partial_count_impl(int planes, int H, int W) {
 void gsr_launch_ssim_mean_forward(int planes, int H, int W, const float* img1, const float* img2, float* partials,
                                   float* mean_out, float* dm_dmu1, float* dm_dex2, float* dm_dexy, hipStream_t st) {
     const dim3 grid((W + TXO - 1) / TXO, (H + TYO - 1) / TYO, planes);
-    hipLaunchKernelGGL(ssim_fwd_kernel<true>, grid, dim3(256), 0, st, H, W, img1, img2, partials, dm_dmu1, dm_dex2, dm_dexy);
+    hipLaunchKernelGGL(ssim_fwd_kernel<1>, grid, dim3(256), 0, st, H, W, img1, img2, partials, dm_dmu1, dm_dex2, dm_dexy);
     const double count = (double)planes * H * W;
     hipLaunchKernelGGL(ssim_mean_kernel, dim3(1), dim3(256), 0, st, partials, (int)gsr_ssim_partial_count_impl(planes, H, W),
                        (float)(1.0 / count), mean_out);
@@ -305,13 +344,31 @@ void gsr_launch_ssim_mean_backward(int planes, int H, int W, const float* img1, 
                                    hipStream_t st) {
     const dim3 grid((W + TXO - 1) / TXO, (H + TYO - 1) / TYO, planes);
     const double count = (double)planes * H * W;
-    hipLaunchKernelGGL(ssim_bwd_kernel<true>, grid, dim3(256), 0, st, H, W, img1, img2, dL_dmean, (float)(1.0 / count), dm_dmu1,
+    hipLaunchKernelGGL(ssim_bwd_kernel<1>, grid, dim3(256), 0, st, H, W, img1, img2, dL_dmean, (float)(1.0 / count), 0.f, dm_dmu1,
                        dm_dex2, dm_dexy, dL_dimg1);
 }
 
 void gsr_launch_ssim_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dmap,
                               const float* dm_dmu1, const float* dm_dex2, const float* dm_dexy, float* dL_dimg1, hipStream_t st) {
     const dim3 grid((W + TXO - 1) / TXO, (H + TYO - 1) / TYO, planes);
-    hipLaunchKernelGGL(ssim_bwd_kernel<false>, grid, dim3(256), 0, st, H, W, img1, img2, dL_dmap, 0.f, dm_dmu1, dm_dex2, dm_dexy,
+    hipLaunchKernelGGL(ssim_bwd_kernel<0>, grid, dim3(256), 0, st, H, W, img1, img2, dL_dmap, 0.f, 0.f, dm_dmu1, dm_dex2, dm_dexy,
                        dL_dimg1);
+}
+
+// fused training loss (train.py:119-126): loss = (1 - lambda) L1 + lambda (1 - SSIM); partials holds 2 x gsr_ssim_partial_count floats
+void gsr_launch_train_loss_forward(int planes, int H, int W, const float* img1, const float* img2, float lambda, float* partials,
+                                   float* loss_out /*[3]: loss, L1, SSIM*/, float* dm_dmu1, float* dm_dex2, float* dm_dexy, hipStream_t st) {
+    const dim3 grid((W + TXO - 1) / TXO, (H + TYO - 1) / TYO, planes);
+    hipLaunchKernelGGL(ssim_fwd_kernel<2>, grid, dim3(256), 0, st, H, W, img1, img2, partials, dm_dmu1, dm_dex2, dm_dexy);
+    const double count = (double)planes * H * W;
+    hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(256), 0, st, partials, (int)gsr_ssim_partial_count_impl(planes, H, W),
+                       (float)(1.0 / count), lambda, loss_out);
+}
+
+void gsr_launch_train_loss_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dloss, float lambda,
+                                    const float* dm_dmu1, const float* dm_dex2, const float* dm_dexy, float* dL_dimg1, hipStream_t st) {
+    const dim3 grid((W + TXO - 1) / TXO, (H + TYO - 1) / TYO, planes);
+    const double count = (double)planes * H * W;
+    hipLaunchKernelGGL(ssim_bwd_kernel<2>, grid, dim3(256), 0, st, H, W, img1, img2, dL_dloss, (float)(1.0 / count), lambda, dm_dmu1,
+                       dm_dex2, dm_dexy, dL_dimg1);
 }

@@ -269,6 +269,20 @@ int gsr_ssim_mean_backward(int planes, int H, int W, const float* img1, const fl
                            const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12, float* dL_dimg1,
                            void* stream);
 
+/*
+ * The whole training loss of train.py:119-126 in the same two kernels (round 3, SURVEY.md 8(f) N1 "fused SSIM + L1"):
+ *     loss = (1 - lambda_dssim) * mean|img1 - img2| + lambda_dssim * (1 - mean SSIM(img1, img2))
+ * (utils/loss_utils.py:40-41 for the L1 term).  The forward reads both images once (the L1 sum comes from the pixels the
+ * SSIM window already staged) and writes loss_out[3] = (loss, L1, SSIM) -- the two parts for the progress bar of
+ * train.py:147-151; the backward takes dL/dloss as ONE device scalar and writes dL/dimg1 = -lambda dSSIM/dimg1 +
+ * (1 - lambda) sign(img1 - img2) / count once.  partials: 2 * gsr_ssim_partial_count(planes, H, W) floats.
+ */
+int gsr_train_loss_forward(int planes, int H, int W, const float* img1, const float* img2, float lambda_dssim, float* partials,
+                           float* loss_out, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12, void* stream);
+int gsr_train_loss_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dloss,
+                            float lambda_dssim, const float* dm_dmu1, const float* dm_dsigma1_sq, const float* dm_dsigma12,
+                            float* dL_dimg1, void* stream);
+
 /* Replaces _C.mark_visible: present[i] = 1 iff Gaussian i is in front of the 0.2 near plane. */
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);

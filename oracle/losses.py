@@ -2,7 +2,12 @@
     loss = (1 - lambda_dssim) * L1(image, gt) + lambda_dssim * (1 - SSIM(image, gt))       (train.py:119-126)
 with L1 = mean |a - b| (utils/loss_utils.py:40-41), SSIM = 11x11 Gaussian window (sigma 1.5), grouped conv2d with
 padding 5, C1 = 0.01^2, C2 = 0.03^2, mean over the map (utils/loss_utils.py:43-87), lambda_dssim = 0.2
-(arguments/__init__.py:88).  Used until the fused SSIM kernel exists."""
+(arguments/__init__.py:88).
+
+TEST INFRASTRUCTURE (moved here from the product package in round 3): the checker of the fused HIP loss
+kernels (fused_ssim.fused_ssim / fused_train_loss).  Pinned to the reference's own utils/loss_utils.py by the golden vector of
+tests/golden/reference_fragments.npz (tests/test_oracle.py::test_train_loss_matches_reference_loss_utils).  Imported only
+by tests/ and by bench.py's optional --compare-torch-adam comparison leg; the product never routes through it."""
 import math
 
 import torch

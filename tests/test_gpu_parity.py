@@ -547,10 +547,10 @@ def test_fused_adam_matches_torch_adam():
 
 @pytest.mark.parametrize("shape", [(1, 3, 67, 93), (2, 3, 128, 160), (1, 1, 16, 16), (1, 3, 11, 300)])
 def test_fused_ssim_matches_reference_formula(shape):
-    """fused_ssim (HIP) == utils/loss_utils.py:56-87 (restated in gsr_synth.losses, which is pinned to the
+    """fused_ssim (HIP) == utils/loss_utils.py:56-87 (restated in oracle.losses, which is pinned to the
     reference by tests/test_oracle.py::test_train_loss_matches_reference_loss_utils) -- value and gradient."""
     from fused_ssim import fused_ssim
-    from gsr_synth.losses import ssim as torch_ssim
+    from oracle.losses import ssim as torch_ssim
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(shape[2])
     a = torch.rand(shape, generator=g)
@@ -574,6 +574,36 @@ def test_fused_ssim_matches_reference_formula(shape):
     assert abs(m3.item() - v1.item()) < 1e-6
     (m3 * 3.0).backward()
     assert (a3.grad - a1.grad).abs().max().item() <= 1e-6 * a1.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("shape,lam", [((3, 67, 93), 0.2), ((1, 3, 128, 160), 0.2), ((3, 16, 16), 0.5), ((3, 11, 300), 0.0), ((3, 40, 40), 1.0)])
+def test_fused_train_loss_matches_reference_formula(shape, lam):
+    """SURVEY 8(f) N1 "fused SSIM + L1": fused_train_loss (ONE HIP kernel pair) == (1 - lambda) l1_loss + lambda (1 - ssim) of
+    utils/loss_utils.py:40-87 / train.py:119-126 (restated in oracle.losses, pinned to the reference by the golden vector of
+    tests/test_oracle.py::test_train_loss_matches_reference_loss_utils) -- value, the two read-outs and the gradient, incl.
+    pixels where image == gt (torch's sign(0) = 0) and the pure-L1 / pure-SSIM mixes."""
+    from fused_ssim import fused_train_loss
+    from oracle.losses import train_loss, l1_loss, ssim as torch_ssim
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(shape[-1])
+    a = torch.rand(shape, generator=g)
+    b = (a + 0.2 * torch.randn(shape, generator=g)).clamp(0, 1)
+    b[..., :3, :5] = a[..., :3, :5]                    # exact ties: zero L1 gradient there
+    a1 = a.clone().to(dev).requires_grad_(True)
+    a2 = a.clone().double().requires_grad_(True)
+    v1, l1_part, ssim_part = fused_train_loss(a1, b.to(dev), lam, return_parts=True)
+    v2 = train_loss(a2, b.double(), lam)               # fp64 CPU reference of the same formula
+    assert abs(v1.item() - v2.item()) < 2e-6
+    assert abs(l1_part.item() - l1_loss(a.double(), b.double()).item()) < 1e-6
+    assert abs(ssim_part.item() - torch_ssim(a.double(), b.double()).item()) < 2e-6
+    assert not l1_part.requires_grad and not ssim_part.requires_grad
+    (v1 * 3.0).backward()
+    (v2 * 3.0).backward()
+    torch.cuda.synchronize()
+    d = (a1.grad.cpu().double() - a2.grad).abs().max().item()
+    assert d <= 2e-5 * a2.grad.abs().max().item(), d
+    with torch.no_grad():                               # inference form: no derivative maps kept
+        assert abs(fused_train_loss(a.to(dev), b.to(dev), lam).item() - v2.item()) < 2e-6
 
 
 @pytest.mark.parametrize("no_backward", [False, True], ids=["track", "inference"])

@@ -338,8 +338,8 @@ def test_means2D_gradient_is_ndc_scaled_pixel_gradient():
 
 
 def test_train_loss_matches_reference_loss_utils(frag):
-    """gsr_synth.losses (used by bench.py's train step) == utils/loss_utils.py l1_loss / ssim of the reference."""
-    from gsr_synth.losses import ssim, l1_loss, train_loss
+    """oracle.losses (the checker of the fused HIP loss kernels) == utils/loss_utils.py l1_loss / ssim of the reference."""
+    from oracle.losses import ssim, l1_loss, train_loss
     img, gt = torch.tensor(frag["loss_img"]), torch.tensor(frag["loss_gt"])
     assert abs(ssim(img, gt).item() - float(frag["loss_ssim"])) < 1e-6
     assert abs(l1_loss(img, gt).item() - float(frag["loss_l1"])) < 1e-7
