@@ -8,8 +8,13 @@
 One "step" = one forward render of the whole frame (preprocess -> depth sort -> scan -> emit -> tile sort -> ranges
 -> blend, including the 4-byte num_rendered read-back) of the synthetic stand-in for configs[1] ("garden", ~1 M
 Gaussians, 1080p): P = 1e6, 1920x1080, SURVEY.md 8(d) generator, seed 0, s_med 0.012.  With N > 1 GPUs the SAME
-frame is split into N bands of tile rows (strong scaling), every rank renders its band and the strips are
-all-gathered over RCCL; value = W*H / (max-over-ranks time per frame).
+frame is rendered by all ranks together (strong scaling) in mode C of diff_gaussian_rasterization/parallel.py: rank g owns
+P/N Gaussians and a band of tile rows, projects its shard, sends every projected splat only to the ranks whose band it
+touches (one variable-size all-to-all of 48-byte records), bins + blends its band and the strips are all-gathered over
+RCCL; frames are pipelined two deep so that both collectives overlap the neighbouring frames' kernels;
+value = W*H / (max-over-ranks time per frame).  If a collective of that mode is refused at the first contact with RCCL the
+run falls back to mode B (replicated parameters, bands only) and says so in the line; any other failure still prints a JSON
+line with an "error" field.
 
 The JSON line also carries
   train_iters_per_s : forward + loss + backward + Adam on all parameters, a NEW CAMERA EVERY ITERATION (train.py:96-102:
@@ -46,6 +51,11 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
 HBM_ACHIEVABLE_GBS = 6290.0
 FP32_VALU_PEAK_TF = 157.3
+# measured with tools/microbench/valu_issue.hip (profiles/r03_valu_issue.txt): the sustained issue rate of independent full-rate
+# fp32 VALU instructions (v_fma / v_mul / v_add) at >= 8 waves per SIMD, in 1e12 lane-operations per second.  The datasheet rate
+# is 78.6 (157.3 TFLOP/s / 2 FLOP); the part sustains 2.05-2.1 GHz under this load, not 2.4.  Other classes cost more issue
+# time per instruction: v_exp / v_rcp / v_permlane*_swap x3.2, DPP-modified adds x1.6, v_cmp + v_cndmask pairs x1.5, v_pk_fma x1.8.
+MEASURED_VALU_LANE_OPS_T = 60.0
 
 
 def parse():
@@ -73,6 +83,9 @@ def parse():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="gsr_set_option(NAME, VALUE) before timing (A/B switches)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short forward measurements of configs[3] (1 M @4K) and configs[4] (6 M @1080p)")
     ap.add_argument("--views", type=int, default=32, help="training views cycled by the train legs (1 = the static camera of round 1)")
+    ap.add_argument("--densify-iters", type=int, default=600, help="iterations of the train leg with density control every 100 (0 disables it)")
+    ap.add_argument("--mode", default="C", choices=["B", "C"], help="N > 1: C = Gaussian-sharded with the targeted all-to-all (default), B = replicated parameters + bands")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="worker processes of the CPU baseline's blend (0 = all host cores)")
     return ap.parse_args()
 
 
@@ -111,7 +124,22 @@ def make_views(make_camera, look_at_camera, W, H, n):
 
 
 def main():
+    """Runs the benchmark; ANY failure (a refused collective, a HIP error on one rank) still ends in one JSON line with an
+    "error" field on rank 0 instead of a silent non-zero exit."""
     a = parse()
+    try:
+        _run(a)
+    except Exception as ex:      # noqa: BLE001
+        import traceback
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"metric": "Mpix/s forward (1 M Gaussians @1080p); train iters/s alongside", "value": None, "unit": "Mpix/s",
+                              "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "steps": a.steps, "warmup": a.warmup,
+                              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "error": repr(ex)[:500], "traceback": traceback.format_exc()[-1500:]}), flush=True)
+        raise
+
+
+def _run(a):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -128,16 +156,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("GSR_BENCH_TIMEOUT_S", "180")))      # a hung collective must not eat the driver's slot
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
-    from gsr_synth import look_at_camera, make_camera, make_scene
+    from gsr_synth import look_at_camera, make_camera, make_scene, make_clustered_scene
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _lib, rasterize_gaussians
     from diff_gaussian_rasterization.debug import forward_with_views
-    from diff_gaussian_rasterization.parallel import BandPlan, gather_strips_async, row_costs_from_ranges
+    from diff_gaussian_rasterization.parallel import (BandPlan, gather_strips_async, row_costs_from_ranges, probe_collectives,
+                                                     set_exact_strips, sharded_forward_begin, sharded_forward_finish)
 
     _lib.load()
     if a.variant is not None:
@@ -170,12 +201,36 @@ def main():
     plan = BandPlan.uniform(gy, world) if (a.uniform_bands or world == 1) else BandPlan.balanced(row_cost, world)
     band = None if world == 1 else plan.band(rank)
 
-    # N > 1: frames are pipelined two deep -- the strip all-gather of frame i (RCCL stream) overlaps the rasterization
-    # of frame i+1; every frame is complete (assembled on every rank) before the closing barrier of the timed region.
-    in_flight = []
+    # N > 1: first contact with the backend -- one tiny instance of every collective, so that the mode can be chosen and a
+    # refusal is reported, not fatal
+    mode = "single" if world == 1 else a.mode
+    collectives = None
+    if world > 1:
+        collectives = probe_collectives(device=dev)
+        if not collectives["all_gather"]:
+            raise RuntimeError(f"all_gather_into_tensor is not usable on backend {backend}: {collectives['errors']}")
+        if not collectives["all_gather_uneven"]:
+            set_exact_strips(False)
+        if mode == "C" and not collectives["all_to_all_single"]:
+            mode = "B"
+    lo, hi = (P * rank) // world, (P * (rank + 1)) // world
+    shard = None if mode != "C" else tuple(t[lo:hi].contiguous() for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations))
+
+    # N > 1: frames are pipelined two deep.  Mode C: frame i+1 is projected, routed and its all-to-all launched BEFORE frame i
+    # is binned and blended, and the strip all-gather of frame i (RCCL stream) overlaps frame i+1 -- both collectives run
+    # beside kernels of the neighbouring frames.  Every frame is complete (assembled on every rank) before the closing
+    # barrier of the timed region.
+    in_flight, pending = [], []
 
     def forward_step():
         with torch.no_grad():
+            if mode == "C":
+                pending.append(sharded_forward_begin(rs, *shard, plan))
+                if len(pending) > 1:
+                    in_flight.append(sharded_forward_finish(pending.pop(0)))
+                    if len(in_flight) > 1:
+                        return in_flight.pop(0).wait()
+                return None
             color, radii, invd = rasterize_gaussians(sc.means3D, None, sc.shs, None, sc.opacities, sc.scales,
                                                      sc.rotations, None, rs, band)
             if world > 1:
@@ -184,9 +239,14 @@ def main():
                     color = in_flight.pop(0).wait()
         return color
 
-    def sync_all():
+    def drain():
+        while pending:
+            in_flight.append(sharded_forward_finish(pending.pop(0)))
         while in_flight:
             in_flight.pop(0).wait()
+
+    def sync_all():
+        drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -202,13 +262,18 @@ def main():
     STALL_MS = 20.0
     retimed = {}
 
+    event_stats = {}
+
     def timed_loop(step, n, name):
         for attempt in range(2):
             sync_all()
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
             t0 = time.perf_counter()
             stamps = [t0]
-            for _ in range(n):
+            evs[0].record()
+            for i in range(n):
                 step()
+                evs[i + 1].record()           # GPU-side time stamp on the stream the step was enqueued on (event timing)
                 stamps.append(time.perf_counter())
             sync_all()
             dt = time.perf_counter() - t0
@@ -220,6 +285,10 @@ def main():
             if float(flag.item()) == 0.0 or attempt == 1:
                 break
             retimed[name] = retimed.get(name, 0) + 1
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n))
+        if per:
+            event_stats[name] = {"median_ms": round(per[len(per) // 2], 4), "p10_ms": round(per[len(per) // 10], 4),
+                                 "p90_ms": round(per[min(len(per) - 1, (len(per) * 9) // 10)], 4), "mean_ms": round(sum(per) / len(per), 4)}
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -269,8 +338,7 @@ def main():
     _lib.profile_enable(True)
     for _ in range(a.steps):
         forward_step()
-    while in_flight:
-        in_flight.pop(0).wait()
+    drain()
     torch.cuda.synchronize()
     stages = _lib.profile_read()
     _lib.profile_enable(False)
@@ -281,8 +349,7 @@ def main():
     ncount = min(3, a.steps)
     for _ in range(ncount):
         forward_step()
-    while in_flight:
-        in_flight.pop(0).wait()
+    drain()
     torch.cuda.synchronize()
     fwd_counters = _lib.profile_counters(reset=True)
     _lib.profile_enable(False)
@@ -324,12 +391,17 @@ def main():
     tsteps = a.steps if a.train_steps < 0 else a.train_steps
     if tsteps > 0:
         from gsr_optim import FusedAdam
-        from gsr_synth.losses import train_loss, l1_loss
-        from fused_ssim import fused_ssim
+        from fused_ssim import fused_ssim, fused_train_loss
         from diff_gaussian_rasterization import SparseGaussianAdam
 
-        def fused_train_loss(image, gt_image, lambda_dssim=0.2):      # train.py:119-126 with FUSED_SSIM_AVAILABLE
+        def l1_loss(x, y):                                             # utils/loss_utils.py:40-41
+            return (x - y).abs().mean()
+
+        def unfused_l1_train_loss(image, gt_image, lambda_dssim=0.2):  # round 2's form: fused SSIM, L1 + mix as torch ops
             return (1.0 - lambda_dssim) * l1_loss(image, gt_image) + lambda_dssim * (1.0 - fused_ssim(image[None], gt_image[None]))
+        train_loss = None
+        if a.compare_torch_adam:
+            from oracle.losses import train_loss      # comparison leg only: SSIM through torch conv2d ops (the checker's formula)
         views = make_views(make_camera, look_at_camera, W, H, max(1, a.views))
         rs_views, gts = [], []
         for i, vc in enumerate(views):
@@ -337,17 +409,18 @@ def main():
             rs_views.append(GaussianRasterizationSettings(H, W, vc.tanfovx, vc.tanfovy, bg, 1.0, vd.world_view_transform,
                                                           vd.full_proj_transform, 3, vd.camera_center, False, False, False))
             gts.append(torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(1 + i)))
-        legs = [("ssim", "dense", fused_train_loss), ("sparse_adam", "sparse", fused_train_loss), ("l1", "dense", l1_loss)]
+        legs = [("ssim", "dense", fused_train_loss), ("sparse_adam", "sparse", fused_train_loss), ("l1", "dense", l1_loss),
+                ("ssim_unfused_l1", "dense", unfused_l1_train_loss)]
         if a.compare_torch_adam:
             legs.append(("l1_torch_adam", "torch", l1_loss))
             legs.append(("ssim_torch", "dense", train_loss))
         if world > 1:
             legs = [l for l in legs if l[1] != "sparse"]      # the sharded path keeps the fused [P,16,3] SH tensor
-        from diff_gaussian_rasterization.parallel import render_two_axis, padded_shard_size
-        # N > 1: two-axis sharding -- rank g owns Gaussians [lo, hi) (parameters + Adam state) and a band of
-        # tile rows; 64-byte splat records are all-gathered forward, 48-byte gradient records reduce-scattered backward
-        lo, hi = (P * rank) // world, (P * (rank + 1)) // world
-        P_pad = padded_shard_size(hi - lo) if world > 1 else P
+        from diff_gaussian_rasterization.parallel import render_two_axis, render_gaussian_sharded, padded_shard_size
+        # N > 1: rank g owns Gaussians [lo, hi) (parameters + Adam state) and a band of tile rows.  Mode C: 48-byte packed splat
+        # records travel only to the bands they touch (all-to-all) and the 48-byte gradient rows come back the same way;
+        # mode B / fallback: two-axis sharding with the record all-gather + gradient reduce-scatter of round 2
+        P_pad = padded_shard_size(hi - lo) if (world > 1 and mode != "C") else P
         for leg, opt_kind, loss_fn in legs:
             if opt_kind == "sparse":
                 src = (sc.means3D, sc.shs[:, :1].contiguous(), sc.shs[:, 1:].contiguous(), sc.opacities, sc.scales, sc.rotations)
@@ -369,6 +442,9 @@ def main():
                 if opt_kind == "sparse":
                     m, dc, rest, o, s_, r_ = params
                     color, radii, invd = rasterize_gaussians(m, None, rest, None, o, s_, r_, None, rs_views[vi], None, None, dc)
+                elif world > 1 and mode == "C":
+                    m, sh, o, s_, r_ = params
+                    color, radii, invd = render_gaussian_sharded(rs_views[vi], m, sh, o, s_, r_, plan, gather_invdepth=False)
                 elif world > 1:
                     m, sh, o, s_, r_ = params
                     color, radii, invd = render_two_axis(rs_views[vi], m, sh, o, s_, r_, plan, P_pad)
@@ -410,27 +486,121 @@ def main():
     train_ms = train.get("ssim")
     train_ips = None if train_ms is None else 1e3 / train_ms
 
-    # ---- the other GPU configs of BASELINE.json, forward only, same sharding (short: they are not the headline metric) ----
-    #   configs[3] stand-in: 1 M Gaussians @3840x2160;  configs[4] stand-in: 6 M Gaussians @1920x1080
+    # ---- the forward leg with a NEW CAMERA EVERY FRAME (re-rendering one camera lets the 236 MB scene sit in
+    # the 256 MiB Infinity Cache from frame to frame; the train legs already cycle views) ----
+    cycled = None
+    if world == 1 and tsteps > 0:
+        cyc = [0]
+
+        def forward_cycled():
+            with torch.no_grad():
+                rasterize_gaussians(sc.means3D, None, sc.shs, None, sc.opacities, sc.scales, sc.rotations, None,
+                                    rs_views[cyc[0] % len(rs_views)], None)
+            cyc[0] += 1
+        for _ in range(len(rs_views)):
+            forward_cycled()
+        ncyc = max(a.steps, len(rs_views))
+        cdt = timed_loop(forward_cycled, ncyc, "forward_cycled")[0]
+        cycled = {"views": len(rs_views), "steps": ncyc, "ms_per_frame": round(cdt / ncyc * 1e3, 4), "Mpix_s": round(npix / (cdt / ncyc) / 1e6, 1),
+                  "gpu_event_ms": event_stats.get("forward_cycled"),
+                  "note": "the headline re-renders view 0 (the frame whose V / R the config names); its 236 MB of parameters fit the 256 MiB "
+                          "Infinity Cache, and so do they here -- the views change R, the lists and the scratch sizes, not the residency"}
+
+    # ---- train leg WITH density control ("one step = forward + L1/SSIM loss + backward + Adam + amortised densify",
+    # train.py:111-186): the reference's statistics every iteration and clone / split / prune every 100 iterations
+    # (train.py:160-174, arguments/__init__.py:91-95) through gsr_scene.densify, sparse Adam + separate-SH call form ----
+    densify_leg = None
+    if world == 1 and tsteps > 0 and a.densify_iters > 0:
+        import torch.nn as nn
+        from gsr_scene.densify import DensifyStats, densify_and_prune
+
+        def par(t):
+            return nn.Parameter(t.detach().clone().contiguous().requires_grad_(True))
+        eps_ = 1e-6
+        dparams = {"xyz": par(sc.means3D), "f_dc": par(sc.shs[:, :1]), "f_rest": par(sc.shs[:, 1:]),
+                   "opacity": par(torch.logit(sc.opacities.clamp(eps_, 1 - eps_))), "scaling": par(torch.log(sc.scales)),
+                   "rotation": par(sc.rotations)}
+        groups = [{"params": [dparams[k]], "lr": 1e-5, "name": k} for k in dparams]
+        dopt = SparseGaussianAdam(groups, lr=1e-5, eps=1e-15)
+        dstats = DensifyStats.zeros(P, dev)
+        state = {"params": dparams, "stats": dstats, "it": 0, "P_max": P}
+
+        def densify_step():
+            pr, st_ = state["params"], state["stats"]
+            state["it"] += 1
+            it = state["it"]
+            vi = it % len(rs_views)
+            n = pr["xyz"].shape[0]
+            m2 = torch.zeros(n, 3, device=dev, requires_grad=True)
+            img, radii, _ = rasterize_gaussians(pr["xyz"], m2, pr["f_rest"], None, torch.sigmoid(pr["opacity"]), torch.exp(pr["scaling"]),
+                                                torch.nn.functional.normalize(pr["rotation"]), None, rs_views[vi], None, None, pr["f_dc"])
+            fused_train_loss(img, gts[vi]).backward()
+            with torch.no_grad():
+                st_.add(m2.grad, radii > 0, radii)
+                if it % 100 == 0:
+                    # the synthetic targets are noise, so gradients are large everywhere: the threshold is set where the
+                    # reference's schedule typically lands (a few per cent of the set cloned / split per step, about as many pruned)
+                    g = st_.xyz_gradient_accum / st_.denom.clamp_min(1)
+                    thr = float(torch.quantile(g[st_.denom > 0].flatten()[:1_000_000], 0.97)) if bool((st_.denom > 0).any()) else 1e30
+                    state["params"], state["stats"], _ = densify_and_prune(dopt, st_, max_grad=thr, min_opacity=0.005, extent=4.0,
+                                                                            max_screen_size=None, radii=radii)
+                    state["P_max"] = max(state["P_max"], int(state["params"]["xyz"].shape[0]))
+                else:
+                    dopt.step(radii > 0, radii.shape[0])
+                dopt.zero_grad(set_to_none=True)
+
+        for _ in range(8):
+            densify_step()
+        state["it"] = 0
+        nd = max(200, (a.densify_iters // 100) * 100)
+        ddt = timed_loop(densify_step, nd, "train_densify")[0]
+        densify_leg = {"iters": nd, "densify_every": 100, "iters_per_s": round(nd / ddt, 3), "ms_per_iter": round(ddt / nd * 1e3, 4),
+                       "P_start": P, "P_end": int(state["params"]["xyz"].shape[0]), "P_max": state["P_max"],
+                       "gpu_event_ms": event_stats.get("train_densify"),
+                       "what": "forward (separate-SH form) + fused L1/SSIM loss + backward + density statistics every iteration + "
+                               "SparseGaussianAdam; clone / split / prune (gsr_scene.densify) every 100 iterations, amortised"}
+        del dparams, dopt, dstats, state
+        torch.cuda.empty_cache()
+
+    # ---- other scenes / configs, forward only, same sharding (short: they are not the headline metric) ----
+    #   configs[3] stand-in: 1 M Gaussians @3840x2160;  configs[4] stand-in: 6 M Gaussians @1920x1080;
+    #   configs[1] at s_med 0.006 ("closer to trained scenes") and the CLUSTERED stand-in (gsr_synth.make_clustered_scene:
+    #   200 anisotropic clusters with log-normal populations, 5 % large floaters, ~40 % of the Gaussians visible) -- each with the
+    #   per-tile list-length distribution and the tail of the blend launches (steps of the heaviest wave / mean wave)
     other = {}
     if not a.no_other_configs and (P, W, H) == (1_000_000, 1920, 1080):
-        for oname, oP, oW, oH in (("configs[3] 1M@4K", 1_000_000, 3840, 2160), ("configs[4] 6M@1080p", 6_000_000, 1920, 1080)):
+        specs = [("configs[3] 1M@4K", 1_000_000, 3840, 2160, "uniform", a.s_med), ("configs[4] 6M@1080p", 6_000_000, 1920, 1080, "uniform", a.s_med),
+                 ("configs[1] s_med 0.006", 1_000_000, 1920, 1080, "uniform", 0.006), ("configs[1] clustered", 1_000_000, 1920, 1080, "clustered", a.s_med)]
+        for oname, oP, oW, oH, kind, osm in specs:
             ocam = make_camera(oW, oH)
-            osc = make_scene(oP, ocam, seed=a.seed, s_med=a.s_med).to(dev)
+            osc_cpu = make_clustered_scene(oP, ocam, seed=a.seed, s_med=osm) if kind == "clustered" else make_scene(oP, ocam, seed=a.seed, s_med=osm)
+            osc = osc_cpu.to(dev)
+            del osc_cpu
             ocd = ocam.to(dev)
             ors = GaussianRasterizationSettings(oH, oW, ocam.tanfovx, ocam.tanfovy, bg, 1.0, ocd.world_view_transform,
                                                 ocd.full_proj_transform, 3, ocd.camera_center, False, False, False)
             ogx, ogy = (oW + 15) // 16, (oH + 15) // 16
             with torch.no_grad():
                 ov = forward_with_views(ors, osc.means3D, osc.opacities, shs=osc.shs, scales=osc.scales, rotations=osc.rotations)
-                oR = int(ov["R"])
+                oR, oV = int(ov["R"]), int((ov["radii"] > 0).sum())
                 orow = row_costs_from_ranges(ov["ranges"].long(), ogx, ogy, banded=False)
+                cnt = (ov["ranges"][:, 1] - ov["ranges"][:, 0]).float()
+                tile_stats = {"p50": int(cnt.median()), "p99": int(torch.quantile(cnt, 0.99)), "max": int(cnt.max()), "mean": round(float(cnt.mean()), 1)}
                 del ov
             oplan = BandPlan.uniform(ogy, world) if (a.uniform_bands or world == 1) else BandPlan.balanced(orow, world)
             oband = None if world == 1 else oplan.band(rank)
+            olo, ohi = (oP * rank) // world, (oP * (rank + 1)) // world
+            oshard = None if mode != "C" else tuple(t[olo:ohi].contiguous() for t in (osc.means3D, osc.shs, osc.opacities, osc.scales, osc.rotations))
 
             def ostep():
                 with torch.no_grad():
+                    if mode == "C":
+                        pending.append(sharded_forward_begin(ors, *oshard, oplan))
+                        if len(pending) > 1:
+                            in_flight.append(sharded_forward_finish(pending.pop(0)))
+                            if len(in_flight) > 1:
+                                in_flight.pop(0).wait()
+                        return
                     color, _, _ = rasterize_gaussians(osc.means3D, None, osc.shs, None, osc.opacities, osc.scales, osc.rotations,
                                                       None, ors, oband)
                     if world > 1:
@@ -441,41 +611,72 @@ def main():
                 ostep()
             osteps = max(5, min(20, a.steps))
             odt = timed_loop(ostep, osteps, "other_" + oname)[0]
-            other[oname] = {"P": oP, "width": oW, "height": oH, "num_rendered": oR, "steps": osteps,
-                            "ms_per_frame": round(odt / osteps * 1e3, 4), "Mpix_s": round(oW * oH / (odt / osteps) / 1e6, 1)}
+            e = {"P": oP, "width": oW, "height": oH, "kind": kind, "s_med": osm, "visible": oV, "num_rendered": oR, "steps": osteps,
+                 "ms_per_frame": round(odt / osteps * 1e3, 4), "Mpix_s": round(oW * oH / (odt / osteps) / 1e6, 1),
+                 "tile_list_length": tile_stats}
+            if world == 1:
+                # stage times + the blend launches' tail (counters in their own pass), forward and backward
+                _lib.profile_reset()
+                _lib.profile_enable(True)
+                for _ in range(5):
+                    ostep()
+                torch.cuda.synchronize()
+                ost = _lib.profile_read()
+                _lib.profile_enable(False)
+                e["stage_ms"] = {k: round(v["ms"] / v["launches"], 4) for k, v in ost.items() if v["launches"]}
+                oreq = [t.detach().clone().requires_grad_(True) for t in (osc.means3D, osc.shs, osc.opacities, osc.scales, osc.rotations)]
+                ogt = torch.rand(3, oH, oW, device=dev, generator=torch.Generator(device=dev).manual_seed(99))
+
+                def otrain():
+                    for t in oreq:
+                        t.grad = None
+                    col, _, _ = rasterize_gaussians(oreq[0], None, oreq[1], None, oreq[2], oreq[3], oreq[4], None, ors, None)
+                    fused_train_loss(col, ogt).backward() if tsteps > 0 else (col - ogt).abs().mean().backward()
+                for _ in range(3):
+                    otrain()
+                if kind == "clustered" or osm != a.s_med:
+                    tdt = timed_loop(otrain, osteps, "other_train_" + oname)[0]
+                    e["fwd_loss_bwd_ms"] = round(tdt / osteps * 1e3, 4)
+                _lib.profile_reset()
+                _lib.profile_enable(True)
+                for _ in range(3):
+                    otrain()
+                torch.cuda.synchronize()
+                ost = _lib.profile_read()
+                _lib.profile_enable(False)
+                for k in ("render_bwd", "gather_bwd", "preprocess_bwd"):
+                    if ost[k]["launches"]:
+                        e["stage_ms"][k] = round(ost[k]["ms"] / ost[k]["launches"], 4)
+                _lib.profile_enable(False, counters=True)
+                _lib.profile_counters(reset=True)
+                otrain()
+                torch.cuda.synchronize()
+                oc = _lib.profile_counters(reset=True)
+                _lib.profile_enable(False)
+                nfw, nbw = ogx * ogy * 4, ogx * ogy * 2           # waves of the forward (8x8 blocks) / backward (half tiles) launches
+                e["blend_tail"] = {"fwd_heaviest_wave_over_mean": round(oc["fwd_max_wave_steps"] / max(1e-9, oc["fwd_steps"] / nfw), 2),
+                                   "bwd_heaviest_wave_over_mean": round(oc["bwd_max_wave_steps"] / max(1e-9, oc["bwd_steps"] / nbw), 2),
+                                   "fwd_steps": oc["fwd_steps"], "bwd_steps": oc["bwd_steps"],
+                                   "note": "steps of the heaviest wave / mean steps per wave (work proxy: a wave's time is proportional to its steps)"}
+                del oreq, ogt
+            other[oname] = e
             del osc
             torch.cuda.empty_cache()
 
-    # ---- CPU baseline (rank 0, N=1 only): pure-PyTorch oracle on a bounded sample of the same frame ----
+    # ---- CPU baseline (rank 0, N=1 only): the pure-PyTorch oracle on ALL host cores, whole frame (no extrapolation), in a
+    # subprocess (oracle/cpu_baseline.py forks one single-threaded worker per core for the tile blend; forking from this process,
+    # which owns a HIP context and OpenMP pools, would not be safe) ----
     cpu_baseline = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        from oracle import torch_oracle as O   # cpu_baseline leg only
-        # many small tensor ops: beyond ~16 threads torch's intra-op pool only adds overhead (measured: 256
-        # threads on the GPU box's host were >10x slower than 16), so the baseline uses min(cores, 16) threads
-        cores = min(os.cpu_count() or 1, 16)
-        torch.set_num_threads(cores)
-        s = O.settings_from_camera(cam, torch.zeros(3))
-        with torch.no_grad():
-            t0 = time.perf_counter()
-            pre = O.preprocess(scene_cpu.means3D, scene_cpu.opacities, s, shs=scene_cpu.shs, scales=scene_cpu.scales,
-                               rotations=scene_cpu.rotations)
-            t_pre = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            bins = O.bin_and_sort(pre)
-            t_bin = time.perf_counter() - t0
-            ntile = gx * gy
-            k = max(1, min(a.cpu_tiles, ntile))
-            sample = [int(i * ntile / k) for i in range(k)]
-            t0 = time.perf_counter()
-            O.render_tiles(pre, bins, s, tiles=sample)
-            t_blend = time.perf_counter() - t0
-        inst_sample = int((bins["ranges"][sample, 1] - bins["ranges"][sample, 0]).sum())
-        # extrapolate the blend by instance count (the blend cost is proportional to list length)
-        t_full = t_pre + t_bin + t_blend * (bins["R"] / max(1, inst_sample))
-        cpu_baseline = {"value": round(npix / t_full / 1e6, 6), "host_cores": os.cpu_count(), "unit": "Mpix/s", "cores": cores, "kind": "port",
-                        "sample": f"full preprocess ({t_pre:.1f}s) + full binning/sort ({t_bin:.1f}s) on all {P} Gaussians; "
-                                  f"blend timed on {k} of {ntile} tiles ({inst_sample} of {bins['R']} instances, {t_blend:.1f}s) "
-                                  f"and scaled by instance count; pure-PyTorch oracle, torch threads={cores}"}
+        import subprocess
+        cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--P", str(P), "--width", str(W), "--height", str(H),
+               "--seed", str(a.seed), "--s-med", str(a.s_med), "--workers", str(a.cpu_workers), "--budget-s", "40"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            cpu_baseline = json.loads(line[-1]) if line else {"value": None, "error": (r.stderr or r.stdout)[-400:]}
+        except Exception as ex:      # noqa: BLE001
+            cpu_baseline = {"value": None, "error": repr(ex)[:300]}
 
     if rank == 0:
         ab = algorithmic_bytes(P, V, R, gx * gy, npix)
@@ -518,6 +719,9 @@ def main():
                 lane_ops = pmc_entry["SQ_INSTS_VALU"] * 64.0 / (ms * 1e-3) / 1e12
                 r["valu_lane_ops_T_per_s"] = round(lane_ops, 2)
                 r["valu_issue_frac_of_spec"] = round(lane_ops / (FP32_VALU_PEAK_TF / 2.0), 4)     # spec: one lane-op per lane and clock at 2.4 GHz
+                r["valu_issue_frac_of_measured_ceiling"] = round(lane_ops / MEASURED_VALU_LANE_OPS_T, 4)
+                r["valu_ceiling_source"] = ("profiles/r03_valu_issue.txt (tools/microbench/valu_issue.hip): 60 T lane-ops/s for independent "
+                                            "v_fma_f32 at >= 8 waves/SIMD; instruction counts from the committed SQ pass (profiles/pmc_latest.json)")
                 r["valu_instructions_per_launch"] = int(pmc_entry["SQ_INSTS_VALU"])
             return r
 
@@ -556,9 +760,12 @@ def main():
             "config": {"workload": "configs[1] stand-in: 1M random Gaussians (SURVEY 8(d) generator, seed %d, s_med %.4g), "
                                    "%dx%d forward render, SH degree 3" % (a.seed, a.s_med, W, H),
                        "P": P, "visible": V, "num_rendered": R, "tiles": gx * gy,
-                       "parallelism": "tile-row bands x%d%s" % (world, "" if world == 1 else
-                                                                (" (uniform)" if a.uniform_bands else " (instance-balanced)") +
-                                                                ", strip all-gather of frame i overlapped with frame i+1"),
+                       "parallelism": ("one GPU" if world == 1 else
+                                       ("mode C x%d: Gaussians sharded (P/N per rank) + tile-row bands%s; 48-byte packed splat records sent only to "
+                                        "the bands they touch (all_to_all_single), strips all-gathered; frames pipelined two deep" if mode == "C" else
+                                        "mode B x%d: replicated parameters, tile-row bands%s, strip all-gather of frame i overlapped with frame i+1")
+                                       % (world, " (uniform)" if a.uniform_bands else " (instance-balanced)")),
+                       "mode": mode, "collectives": collectives,
                        "render_fwd_variant": a.variant or 0, "options": os.environ.get("GSR_OPTIONS", ""),
                        "frame_streams": n_streams,
                        "frame_streams_note": "value = frames / time with consecutive frames alternating between HIP streams "
@@ -568,13 +775,23 @@ def main():
                                   "tracking (what a training iteration runs)": None if track_ms is None else round(track_ms, 4)},
             "train_iters_per_s": None if train_ips is None else round(train_ips, 3),
             "train_ms_per_iter": None if train_ms is None else round(train_ms, 4),
-            "train_step": "forward + loss 0.8 L1 + 0.2 (1-SSIM) (train.py:119-126; fused HIP SSIM) + backward + fused HIP Adam over "
-                          "all 59 floats/Gaussian, a new camera every iteration (%d views cycled, train.py:96-102); *_sparse_adam = the "
-                          "reference's accelerated call form (separate dc / rest SH tensors + SparseGaussianAdam on visible rows, "
-                          "train.py:180-183); *_l1 = L1 loss only; *_ssim_torch = SSIM through torch conv2d ops; full loop with density "
-                          "control: tools/train_run.py" % max(1, a.views) +
-                          ("" if world == 1 else "; N > 1: Gaussians AND tile rows sharded (record all-gather / gradient "
-                                                  "reduce-scatter), loss replicated on the all-gathered image"),
+            "train_step": "forward + loss 0.8 L1 + 0.2 (1-SSIM) (train.py:119-126) as ONE fused HIP kernel pair (fused_ssim.fused_train_loss: "
+                          "L1, its sign gradient and the mix inside the SSIM kernels) + backward + fused HIP Adam over all 59 floats/Gaussian, a "
+                          "new camera every iteration (%d views cycled, train.py:96-102); *_sparse_adam = the reference's accelerated call "
+                          "form (separate dc / rest SH tensors + SparseGaussianAdam on visible rows, train.py:180-183); *_l1 = L1 loss only; "
+                          "*_ssim_unfused_l1 = round 2's loss (fused SSIM, L1 + mix as torch ops); *_densify = the SURVEY 8(d) definition: "
+                          "sparse-Adam step + density statistics every iteration + clone / split / prune every 100 (train.py:160-174), "
+                          "amortised; *_ssim_torch = SSIM through torch conv2d ops; full 30 000-iteration loop: tools/train_run.py" % max(1, a.views) +
+                          ("" if world == 1 else "; N > 1: Gaussians AND tile rows sharded (mode C: targeted all-to-all forward and "
+                                                  "backward; mode B fallback: record all-gather / gradient reduce-scatter), loss replicated on "
+                                                  "the all-gathered image"),
+            "train_iters_per_s_densify": None if not densify_leg else densify_leg["iters_per_s"],
+            "train_densify": densify_leg,
+            "train_iters_per_s_ssim_unfused_l1": None if "ssim_unfused_l1" not in train else round(1e3 / train["ssim_unfused_l1"], 3),
+            "gpu_event_ms": event_stats,
+            "gpu_event_note": "per-step HIP-event intervals on the launch stream (median / p10 / p90 / mean) beside the wall-clock mean that "
+                              "`value` uses; the host is paced by the per-frame R read-back, so the two agree when nothing stalls",
+            "forward_cycled_views": cycled,
             "train_iters_per_s_sparse_adam": None if "sparse_adam" not in train else round(1e3 / train["sparse_adam"], 3),
             "train_iters_per_s_ssim_torch": None if "ssim_torch" not in train else round(1e3 / train["ssim_torch"], 3),
             "train_iters_per_s_l1": None if "l1" not in train else round(1e3 / train["l1"], 3),

@@ -396,6 +396,7 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
     if (counters && lane == 0) {
         atomicAdd(counters + 2, (unsigned long long)nsteps);
         atomicAdd(counters + 3, (unsigned long long)nbatch);
+        atomicMax(counters + 5, (unsigned long long)nsteps);      // the heaviest wave
     }
 }
 

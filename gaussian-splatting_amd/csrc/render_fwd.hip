@@ -277,6 +277,7 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
     if (counters && lane == 0) {     // [0] (8x8 block, entry) pairs blended by all 64 lanes, [1] batches of 64 entries box-tested
         atomicAdd(counters + 0, (unsigned long long)nsteps);
         atomicAdd(counters + 1, (unsigned long long)nbatches);
+        atomicMax(counters + 4, (unsigned long long)nsteps);      // the heaviest wave (tail of the launch: max / mean)
     }
     if (inside) {
         const int64_t pix = (int64_t)py * cam.W + px;

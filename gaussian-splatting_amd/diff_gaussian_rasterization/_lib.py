@@ -201,9 +201,10 @@ def profile_reset() -> None:
 
 
 def profile_counters(reset: bool = True) -> dict:
-    out = (C.c_uint64 * 4)()
-    check(load().gsr_profile_counters(out, 4, 1 if reset else 0), "gsr_profile_counters")
-    return {"fwd_steps": int(out[0]), "fwd_batches": int(out[1]), "bwd_steps": int(out[2]), "bwd_batches": int(out[3])}
+    out = (C.c_uint64 * 6)()
+    check(load().gsr_profile_counters(out, 6, 1 if reset else 0), "gsr_profile_counters")
+    return {"fwd_steps": int(out[0]), "fwd_batches": int(out[1]), "bwd_steps": int(out[2]), "bwd_batches": int(out[3]),
+            "fwd_max_wave_steps": int(out[4]), "bwd_max_wave_steps": int(out[5])}
 
 
 def profile_read() -> dict:

@@ -104,6 +104,16 @@ class StripGather:
         return full
 
 
+_exact_strips_default: Optional[bool] = None      # None: exact sizes iff the backend is "nccl"; set by set_exact_strips()
+
+
+def set_exact_strips(flag: Optional[bool]) -> None:
+    """Force the padded (False) or the exact-size (True) strip all-gather, e.g. after probe_collectives() found that the
+    backend refuses all_gather with unequal tensors."""
+    global _exact_strips_default
+    _exact_strips_default = flag
+
+
 class _StripGatherList:
     """Exact-size form of StripGather: one receive buffer per rank (dist.all_gather with unequal sizes)."""
 
@@ -133,7 +143,7 @@ def gather_strips_async(local: torch.Tensor, plan: BandPlan, H: int, group=None,
     heights = [b - a for a, b in rows]
     a, b = rows[rank]
     if exact is None:
-        exact = dist.get_backend(group) == "nccl"
+        exact = _exact_strips_default if _exact_strips_default is not None else dist.get_backend(group) == "nccl"
     if exact and len(set(heights)) > 1 and min(heights) > 0:
         try:
             bufs = [local.new_empty(C, h, W) for h in heights]
@@ -429,6 +439,13 @@ def all_to_all_rows(send: torch.Tensor, send_counts: Sequence[int], recv_counts:
     if world == 1:
         recv.copy_(send)
         return recv, None
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        # CPU-test backend with device tensors (tests/: two ranks sharing one GPU over gloo): gloo's all-to-all takes host
+        # tensors only, so the rows are staged through host memory.  RCCL ("nccl") takes the device tensors directly.
+        r_cpu = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(r_cpu, send.contiguous().cpu(), [int(c) for c in recv_counts], [int(c) for c in send_counts], group=group)
+        recv.copy_(r_cpu)
+        return recv, None
     work = dist.all_to_all_single(recv, send.contiguous(), [int(c) for c in recv_counts], [int(c) for c in send_counts],
                                   group=group, async_op=async_op)
     return recv, (work if async_op else None)
@@ -676,3 +693,66 @@ def sharded_forward_finish(fr: ShardedFrame):
         color, _, _ = hip_render_packed(fr.rs, fr.plan.band(rank), fr.recv, True)
         fr.keep = None
         return gather_strips_async(color, fr.plan, int(fr.rs.image_height), fr.group)
+
+
+def probe_collectives(group=None, device=None) -> dict:
+    """First contact with the collective backend (RCCL has never run before the driver's multi-GPU bench: VERDICT r02 weak #8):
+    one tiny instance of every collective the renderers use, each in its own try / except, so that a caller can pick a mode
+    that works and REPORT what failed instead of dying inside a frame.  Returns {"backend", "all_reduce", "all_gather",
+    "all_to_all_single", "all_gather_uneven", "reduce_scatter", "errors": {name: message}}."""
+    out = {"backend": None, "all_reduce": False, "all_gather": False, "all_to_all_single": False, "all_gather_uneven": False,
+           "reduce_scatter": False, "errors": {}}
+    world = _world(group)
+    if world == 1:
+        return out
+    rank = dist.get_rank(group)
+    out["backend"] = dist.get_backend(group)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if out["backend"] == "nccl" else torch.device("cpu")
+
+    def attempt(name, fn):
+        try:
+            fn()
+            if device.type == "cuda":
+                torch.cuda.synchronize(device)
+            out[name] = True
+        except Exception as ex:          # noqa: BLE001 -- the message is the result
+            out["errors"][name] = repr(ex)[:300]
+
+    def _all_reduce():
+        t = torch.ones(4, device=device)
+        dist.all_reduce(t, group=group)
+        assert float(t[0]) == world
+
+    def _all_gather():
+        t = torch.full((8,), float(rank), device=device)
+        o = torch.empty(8 * world, device=device)
+        dist.all_gather_into_tensor(o, t, group=group)
+        assert float(o[-1]) == world - 1
+
+    def _a2a():
+        send_counts = [1 + ((rank + d) % 3) for d in range(world)]
+        recv_counts = [1 + ((r + rank) % 3) for r in range(world)]
+        send = torch.full((sum(send_counts), PACKED_WORDS), float(rank), device=device)
+        recv, _ = all_to_all_rows(send, send_counts, recv_counts, group)
+        assert recv.shape[0] == sum(recv_counts) and float(recv[-1, 0]) == world - 1
+
+    def _uneven():
+        bufs = [torch.empty(r + 1, 4, device=device) for r in range(world)]
+        dist.all_gather(bufs, torch.full((rank + 1, 4), float(rank), device=device), group=group)
+        assert float(bufs[-1][0, 0]) == world - 1
+
+    def _reduce_scatter():
+        if out["backend"] == "gloo":
+            raise RuntimeError("gloo has no reduce_scatter (the callers use all_reduce + slice)")
+        full = torch.ones(world * 4, device=device)
+        o = torch.empty(4, device=device)
+        dist.reduce_scatter_tensor(o, full, group=group)
+        assert float(o[0]) == world
+
+    attempt("all_reduce", _all_reduce)
+    attempt("all_gather", _all_gather)
+    attempt("all_to_all_single", _a2a)
+    attempt("all_gather_uneven", _uneven)
+    attempt("reduce_scatter", _reduce_scatter)
+    return out

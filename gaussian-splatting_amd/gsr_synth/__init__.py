@@ -179,3 +179,75 @@ def make_edge_scene(P: int, cam: Camera, seed: int = 1) -> Scene:
         sc.means3D[2 * n:3 * n] = sc.means3D[3 * n:4 * n]
     sc.meta["kind"] = "edge"
     return sc
+
+
+def make_clustered_scene(P: int, cam: Camera, seed: int = 0, n_clusters: int = 200, s_med: float = 0.012, overscan: float = 1.6,
+                         z_min: float = 1.5, z_max: float = 14.0, floaters: float = 0.05, sh_degree: int = 3,
+                         max_sh_degree: int = 3) -> Scene:
+    """A stand-in that looks more like a TRAINED scene than the i.i.d.-uniform cloud of make_scene (VERDICT r02 missing #6:
+    configs name garden / bicycle / truck, every timing was on uniform Gaussians):
+      * a mixture of `n_clusters` anisotropic clusters ("objects / surfaces"), log-normal cluster populations (sigma 1.0: the
+        largest clusters hold tens of times the median), cluster extents log-normal around 0.35 (sigma 0.7) per axis with one
+        axis flattened x0.15 (surface-like sheets), random orientation;
+      * cluster centres spread over 1.6x the frustum of `cam` laterally, so only ~40 % of the Gaussians are visible from any
+        one view (a trained scene is much larger than one camera's frustum -- this is what SparseGaussianAdam exploits,
+        README.md:496);
+      * per-Gaussian scales log-normal around s_med x a per-cluster factor (sigma 0.5), flattened x0.2 along one axis;
+      * bimodal opacities (sigmoid of N(0, 2.5^2): many nearly transparent, many nearly opaque);
+      * `floaters` (5 %): isolated Gaussians anywhere in the volume with 4-12x the scale and low opacity -- the large
+        semi-transparent splats a real optimisation leaves behind, which touch dozens to hundreds of tiles each.
+    Same frozen-generator contract as make_scene: (seed, P, camera, arguments) determine the scene."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    f32 = torch.float32
+    n_float = int(P * floaters)
+    n_clu = P - n_float
+    # cluster populations
+    wgt = torch.exp(torch.randn(n_clusters, generator=g, dtype=torch.float64) * 1.0)
+    owner = torch.multinomial(wgt / wgt.sum(), n_clu, replacement=True, generator=g)
+    # cluster frames in the camera space of `cam`
+    cz = torch.rand(n_clusters, generator=g, dtype=f32) * (z_max - z_min) + z_min
+    cu = torch.rand(n_clusters, generator=g, dtype=f32) * 2 - 1
+    cv = torch.rand(n_clusters, generator=g, dtype=f32) * 2 - 1
+    centre = torch.stack([cu * cz * cam.tanfovx * overscan, cv * cz * cam.tanfovy * overscan, cz], dim=1)
+    ext = torch.exp(torch.randn(n_clusters, 3, generator=g, dtype=f32) * 0.7 + math.log(0.35))
+    flat_axis = torch.randint(0, 3, (n_clusters,), generator=g)
+    ext[torch.arange(n_clusters), flat_axis] *= 0.15
+    cq = torch.randn(n_clusters, 4, generator=g, dtype=f32)
+    cq = cq / cq.norm(dim=1, keepdim=True)
+    r, x, y, z = cq[:, 0], cq[:, 1], cq[:, 2], cq[:, 3]
+    Rc = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                      2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                      2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).view(n_clusters, 3, 3)
+    local = torch.randn(n_clu, 3, generator=g, dtype=f32) * ext[owner]
+    pc = centre[owner] + torch.bmm(Rc[owner], local.unsqueeze(2)).squeeze(2)
+    cscale = torch.exp(torch.randn(n_clusters, generator=g, dtype=f32) * 0.5)
+    log_s = torch.randn(n_clu, 3, generator=g, dtype=f32) * 0.6 + math.log(s_med) + torch.log(cscale[owner])[:, None]
+    thin = torch.randint(0, 3, (n_clu,), generator=g)
+    log_s[torch.arange(n_clu), thin] += math.log(0.2)
+    opac_logit = torch.randn(n_clu, 1, generator=g, dtype=f32) * 2.5
+    # floaters
+    fz = torch.rand(n_float, generator=g, dtype=f32) * (z_max - z_min) + z_min
+    fu = torch.rand(n_float, generator=g, dtype=f32) * 2 - 1
+    fv = torch.rand(n_float, generator=g, dtype=f32) * 2 - 1
+    fpc = torch.stack([fu * fz * cam.tanfovx * overscan, fv * fz * cam.tanfovy * overscan, fz], dim=1)
+    flog_s = torch.randn(n_float, 3, generator=g, dtype=f32) * 0.5 + math.log(s_med) + \
+        torch.log(4.0 + 8.0 * torch.rand(n_float, 1, generator=g, dtype=f32))
+    fop_logit = torch.randn(n_float, 1, generator=g, dtype=f32) * 1.0 - 2.0
+    pc = torch.cat([pc, fpc], dim=0)
+    log_s = torch.cat([log_s, flog_s], dim=0)
+    opac = torch.sigmoid(torch.cat([opac_logit, fop_logit], dim=0))
+    # interleave floaters and cluster members (a trained model's order carries no structure)
+    perm = torch.randperm(P, generator=g)
+    pc, log_s, opac = pc[perm], log_s[perm], opac[perm]
+    w2c = cam.world_view_transform.transpose(0, 1).to(f32)
+    Rm, t = w2c[:3, :3], w2c[:3, 3]
+    means = (pc - t[None, :]) @ Rm
+    q = torch.randn(P, 4, generator=g, dtype=f32)
+    q = q / q.norm(dim=1, keepdim=True)
+    M = (max_sh_degree + 1) ** 2
+    shs = torch.randn(P, M, 3, generator=g, dtype=f32) * 0.1
+    shs[:, 0, :] = torch.randn(P, 3, generator=g, dtype=f32) * 0.5
+    return Scene(means.contiguous(), torch.exp(log_s).contiguous(), q.contiguous(), opac.contiguous(), shs.contiguous(), sh_degree,
+                 {"seed": seed, "P": P, "s_med": s_med, "overscan": overscan, "kind": "clustered", "n_clusters": n_clusters,
+                  "floaters": floaters, "W": cam.image_width, "H": cam.image_height})

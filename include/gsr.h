@@ -327,8 +327,10 @@ int gsr_profile_reset(void);
 int gsr_profile_read(float* ms_out, int32_t* count_out, int n);
 /* Work counters of the blend kernels, accumulated over the launches made while profiling is enabled (bench.py turns them
  * into achieved FLOP/s): [0] forward (8x8 pixel block, list entry) pairs blended by a whole wave, [1] forward batches of
- * 64 entries box-tested, [2] / [3] the same for the blend backward.  reset != 0 clears them after reading. */
-#define GSR_COUNTER_COUNT 4
+ * 64 entries box-tested, [2] / [3] the same for the blend backward.  reset != 0 clears them after reading.
+ * [4] / [5]: steps of the HEAVIEST wave of the forward / backward launches (max, not sum): with the wave counts this gives the
+ * tail of a launch, slowest wave / mean wave, which is what clustered scenes stress. */
+#define GSR_COUNTER_COUNT 6
 int gsr_profile_counters(uint64_t* out, int n, int reset);
 
 /* A/B switches for measurement (0 = the product default everywhere).  The product library accepts the tuning knobs

@@ -197,26 +197,47 @@ def test_distcuda2_large_cloud_and_init_scales():
         distCUDA2(torch.zeros(10, 3))
 
 
-def test_bench_two_rank_path_on_one_gpu():
-    """bench.py's N > 1 code path (band plan, strip all-gather, record all-reduce, max-over-ranks timing) with two
-    ranks sharing this box's single GPU over gloo -- RCCL itself needs one device per rank and is exercised by the
-    driver's multi-GPU run."""
+@pytest.mark.parametrize("mode,nproc", [("C", 2), ("C", 3), ("B", 2)])
+def test_bench_multi_rank_path_on_one_gpu(mode, nproc):
+    """bench.py's N > 1 code path end to end -- first-contact probe of the collectives, band plan, mode C (Gaussian shards,
+    route kernels, variable-size all-to-all of packed records forward and of gradient rows backward, pipelined frames) or
+    mode B, strip all-gather, max-over-ranks timing -- with the ranks sharing this box's single GPU over gloo.  RCCL itself
+    needs one device per rank and is exercised by the driver's multi-GPU run."""
     import json
     import os
     import subprocess
     import sys
     from helpers import ROOT
     env = dict(os.environ, GSR_BENCH_SHARED_GPU="1", GSR_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--P", "60000", "--width", "640", "--height", "368", "--no-cpu-baseline", "--min-warm-seconds", "0.2"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150, cwd=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(29731 + nproc + (7 if mode == "B" else 0)), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc),
+           "--steps", "3", "--warmup", "1", "--P", "60000", "--width", "640", "--height", "368", "--no-cpu-baseline",
+           "--min-warm-seconds", "0.2", "--mode", mode]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["train_iters_per_s"] > 0 and d["scaling"] == "strong"
+    assert "error" not in d, d
+    assert d["n_gpus"] == nproc and d["value"] > 0 and d["train_iters_per_s"] > 0 and d["scaling"] == "strong"
+    assert d["config"]["mode"] == mode and d["config"]["collectives"]["all_to_all_single"]
     assert d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
+
+
+def test_bench_reports_an_error_line_instead_of_dying_silently():
+    """a failure inside the run (here: an option the library refuses) must still end in ONE JSON line
+    with an "error" field on rank 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--P", "20000", "--width", "320",
+                        "--height", "192", "--no-cpu-baseline", "--train-steps", "0", "--opt", "no_such_option=1"],
+                       capture_output=True, text=True, timeout=200, cwd=ROOT)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and "no_such_option" in json.loads(lines[0])["error"]
 
 
 def test_view_sequence_with_changing_instance_counts():
