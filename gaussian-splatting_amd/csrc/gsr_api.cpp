@@ -280,6 +280,9 @@ GsrBwdScratch gsr_carve_bwd(char* base, int P, int64_t R) {
     b.splat_grads = (float*)take(np * 48);
     b.inst_grads = (float*)take(nr * 48 * GSR_BWD_SLOTS);
     b.inst_flag = (uint32_t*)take(nr * 4);
+    const size_t nu = gsr_reduce_units((int64_t)nr);
+    b.unit_first = (uint2*)take(nu * 8);
+    b.unit_piece = (float*)take(nu * 96);
     b.bytes = off;
     return b;
 }
@@ -876,7 +879,7 @@ int gsr_backward_blend(const GsrRasterSettings* settings, int P, int32_t num_ren
     if (g_render_bwd_variant != 1 && num_rendered > 0) {
         StageTimer t(GSR_STAGE_GATHER_BWD, st);
         gsr_launch_reduce_instances(P, num_rendered, g.vals[depth_order_buffer_index()], g.offsets, g.splats, w.inst_grads,
-                                    w.inst_flag, sg, st);
+                                    w.inst_flag, sg, w.unit_first, w.unit_piece, st);
     }
     STAGE_CHECK("render backward reduce");
     HIP_OK(hipGetLastError());

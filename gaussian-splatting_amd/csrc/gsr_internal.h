@@ -200,8 +200,10 @@ void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const
                                 const float* dL_dpix, const float* dL_dinvdepth, float* splat_grads /*[P,12] variant 1*/,
                                 float* inst_grads /*[4][R,12]*/, uint32_t* inst_flag /*[R]*/, int64_t R, int variant,
                                 unsigned long long* counters, hipStream_t st);
+size_t gsr_reduce_units(int64_t R);      // units of 1024 instance records the reduce works in
 void gsr_launch_reduce_instances(int P, int64_t R, const uint32_t* order, const uint32_t* offsets, const float4* splats,
-                                 const float* inst_grads, const uint32_t* inst_flag, float* splat_grads, hipStream_t st);
+                                 const float* inst_grads, const uint32_t* inst_flag, float* splat_grads, uint2* unit_first,
+                                 float* unit_piece, hipStream_t st);
 
 // backward scratch (caller-owned, gsr_backward_scratch_bytes): per-Gaussian record, per-instance records, maps
 // record slots per instance: one per 16x8 half tile (the measurement build's per-quadrant kernel needs four)
@@ -214,6 +216,8 @@ struct GsrBwdScratch {
     float* splat_grads;     // [P,12]
     float* inst_grads;      // [GSR_BWD_SLOTS][R,12]  one record slot per (half tile, instance), slot-major
     uint32_t* inst_flag;    // [R]  byte q != 0: slot q of the instance has a record
+    uint2* unit_first;      // [units]  reduce: (owner of the unit's first record, that owner's first record)
+    float* unit_piece;      // [units][2][12]  reduce: head / tail partial rows of every unit
     size_t bytes;
 };
 GsrBwdScratch gsr_carve_bwd(char* base, int P, int64_t R);

@@ -34,6 +34,7 @@
 // 5 dL/d(opacity*aa) 6,7,8 dL/d(rgb) 9 dL/d(1/depth) 10,11 pad.  Instance records hold the raw moments
 // (sum m dx, sum m dy, sum m dx^2, sum m dx dy, sum m dy^2) in slots 0..4 instead.
 #include "gsr_internal.h"
+#include "gsr_wave.h"
 
 namespace {
 
@@ -663,72 +664,124 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
 #endif  // GSR_AB_VARIANTS
 
 // splat_grads[g] = sum of the instance records of Gaussian g.  In emission (= depth) order a Gaussian's records are one
-// contiguous run, and the runs of 64 consecutive Gaussians of the depth order form one contiguous stream.  One
-// WORKGROUP per 64 Gaussians: its RED_WAVES waves take the stream's 64-record chunks round-robin (lane = record, fully
-// coalesced), find each record's owner with the same 6-step cross-lane binary search as emit_instances, sum records
-// of the same owner with a SEGMENTED inclusive scan across the lanes, and the last lane of each segment adds the
-// segment total into the owner's row of the wave's private LDS accumulator; the accumulators are added in
-// fixed order at the end (deterministic).  History on the 1 M / 1080p frame: lane-per-Gaussian loop 0.49 ms (the wave
-// waits for its largest splat), one wave per 64 Gaussians 0.17 ms (depth order puts the largest splats -- hundreds of
-// tiles each -- into the same few waves, whose serial flag -> record chain sets the kernel time).
-constexpr int RED_WAVES = 4;        // waves per 64-Gaussian group (1: 170 us, 4: 93 us, 8: 117 us on the bench frame)
+// contiguous run.  Round 3: the stream of R records is cut into UNITS of 1024 records, one wave per unit, whatever the
+// Gaussians look like -- round 2 gave one workgroup to every 64 Gaussians of the depth order, and a splat that covers the
+// whole frame (8 160 records; trained-looking scenes have many of hundreds) made its workgroup the kernel's tail: 0.09 ms on
+// the uniform bench frame but 0.45 ms on the clustered stand-in, 41 % of its backward.
+//   reduce_prepare    per Gaussian: the units whose first record it owns get (owner, owner's first record) -- the only
+//                     thing a unit needs to find all its owners; Gaussians without records get their zero row here
+//   bwd_reduce_units  one wave per unit: the starts of the next <= 1024 Gaussians are fetched in one batch and marked in LDS,
+//                     a running max-scan over the marks gives every record its owner; 64 records per step (lane = record,
+//                     fully coalesced; flag words up front, records one step ahead), the <= 2 slot records of an instance
+//                     added in fixed order, a segmented scan (DPP) sums the runs; a run that begins and ends inside the unit is
+//                     finished on the spot (moments -> derivatives with the Gaussian's conic), the run that enters from the
+//                     previous unit becomes the unit's HEAD piece, the run that is still open at the unit's end its TAIL piece
+//   reduce_stitch     per unit with a tail piece: tail + the head pieces of the following units while they belong to the same
+//                     Gaussian (fixed order) -> the finished row
+// Every sum has a fixed association order -> two runs agree bit for bit.
+constexpr int RU = 1024;
+constexpr int RU_STEPS = RU / 64;
 
-__global__ void __launch_bounds__(RED_WAVES * 64)
-bwd_reduce_instances(int P, int64_t R, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
-                     const float4* __restrict__ slot_grads /*[4][R] records*/, const uint32_t* __restrict__ inst_flag /*[R], byte q = quadrant q*/,
-                     const float4* __restrict__ splats, float4* __restrict__ splat_grads) {
-    __shared__ float s_acc[RED_WAVES][64 * 12];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t j0 = (int64_t)blockIdx.x * 64;
-    if (j0 >= P) return;
-    const int64_t j = j0 + lane;
-    const uint32_t base = j0 > 0 ? offsets[j0 - 1] : 0u;
-    const uint32_t incl = j < P ? offsets[j] - base : 0xFFFFFFFFu;
-    const int last = (int)((P - j0) < 64 ? (P - j0 - 1) : 63);
-    const uint32_t total = __shfl(incl, last, 64);
-    // most groups have fewer than 64 records: waves without a chunk only wait at the barrier, and the final sum reads
-    // the accumulators of the working waves only
-    const int nwork = (int)min((uint32_t)RED_WAVES, (total + 63u) >> 6);
-    float* acc = s_acc[wv];
-    if (wv < nwork) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) acc[lane * 12 + i] = 0.f;
+__device__ __forceinline__ void finish_row(const uint32_t* __restrict__ order, const float4* __restrict__ splats,
+                                           float4* __restrict__ splat_grads, uint32_t j, const float (&v)[10]) {
+    const uint32_t g = order[j];
+    float4 t0 = make_float4(v[0], v[1], v[2], v[3]), t1 = make_float4(v[4], v[5], v[6], v[7]);
+    const float4 q0 = splats[(int64_t)g * 4 + 0];
+    moments_to_grads(q0.z, q0.w, splats[(int64_t)g * 4 + 1].x, t0, t1);
+    splat_grads[(int64_t)g * 3 + 0] = t0;
+    splat_grads[(int64_t)g * 3 + 1] = t1;
+    splat_grads[(int64_t)g * 3 + 2] = make_float4(v[8], v[9], 0.f, 0.f);
+}
+__device__ __forceinline__ void write_piece(float4* __restrict__ piece, uint32_t j, const float (&v)[10], bool valid) {
+    piece[0] = make_float4(v[0], v[1], v[2], v[3]);
+    piece[1] = make_float4(v[4], v[5], v[6], v[7]);
+    piece[2] = make_float4(v[8], v[9], __uint_as_float(j), __uint_as_float(valid ? 1u : 0u));
+}
+
+__global__ void __launch_bounds__(256)
+reduce_prepare(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets, uint2* __restrict__ unit_first,
+               float4* __restrict__ splat_grads) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < P; j += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t incl = offsets[j], excl = j ? offsets[j - 1] : 0u;
+        if (incl == excl) {                    // no record: the row is zero
+            const uint32_t g = order[j];
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            splat_grads[(int64_t)g * 3 + 0] = z; splat_grads[(int64_t)g * 3 + 1] = z; splat_grads[(int64_t)g * 3 + 2] = z;
+            continue;
+        }
+        for (uint32_t k = (excl + RU - 1u) / RU; k <= (incl - 1u) / RU; ++k) unit_first[k] = make_uint2((uint32_t)j, excl);
     }
-    const float4* stream = slot_grads + (int64_t)base * 3;
-    // The walk is a chain of dependent loads (offsets -> flag words -> records) over only a few chunks per wave, i.e. pure
-    // memory latency.  Two-deep software pipeline: while chunk c is reduced, the records of chunk c+1 (whose flag words
-    // arrived one trip earlier) and the flag words of chunk c+2 are already in flight.
-    constexpr uint32_t STEP = RED_WAVES * 64u;
-    auto load_flags = [&](uint32_t c0) -> uint32_t {
-        const uint32_t r = c0 + (uint32_t)lane;
-        return (c0 < total && r < total) ? inst_flag[(int64_t)base + r] : 0u;
-    };
-    auto load_recs = [&](uint32_t c0, uint32_t flags, float4 (&u)[GSR_BWD_SLOTS][3]) {
-        const uint32_t r = c0 + (uint32_t)lane;
+}
+
+__global__ void __launch_bounds__(64)
+bwd_reduce_units(int P, int64_t R, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
+                 const uint2* __restrict__ unit_first, const float4* __restrict__ slot_grads /*[SLOTS][R] records*/,
+                 const uint32_t* __restrict__ inst_flag /*[R], byte q = slot q*/, const float4* __restrict__ splats,
+                 float4* __restrict__ splat_grads, float4* __restrict__ unit_piece /*[units][2][3]*/) {
+    __shared__ uint32_t s_mark[RU];
+    const int lane = threadIdx.x;
+    const int64_t u = blockIdx.x;
+    const uint32_t c0 = (uint32_t)(u * RU);
+    const uint32_t n = (uint32_t)((R - (int64_t)c0) < (int64_t)RU ? (R - (int64_t)c0) : RU);
+    const uint2 uf = unit_first[u];
+    const uint32_t j0 = uf.x;
+    const bool head_case = uf.y < c0;                 // owner 0's run began in an earlier unit
+    // ---- every independent load of the unit up front: the starts of the next RU Gaussians, the flag words of all steps ----
+    uint32_t st[RU_STEPS], fl[RU_STEPS];
+#pragma unroll
+    for (int t = 0; t < RU_STEPS; ++t) {
+        const int64_t jj = (int64_t)j0 + 1 + t * 64 + lane;          // Gaussian jj starts at offsets[jj - 1]
+        st[t] = offsets[jj <= (int64_t)P - 1 ? jj - 1 : (int64_t)P - 1];
+        if (jj > (int64_t)P - 1) st[t] = 0xFFFFFFFFu;
+        const uint32_t r = (uint32_t)t * 64u + (uint32_t)lane;
+        fl[t] = inst_flag[(int64_t)c0 + (r < n ? r : 0u)];
+        if (r >= n) fl[t] = 0u;
+    }
+#pragma unroll
+    for (int t = 0; t < RU_STEPS; ++t) s_mark[t * 64 + lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < RU_STEPS; ++t)
+        if (st[t] >= c0 && st[t] - c0 < n) s_mark[st[t] - c0] = (uint32_t)(1 + t * 64 + lane);      // (Gaussians without records start at R)
+    __builtin_amdgcn_wave_barrier();
+
+    const float4* stream = slot_grads + (int64_t)c0 * 3;
+    auto load_recs = [&](int t, uint32_t flags, float4 (&rec)[GSR_BWD_SLOTS][3]) {
+        const uint32_t r = (uint32_t)t * 64u + (uint32_t)lane;
 #pragma unroll
         for (int q = 0; q < GSR_BWD_SLOTS; ++q) {
             if ((flags >> (8 * q)) & 0xFFu) {
-                const float4* rec = stream + ((int64_t)q * R + (int64_t)r) * 3;
-                u[q][0] = rec[0]; u[q][1] = rec[1]; u[q][2] = rec[2];
+                const float4* p = stream + ((int64_t)q * R + (int64_t)r) * 3;
+                rec[q][0] = p[0]; rec[q][1] = p[1]; rec[q][2] = p[2];
             } else {
-                u[q][0] = u[q][1] = u[q][2] = make_float4(0.f, 0.f, 0.f, 0.f);
+                rec[q][0] = rec[q][1] = rec[q][2] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
-    const uint32_t cfirst = (uint32_t)wv * 64u;
-    uint32_t flags_cur = load_flags(cfirst);
-    uint32_t flags_nxt = load_flags(cfirst + STEP);
     float4 rec_cur[GSR_BWD_SLOTS][3], rec_nxt[GSR_BWD_SLOTS][3];
-    load_recs(cfirst, flags_cur, rec_cur);
-    for (uint32_t c0 = cfirst; c0 < total; c0 += STEP) {
-        const uint32_t r = c0 + lane;
-        const bool valid = r < total;
-        const uint32_t flags = flags_cur;
-        const bool has_rec = flags != 0u;                 // untouched instances have no record
-        load_recs(c0 + STEP, flags_nxt, rec_nxt);
-        const uint32_t flags_nn = load_flags(c0 + 2 * STEP);
+    load_recs(0, fl[0], rec_cur);
+    uint32_t run_owner = 0u;                      // max-scan carry: owner (local index) of the last record seen
+    bool have_open = false, head_written = false;
+    uint32_t open_owner = 0u;
+    float open_v[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) open_v[i] = 0.f;
+    const int nsteps = (int)((n + 63u) >> 6);
+    float4* piece = unit_piece + u * 6;
+#pragma unroll 1
+    for (int t = 0; t < nsteps; ++t) {
+        const uint32_t r = (uint32_t)t * 64u + (uint32_t)lane;
+        const bool valid = r < n;
+        if (t + 1 < nsteps) {
+            uint32_t fnext = 0u;
+#pragma unroll
+            for (int k = 0; k < RU_STEPS; ++k) fnext = (k == t + 1) ? fl[k] : fnext;      // (register array: selected by unrolled compare)
+            load_recs(t + 1, fnext, rec_nxt);
+        }
+        const uint32_t m = s_mark[r];
+        const uint32_t own = max(run_owner, gsrw::wave_incl_max_u32(m));
+        run_owner = (uint32_t)__builtin_amdgcn_readlane((int)own, 63);
         float v[10];
-        // the records of the instance (one per half tile; per quadrant in the A/B build), added in fixed slot order
         {
             float4 a0 = rec_cur[0][0], a1 = rec_cur[0][1], a2 = rec_cur[0][2];
 #pragma unroll
@@ -740,57 +793,75 @@ bwd_reduce_instances(int P, int64_t R, const uint32_t* __restrict__ order, const
             v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
             v[8] = a2.x; v[9] = a2.y;
         }
-        flags_cur = flags_nxt;
-        flags_nxt = flags_nn;
 #pragma unroll
         for (int q = 0; q < GSR_BWD_SLOTS; ++q) { rec_cur[q][0] = rec_nxt[q][0]; rec_cur[q][1] = rec_nxt[q][1]; rec_cur[q][2] = rec_nxt[q][2]; }
-        if (__ballot(has_rec) == 0ull) continue;     // e.g. far Gaussians that every pixel terminated in front of
-        int lo = 0, hi = last;
+        // the run left open by the previous step: it continues into lane 0, or it is complete
+        const uint32_t own0 = (uint32_t)__builtin_amdgcn_readlane((int)own, 0);
+        if (have_open) {
+            if (own0 == open_owner) {
+                if (lane == 0) {
 #pragma unroll
-        for (int it = 0; it < 6; ++it) {
-            const int mid = (lo + hi) >> 1;
-            const uint32_t vv = __shfl(incl, mid, 64);
-            if (vv > r) hi = mid; else lo = mid + 1;
-        }
-        const int s = valid ? (lo > last ? last : lo) : 64 + lane;     // invalid lanes never merge
-        // segmented inclusive scan (segments = Gaussians, ids ascending) with DPP moves instead of __shfl_up: four
-        // Hillis-Steele steps inside the 16-lane rows, then the rows are chained with row_bcast:15 / row_bcast:31.  A lane
-        // without a source (row start, masked row) receives the sentinel -1 as segment id and takes nothing.  66 VALU
-        // moves replace 66 ds_bpermute round trips per chunk.
-        seg_scan_step<0x111, 0xf>(s, v);      // row_shr:1
-        seg_scan_step<0x112, 0xf>(s, v);      // row_shr:2
-        seg_scan_step<0x114, 0xf>(s, v);      // row_shr:4
-        seg_scan_step<0x118, 0xf>(s, v);      // row_shr:8
-        seg_scan_step<0x142, 0xa>(s, v);      // row_bcast:15 -> rows 1, 3
-        seg_scan_step<0x143, 0xc>(s, v);      // row_bcast:31 -> rows 2, 3
-        const int s_next = __shfl_down(s, 1, 64);
-        const bool tail = valid && (lane == 63 || s_next != s);
-        if (tail) {
-#pragma unroll
-            for (int i = 0; i < 10; ++i) acc[s * 12 + i] += v[i];
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    if (wv == 0 && j < P) {
-        const uint32_t g = order[j];
-        float4 t[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int k = 0; k < nwork; ++k) {       // fixed order: deterministic
-                const float4 b = *reinterpret_cast<const float4*>(&s_acc[k][lane * 12 + q * 4]);
-                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                    for (int i = 0; i < 10; ++i) v[i] += open_v[i];
+                }
+            } else if (lane == 0) {
+                if (open_owner == 0u && head_case) write_piece(piece, j0, open_v, true);
+                else finish_row(order, splats, splat_grads, j0 + open_owner, open_v);
             }
-            t[q] = a;
+            if (own0 != open_owner && open_owner == 0u && head_case) head_written = true;
         }
-        // the instance records carry moments (see bwd_step): turn the sums into derivatives with this Gaussian's conic
-        const float4 q0 = splats[(int64_t)g * 4 + 0];
-        moments_to_grads(q0.z, q0.w, splats[(int64_t)g * 4 + 1].x, t[0], t[1]);
-        splat_grads[(int64_t)g * 3 + 0] = t[0];
-        splat_grads[(int64_t)g * 3 + 1] = t[1];
-        splat_grads[(int64_t)g * 3 + 2] = t[2];
+        const int seg = valid ? (int)own : 0x40000000 + lane;          // invalid lanes never merge
+        seg_scan_step<0x111, 0xf>(seg, v);      // row_shr:1
+        seg_scan_step<0x112, 0xf>(seg, v);      // row_shr:2
+        seg_scan_step<0x114, 0xf>(seg, v);      // row_shr:4
+        seg_scan_step<0x118, 0xf>(seg, v);      // row_shr:8
+        seg_scan_step<0x142, 0xa>(seg, v);      // row_bcast:15 -> rows 1, 3
+        seg_scan_step<0x143, 0xc>(seg, v);      // row_bcast:31 -> rows 2, 3
+        const int last_lane = (int)min(63u, n - 1u - (uint32_t)t * 64u);
+        const int seg_next = __shfl_down(seg, 1, 64);
+        const bool complete = valid && lane < last_lane && seg_next != seg;      // a run that ends strictly inside the step
+        if (complete) {
+            if (own == 0u && head_case) write_piece(piece, j0, v, true);
+            else finish_row(order, splats, splat_grads, j0 + own, v);
+        }
+        if (__ballot(complete && own == 0u && head_case) != 0ull) head_written = true;
+        have_open = true;
+        open_owner = (uint32_t)__builtin_amdgcn_readlane((int)own, last_lane);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) open_v[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[i]), last_lane));
     }
+    // ---- the run still open at the unit's end: head piece (it entered from the previous unit and covers the whole unit) or tail ----
+    if (lane == 0) {
+        const bool open_is_head = have_open && open_owner == 0u && head_case;
+        float zero[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) zero[i] = 0.f;
+        if (open_is_head) write_piece(piece, j0, open_v, true);
+        else if (!head_written) write_piece(piece, 0u, zero, false);
+        if (have_open && !open_is_head) write_piece(piece + 3, j0 + open_owner, open_v, true);
+        else write_piece(piece + 3, 0u, zero, false);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+reduce_stitch(int64_t nunits, const uint32_t* __restrict__ order, const float4* __restrict__ splats,
+              const float4* __restrict__ unit_piece, float4* __restrict__ splat_grads) {
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nunits) return;
+    const float4* tp = unit_piece + u * 6 + 3;
+    const float4 t2 = tp[2];
+    if (__float_as_uint(t2.w) == 0u) return;
+    const uint32_t j = __float_as_uint(t2.z);
+    const float4 t0 = tp[0], t1 = tp[1];
+    float v[10] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y};
+    for (int64_t k = u + 1; k < nunits; ++k) {           // the head pieces of the following units, in order, while they are this Gaussian's
+        const float4* hp = unit_piece + k * 6;
+        const float4 h2 = hp[2];
+        if (__float_as_uint(h2.w) == 0u || __float_as_uint(h2.z) != j) break;
+        const float4 h0 = hp[0], h1 = hp[1];
+        v[0] += h0.x; v[1] += h0.y; v[2] += h0.z; v[3] += h0.w; v[4] += h1.x; v[5] += h1.y; v[6] += h1.z; v[7] += h1.w;
+        v[8] += h2.x; v[9] += h2.y;
+    }
+    finish_row(order, splats, splat_grads, j, v);
 }
 
 #ifdef GSR_AB_VARIANTS
@@ -932,9 +1003,18 @@ void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const
                            reinterpret_cast<uint8_t*>(inst_flag), R, counters);
 }
 
+size_t gsr_reduce_units(int64_t R) { return (size_t)((R + RU - 1) / RU); }
+
 void gsr_launch_reduce_instances(int P, int64_t R, const uint32_t* order, const uint32_t* offsets, const float4* splats,
-                                 const float* inst_grads, const uint32_t* inst_flag, float* splat_grads, hipStream_t st) {
-    const int64_t groups = ((int64_t)P + 63) / 64;       // one workgroup per 64 Gaussians of the depth order
-    hipLaunchKernelGGL(bwd_reduce_instances, dim3((int)groups), dim3(RED_WAVES * 64), 0, st, P, R, order, offsets,
-                       reinterpret_cast<const float4*>(inst_grads), inst_flag, splats, reinterpret_cast<float4*>(splat_grads));
+                                 const float* inst_grads, const uint32_t* inst_flag, float* splat_grads, uint2* unit_first,
+                                 float* unit_piece, hipStream_t st) {
+    const int64_t nunits = (R + RU - 1) / RU;
+    int64_t nb = ((int64_t)P + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(reduce_prepare, dim3((int)nb), dim3(256), 0, st, P, order, offsets, unit_first, reinterpret_cast<float4*>(splat_grads));
+    hipLaunchKernelGGL(bwd_reduce_units, dim3((int)nunits), dim3(64), 0, st, P, R, order, offsets, unit_first,
+                       reinterpret_cast<const float4*>(inst_grads), inst_flag, splats, reinterpret_cast<float4*>(splat_grads),
+                       reinterpret_cast<float4*>(unit_piece));
+    hipLaunchKernelGGL(reduce_stitch, dim3((int)((nunits + 255) / 256)), dim3(256), 0, st, nunits, order, splats,
+                       reinterpret_cast<const float4*>(unit_piece), reinterpret_cast<float4*>(splat_grads));
 }

@@ -13,7 +13,7 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-from gsr_synth import make_camera, look_at_camera, make_scene, make_edge_scene  # noqa: E402
+from gsr_synth import make_camera, look_at_camera, make_scene, make_edge_scene, make_clustered_scene  # noqa: E402
 from oracle import torch_oracle as O  # noqa: E402
 
 

@@ -70,6 +70,46 @@ def test_split_sh_equals_fused_form(P, W, H, deg, Mstore):
     assert float(gs[4].abs().max()) > 0 and (Mstore == 1 or deg == 0 or float(gs[5].abs().max()) > 0)
 
 
+@pytest.mark.parametrize("deg", [3, 1])
+def test_split_sh_form_against_the_oracle(deg):
+    """the separate-SH call form compared with the ORACLE directly (not only with the fused HIP form):
+    image, radii and every gradient -- the oracle sees dc and rest concatenated the way the reference's get_features does
+    (scene/gaussian_model.py:121-125), so its autograd hands back the two gradients by slicing."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from helpers import O
+    dev = torch.device("cuda:0")
+    W, H, P = 208, 160, 3000
+    cam = make_camera(W, H)
+    sc = make_scene(P, cam, seed=23, s_med=0.04)
+    s = oracle_settings(cam, sh_degree=deg, bg=torch.tensor([0.2, 0.1, 0.3]))
+    g = torch.Generator().manual_seed(6)
+    wgt, wd = torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g) * 0.3
+    names = ("means3D", "opacities", "scales", "rotations")
+    Lc = {k: getattr(sc, k).clone().requires_grad_(True) for k in names}
+    dc_c = sc.shs[:, :1].clone().contiguous().requires_grad_(True)
+    rest_c = sc.shs[:, 1:].clone().contiguous().requires_grad_(True)
+    col, radii, invd, aux = O.rasterize(Lc["means3D"], None, Lc["opacities"], s, shs=torch.cat([dc_c, rest_c], dim=1), scales=Lc["scales"],
+                                        rotations=Lc["rotations"], want_fragile=True, return_aux=True)
+    ((col * wgt).sum() + (invd * wd).sum()).backward()
+    Lg = {k: getattr(sc, k).clone().to(dev).requires_grad_(True) for k in names}
+    dc_g = sc.shs[:, :1].clone().contiguous().to(dev).requires_grad_(True)
+    rest_g = sc.shs[:, 1:].clone().contiguous().to(dev).requires_grad_(True)
+    gcol, gradii, ginvd = GaussianRasterizer(gpu_settings(s, dev))(means3D=Lg["means3D"], means2D=None, dc=dc_g, shs=rest_g,
+                                                                    opacities=Lg["opacities"], scales=Lg["scales"], rotations=Lg["rotations"])
+    ((gcol * wgt.to(dev)).sum() + (ginvd * wd.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(gradii.cpu(), radii)
+    err = (gcol.detach().cpu() - col.detach()).abs().amax(0)
+    assert float(err[~aux["fragile"]].max()) <= 1e-5
+    pairs = [(Lg[k].grad.cpu(), Lc[k].grad) for k in names] + [(dc_g.grad.cpu(), dc_c.grad), (rest_g.grad.cpu(), rest_c.grad)]
+    for a, b in pairs:
+        assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-12
+        if b.numel() > 1000:
+            dd = ((a - b).abs() / float(b.abs().max())).flatten()
+            assert float(torch.quantile(dd[:4_000_000], 0.999)) <= 1e-4
+    assert float(dc_c.grad.abs().max()) > 0 and float(rest_c.grad.abs().max()) > 0
+
+
 def test_split_sh_degree0_model_with_empty_rest():
     """max_sh_degree = 0: features_rest is [P,0,3]; the DC tensor alone is the SH record."""
     from diff_gaussian_rasterization import GaussianRasterizer

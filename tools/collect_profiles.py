@@ -27,13 +27,19 @@ line = [ln for ln in open(os.path.join(G, "p_bench_default.log")) if ln.startswi
 json.loads(line)
 open(os.path.join(ROOT, "profiles", f"{tag}_bench_default.json"), "w").write(line)
 
-stats = glob.glob(os.path.join(G, "prof_stats", "**", "*kernel_stats.csv"), recursive=True)[0]
-rows = list(csv.DictReader(open(stats)))
-with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"), "w") as f:
-    w = csv.writer(f)
-    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
-    for r in rows:
-        w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+steady = os.path.join(G, "kernel_stats_steady.csv")
+if os.path.exists(steady):
+    # tools/kernel_trace_stats.py: warm-up dispatches dropped, median / p10 / p90 beside the mean
+    rows = list(csv.DictReader(open(steady)))
+    open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"), "w").write(open(steady).read())
+else:
+    stats = glob.glob(os.path.join(G, "prof_stats", "**", "*kernel_stats.csv"), recursive=True)[0]
+    rows = list(csv.DictReader(open(stats)))
+    with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
 
 agg = collections.defaultdict(lambda: {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]})
 for d in ("prof_fetch", "prof_write"):

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 R="$PWD"
 cd /tmp
 rm -rf "$R/gpurun_out/prof_k"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_k" -o r1 -- python "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --train-steps 8 --min-warm-seconds 0.2 $BENCH_EXTRA > "$R/gpurun_out/k_prof.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_k" -o r1 -- python "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --densify-iters 0 --train-steps 8 --min-warm-seconds 0.2 $BENCH_EXTRA > "$R/gpurun_out/k_prof.log" 2>&1
 cd "$R"
 python - <<'PY'
 import csv, glob, re
