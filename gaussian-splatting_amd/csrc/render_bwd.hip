@@ -664,13 +664,13 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
 #endif  // GSR_AB_VARIANTS
 
 // splat_grads[g] = sum of the instance records of Gaussian g.  In emission (= depth) order a Gaussian's records are one
-// contiguous run.  Round 3: the stream of R records is cut into UNITS of 1024 records, one wave per unit, whatever the
+// contiguous run.  Round 3: the stream of R records is cut into UNITS of 256 records, one wave per unit, whatever the
 // Gaussians look like -- round 2 gave one workgroup to every 64 Gaussians of the depth order, and a splat that covers the
 // whole frame (8 160 records; trained-looking scenes have many of hundreds) made its workgroup the kernel's tail: 0.09 ms on
 // the uniform bench frame but 0.45 ms on the clustered stand-in, 41 % of its backward.
 //   reduce_prepare    per Gaussian: the units whose first record it owns get (owner, owner's first record) -- the only
 //                     thing a unit needs to find all its owners; Gaussians without records get their zero row here
-//   bwd_reduce_units  one wave per unit: the starts of the next <= 1024 Gaussians are fetched in one batch and marked in LDS,
+//   bwd_reduce_units  one wave per unit: the starts of the next <= 256 Gaussians are fetched in one batch and marked in LDS,
 //                     a running max-scan over the marks gives every record its owner; 64 records per step (lane = record,
 //                     fully coalesced; flag words up front, records one step ahead), the <= 2 slot records of an instance
 //                     added in fixed order, a segmented scan (DPP) sums the runs; a run that begins and ends inside the unit is
@@ -679,7 +679,7 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
 //   reduce_stitch     per unit with a tail piece: tail + the head pieces of the following units while they belong to the same
 //                     Gaussian (fixed order) -> the finished row
 // Every sum has a fixed association order -> two runs agree bit for bit.
-constexpr int RU = 1024;
+constexpr int RU = 256;                  // (1024 measured slower on regular scenes: 16 dependent steps per wave are a latency chain)
 constexpr int RU_STEPS = RU / 64;
 
 __device__ __forceinline__ void finish_row(const uint32_t* __restrict__ order, const float4* __restrict__ splats,
@@ -810,14 +810,25 @@ bwd_reduce_units(int P, int64_t R, const uint32_t* __restrict__ order, const uin
             if (own0 != open_owner && open_owner == 0u && head_case) head_written = true;
         }
         const int seg = valid ? (int)own : 0x40000000 + lane;          // invalid lanes never merge
-        seg_scan_step<0x111, 0xf>(seg, v);      // row_shr:1
-        seg_scan_step<0x112, 0xf>(seg, v);      // row_shr:2
-        seg_scan_step<0x114, 0xf>(seg, v);      // row_shr:4
-        seg_scan_step<0x118, 0xf>(seg, v);      // row_shr:8
-        seg_scan_step<0x142, 0xa>(seg, v);      // row_bcast:15 -> rows 1, 3
-        seg_scan_step<0x143, 0xc>(seg, v);      // row_bcast:31 -> rows 2, 3
+        uint32_t fcur = 0u;
+#pragma unroll
+        for (int k = 0; k < RU_STEPS; ++k) fcur = (k == t) ? fl[k] : fcur;
+        if (__ballot(fcur != 0u) != 0ull) {
+            seg_scan_step<0x111, 0xf>(seg, v);      // row_shr:1
+            seg_scan_step<0x112, 0xf>(seg, v);      // row_shr:2
+            seg_scan_step<0x114, 0xf>(seg, v);      // row_shr:4
+            seg_scan_step<0x118, 0xf>(seg, v);      // row_shr:8
+            seg_scan_step<0x142, 0xa>(seg, v);      // row_bcast:15 -> rows 1, 3
+            seg_scan_step<0x143, 0xc>(seg, v);      // row_bcast:31 -> rows 2, 3
+        } else {
+            // no record in these 64 instances (far Gaussians hidden behind nearer ones: most of the stream): every sum is zero
+            // except the run that continues the open one -- the scan's result without the scan
+            const bool cont = have_open && own0 == open_owner && own == own0 && valid;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) v[i] = cont ? open_v[i] : 0.0f;
+        }
         const int last_lane = (int)min(63u, n - 1u - (uint32_t)t * 64u);
-        const int seg_next = __shfl_down(seg, 1, 64);
+        const int seg_next = __builtin_amdgcn_update_dpp(-2, seg, 0x130, 0xf, 0xf, false);      // wave_shl:1 = the next lane's segment (DPP, no LDS round trip)
         const bool complete = valid && lane < last_lane && seg_next != seg;      // a run that ends strictly inside the step
         if (complete) {
             if (own == 0u && head_case) write_piece(piece, j0, v, true);

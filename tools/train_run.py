@@ -9,7 +9,7 @@ What is mirrored from the reference (train.py:73-190, arguments/__init__.py:72-1
     synthetic views of a synthetic target scene (no dataset ships with this repo; SURVEY.md 8(d) generator);
   * render through `GaussianRasterizer` in the separate-SH call form with `SparseGaussianAdam` (what the reference selects
     when the accelerated rasterizer is importable, train.py:37-41,180-183) or `--dense-adam` for the default optimizer;
-  * loss 0.8 L1 + 0.2 (1 - SSIM) with the fused SSIM (train.py:119-126);
+  * loss 0.8 L1 + 0.2 (1 - SSIM) as one fused kernel pair (fused_ssim.fused_train_loss; train.py:119-126);
   * SH degree + 1 every 1000 iterations (train.py:92-94), exponential position learning-rate schedule
     (utils/general_utils.py:get_expon_lr_func; position_lr 1.6e-4 -> 1.6e-6 over 30 000 steps, scaled by the scene extent);
   * density statistics every iteration and clone / split / prune every 100 iterations from 500 to 15 000 with gradient
@@ -67,7 +67,7 @@ def main():
     from gsr_synth import look_at_camera, make_camera, make_scene
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, SparseGaussianAdam
     import diff_gaussian_rasterization as dgr
-    from fused_ssim import fused_ssim
+    from fused_ssim import fused_train_loss
     from gsr_optim import FusedAdam
     from gsr_scene.densify import DensifyStats, densify_and_prune, reset_opacity
 
@@ -142,7 +142,7 @@ def main():
             means3D=params["xyz"], means2D=m2, dc=params["f_dc"], shs=params["f_rest"], opacities=torch.sigmoid(params["opacity"]),
             scales=torch.exp(params["scaling"]), rotations=torch.nn.functional.normalize(params["rotation"]))
         gt = gts[ci]
-        loss = 0.8 * (img - gt).abs().mean() + 0.2 * (1.0 - fused_ssim(img.unsqueeze(0), gt.unsqueeze(0)))
+        loss = fused_train_loss(img, gt, 0.2)          # train.py:119-126 as one fused kernel pair (L1 + SSIM + mix)
         loss.backward()
         with torch.no_grad():
             if it < 15000:
@@ -164,6 +164,7 @@ def main():
             now = time.perf_counter()
             window_t.append({"until_iter": it, "iters_per_s": round((5000 if it % 5000 == 0 else it % 5000) / (now - t_win), 2),
                              "P": int(params["xyz"].shape[0]), "loss": round(float(loss.detach()), 5),
+                             "psnr_last_view": round(float(-10.0 * torch.log10(((img.detach() - gt) ** 2).mean().clamp_min(1e-12))), 2),
                              "num_rendered": int(dgr._last_R) if hasattr(dgr, "_last_R") else None,
                              "mem_allocated": int(torch.cuda.memory_allocated()), "mem_reserved": int(torch.cuda.memory_reserved())})
             t_win = now
