@@ -333,6 +333,21 @@ def _run(a):
     ms_per_step = dt / a.steps * 1e3
     mpix_s = npix / (dt / a.steps) / 1e6
 
+    # N > 1, for context only (NOT `value`): frame-parallel rendering -- every rank renders whole frames on its own (what
+    # render.py does with a camera list split over GPUs): no collective at all, so it scales with N by construction, but it
+    # needs all parameters on every GPU and does not shorten the latency of one frame
+    replicas = None
+    if world > 1:
+        def replica_step():
+            with torch.no_grad():
+                rasterize_gaussians(sc.means3D, None, sc.shs, None, sc.opacities, sc.scales, sc.rotations, None, rs, None)
+        for _ in range(3):
+            replica_step()
+        rdt = timed_loop(replica_step, a.steps, "replicas")[0]
+        replicas = {"ms_per_frame_per_rank": round(rdt / a.steps * 1e3, 4), "aggregate_Mpix_s": round(world * npix / (rdt / a.steps) / 1e6, 1),
+                    "note": "each rank renders whole frames independently (no sharding, no collective); context for `value`, which is ONE "
+                            "frame rendered by all ranks together"}
+
     # ---- per-stage HIP-event timing (separate pass: event pairs around every stage perturb the pipeline) ----
     _lib.profile_reset()
     _lib.profile_enable(True)
@@ -796,6 +811,7 @@ def _run(a):
             "gpu_event_note": "per-step HIP-event intervals on the launch stream (median / p10 / p90 / mean) beside the wall-clock mean that "
                               "`value` uses; the host is paced by the per-frame R read-back, so the two agree when nothing stalls",
             "forward_cycled_views": cycled,
+            "frame_parallel_replicas": replicas,
             "train_iters_per_s_sparse_adam": None if "sparse_adam" not in train else round(1e3 / train["sparse_adam"], 3),
             "train_iters_per_s_ssim_torch": None if "ssim_torch" not in train else round(1e3 / train["ssim_torch"], 3),
             "train_iters_per_s_l1": None if "l1" not in train else round(1e3 / train["l1"], 3),

@@ -349,7 +349,7 @@ int gsr_set_option(const char* name, int value) {
         return GSR_OK;
     }
     if (!strcmp(name, "color_overlap")) {
-        if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARG, "color_overlap must be 0 (fused preprocess), 1 (split, one stream) or 2 (split, colour on a second stream)");
+        if (value < 0 || value > 6) return fail(GSR_ERR_INVALID_ARG, "color_overlap must be 0 (fused preprocess), 1 (split, one stream), 2 (split, colour on a second stream) or 3..6 (second stream restricted to 7/8, 3/4, 1/2, 1/4 of the CUs with hipExtStreamCreateWithCUMask)");
         if (value && !gsr_preprocess_split_available()) return fail(GSR_ERR_UNSUPPORTED, "color_overlap needs a -DGSR_AB_VARIANTS build");
         g_color_overlap = value;
         return GSR_OK;
@@ -666,17 +666,40 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
     STAGE_CHECK("preprocess (geometry)");
     hipEvent_t join = nullptr;
     hipStream_t cst = st;
-    if (g_color_overlap == 2) {
+    if (g_color_overlap >= 2) {
         int dev_id = 0;
         HIP_OK(hipGetDevice(&dev_id));
         if (dev_id < 0 || dev_id >= GSR_MAX_DEVICES) return fail(GSR_ERR_UNSUPPORTED, "device ordinal out of range");
         AuxStream& aux = g_aux[dev_id];
+        static thread_local int aux_kind[GSR_MAX_DEVICES] = {0};
+        if (aux.s && aux_kind[dev_id] != g_color_overlap) {      // (measurement build) the option changed: new stream
+            (void)hipStreamDestroy(aux.s);
+            aux.s = nullptr;
+        }
         if (!aux.s) {
-            int least = 0, greatest = 0;
-            HIP_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIP_OK(hipStreamCreateWithPriority(&aux.s, hipStreamNonBlocking, least));
-            HIP_OK(hipEventCreateWithFlags(&aux.fork, hipEventDisableTiming));
-            HIP_OK(hipEventCreateWithFlags(&aux.join, hipEventDisableTiming));
+            if (g_color_overlap == 2) {
+                int least = 0, greatest = 0;
+                HIP_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                HIP_OK(hipStreamCreateWithPriority(&aux.s, hipStreamNonBlocking, least));
+            } else {
+                // the colour kernel beside the latency-bound depth sort lost in round 2 because the two SHARED
+                // the CUs (the sort's workgroups queued behind streaming workgroups).  Here the colour stream is restricted to a
+                // fraction of the CUs of EVERY XCD (mask bit i <-> CU i; the pattern repeats every 8 bits and again every 64, so
+                // it removes the same share whichever way the runtime interleaves XCDs), the rest stay free for the sort.
+                hipDeviceProp_t prop;
+                HIP_OK(hipGetDeviceProperties(&prop, dev_id));
+                const int ncu = prop.multiProcessorCount;
+                const int keep8 = g_color_overlap == 3 ? 7 : g_color_overlap == 4 ? 6 : g_color_overlap == 5 ? 4 : 2;      // of every 8 CUs
+                std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+                for (int i = 0; i < ncu; ++i)
+                    if (((i >> 3) & 7) < keep8) mask[(size_t)i >> 5] |= 1u << (i & 31);
+                HIP_OK(hipExtStreamCreateWithCUMask(&aux.s, (uint32_t)mask.size(), mask.data()));
+            }
+            aux_kind[dev_id] = g_color_overlap;
+            if (!aux.fork) {
+                HIP_OK(hipEventCreateWithFlags(&aux.fork, hipEventDisableTiming));
+                HIP_OK(hipEventCreateWithFlags(&aux.join, hipEventDisableTiming));
+            }
         }
         HIP_OK(hipEventRecord(aux.fork, st));
         HIP_OK(hipStreamWaitEvent(aux.s, aux.fork, 0));

@@ -176,8 +176,8 @@ __device__ __forceinline__ bool bwd_step(BwdPix& s, bool take, float pxf, float 
     }
     const v2f g01 = w * dL01, g23 = w * dL23;
     g_r = g01.x; g_g = g01.y; g_b = g23.x; g_d = g23.y;
-    g_op = G * dL_dalpha;
-    const float m = op * g_op;
+    const float m = op * (G * dL_dalpha);
+    g_op = m;                            // zeroth moment (see moments_to_grads)
     const v2f md = m * d;                // (m dx, m dy)
     const v2f mxd = md.x * d;            // (m dx^2, m dx dy)
     mx = md.x; my = md.y;
@@ -187,13 +187,17 @@ __device__ __forceinline__ bool bwd_step(BwdPix& s, bool take, float pxf, float 
 }
 
 // per-Gaussian conversion of the summed moments into the derivatives (record layout of the file header)
-__device__ __forceinline__ void moments_to_grads(float A, float B, float C, float4& u0, float4& u1) {
+// Slot 5 of an instance record carries the ZEROTH moment sum(m) = opacity * sum(G dL/dalpha) (round 3: the blend kernel needs m
+// anyway, so dL/dopacity = sum(m) / opacity is one division per Gaussian here instead of two multiplies and an add per step there;
+// a Gaussian with opacity 0 never passes alpha >= 1/255, its sum is exactly 0).
+__device__ __forceinline__ void moments_to_grads(float A, float B, float C, float opacity, float4& u0, float4& u1) {
     const float mx = u0.x, my = u0.y, mxx = u0.z, mxy = u0.w, myy = u1.x;
     u0.x = -A * mx - B * my;
     u0.y = -C * my - B * mx;
     u0.z = -0.5f * mxx;
     u0.w = -mxy;
     u1.x = -0.5f * myy;
+    u1.y = opacity > 0.0f ? u1.y / opacity : 0.0f;
 }
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -334,13 +338,14 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
             const float tA = fmaf(b2, dy, a2 * dxA), tB = fmaf(b2, dy, a2 * dxB);
             const float p2A = fmaf(dxA, tA, u), p2B = fmaf(dxB, tB, u);
             const float GA = __builtin_amdgcn_exp2f(p2A), GB = __builtin_amdgcn_exp2f(p2B);
-            const float alA = fminf(GSR_ALPHA_MAX, op * GA), alB = fminf(GSR_ALPHA_MAX, op * GB);
+            const float ogA = op * GA, ogB = op * GB;
+            const float alA = fminf(GSR_ALPHA_MAX, ogA), alB = fminf(GSR_ALPHA_MAX, ogB);
             const bool actA = doA & (pos0 < lastA) & (p2A <= 0.0f) & (alA >= GSR_ALPHA_MIN);
             const bool actB = doB & (pos0 < lastB) & (p2B <= 0.0f) & (alB >= GSR_ALPHA_MIN);
             if (__builtin_amdgcn_ballot_w64(actA | actB) == 0ull) continue;
-            // ---- the only selects of the step: a skipped pixel takes part with alpha = 0 and G = 0 ----
+            // ---- the only selects of the step: a skipped pixel takes part with alpha = 0 and opacity * G = 0 ----
             const v2f alpha = {actA ? alA : 0.0f, actB ? alB : 0.0f};
-            const v2f G = {actA ? GA : 0.0f, actB ? GB : 0.0f};
+            const v2f opG = {actA ? ogA : 0.0f, actB ? ogB : 0.0f};
             const v2f dx = {dxA, dxB};
             // ---- recurrences (Appendix A.5) ----
             v2f cD = r1.z * dLr + r1.w * dLg + r2x * dLb;
@@ -354,13 +359,12 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
             const v2f w = alpha * s.T;
             // ---- the per-pair terms, the two pixels added per lane ----
             const v2f gr2 = w * dLr, gg2 = w * dLg, gb2 = w * dLb;
-            const v2f gop2 = G * dL_dalpha;
-            const v2f m = op * gop2;
+            const v2f m = opG * dL_dalpha;          // m = dL/dG * G = opacity G dL/dalpha (straight-through the 0.99 cap, Appendix A.5)
             const v2f mdx = m * dx;                 // m dx
             const v2f mdxx = mdx * dx;              // m dx^2
             const float msum = m.x + m.y, mdxsum = mdx.x + mdx.y;
             const float g_px = mdxsum, g_py = msum * dy, g_A = mdxx.x + mdxx.y, g_B = mdxsum * dy, g_C = (msum * dy) * dy;
-            const float g_op = gop2.x + gop2.y, g_r = gr2.x + gr2.y, g_g = gg2.x + gg2.y, g_b = gb2.x + gb2.y;
+            const float g_op = msum, g_r = gr2.x + gr2.y, g_g = gg2.x + gg2.y, g_b = gb2.x + gb2.y;      // g_op: the zeroth moment
             const float v0 = reduce4(g_px, g_A, g_py, g_B);     // -> slots 0,1,2,3
             const float v1 = reduce4(g_C, g_r, g_op, g_g);      // -> slots 4,5,6,7
             float v2;
@@ -668,8 +672,9 @@ render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t*
 // Gaussians look like -- round 2 gave one workgroup to every 64 Gaussians of the depth order, and a splat that covers the
 // whole frame (8 160 records; trained-looking scenes have many of hundreds) made its workgroup the kernel's tail: 0.09 ms on
 // the uniform bench frame but 0.45 ms on the clustered stand-in, 41 % of its backward.
+//   (memset)          all rows zero: Gaussians without records, and runs inside units that hold no record at all, are never written
 //   reduce_prepare    per Gaussian: the units whose first record it owns get (owner, owner's first record) -- the only
-//                     thing a unit needs to find all its owners; Gaussians without records get their zero row here
+//                     thing a unit needs to find all its owners
 //   bwd_reduce_units  one wave per unit: the starts of the next <= 256 Gaussians are fetched in one batch and marked in LDS,
 //                     a running max-scan over the marks gives every record its owner; 64 records per step (lane = record,
 //                     fully coalesced; flag words up front, records one step ahead), the <= 2 slot records of an instance
@@ -687,7 +692,18 @@ __device__ __forceinline__ void finish_row(const uint32_t* __restrict__ order, c
     const uint32_t g = order[j];
     float4 t0 = make_float4(v[0], v[1], v[2], v[3]), t1 = make_float4(v[4], v[5], v[6], v[7]);
     const float4 q0 = splats[(int64_t)g * 4 + 0];
-    moments_to_grads(q0.z, q0.w, splats[(int64_t)g * 4 + 1].x, t0, t1);
+    const float4 q1 = splats[(int64_t)g * 4 + 1];
+    moments_to_grads(q0.z, q0.w, q1.x, q1.y, t0, t1);
+    splat_grads[(int64_t)g * 3 + 0] = t0;
+    splat_grads[(int64_t)g * 3 + 1] = t1;
+    splat_grads[(int64_t)g * 3 + 2] = make_float4(v[8], v[9], 0.f, 0.f);
+}
+// the same with the owner's (Gaussian id, conic) already staged in LDS by the unit's prologue: three stores, no dependent load
+__device__ __forceinline__ void finish_row_staged(const float4 ow /*(id bits, A, B, C)*/, float opacity, float4* __restrict__ splat_grads,
+                                                  const float (&v)[10]) {
+    const uint32_t g = __float_as_uint(ow.x);
+    float4 t0 = make_float4(v[0], v[1], v[2], v[3]), t1 = make_float4(v[4], v[5], v[6], v[7]);
+    moments_to_grads(ow.y, ow.z, ow.w, opacity, t0, t1);
     splat_grads[(int64_t)g * 3 + 0] = t0;
     splat_grads[(int64_t)g * 3 + 1] = t1;
     splat_grads[(int64_t)g * 3 + 2] = make_float4(v[8], v[9], 0.f, 0.f);
@@ -703,12 +719,7 @@ reduce_prepare(int P, const uint32_t* __restrict__ order, const uint32_t* __rest
                float4* __restrict__ splat_grads) {
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < P; j += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t incl = offsets[j], excl = j ? offsets[j - 1] : 0u;
-        if (incl == excl) {                    // no record: the row is zero
-            const uint32_t g = order[j];
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            splat_grads[(int64_t)g * 3 + 0] = z; splat_grads[(int64_t)g * 3 + 1] = z; splat_grads[(int64_t)g * 3 + 2] = z;
-            continue;
-        }
+        if (incl == excl) continue;            // no record (the rows were zeroed by the launcher's memset)
         for (uint32_t k = (excl + RU - 1u) / RU; k <= (incl - 1u) / RU; ++k) unit_first[k] = make_uint2((uint32_t)j, excl);
     }
 }
@@ -719,6 +730,8 @@ bwd_reduce_units(int P, int64_t R, const uint32_t* __restrict__ order, const uin
                  const uint32_t* __restrict__ inst_flag /*[R], byte q = slot q*/, const float4* __restrict__ splats,
                  float4* __restrict__ splat_grads, float4* __restrict__ unit_piece /*[units][2][3]*/) {
     __shared__ uint32_t s_mark[RU];
+    __shared__ float4 s_own[RU + 1];              // per owner of the unit: (Gaussian id bits, conic A, B, C)
+    __shared__ float s_own_op[RU + 1];            // ... and its opacity
     const int lane = threadIdx.x;
     const int64_t u = blockIdx.x;
     const uint32_t c0 = (uint32_t)(u * RU);
@@ -745,6 +758,41 @@ bwd_reduce_units(int P, int64_t R, const uint32_t* __restrict__ order, const uin
         if (st[t] >= c0 && st[t] - c0 < n) s_mark[st[t] - c0] = (uint32_t)(1 + t * 64 + lane);      // (Gaussians without records start at R)
     __builtin_amdgcn_wave_barrier();
 
+    uint32_t mymax = 0u;
+#pragma unroll
+    for (int t = 0; t < RU_STEPS; ++t) mymax = max(mymax, s_mark[t * 64 + lane]);
+    const uint32_t nown = (uint32_t)__builtin_amdgcn_readlane((int)gsrw::wave_incl_max_u32(mymax), 63);
+    float4* piece = unit_piece + u * 6;
+    {   // A unit without a single record (most of the stream: instances of far Gaussians that every pixel terminated in front of):
+        // all its sums are zero and the rows are already zero -- only the two pieces are written (valid zeros, so that a run
+        // that crosses this unit keeps its chain for reduce_stitch).
+        uint32_t anyf = 0u;
+#pragma unroll
+        for (int t = 0; t < RU_STEPS; ++t) anyf |= fl[t];
+        if (__ballot(anyf != 0u) == 0ull) {
+            if (lane == 0) {
+                float zero[10];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) zero[i] = 0.f;
+                write_piece(piece, j0, zero, head_case);
+                write_piece(piece + 3, j0 + nown, zero, !(nown == 0u && head_case));
+            }
+            return;
+        }
+    }
+    // owners of the unit = local indices 0 .. nown: their Gaussian id and conic are fetched NOW (two dependent gathers, once per
+    // unit, in flight beside the record loads) and parked in LDS -- fetched at the moment a run completes they were two
+    // serial memory round trips in every step of the walk
+    for (uint32_t k = 0; k * 64u <= nown; ++k) {          // wave-uniform trip count (usually one)
+        const uint32_t o = min(k * 64u + (uint32_t)lane, nown);
+        const uint32_t g = order[(int64_t)j0 + o];
+        const float4 q0 = splats[(int64_t)g * 4 + 0];
+        const float4 q1 = splats[(int64_t)g * 4 + 1];
+        s_own[o] = make_float4(__uint_as_float(g), q0.z, q0.w, q1.x);
+        s_own_op[o] = q1.y;
+    }
+    __builtin_amdgcn_wave_barrier();
+
     const float4* stream = slot_grads + (int64_t)c0 * 3;
     auto load_recs = [&](int t, uint32_t flags, float4 (&rec)[GSR_BWD_SLOTS][3]) {
         const uint32_t r = (uint32_t)t * 64u + (uint32_t)lane;
@@ -767,7 +815,6 @@ bwd_reduce_units(int P, int64_t R, const uint32_t* __restrict__ order, const uin
 #pragma unroll
     for (int i = 0; i < 10; ++i) open_v[i] = 0.f;
     const int nsteps = (int)((n + 63u) >> 6);
-    float4* piece = unit_piece + u * 6;
 #pragma unroll 1
     for (int t = 0; t < nsteps; ++t) {
         const uint32_t r = (uint32_t)t * 64u + (uint32_t)lane;
@@ -805,7 +852,7 @@ bwd_reduce_units(int P, int64_t R, const uint32_t* __restrict__ order, const uin
                 }
             } else if (lane == 0) {
                 if (open_owner == 0u && head_case) write_piece(piece, j0, open_v, true);
-                else finish_row(order, splats, splat_grads, j0 + open_owner, open_v);
+                else finish_row_staged(s_own[open_owner], s_own_op[open_owner], splat_grads, open_v);
             }
             if (own0 != open_owner && open_owner == 0u && head_case) head_written = true;
         }
@@ -832,7 +879,7 @@ bwd_reduce_units(int P, int64_t R, const uint32_t* __restrict__ order, const uin
         const bool complete = valid && lane < last_lane && seg_next != seg;      // a run that ends strictly inside the step
         if (complete) {
             if (own == 0u && head_case) write_piece(piece, j0, v, true);
-            else finish_row(order, splats, splat_grads, j0 + own, v);
+            else finish_row_staged(s_own[own], s_own_op[own], splat_grads, v);
         }
         if (__ballot(complete && own == 0u && head_case) != 0ull) head_written = true;
         have_open = true;
@@ -953,10 +1000,11 @@ render_bwd_wave(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
             if (lane == 63) {
                 float* o = grads + (int64_t)gid * 12;
                 float4 u0 = make_float4(g_px, g_py, g_A, g_B), u1 = make_float4(g_C, 0.f, 0.f, 0.f);
-                moments_to_grads(cA, cB, cC, u0, u1);
+                u1.y = g_op;
+                moments_to_grads(cA, cB, cC, op, u0, u1);
                 atomicAdd(o + 0, u0.x); atomicAdd(o + 1, u0.y);
                 atomicAdd(o + 2, u0.z); atomicAdd(o + 3, u0.w); atomicAdd(o + 4, u1.x);
-                atomicAdd(o + 5, g_op);
+                atomicAdd(o + 5, u1.y);
                 atomicAdd(o + 6, g_r); atomicAdd(o + 7, g_g); atomicAdd(o + 8, g_b);
                 atomicAdd(o + 9, g_d);
             }
@@ -1022,6 +1070,7 @@ void gsr_launch_reduce_instances(int P, int64_t R, const uint32_t* order, const 
     const int64_t nunits = (R + RU - 1) / RU;
     int64_t nb = ((int64_t)P + 255) / 256;
     if (nb > 4096) nb = 4096;
+    (void)hipMemsetAsync(splat_grads, 0, (size_t)P * 48, st);
     hipLaunchKernelGGL(reduce_prepare, dim3((int)nb), dim3(256), 0, st, P, order, offsets, unit_first, reinterpret_cast<float4*>(splat_grads));
     hipLaunchKernelGGL(bwd_reduce_units, dim3((int)nunits), dim3(64), 0, st, P, R, order, offsets, unit_first,
                        reinterpret_cast<const float4*>(inst_grads), inst_flag, splats, reinterpret_cast<float4*>(splat_grads),
