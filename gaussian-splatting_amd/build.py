@@ -22,13 +22,14 @@ CSRC = os.path.join(HERE, "csrc")
 # GSR_AB=1: measurement build with the A/B kernel variants compiled in (-DGSR_AB_VARIANTS) -> lib_ab/libgsr_hip.so;
 # select it at run time with GSR_LIB=<path>.  The default (product) build contains the default kernels only.
 AB = os.environ.get("GSR_AB") == "1"
-OUT = os.path.join(HERE, "lib_ab" if AB else "lib")
+# tuning builds: GSR_OUT=<dir name under gaussian-splatting_amd/> GSR_EXTRA_FLAGS="-DGSR_TS_ITEMS=2048" python build.py
+OUT = os.path.join(HERE, os.environ.get("GSR_OUT") or ("lib_ab" if AB else "lib"))
 LIB = os.path.join(OUT, "libgsr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-          "-Wall", "-Wno-unused-function"] + (["-DGSR_AB_VARIANTS"] if AB else [])
+          "-Wall", "-Wno-unused-function"] + (["-DGSR_AB_VARIANTS"] if AB else []) + os.environ.get("GSR_EXTRA_FLAGS", "").split()
 UNITS = [
     ("preprocess.hip", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]),
     ("sort.hip", []),

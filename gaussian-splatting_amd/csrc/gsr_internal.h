@@ -25,7 +25,9 @@ static inline size_t gsr_align128(size_t x) { return (x + 127) & ~(size_t)127; }
 #define GSR_SORT_ITEMS 4096      // items per workgroup in a radix pass (256 threads x 16)
 #define GSR_SORT_ITEMS_SMALL 1024
 #define GSR_SCAN_ITEMS 1024      // items per workgroup in the tiles_touched scan
-#define GSR_TS_ITEMS 4096        // instances per workgroup of the fused emission / tile sort (tilesort.hip)
+#ifndef GSR_TS_ITEMS
+#define GSR_TS_ITEMS 4096        // instances per workgroup of the fused emission / tile sort (tilesort.hip); tuning builds: -DGSR_TS_ITEMS=2048
+#endif
 // capacity of the per-block "first Gaussian" table the scan kernel fills: enough for 64 tiles per Gaussian on average;
 // frames beyond that get the table from a fallback kernel once R is known (gsr_launch_fill_block_first)
 static inline size_t gsr_block_first_cap(int P) { return (size_t)(P > 0 ? P : 1) / 64 + 66; }
