@@ -204,10 +204,16 @@ __global__ void __launch_bounds__(256)
 loss_mean_kernel(const float* __restrict__ partials, int n, float inv_count, float lambda, float* __restrict__ out) {
     __shared__ float s_part[8];
     const int tid = threadIdx.x;
-    const int chunk = (n + 255) / 256;
-    const int lo = min(tid * chunk, n), hi = min(lo + chunk, n);
     float v = 0.f, u = 0.f;
-    for (int i = lo; i < hi; ++i) { v += partials[i]; u += partials[n + i]; }
+    int i = tid;
+    for (; i + 3 * 256 < n; i += 4 * 256) {          // coalesced, eight independent loads in flight per trip (see ssim_mean_kernel)
+        float a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[k] = partials[i + k * 256]; b[k] = partials[n + i + k * 256]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v += a[k]; u += b[k]; }
+    }
+    for (; i < n; i += 256) { v += partials[i]; u += partials[n + i]; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); u += __shfl_xor(u, off, 64); }
     if ((tid & 63) == 0) { s_part[tid >> 6] = v; s_part[4 + (tid >> 6)] = u; }
@@ -226,10 +232,18 @@ __global__ void __launch_bounds__(256)
 ssim_mean_kernel(const float* __restrict__ partials, int n, float inv_count, float* __restrict__ mean_out) {
     __shared__ float s_part[4];
     const int tid = threadIdx.x;
-    const int chunk = (n + 255) / 256;
-    const int lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+    // thread t adds elements t, t + 256, ... (coalesced; eight independent loads in flight per trip: the chunk-per-thread form
+    // was a chain of dependent trips, 6-9 us for 6 000 partials); any FIXED order is deterministic
     float v = 0.f;
-    for (int i = lo; i < hi; ++i) v += partials[i];
+    int i = tid;
+    for (; i + 7 * 256 < n; i += 8 * 256) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = partials[i + k * 256];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += t[k];
+    }
+    for (; i < n; i += 256) v += partials[i];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     if ((tid & 63) == 0) s_part[tid >> 6] = v;
