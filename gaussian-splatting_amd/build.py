@@ -45,6 +45,7 @@ UNITS = [
     # A/B'd too (fused forms -1..2 %, split-SH forward +27 %) and keep the default
     ("ssim.hip", ["-ffp-contract=fast", "-fno-slp-vectorize"]),
     ("knn.hip", ["-ffp-contract=off"]),
+    ("density.hip", ["-ffp-contract=off"]),
     ("gsr_api.cpp", ["-x", "hip"]),
 ]
 

@@ -983,6 +983,18 @@ int gsr_sparse_adam_step(float* param, const float* grad, float* exp_avg, float*
     return GSR_OK;
 }
 
+int gsr_density_stats(int P, const float* viewspace_grad, const uint8_t* visible, const int32_t* radii, float* grad_accum, float* denom,
+                      float* max_radii2D, void* stream) {
+    if (P < 0) return fail(GSR_ERR_INVALID_ARG, "P < 0");
+    if (P == 0) return GSR_OK;
+    if (!viewspace_grad || !grad_accum || !denom) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
+    if (!visible && !radii) return fail(GSR_ERR_INVALID_ARG, "give the visibility mask or the radii (visible = radii > 0)");
+    if (radii && !max_radii2D) return fail(GSR_ERR_INVALID_ARG, "radii given but max_radii2D is NULL");
+    gsr_launch_density_stats(P, viewspace_grad, visible, radii, grad_accum, denom, max_radii2D, (hipStream_t)stream);
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
+}
+
 size_t gsr_knn_scratch_bytes(int N) { return gsr_knn_scratch_bytes_impl(N); }
 
 int gsr_knn_mean_dist2(int N, const float* points, float* mean_dist2, void* scratch, void* stream) {

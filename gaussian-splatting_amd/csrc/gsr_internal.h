@@ -237,6 +237,9 @@ void gsr_launch_ssim_backward(int planes, int H, int W, const float* img1, const
 // adam.hip: sparse step (rows of M elements, skipped entirely when visible[row] == 0)
 void gsr_launch_sparse_adam(float* p, const float* g, float* m, float* v, const uint8_t* visible, int64_t N, int64_t M,
                             double lr, double beta1, double beta2, double eps, hipStream_t st);
+// density.hip: per-iteration density-control statistics
+void gsr_launch_density_stats(int P, const float* grad, const uint8_t* visible, const int32_t* radii, float* accum, float* denom,
+                              float* max_radii, hipStream_t st);
 // knn.hip
 size_t gsr_knn_scratch_bytes_impl(int N);
 void gsr_launch_knn(int N, const float* points, float* out, void* scratch, hipStream_t st);

@@ -49,7 +49,7 @@ EXPORTS = [
     "gsr_route_scratch_bytes", "gsr_route_count", "gsr_route_pack", "gsr_rasterize_from_packed", "gsr_route_return",
     "gsr_mark_visible", "gsr_forward_views", "gsr_adam_step", "gsr_sparse_adam_step", "gsr_ssim_forward", "gsr_ssim_backward",
     "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_ssim_partial_count", "gsr_ssim_mean_forward", "gsr_ssim_mean_backward",
-    "gsr_train_loss_forward", "gsr_train_loss_backward",
+    "gsr_train_loss_forward", "gsr_train_loss_backward", "gsr_density_stats",
     "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_profile_counters", "gsr_set_option",
 ]
 
@@ -156,6 +156,9 @@ def load() -> C.CDLL:
         lib.gsr_train_loss_forward.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp]
         lib.gsr_train_loss_backward.restype = C.c_int
         lib.gsr_train_loss_backward.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
+    if hasattr(lib, "gsr_density_stats"):
+        lib.gsr_density_stats.restype = C.c_int
+        lib.gsr_density_stats.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_ssim_backward.restype = C.c_int
     lib.gsr_ssim_backward.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_mark_visible.restype = C.c_int

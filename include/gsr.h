@@ -235,6 +235,17 @@ int gsr_sparse_adam_step(float* param, const float* grad, float* exp_avg, float*
                          int64_t N, int64_t M, double lr, double beta1, double beta2, double eps, void* stream);
 
 /*
+ * Per-iteration statistics of adaptive density control: GaussianModel.add_densification_stats
+ * (scene/gaussian_model.py:471-473, called at train.py:167) and the max_radii2D update of train.py:166, as ONE pass instead of
+ * boolean-mask torch ops (three host synchronisations per training iteration):
+ *   for visible i:  grad_accum[i] += sqrt(g[i,0]^2 + g[i,1]^2);  denom[i] += 1;  max_radii2D[i] = max(max_radii2D[i], radii[i])
+ * viewspace_grad[P,3] = the operator's dL/dmeans2D; visible uint8/bool [P] or NULL (= radii > 0, what
+ * gaussian_renderer/__init__.py:123 passes); radii int32 [P] or NULL (then max_radii2D is not touched).
+ */
+int gsr_density_stats(int P, const float* viewspace_grad, const uint8_t* visible, const int32_t* radii, float* grad_accum,
+                      float* denom, float* max_radii2D, void* stream);
+
+/*
  * Replaces `simple_knn._C.distCUDA2` (un-vendored submodule submodules/simple-knn, .gitmodules:1-3; called once per
  * scene at scene/gaussian_model.py:159): mean_dist2[i] = mean of the squared Euclidean distances
  * from points[i] to its 3 nearest OTHER points (exact; coincident points count with distance 0; fewer than 4 points

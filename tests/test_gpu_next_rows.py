@@ -459,6 +459,37 @@ def test_two_axis_pieces_two_shards_two_bands_on_one_gpu():
             assert (got.view(-1) - want[a:b].reshape(-1)).abs().max().item() <= 5e-5 * want.abs().max().item()
 
 
+@pytest.mark.parametrize("P", [1, 1000, 70001])
+def test_density_statistics_kernel_matches_the_reference_expression(P):
+    """gsr_density_stats (the per-iteration part of density control, one HIP pass) == the boolean-mask expressions of
+    GaussianModel.add_densification_stats (scene/gaussian_model.py:471-473) + train.py:166, accumulated over several
+    iterations with changing visibility; with and without the radii update; explicit mask and radii-derived mask."""
+    from gsr_scene.densify import DensifyStats
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(P)
+    a = DensifyStats.zeros(P, dev)
+    acc = torch.zeros(P, 1, device=dev)
+    den = torch.zeros(P, 1, device=dev)
+    mx = torch.zeros(P, device=dev)
+    for it in range(5):
+        grad = (torch.randn(P, 3, generator=g) * 10.0 ** (it - 2)).to(dev)
+        radii = torch.randint(0, 50, (P,), generator=g, dtype=torch.int32).to(dev)
+        radii[torch.rand(P, generator=g).to(dev) < 0.4] = 0
+        vis = radii > 0
+        with_r = it != 2
+        a.add(grad, vis, radii if with_r else None)
+        acc[vis] += torch.norm(grad[vis, :2], dim=-1, keepdim=True)
+        den[vis] += 1
+        if with_r:
+            mx[vis] = torch.max(mx[vis], radii[vis].float())
+    torch.cuda.synchronize()
+    assert torch.equal(a.denom, den) and torch.equal(a.max_radii2D, mx)
+    assert (a.xyz_gradient_accum - acc).abs().max().item() <= 2e-6 * max(1.0, acc.abs().max().item())
+    with pytest.raises(Exception):
+        from diff_gaussian_rasterization import _lib
+        _lib.check(_lib.load().gsr_density_stats(5, None, None, None, None, None, None, None), "gsr_density_stats")
+
+
 def test_training_loop_with_density_control():
     """train.py:111-186 in miniature on the drop-in pieces: render (split-SH form), reference loss, backward, density
     statistics from the operator's means2D gradient and radii, FusedAdam step, clone / split / prune every 50 iterations
