@@ -395,7 +395,9 @@ class SparseGaussianAdam(torch.optim.Adam):
         lib = _lib.load()
         N = int(N)
         vis = visibility.reshape(-1)
-        if vis.dtype != torch.uint8:
+        if vis.dtype == torch.bool:
+            vis = vis.contiguous().view(torch.uint8)      # a bool tensor IS one byte per element: no conversion kernel
+        elif vis.dtype != torch.uint8:
             vis = vis.to(torch.uint8)
         vis = vis.contiguous()
         for group in self.param_groups:

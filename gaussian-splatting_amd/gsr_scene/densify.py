@@ -51,8 +51,8 @@ class DensifyStats:
             import ctypes as C
             from diff_gaussian_rasterization import _lib
             lib = _lib.load()
-            vis = visible if visible.dtype == torch.uint8 else visible.to(torch.uint8)
-            vis = vis.contiguous()
+            vis = visible.contiguous()
+            vis = vis.view(torch.uint8) if vis.dtype == torch.bool else (vis if vis.dtype == torch.uint8 else vis.to(torch.uint8))
             p = lambda t: None if t is None else C.c_void_p(t.data_ptr())      # noqa: E731
             with torch.cuda.device(g.device):
                 _lib.check(lib.gsr_density_stats(int(g.shape[0]), p(g), p(vis), p(radii), p(self.xyz_gradient_accum), p(self.denom),
