@@ -720,7 +720,7 @@ def _run(a):
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         import subprocess
         cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--P", str(P), "--width", str(W), "--height", str(H),
-               "--seed", str(a.seed), "--s-med", str(a.s_med), "--workers", str(a.cpu_workers), "--budget-s", "40"]
+               "--seed", str(a.seed), "--s-med", str(a.s_med), "--workers", str(a.cpu_workers), "--budget-s", "100"]
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -74,8 +74,12 @@ def main():
     R = int(bins["R"])
     ctx = mp.get_context("fork")
     with ctx.Pool(workers, initializer=_init_worker) as pool:
-        # probe: two tiles per worker, spread over the frame
-        probe = [int(i * ntile / (2 * workers)) for i in range(2 * workers)]
+        # probe: two tiles per worker, spread over the frame; a first round of one tile each absorbs the workers' start-up
+        # (page faults of the forked state, torch's lazy initialisation), which the first version billed to the estimate and
+        # therefore blended only every second tile on a box that had time for all of them
+        pool.map(_blend_chunk, [[int(i * ntile / workers)] for i in range(workers)])
+        probe = [int(i * ntile / (2 * workers)) + 1 for i in range(2 * workers)]
+        probe = [min(t, ntile - 1) for t in probe]
         t0 = time.perf_counter()
         pool.map(_blend_chunk, [[t] for t in probe])
         t_probe = time.perf_counter() - t0
