@@ -557,10 +557,12 @@ def _run(a):
                     # the reference's schedule typically lands -- the hottest 3 % of the seen Gaussians are cloned / split per step
                     # (k-th value over ALL of them: clones are appended at the end, a prefix sample would be biased) -- and growth
                     # stops at 1.3x the start (identical twins stay hot on a noise target; a real loss would cool them down)
+                    # (a full sort, ~0.3 ms: torch's kthvalue takes 6-7 ms on 1 M values, more than twice the clone / split / prune step
+                    # it would feed; the reference has no such step at all -- its threshold is a constant)
                     g = (st_.xyz_gradient_accum / st_.denom.clamp_min(1))[st_.denom > 0]
                     thr = 1e30
                     if g.numel() > 100 and n < 1.3 * P:
-                        thr = float(g.kthvalue(int(0.97 * g.numel())).values)
+                        thr = float(torch.sort(g.flatten()).values[int(0.97 * g.numel())])
                     state["params"], state["stats"], _ = densify_and_prune(dopt, st_, max_grad=thr, min_opacity=0.005, extent=4.0,
                                                                             max_screen_size=None, radii=radii)
                     state["P_max"] = max(state["P_max"], int(state["params"]["xyz"].shape[0]))
@@ -568,13 +570,16 @@ def _run(a):
                     dopt.step(radii > 0, radii.shape[0])
                 dopt.zero_grad(set_to_none=True)
 
-        for _ in range(8):
+        # warm-up = one full period including its clone / split / prune event: the first event loads a dozen torch kernels
+        # (0.3-0.9 s of module loading, measured with tools/gpu_densify_time.py), a one-time cost a 30 000-iteration run never sees
+        for _ in range(100):
             densify_step()
         state["it"] = 0
+        P_timed_start = int(state["params"]["xyz"].shape[0])
         nd = max(200, (a.densify_iters // 100) * 100)
         ddt = timed_loop(densify_step, nd, "train_densify", stall_check=False)[0]      # (a densify step legitimately takes > STALL_MS)
         densify_leg = {"iters": nd, "densify_every": 100, "iters_per_s": round(nd / ddt, 3), "ms_per_iter": round(ddt / nd * 1e3, 4),
-                       "P_start": P, "P_end": int(state["params"]["xyz"].shape[0]), "P_max": state["P_max"],
+                       "P_start": P_timed_start, "P_end": int(state["params"]["xyz"].shape[0]), "P_max": state["P_max"],
                        "gpu_event_ms": event_stats.get("train_densify"),
                        "what": "forward (separate-SH form) + fused L1/SSIM loss + backward + density statistics every iteration + "
                                "SparseGaussianAdam; clone / split / prune (gsr_scene.densify) every 100 iterations, amortised"}

@@ -35,6 +35,7 @@ int fail(int code, const std::string& msg) {
 int g_render_fwd_variant = 0;
 int g_render_bwd_variant = 0;
 int g_depth_sort_mode = 0;      // 0 = hist / scan / scatter per pass, 1 = one kernel per pass ("onesweep", sort.hip)
+int g_bwd_heavy_first = 1;      // 1 = the blend backward starts its heaviest tiles first (plan kernel, render_bwd.hip); 0 = index order (A/B)
 int g_tile_sort_mode = 0;       // 0 = fused emission + two-level sort (tilesort.hip), 1 = legacy emit + LSD passes (A/B)
 int g_first_hist = 0;           // 1 = the preprocess kernel also produces the histogram of the depth sort's first pass (large P).
                                 // Measured (1 M Gaussians): the sort saves 4.3 us, the preprocess -- one workgroup per 1024
@@ -296,6 +297,8 @@ GsrImage gsr_carve_image(char* base, int W, int H) {
     im.final_T = (float*)take(npix * 4);
     im.n_contrib = (uint32_t*)take(npix * 4);
     im.ranges = (uint2*)take(nt * 8);
+    im.block_steps = (uint32_t*)take(nt * 16);
+    im.tile_order = (uint32_t*)take(nt * 4);
     im.bytes = off;
     return im;
 }
@@ -352,6 +355,11 @@ int gsr_set_option(const char* name, int value) {
         if (value < 0 || value > 6) return fail(GSR_ERR_INVALID_ARG, "color_overlap must be 0 (fused preprocess), 1 (split, one stream), 2 (split, colour on a second stream) or 3..6 (second stream restricted to 7/8, 3/4, 1/2, 1/4 of the CUs with hipExtStreamCreateWithCUMask)");
         if (value && !gsr_preprocess_split_available()) return fail(GSR_ERR_UNSUPPORTED, "color_overlap needs a -DGSR_AB_VARIANTS build");
         g_color_overlap = value;
+        return GSR_OK;
+    }
+    if (!strcmp(name, "bwd_heavy_first")) {
+        if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "bwd_heavy_first must be 0 (tiles in index order) or 1 (heaviest tiles first)");
+        g_bwd_heavy_first = value;
         return GSR_OK;
     }
     if (!strcmp(name, "tile_sort_mode")) {
@@ -605,8 +613,8 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     if (colors_done) HIP_OK(hipStreamWaitEvent(st, colors_done, 0));      // the blend is the first reader of the colours
     {   StageTimer t(GSR_STAGE_RENDER, st);
         gsr_launch_render_forward(cam, im.ranges, b.vals[list_buf], g.splats, settings->no_backward ? nullptr : im.final_T,
-                                  settings->no_backward ? nullptr : im.n_contrib, out_color, out_invdepth,
-                                  g_render_fwd_variant, g_count_on ? counters_for_current_device() : nullptr, st);
+                                  settings->no_backward ? nullptr : im.n_contrib, settings->no_backward ? nullptr : im.block_steps,
+                                  out_color, out_invdepth, g_render_fwd_variant, g_count_on ? counters_for_current_device() : nullptr, st);
     }
     STAGE_CHECK("render");
     HIP_OK(hipGetLastError());
@@ -888,12 +896,13 @@ int gsr_backward_blend(const GsrRasterSettings* settings, int P, int32_t num_ren
         if (g_render_bwd_variant == 1 || num_rendered <= 0) {
             HIP_OK(hipMemsetAsync(sg, 0, (size_t)P * 12 * sizeof(float), st));
             if (num_rendered > 0)
-                gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib,
+                gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib, im.block_steps, nullptr,
                                            dL_dout_color, dL_dout_invdepth, sg, nullptr, nullptr, num_rendered, 1, nullptr, st);
         } else {
             // instances that contributed nowhere get no record: only their flag words are cleared
             HIP_OK(hipMemsetAsync(w.inst_flag, 0, (size_t)num_rendered * 4, st));
-            gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib,
+            gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib, im.block_steps,
+                                       g_bwd_heavy_first ? im.tile_order : nullptr,
                                        dL_dout_color, dL_dout_invdepth, nullptr, w.inst_grads, w.inst_flag, num_rendered,
                                        g_render_bwd_variant, g_count_on ? counters_for_current_device() : nullptr, st);
         }

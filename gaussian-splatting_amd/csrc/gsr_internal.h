@@ -106,6 +106,8 @@ struct GsrImage {
     float* final_T;              // [H*W]
     uint32_t* n_contrib;         // [H*W]
     uint2* ranges;               // [n_tiles]
+    uint32_t* block_steps;       // [n_tiles*4] list entries the forward blended per 8x8 block (tracking build): the backward's work estimate
+    uint32_t* tile_order;        // [n_tiles]   band-local tile indices, heaviest first (written by the backward's plan kernel)
     size_t bytes;
 };
 GsrImage gsr_carve_image(char* base, int W, int H);
@@ -190,15 +192,16 @@ void gsr_launch_ranges(int64_t R, int n_tiles, const void* sorted_keys, bool key
 
 // render_fwd.hip / render_bwd.hip
 void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,
-                               const float4* splats, float* final_T, uint32_t* n_contrib, float* out_color,
-                               float* out_invdepth, int variant, unsigned long long* counters /*NULL or [4] work counters*/,
-                               hipStream_t st);
+                               const float4* splats, float* final_T, uint32_t* n_contrib, uint32_t* block_steps /*NULL unless tracking*/,
+                               float* out_color, float* out_invdepth, int variant,
+                               unsigned long long* counters /*NULL or [4] work counters*/, hipStream_t st);
 // variant: 0 = default (independent quadrant waves); 1 (global atomics) and 4 (round 1's workgroup-per-tile kernel) exist
 // only in builds with -DGSR_AB_VARIANTS
 int gsr_render_backward_variant_available(int variant);
 int gsr_render_forward_variant_available(int variant);
 void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,
                                 const float4* splats, const float* final_T, const uint32_t* n_contrib,
+                                const uint32_t* block_steps, uint32_t* tile_order /*NULL: tiles in index order*/,
                                 const float* dL_dpix, const float* dL_dinvdepth, float* splat_grads /*[P,12] variant 1*/,
                                 float* inst_grads /*[4][R,12]*/, uint32_t* inst_flag /*[R]*/, int64_t R, int variant,
                                 unsigned long long* counters, hipStream_t st);

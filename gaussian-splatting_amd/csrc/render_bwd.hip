@@ -240,15 +240,18 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
                 const float4* __restrict__ splats, const float* __restrict__ final_T,
                 const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                 const float* __restrict__ dL_dinvdepth, float4* __restrict__ slot_grads /*[4][R] records of 3 float4*/,
-                uint8_t* __restrict__ slot_flags /*[R][4]*/, int64_t R, unsigned long long* __restrict__ counters) {
+                uint8_t* __restrict__ slot_flags /*[R][4]*/, int64_t R, const uint32_t* __restrict__ tile_order /*NULL: index order*/,
+                unsigned long long* __restrict__ counters) {
     __shared__ float4 s_rec[64 * REC_STRIDE];
     __shared__ float s_grad[64 * 12];
-    // the two halves of a tile get workgroup ids b and b + 16 -> same XCD -> they share the gathered records in L2
+    // the two halves of a tile get workgroup ids b and b + 16 -> same XCD -> they share the gathered records in L2;
+    // workgroups are dispatched in id order, and tile_order lists the heaviest tiles first (bwd_plan_kernel below)
     const int b = blockIdx.x;
     const int grp = b >> 5, r32 = b & 31;
-    const int tile_local = grp * 16 + (r32 & 15);
+    const int turn = grp * 16 + (r32 & 15);
     const int half = r32 >> 4;
-    if (tile_local >= n_band_tiles) return;
+    if (turn >= n_band_tiles) return;
+    const int tile_local = tile_order ? (int)tile_order[turn] : turn;
     const int tile = cam.tile_y0 * cam.gx + tile_local;
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const int lane = threadIdx.x;
@@ -1014,6 +1017,47 @@ render_bwd_wave(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
 
 #endif  // GSR_AB_VARIANTS
 
+// ------------------------------------------------------------------------------------------------
+// Heaviest tiles first.  A wave of the blend backward lives for a third of the kernel, the heaviest does 1.8-2x the mean
+// number of steps, and workgroups start in id order: a heavy tile that starts in the last round IS the kernel's tail.  The
+// forward has already counted, per 8x8 block, the entries it blended before the block's last pixel terminated -- the very
+// survivors the backward walks back from the same point -- so the cost of every tile is known before the launch.  One
+// workgroup counting-sorts the band's tiles by that cost, descending (1024 bins, LDS atomics: the order inside a bin varies
+// from run to run, the gradients do not -- every wave writes its own slots).
+// ------------------------------------------------------------------------------------------------
+constexpr int PLAN_THREADS = 1024, PLAN_BINS = 1024;
+__device__ __forceinline__ int plan_bin(uint32_t w) {       // monotone; 4-step bins where frames live, 32-step bins above
+    return w < 2048u ? (int)(w >> 2) : min(PLAN_BINS - 1, 512 + (int)((w - 2048u) >> 5));
+}
+
+__global__ void __launch_bounds__(PLAN_THREADS)
+bwd_plan_kernel(int tile0, int n_band_tiles, const uint4* __restrict__ block_steps, uint32_t* __restrict__ tile_order) {
+    __shared__ uint32_t s_bin[PLAN_BINS];
+    __shared__ uint32_t s_wsum[PLAN_THREADS / 64];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    s_bin[t] = 0u;
+    __syncthreads();
+    for (int i = t; i < n_band_tiles; i += PLAN_THREADS) {
+        const uint4 v = block_steps[tile0 + i];
+        atomicAdd(&s_bin[plan_bin(v.x + v.y + v.z + v.w)], 1u);
+    }
+    __syncthreads();
+    const uint32_t c = s_bin[PLAN_BINS - 1 - t];            // thread t owns the t-th heaviest bin
+    const uint32_t incl = gsrw::wave_incl_scan_u32(c, lane);
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0u;
+#pragma unroll
+    for (int k = 0; k < PLAN_THREADS / 64; ++k)
+        if (k < wv) base += s_wsum[k];
+    s_bin[PLAN_BINS - 1 - t] = base + incl - c;             // the bin's cursor
+    __syncthreads();
+    for (int i = t; i < n_band_tiles; i += PLAN_THREADS) {
+        const uint4 v = block_steps[tile0 + i];
+        tile_order[atomicAdd(&s_bin[plan_bin(v.x + v.y + v.z + v.w)], 1u)] = (uint32_t)i;
+    }
+}
+
 }  // namespace
 
 int gsr_render_backward_variant_available(int variant) {
@@ -1026,6 +1070,7 @@ int gsr_render_backward_variant_available(int variant) {
 
 void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,
                                 const float4* splats, const float* final_T, const uint32_t* n_contrib,
+                                const uint32_t* block_steps, uint32_t* tile_order,
                                 const float* dL_dpix, const float* dL_dinvdepth, float* splat_grads, float* inst_grads,
                                 uint32_t* inst_flag, int64_t R, int variant, unsigned long long* counters, hipStream_t st) {
     const int n_band_tiles = cam.gx * (cam.tile_y1 - cam.tile_y0);
@@ -1052,14 +1097,19 @@ void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const
 #endif
     (void)variant; (void)splat_grads; (void)groups;
     const int groups16 = (n_band_tiles + 15) / 16;
+    if (tile_order && block_steps)
+        hipLaunchKernelGGL(bwd_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, cam.tile_y0 * cam.gx, n_band_tiles,
+                           reinterpret_cast<const uint4*>(block_steps), tile_order);
+    else
+        tile_order = nullptr;
     if (dL_dinvdepth)
         hipLaunchKernelGGL(render_bwd_half<true>, dim3(groups16 * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list, splats,
                            final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads),
-                           reinterpret_cast<uint8_t*>(inst_flag), R, counters);
+                           reinterpret_cast<uint8_t*>(inst_flag), R, tile_order, counters);
     else
         hipLaunchKernelGGL(render_bwd_half<false>, dim3(groups16 * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list, splats,
                            final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads),
-                           reinterpret_cast<uint8_t*>(inst_flag), R, counters);
+                           reinterpret_cast<uint8_t*>(inst_flag), R, tile_order, counters);
 }
 
 size_t gsr_reduce_units(int64_t R) { return (size_t)((R + RU - 1) / RU); }

@@ -188,8 +188,9 @@ template <bool USE_LDS, int WPB, bool TRACK>
 __global__ void __launch_bounds__(64 * WPB)
 render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ranges,
                    const uint32_t* __restrict__ point_list, const float4* __restrict__ splats,
-                   float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-                   float* __restrict__ out_invdepth, unsigned long long* __restrict__ counters /*NULL unless profiling*/) {
+                   float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ block_steps,
+                   float* __restrict__ out_color, float* __restrict__ out_invdepth,
+                   unsigned long long* __restrict__ counters /*NULL unless profiling*/) {
     __shared__ float4 s_rec_all[USE_LDS ? WPB * 64 * 3 : 1];
     float4* s_rec = s_rec_all + (USE_LDS ? (threadIdx.x >> 6) * 64 * 3 : 0);
     int tile_local, quad;
@@ -209,7 +210,10 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const int lane = threadIdx.x & 63;
     const int bx0 = tx * GSR_TILE + (quad & 1) * 8, by0 = ty * GSR_TILE + (quad >> 1) * 8;
-    if (bx0 >= cam.W || by0 >= cam.H) return;
+    if (bx0 >= cam.W || by0 >= cam.H) {
+        if (TRACK && lane == 0) block_steps[tile * 4 + quad] = 0u;
+        return;
+    }
     const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
     const bool inside = px < cam.W && py < cam.H;
     const float pxf = (float)px, pyf = (float)py;
@@ -279,6 +283,9 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
         atomicAdd(counters + 1, (unsigned long long)nbatches);
         atomicMax(counters + 4, (unsigned long long)nsteps);      // the heaviest wave (tail of the launch: max / mean)
     }
+    // the entries this block blended until its last pixel terminated = the steps its quadrant costs the blend backward,
+    // which walks the same survivors back from the same point: the backward's plan kernel orders the tiles by it
+    if (TRACK && lane == 0) block_steps[tile * 4 + quad] = nsteps;
     if (inside) {
         const int64_t pix = (int64_t)py * cam.W + px;
         const int64_t HW = (int64_t)cam.H * cam.W;
@@ -304,23 +311,24 @@ int gsr_render_forward_variant_available(int variant) {
 }
 
 void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,
-                               const float4* splats, float* final_T, uint32_t* n_contrib, float* out_color,
-                               float* out_invdepth, int variant, unsigned long long* counters, hipStream_t st) {
+                               const float4* splats, float* final_T, uint32_t* n_contrib, uint32_t* block_steps,
+                               float* out_color, float* out_invdepth, int variant, unsigned long long* counters, hipStream_t st) {
     const int n_band_tiles = cam.gx * (cam.tile_y1 - cam.tile_y0);
     if (n_band_tiles <= 0) return;
     const int groups = (n_band_tiles + 7) / 8;
-    const bool track = final_T != nullptr && n_contrib != nullptr;
+    const bool track = final_T != nullptr && n_contrib != nullptr && block_steps != nullptr;
 #define GSR_LAUNCH_BF(USE_LDS_, WPB_, GRID_, BLOCK_)                                                                              \
     do {                                                                                                                          \
         if (track)                                                                                                                \
             hipLaunchKernelGGL((render_fwd_wave_bf<USE_LDS_, WPB_, true>), dim3(GRID_), dim3(BLOCK_), 0, st, cam, n_band_tiles,    \
-                               ranges, point_list, splats, final_T, n_contrib, out_color, out_invdepth, counters);               \
+                               ranges, point_list, splats, final_T, n_contrib, block_steps, out_color, out_invdepth, counters);  \
         else                                                                                                                      \
             hipLaunchKernelGGL((render_fwd_wave_bf<USE_LDS_, WPB_, false>), dim3(GRID_), dim3(BLOCK_), 0, st, cam, n_band_tiles,   \
-                               ranges, point_list, splats, final_T, n_contrib, out_color, out_invdepth, counters);               \
+                               ranges, point_list, splats, final_T, n_contrib, block_steps, out_color, out_invdepth, counters);  \
     } while (0)
 #ifdef GSR_AB_VARIANTS
     if (variant == 1) {
+        if (track) (void)hipMemsetAsync(block_steps + (size_t)cam.tile_y0 * cam.gx * 4, 0, (size_t)n_band_tiles * 16, st);   // no estimate: any order
         hipLaunchKernelGGL(render_fwd_block, dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats,
                            final_T, n_contrib, out_color, out_invdepth);
         return;

@@ -324,6 +324,15 @@ def test_backward_is_bit_reproducible_and_variants_agree():
     a, b = grads(0), grads(0)
     for x, y in zip(a, b):
         assert torch.equal(x, y), "default backward is not bit-reproducible"
+    # the order in which the blend backward starts its tiles (heaviest first, planned from the forward's step counts) is
+    # scheduling only: every wave writes its own slots, so the gradients are the same bits in either order
+    _lib.set_option("bwd_heavy_first", 0)
+    try:
+        c = grads(0)
+    finally:
+        _lib.set_option("bwd_heavy_first", 1)
+    for x, z in zip(a, c):
+        assert torch.equal(x, z), "tile order of the blend backward changed a gradient"
     for variant, tol in ((1, 2e-4), (4, 5e-5), (5, 5e-5)):
         try:
             c = grads(variant)
