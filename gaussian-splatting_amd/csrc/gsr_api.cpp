@@ -357,6 +357,12 @@ int gsr_set_option(const char* name, int value) {
         g_color_overlap = value;
         return GSR_OK;
     }
+    if (!strcmp(name, "ssim_variant")) {
+        if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "ssim_variant must be 0 (marching waves) or 1 (LDS tiles)");
+        gsr_set_ssim_variant(value);
+        return GSR_OK;
+    }
+    if (!strcmp(name, "ssim_target_waves")) { gsr_set_ssim_target_waves(value); return GSR_OK; }
     if (!strcmp(name, "bwd_heavy_first")) {
         if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "bwd_heavy_first must be 0 (tiles in index order) or 1 (heaviest tiles first)");
         g_bwd_heavy_first = value;

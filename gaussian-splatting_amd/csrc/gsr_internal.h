@@ -247,6 +247,8 @@ void gsr_launch_density_stats(int P, const float* grad, const uint8_t* visible, 
 size_t gsr_knn_scratch_bytes_impl(int N);
 void gsr_launch_knn(int N, const float* points, float* out, void* scratch, hipStream_t st);
 // ssim.hip: mean-SSIM form (no map round trip)
+void gsr_set_ssim_variant(int v);      // 0 = marching waves (default), 1 = LDS tiles (A/B)
+void gsr_set_ssim_target_waves(int v); // tuning: waves per launch the marching form aims for
 int64_t gsr_ssim_partial_count_impl(int planes, int H, int W);
 void gsr_launch_ssim_mean_forward(int planes, int H, int W, const float* img1, const float* img2, float* partials,
                                   float* mean_out, float* dm_dmu1, float* dm_dex2, float* dm_dexy, hipStream_t st);

@@ -20,6 +20,8 @@
 // workgroups per CU (50 KB of LDS each).  A barrier-free "marching" form (one wave per column strip, 11-row ring of the
 // horizontal moments in registers) was costed and dropped: at 1080p it has either < 3 waves per SIMD or > 30 % halo rows.
 #include "gsr_internal.h"
+#include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -355,7 +357,304 @@ ssim_bwd_kernel(int H, int W, int planes, const float* __restrict__ img1, const 
     }
 }
 
-// 1-D launch: 8 x ceil(tiles / 8) workgroups, see ssim_tile_of_block
+// ================================================================================================
+// Round 3, second form: MARCHING waves (the default).  The tiled kernels above stay as A/B variant 1 (`ssim_variant`).
+//
+// The tiled form is neither HBM- nor FMA-bound: it is a sequence of phases (global -> LDS, barrier, horizontal, barrier, vertical)
+// with three resident workgroups per CU (50 KB of LDS each) and nothing to overlap them with: 78 us forward + 58 us backward for
+// 25 MB planes, against ~15 us of FMA issue.  Here a wave owns a strip of 64 image columns and walks DOWN it, one image row per
+// step, with no LDS and no barrier:
+//   * lane = column.  The horizontal 11-tap window needs the five neighbours on either side: x and y (not the five moments)
+//     travel across the lanes with `v_mov_b32_dpp wave_shr:1 / wave_shl:1` chains -- plain VALU moves, gfx9's whole-wave DPP
+//     shifts -- and the three products are formed per tap; symmetric taps are paired (w (a + b), w (a a + b b)).  The outer five
+//     lanes on either side only feed their neighbours: 54 outputs per 64 lanes.
+//   * the vertical window is a SYSTOLIC register pipeline: eleven partial outputs per moment, and a new horizontally filtered
+//     row h updates them as A[j] = fma(w[j], h, A[j + 1]) -- the shift of the pipeline is the choice of the destination
+//     register, no moves, no unrolling by eleven; A[0] is complete five rows behind the row just read.
+//   * rows are requested MPF steps ahead into a register ring; the zero padding is applied when a row is CONSUMED (a select next
+//     to the load would pin the wait there).
+// A strip is cut into segments of `seg` rows (ten extra rows per segment) so that ~3-4 waves sit on every SIMD.
+// ================================================================================================
+constexpr int MW = 54;            // output columns per wave
+constexpr int MPF = 5;            // rows in flight
+constexpr int MWARM = 10;         // warm-up rows (= 2 * HALO, a multiple of MPF): the pipeline fills, nothing is written
+constexpr uint32_t OOB = 0x80000000u;      // a buffer offset beyond every plane: loads return 0, stores are dropped
+
+__device__ __forceinline__ float wave_shr1(float v) {       // lane i <- lane i - 1 (lane 0 <- 0)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_shl1(float v) {       // lane i <- lane i + 1 (lane 63 <- 0)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+// Raw buffer access (stride 0, range-checked by the hardware): every plane is its own buffer of H * W * 4 bytes, so the
+// conv2d zero padding is an out-of-range LOAD and a lane / row without an output is an out-of-range STORE.  No select next to
+// a load, no exec-masked store block, no branch in the row loop: the loop body is straight-line code, which is what lets the
+// compiler count the memory operations in flight.  (With `if (valid) store` the waitcnt pass had to assume the worst at every
+// join and drained the queue -- s_waitcnt vmcnt(0) -- once per four rows: the prefetch ring was one row deep in effect.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_buffer(const float* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ void buf_store(__amdgpu_buffer_rsrc_t r, uint32_t off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), r, (int)off, 0, 0);
+}
+
+template <int MODE, bool DERIV>
+__global__ void __launch_bounds__(64)
+ssim_fwd_march(int H, int W, int planes, int nsx, int nsy, int seg, const float* __restrict__ img1, const float* __restrict__ img2,
+               float* __restrict__ ssim_map, float* __restrict__ dm_dmu1, float* __restrict__ dm_dex2, float* __restrict__ dm_dexy) {
+    constexpr bool MEAN = MODE != 0;
+    const int lane = threadIdx.x;
+    int sx, sy, plane;
+    int64_t tlin;
+    if (!ssim_tile_of_block(nsx, nsy, planes, sx, sy, plane, tlin)) return;
+    const int col = sx * MW - HALO + lane;              // this lane's image column (input AND output)
+    const bool col_ok = col >= 0 && col < W;
+    const bool col_out = lane >= HALO && lane < HALO + MW && col < W;
+    const int y0 = sy * seg, y1 = min(y0 + seg, H);      // output rows [y0, y1)
+    const int r_last = min(y1 + HALO, H);                // input rows beyond it are never needed
+    const int64_t pbase = (int64_t)plane * H * W;
+    const uint32_t pbytes = (uint32_t)H * (uint32_t)W * 4u;
+    const __amdgpu_buffer_rsrc_t b1 = plane_buffer(img1 + pbase, pbytes), b2 = plane_buffer(img2 + pbase, pbytes);
+    const __amdgpu_buffer_rsrc_t bm = plane_buffer(MEAN ? img1 : ssim_map + pbase, MEAN ? 0u : pbytes);
+    const __amdgpu_buffer_rsrc_t d1 = plane_buffer(DERIV ? dm_dmu1 + pbase : img1, DERIV ? pbytes : 0u);
+    const __amdgpu_buffer_rsrc_t d2 = plane_buffer(DERIV ? dm_dex2 + pbase : img1, DERIV ? pbytes : 0u);
+    const __amdgpu_buffer_rsrc_t d3 = plane_buffer(DERIV ? dm_dexy + pbase : img1, DERIV ? pbytes : 0u);
+    const uint32_t col4 = (uint32_t)col * 4u, row4 = (uint32_t)W * 4u;
+    float rx[MPF], ry[MPF];
+    float A[5][11];
+#pragma unroll
+    for (int m = 0; m < 5; ++m)
+#pragma unroll
+        for (int j = 0; j < 11; ++j) A[m][j] = 0.f;
+    float m_own = 0.f, l1_own = 0.f;
+    auto request = [&](int rr, int k) {
+        const uint32_t off = (col_ok && rr >= 0 && rr < r_last) ? (uint32_t)rr * row4 + col4 : OOB;
+        rx[k] = buf_load(b1, off);
+        ry[k] = buf_load(b2, off);
+    };
+    // one image row; ONE loop with one body, the MWARM rows that only fill the pipeline included (their output offset is out
+    // of range) -- see the backward kernel for what a separate warm-up loop did to the waits
+    auto step = [&](int r, int k) {
+        const float x = rx[k], y = ry[k];
+        if (MODE == 2) l1_own += (col_out && r >= y0 && r < y1) ? fabsf(x - y) : 0.f;
+        // ---- horizontal: x, y of the five lanes on either side ----
+        float xm[6], xp[6], ym[6], yp[6];
+        xm[0] = x; xp[0] = x; ym[0] = y; yp[0] = y;
+#pragma unroll
+        for (int d = 1; d <= 5; ++d) {
+            xm[d] = wave_shr1(xm[d - 1]); xp[d] = wave_shl1(xp[d - 1]);
+            ym[d] = wave_shr1(ym[d - 1]); yp[d] = wave_shl1(yp[d - 1]);
+        }
+        float h[5];
+        {   const float w = GSR_WIN(5);
+            h[0] = w * x; h[1] = w * y; h[2] = w * (x * x); h[3] = w * (y * y); h[4] = w * (x * y);
+        }
+#pragma unroll
+        for (int d = 1; d <= 5; ++d) {
+            const float w = GSR_WIN(5 - d);
+            const float a = xm[d], b = xp[d], c = ym[d], e = yp[d];
+            h[0] = fmaf(w, a + b, h[0]);
+            h[1] = fmaf(w, c + e, h[1]);
+            h[2] = fmaf(w, fmaf(b, b, a * a), h[2]);
+            h[3] = fmaf(w, fmaf(e, e, c * c), h[3]);
+            h[4] = fmaf(w, fmaf(b, e, a * c), h[4]);
+        }
+        // the slot's registers are free now: request the row MPF steps ahead INTO THEM.  The fences keep the scheduler from
+        // hoisting the loads above the last use of the old values -- it then needs a fifth set of registers and rotates the
+        // ring with v_mov at the loop latch, and moves of loaded registers are waits (s_waitcnt vmcnt(1..5) every trip)
+        __builtin_amdgcn_sched_barrier(0);
+        request(r + MPF, k);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- vertical: the systolic pipeline; A[.][0] is now complete for output row r - 5 ----
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+#pragma unroll
+            for (int j = 0; j < 10; ++j) A[m][j] = fmaf(GSR_WIN(j), h[m], A[m][j + 1]);
+            A[m][10] = GSR_WIN(10) * h[m];
+        }
+        {
+            const int o = r - HALO;
+            const bool valid = col_out && o >= y0 && o < y1;
+            const uint32_t off = valid ? (uint32_t)o * row4 + col4 : OOB;
+            const float mu1 = A[0][0], mu2 = A[1][0], ex2 = A[2][0], ey2 = A[3][0], exy = A[4][0];
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float sigma1_sq = ex2 - mu1_sq, sigma2_sq = ey2 - mu2_sq, sigma12 = exy - mu12;
+            const float Aa = mu1_sq + mu2_sq + C1, B = sigma1_sq + sigma2_sq + C2;
+            const float Cc = 2.f * mu12 + C1, D = 2.f * sigma12 + C2;
+            const float inv_A = __builtin_amdgcn_rcpf(Aa), inv_B = __builtin_amdgcn_rcpf(B);
+            const float inv_AB = inv_A * inv_B;
+            const float mv = Cc * D * inv_AB;
+            m_own += valid ? mv : 0.f;
+            if (!MEAN) buf_store(bm, off, mv);
+            if (DERIV) {
+                buf_store(d1, off, 2.f * mu2 * (D - Cc) * inv_AB + 2.f * mu1 * mv * (inv_B - inv_A));
+                buf_store(d2, off, -mv * inv_B);
+                buf_store(d3, off, 2.f * Cc * inv_AB);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);          // (keeps the four unrolled steps apart: without stores the scheduler
+                                                    //  batches their formulas and holds all four rows' moments in registers)
+    };
+    int r = y0 + HALO - MWARM;
+#pragma unroll
+    for (int k = 0; k < MPF; ++k) request(r + k, k);
+    const int r_end = y1 + HALO;                         // (rows past it are padding of the last group: no output, no load)
+#pragma unroll 1
+    for (; r < r_end; r += MPF) {
+#pragma unroll
+        for (int k = 0; k < MPF; ++k) step(r + k, k);
+    }
+    if (MEAN) {
+        float v = m_own, u = l1_own;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            v += __shfl_xor(v, off, 64);
+            if (MODE == 2) u += __shfl_xor(u, off, 64);
+        }
+        if (lane == 0) {
+            ssim_map[tlin] = v;
+            if (MODE == 2) ssim_map[(int64_t)planes * nsy * nsx + tlin] = u;
+        }
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64)
+ssim_bwd_march(int H, int W, int planes, int nsx, int nsy, int seg, const float* __restrict__ img1, const float* __restrict__ img2,
+               const float* __restrict__ dL_dmap, float inv_count, float lambda, const float* __restrict__ dm_dmu1,
+               const float* __restrict__ dm_dex2, const float* __restrict__ dm_dexy, float* __restrict__ dL_dimg1) {
+    constexpr bool MEAN = MODE != 0;
+    const int lane = threadIdx.x;
+    int sx, sy, plane;
+    int64_t tlin;
+    if (!ssim_tile_of_block(nsx, nsy, planes, sx, sy, plane, tlin)) return;
+    const int col = sx * MW - HALO + lane;
+    const bool col_ok = col >= 0 && col < W;
+    const bool col_out = lane >= HALO && lane < HALO + MW && col < W;
+    const int y0 = sy * seg, y1 = min(y0 + seg, H);
+    const int r_last = min(y1 + HALO, H);
+    const int64_t pbase = (int64_t)plane * H * W;
+    const uint32_t pbytes = (uint32_t)H * (uint32_t)W * 4u;
+    const __amdgpu_buffer_rsrc_t ba = plane_buffer(dm_dmu1 + pbase, pbytes), bb = plane_buffer(dm_dex2 + pbase, pbytes);
+    const __amdgpu_buffer_rsrc_t bc = plane_buffer(dm_dexy + pbase, pbytes);
+    const __amdgpu_buffer_rsrc_t bg = plane_buffer(MEAN ? img1 : dL_dmap + pbase, MEAN ? 0u : pbytes);
+    const __amdgpu_buffer_rsrc_t b1 = plane_buffer(img1 + pbase, pbytes), b2 = plane_buffer(img2 + pbase, pbytes);
+    const __amdgpu_buffer_rsrc_t bo = plane_buffer(dL_dimg1 + pbase, pbytes);
+    const uint32_t col4 = (uint32_t)col * 4u, row4 = (uint32_t)W * 4u;
+    const float gmean = MODE == 2 ? -lambda * dL_dmap[0] * inv_count : (MEAN ? dL_dmap[0] * inv_count : 0.f);
+    const float gl1 = MODE == 2 ? (1.0f - lambda) * dL_dmap[0] * inv_count : 0.f;
+    // ring slot k: the three maps (and dL/dmap) of input row r, and the two images at the OUTPUT row r - 5 of the same step
+    float ra[MPF], rb[MPF], rc[MPF], rg[MPF], ri1[MPF], ri2[MPF];
+    auto request_maps = [&](int rr, int k) {
+        const uint32_t off = (col_ok && rr >= 0 && rr < r_last) ? (uint32_t)rr * row4 + col4 : OOB;
+        ra[k] = buf_load(ba, off);
+        rb[k] = buf_load(bb, off);
+        rc[k] = buf_load(bc, off);
+        if (!MEAN) rg[k] = buf_load(bg, off);
+    };
+    auto request_images = [&](int rr, int k) {
+        const int ro = rr - HALO;
+        const uint32_t oo = (col_out && ro >= y0 && ro < y1) ? (uint32_t)ro * row4 + col4 : OOB;
+        ri1[k] = buf_load(b1, oo);
+        ri2[k] = buf_load(b2, oo);
+    };
+    float A[3][11];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int j = 0; j < 11; ++j) A[m][j] = 0.f;
+    // ONE loop with one body, warm-up rows included (their output offset is out of range): with a separate warm-up loop the
+    // compiler dropped the image loads there, re-issued them in a batch in front of the main loop, and the wait for them --
+    // the youngest loads on the first trip -- became s_waitcnt vmcnt(5) on EVERY trip
+    auto step = [&](int r, int k) {
+        const float g = MEAN ? gmean : rg[k];
+        const float v0 = g * ra[k], v1 = g * rb[k], v2 = g * rc[k];       // an out-of-range row / column loaded 0
+        float am[6], ap[6], bmm[6], bp[6], cm[6], cp[6];
+        am[0] = v0; ap[0] = v0; bmm[0] = v1; bp[0] = v1; cm[0] = v2; cp[0] = v2;
+#pragma unroll
+        for (int d = 1; d <= 5; ++d) {
+            am[d] = wave_shr1(am[d - 1]); ap[d] = wave_shl1(ap[d - 1]);
+            bmm[d] = wave_shr1(bmm[d - 1]); bp[d] = wave_shl1(bp[d - 1]);
+            cm[d] = wave_shr1(cm[d - 1]); cp[d] = wave_shl1(cp[d - 1]);
+        }
+        float h[3];
+        h[0] = GSR_WIN(5) * v0; h[1] = GSR_WIN(5) * v1; h[2] = GSR_WIN(5) * v2;
+#pragma unroll
+        for (int d = 1; d <= 5; ++d) {
+            const float w = GSR_WIN(5 - d);
+            h[0] = fmaf(w, am[d] + ap[d], h[0]);
+            h[1] = fmaf(w, bmm[d] + bp[d], h[1]);
+            h[2] = fmaf(w, cm[d] + cp[d], h[2]);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // (see the forward kernel: loads go into registers that are dead by now)
+        request_maps(r + MPF, k);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+#pragma unroll
+            for (int j = 0; j < 10; ++j) A[m][j] = fmaf(GSR_WIN(j), h[m], A[m][j + 1]);
+            A[m][10] = GSR_WIN(10) * h[m];
+        }
+        {
+            const float im1 = ri1[k], im2 = ri2[k];
+            const int o = r - HALO;
+            const uint32_t off = (col_out && o >= y0 && o < y1) ? (uint32_t)o * row4 + col4 : OOB;
+            float v = A[0][0] + 2.f * im1 * A[1][0] + im2 * A[2][0];
+            if (MODE == 2) { const float d = im1 - im2; v += d > 0.f ? gl1 : (d < 0.f ? -gl1 : 0.f); }      // torch's sign(0) = 0
+            buf_store(bo, off, v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        request_images(r + MPF, k);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int r = y0 + HALO - MWARM;
+#pragma unroll
+    for (int k = 0; k < MPF; ++k) { request_maps(r + k, k); request_images(r + k, k); }
+    const int r_end = y1 + HALO;
+#pragma unroll 1
+    for (; r < r_end; r += MPF) {
+#pragma unroll
+        for (int k = 0; k < MPF; ++k) step(r + k, k);
+    }
+}
+
+int g_ssim_variant = 0;           // 0 = marching waves, 1 = LDS tiles (A/B)
+int g_ssim_target_waves = 2048;   // waves a launch of the marching form aims for (1024 SIMDs x waves per SIMD)
+
+struct MarchPlan { int nsx, nsy, seg; unsigned lds; };
+// Launch shape.  A launch has FEWER waves than the chip has slots for, and the dispatcher fills a CU to its limit before it
+// moves on: 3 672 one-wave workgroups went to 184 CUs, five per SIMD, 72 CUs idle (SQ_BUSY_CYCLES 42 %, mean wave life 43 us of
+// a 78 us kernel).  So every workgroup also asks for 160 KB / (workgroups per CU) of LDS it never touches: that caps a CU at
+// the even share and the launch spreads over all 256.  Measured at 1080p (forward / backward, us) against the waves per CU,
+// MPF = 4: 8 -> 52 / 35, 12 -> 71 / 45, 16 -> 55 / 38, 20 -> 57 / 40 -- the waves of one-wave workgroups reach the four SIMDs
+// in pairs, so 12 per CU run as 4 + 4 + 2 + 2; workgroups of four waves were worse still (72 / 56).  With MPF = 5 (ten
+// warm-up rows instead of twelve): 8 per CU 48.8 / 33.8, 16 per CU 50.5 / 34.6.  Two waves per SIMD do not saturate the VALU
+// (a wave issues one instruction per ~5 cycles) but carry 10 halo rows per 57 instead of per 30: `g_ssim_target_waves` = 2048.
+// 16 <= seg <= 128 rows.
+MarchPlan march_plan(int planes, int H, int W) {
+    MarchPlan p;
+    p.nsx = (W + MW - 1) / MW;
+    const int64_t strips = (int64_t)planes * p.nsx;
+    const int want = (int)std::max<int64_t>(1, g_ssim_target_waves / strips);       // segments per strip
+    int seg = (H + want - 1) / want;
+    seg = std::min(std::max(seg, 16), 128);
+    p.seg = seg;
+    p.nsy = (H + seg - 1) / seg;
+    const int64_t waves = strips * p.nsy;
+    const int64_t per_cu = (waves + 255) / 256;
+    p.lds = per_cu >= 20 ? 0u : (unsigned)(((160 * 1024) / per_cu) & ~(int64_t)511);
+    if (p.lds > 64 * 1024) p.lds = 64 * 1024;                        // (the default dynamic-LDS limit; small images need no cap)
+    return p;
+}
+dim3 march_grid(const MarchPlan& p, int planes) {
+    const int64_t n = (int64_t)planes * p.nsx * p.nsy;
+    return dim3((unsigned)(8 * ((n + 7) / 8)));
+}
+
+// tiled form, 1-D launch: 8 x ceil(tiles / 8) workgroups, see ssim_tile_of_block
 dim3 ssim_grid(int planes, int H, int W) {
     const int64_t ntiles = (int64_t)planes * ((W + TXO - 1) / TXO) * ((H + TYO - 1) / TYO);
     return dim3((unsigned)(8 * ((ntiles + 7) / 8)));
@@ -363,20 +662,66 @@ dim3 ssim_grid(int planes, int H, int W) {
 
 }  // namespace
 
-void gsr_launch_ssim_forward(int planes, int H, int W, const float* img1, const float* img2, float* ssim_map, float* dm_dmu1,
-                             float* dm_dex2, float* dm_dexy, hipStream_t st) {
-    hipLaunchKernelGGL(ssim_fwd_kernel<0>, ssim_grid(planes, H, W), dim3(256), 0, st, H, W, planes, img1, img2, ssim_map, dm_dmu1, dm_dex2, dm_dexy);
+// the LDS-tiled form: on request (A/B), for planes beyond a 2 GB buffer descriptor, and for the mean forms without maps
+static bool ssim_use_tiles(int H, int W, bool mean_without_maps) {
+    return g_ssim_variant == 1 || (int64_t)H * W * 4 >= 0x7FFFFFFFll || mean_without_maps;
 }
 
+void gsr_set_ssim_variant(int v) { g_ssim_variant = v; }
+void gsr_set_ssim_target_waves(int v) { g_ssim_target_waves = std::max(v, 256); }
+
+/* the tiled form also serves the mean forms WITHOUT derivative maps (no-grad evaluation): with nothing to store per row the  \
+   marching loop compiles to 170+ registers */                                                                                    \
+#define GSR_SSIM_FWD(MODE_, OUT_)                                                                                                  \
+    do {                                                                                                                           \
+        if (ssim_use_tiles(H, W, MODE_ != 0 && !dm_dmu1)) {                                                                        \
+            hipLaunchKernelGGL(ssim_fwd_kernel<MODE_>, ssim_grid(planes, H, W), dim3(256), 0, st, H, W, planes, img1, img2, OUT_,  \
+                               dm_dmu1, dm_dex2, dm_dexy);                                                                         \
+        } else {                                                                                                                   \
+            const MarchPlan mp = march_plan(planes, H, W);                                                                         \
+            if (dm_dmu1)                                                                                                           \
+                hipLaunchKernelGGL((ssim_fwd_march<MODE_, true>), march_grid(mp, planes), dim3(64), mp.lds, st, H, W, planes,      \
+                                   mp.nsx, mp.nsy, mp.seg, img1, img2, OUT_, dm_dmu1, dm_dex2, dm_dexy);                           \
+            else                                                                                                                   \
+                hipLaunchKernelGGL((ssim_fwd_march<0, false>), march_grid(mp, planes), dim3(64), mp.lds, st, H, W, planes,         \
+                                   mp.nsx, mp.nsy, mp.seg, img1, img2, OUT_, dm_dmu1, dm_dex2, dm_dexy);                           \
+        }                                                                                                                          \
+    } while (0)
+#define GSR_SSIM_BWD(MODE_, G_, INV_, LAMBDA_)                                                                                     \
+    do {                                                                                                                           \
+        if (ssim_use_tiles(H, W, false)) {                                                                                         \
+            hipLaunchKernelGGL(ssim_bwd_kernel<MODE_>, ssim_grid(planes, H, W), dim3(256), 0, st, H, W, planes, img1, img2, G_,    \
+                               INV_, LAMBDA_, dm_dmu1, dm_dex2, dm_dexy, dL_dimg1);                                                \
+        } else {                                                                                                                   \
+            const MarchPlan mp = march_plan(planes, H, W);                                                                         \
+            hipLaunchKernelGGL(ssim_bwd_march<MODE_>, march_grid(mp, planes), dim3(64), mp.lds, st, H, W, planes, mp.nsx, mp.nsy,       \
+                               mp.seg, img1, img2, G_, INV_, LAMBDA_, dm_dmu1, dm_dex2, dm_dexy, dL_dimg1);                        \
+        }                                                                                                                          \
+    } while (0)
+
+// partial sums the forward that WILL run writes (per tile / per wave)
+static int64_t ssim_partials_now(int planes, int H, int W, bool no_maps) {
+    if (ssim_use_tiles(H, W, no_maps)) return (int64_t)planes * ((W + TXO - 1) / TXO) * ((H + TYO - 1) / TYO);
+    const MarchPlan mp = march_plan(planes, H, W);
+    return (int64_t)planes * mp.nsx * mp.nsy;
+}
+
+void gsr_launch_ssim_forward(int planes, int H, int W, const float* img1, const float* img2, float* ssim_map, float* dm_dmu1,
+                             float* dm_dex2, float* dm_dexy, hipStream_t st) {
+    GSR_SSIM_FWD(0, ssim_map);
+}
+
+// callers size `partials` with this: enough for either variant
 int64_t gsr_ssim_partial_count_impl(int planes, int H, int W) {
-    return (int64_t)planes * ((W + TXO - 1) / TXO) * ((H + TYO - 1) / TYO);
+    const MarchPlan mp = march_plan(planes, H, W);
+    return std::max((int64_t)planes * ((W + TXO - 1) / TXO) * ((H + TYO - 1) / TYO), (int64_t)planes * mp.nsx * mp.nsy);
 }
 
 void gsr_launch_ssim_mean_forward(int planes, int H, int W, const float* img1, const float* img2, float* partials,
                                   float* mean_out, float* dm_dmu1, float* dm_dex2, float* dm_dexy, hipStream_t st) {
-    hipLaunchKernelGGL(ssim_fwd_kernel<1>, ssim_grid(planes, H, W), dim3(256), 0, st, H, W, planes, img1, img2, partials, dm_dmu1, dm_dex2, dm_dexy);
+    GSR_SSIM_FWD(1, partials);
     const double count = (double)planes * H * W;
-    hipLaunchKernelGGL(ssim_mean_kernel, dim3(1), dim3(256), 0, st, partials, (int)gsr_ssim_partial_count_impl(planes, H, W),
+    hipLaunchKernelGGL(ssim_mean_kernel, dim3(1), dim3(256), 0, st, partials, (int)ssim_partials_now(planes, H, W, dm_dmu1 == nullptr),
                        (float)(1.0 / count), mean_out);
 }
 
@@ -384,28 +729,25 @@ void gsr_launch_ssim_mean_backward(int planes, int H, int W, const float* img1, 
                                    const float* dm_dmu1, const float* dm_dex2, const float* dm_dexy, float* dL_dimg1,
                                    hipStream_t st) {
     const double count = (double)planes * H * W;
-    hipLaunchKernelGGL(ssim_bwd_kernel<1>, ssim_grid(planes, H, W), dim3(256), 0, st, H, W, planes, img1, img2, dL_dmean, (float)(1.0 / count), 0.f, dm_dmu1,
-                       dm_dex2, dm_dexy, dL_dimg1);
+    GSR_SSIM_BWD(1, dL_dmean, (float)(1.0 / count), 0.f);
 }
 
 void gsr_launch_ssim_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dmap,
                               const float* dm_dmu1, const float* dm_dex2, const float* dm_dexy, float* dL_dimg1, hipStream_t st) {
-    hipLaunchKernelGGL(ssim_bwd_kernel<0>, ssim_grid(planes, H, W), dim3(256), 0, st, H, W, planes, img1, img2, dL_dmap, 0.f, 0.f, dm_dmu1, dm_dex2, dm_dexy,
-                       dL_dimg1);
+    GSR_SSIM_BWD(0, dL_dmap, 0.f, 0.f);
 }
 
 // fused training loss (train.py:119-126): loss = (1 - lambda) L1 + lambda (1 - SSIM); partials holds 2 x gsr_ssim_partial_count floats
 void gsr_launch_train_loss_forward(int planes, int H, int W, const float* img1, const float* img2, float lambda, float* partials,
                                    float* loss_out /*[3]: loss, L1, SSIM*/, float* dm_dmu1, float* dm_dex2, float* dm_dexy, hipStream_t st) {
-    hipLaunchKernelGGL(ssim_fwd_kernel<2>, ssim_grid(planes, H, W), dim3(256), 0, st, H, W, planes, img1, img2, partials, dm_dmu1, dm_dex2, dm_dexy);
+    GSR_SSIM_FWD(2, partials);
     const double count = (double)planes * H * W;
-    hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(256), 0, st, partials, (int)gsr_ssim_partial_count_impl(planes, H, W),
+    hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(256), 0, st, partials, (int)ssim_partials_now(planes, H, W, dm_dmu1 == nullptr),
                        (float)(1.0 / count), lambda, loss_out);
 }
 
 void gsr_launch_train_loss_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dloss, float lambda,
                                     const float* dm_dmu1, const float* dm_dex2, const float* dm_dexy, float* dL_dimg1, hipStream_t st) {
     const double count = (double)planes * H * W;
-    hipLaunchKernelGGL(ssim_bwd_kernel<2>, ssim_grid(planes, H, W), dim3(256), 0, st, H, W, planes, img1, img2, dL_dloss, (float)(1.0 / count), lambda, dm_dmu1,
-                       dm_dex2, dm_dexy, dL_dimg1);
+    GSR_SSIM_BWD(2, dL_dloss, (float)(1.0 / count), lambda);
 }

@@ -269,8 +269,8 @@ int gsr_ssim_backward(int planes, int H, int W, const float* img1, const float* 
 
 /*
  * Mean-SSIM form of the same kernels -- what `fused_ssim(img1, img2)` returns (train.py:122): the forward writes one
- * partial sum per 16x16 tile into `partials` (gsr_ssim_partial_count floats) and their mean, added in fixed order, into
- * mean_out[1]; the backward takes dL/dmean as ONE device scalar.  Saves the SSIM-map round trip and the framework's
+ * partial sum per wave (per tile in the LDS-tiled A/B form) into `partials` -- gsr_ssim_partial_count floats is room for
+ * either form -- and their mean, added in fixed order, into mean_out[1]; the backward takes dL/dmean as ONE device scalar.  Saves the SSIM-map round trip and the framework's
  * reduction / broadcast kernels; results equal gsr_ssim_forward + mean up to fp32 summation order.
  */
 int64_t gsr_ssim_partial_count(int planes, int H, int W);

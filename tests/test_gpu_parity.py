@@ -554,8 +554,17 @@ def test_fused_adam_matches_torch_adam():
             assert (sa[key] - sb[key]).abs().max().item() <= 2e-6 * sb[key].abs().max().item()
 
 
-@pytest.mark.parametrize("shape", [(1, 3, 67, 93), (2, 3, 128, 160), (1, 1, 16, 16), (1, 3, 11, 300)])
-def test_fused_ssim_matches_reference_formula(shape):
+@pytest.fixture(params=[0, 1], ids=["marching", "tiled"])
+def ssim_variant(request):
+    """Both forms of the SSIM kernels (ssim.hip): marching waves (the default) and the LDS-tiled A/B form."""
+    from diff_gaussian_rasterization import _lib
+    _lib.set_option("ssim_variant", request.param)
+    yield request.param
+    _lib.set_option("ssim_variant", 0)
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 67, 93), (2, 3, 128, 160), (1, 1, 16, 16), (1, 3, 11, 300), (1, 3, 5, 7), (1, 2, 150, 55)])
+def test_fused_ssim_matches_reference_formula(shape, ssim_variant):
     """fused_ssim (HIP) == utils/loss_utils.py:56-87 (restated in oracle.losses, which is pinned to the
     reference by tests/test_oracle.py::test_train_loss_matches_reference_loss_utils) -- value and gradient."""
     from fused_ssim import fused_ssim
@@ -586,7 +595,7 @@ def test_fused_ssim_matches_reference_formula(shape):
 
 
 @pytest.mark.parametrize("shape,lam", [((3, 67, 93), 0.2), ((1, 3, 128, 160), 0.2), ((3, 16, 16), 0.5), ((3, 11, 300), 0.0), ((3, 40, 40), 1.0)])
-def test_fused_train_loss_matches_reference_formula(shape, lam):
+def test_fused_train_loss_matches_reference_formula(shape, lam, ssim_variant):
     """SURVEY 8(f) N1 "fused SSIM + L1": fused_train_loss (ONE HIP kernel pair) == (1 - lambda) l1_loss + lambda (1 - ssim) of
     utils/loss_utils.py:40-87 / train.py:119-126 (restated in oracle.losses, pinned to the reference by the golden vector of
     tests/test_oracle.py::test_train_loss_matches_reference_loss_utils) -- value, the two read-outs and the gradient, incl.

@@ -17,15 +17,16 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 enum Kind { FMA_IND = 0, FMA_DEP, MULADD_IND, CMP_CNDMASK, EXP_IND, RCP_IND, PK_FMA_IND, DPP_ADD, PERMLANE32, FMA_SALU, BODY_LDS, BODY_SGPR,
-            FMA_EXP_7_1, KIND_COUNT };
+            FMA_EXP_7_1, WAVE_SHR_MOV, ROW_SHR_MOV, KIND_COUNT };
 static const char* kind_name[KIND_COUNT] = {
     "v_fma_f32, 8 independent chains", "v_fma_f32, 1 dependent chain", "v_mul_f32 + v_add_f32 alternating, 8 chains",
     "v_cmp_gt_f32 + v_cndmask_b32 pairs", "v_exp_f32, 8 independent", "v_rcp_f32, 8 independent",
     "v_pk_fma_f32, 8 independent (2 lanes' worth each)", "v_add_f32 row_shr:1 (DPP), 8 chains", "v_permlane32_swap, 4 pairs",
     "v_fma_f32 (8 chains) + 1 s_add_u32 per 2 VALU", "forward blend body, record via uniform ds_read_b128 (product form)",
-    "forward blend body, record in SGPRs (s_load)", "7 v_fma_f32 + 1 v_exp_f32 per 8"};
+    "forward blend body, record in SGPRs (s_load)", "7 v_fma_f32 + 1 v_exp_f32 per 8",
+    "v_mov_b32 wave_shr:1 (whole-wave DPP shift), 8 chains", "v_mov_b32 row_shr:1 (DPP), 8 chains"};
 // VALU instructions per loop iteration of each kind (BODY kinds: filled from the compiled ISA, see body_valu below)
-static const int kind_valu_per_iter[KIND_COUNT] = {64, 64, 64, 64, 64, 64, 64, 64, 32, 64, 0, 0, 64};
+static const int kind_valu_per_iter[KIND_COUNT] = {64, 64, 64, 64, 64, 64, 64, 64, 32, 64, 0, 0, 64, 64, 64};
 
 struct WaveOut { unsigned long long cycles, ticks; };
 
@@ -71,6 +72,14 @@ typedef unsigned uint2v __attribute__((ext_vector_type(2)));
     "v_fma_f32 %0, %8, %9, %0\n v_fma_f32 %1, %8, %9, %1\n v_fma_f32 %2, %8, %9, %2\n v_fma_f32 %3, %8, %9, %3\n" \
     "v_fma_f32 %4, %8, %9, %4\n v_fma_f32 %5, %8, %9, %5\n v_fma_f32 %6, %8, %9, %6\n v_exp_f32 %7, %7\n" \
     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+#define ASM_SHIFT8(CTRL) asm volatile( \
+    "v_mov_b32_dpp %0, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_mov_b32_dpp %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0\n" \
+    "v_mov_b32_dpp %2, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_mov_b32_dpp %3, %3 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0\n" \
+    "v_mov_b32_dpp %4, %4 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_mov_b32_dpp %5, %5 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0\n" \
+    "v_mov_b32_dpp %6, %6 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_mov_b32_dpp %7, %7 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:0\n" \
+    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+#define ASM_WAVE_SHR8 ASM_SHIFT8("wave_shr:1")
+#define ASM_ROW_SHR8 ASM_SHIFT8("row_shr:1")
 
 template <int KIND>
 __global__ void __launch_bounds__(256) stream_kernel(WaveOut* out, float* sink, int iters, float seed) {
@@ -91,6 +100,8 @@ __global__ void __launch_bounds__(256) stream_kernel(WaveOut* out, float* sink, 
         if (KIND == PERMLANE32) { REP8(ASM_PERM4) }
         if (KIND == FMA_SALU) { REP8(ASM_FMA_SALU8) }
         if (KIND == FMA_EXP_7_1) { REP8(ASM_FMA7_EXP1) }
+        if (KIND == WAVE_SHR_MOV) { REP8(ASM_WAVE_SHR8) }
+        if (KIND == ROW_SHR_MOV) { REP8(ASM_ROW_SHR8) }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = {t1 - t0, r1 - r0};
@@ -196,11 +207,12 @@ int main(int argc, char** argv) {
     set_lds((const void*)stream_kernel<FMA_IND>); set_lds((const void*)stream_kernel<FMA_DEP>); set_lds((const void*)stream_kernel<MULADD_IND>);
     set_lds((const void*)stream_kernel<CMP_CNDMASK>); set_lds((const void*)stream_kernel<EXP_IND>); set_lds((const void*)stream_kernel<RCP_IND>);
     set_lds((const void*)stream_kernel<DPP_ADD>); set_lds((const void*)stream_kernel<PERMLANE32>); set_lds((const void*)stream_kernel<FMA_SALU>);
-    set_lds((const void*)stream_kernel<FMA_EXP_7_1>);
+    set_lds((const void*)stream_kernel<FMA_EXP_7_1>); set_lds((const void*)stream_kernel<WAVE_SHR_MOV>); set_lds((const void*)stream_kernel<ROW_SHR_MOV>);
     set_lds((const void*)pk_kernel); set_lds((const void*)body_kernel<false>); set_lds((const void*)body_kernel<true>);
 
     printf("%-62s %3s %12s %12s %10s %10s %9s\n", "instruction stream", "W", "cyc/VALU/SIMD", "(max wave)", "GHz", "wall us", "T lane-op/s");
-    for (int kind = 0; kind < KIND_COUNT; ++kind) {
+    const int first_kind = getenv("VALU_FIRST_KIND") ? atoi(getenv("VALU_FIRST_KIND")) : 0;      // e.g. 13: only the streams added last
+    for (int kind = first_kind; kind < KIND_COUNT; ++kind) {
         for (int W : {1, 2, 3, 4, 5, 6, 8}) {
             const size_t lds = (size_t)(LDS_TOTAL / W) & ~(size_t)1023;        // W workgroups fill the CU's LDS: at most W resident per CU
             if (W == 8 && lds * 9 <= (size_t)LDS_TOTAL) continue;
@@ -216,6 +228,7 @@ int main(int argc, char** argv) {
 #define LAUNCH_STREAM(K) case K: hipLaunchKernelGGL(stream_kernel<K>, dim3(grid), dim3(256), lds, st, d_out, d_sink, iters, 1.0f + rep); break;
                     LAUNCH_STREAM(FMA_IND) LAUNCH_STREAM(FMA_DEP) LAUNCH_STREAM(MULADD_IND) LAUNCH_STREAM(CMP_CNDMASK) LAUNCH_STREAM(EXP_IND)
                     LAUNCH_STREAM(RCP_IND) LAUNCH_STREAM(DPP_ADD) LAUNCH_STREAM(PERMLANE32) LAUNCH_STREAM(FMA_SALU) LAUNCH_STREAM(FMA_EXP_7_1)
+                    LAUNCH_STREAM(WAVE_SHR_MOV) LAUNCH_STREAM(ROW_SHR_MOV)
                     case PK_FMA_IND: hipLaunchKernelGGL(pk_kernel, dim3(grid), dim3(256), lds, st, d_out, d_sink, iters, 1.0f + rep); break;
                     case BODY_LDS: hipLaunchKernelGGL(body_kernel<false>, dim3(grid), dim3(256), lds, st, d_out, d_sink, iters, 0.25f * rep, d_recs); break;
                     case BODY_SGPR: hipLaunchKernelGGL(body_kernel<true>, dim3(grid), dim3(256), lds, st, d_out, d_sink, iters, 0.25f * rep, d_recs); break;
