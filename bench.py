@@ -198,6 +198,14 @@ def _run(a):
         R = int(v0["R"])
         row_cost = row_costs_from_ranges(v0["ranges"].long(), gx, gy, banded=False)   # full frame on every rank
         del v0
+        # the instances the REFERENCE would bin (tile square of radius 3 sqrt(lambda_max)); the product bins the snug rectangle of
+        # the alpha >= 1/255 ellipse -- same outputs bit for bit (tests/test_gpu_parity.py::test_snug_tiles_change_no_bit)
+        snug_opt = int(dict(o.split("=") for o in a.opt).get("snug_tiles", 1))      # (an A/B run may have switched it off)
+        _lib.set_option("snug_tiles", 0)
+        try:
+            R_reference = int(forward_with_views(rs, sc.means3D, sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)["R"])
+        finally:
+            _lib.set_option("snug_tiles", snug_opt)
     plan = BandPlan.uniform(gy, world) if (a.uniform_bands or world == 1) else BandPlan.balanced(row_cost, world)
     band = None if world == 1 else plan.band(rank)
 
@@ -814,7 +822,7 @@ def _run(a):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "parity": "oracle-only (the reference rasterizer is an un-vendored submodule)",
             "config": {"workload": "configs[1] stand-in: 1M random Gaussians (SURVEY 8(d) generator, seed %d, s_med %.4g), "
                                    "%dx%d forward render, SH degree 3" % (a.seed, a.s_med, W, H),
-                       "P": P, "visible": V, "num_rendered": R, "tiles": gx * gy,
+                       "P": P, "visible": V, "num_rendered": R, "num_rendered_reference_tile_squares": R_reference, "tiles": gx * gy,
                        "parallelism": ("one GPU" if world == 1 else
                                        ("mode C x%d: Gaussians sharded (P/N per rank) + tile-row bands%s; 48-byte packed splat records sent only to "
                                         "the bands they touch (all_to_all_single), strips all-gathered; frames pipelined two deep" if mode == "C" else

@@ -35,6 +35,7 @@ int fail(int code, const std::string& msg) {
 int g_render_fwd_variant = 0;
 int g_render_bwd_variant = 0;
 int g_depth_sort_mode = 0;      // 0 = hist / scan / scatter per pass, 1 = one kernel per pass ("onesweep", sort.hip)
+int g_snug_tiles = 1;           // 1 = bin every Gaussian into its snug tile rectangle (gsr_math.h); 0 = the reference's square (A/B)
 int g_bwd_heavy_first = 1;      // 1 = the blend backward starts its heaviest tiles first (plan kernel, render_bwd.hip); 0 = index order (A/B)
 int g_tile_sort_mode = 0;       // 0 = fused emission + two-level sort (tilesort.hip), 1 = legacy emit + LSD passes (A/B)
 int g_first_hist = 0;           // 1 = the preprocess kernel also produces the histogram of the depth sort's first pass (large P).
@@ -107,6 +108,7 @@ int make_cam(const GsrRasterSettings* s, int M, GsrCamDev& c) {
     c.sh_degree = s->sh_degree;
     c.M = M;
     c.antialiasing = s->antialiasing ? 1 : 0;
+    c.snug = g_snug_tiles;
     int y0 = s->tile_y0, y1 = s->tile_y1;
     if (y1 <= 0) { y0 = 0; y1 = c.gy; }
     if (y0 < 0) y0 = 0;
@@ -363,6 +365,11 @@ int gsr_set_option(const char* name, int value) {
         return GSR_OK;
     }
     if (!strcmp(name, "ssim_target_waves")) { gsr_set_ssim_target_waves(value); return GSR_OK; }
+    if (!strcmp(name, "snug_tiles")) {
+        if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "snug_tiles must be 1 (snug tile rectangles) or 0 (the reference's tile square)");
+        g_snug_tiles = value;
+        return GSR_OK;
+    }
     if (!strcmp(name, "bwd_heavy_first")) {
         if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "bwd_heavy_first must be 0 (tiles in index order) or 1 (heaviest tiles first)");
         g_bwd_heavy_first = value;

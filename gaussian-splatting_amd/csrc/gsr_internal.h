@@ -11,6 +11,7 @@ struct GsrCamDev {
     int W, H, gx, gy;
     float focal_x, focal_y, limx, limy, scale_modifier;
     int sh_degree, M, antialiasing, tile_y0, tile_y1;
+    int snug;                // gsr_math.h GsrCam::snug
     const float* view;
     const float* proj;
     const float* campos;
@@ -78,9 +79,7 @@ __device__ __forceinline__ void gsr_report_key_overflow(bool overflow, uint32_t*
     if (overflow && key_overflow) __hip_atomic_store(key_overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // the two derived fields of a splat record, written by the preprocess and recomputed bit-identically from (opacity, depth) by the
-// receiver of a packed record (route.hip): explicit single roundings, independent of the translation unit's -ffp-contract
-// tau = 2 ln(255 opacity) + slack: a splat reaches alpha >= 1/255 only where its quadratic form is <= tau (box cull of the blend)
-__device__ __forceinline__ float gsr_tau(float opacity) { return __fadd_rn(__fmul_rn(2.0f, logf(__fmul_rn(255.0f, opacity))), 0.01f); }
+// receiver of a packed record (route.hip): tau = gsr_tau(opacity) (gsr_math.h) and 1 / depth, an explicit single rounding
 __device__ __forceinline__ float gsr_inv_depth(float depth) { return __fdiv_rn(1.0f, depth); }
 #endif
 

@@ -52,16 +52,71 @@ struct GsrCam {
     float scale_modifier;
     int sh_degree, M;
     int antialiasing;
+    int snug;                 // 1 = snug tile rectangle (default), 0 = the reference's square (A/B: same outputs, longer lists)
     int tile_y0, tile_y1;     // band of tile rows that is binned
     float view[16];           // flat, as passed (transposed math matrix)
     float proj[16];
     float campos[3];
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// tau = 2 ln(255 opacity) + 0.01: a splat reaches alpha >= 1/255 only where its quadratic form q = d^T conic d is <= tau
+// (alpha = opacity exp(-q/2); the 0.01 is slack for the blend's own rounding).  Two consumers: the blend kernels' box test
+// (the value travels in the splat record) and the SNUG tile rectangle below.  The second one DECIDES INTEGERS (tiles_touched,
+// the instance lists), so tau must come out bit-identical on the GPU, in the host build of this header and in the oracle's
+// restatement (oracle/torch_oracle.py: det_log / tau_of_opacity): no libm -- `logf` differs by an ulp between implementations --
+// but frexp (exact) + the atanh series in fp64, one IEEE rounding per written operation, contraction switched off locally so
+// that translation units built with -ffp-contract=fast (route.hip) get the same bits.
+// ---------------------------------------------------------------------------------------------------------------------
+GSR_HD double gsr_log_det(double v) {            // ln(v), v finite and > 0
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    // v = m 2^e, m in [0.5, 1): frexp spelled out on the bits of a positive normal double (the library call takes a pointer, an
+    // opaque access the scheduler will not move loads across)
+    uint64_t bits;
+    __builtin_memcpy(&bits, &v, 8);
+    const int e0 = (int)((bits >> 52) & 0x7ffu) - 1022;
+    const uint64_t mbits = (bits & 0x800FFFFFFFFFFFFFull) | 0x3FE0000000000000ull;
+    double m0;
+    __builtin_memcpy(&m0, &mbits, 8);
+    const bool low = m0 < 0.70710678118654752;   // (selects, not branches: see gsr_project's snug block)
+    const double m = low ? m0 * 2.0 : m0;
+    const int e = low ? e0 - 1 : e0;
+    const double s = (m - 1.0) / (m + 1.0);      // |s| <= 0.1716; ln m = 2 atanh s
+    const double s2 = s * s;
+    double p = 1.0 / 19.0;
+    p = p * s2 + 1.0 / 17.0;
+    p = p * s2 + 1.0 / 15.0;
+    p = p * s2 + 1.0 / 13.0;
+    p = p * s2 + 1.0 / 11.0;
+    p = p * s2 + 1.0 / 9.0;
+    p = p * s2 + 1.0 / 7.0;
+    p = p * s2 + 1.0 / 5.0;
+    p = p * s2 + 1.0 / 3.0;
+    p = p * s2 + 1.0;
+    const double t1 = (double)e * 0.6931471805599453;
+    const double t3 = (2.0 * s) * p;
+    return t1 + t3;
+}
+
+GSR_HD float gsr_tau(float opacity) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const float vf = 255.0f * opacity;
+    const bool ok = vf > 0.0f && vf < 3.0e38f;
+    const double t = 2.0 * gsr_log_det(ok ? (double)vf : 1.0) + 0.01;
+    // as logf outside the domain: ln 0 = -inf (culled everywhere), ln(+inf) = +inf, ln(negative / NaN) = NaN
+    const float bad = vf == 0.0f ? -INFINITY : (vf >= 3.0e38f ? INFINITY : NAN);
+    return ok ? (float)t : bad;
+}
+
 struct GsrSplat {             // result of the forward preprocess for one Gaussian
     float px, py;             // pixel-space centre
     float conA, conB, conC;   // inverse 2-D covariance
     float opacity;            // opacity * aa
+    float tau;                // gsr_tau(opacity)
     float r, g, b;
     float depth;              // view-space z
     int radius;               // 0 = not visible
@@ -166,14 +221,51 @@ GSR_HD bool gsr_project(const GsrCam& cam, const float* mean, const float* cov, 
     if ((maxx - minx) * (maxy - miny) <= 0) return false;
     if (!(radius_f < 2.0e9f)) return false;   // inf / NaN radius: treated as culled (oracle: radii = 0)
     out.radius = (int)radius_f;
-    const int bminy = miny < cam.tile_y0 ? cam.tile_y0 : (miny > cam.tile_y1 ? cam.tile_y1 : miny);
-    const int bmaxy = maxy < cam.tile_y0 ? cam.tile_y0 : (maxy > cam.tile_y1 ? cam.tile_y1 : maxy);
-    out.minx = (uint32_t)minx;
-    out.maxx = (uint32_t)maxx;
+    out.opacity = opacity_in * aa;
+    out.tau = gsr_tau(out.opacity);
+    // SNUG tile rectangle (NOT in the reference, which bins the square of radius 3 sqrt(lambda_max) whatever the shape and the
+    // opacity): only tiles that the ellipse q <= tau can reach hold a pixel with alpha >= 1/255; every other (tile, Gaussian)
+    // instance is skipped pixel by pixel in the reference's blend (forward.cu renderCUDA: `if (alpha < 1/255) continue`) and
+    // contributes nothing, so dropping it leaves every output bit unchanged and removes 33 % (uniform scene) to 49 %
+    // (clustered) of the instances from emission, tile sort and blend.  Half extents of the ellipse of the ROUNDED conic the
+    // blend evaluates: ex^2 = tau C / (A C - B^2), ey^2 = tau A / (A C - B^2) -- in fp64 from the fp32 values (the products are
+    // exact, so cancellation in A C - B^2 costs nothing), inflated by 1 % + half a pixel against the blend's fp32 rounding of q.
+    // `radius` (the operator's `radii` output) stays the reference's.
+    int sminx = minx, smaxx = maxx, sminy = miny, smaxy = maxy;
+    {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+        // (written with selects, not branches: control flow in here made hipcc serialise the split-SH loader of the forward
+        //  kernel into a 14-long load -> wait chain, tools/isa_audit.py)
+        const double td = (double)out.tau;
+        const double Ad = (double)out.conA, Bd = (double)out.conB, Cd = (double)out.conC;
+        const double detc = Ad * Cd - Bd * Bd;
+        const bool on = cam.snug != 0;
+        const bool dead = on && td <= 0.0;        // opacity <= 1/255 (incl. tau = -inf): alpha < 1/255 everywhere
+        bool shrink = on && !dead && detc > 0.0 && td < 1.0e30;      // (NaN / +inf anywhere: keep the reference rectangle)
+        const double sdet = shrink ? detc : 1.0, st = shrink ? td : 1.0;
+        const double ex = sqrt(st * Cd / sdet) * 1.01 + 0.5;
+        const double ey = sqrt(st * Ad / sdet) * 1.01 + 0.5;
+        shrink = shrink && ex < 1.0e9 && ey < 1.0e9;
+        const double cx = (double)pixx, cy = (double)pixy;
+        const double big = 1.0e9;
+        const double lx = fmin(fmax(floor((cx - ex) / 16.0), -big), big), hx = fmin(fmax(floor((cx + ex) / 16.0) + 1.0, -big), big);
+        const double ly = fmin(fmax(floor((cy - ey) / 16.0), -big), big), hy = fmin(fmax(floor((cy + ey) / 16.0) + 1.0, -big), big);
+        sminx = (shrink && lx > (double)minx) ? (lx < (double)maxx ? (int)lx : maxx) : minx;
+        smaxx = (shrink && hx < (double)maxx) ? (hx > (double)sminx ? (int)hx : sminx) : maxx;
+        sminy = (shrink && ly > (double)miny) ? (ly < (double)maxy ? (int)ly : maxy) : miny;
+        smaxy = (shrink && hy < (double)maxy) ? (hy > (double)sminy ? (int)hy : sminy) : maxy;
+        smaxx = dead ? sminx : smaxx;
+        smaxy = dead ? sminy : smaxy;
+    }
+    const int bminy = sminy < cam.tile_y0 ? cam.tile_y0 : (sminy > cam.tile_y1 ? cam.tile_y1 : sminy);
+    const int bmaxy = smaxy < cam.tile_y0 ? cam.tile_y0 : (smaxy > cam.tile_y1 ? cam.tile_y1 : smaxy);
+    out.minx = (uint32_t)sminx;
+    out.maxx = (uint32_t)smaxx;
     out.miny = (uint32_t)bminy;
     out.maxy = (uint32_t)bmaxy;
-    out.tiles = (uint32_t)((maxx - minx) * (bmaxy - bminy));
-    out.opacity = opacity_in * aa;
+    out.tiles = (uint32_t)((smaxx - sminx) * (bmaxy - bminy));
     return true;
 }
 

@@ -31,11 +31,27 @@ __device__ __forceinline__ void load_cam(const GsrCamDev& c, GsrCam& cam) {
     cam.W = c.W; cam.H = c.H; cam.gx = c.gx; cam.gy = c.gy;
     cam.focal_x = c.focal_x; cam.focal_y = c.focal_y; cam.limx = c.limx; cam.limy = c.limy;
     cam.scale_modifier = c.scale_modifier; cam.sh_degree = c.sh_degree; cam.M = c.M;
-    cam.antialiasing = c.antialiasing; cam.tile_y0 = c.tile_y0; cam.tile_y1 = c.tile_y1;
+    cam.antialiasing = c.antialiasing; cam.tile_y0 = c.tile_y0; cam.tile_y1 = c.tile_y1; cam.snug = c.snug;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { cam.view[i] = c.view[i]; cam.proj[i] = c.proj[i]; }
 #pragma unroll
     for (int i = 0; i < 3; ++i) cam.campos[i] = c.campos[i];
+}
+
+// "All twelve loads are issued before the first LDS write."  A scheduling barrier alone does not guarantee that: it is not a
+// memory operation, so the IR optimiser may sink every load across it, next to its LDS write -- which it did in the split-SH
+// forward the moment the surrounding kernel changed (13 x load -> s_waitcnt vmcnt(0) -> ds_write_b128, tools/isa_audit.py).
+// One empty asm statement that names ALL the loaded registers as operands can only be placed after the last load was issued.
+typedef float gsr_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fence_loaded12(float4 (&v)[12]) {
+    gsr_v4f r[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) r[k] = (gsr_v4f){v[k].x, v[k].y, v[k].z, v[k].w};
+    asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]),
+                      "+v"(r[9]), "+v"(r[10]), "+v"(r[11]));
+#pragma unroll
+    for (int k = 0; k < 12; ++k) v[k] = make_float4(r[k].x, r[k].y, r[k].z, r[k].w);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // Cooperative, coalesced copy of the SH rows of the wave's 64 Gaussians [i0, i0+64) from global memory into the wave's
@@ -53,7 +69,7 @@ __device__ __forceinline__ void wave_load_sh16(const float* __restrict__ shs, in
         const int g = idx / 12;
         v[it] = src[(((rows >> g) & 1ull) && i0 + g < P) ? idx : 0];      // (piece 0 is always valid)
     }
-    __builtin_amdgcn_sched_barrier(0);      // keep the loads together: the scheduler otherwise sinks each one to its LDS write
+    fence_loaded12(v);      // keep the loads together: the scheduler otherwise sinks each one to its LDS write
     // ... and unconditional LDS writes (a conditional write makes the compiler sink the load into the branch, which brings
     // the serial round trips back); rows that were not fetched receive piece 0 and are never read
 #pragma unroll
@@ -156,7 +172,7 @@ __device__ __forceinline__ void wave_load_sh_split_dense(const float* __restrict
     const int fd = lane * 4;
     const bool okd = rows != 0ull && fd + 3 < ndc;
     const float4 vd = *reinterpret_cast<const float4*>(sdc + (okd ? fd : 0));
-    __builtin_amdgcn_sched_barrier(0);      // keep the loads together: the scheduler otherwise sinks each one to its LDS write
+    fence_loaded12(v);      // keep the loads together: the scheduler otherwise sinks each one to its LDS write
     // ... and unconditional LDS writes (a conditional write makes the compiler sink the load into the branch, which brings
     // the serial round trips back): pieces that were not fetched land in rows nobody reads, or -- past the end of the two
     // blocks -- in the 256 spare floats at the end of the tile
@@ -332,7 +348,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             q1 = make_float4(sp.conC, sp.opacity, rgb[0], rgb[1]);
             // tau = 2 ln(255 opacity) + slack: a splat reaches alpha >= 1/255 only where its quadratic form is <= tau
             // (box-cull threshold of the blend kernels); 1/depth feeds the inverse-depth image.
-            q2 = make_float4(rgb[2], sp.depth, gsr_tau(sp.opacity), gsr_inv_depth(sp.depth));
+            q2 = make_float4(rgb[2], sp.depth, sp.tau, gsr_inv_depth(sp.depth));
         }
         const uint2 rc = make_uint2(sp.minx | (sp.maxx << 16), sp.miny | (sp.maxy << 16));
         splats[i * 4 + 0] = q0;
@@ -404,7 +420,7 @@ preprocess_geom_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D,
             }
             q0 = make_float4(sp.px, sp.py, sp.conA, sp.conB);
             q1 = make_float4(sp.conC, sp.opacity, rgb[0], rgb[1]);
-            q2 = make_float4(rgb[2], sp.depth, gsr_tau(sp.opacity), gsr_inv_depth(sp.depth));
+            q2 = make_float4(rgb[2], sp.depth, sp.tau, gsr_inv_depth(sp.depth));
         }
         const uint2 rc = make_uint2(sp.minx | (sp.maxx << 16), sp.miny | (sp.maxy << 16));
         splats[i * 4 + 0] = q0;

@@ -14,6 +14,14 @@ branch dr_aa) and is frozen here as this repo's specification.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 
+SNUG TILE RECTANGLES (`SNUG_TILES`, `preprocess(..., snug=)`): the reference bins every Gaussian into the tiles of the square
+of radius 3 sqrt(lambda_max) around its centre.  The product bins it only into the tiles the ellipse q <= 2 ln(255 opacity)
++ 0.01 can reach -- everywhere else alpha < 1/255 and the reference's blend skips the pair -- which changes tiles_touched, the
+instance lists and the contributor positions, and NO output (tests/test_oracle.py::test_snug_tiles_change_no_output renders both
+ways and compares the bits).  The default here is the reference's square (`SNUG_TILES = False`); the parity tests of the product
+switch it on, and the restatement below follows csrc/gsr_math.h operation by operation (fp64, frexp + atanh series for the
+logarithm: no libm call whose last bit differs between implementations).
+
 Arithmetic contract (what "bit-exact bin counts" means): every quantity that decides an integer
 output (radii, tile rectangle, tiles_touched, sort keys) is computed in fp32 by the EXACT expression
 trees below -- one IEEE-754 rounding per written operation, left-to-right, no fused multiply-add --
@@ -43,6 +51,36 @@ SH_C1 = 0.4886025119029199
 SH_C2 = [1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396]
 SH_C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154,
          -0.4570457994644658, 1.445305721320277, -0.5900435899266435]
+
+
+SNUG_TILES = False      # module default of preprocess(snug=None): False = the reference's tile square, True = the product's snug rectangle
+
+
+def det_log(v: torch.Tensor) -> torch.Tensor:
+    """ln(v) for finite v > 0 (float64) from IEEE basic operations only -- csrc/gsr_math.h gsr_log_det, operation by operation."""
+    m, e = torch.frexp(v)
+    low = m < 0.70710678118654752
+    m = torch.where(low, m * 2.0, m)
+    e = torch.where(low, e - 1, e)
+    sv = (m - 1.0) / (m + 1.0)
+    s2 = sv * sv
+    p = torch.full_like(v, 1.0 / 19.0)
+    for k in (17.0, 15.0, 13.0, 11.0, 9.0, 7.0, 5.0, 3.0):
+        p = p * s2 + 1.0 / k
+    p = p * s2 + 1.0
+    t1 = e.to(torch.float64) * 0.6931471805599453
+    t3 = (2.0 * sv) * p
+    return t1 + t3
+
+
+def tau_of_opacity(opacity: torch.Tensor) -> torch.Tensor:
+    """tau = 2 ln(255 opacity) + 0.01 as float32 (csrc/gsr_math.h gsr_tau): a splat reaches alpha >= 1/255 only where q <= tau."""
+    vf = torch.tensor(255.0, dtype=torch.float32) * opacity.to(torch.float32)
+    ok = (vf > 0) & (vf < 3.0e38)
+    t = (2.0 * det_log(torch.where(ok, vf, torch.ones_like(vf)).to(torch.float64)) + 0.01).to(torch.float32)
+    t = torch.where(ok, t, torch.where(vf == 0, torch.full_like(t, -math.inf),
+                                       torch.where(vf >= 3.0e38, torch.full_like(t, math.inf), torch.full_like(t, math.nan))))
+    return t
 
 
 class Settings(NamedTuple):
@@ -167,7 +205,7 @@ def eval_sh_colors(deg, shs, means3D, campos, dtype):
 
 
 def preprocess(means3D, opacities, s: Settings, shs=None, colors_precomp=None, scales=None, rotations=None,
-               cov3D_precomp=None, means2D=None, tile_y0: int = 0, tile_y1: Optional[int] = None):
+               cov3D_precomp=None, means2D=None, tile_y0: int = 0, tile_y1: Optional[int] = None, snug: Optional[bool] = None):
     """SURVEY Appendix A.2.  All tensors on CPU, dtype = means3D.dtype (fp32 for parity, fp64 for
     finite-difference references).  tile_y0/tile_y1 restrict binning to a band of tile rows
     (multi-GPU screen sharding); radii are NOT affected by the band."""
@@ -291,6 +329,37 @@ def preprocess(means3D, opacities, s: Settings, shs=None, colors_precomp=None, s
         visible = in_front & det_ok & (area_full > 0) & (radius_f < 2.0e9)
         radii = torch.where(visible, torch.nan_to_num(radius_f, nan=0.0, posinf=0.0).to(torch.int64),
                             torch.zeros_like(area_full)).to(torch.int32)
+        if SNUG_TILES if snug is None else snug:
+            # the product's snug rectangle (csrc/gsr_math.h gsr_project, same operations in the same order, fp64 from the fp32
+            # conic / centre / opacity); `radii` keeps the reference's value
+            td = tau_of_opacity((opacities.reshape(P) * aa).detach()).to(torch.float64)
+            Ad, Bd, Cd = conA.detach().to(torch.float64), conB.detach().to(torch.float64), conC.detach().to(torch.float64)
+            detc = Ad * Cd - Bd * Bd
+            dead = td <= 0.0
+            shrink = (~dead) & (detc > 0.0) & (td < 1.0e30)
+            safe = torch.where(shrink, detc, torch.ones_like(detc))
+            tds = torch.where(shrink, td, torch.ones_like(td))
+            sqrt64 = lambda t: torch.from_numpy(np.sqrt(t.numpy()))      # (torch.sqrt is not correctly rounded on CPU, see _sqrt)
+            ex = sqrt64(tds * Cd / safe) * 1.01 + 0.5
+            ey = sqrt64(tds * Ad / safe) * 1.01 + 0.5
+            shrink = shrink & (ex < 1.0e9) & (ey < 1.0e9)
+            cxd, cyd = pixx.detach().to(torch.float64), pixy.detach().to(torch.float64)
+
+            def snug_axis(cd, e, lo, hi):
+                lo_d, hi_d = lo.to(torch.float64), hi.to(torch.float64)
+                l = torch.floor((cd - e) / 16.0)
+                h = torch.floor((cd + e) / 16.0) + 1.0
+                l = torch.nan_to_num(l, nan=0.0, posinf=0.0, neginf=0.0)
+                h = torch.nan_to_num(h, nan=0.0, posinf=0.0, neginf=0.0)
+                lo2 = torch.where(shrink & (l > lo_d), torch.where(l < hi_d, l, hi_d), lo_d)
+                hi2 = torch.where(shrink & (h < hi_d), torch.where(h > lo2, h, lo2), hi_d)
+                return lo2.to(torch.int64), hi2.to(torch.int64)
+
+            sminx, smaxx = snug_axis(cxd, ex, rminx, rmaxx)
+            sminy, smaxy = snug_axis(cyd, ey, rminy, rmaxy)
+            smaxx = torch.where(dead, sminx, smaxx)
+            smaxy = torch.where(dead, sminy, smaxy)
+            rminx, rmaxx, rminy, rmaxy = sminx, smaxx, sminy, smaxy
         # band restriction (multi-GPU): only the rows [tile_y0, tile_y1) are binned
         bminy = torch.clamp(rminy, tile_y0, tile_y1)
         bmaxy = torch.clamp(rmaxy, tile_y0, tile_y1)

@@ -16,6 +16,21 @@ for p in (ROOT, PKG):
 from gsr_synth import make_camera, look_at_camera, make_scene, make_edge_scene, make_clustered_scene  # noqa: E402
 from oracle import torch_oracle as O  # noqa: E402
 
+# The product bins every Gaussian into its SNUG tile rectangle (csrc/gsr_math.h); the oracle's default is the reference's square.
+# Every test that compares the product's integers (tiles_touched, lists, ranges, contributor positions) with the oracle's goes
+# through this module and gets the snug restatement; tests/test_oracle.py checks that the switch changes no output.
+O.SNUG_TILES = True
+
+
+class reference_tiles:
+    """`with reference_tiles():` -- the oracle bins the reference's tile square (frozen reference-side vectors)."""
+
+    def __enter__(self):
+        self.prev, O.SNUG_TILES = O.SNUG_TILES, False
+
+    def __exit__(self, *exc):
+        O.SNUG_TILES = self.prev
+
 
 def oracle_settings(cam, bg=None, sh_degree=3, scale_modifier=1.0, antialiasing=False):
     bg = torch.zeros(3) if bg is None else bg

@@ -140,8 +140,12 @@ def test_config1_1M_1080p_forward_both_builds():
     """BASELINE configs[1] stand-in, exactly as bench.py builds it (P = 1e6, 1920x1080, seed 0, s_med 0.012)."""
     _forward_case(1_000_000, 1920, 1080, 240, "configs[1] 1M@1080p")
     cam, sc, s, pre, bins, _ = _config(1_000_000, 1920, 1080)
-    # SURVEY 8(d) probe numbers of this generator (they identify the frame the bench line is quoted on)
-    assert int((pre["radii"] > 0).sum()) == 876281 and bins["R"] == 11330172
+    # SURVEY 8(d) probe numbers of this generator (they identify the frame the bench line is quoted on): 11 330 172 instances in
+    # the reference's tile squares, 7 916 318 of them in the snug rectangles the product bins
+    assert int((pre["radii"] > 0).sum()) == 876281 and bins["R"] == 7916318
+    with torch.no_grad():
+        ref = O.preprocess(sc.means3D, sc.opacities, s, shs=sc.shs, scales=sc.scales, rotations=sc.rotations, snug=False)
+    assert int(ref["tiles_touched"].sum()) == 11330172 and torch.equal(ref["radii"], pre["radii"])
 
 
 def _backward_case(P, W, H, n_tiles, name, kind="uniform"):

@@ -342,6 +342,41 @@ def test_backward_is_bit_reproducible_and_variants_agree():
             assert (x - z).abs().max().item() <= tol * z.abs().max().item()
 
 
+@pytest.mark.parametrize("scene", ["uniform", "edge_aa"])
+def test_snug_tiles_change_no_bit(scene):
+    """The product bins a Gaussian only into the tiles its alpha >= 1/255 ellipse reaches (csrc/gsr_math.h, `snug_tiles` = 1, the
+    default); with `snug_tiles` = 0 it bins the reference's tile square.  Every instance the snug rectangle drops is skipped pixel
+    by pixel by the blend, the blend adds a pixel's terms one entry at a time and the backward adds a Gaussian's records in a fixed
+    order, so BOTH WAYS GIVE THE SAME BITS -- image, inverse depth, radii and every gradient -- from lists a third shorter."""
+    from diff_gaussian_rasterization import GaussianRasterizer, _lib
+    dev = torch.device("cuda:0")
+    cam = make_camera(640, 360)
+    aa = scene == "edge_aa"
+    sc = (make_edge_scene(20000, cam, seed=11) if aa else make_scene(60000, cam, seed=17, s_med=0.02)).to(dev)
+    s = oracle_settings(cam, antialiasing=aa, bg=torch.tensor([0.1, 0.2, 0.3]))
+    wc = torch.randn(3, 360, 640, generator=torch.Generator().manual_seed(0)).to(dev)
+
+    def run(snug):
+        _lib.set_option("snug_tiles", snug)
+        try:
+            L = [t.detach().clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+            m2 = torch.zeros(sc.P, 3, device=dev, requires_grad=True)
+            col, radii, invd = GaussianRasterizer(gpu_settings(s, dev))(means3D=L[0], means2D=m2, opacities=L[2], shs=L[1],
+                                                                        scales=L[3], rotations=L[4])
+            ((col * wc).sum() + invd.sum()).backward()
+            torch.cuda.synchronize()
+            R = run_gpu(s, sc.cpu())["R"]
+        finally:
+            _lib.set_option("snug_tiles", 1)
+        return [col.detach(), radii, invd.detach()] + [t.grad for t in L] + [m2.grad], R
+
+    a, Ra = run(1)
+    b, Rb = run(0)
+    assert Ra < 0.85 * Rb, (Ra, Rb)
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y), f"output {k} changed with the tile rectangle ({(x.float() - y.float()).abs().max().item():.3e})"
+
+
 def test_backward_parity_edge_aa():
     _backward_case("edge_aa_scale", 1500, seed=3)
 

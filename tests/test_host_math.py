@@ -56,6 +56,10 @@ def test_forward_matches_oracle_bitwise(name, mkcam, mkscene, aa):
     np.testing.assert_array_equal(out_f[vis][:, 2:5], pre["conic"].numpy()[vis])
     np.testing.assert_array_equal(out_f[vis][:, 5], pre["opacity"].numpy()[vis])
     np.testing.assert_array_equal(out_f[vis][:, 9], pre["depths"].numpy()[vis])
+    # tau = 2 ln(255 opacity) + 0.01 decides the snug tile rectangle: its logarithm is a fixed sequence of IEEE operations
+    np.testing.assert_array_equal(out_f[vis][:, 10], O.tau_of_opacity(pre["opacity"]).numpy()[vis])
+    assert int(pre["tiles_touched"].sum()) < int(O.preprocess(sc.means3D, sc.opacities, s, shs=sc.shs, scales=sc.scales,
+                                                                rotations=sc.rotations, snug=False)["tiles_touched"].sum())
     # SH colours go through one more op chain; x86 and torch evaluate them identically as well
     np.testing.assert_allclose(out_f[vis][:, 6:9], pre["rgb"].numpy()[vis], rtol=0, atol=1e-6)
     cl = pre["clamped"].numpy()

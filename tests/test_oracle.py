@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import O, make_camera, look_at_camera, make_scene, make_edge_scene, oracle_settings
+from helpers import O, make_camera, look_at_camera, make_scene, make_edge_scene, oracle_settings, reference_tiles
 from gsr_synth import Camera
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -195,6 +195,57 @@ def test_tie_order_follows_gaussian_index():
             assert pl[a:b].tolist() == sorted(pl[a:b].tolist())
 
 
+# ----------------------------------------------------------------------------- snug tile rectangles
+@pytest.mark.parametrize("maker,aa,size", [(lambda c: make_scene(3000, c, seed=2, s_med=0.03), False, (250, 131)),
+                                           (lambda c: make_edge_scene(3000, c, seed=8), True, (250, 131)),
+                                           (lambda c: make_edge_scene(2000, c, seed=21), False, (333, 200)),
+                                           (lambda c: make_scene(4000, c, seed=5, s_med=0.006), True, (640, 360))])
+def test_snug_tiles_change_no_output(maker, aa, size):
+    """The product bins a Gaussian only into the tiles its alpha >= 1/255 ellipse can reach (csrc/gsr_math.h, restated in
+    O.preprocess(snug=True)); the reference bins the square of radius 3 sqrt(lambda_max).  Every instance the snug rectangle
+    drops is one the reference's blend skips pixel by pixel, so colour, inverse depth, final transmittance and radii are the SAME
+    BITS either way; only the lists get shorter (and the contributor positions move with them)."""
+    cam = look_at_camera(size[0], size[1], (0.2, 0.1, -0.6), (0.0, 0.0, 4.0))
+    sc = maker(cam)
+    s = oracle_settings(cam, antialiasing=aa, bg=torch.tensor([0.2, 0.3, 0.4]))
+    kw = dict(shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+    outs = {}
+    for snug in (False, True):
+        with torch.no_grad():
+            pre = O.preprocess(sc.means3D, sc.opacities, s, snug=snug, **kw)
+            bins = O.bin_and_sort(pre)
+            col, invd, fT, ncon, _ = O.render_tiles(pre, bins, s, False)
+        outs[snug] = (pre, bins, col, invd, fT, ncon)
+    (pre0, bins0, col0, invd0, fT0, n0), (pre1, bins1, col1, invd1, fT1, n1) = outs[False], outs[True]
+    # (the oracle adds a pixel's terms with a vectorised sum whose pairing depends on the list length: a few ulp; the product adds
+    #  them one entry at a time, and tests/test_gpu_parity.py::test_snug_tiles_change_no_bit compares ITS two ways bit for bit)
+    assert torch.equal(fT0, fT1)
+    assert (col0 - col1).abs().max().item() <= 1e-6 and (invd0 - invd1).abs().max().item() <= 1e-6 * max(1.0, float(invd0.max()))
+    assert torch.equal(pre0["radii"], pre1["radii"])
+    R0, R1 = int(bins0["R"]), int(bins1["R"])
+    assert R1 < 0.9 * R0, (R0, R1)
+    # the snug rectangle lies inside the reference's, and the snug list of every tile is a subsequence of the reference's
+    r0, r1 = pre0["rect"], pre1["rect"]
+    listed = pre1["tiles_touched"] > 0
+    assert (r1[listed, 0] >= r0[listed, 0]).all() and (r1[listed, 2] <= r0[listed, 2]).all()
+    assert (r1[listed, 1] >= r0[listed, 1]).all() and (r1[listed, 3] <= r0[listed, 3]).all()
+    for t in range(0, bins0["ranges"].shape[0], 7):
+        a = bins0["point_list"][bins0["ranges"][t, 0]:bins0["ranges"][t, 1]].tolist()
+        b = bins1["point_list"][bins1["ranges"][t, 0]:bins1["ranges"][t, 1]].tolist()
+        it = iter(a)
+        assert all(x in it for x in b), t
+    # the contributor count of a pixel never grows, and the last contributor is the same Gaussian
+    assert (n1 <= n0).all()
+    gx = pre0["grid"][0]
+    H, W = size[1], size[0]
+    tid = (torch.arange(H)[:, None] // 16) * gx + torch.arange(W)[None, :] // 16
+    has = n1 > 0
+    g0 = bins0["point_list"][(bins0["ranges"][tid, 0] + n0 - 1)[has]]
+    g1 = bins1["point_list"][(bins1["ranges"][tid, 0] + n1 - 1)[has]]
+    assert torch.equal(g0, g1)
+    assert torch.equal(n0 > 0, n1 > 0)
+
+
 # ----------------------------------------------------------------------------- invariants
 @pytest.mark.parametrize("maker,aa", [(lambda c: make_scene(1500, c, seed=2, s_med=0.03), False),
                                       (lambda c: make_edge_scene(1500, c, seed=8), True)])
@@ -217,7 +268,7 @@ def test_invariants(maker, aa):
     tid = (torch.arange(H)[:, None] // 16) * gx + torch.arange(W)[None, :] // 16
     assert (aux["n_contrib"] <= cnt[tid]).all()
     assert (aux["final_T"] >= 0).all() and (aux["final_T"] <= 1).all()
-    assert torch.equal(radii > 0, aux["tiles_touched"] > 0)
+    assert not ((aux["tiles_touched"] > 0) & ~(radii > 0)).any()      # (snug rectangles: a visible Gaussian may reach no tile)
     # permuting the Gaussians changes nothing except tie order among bit-identical depths
     dv = aux["depths"][radii > 0]
     if torch.unique(dv).numel() != dv.numel():
@@ -249,7 +300,7 @@ def test_frozen_c1_outputs():
     cam = make_camera(256, 256)
     sc = make_scene(1000, cam, seed=0)
     s = oracle_settings(cam)
-    with torch.no_grad():
+    with torch.no_grad(), reference_tiles():      # the frozen lists are the reference's (R = 1711 is SURVEY 8(d)'s probe value)
         col, radii, invd, aux = O.rasterize(sc.means3D, None, sc.opacities, s, shs=sc.shs, scales=sc.scales,
                                             rotations=sc.rotations, return_aux=True)
     assert aux["R"] == int(g["R"]) == 1711 and int((radii > 0).sum()) == 874     # SURVEY 8(d) probe values
