@@ -226,8 +226,8 @@ GSR_HD bool gsr_project(const GsrCam& cam, const float* mean, const float* cov, 
     // SNUG tile rectangle (NOT in the reference, which bins the square of radius 3 sqrt(lambda_max) whatever the shape and the
     // opacity): only tiles that the ellipse q <= tau can reach hold a pixel with alpha >= 1/255; every other (tile, Gaussian)
     // instance is skipped pixel by pixel in the reference's blend (forward.cu renderCUDA: `if (alpha < 1/255) continue`) and
-    // contributes nothing, so dropping it leaves every output bit unchanged and removes 33 % (uniform scene) to 49 %
-    // (clustered) of the instances from emission, tile sort and blend.  Half extents of the ellipse of the ROUNDED conic the
+    // contributes nothing, so dropping it leaves every bit of the forward outputs unchanged (the gradients: to fp32 summation
+    // order) and removes 30 % (uniform scene) to 49 % (clustered) of the instances from emission, tile sort and blend.  Half extents of the ellipse of the ROUNDED conic the
     // blend evaluates: ex^2 = tau C / (A C - B^2), ey^2 = tau A / (A C - B^2) -- in fp64 from the fp32 values (the products are
     // exact, so cancellation in A C - B^2 costs nothing), inflated by 1 % + half a pixel against the blend's fp32 rounding of q.
     // `radius` (the operator's `radii` output) stays the reference's.

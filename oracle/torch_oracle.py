@@ -18,7 +18,7 @@ SNUG TILE RECTANGLES (`SNUG_TILES`, `preprocess(..., snug=)`): the reference bin
 of radius 3 sqrt(lambda_max) around its centre.  The product bins it only into the tiles the ellipse q <= 2 ln(255 opacity)
 + 0.01 can reach -- everywhere else alpha < 1/255 and the reference's blend skips the pair -- which changes tiles_touched, the
 instance lists and the contributor positions, and NO output (tests/test_oracle.py::test_snug_tiles_change_no_output renders both
-ways and compares the bits).  The default here is the reference's square (`SNUG_TILES = False`); the parity tests of the product
+ways; tests/test_gpu_parity.py::test_snug_tiles_change_no_bit compares the product's two ways bit for bit).  The default here is the reference's square (`SNUG_TILES = False`); the parity tests of the product
 switch it on, and the restatement below follows csrc/gsr_math.h operation by operation (fp64, frexp + atanh series for the
 logarithm: no libm call whose last bit differs between implementations).
 

@@ -346,13 +346,16 @@ def test_backward_is_bit_reproducible_and_variants_agree():
 def test_snug_tiles_change_no_bit(scene):
     """The product bins a Gaussian only into the tiles its alpha >= 1/255 ellipse reaches (csrc/gsr_math.h, `snug_tiles` = 1, the
     default); with `snug_tiles` = 0 it bins the reference's tile square.  Every instance the snug rectangle drops is skipped pixel
-    by pixel by the blend, the blend adds a pixel's terms one entry at a time and the backward adds a Gaussian's records in a fixed
-    order, so BOTH WAYS GIVE THE SAME BITS -- image, inverse depth, radii and every gradient -- from lists a third shorter."""
+    by pixel by the blend, and the blend adds a pixel's terms one entry at a time: image, inverse depth and radii are THE SAME BITS
+    either way, from lists a third shorter.  The gradients are the same sums of the same per-instance records; the reduce adds them
+    in units of 256 records whose boundaries move with the emission indices, so they agree to fp32 summation order (a few 1e-6 of the
+    largest entry), not bit for bit."""
     from diff_gaussian_rasterization import GaussianRasterizer, _lib
     dev = torch.device("cuda:0")
     cam = make_camera(640, 360)
     aa = scene == "edge_aa"
-    sc = (make_edge_scene(20000, cam, seed=11) if aa else make_scene(60000, cam, seed=17, s_med=0.02)).to(dev)
+    sc_cpu = make_edge_scene(20000, cam, seed=11) if aa else make_scene(60000, cam, seed=17, s_med=0.02)
+    sc = sc_cpu.to(dev)
     s = oracle_settings(cam, antialiasing=aa, bg=torch.tensor([0.1, 0.2, 0.3]))
     wc = torch.randn(3, 360, 640, generator=torch.Generator().manual_seed(0)).to(dev)
 
@@ -365,7 +368,7 @@ def test_snug_tiles_change_no_bit(scene):
                                                                         scales=L[3], rotations=L[4])
             ((col * wc).sum() + invd.sum()).backward()
             torch.cuda.synchronize()
-            R = run_gpu(s, sc.cpu())["R"]
+            R = run_gpu(s, sc_cpu)["R"]
         finally:
             _lib.set_option("snug_tiles", 1)
         return [col.detach(), radii, invd.detach()] + [t.grad for t in L] + [m2.grad], R
@@ -373,8 +376,10 @@ def test_snug_tiles_change_no_bit(scene):
     a, Ra = run(1)
     b, Rb = run(0)
     assert Ra < 0.85 * Rb, (Ra, Rb)
-    for k, (x, y) in enumerate(zip(a, b)):
-        assert torch.equal(x, y), f"output {k} changed with the tile rectangle ({(x.float() - y.float()).abs().max().item():.3e})"
+    for k, (x, y) in enumerate(zip(a[:3], b[:3])):
+        assert torch.equal(x, y), f"forward output {k} changed with the tile rectangle ({(x.float() - y.float()).abs().max().item():.3e})"
+    for k, (x, y) in enumerate(zip(a[3:], b[3:])):
+        assert (x - y).abs().max().item() <= 1e-5 * y.abs().max().item(), f"gradient {k}: {(x - y).abs().max().item():.3e} of {y.abs().max().item():.3e}"
 
 
 def test_backward_parity_edge_aa():
@@ -524,7 +529,7 @@ def test_full_size_invariants_and_determinism():
     R = out["R"]
     tt = out["tiles_touched"].long()
     assert int(tt.sum()) == R and R > 5_000_000
-    assert torch.equal(tt > 0, out["radii"] > 0)
+    assert not ((tt > 0) & ~(out["radii"] > 0)).any()      # (snug rectangles: a visible Gaussian may reach no tile)
     rng = out["ranges"].long()
     cnt = rng[:, 1] - rng[:, 0]
     nz = cnt > 0
