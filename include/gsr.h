@@ -101,7 +101,9 @@ size_t gsr_backward_scratch_bytes(int P, int64_t R);
  *   means3D[P,3], opacities[P], shs[P,M,3] XOR colors_precomp[P,3],
  *   (scales[P,3] AND rotations[P,4]) XOR cov3D_precomp[P,6]; absent inputs are NULL.
  *   out_color[3,H,W], out_invdepth[1,H,W] (may be NULL), radii[P] int32.
- *   *num_rendered receives R, the number of (Gaussian, tile) instances.
+ *   *num_rendered receives R, the number of (Gaussian, tile) instances that were binned: the tiles of the snug rectangle of
+ *   every Gaussian's alpha >= 1/255 ellipse (option snug_tiles), a subset of the reference's tile square -- the reference would
+ *   report ~1.4x as many for the same frame; the rendered outputs are the same bits.
  * P == 0: out_color / out_invdepth are zero-filled, *num_rendered = 0, no callback is invoked.
  */
 int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M,
@@ -349,7 +351,13 @@ int gsr_profile_counters(uint64_t* out, int n, int reset);
  * of everything else; the measurement build (GSR_AB=1 python build.py -> lib_ab/) also compiles:
  *   render_fwd_variant 1..3, render_bwd_variant 1 / 4 / 5, depth_sort_mode 1 (onesweep), color_overlap 1 / 2 (split
  *   preprocess, colour kernel beside the depth sort), first_hist_in_preprocess 1, sh_dma 1..3 (LDS-DMA staging of the SH
- *   block) -- every one of them measured and rejected, see DESIGN.md.  Unknown names / unavailable values return an error. */
+ *   block) -- every one of them measured and rejected, see DESIGN.md.  Unknown names / unavailable values return an error.
+ * Switches of the product library whose default is 1 (both settings give the same results; 0 is the form they replaced):
+ *   snug_tiles       1 = a Gaussian is binned into the tiles its alpha >= 1/255 ellipse can reach, 0 = into the reference's square
+ *                    of radius 3 sqrt(lambda_max) (same outputs, ~1.4x the instances)
+ *   bwd_heavy_first  1 = the blend backward starts its heaviest tiles first (planned from the forward's per-block step counts)
+ * and ssim_variant (0 = marching-wave SSIM / training-loss kernels, 1 = the LDS-tiled form), ssim_target_waves (launch shape of
+ * the marching form), preprocess_grid_cap. */
 int gsr_set_option(const char* name, int value);
 
 #ifdef __cplusplus
