@@ -1022,39 +1022,57 @@ render_bwd_wave(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
 // number of steps, and workgroups start in id order: a heavy tile that starts in the last round IS the kernel's tail.  The
 // forward has already counted, per 8x8 block, the entries it blended before the block's last pixel terminated -- the very
 // survivors the backward walks back from the same point -- so the cost of every tile is known before the launch.  One
-// workgroup counting-sorts the band's tiles by that cost, descending (1024 bins, LDS atomics: the order inside a bin varies
+// workgroup counting-sorts the band's tiles by that cost, descending (512 bins, LDS atomics: the order inside a bin varies
 // from run to run, the gradients do not -- every wave writes its own slots).
 // ------------------------------------------------------------------------------------------------
-constexpr int PLAN_THREADS = 1024, PLAN_BINS = 1024;
-__device__ __forceinline__ int plan_bin(uint32_t w) {       // monotone; 4-step bins where frames live, 32-step bins above
-    return w < 2048u ? (int)(w >> 2) : min(PLAN_BINS - 1, 512 + (int)((w - 2048u) >> 5));
+constexpr int PLAN_THREADS = 1024, PLAN_WAVES = PLAN_THREADS / 64, PLAN_BINS = 512;
+__device__ __forceinline__ int plan_bin(uint32_t w) {       // monotone; 8-step bins where frames live, 64-step bins above
+    return w < 2048u ? (int)(w >> 3) : min(PLAN_BINS - 1, 256 + (int)((w - 2048u) >> 6));
 }
 
+// Every wave counts into its OWN copy of the histogram (a frame's tiles crowd into a few dozen bins).  The kernel takes ~9 us --
+// one workgroup, five dependent phases -- whichever way its loads and atomics are arranged (one shared copy 9.1, per-wave copies
+// 8.9, loads batched eight deep 12.6 on a slower box): more than half of what the order saves.  Filling the bins from the tail
+// of the forward waves would remove it.
 __global__ void __launch_bounds__(PLAN_THREADS)
 bwd_plan_kernel(int tile0, int n_band_tiles, const uint4* __restrict__ block_steps, uint32_t* __restrict__ tile_order) {
-    __shared__ uint32_t s_bin[PLAN_BINS];
-    __shared__ uint32_t s_wsum[PLAN_THREADS / 64];
+    __shared__ uint32_t s_bin[PLAN_WAVES][PLAN_BINS];       // 32 KB
+    __shared__ uint32_t s_wsum[PLAN_WAVES];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    s_bin[t] = 0u;
+    for (int k = t; k < PLAN_WAVES * PLAN_BINS; k += PLAN_THREADS) (&s_bin[0][0])[k] = 0u;
     __syncthreads();
     for (int i = t; i < n_band_tiles; i += PLAN_THREADS) {
         const uint4 v = block_steps[tile0 + i];
-        atomicAdd(&s_bin[plan_bin(v.x + v.y + v.z + v.w)], 1u);
+        atomicAdd(&s_bin[wv][plan_bin(v.x + v.y + v.z + v.w)], 1u);
     }
     __syncthreads();
-    const uint32_t c = s_bin[PLAN_BINS - 1 - t];            // thread t owns the t-th heaviest bin
+    // thread t < PLAN_BINS owns the t-th heaviest bin: its total over the copies, then (after the scan over bins) a cursor per copy
+    const int b = PLAN_BINS - 1 - (t & (PLAN_BINS - 1));
+    uint32_t c = 0u;
+    if (t < PLAN_BINS) {
+#pragma unroll
+        for (int k = 0; k < PLAN_WAVES; ++k) c += s_bin[k][b];
+    }
     const uint32_t incl = gsrw::wave_incl_scan_u32(c, lane);
     if (lane == 63) s_wsum[wv] = incl;
     __syncthreads();
     uint32_t base = 0u;
 #pragma unroll
-    for (int k = 0; k < PLAN_THREADS / 64; ++k)
+    for (int k = 0; k < PLAN_WAVES; ++k)
         if (k < wv) base += s_wsum[k];
-    s_bin[PLAN_BINS - 1 - t] = base + incl - c;             // the bin's cursor
+    if (t < PLAN_BINS) {
+        uint32_t run = base + incl - c;
+#pragma unroll
+        for (int k = 0; k < PLAN_WAVES; ++k) {
+            const uint32_t n = s_bin[k][b];
+            s_bin[k][b] = run;
+            run += n;
+        }
+    }
     __syncthreads();
-    for (int i = t; i < n_band_tiles; i += PLAN_THREADS) {
+    for (int i = t; i < n_band_tiles; i += PLAN_THREADS) {      // (a wave sees the tiles it counted)
         const uint4 v = block_steps[tile0 + i];
-        tile_order[atomicAdd(&s_bin[plan_bin(v.x + v.y + v.z + v.w)], 1u)] = (uint32_t)i;
+        tile_order[atomicAdd(&s_bin[wv][plan_bin(v.x + v.y + v.z + v.w)], 1u)] = (uint32_t)i;
     }
 }
 
