@@ -1032,8 +1032,9 @@ __device__ __forceinline__ int plan_bin(uint32_t w) {       // monotone; 8-step 
 
 // Every wave counts into its OWN copy of the histogram (a frame's tiles crowd into a few dozen bins).  The kernel takes ~9 us --
 // one workgroup, five dependent phases -- whichever way its loads and atomics are arranged (one shared copy 9.1, per-wave copies
-// 8.9, loads batched eight deep 12.6 on a slower box): more than half of what the order saves.  Filling the bins from the tail
-// of the forward waves would remove it.
+// 8.9, loads batched eight deep 12.6 on a slower box): more than half of what the order saves.  Filling work bins from the
+// tail of the forward's waves instead (one returning atomic per block) was measured too: it takes the kernel out of the backward
+// and puts its cost, and a little more, into the tracking forward.
 __global__ void __launch_bounds__(PLAN_THREADS)
 bwd_plan_kernel(int tile0, int n_band_tiles, const uint4* __restrict__ block_steps, uint32_t* __restrict__ tile_order) {
     __shared__ uint32_t s_bin[PLAN_WAVES][PLAN_BINS];       // 32 KB
