@@ -246,6 +246,49 @@ def test_snug_tiles_change_no_output(maker, aa, size):
     assert torch.equal(n0 > 0, n1 > 0)
 
 
+@pytest.mark.parametrize("seed,aa", [(3, False), (4, True)])
+def test_snug_rectangle_holds_every_pixel_that_can_contribute(seed, aa):
+    """Pixel by pixel, for adversarial splats -- needles with aspect ratios up to 1e4 at every angle, splats larger than the frame,
+    opacities from far below 1/255 to 1, centres off screen -- with the blend's own fp32 arithmetic: wherever
+    alpha = opacity exp(-q/2) reaches 1/255 inside the reference's tile square, the pixel's tile lies inside the snug rectangle."""
+    W, H = 208, 144
+    cam = look_at_camera(W, H, (0.3, -0.2, -0.5), (0.0, 0.0, 4.0))
+    g = torch.Generator().manual_seed(seed)
+    P = 800
+    sc = make_scene(P, cam, seed=seed, s_med=0.05, overscan=1.5)
+    logs = torch.rand(P, 3, generator=g) * 9.2 - 6.9                  # scales 1e-3 .. 10, independent per axis
+    sc.scales[:] = torch.exp(logs)
+    sc.rotations[:] = torch.nn.functional.normalize(torch.randn(P, 4, generator=g), dim=1)
+    sc.opacities[:] = torch.exp(torch.rand(P, 1, generator=g) * 7.0 - 7.0)      # 9e-4 .. 1
+    sc.opacities[::7] = (1.0 / 255.0) * (1.0 + (torch.rand(sc.opacities[::7].shape, generator=g) - 0.5) * 0.02)   # on the threshold
+    s = oracle_settings(cam, antialiasing=aa)
+    with torch.no_grad():
+        pre = O.preprocess(sc.means3D, sc.opacities, s, shs=sc.shs, scales=sc.scales, rotations=sc.rotations, snug=True)
+        ref = O.preprocess(sc.means3D, sc.opacities, s, shs=sc.shs, scales=sc.scales, rotations=sc.rotations, snug=False)
+    vis = ref["tiles_touched"] > 0
+    assert int(vis.sum()) > 150
+    m2, con, op, rect, rrect = pre["means2D"][vis], pre["conic"][vis], pre["opacity"][vis].reshape(-1), pre["rect"][vis], ref["rect"][vis]
+    px = torch.arange(W, dtype=torch.float32)[None, None, :]
+    py = torch.arange(H, dtype=torch.float32)[None, :, None]
+    dx = m2[:, 0, None, None] - px
+    dy = m2[:, 1, None, None] - py
+    # the reference's expression (forward.cu renderCUDA) and the product's (mul, fma, fma in log2 units): either may decide a pixel
+    power = -0.5 * (con[:, 0, None, None] * dx * dx + con[:, 2, None, None] * dy * dy) - con[:, 1, None, None] * dx * dy
+    alpha = torch.minimum(torch.tensor(0.99), op[:, None, None] * torch.exp(power))
+    hit = (power <= 0) & (alpha >= 1.0 / 255.0)
+    tx = (torch.arange(W) // 16)[None, None, :]
+    ty = (torch.arange(H) // 16)[None, :, None]
+    inside = (tx >= rect[:, 0, None, None]) & (tx < rect[:, 2, None, None]) & (ty >= rect[:, 1, None, None]) & (ty < rect[:, 3, None, None])
+    # (the reference itself never blends a splat outside its 3-sigma tile square, however opaque: only pixels in there count)
+    listed = (tx >= rrect[:, 0, None, None]) & (tx < rrect[:, 2, None, None]) & (ty >= rrect[:, 1, None, None]) & (ty < rrect[:, 3, None, None])
+    hit = hit & listed
+    assert int(hit.sum()) > 5000
+    missed = hit & ~inside
+    assert not missed.any(), f"{int(missed.sum())} contributing pixels outside the snug rectangle (Gaussians {torch.nonzero(missed.flatten(1).any(1)).flatten()[:5].tolist()})"
+    # and the rectangles do shrink
+    assert int(pre["tiles_touched"].sum()) < 0.8 * int(ref["tiles_touched"].sum())
+
+
 # ----------------------------------------------------------------------------- invariants
 @pytest.mark.parametrize("maker,aa", [(lambda c: make_scene(1500, c, seed=2, s_med=0.03), False),
                                       (lambda c: make_edge_scene(1500, c, seed=8), True)])
