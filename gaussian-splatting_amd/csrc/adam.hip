@@ -33,10 +33,10 @@ __device__ __forceinline__ void ntstore4(float4* p, const float4& v) {
     __builtin_nontemporal_store(t, reinterpret_cast<float4v*>(p));
 }
 
-__global__ void __launch_bounds__(256)
-adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
-            float om_b1, float b2, float om_b2, float step_size, float inv_bc2_sqrt, float eps, int vec) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+// one tensor, walked by `nthreads` threads of which this one is number `tid0`
+__device__ __forceinline__ void adam_walk(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                          int64_t n, float om_b1, float b2, float om_b2, float step_size, float inv_bc2_sqrt, float eps,
+                                          int vec, int64_t tid0, int64_t stride) {
     if (vec) {
         const int64_t n4 = n >> 2;
         float4* p4 = reinterpret_cast<float4*>(p);
@@ -45,7 +45,7 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
         float4* v4 = reinterpret_cast<float4*>(v);
         // two independent 64-byte groups per trip (8 x 16-byte loads in flight per lane), streamed past the caches:
         // every element is touched exactly once per step
-        int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        int64_t i = tid0;
         for (; i + stride < n4; i += 2 * stride) {
             const int64_t k = i + stride;
             float4 pa = ntload4(p4 + i), ma = ntload4(m4 + i), va = ntload4(v4 + i);
@@ -63,18 +63,51 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
             adam4(pp, gg, mm, vv, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
             ntstore4(p4 + i, pp); ntstore4(m4 + i, mm); ntstore4(v4 + i, vv);
         }
-        for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-            float pp = p[i], mm = m[i], vv = v[i];
-            adam1(pp, g[i], mm, vv, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
-            p[i] = pp; m[i] = mm; v[i] = vv;
+        for (int64_t j = (n4 << 2) + tid0; j < n; j += stride) {
+            float pp = p[j], mm = m[j], vv = v[j];
+            adam1(pp, g[j], mm, vv, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
+            p[j] = pp; m[j] = mm; v[j] = vv;
         }
     } else {
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-            float pp = p[i], mm = m[i], vv = v[i];
-            adam1(pp, g[i], mm, vv, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
-            p[i] = pp; m[i] = mm; v[i] = vv;
+        for (int64_t j = tid0; j < n; j += stride) {
+            float pp = p[j], mm = m[j], vv = v[j];
+            adam1(pp, g[j], mm, vv, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
+            p[j] = pp; m[j] = mm; v[j] = vv;
         }
     }
+}
+
+__global__ void __launch_bounds__(256)
+adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+            float om_b1, float b2, float om_b2, float step_size, float inv_bc2_sqrt, float eps, int vec) {
+    adam_walk(p, g, m, v, n, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps, vec, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
+              (int64_t)gridDim.x * blockDim.x);
+}
+
+// Several tensors in ONE launch (gsr_adam_step_multi): a 3DGS model is five or six parameter tensors, four of them small --
+// 6-20 us of kernel each, separated by launch boundaries.  Every tensor gets the block range [block_begin, next block_begin) and
+// is walked exactly as by its own launch.
+struct AdamTensorDev {
+    float* p; const float* g; float* m; float* v;
+    int64_t n;
+    float om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps;
+    int vec, block_begin;
+};
+struct AdamBatchDev {
+    AdamTensorDev t[GSR_ADAM_MAX_TENSORS];
+    int count, total_blocks;
+};
+__global__ void __launch_bounds__(256)
+adam_multi_kernel(AdamBatchDev b) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < GSR_ADAM_MAX_TENSORS; ++j)
+        if (j < b.count && (int)blockIdx.x >= b.t[j].block_begin) k = j;
+    const AdamTensorDev& t = b.t[k];
+    const int end = k + 1 < b.count ? b.t[k + 1].block_begin : b.total_blocks;
+    const int64_t nthreads = (int64_t)(end - t.block_begin) * blockDim.x;
+    adam_walk(t.p, t.g, t.m, t.v, t.n, t.om_b1, t.b2, t.om_b2, t.step_size, t.inv_bc2_sqrt, t.eps, t.vec,
+              (int64_t)((int)blockIdx.x - t.block_begin) * blockDim.x + threadIdx.x, nthreads);
 }
 
 // Sparse variant (SparseGaussianAdam.step(visibility, N), train.py:180-183): the tensor is N rows of M elements; rows of
@@ -161,4 +194,29 @@ void gsr_launch_adam(float* p, const float* g, float* m, float* v, int64_t n, do
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(adam_kernel, dim3((int)nb), dim3(256), 0, st, p, g, m, v, n, (float)(1.0 - beta1), (float)beta2,
                        (float)(1.0 - beta2), step_size, inv_bc2_sqrt, (float)eps, vec);
+}
+
+void gsr_launch_adam_multi(const GsrAdamTensor* tensors, int count, hipStream_t st) {
+    AdamBatchDev b;
+    b.count = 0;
+    int blocks = 0;
+    for (int i = 0; i < count && b.count < GSR_ADAM_MAX_TENSORS; ++i) {
+        const GsrAdamTensor& a = tensors[i];
+        if (a.n <= 0) continue;
+        AdamTensorDev& t = b.t[b.count++];
+        const double bc1 = 1.0 - pow(a.beta1, (double)a.step);
+        const double bc2 = 1.0 - pow(a.beta2, (double)a.step);
+        t.p = a.param; t.g = a.grad; t.m = a.exp_avg; t.v = a.exp_avg_sq; t.n = a.n;
+        t.om_b1 = (float)(1.0 - a.beta1); t.b2 = (float)a.beta2; t.om_b2 = (float)(1.0 - a.beta2);
+        t.step_size = (float)(a.lr / bc1); t.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2)); t.eps = (float)a.eps;
+        t.vec = ((((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0) ? 1 : 0;
+        const int64_t work = t.vec ? (t.n + 3) / 4 : t.n;
+        int64_t nb = (work + 255) / 256;
+        if (nb > 4096) nb = 4096;
+        t.block_begin = blocks;
+        blocks += (int)nb;
+    }
+    if (b.count == 0) return;
+    b.total_blocks = blocks;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, st, b);
 }

@@ -994,6 +994,21 @@ int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
     return GSR_OK;
 }
 
+int gsr_adam_step_multi(const GsrAdamTensor* tensors, int32_t count, void* stream) {
+    if (count < 0) return fail(GSR_ERR_INVALID_ARG, "count < 0");
+    if (count == 0) return GSR_OK;
+    if (!tensors) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
+    for (int i = 0; i < count; ++i) {
+        const GsrAdamTensor& a = tensors[i];
+        if (a.n < 0 || a.step < 1) return fail(GSR_ERR_INVALID_ARG, "n < 0 or step < 1");
+        if (a.n > 0 && (!a.param || !a.grad || !a.exp_avg || !a.exp_avg_sq)) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
+    }
+    for (int i = 0; i < count; i += GSR_ADAM_MAX_TENSORS)
+        gsr_launch_adam_multi(tensors + i, count - i < GSR_ADAM_MAX_TENSORS ? count - i : GSR_ADAM_MAX_TENSORS, (hipStream_t)stream);
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
+}
+
 int gsr_sparse_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* visible,
                          int64_t N, int64_t M, double lr, double beta1, double beta2, double eps, void* stream) {
     if (N < 0 || M < 0) return fail(GSR_ERR_INVALID_ARG, "N < 0 or M < 0");

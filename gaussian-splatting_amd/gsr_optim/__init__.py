@@ -1,7 +1,7 @@
 """Fused Adam for the Gaussian parameters -- drop-in for the torch.optim.Adam instance the reference
 builds in scene/gaussian_model.py:178-211 (per-group learning rates, eps=1e-15, updated every iteration by
-update_learning_rate, train.py:91) and steps at train.py:177-186.  One HIP kernel per parameter tensor
-(gsr_adam_step in libgsr_hip.so) instead of torch's multi-kernel foreach implementation.  State-dict layout
+update_learning_rate, train.py:91) and steps at train.py:177-186.  One HIP kernel for all parameter tensors
+(gsr_adam_step_multi in libgsr_hip.so) instead of torch's multi-kernel foreach implementation.  State-dict layout
 (`step`, `exp_avg`, `exp_avg_sq`) matches torch.optim.Adam so checkpoints (train.py:188-190) interchange."""
 from __future__ import annotations
 
@@ -25,6 +25,8 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
+        # all tensors of a device in ONE launch (gsr_adam_step_multi): a 3DGS model is six small-to-large tensors
+        batches = {}
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -39,10 +41,12 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] = int(st["step"]) + 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                with torch.cuda.device(p.device):
-                    _lib.check(lib.gsr_adam_step(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()),
-                                                 C.c_void_p(st["exp_avg"].data_ptr()), C.c_void_p(st["exp_avg_sq"].data_ptr()),
-                                                 p.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                                 int(st["step"]), C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)),
-                               "gsr_adam_step")
+                t = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
+                                    float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(st["step"]), 0)
+                batches.setdefault(p.device, []).append((t, g))      # (g kept alive until the launch)
+        for dev, items in batches.items():
+            arr = (_lib.AdamTensor * len(items))(*[t for t, _ in items])
+            with torch.cuda.device(dev):
+                _lib.check(lib.gsr_adam_step_multi(arr, len(items), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                           "gsr_adam_step_multi")
         return loss

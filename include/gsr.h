@@ -225,6 +225,23 @@ int gsr_route_return(int P, int n_bands, const int64_t* band_offsets, const int3
  */
 int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   double lr, double beta1, double beta2, double eps, int32_t step, void* stream);
+/*
+ * The same step for several tensors (a 3DGS model: positions, SH, opacities, scales, rotations -- one param group each,
+ * scene/gaussian_model.py:178-211) in as few launches as possible: up to GSR_ADAM_MAX_TENSORS tensors share one kernel launch,
+ * longer lists are split.  Results are bit-identical to gsr_adam_step on every tensor.
+ */
+#define GSR_ADAM_MAX_TENSORS 8
+typedef struct GsrAdamTensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t n;
+    double lr, beta1, beta2, eps;
+    int32_t step;            /* 1-based, after incrementing */
+    int32_t reserved;
+} GsrAdamTensor;
+int gsr_adam_step_multi(const GsrAdamTensor* tensors, int32_t count, void* stream);
 
 /*
  * Sparse Adam step: replaces `_C.adamUpdate` behind `SparseGaussianAdam.step(visibility, N)` of the

@@ -594,6 +594,43 @@ def test_fused_adam_matches_torch_adam():
             assert (sa[key] - sb[key]).abs().max().item() <= 2e-6 * sb[key].abs().max().item()
 
 
+def test_fused_adam_one_launch_equals_one_launch_per_tensor():
+    """gsr_optim.FusedAdam steps all tensors of a model in one launch (gsr_adam_step_multi); every tensor must come out exactly as
+    from its own gsr_adam_step launch -- odd sizes, a tensor that is not 16-byte aligned, different steps and learning rates."""
+    import ctypes as C
+    from diff_gaussian_rasterization import _lib
+    from gsr_optim import FusedAdam
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    shapes = [(1000, 3), (1000, 16, 3), (1000, 1), (1000, 3), (1000, 4), (777,), (5,), (4099, 3), (33, 16, 3), (12,)]      # > 8 tensors: two launches
+    params = [torch.randn(sh, generator=g).to(dev) for sh in shapes]
+    lrs = [1e-3 * (k + 1) for k in range(len(shapes))]
+    a = [p.clone().requires_grad_(True) for p in params]
+    b = [p.clone() for p in params]
+    pad_a, pad_b = torch.empty(4 + 777, device=dev), torch.empty(4 + 777, device=dev)      # tensor 5: 4-byte aligned only, both ways
+    pad_a[1:778] = params[5]
+    pad_b[1:778] = params[5]
+    a[5] = pad_a[1:778].requires_grad_(True)
+    b[5] = pad_b[1:778]
+    opt = FusedAdam([{"params": [q], "lr": lr} for q, lr in zip(a, lrs)], eps=1e-15)
+    m = [torch.zeros_like(p) for p in b]
+    v = [torch.zeros_like(p) for p in b]
+    lib = _lib.load()
+    for it in range(1, 4):
+        grads = [torch.randn(p.shape, generator=g).to(dev) for p in params]
+        for q, gr in zip(a, grads):
+            q.grad = gr.clone()
+        opt.step()
+        for k in range(len(b)):
+            _lib.check(lib.gsr_adam_step(C.c_void_p(b[k].data_ptr()), C.c_void_p(grads[k].data_ptr()), C.c_void_p(m[k].data_ptr()),
+                                         C.c_void_p(v[k].data_ptr()), b[k].numel(), lrs[k], 0.9, 0.999, 1e-15, it,
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gsr_adam_step")
+    torch.cuda.synchronize()
+    for k in range(len(b)):
+        assert torch.equal(a[k].detach(), b[k]), k
+        assert torch.equal(opt.state[a[k]]["exp_avg"], m[k]) and torch.equal(opt.state[a[k]]["exp_avg_sq"], v[k]), k
+
+
 @pytest.fixture(params=[0, 1], ids=["marching", "tiled"])
 def ssim_variant(request):
     """Both forms of the SSIM kernels (ssim.hip): marching waves (the default) and the LDS-tiled A/B form."""
