@@ -433,36 +433,48 @@ def _run(a):
                                                           vd.full_proj_transform, 3, vd.camera_center, False, False, False))
             gts.append(torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(1 + i)))
         legs = [("ssim", "dense", fused_train_loss), ("sparse_adam", "sparse", fused_train_loss), ("l1", "dense", l1_loss),
-                ("ssim_unfused_l1", "dense", unfused_l1_train_loss)]
+                ("ssim_unfused_l1", "dense", unfused_l1_train_loss),
+                # opt-in: the Adam step of the two SH tensors applied inside the per-Gaussian backward (separate_sh form)
+                ("sparse_adam_sh_step_in_backward", "sparse+fused", fused_train_loss),
+                ("dense_adam_sh_step_in_backward", "split+fused", fused_train_loss)]
         if a.compare_torch_adam:
             legs.append(("l1_torch_adam", "torch", l1_loss))
             legs.append(("ssim_torch", "dense", train_loss))
         if world > 1:
-            legs = [l for l in legs if l[1] != "sparse"]      # the sharded path keeps the fused [P,16,3] SH tensor
+            legs = [l for l in legs if l[1] not in ("sparse", "sparse+fused", "split+fused")]      # the sharded path keeps the fused [P,16,3] SH tensor
         from diff_gaussian_rasterization.parallel import render_two_axis, render_gaussian_sharded, padded_shard_size
         # N > 1: rank g owns Gaussians [lo, hi) (parameters + Adam state) and a band of tile rows.  Mode C: 48-byte packed splat
         # records travel only to the bands they touch (all-to-all) and the 48-byte gradient rows come back the same way;
         # mode B / fallback: two-axis sharding with the record all-gather + gradient reduce-scatter of round 2
         P_pad = padded_shard_size(hi - lo) if (world > 1 and mode != "C") else P
         for leg, opt_kind, loss_fn in legs:
-            if opt_kind == "sparse":
+            fuse_sh = opt_kind.endswith("+fused")
+            split_sh = opt_kind in ("sparse", "sparse+fused", "split+fused")
+            sparse_opt = opt_kind in ("sparse", "sparse+fused")
+            if split_sh:
                 src = (sc.means3D, sc.shs[:, :1].contiguous(), sc.shs[:, 1:].contiguous(), sc.opacities, sc.scales, sc.rotations)
             else:
                 src = (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)
             params = [t[lo:hi].detach().clone().requires_grad_(True) for t in src]
-            if opt_kind == "sparse":
+            if sparse_opt:
                 opt = SparseGaussianAdam([{"params": [p_], "lr": 1e-5} for p_ in params], lr=1e-5, eps=1e-15)
+            elif split_sh:
+                opt = FusedAdam([{"params": [p_], "lr": 1e-5} for p_ in params], lr=1e-5, eps=1e-15)
             elif opt_kind == "torch":
                 opt = torch.optim.Adam(params, lr=1e-5, eps=1e-15)
             else:
                 opt = FusedAdam(params, lr=1e-5, eps=1e-15)
             it_no = [0]
+            fusion = None
+            if fuse_sh:
+                from diff_gaussian_rasterization import fuse_sh_adam_into_backward
+                fusion = fuse_sh_adam_into_backward(opt, params[1], params[2])
 
             def train_step():
                 vi = it_no[0] % len(rs_views)
                 it_no[0] += 1
                 opt.zero_grad(set_to_none=True)
-                if opt_kind == "sparse":
+                if split_sh:
                     m, dc, rest, o, s_, r_ = params
                     color, radii, invd = rasterize_gaussians(m, None, rest, None, o, s_, r_, None, rs_views[vi], None, None, dc)
                 elif world > 1 and mode == "C":
@@ -476,7 +488,7 @@ def _run(a):
                     color, radii, invd = rasterize_gaussians(m, None, sh, None, o, s_, r_, None, rs_views[vi], None)
                 loss = loss_fn(color, gts[vi])
                 loss.backward()
-                if opt_kind == "sparse":
+                if sparse_opt:
                     opt.step(radii > 0, radii.shape[0])
                 else:
                     opt.step()
@@ -505,6 +517,8 @@ def _run(a):
                 torch.cuda.synchronize()
                 bwd_counters = _lib.profile_counters(reset=True)
                 _lib.profile_enable(False)
+            if fusion is not None:
+                fusion.remove()
             del params, opt      # (no empty_cache(): the next leg re-uses the cached blocks instead of re-allocating)
     train_ms = train.get("ssim")
     train_ips = None if train_ms is None else 1e3 / train_ms
@@ -857,6 +871,8 @@ def _run(a):
             "forward_cycled_views": cycled,
             "frame_parallel_replicas": replicas,
             "train_iters_per_s_sparse_adam": None if "sparse_adam" not in train else round(1e3 / train["sparse_adam"], 3),
+            "train_iters_per_s_sh_step_in_backward": {k: round(1e3 / train[k], 3) for k in ("sparse_adam_sh_step_in_backward", "dense_adam_sh_step_in_backward") if k in train}
+                                                     or None,
             "train_iters_per_s_ssim_torch": None if "ssim_torch" not in train else round(1e3 / train["ssim_torch"], 3),
             "train_iters_per_s_l1": None if "l1" not in train else round(1e3 / train["l1"], 3),
             "train_iters_per_s_l1_torch_adam": None if "l1_torch_adam" not in train else round(1e3 / train["l1_torch_adam"], 3),

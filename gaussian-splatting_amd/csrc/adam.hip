@@ -5,15 +5,13 @@
 // once (28 B per parameter = 1.65 GB -> HBM-bound).  Arithmetic follows torch.optim.Adam (no weight decay, no amsgrad):
 //   m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g g;  p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 #include "gsr_internal.h"
+#include "gsr_adam_math.h"
 
 namespace {
 
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float om_b1, float b2, float om_b2, float step_size,
                                       float inv_bc2_sqrt, float eps) {
-    m = m + (g - m) * om_b1;
-    v = v * b2 + om_b2 * g * g;
-    const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
-    p = p - step_size * (m / denom);
+    gsr_adam1(p, g, m, v, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
 }
 
 __device__ __forceinline__ void adam4(float4& p, const float4& g, float4& m, float4& v, float om_b1, float b2, float om_b2,
@@ -120,9 +118,7 @@ adam_multi_kernel(AdamBatchDev b) {
 // visible rows only.  Partially visible groups write the untouched components back unchanged.
 __device__ __forceinline__ void sparse_adam1(float& p, float g, float& m, float& v, float lr, float b1, float om_b1, float b2,
                                              float om_b2, float eps) {
-    m = b1 * m + om_b1 * g;
-    v = b2 * v + om_b2 * g * g;
-    p += -lr * m / (sqrtf(v) + eps);
+    gsr_sparse_adam1(p, g, m, v, lr, b1, om_b1, b2, om_b2, eps);
 }
 
 __global__ void __launch_bounds__(256)

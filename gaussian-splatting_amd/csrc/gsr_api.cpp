@@ -966,6 +966,60 @@ int gsr_backward_preprocess(const GsrRasterSettings* settings, int P, int M, con
     return GSR_OK;
 }
 
+int gsr_backward_preprocess_sh_adam(const GsrRasterSettings* settings, int P, int M, const float* means3D, float* shs_rest,
+                                    const float* opacities, const float* scales, const float* rotations,
+                                    const float* cov3D_precomp, const int32_t* radii, const void* geom_buffer,
+                                    const float* splat_grads, float* dL_dmeans2D, float* dL_dopacity, float* dL_dmeans3D,
+                                    float* dL_dcov3D, float* dL_dscales, float* dL_drotations, const GsrShAdam* adam,
+                                    void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!settings || !adam) return fail(GSR_ERR_INVALID_ARG, "settings / adam are NULL");
+    GsrCamDev cam;
+    int rc = make_cam(settings, M, cam);
+    if (rc != GSR_OK) return rc;
+    rc = check_inputs(P, M, means3D, shs_rest, nullptr, opacities, scales, rotations, cov3D_precomp, cam.sh_degree);
+    if (rc != GSR_OK) return rc;
+    rc = check_split_sh(settings, P, M, shs_rest, false);
+    if (rc != GSR_OK) return rc;
+    if (M != 16 || !settings->sh_dc) return fail(GSR_ERR_UNSUPPORTED, "the fused SH Adam step needs the split SH form with M = 16 (sh_dc + 15 coefficients)");
+    if (P == 0) return GSR_OK;
+    if (!radii || !splat_grads) return fail(GSR_ERR_INVALID_ARG, "radii / splat_grads are NULL");
+    if (!dL_dmeans2D || !dL_dopacity || !dL_dmeans3D) return fail(GSR_ERR_INVALID_ARG, "gradient outputs are NULL");
+    if (cov3D_precomp && !dL_dcov3D) return fail(GSR_ERR_INVALID_ARG, "dL_dcov3D is NULL");
+    if (scales && (!dL_dscales || !dL_drotations)) return fail(GSR_ERR_INVALID_ARG, "dL_dscales / dL_drotations are NULL");
+    if (!adam->dc_exp_avg || !adam->dc_exp_avg_sq || !adam->rest_exp_avg || !adam->rest_exp_avg_sq)
+        return fail(GSR_ERR_INVALID_ARG, "Adam moments are NULL");
+    if (((uintptr_t)settings->sh_dc | (uintptr_t)shs_rest | (uintptr_t)adam->dc_exp_avg | (uintptr_t)adam->dc_exp_avg_sq |
+         (uintptr_t)adam->rest_exp_avg | (uintptr_t)adam->rest_exp_avg_sq) & 15)
+        return fail(GSR_ERR_UNSUPPORTED, "the fused SH Adam step needs 16-byte aligned SH tensors and moments");
+    if (!adam->sparse && (adam->step_dc < 1 || adam->step_rest < 1)) return fail(GSR_ERR_INVALID_ARG, "step < 1");
+    GsrShAdamDev d;
+    d.dc = const_cast<float*>(settings->sh_dc); d.dc_m = adam->dc_exp_avg; d.dc_v = adam->dc_exp_avg_sq;
+    d.rest = shs_rest; d.rest_m = adam->rest_exp_avg; d.rest_v = adam->rest_exp_avg_sq;
+    d.sparse = adam->sparse ? 1 : 0;
+    auto fill = [&](float (&a)[6], double lr, int step) {
+        if (d.sparse) {      // lr, b1, 1 - b1, b2, 1 - b2, eps  (gsr_launch_sparse_adam)
+            a[0] = (float)lr; a[1] = (float)adam->beta1; a[2] = (float)(1.0 - adam->beta1); a[3] = (float)adam->beta2;
+            a[4] = (float)(1.0 - adam->beta2); a[5] = (float)adam->eps;
+        } else {             // 1 - b1, b2, 1 - b2, step size, 1 / sqrt(1 - b2^t), eps  (gsr_launch_adam: doubles until the last moment)
+            const double bc1 = 1.0 - pow(adam->beta1, (double)step), bc2 = 1.0 - pow(adam->beta2, (double)step);
+            a[0] = (float)(1.0 - adam->beta1); a[1] = (float)adam->beta2; a[2] = (float)(1.0 - adam->beta2);
+            a[3] = (float)(lr / bc1); a[4] = (float)(1.0 / sqrt(bc2)); a[5] = (float)adam->eps;
+        }
+    };
+    fill(d.dc_a, adam->lr_dc, adam->step_dc);
+    fill(d.rest_a, adam->lr_rest, adam->step_rest);
+    GsrGeom g = gsr_carve_geom(geom_buffer ? (char*)geom_buffer : nullptr, P);
+    {   StageTimer t(GSR_STAGE_PREPROCESS_BWD, st);
+        gsr_launch_preprocess_backward_sh_adam(cam, P, means3D, opacities, scales, rotations, cov3D_precomp, radii, g, splat_grads,
+                                               dL_dmeans2D, dL_dopacity, dL_dmeans3D, dL_dcov3D, scales ? dL_dscales : nullptr,
+                                               scales ? dL_drotations : nullptr, d, st);
+    }
+    STAGE_CHECK("preprocess backward (fused SH Adam)");
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
+}
+
 int gsr_rasterize_backward(const GsrRasterSettings* settings, int P, int M, int32_t num_rendered, const float* means3D,
                            const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
                            const float* rotations, const float* cov3D_precomp, const int32_t* radii,

@@ -132,6 +132,20 @@ void gsr_launch_preprocess_backward(const GsrCamDev& cam, int P, const float* me
                                     GsrGeom g, const float* splat_grads /*[P,12]*/, float* dL_dmeans2D,
                                     float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D,
                                     float* dL_dsh, float* dL_dscales, float* dL_drotations, hipStream_t st);
+// the same kernel, but the SH gradient of the split form is not written: the Adam update of the two SH tensors is applied in
+// place from the gradient tile (gsr_backward_preprocess_sh_adam); dense: every row, sparse: rows with radii > 0
+struct GsrShAdamDev {
+    float* dc;  float* dc_m;  float* dc_v;            // [P,1,3]
+    float* rest; float* rest_m; float* rest_v;        // [P,15,3]
+    // dense (torch.optim.Adam): om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps;  sparse: lr, b1, om_b1, b2, om_b2, eps
+    float dc_a[6], rest_a[6];
+    int sparse;
+};
+void gsr_launch_preprocess_backward_sh_adam(const GsrCamDev& cam, int P, const float* means3D, const float* opacities,
+                                            const float* scales, const float* rotations, const float* cov3D_precomp,
+                                            const int32_t* radii, GsrGeom g, const float* splat_grads, float* dL_dmeans2D,
+                                            float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales,
+                                            float* dL_drotations, const GsrShAdamDev& adam, hipStream_t st);
 void gsr_set_preprocess_grid_cap(int cap);      // tuning knob (option preprocess_grid_cap)
 int gsr_set_sh_dma(int mask);     // A/B builds: LDS-DMA staging of the SH block (option sh_dma: bit 0 forward, bit 1 backward); 0 = not in this build
 void gsr_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st);

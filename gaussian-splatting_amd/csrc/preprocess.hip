@@ -13,6 +13,7 @@
 // ds_write_b128 per lane), skipping rows of culled Gaussians at 16-byte granularity.  Camera matrices are
 // wave-uniform -> scalar loads.
 #include "gsr_internal.h"
+#include "gsr_adam_math.h"
 
 namespace {
 
@@ -487,7 +488,86 @@ preprocess_color_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D
 
 #endif  // GSR_AB_VARIANTS
 
-template <bool SPLIT, bool DMA>
+// The Adam step of the two SH tensors straight from the gradient tile (gsr_backward_preprocess_sh_adam): the gradient never
+// travels to HBM and back, and the parameter rows the kernel loaded a moment ago are re-read from L2.  Same pieces, same 16-byte
+// accesses as wave_store_sh_split_dense; four pieces per trip (p, m, v of four pieces = 48 registers in flight).
+// rows: bit r set = row r takes part (dense Adam: all rows; SparseGaussianAdam: the visible ones).  A piece spans at most two
+// rows; components of rows that do not take part are written back unchanged.
+__device__ __forceinline__ void adam_piece(float4& p, const float4& g, float4& m, float4& v, const float (&a)[6], int sparse, bool k0, bool k1,
+                                           bool k2, bool k3) {
+    if (sparse) {
+        if (k0) gsr_sparse_adam1(p.x, g.x, m.x, v.x, a[0], a[1], a[2], a[3], a[4], a[5]);
+        if (k1) gsr_sparse_adam1(p.y, g.y, m.y, v.y, a[0], a[1], a[2], a[3], a[4], a[5]);
+        if (k2) gsr_sparse_adam1(p.z, g.z, m.z, v.z, a[0], a[1], a[2], a[3], a[4], a[5]);
+        if (k3) gsr_sparse_adam1(p.w, g.w, m.w, v.w, a[0], a[1], a[2], a[3], a[4], a[5]);
+    } else {
+        gsr_adam1(p.x, g.x, m.x, v.x, a[0], a[1], a[2], a[3], a[4], a[5]);
+        gsr_adam1(p.y, g.y, m.y, v.y, a[0], a[1], a[2], a[3], a[4], a[5]);
+        gsr_adam1(p.z, g.z, m.z, v.z, a[0], a[1], a[2], a[3], a[4], a[5]);
+        gsr_adam1(p.w, g.w, m.w, v.w, a[0], a[1], a[2], a[3], a[4], a[5]);
+    }
+}
+__device__ __forceinline__ void wave_adam_sh_split_dense(const GsrShAdamDev& ad, int64_t i0, int P, uint64_t rows, int lane, const float* tile) {
+    const int nrow = (int)((P - i0) < 64 ? (P - i0) : 64);
+    const int nrest = nrow * 45, ndc = nrow * 3;
+    float* pr = ad.rest + i0 * 45; float* mr = ad.rest_m + i0 * 45; float* vr = ad.rest_v + i0 * 45;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int it0 = 0; it0 < 12; it0 += 4) {     // (a real loop: unrolled, the three trips' loads were hoisted together -- 360 registers)
+        float4 pp[4], mm[4], vv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {           // (pieces beyond the block read its first 16 bytes: always valid)
+            const int f = ((it0 + k) * 64 + lane) * 4;
+            const int fo = f + 3 < nrest ? f : 0;
+            pp[k] = *reinterpret_cast<const float4*>(pr + fo);
+            mm[k] = *reinterpret_cast<const float4*>(mr + fo);
+            vv[k] = *reinterpret_cast<const float4*>(vr + fo);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int f = ((it0 + k) * 64 + lane) * 4;
+            if (f + 3 < nrest) {
+                const float4 g = *reinterpret_cast<const float4*>(tile + f);
+                const int r0 = f / 45, r1 = (f + 1) / 45, r2 = (f + 2) / 45, r3 = (f + 3) / 45;
+                adam_piece(pp[k], g, mm[k], vv[k], ad.rest_a, ad.sparse, (rows >> r0) & 1ull, (rows >> r1) & 1ull, (rows >> r2) & 1ull,
+                           (rows >> r3) & 1ull);
+                *reinterpret_cast<float4*>(pr + f) = pp[k];
+                *reinterpret_cast<float4*>(mr + f) = mm[k];
+                *reinterpret_cast<float4*>(vr + f) = vv[k];
+            } else if (f < nrest) {             // ragged end of the last block
+                for (int c = 0; c < 3; ++c)
+                    if (f + c < nrest && ((rows >> ((f + c) / 45)) & 1ull)) {
+                        float p1 = pr[f + c], m1 = mr[f + c], v1 = vr[f + c];
+                        if (ad.sparse) gsr_sparse_adam1(p1, tile[f + c], m1, v1, ad.rest_a[0], ad.rest_a[1], ad.rest_a[2], ad.rest_a[3], ad.rest_a[4], ad.rest_a[5]);
+                        else gsr_adam1(p1, tile[f + c], m1, v1, ad.rest_a[0], ad.rest_a[1], ad.rest_a[2], ad.rest_a[3], ad.rest_a[4], ad.rest_a[5]);
+                        pr[f + c] = p1; mr[f + c] = m1; vr[f + c] = v1;
+                    }
+            }
+        }
+    }
+    float* pd = ad.dc + i0 * 3; float* md = ad.dc_m + i0 * 3; float* vd = ad.dc_v + i0 * 3;
+    const int fd = lane * 4;
+    if (fd + 3 < ndc) {
+        float4 p4 = *reinterpret_cast<const float4*>(pd + fd), m4 = *reinterpret_cast<const float4*>(md + fd), v4 = *reinterpret_cast<const float4*>(vd + fd);
+        const float4 g = *reinterpret_cast<const float4*>(tile + SPLIT_DC + fd);
+        adam_piece(p4, g, m4, v4, ad.dc_a, ad.sparse, (rows >> (fd / 3)) & 1ull, (rows >> ((fd + 1) / 3)) & 1ull, (rows >> ((fd + 2) / 3)) & 1ull,
+                   (rows >> ((fd + 3) / 3)) & 1ull);
+        *reinterpret_cast<float4*>(pd + fd) = p4;
+        *reinterpret_cast<float4*>(md + fd) = m4;
+        *reinterpret_cast<float4*>(vd + fd) = v4;
+    } else if (fd < ndc) {
+        for (int c = 0; c < 3; ++c)
+            if (fd + c < ndc && ((rows >> ((fd + c) / 3)) & 1ull)) {
+                float p1 = pd[fd + c], m1 = md[fd + c], v1 = vd[fd + c];
+                if (ad.sparse) gsr_sparse_adam1(p1, tile[SPLIT_DC + fd + c], m1, v1, ad.dc_a[0], ad.dc_a[1], ad.dc_a[2], ad.dc_a[3], ad.dc_a[4], ad.dc_a[5]);
+                else gsr_adam1(p1, tile[SPLIT_DC + fd + c], m1, v1, ad.dc_a[0], ad.dc_a[1], ad.dc_a[2], ad.dc_a[3], ad.dc_a[4], ad.dc_a[5]);
+                pd[fd + c] = p1; md[fd + c] = m1; vd[fd + c] = v1;
+            }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool SPLIT, bool DMA, bool ADAM = false>
 __global__ void __launch_bounds__(256) GSR_PRE_OCC
 preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
                       const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -496,7 +576,7 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
                       const uint32_t* __restrict__ clamped, const float4* __restrict__ grads,
                       float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
                       float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
-                      float* __restrict__ dL_dscales, float* __restrict__ dL_drotations) {
+                      float* __restrict__ dL_dscales, float* __restrict__ dL_drotations, GsrShAdamDev adam) {
     __shared__ __attribute__((aligned(16))) float s_sh[4][64 * SH_ROW];
     GsrCam cam;
     load_cam(camd, cam);
@@ -608,7 +688,8 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             }
         }
         if (staged_sh) {
-            if (SPLIT) wave_store_sh_split_dense(dL_ddc, dL_dsh, i0, P, lane, tile);
+            if (SPLIT && ADAM) wave_adam_sh_split_dense(adam, i0, P, adam.sparse ? __ballot(vis) : ~0ull, lane, tile);
+            else if (SPLIT) wave_store_sh_split_dense(dL_ddc, dL_dsh, i0, P, lane, tile);
             else if (dma_sh) wave_store_sh16_dense(dL_dsh, i0, P, lane, tile);
             else wave_store_sh16(dL_dsh, i0, P, lane, tile);
         }
@@ -719,7 +800,7 @@ void gsr_launch_preprocess_backward(const GsrCamDev& cam, int P, const float* me
     hipLaunchKernelGGL((preprocess_bwd_kernel<SPLIT_, DMA_>), dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs,             \
                        colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g.clamped,                                 \
                        reinterpret_cast<const float4*>(splat_grads), dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D,     \
-                       dL_dsh, dL_dscales, dL_drotations)
+                       dL_dsh, dL_dscales, dL_drotations, GsrShAdamDev{})
     if (cam.sh_dc) GSR_PRE_BWD(true, false);
 #ifdef GSR_AB_VARIANTS
     else if (dma) GSR_PRE_BWD(false, true);
@@ -727,6 +808,18 @@ void gsr_launch_preprocess_backward(const GsrCamDev& cam, int P, const float* me
     else GSR_PRE_BWD(false, false);
 #undef GSR_PRE_BWD
     (void)dma;
+}
+
+void gsr_launch_preprocess_backward_sh_adam(const GsrCamDev& cam, int P, const float* means3D, const float* opacities,
+                                            const float* scales, const float* rotations, const float* cov3D_precomp,
+                                            const int32_t* radii, GsrGeom g, const float* splat_grads, float* dL_dmeans2D,
+                                            float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales,
+                                            float* dL_drotations, const GsrShAdamDev& adam, hipStream_t st) {
+    // split-SH form, M == 16: cam.sh_dc / `shs` are adam.dc / adam.rest (read for the colour clamp, then updated in place)
+    hipLaunchKernelGGL((preprocess_bwd_kernel<true, false, true>), dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D,
+                       (const float*)adam.rest, (const float*)nullptr, opacities, scales, rotations, cov3D_precomp, radii, g.clamped,
+                       reinterpret_cast<const float4*>(splat_grads), dL_dmeans2D, (float*)nullptr, dL_dopacity, dL_dmeans3D, dL_dcov3D,
+                       (float*)nullptr, dL_dscales, dL_drotations, adam);
 }
 
 void gsr_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st) {

@@ -162,6 +162,71 @@ def _require_cuda(t: torch.Tensor, name: str):
         raise GsrError(f"{name} must live on a HIP device ('cuda'); the MI355X rasterizer has no CPU path")
 
 
+# ---- opt-in: the Adam step of the two SH tensors inside the backward (gsr_backward_preprocess_sh_adam) --------------------------
+_SH_ADAM = {}      # id(rest parameter) -> _ShAdamFusion
+
+
+class _ShAdamFusion:
+    """Registered by `fuse_sh_adam_into_backward`.  While it is active, a rasterizer call in the reference's separate_sh form whose
+    `dc=` / `shs=` arguments ARE the two registered leaf parameters does not return their gradients from backward: the per-Gaussian
+    backward kernel applies the optimizer's update to them in place (and to the optimizer's moments), bit for bit what
+    `optimizer.step()` would have done with the gradient, which therefore never travels to HBM and back.  `optimizer.step()`
+    afterwards skips the two tensors (their .grad is None) and steps the rest as usual."""
+
+    def __init__(self, optimizer, dc, rest):
+        import weakref
+        self.optimizer, self.dc, self.rest = optimizer, weakref.ref(dc), weakref.ref(rest)
+        self.sparse = isinstance(optimizer, SparseGaussianAdam)
+        self.key = id(rest)
+
+    def matches(self, dc, rest):
+        return self.dc() is dc and self.rest() is rest
+
+    def remove(self):
+        _SH_ADAM.pop(self.key, None)
+
+    def _group(self, param):
+        for g in self.optimizer.param_groups:
+            if any(q is param for q in g["params"]):
+                return g
+        raise GsrError("fused SH Adam: the parameter is not in the optimizer any more (re-register after densification)")
+
+    def arm(self):
+        """Moments (created on first use), hyper-parameters and -- dense Adam -- the incremented step counts as a _lib.ShAdam."""
+        dc, rest = self.dc(), self.rest()      # (the Parameter objects: the optimizer's state is keyed by them)
+        if dc is None or rest is None:
+            raise GsrError("fused SH Adam: a registered parameter no longer exists")
+        st = []
+        for q in (dc, rest):
+            s_ = self.optimizer.state[q]
+            if len(s_) == 0:
+                s_["step"] = torch.tensor(0.0, dtype=torch.float32) if self.sparse else 0
+                s_["exp_avg"] = torch.zeros_like(q, memory_format=torch.contiguous_format)
+                s_["exp_avg_sq"] = torch.zeros_like(q, memory_format=torch.contiguous_format)
+            if not self.sparse:
+                s_["step"] = int(s_["step"]) + 1
+            st.append(s_)
+        g_dc, g_rest = self._group(dc), self._group(rest)
+        b1, b2 = (0.9, 0.999) if self.sparse else g_rest["betas"]
+        if not self.sparse and tuple(g_dc["betas"]) != tuple(g_rest["betas"]) or g_dc["eps"] != g_rest["eps"]:
+            raise GsrError("fused SH Adam: the two SH parameter groups must share betas and eps")
+        return _lib.ShAdam(st[0]["exp_avg"].data_ptr(), st[0]["exp_avg_sq"].data_ptr(), st[1]["exp_avg"].data_ptr(),
+                           st[1]["exp_avg_sq"].data_ptr(), float(g_dc["lr"]), float(g_rest["lr"]), float(b1), float(b2),
+                           float(g_rest["eps"]), 0 if self.sparse else int(st[0]["step"]), 0 if self.sparse else int(st[1]["step"]),
+                           1 if self.sparse else 0, 0)
+
+
+def fuse_sh_adam_into_backward(optimizer, dc_param, rest_param):
+    """OPT-IN (no reference counterpart): from now on `loss.backward()` applies `optimizer`'s step to `dc_param` ([P,1,3]) and
+    `rest_param` ([P,15,3]) itself when they reach the rasterizer as `dc=` / `shs=` (gaussian_renderer/__init__.py:82-100,
+    separate_sh).  `optimizer` is a `SparseGaussianAdam` (rows with radii > 0, as `step(radii > 0, N)` would) or a
+    `gsr_optim.FusedAdam` / `torch.optim.Adam`-configured optimizer (every row).  One backward per step; call `.remove()` on the
+    returned handle -- or register the new parameters -- when densification replaces the tensors."""
+    ent = _ShAdamFusion(optimizer, dc_param, rest_param)
+    _SH_ADAM[ent.key] = ent
+    return ent
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -234,6 +299,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.flags = (sh_c is not None, colors_precomp is not None, scales is not None, rotations is not None,
                      cov3Ds_precomp is not None)
         ctx.has_dc = dc_c is not None
+        ctx.sh_adam = None
+        if ctx.dc_mode == "split" and grad_sync is None and colors_precomp is None and _SH_ADAM:
+            ent = _SH_ADAM.get(id(sh))
+            if ent is not None and ent.matches(dc, sh) and sh_c is sh and dc_c is dc and sh.requires_grad and dc.requires_grad:
+                ctx.sh_adam = ent
         ctx.sh_given = sh is not None
         ctx.dc_shape = tuple(dc.shape) if dc is not None else None
         ctx.save_for_backward(means3D_c, sh_c if sh_c is not None else means3D_c.new_empty(0),
@@ -269,8 +339,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         dL_dmeans3D = torch.empty(P, 3, **f)
         dL_dcov3D = torch.empty(P, 6, **f) if has_cov else None
         has_dc = ctx.has_dc
-        dL_dsh = torch.empty(P, M - 1 if has_dc else M, 3, **f) if has_sh else None
-        dL_ddc = torch.empty(P, 1, 3, **f) if has_dc else None
+        fused_adam = ctx.sh_adam if (ctx.sh_adam is not None and _SH_ADAM.get(ctx.sh_adam.key) is ctx.sh_adam) else None
+        dL_dsh = torch.empty(P, M - 1 if has_dc else M, 3, **f) if (has_sh and fused_adam is None) else None
+        dL_ddc = torch.empty(P, 1, 3, **f) if (has_dc and fused_adam is None) else None
         dL_dscales = torch.empty(P, 3, **f) if has_sc else None
         dL_drot = torch.empty(P, 4, **f) if has_rot else None
         if P > 0:
@@ -283,7 +354,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 s = _make_settings(rs, keep, ctx.tile_rows)
                 if has_dc:
                     s.sh_dc = dc.data_ptr()
-                    s.dL_dsh_dc = dL_ddc.data_ptr()
+                    s.dL_dsh_dc = dL_ddc.data_ptr() if dL_ddc is not None else None
                 st = _stream_ptr(device)
                 inputs = (_ptr(means3D), _ptr(sh) if has_sh else None, _ptr(col) if has_col else None, _ptr(op),
                           _ptr(sc) if has_sc else None, _ptr(rot) if has_rot else None, _ptr(cov) if has_cov else None,
@@ -292,6 +363,19 @@ class _RasterizeGaussians(torch.autograd.Function):
                         _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drot))
 
                 def _run():
+                    if fused_adam is not None:
+                        # blend backward, then the per-Gaussian backward that steps the two SH tensors in place
+                        rec_ptr = C.c_void_p(0)
+                        _lib.check(lib.gsr_backward_blend(C.byref(s), P, ctx.num_rendered, _ptr(geom), _ptr(binning), _ptr(img),
+                                                          _ptr(g_color), _ptr(g_depth), _ptr(scratch), C.byref(rec_ptr), st),
+                                   "gsr_backward_blend")
+                        adam = fused_adam.arm()
+                        _lib.check(lib.gsr_backward_preprocess_sh_adam(
+                            C.byref(s), P, M, _ptr(means3D), _ptr(sh), _ptr(op), _ptr(sc) if has_sc else None,
+                            _ptr(rot) if has_rot else None, _ptr(cov) if has_cov else None, _ptr(radii), _ptr(geom), rec_ptr,
+                            _ptr(dL_dmeans2D), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dscales),
+                            _ptr(dL_drot), C.byref(adam), st), "gsr_backward_preprocess_sh_adam")
+                        return
                     if ctx.grad_sync is None:
                         _lib.check(lib.gsr_rasterize_backward(C.byref(s), P, M, ctx.num_rendered, *inputs, _ptr(geom),
                                                               _ptr(binning), _ptr(img), _ptr(g_color), _ptr(g_depth), *outs,
@@ -326,7 +410,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         elif ctx.dc_mode == "cat":
             dL_ddc = dL_dsh[:, :1].reshape(ctx.dc_shape)
             dL_dsh = dL_dsh[:, 1:]
-        elif has_dc:
+        elif has_dc and dL_ddc is not None:
             dL_ddc = dL_ddc.view(ctx.dc_shape)
         return (dL_dmeans3D, dL_dmeans2D if ctx.has_means2D else None, dL_dsh, dL_dcolors if has_col else None, dL_dopacity, dL_dscales, dL_drot,
                 dL_dcov3D if has_cov else None, None, None, None, dL_ddc)

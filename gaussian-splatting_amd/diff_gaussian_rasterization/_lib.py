@@ -47,7 +47,7 @@ EXPORTS = [
     "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_backward_blend", "gsr_backward_preprocess",
     "gsr_preprocess_forward", "gsr_rasterize_from_splats",
     "gsr_route_scratch_bytes", "gsr_route_count", "gsr_route_pack", "gsr_rasterize_from_packed", "gsr_route_return",
-    "gsr_mark_visible", "gsr_forward_views", "gsr_adam_step", "gsr_adam_step_multi", "gsr_sparse_adam_step", "gsr_ssim_forward", "gsr_ssim_backward",
+    "gsr_mark_visible", "gsr_forward_views", "gsr_adam_step", "gsr_adam_step_multi", "gsr_backward_preprocess_sh_adam", "gsr_sparse_adam_step", "gsr_ssim_forward", "gsr_ssim_backward",
     "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_ssim_partial_count", "gsr_ssim_mean_forward", "gsr_ssim_mean_backward",
     "gsr_train_loss_forward", "gsr_train_loss_backward", "gsr_density_stats",
     "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_profile_counters", "gsr_set_option",
@@ -63,6 +63,13 @@ class GsrError(RuntimeError):
 def lib_path() -> str:
     return os.environ.get("GSR_LIB", _LIB_PATH)
 
+
+
+class ShAdam(C.Structure):
+    """GsrShAdam of include/gsr.h (gsr_backward_preprocess_sh_adam)."""
+    _fields_ = [("dc_exp_avg", C.c_void_p), ("dc_exp_avg_sq", C.c_void_p), ("rest_exp_avg", C.c_void_p), ("rest_exp_avg_sq", C.c_void_p),
+                ("lr_dc", C.c_double), ("lr_rest", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("step_dc", C.c_int32), ("step_rest", C.c_int32), ("sparse", C.c_int32), ("reserved", C.c_int32)]
 
 
 class AdamTensor(C.Structure):
@@ -123,6 +130,9 @@ def load() -> C.CDLL:
     lib.gsr_backward_preprocess.argtypes = [C.POINTER(GsrRasterSettings), C.c_int, C.c_int,
                                             vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                             vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_backward_preprocess_sh_adam.restype = C.c_int
+    lib.gsr_backward_preprocess_sh_adam.argtypes = [C.POINTER(GsrRasterSettings), C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                                    vp, vp, vp, vp, vp, vp, C.POINTER(ShAdam), vp]
     lib.gsr_preprocess_forward.restype = C.c_int
     lib.gsr_preprocess_forward.argtypes = [C.POINTER(GsrRasterSettings), C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_rasterize_from_splats.restype = C.c_int

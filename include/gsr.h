@@ -219,6 +219,34 @@ int gsr_route_return(int P, int n_bands, const int64_t* band_offsets, const int3
                      float* splat_grads, void* stream);
 
 /*
+ * OPT-IN fusion of the optimizer into the backward (no reference counterpart): gsr_backward_preprocess for the split-SH form
+ * (settings->sh_dc = coefficient 0 [P,1,3], shs_rest = coefficients 1..15 [P,15,3], M = 16) that does NOT write the two SH
+ * gradients but applies their Adam step in place, from the gradient tile in LDS: the gradient (204 B per Gaussian) never travels
+ * to HBM and back.  settings->sh_dc and shs_rest are read (colour clamp) and then UPDATED; the moments likewise.
+ *   sparse = 0: torch.optim.Adam on every row (rows without gradient take the g = 0 step), bias correction with step_dc / step_rest
+ *   sparse = 1: SparseGaussianAdam on the rows with radii > 0, no bias correction
+ * Every parameter comes out bit-identical to gsr_backward_preprocess followed by gsr_adam_step / gsr_sparse_adam_step on the two
+ * tensors.  The caller owns the consequences: the step happens inside backward, once per call (no gradient accumulation).
+ * All six SH arrays must be 16-byte aligned; colors_precomp is not supported in this form.
+ */
+typedef struct GsrShAdam {
+    float* dc_exp_avg;
+    float* dc_exp_avg_sq;
+    float* rest_exp_avg;
+    float* rest_exp_avg_sq;
+    double lr_dc, lr_rest, beta1, beta2, eps;
+    int32_t step_dc, step_rest;      /* 1-based, after incrementing; ignored when sparse */
+    int32_t sparse;
+    int32_t reserved;
+} GsrShAdam;
+int gsr_backward_preprocess_sh_adam(const GsrRasterSettings* settings, int P, int M, const float* means3D, float* shs_rest,
+                                    const float* opacities, const float* scales, const float* rotations,
+                                    const float* cov3D_precomp, const int32_t* radii, const void* geom_buffer,
+                                    const float* splat_grads, float* dL_dmeans2D, float* dL_dopacity, float* dL_dmeans3D,
+                                    float* dL_dcov3D, float* dL_dscales, float* dL_drotations, const GsrShAdam* adam,
+                                    void* stream);
+
+/*
  * Fused dense Adam step on one fp32 tensor of n elements (the optimizer step of train.py:177-186).
  * Same arithmetic as torch.optim.Adam(betas, eps) without weight decay / amsgrad; `step` is the 1-based step count
  * AFTER incrementing; state tensors exp_avg / exp_avg_sq are updated in place.

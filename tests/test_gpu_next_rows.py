@@ -589,3 +589,60 @@ def test_no_device_memory_growth_without_garbage_collector():
     finally:
         gc.enable()
     assert grown <= 1 << 20, f"device memory grew by {grown} bytes over 40 iterations with the garbage collector off"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sparse", "dense"])
+def test_sh_adam_fused_into_backward_equals_separate_step(kind):
+    """OPT-IN fusion (gsr_backward_preprocess_sh_adam, diff_gaussian_rasterization.fuse_sh_adam_into_backward): the per-Gaussian
+    backward applies the optimizer's step to the two SH tensors of the separate_sh form itself.  Three training iterations both
+    ways -- SparseGaussianAdam (visible rows) and gsr_optim.FusedAdam (every row, bias correction): parameters and moments come
+    out BIT-IDENTICAL, the other tensors' gradients too; P is not a multiple of 64 (ragged last block)."""
+    from diff_gaussian_rasterization import SparseGaussianAdam, fuse_sh_adam_into_backward, rasterize_gaussians
+    from gsr_optim import FusedAdam
+    dev = torch.device("cuda:0")
+    cam = make_camera(320, 240)
+    sc = make_scene(7013, cam, seed=9, s_med=0.03)
+    rs = gpu_settings(oracle_settings(cam, bg=torch.tensor([0.1, 0.2, 0.3])), dev)
+    gt = torch.rand(3, 240, 320, generator=torch.Generator().manual_seed(1)).to(dev)
+
+    def setup():
+        par = lambda t: torch.nn.Parameter(t.detach().clone().to(dev).contiguous())
+        ps = {"xyz": par(sc.means3D), "dc": par(sc.shs[:, :1]), "rest": par(sc.shs[:, 1:]), "op": par(sc.opacities),
+              "scale": par(sc.scales), "rot": par(sc.rotations)}
+        groups = [{"params": [ps[k]], "lr": lr, "name": k} for k, lr in
+                  (("xyz", 1.6e-4), ("dc", 2.5e-3), ("rest", 2.5e-3 / 20), ("op", 2.5e-2), ("scale", 5e-3), ("rot", 1e-3))]
+        opt = SparseGaussianAdam(groups, lr=0.0, eps=1e-15) if kind == "sparse" else FusedAdam(groups, lr=0.0, eps=1e-15)
+        return ps, opt
+
+    def run(fused):
+        ps, opt = setup()
+        handle = fuse_sh_adam_into_backward(opt, ps["dc"], ps["rest"]) if fused else None
+        try:
+            for it in range(3):
+                m2 = torch.zeros(ps["xyz"].shape[0], 3, device=dev, requires_grad=True)
+                img, radii, _ = rasterize_gaussians(ps["xyz"], m2, ps["rest"], None, ps["op"], ps["scale"], ps["rot"], None, rs, None,
+                                                    None, ps["dc"])
+                ((img - gt) ** 2).mean().backward()
+                if fused:
+                    assert ps["dc"].grad is None and ps["rest"].grad is None
+                if kind == "sparse":
+                    opt.step(radii > 0, radii.shape[0])
+                else:
+                    opt.step()
+                opt.zero_grad(set_to_none=True)
+        finally:
+            if handle is not None:
+                handle.remove()
+        torch.cuda.synchronize()
+        return ps, opt
+
+    a, oa = run(False)
+    b, ob = run(True)
+    for k in a:
+        assert torch.equal(a[k].detach(), b[k].detach()), f"parameter {k} differs"
+        for key in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(oa.state[a[k]][key], ob.state[b[k]][key]), (k, key)
+    assert (a["rest"].detach() - sc.shs[:, 1:].to(dev)).abs().max().item() > 0      # (the step did something)
+    if kind == "dense":
+        assert int(ob.state[b["dc"]]["step"]) == 3 and int(ob.state[b["rest"]]["step"]) == 3

@@ -62,6 +62,10 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--grad-threshold", type=float, default=0.0002, help="densify_grad_threshold (arguments/__init__.py:95)")
     ap.add_argument("--tag", default="")
+    ap.add_argument("--fuse-sh-step", action="store_true",
+                    help="opt-in: the optimizer step of f_dc / f_rest is applied by the per-Gaussian backward kernel "
+                         "(diff_gaussian_rasterization.fuse_sh_adam_into_backward); switched off on the iterations that densify, "
+                         "where the reference's loop steps nothing")
     a = ap.parse_args()
 
     from gsr_synth import look_at_camera, make_camera, make_scene
@@ -120,6 +124,15 @@ def main():
     groups = [{"params": [params[k]], "lr": lrs[k], "name": k} for k in params]
     opt = FusedAdam(groups, lr=0.0, eps=1e-15) if a.dense_adam else SparseGaussianAdam(groups, lr=0.0, eps=1e-15)
     stats = DensifyStats.zeros(P0, dev)
+    fusion = [None, None]          # handle, the f_rest tensor it was registered for
+
+    def set_fusion(on):
+        from diff_gaussian_rasterization import fuse_sh_adam_into_backward
+        if fusion[0] is not None and (not on or fusion[1] is not params["f_rest"]):
+            fusion[0].remove()
+            fusion[0] = None
+        if on and fusion[0] is None:
+            fusion[0], fusion[1] = fuse_sh_adam_into_backward(opt, params["f_dc"], params["f_rest"]), params["f_rest"]
     deg = 0
     stack = []
     sizes, window_t, losses = [], [], []
@@ -137,6 +150,8 @@ def main():
             stack = list(range(len(cams)))
         ci = stack.pop(random.randint(0, len(stack) - 1))
         P = params["xyz"].shape[0]
+        if a.fuse_sh_step:      # (the tensors change at every densification; no fused step where the loop below replaces them)
+            set_fusion(not (500 < it < 15000 and it % 100 == 0) and it < a.iters)
         m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
         img, radii, _ = GaussianRasterizer(settings(cams[ci], deg))(
             means3D=params["xyz"], means2D=m2, dc=params["f_dc"], shs=params["f_rest"], opacities=torch.sigmoid(params["opacity"]),
@@ -176,7 +191,7 @@ def main():
            "value": round(a.iters / total, 2), "unit": "it/s", "iterations": a.iters, "seconds": round(total, 2),
            "config": {"workload": f"configs[2] stand-in: P0 {P0} -> densified, {W}x{H}, {len(cams)} synthetic views cycled without "
                                   f"replacement, target scene {a.P_target} Gaussians (SURVEY 8(d) generator, seed {a.seed})",
-                      "optimizer": "FusedAdam (dense)" if a.dense_adam else "SparseGaussianAdam + separate_sh call form",
+                      "optimizer": ("FusedAdam (dense)" if a.dense_adam else "SparseGaussianAdam + separate_sh call form") + (" + SH step inside backward (opt-in fusion)" if a.fuse_sh_step else ""),
                       "schedule": f"densify 500..15000 every 100 (grad {a.grad_threshold:g}, opacity 0.005, size 20 after 3000), opacity reset / 3000, "
                                   "SH degree +1 / 1000, position lr 1.6e-4 -> 1.6e-6 x extent", "extent": ext},
            "final_P": int(params["xyz"].shape[0]), "max_P": max(sizes + [P0]), "P_every_1000_iters": sizes,
