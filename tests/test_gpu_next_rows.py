@@ -248,9 +248,13 @@ def test_bench_multi_rank_path_on_one_gpu(mode, nproc):
     import subprocess
     import sys
     from helpers import ROOT
+    import socket
+    with socket.socket() as sk:                 # a port nobody holds (a fixed one failed once in a full-suite run)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, GSR_BENCH_SHARED_GPU="1", GSR_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-           "--master-port", str(29731 + nproc + (7 if mode == "B" else 0)), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc),
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc),
            "--steps", "3", "--warmup", "1", "--P", "60000", "--width", "640", "--height", "368", "--no-cpu-baseline",
            "--min-warm-seconds", "0.2", "--mode", mode]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240, cwd=ROOT)
