@@ -622,7 +622,8 @@ ssim_bwd_march(int H, int W, int planes, int nsx, int nsy, int seg, const float*
 }
 
 int g_ssim_variant = 0;           // 0 = marching waves, 1 = LDS tiles (A/B)
-int g_ssim_target_waves = 2048;   // waves a launch of the marching form aims for (1024 SIMDs x waves per SIMD)
+// waves a launch of the marching form aims for (1024 SIMDs x waves per SIMD): [0] forward kernels, [1] backward kernels
+int g_ssim_target_waves[2] = {4096, 2048};
 
 struct MarchPlan { int nsx, nsy, seg; unsigned lds; };
 // Launch shape.  A launch has FEWER waves than the chip has slots for, and the dispatcher fills a CU to its limit before it
@@ -632,13 +633,15 @@ struct MarchPlan { int nsx, nsy, seg; unsigned lds; };
 // MPF = 4: 8 -> 52 / 35, 12 -> 71 / 45, 16 -> 55 / 38, 20 -> 57 / 40 -- the waves of one-wave workgroups reach the four SIMDs
 // in pairs, so 12 per CU run as 4 + 4 + 2 + 2; workgroups of four waves were worse still (72 / 56).  With MPF = 5 (ten
 // warm-up rows instead of twelve): 8 per CU 48.8 / 33.8, 16 per CU 50.5 / 34.6.  Two waves per SIMD do not saturate the VALU
-// (a wave issues one instruction per ~5 cycles) but carry 10 halo rows per 57 instead of per 30: `g_ssim_target_waves` = 2048.
+// (a wave issues one instruction per ~5 cycles) but carry 10 halo rows per 57 instead of per 30.  Inside the training step,
+// on the slower kind of box, two waves per SIMD leave the forward kernel waiting on memory: 77 us against 62 us with four (the
+// backward 49 against 51), reproducibly on one box; on the faster kind the two shapes are within 2 us.  Forward 4096, backward 2048.
 // 16 <= seg <= 128 rows.
-MarchPlan march_plan(int planes, int H, int W) {
+MarchPlan march_plan(int planes, int H, int W, int bwd) {
     MarchPlan p;
     p.nsx = (W + MW - 1) / MW;
     const int64_t strips = (int64_t)planes * p.nsx;
-    const int want = (int)std::max<int64_t>(1, g_ssim_target_waves / strips);       // segments per strip
+    const int want = (int)std::max<int64_t>(1, g_ssim_target_waves[bwd ? 1 : 0] / strips);       // segments per strip
     int seg = (H + want - 1) / want;
     seg = std::min(std::max(seg, 16), 128);
     p.seg = seg;
@@ -668,7 +671,7 @@ static bool ssim_use_tiles(int H, int W, bool mean_without_maps) {
 }
 
 void gsr_set_ssim_variant(int v) { g_ssim_variant = v; }
-void gsr_set_ssim_target_waves(int v) { g_ssim_target_waves = std::max(v, 256); }
+void gsr_set_ssim_target_waves(int v) { g_ssim_target_waves[0] = g_ssim_target_waves[1] = std::max(v, 256); }
 
 /* the tiled form also serves the mean forms WITHOUT derivative maps (no-grad evaluation): with nothing to store per row the  \
    marching loop compiles to 170+ registers */                                                                                    \
@@ -678,7 +681,7 @@ void gsr_set_ssim_target_waves(int v) { g_ssim_target_waves = std::max(v, 256); 
             hipLaunchKernelGGL(ssim_fwd_kernel<MODE_>, ssim_grid(planes, H, W), dim3(256), 0, st, H, W, planes, img1, img2, OUT_,  \
                                dm_dmu1, dm_dex2, dm_dexy);                                                                         \
         } else {                                                                                                                   \
-            const MarchPlan mp = march_plan(planes, H, W);                                                                         \
+            const MarchPlan mp = march_plan(planes, H, W, 0);                                                                         \
             if (dm_dmu1)                                                                                                           \
                 hipLaunchKernelGGL((ssim_fwd_march<MODE_, true>), march_grid(mp, planes), dim3(64), mp.lds, st, H, W, planes,      \
                                    mp.nsx, mp.nsy, mp.seg, img1, img2, OUT_, dm_dmu1, dm_dex2, dm_dexy);                           \
@@ -693,7 +696,7 @@ void gsr_set_ssim_target_waves(int v) { g_ssim_target_waves = std::max(v, 256); 
             hipLaunchKernelGGL(ssim_bwd_kernel<MODE_>, ssim_grid(planes, H, W), dim3(256), 0, st, H, W, planes, img1, img2, G_,    \
                                INV_, LAMBDA_, dm_dmu1, dm_dex2, dm_dexy, dL_dimg1);                                                \
         } else {                                                                                                                   \
-            const MarchPlan mp = march_plan(planes, H, W);                                                                         \
+            const MarchPlan mp = march_plan(planes, H, W, 1);                                                                         \
             hipLaunchKernelGGL(ssim_bwd_march<MODE_>, march_grid(mp, planes), dim3(64), mp.lds, st, H, W, planes, mp.nsx, mp.nsy,       \
                                mp.seg, img1, img2, G_, INV_, LAMBDA_, dm_dmu1, dm_dex2, dm_dexy, dL_dimg1);                        \
         }                                                                                                                          \
@@ -702,7 +705,7 @@ void gsr_set_ssim_target_waves(int v) { g_ssim_target_waves = std::max(v, 256); 
 // partial sums the forward that WILL run writes (per tile / per wave)
 static int64_t ssim_partials_now(int planes, int H, int W, bool no_maps) {
     if (ssim_use_tiles(H, W, no_maps)) return (int64_t)planes * ((W + TXO - 1) / TXO) * ((H + TYO - 1) / TYO);
-    const MarchPlan mp = march_plan(planes, H, W);
+    const MarchPlan mp = march_plan(planes, H, W, 0);
     return (int64_t)planes * mp.nsx * mp.nsy;
 }
 
@@ -713,7 +716,7 @@ void gsr_launch_ssim_forward(int planes, int H, int W, const float* img1, const 
 
 // callers size `partials` with this: enough for either variant
 int64_t gsr_ssim_partial_count_impl(int planes, int H, int W) {
-    const MarchPlan mp = march_plan(planes, H, W);
+    const MarchPlan mp = march_plan(planes, H, W, 0);
     return std::max((int64_t)planes * ((W + TXO - 1) / TXO) * ((H + TYO - 1) / TYO), (int64_t)planes * mp.nsx * mp.nsy);
 }
 
