@@ -912,8 +912,7 @@ int gsr_backward_blend(const GsrRasterSettings* settings, int P, int32_t num_ren
                 gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib, im.block_steps, nullptr,
                                            dL_dout_color, dL_dout_invdepth, sg, nullptr, nullptr, num_rendered, 1, nullptr, st);
         } else {
-            // instances that contributed nowhere get no record: only their flag words are cleared
-            HIP_OK(hipMemsetAsync(w.inst_flag, 0, (size_t)num_rendered * 4, st));
+            // (the flag words of the instances are cleared by the launcher: in the plan kernel's launch, or with a fill)
             gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib, im.block_steps,
                                        g_bwd_heavy_first ? im.tile_order : nullptr,
                                        dL_dout_color, dL_dout_invdepth, nullptr, w.inst_grads, w.inst_flag, num_rendered,

@@ -34,6 +34,7 @@
 // 5 dL/d(opacity*aa) 6,7,8 dL/d(rgb) 9 dL/d(1/depth) 10,11 pad.  Instance records hold the raw moments
 // (sum m dx, sum m dy, sum m dx^2, sum m dx dy, sum m dy^2) in slots 0..4 instead.
 #include "gsr_internal.h"
+#include <algorithm>
 #include "gsr_wave.h"
 
 namespace {
@@ -1035,8 +1036,17 @@ __device__ __forceinline__ int plan_bin(uint32_t w) {       // monotone; 8-step 
 // 8.9, loads batched eight deep 12.6 on a slower box): more than half of what the order saves.  Filling work bins from the
 // tail of the forward's waves instead (one returning atomic per block) was measured too: it takes the kernel out of the backward
 // and puts its cost, and a little more, into the tracking forward.
+// The same launch clears the instance flags (R bytes per record slot: 32 MB on the bench frame): workgroup 0 plans, the others
+// fill -- the plan's 9 us of dependent phases and the fill's 8 us run side by side instead of one after the other, one launch
+// boundary less.
 __global__ void __launch_bounds__(PLAN_THREADS)
-bwd_plan_kernel(int tile0, int n_band_tiles, const uint4* __restrict__ block_steps, uint32_t* __restrict__ tile_order) {
+bwd_plan_kernel(int tile0, int n_band_tiles, const uint4* __restrict__ block_steps, uint32_t* __restrict__ tile_order,
+                uint4* __restrict__ flags16, int64_t n16) {
+    if (blockIdx.x > 0) {
+        const int64_t stride = (int64_t)(gridDim.x - 1) * PLAN_THREADS;
+        for (int64_t i = (int64_t)(blockIdx.x - 1) * PLAN_THREADS + threadIdx.x; i < n16; i += stride) flags16[i] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
     __shared__ uint32_t s_bin[PLAN_WAVES][PLAN_BINS];       // 32 KB
     __shared__ uint32_t s_wsum[PLAN_WAVES];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -1101,6 +1111,7 @@ void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const
                            splats, final_T, n_contrib, dL_dpix, dL_dinvdepth, splat_grads);
         return;
     }
+    if (variant == 4 || variant == 5) (void)hipMemsetAsync(inst_flag, 0, (size_t)R * 4, st);
     if (variant == 4) {
         hipLaunchKernelGGL(render_bwd_tile<256>, dim3(n_band_tiles), dim3(256), 0, st, cam, ranges, point_list, splats,
                            final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads),
@@ -1116,11 +1127,17 @@ void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const
 #endif
     (void)variant; (void)splat_grads; (void)groups;
     const int groups16 = (n_band_tiles + 15) / 16;
-    if (tile_order && block_steps)
-        hipLaunchKernelGGL(bwd_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, cam.tile_y0 * cam.gx, n_band_tiles,
-                           reinterpret_cast<const uint4*>(block_steps), tile_order);
-    else
+    // instances that contributed nowhere get no record: only their flag words are cleared (the caller's scratch is carved in
+    // 128-byte steps, so whole 16-byte words belong to the flag array)
+    const int64_t n16 = (R * 4 + 15) / 16;
+    if (tile_order && block_steps) {
+        const int fill_blocks = (int)std::min<int64_t>(2048, (n16 + PLAN_THREADS - 1) / PLAN_THREADS);
+        hipLaunchKernelGGL(bwd_plan_kernel, dim3(1 + fill_blocks), dim3(PLAN_THREADS), 0, st, cam.tile_y0 * cam.gx, n_band_tiles,
+                           reinterpret_cast<const uint4*>(block_steps), tile_order, reinterpret_cast<uint4*>(inst_flag), n16);
+    } else {
         tile_order = nullptr;
+        (void)hipMemsetAsync(inst_flag, 0, (size_t)R * 4, st);
+    }
     if (dL_dinvdepth)
         hipLaunchKernelGGL(render_bwd_half<true>, dim3(groups16 * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list, splats,
                            final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads),
