@@ -6,8 +6,10 @@
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one forward render of the whole frame (preprocess -> depth sort -> scan -> emit -> tile sort -> ranges
--> blend, including the 4-byte num_rendered read-back) of the synthetic stand-in for configs[1] ("garden", ~1 M
-Gaussians, 1080p): P = 1e6, 1920x1080, SURVEY.md 8(d) generator, seed 0, s_med 0.012.  With N > 1 GPUs the SAME
+-> blend, including the 8-byte num_rendered read-back) of the synthetic stand-in for configs[1] ("garden", ~1 M
+Gaussians, 1080p): P = 1e6, 1920x1080, SURVEY.md 8(d) generator, seed 0, s_med 0.012.  The library bins every Gaussian into
+the snug tile rectangle of its alpha >= 1/255 ellipse (config.num_rendered); the instances the reference's tile squares would
+hold are reported beside it (config.num_rendered_reference_tile_squares) -- the outputs are the same bits either way.  With N > 1 GPUs the SAME
 frame is rendered by all ranks together (strong scaling) in mode C of diff_gaussian_rasterization/parallel.py: rank g owns
 P/N Gaussians and a band of tile rows, projects its shard, sends every projected splat only to the ranks whose band it
 touches (one variable-size all-to-all of 48-byte records), bins + blends its band and the strips are all-gathered over
@@ -20,7 +22,9 @@ The JSON line also carries
   train_iters_per_s : forward + loss + backward + Adam on all parameters, a NEW CAMERA EVERY ITERATION (train.py:96-102:
                       --views synthetic cameras around the generating one, cycled), steps/s; legs for the dense fused Adam,
                       for the reference's accelerated call form (SparseGaussianAdam + separate SH tensors,
-                      train.py:37-41,180-183) and for L1 only
+                      train.py:37-41,180-183), for L1 only, with density control every 100 iterations
+                      (train_iters_per_s_densify) and -- opt-in, no reference counterpart -- with the Adam step of the two SH
+                      tensors applied inside the per-Gaussian backward (train_iters_per_s_sh_step_in_backward)
   stages            : every pipeline stage with its mean HIP-event duration, algorithmic bytes (SURVEY.md 8(d) terms) and
                       the GB/s / fraction of 8 TB/s that gives
   roofline          : the dominant kernel of the forward (the blend).  It is fp32-VALU bound (SQ counters: VALU issue, not
