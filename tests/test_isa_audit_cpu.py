@@ -18,7 +18,7 @@ LEGACY = ("ItLi",)
 
 
 @pytest.mark.parametrize("unit", ["sort.hip", "binning.hip", "tilesort.hip", "render_fwd.hip", "render_bwd.hip", "ssim.hip", "adam.hip",
-                                  "preprocess.hip"])
+                                  "preprocess.hip", "route.hip", "density.hip"])
 def test_no_serial_load_chains_spills_or_stray_flat_accesses(unit):
     import isa_audit
     rows = isa_audit.audit(os.path.join(isa_audit.CSRC, unit), isa_audit.UNITS[unit], [])
