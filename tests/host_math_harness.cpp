@@ -29,6 +29,11 @@ static GsrCam to_cam(const HostCam* h) {
     return c;
 }
 
+// tau = 2 ln(255 opacity) + 0.01 for n opacities (csrc/gsr_math.h gsr_tau)
+void host_tau(int n, const float* opacity, float* out) {
+    for (int i = 0; i < n; ++i) out[i] = gsr_tau(opacity[i]);
+}
+
 // out_f[P][12] = px,py,conA,conB,conC,opacity,r,g,b,depth,tau,0 ; out_i[P][8] = radius,minx,miny,maxx,maxy,tiles,clamped,visible
 void host_preprocess(const HostCam* hc, int P, const float* means, const float* scales, const float* rots,
                      const float* cov_pre, const float* opac, const float* shs, const float* colors,

@@ -169,3 +169,22 @@ def test_sh_backward_all_degrees_and_ragged_blocks(deg, M):
     assert np.abs(o["sh"][:, (deg + 1) ** 2:]).max() == 0 if M > (deg + 1) ** 2 else True
     mref = m.grad.numpy() if m.grad is not None else np.zeros((P, 3), np.float32)   # degree 0 is view independent
     assert np.abs(o["m3"] - mref).max() <= 2e-4 * max(1e-9, np.abs(mref).max())
+
+
+def test_tau_bitwise_over_the_whole_opacity_range():
+    """gsr_tau (host build of csrc/gsr_math.h) == the oracle's restatement, bit for bit: 200 000 opacities from denormal to 1,
+    the threshold 1/255 and its neighbours, 0, infinities and NaN."""
+    lib = host_math_lib()
+    g = torch.Generator().manual_seed(11)
+    op = torch.cat([torch.exp(torch.rand(200000, generator=g) * 100.0 - 100.0), torch.rand(20000, generator=g),
+                    torch.tensor([0.0, 1.0, 1.0 / 255.0, float(np.nextafter(np.float32(1 / 255), np.float32(1))),
+                                  float(np.nextafter(np.float32(1 / 255), np.float32(0))), 1e-45, float("inf"), -0.5])]).to(torch.float32)
+    a = np32(op)
+    out = np.empty_like(a)
+    lib.host_tau(len(a), fptr(a), fptr(out))
+    ref = O.tau_of_opacity(op).numpy()
+    np.testing.assert_array_equal(out.view(np.uint32), ref.view(np.uint32))
+    nan_in = np.array([np.nan], dtype=np.float32)
+    nan_out = np.empty(1, dtype=np.float32)
+    lib.host_tau(1, fptr(nan_in), fptr(nan_out))
+    assert np.isnan(nan_out[0]) and np.isnan(O.tau_of_opacity(torch.tensor([float("nan")])).numpy()[0])

@@ -246,6 +246,21 @@ def test_snug_tiles_change_no_output(maker, aa, size):
     assert torch.equal(n0 > 0, n1 > 0)
 
 
+def test_deterministic_logarithm_is_a_logarithm():
+    """det_log (frexp + atanh series in fp64, the restatement of csrc/gsr_math.h gsr_log_det) against libm over 90 decades, and
+    tau = 2 ln(255 opacity) + 0.01 at the edges of its domain."""
+    v = torch.exp(torch.linspace(-103.0, 103.0, 200001, dtype=torch.float64))
+    v = torch.cat([v, torch.tensor([1.0, 2.0, 0.5, 255.0, 1.0 + 2 ** -52, 2.0 ** -149 * 255.0], dtype=torch.float64)])
+    err = (O.det_log(v) - torch.log(v)).abs()
+    assert float(err.max()) <= 3e-14 * max(1.0, float(torch.log(v).abs().max())), float(err.max())
+    assert float(O.det_log(torch.tensor([1.0], dtype=torch.float64))) == 0.0
+    op = torch.tensor([0.0, 1.0 / 255.0, 0.5, 1.0, float("inf"), float("nan"), -0.1, 1e-45], dtype=torch.float32)
+    tau = O.tau_of_opacity(op)
+    assert tau[0] == -math.inf and abs(float(tau[1]) - 0.01) < 1e-6 and abs(float(tau[2]) - (2 * math.log(127.5) + 0.01)) < 1e-6
+    assert abs(float(tau[3]) - (2 * math.log(255.0) + 0.01)) < 1e-6 and tau[4] == math.inf and math.isnan(float(tau[5])) and math.isnan(float(tau[6]))
+    assert float(tau[7]) < -190.0          # a denormal opacity: finite, far below every q
+
+
 @pytest.mark.parametrize("seed,aa", [(3, False), (4, True)])
 def test_snug_rectangle_holds_every_pixel_that_can_contribute(seed, aa):
     """Pixel by pixel, for adversarial splats -- needles with aspect ratios up to 1e4 at every angle, splats larger than the frame,
