@@ -25,8 +25,22 @@ def run_host_fwd(s, sc, scale_mod=1.0, colors=None, cov=None, tile_rows=(0, 0)):
     return out_f, out_i, out_cov
 
 
+def _needle_scene(cam, seed=3, P=4000):
+    """Adversarial footprints for the snug tile rectangle: per-axis scales from 1e-3 to 10 (aspect ratios up to 1e4 at every
+    angle, splats larger than the frame), opacities from 9e-4 to 1 and a seventh of them within 1 % of the 1/255 threshold."""
+    g = torch.Generator().manual_seed(seed)
+    sc = make_scene(P, cam, seed=seed, s_med=0.05, overscan=1.5)
+    sc.scales[:] = torch.exp(torch.rand(P, 3, generator=g) * 9.2 - 6.9)
+    sc.rotations[:] = torch.nn.functional.normalize(torch.randn(P, 4, generator=g), dim=1)
+    sc.opacities[:] = torch.exp(torch.rand(P, 1, generator=g) * 7.0 - 7.0)
+    sc.opacities[::7] = (1.0 / 255.0) * (1.0 + (torch.rand(sc.opacities[::7].shape, generator=g) - 0.5) * 0.02)
+    return sc
+
+
 CASES = [
     ("c1", lambda: make_camera(256, 256), lambda cam: make_scene(1000, cam, seed=0), False),
+    ("needles", lambda: look_at_camera(640, 360, (0.3, -0.2, -0.5), (0.0, 0.0, 4.0)), lambda cam: _needle_scene(cam), False),
+    ("needles_aa", lambda: look_at_camera(333, 200, (0.1, 0.2, -0.5), (0.0, 0.0, 4.0)), lambda cam: _needle_scene(cam, seed=9), True),
     ("odd_aa", lambda: make_camera(250, 131), lambda cam: make_scene(3000, cam, seed=3, s_med=0.02), True),
     ("edge_lookat", lambda: look_at_camera(333, 200, (0.3, -0.2, -1.0), (0.1, 0.0, 3.0)),
      lambda cam: make_edge_scene(4000, cam, seed=5), False),
