@@ -4,7 +4,7 @@
 
 Translation units and their flags:
   preprocess.hip   -ffp-contract=off   (bit-exact radii / tile counts, see csrc/gsr_math.h)
-  sort.hip, binning.hip                (integer)
+  sort.hip, depthsort.hip, binning.hip (integer)
   render_fwd.hip, render_bwd.hip       (FMA contraction allowed; image tolerance 1e-5)
   gsr_api.cpp                          (host glue, C ABI)
 The library is built IN-TREE (gaussian-splatting_amd/lib/) so it travels to the GPU box with the snapshot.
@@ -33,6 +33,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path
 UNITS = [
     ("preprocess.hip", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]),
     ("sort.hip", []),
+    ("depthsort.hip", []),
     ("binning.hip", []),
     ("tilesort.hip", []),
     ("route.hip", []),

@@ -3,6 +3,7 @@
 // redesigned for wave64 (algorithm: SURVEY.md Appendix A.3).
 #include "gsr_internal.h"
 #include "gsr_wave.h"
+#include "gsr_frame.h"
 
 namespace {
 
@@ -67,7 +68,7 @@ scan_block_sums(int P, const uint32_t* __restrict__ order, const uint2* __restri
 __global__ void __launch_bounds__(SC_THREADS)
 scan_finish(int P, const uint2* __restrict__ rect_sorted, const uint64_t* __restrict__ block_sums,
             uint32_t* __restrict__ offsets, uint2* __restrict__ block_first, uint32_t block_first_cap,
-            uint32_t* __restrict__ num_rendered, uint32_t* host_word, uint32_t seq, const uint32_t* __restrict__ sort_err) {
+            uint32_t* __restrict__ num_rendered, uint32_t* host_word, uint32_t seq) {
     __shared__ uint64_t wsum[SC_THREADS / 64];
     __shared__ uint64_t wtot[SC_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -119,7 +120,6 @@ scan_finish(int P, const uint2* __restrict__ rect_sorted, const uint64_t* __rest
             }
         }
         if (base + k == (int64_t)P - 1) {
-            if (sort_err && *sort_err) run = ~0ull;      // the depth sort reported a spin time-out: the host must not go on
             num_rendered[0] = (uint32_t)run;
             num_rendered[1] = (uint32_t)(run >> 32);
             if (host_word) {   // publish R to the spinning host: value first, then the sequence number (system-scope release)
@@ -244,11 +244,8 @@ tile_ranges(int64_t R, const KeyT* __restrict__ keys, uint2* __restrict__ ranges
 // when it runs with the band itself.
 __global__ void __launch_bounds__(256)
 splat_ingest(int P, const float4* __restrict__ records, int y0, int y1, float4* __restrict__ splats, uint2* __restrict__ rect,
-             uint32_t* __restrict__ tiles, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-             uint32_t* __restrict__ sort_state, uint32_t* key_overflow) {
-    if (sort_state && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < GSR_OS_STATE_WORDS; i += 256) sort_state[i] = 0u;
-    bool key_ovf = false;
+             uint32_t* __restrict__ tiles, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GsrFrameStatsDev fs) {
+    GsrFrameAcc acc;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 q0 = records[i * 4 + 0], q1 = records[i * 4 + 1], q2 = records[i * 4 + 2], q3 = records[i * 4 + 3];
         const uint32_t rx = __float_as_uint(q3.x), ry = __float_as_uint(q3.y), full = __float_as_uint(q3.w);
@@ -263,10 +260,12 @@ splat_ingest(int P, const float4* __restrict__ records, int y0, int y1, float4* 
         splats[i * 4 + 3] = make_float4(__uint_as_float(rc.x), __uint_as_float(rc.y), 0.f, __uint_as_float(t));
         rect[i] = rc;
         tiles[i] = t;
-        keys[i] = gsr_depth_key(q2.y, t != 0u, key_ovf);      // q2.y = view-space depth
+        const uint32_t key = gsr_depth_key(q2.y, t != 0u, acc.ovf);      // q2.y = view-space depth
+        keys[i] = key;
         vals[i] = (uint32_t)i;
+        acc.add(key, t);
     }
-    gsr_report_key_overflow(key_ovf, key_overflow);
+    gsr_frame_stats_commit(fs, acc.tiles, acc.kmin, acc.kmax, acc.ovf);
 }
 
 // fallback of the 27-bit depth sort (a listed Gaussian deeper than 13 107): the full 32-bit keys of round 2
@@ -282,12 +281,12 @@ rekey_full(int P, const float4* __restrict__ splats, const uint32_t* __restrict_
 }  // namespace
 
 void gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
-                             uint32_t* keys, uint32_t* vals, uint32_t* sort_state, uint32_t* key_overflow, hipStream_t st) {
+                             uint32_t* keys, uint32_t* vals, const GsrFrameStatsDev& fs, hipStream_t st) {
     int64_t nb = ((int64_t)P + 255) / 256;
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(splat_ingest, dim3((int)nb), dim3(256), 0, st, P, reinterpret_cast<const float4*>(records), y0, y1, splats,
-                       rect, tiles, keys, vals, sort_state, key_overflow);
+                       rect, tiles, keys, vals, fs);
 }
 
 void gsr_launch_rekey_full(int P, const float4* splats, const uint32_t* tiles, uint32_t* keys, uint32_t* vals, hipStream_t st) {
@@ -299,14 +298,14 @@ void gsr_launch_rekey_full(int P, const float4* splats, const uint32_t* tiles, u
 
 void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint2* rect, uint2* rect_sorted, uint32_t* offsets,
                            uint64_t* block_sums, uint2* block_first, uint32_t block_first_cap, uint32_t* num_rendered,
-                           uint32_t* host_word, uint32_t seq, bool rect_already_sorted, const uint32_t* sort_err, hipStream_t st) {
+                           uint32_t* host_word, uint32_t seq, bool rect_already_sorted, hipStream_t st) {
     const int nb = (P + GSR_SCAN_ITEMS - 1) / GSR_SCAN_ITEMS;
     if (rect_already_sorted)
         hipLaunchKernelGGL(scan_block_sums<false>, dim3(nb), dim3(SC_THREADS), 0, st, P, order, rect, rect_sorted, block_sums);
     else
         hipLaunchKernelGGL(scan_block_sums<true>, dim3(nb), dim3(SC_THREADS), 0, st, P, order, rect, rect_sorted, block_sums);
     hipLaunchKernelGGL(scan_finish, dim3(nb), dim3(SC_THREADS), 0, st, P, rect_sorted, block_sums, offsets, block_first,
-                       block_first_cap, num_rendered, host_word, seq, sort_err);
+                       block_first_cap, num_rendered, host_word, seq);
 }
 
 void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect,

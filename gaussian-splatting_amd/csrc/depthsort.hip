@@ -1,0 +1,571 @@
+// Depth order of the P Gaussians in FOUR launches: one bucket pass over the keys, then every bucket finished in LDS.
+// Replaces (for P <= GSR_DS_MAX_P) the nine launches of the 3 x 9-bit LSD radix sort (sort.hip) AND the two launches of the
+// tile-count scan (binning.hip) -- the reference's cub::DeviceRadixSort / InclusiveSum pair of SURVEY Appendix A.3, whose
+// (tile | depth) order this pipeline reaches as "depth order of the Gaussians, then a stable sort of the instances by tile".
+//
+// Why: at 1 M keys every radix kernel is a 5-14 us latency chain (76.8 us for 80 MB = 0.13 of HBM
+// peak, 12 us more for the scan).  Bytes are irrelevant; the number of dependent launches is the cost.
+//
+//   ds_hist     per workgroup of 4096 keys: histogram over 2048 depth buckets of (a) the keys, (b) their tile counts.
+//               The bucket of a key is (key - kmin) >> shift with kmin / kmax from the key-producing kernel (gsr_frame.h), so
+//               the 2046 usable buckets always span exactly the frame's depth range; Gaussians without a tile take
+//               bucket 2047 and end up behind everything else, as in the LSD sort.
+//   ds_scan     per bucket: exclusive prefix of the counts over the workgroups (in place) + the bucket totals of both tables
+//   ds_scatter  stable scatter (wave64 ballot ranking, no atomics) of (key, id) pairs into bucket order; the tile-less
+//               Gaussians go straight to the tail of the final arrays.  One extra workgroup cuts the bucket-ordered array
+//               into SEGMENTS: the buckets whose first element lies in the same window of 2048 elements (a segment is a whole
+//               number of buckets, usually 2-4 K elements) and records, per segment, its element range, its bucket range and
+//               the number of tile instances in front of it (exclusive scan of the bucket tile totals).
+//   ds_segsort  one workgroup per segment: stable LSD radix sort of the segment in LDS on (key - first key of the segment's
+//               first bucket), 2-3 passes of <= 9 bits; then, in sorted order: Gaussian id, its tile rectangle (gathered),
+//               the INCLUSIVE SCAN of the tile counts (segment base + scan inside the segment) and the per-block table of the
+//               emission -- everything the depth sort's last pass and the two scan kernels used to produce.
+//               A segment beyond the LDS capacity (one bucket holding > 2048 keys more than the window: thousands of Gaussians
+//               within 1/2046 of the depth range) is sorted by the same workgroup with the same passes through global memory --
+//               correct, slow, and reported to the host, which then prefers the LSD sort for a while (gsr_api.cpp).
+//
+// Order: (key, Gaussian index) ascending -- ds_scatter is stable and the segment sort is stable, so equal depths keep index
+// order exactly as the LSD sort (and the reference's stable 64-bit-key sort) leaves them.  No atomics on global memory, no
+// spinning, bit-reproducible.
+#include "gsr_internal.h"
+#include "gsr_wave.h"
+
+using namespace gsrw;
+
+namespace {
+
+constexpr int DS_THREADS = 256;
+constexpr int DS_ITEMS = GSR_DS_ITEMS;
+constexpr int DS_IPT = DS_ITEMS / DS_THREADS;          // 16
+constexpr int DS_NB = GSR_DS_BUCKETS;                  // 2048
+constexpr uint32_t DS_CULL = DS_NB - 1u;
+constexpr int DS_DPT = DS_NB / DS_THREADS;             // 8 buckets per thread
+constexpr int DS_SEG = GSR_DS_SEG;
+constexpr int DS_CAP = GSR_DS_CAP;
+constexpr int DS_OUT = DS_CAP / DS_THREADS;            // 16 elements per thread in the output phase
+constexpr int DS_PASS_BITS = 9;
+constexpr int DS_PASS_BINS = 1 << DS_PASS_BITS;
+static_assert(DS_IPT == 16 && DS_DPT == 8 && DS_OUT == 16, "layout");
+
+// smallest shift with (kmax - kmin) >> shift <= 2046 (bucket 2047 is reserved)
+__device__ __forceinline__ int ds_shift(uint32_t kmin, uint32_t kmax) {
+    if (kmax <= kmin) return 0;
+    const uint32_t range = kmax - kmin;
+    int s = 32 - __clz((int)range) - GSR_DS_BITS;
+    if (s < 0) s = 0;
+    if ((range >> s) > (uint32_t)DS_NB - 2u) ++s;
+    return s;
+}
+__device__ __forceinline__ uint32_t ds_bucket(uint32_t key, uint32_t kmin, int shift) {
+    return key == GSR_DEPTH_KEY_CULLED ? DS_CULL : (key - kmin) >> shift;
+}
+
+// four consecutive words, vector load when whole (p + e0 is 16-byte aligned: e0 is a multiple of 4, arrays are 128-byte aligned)
+__device__ __forceinline__ void load4(const uint32_t* __restrict__ p, int64_t e0, int64_t n, uint32_t fill, uint32_t (&o)[4]) {
+    if (e0 + 4 <= n) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p + e0);
+        o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = e0 + j < n ? p[e0 + j] : fill;
+    }
+}
+
+// ---- D1 ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(DS_THREADS)
+ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ frame,
+        uint32_t* __restrict__ cnt_tab, uint32_t* __restrict__ tile_tab) {
+    __shared__ uint32_t h_cnt[DS_NB], h_tile[DS_NB];
+    const int tid = threadIdx.x;
+    const uint32_t kmin = frame[2], kmax = frame[3];
+    const int shift = ds_shift(kmin, kmax);
+    const int64_t base = (int64_t)blockIdx.x * DS_ITEMS;
+    uint32_t k[4][4], t[4][4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {      // all loads first, the LDS clear rides in their shadow
+        const int64_t e0 = base + ((int64_t)v * DS_THREADS + tid) * 4;
+        load4(keys, e0, P, GSR_DEPTH_KEY_CULLED, k[v]);
+        load4(tiles, e0, P, 0u, t[v]);
+    }
+#pragma unroll
+    for (int i = 0; i < DS_DPT; ++i) {
+        h_cnt[i * DS_THREADS + tid] = 0u;
+        h_tile[i * DS_THREADS + tid] = 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int64_t e0 = base + ((int64_t)v * DS_THREADS + tid) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (e0 + j < P) {
+                const uint32_t d = ds_bucket(k[v][j], kmin, shift);
+                atomicAdd(&h_cnt[d], 1u);
+                if (t[v][j]) atomicAdd(&h_tile[d], t[v][j]);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* crow = cnt_tab + (int64_t)blockIdx.x * DS_NB;
+    uint32_t* trow = tile_tab + (int64_t)blockIdx.x * DS_NB;
+#pragma unroll
+    for (int i = 0; i < DS_DPT; ++i) {
+        crow[i * DS_THREADS + tid] = h_cnt[i * DS_THREADS + tid];
+        trow[i * DS_THREADS + tid] = h_tile[i * DS_THREADS + tid];
+    }
+}
+
+// ---- D2 ------------------------------------------------------------------------------------------------------------
+// tables are [workgroup][bucket]; a workgroup of this kernel owns 16 buckets, thread = (bucket, 1/16 of the rows): the 16
+// lanes of a row segment read 64 contiguous bytes.  cnt_tab[b][d] <- keys of bucket d in workgroups < b; totals of both tables.
+__global__ void __launch_bounds__(DS_THREADS)
+ds_scan(int nblocks, uint32_t* __restrict__ cnt_tab, const uint32_t* __restrict__ tile_tab, uint32_t* __restrict__ cnt_total,
+        uint32_t* __restrict__ tile_total) {
+    __shared__ uint32_t s_c[16][16], s_t[16][16];
+    const int tid = threadIdx.x, dl = tid & 15, bg = tid >> 4;
+    const int d = blockIdx.x * 16 + dl;
+    const int chunk = (nblocks + 15) / 16;
+    const int lo = min(bg * chunk, nblocks), hi = min(lo + chunk, nblocks);
+    constexpr int KEEP = 16;            // rows per thread kept in registers between the two sweeps (<= 256 workgroups = 1 M keys)
+    const bool keep = chunk <= KEEP;
+    uint32_t v[KEEP];
+    uint32_t csum = 0, tsum = 0;
+    if (keep) {
+        uint32_t tt[KEEP];
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {      // unconditional loads (clamped row): one round trip for all of them
+            const int b = min(lo + k, nblocks - 1);
+            v[k] = cnt_tab[(int64_t)b * DS_NB + d];
+            tt[k] = tile_tab[(int64_t)b * DS_NB + d];
+        }
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            if (lo + k >= hi) { v[k] = 0u; tt[k] = 0u; }
+            csum += v[k];
+            tsum += tt[k];
+        }
+    } else {
+#pragma unroll 4
+        for (int b = lo; b < hi; ++b) {
+            csum += cnt_tab[(int64_t)b * DS_NB + d];
+            tsum += tile_tab[(int64_t)b * DS_NB + d];
+        }
+    }
+    s_c[bg][dl] = csum;
+    s_t[bg][dl] = tsum;
+    __syncthreads();
+    uint32_t run = 0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g)
+        if (g < bg) run += s_c[g][dl];
+    if (bg == 15) cnt_total[d] = run + csum;
+    if (bg == 0) {
+        uint32_t tt = 0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) tt += s_t[g][dl];
+        tile_total[d] = tt;
+    }
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            if (lo + k < hi) cnt_tab[(int64_t)(lo + k) * DS_NB + d] = run;
+            run += v[k];
+        }
+    } else {
+#pragma unroll 4
+        for (int b = lo; b < hi; ++b) {
+            const uint32_t c = cnt_tab[(int64_t)b * DS_NB + d];
+            cnt_tab[(int64_t)b * DS_NB + d] = run;
+            run += c;
+        }
+    }
+}
+
+// ---- D3 ------------------------------------------------------------------------------------------------------------
+// plan entry of segment s (8 words): begin, end (elements of the bucket-ordered array), first bucket, end bucket, tile
+// instances in front of the segment, 0, 0, 0
+__global__ void __launch_bounds__(DS_THREADS)
+ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ frame,
+           const uint32_t* __restrict__ cnt_tab, const uint32_t* __restrict__ cnt_total, const uint32_t* __restrict__ tile_total,
+           uint2* __restrict__ pairs, uint32_t* __restrict__ order, uint32_t* __restrict__ offsets, uint2* __restrict__ rect_sorted,
+           uint32_t* __restrict__ plan, int nseg_cap) {
+    __shared__ uint32_t wave_cnt[WG_WAVES][DS_NB];      // 32 KB
+    __shared__ uint32_t digit_base[DS_NB];              //  8 KB
+    __shared__ uint32_t wsum[WG_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+    if ((int)blockIdx.x == nblocks) {
+        // ---- the segment plan (one workgroup, beside the scattering ones) ----
+        uint32_t* cnt_excl = wave_cnt[0];      // [2048]; entry 2047 = number of listed Gaussians
+        uint32_t* tile_excl = wave_cnt[1];
+        uint32_t c[DS_DPT], t[DS_DPT];
+        {
+            const uint4 a0 = reinterpret_cast<const uint4*>(cnt_total)[2 * tid], a1 = reinterpret_cast<const uint4*>(cnt_total)[2 * tid + 1];
+            const uint4 b0 = reinterpret_cast<const uint4*>(tile_total)[2 * tid], b1 = reinterpret_cast<const uint4*>(tile_total)[2 * tid + 1];
+            c[0] = a0.x; c[1] = a0.y; c[2] = a0.z; c[3] = a0.w; c[4] = a1.x; c[5] = a1.y; c[6] = a1.z; c[7] = a1.w;
+            t[0] = b0.x; t[1] = b0.y; t[2] = b0.z; t[3] = b0.w; t[4] = b1.x; t[5] = b1.y; t[6] = b1.z; t[7] = b1.w;
+        }
+        uint32_t crun = block_excl_scan<DS_DPT>(c, wsum, lane, w);
+        uint32_t trun = block_excl_scan<DS_DPT>(t, wsum, lane, w);
+#pragma unroll
+        for (int i = 0; i < DS_DPT; ++i) {
+            cnt_excl[tid * DS_DPT + i] = crun;
+            tile_excl[tid * DS_DPT + i] = trun;
+            crun += c[i];
+            trun += t[i];
+        }
+        __syncthreads();
+        const uint32_t listed = cnt_excl[DS_CULL];
+        auto lower_bound = [&](uint32_t x) {      // first bucket in [0, 2047] whose first element is >= x (2047 if none)
+            uint32_t lo = 0, hi = DS_CULL;
+#pragma unroll 1
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (cnt_excl[mid] >= x) hi = mid; else lo = mid + 1;
+            }
+            return lo;
+        };
+        for (int s = tid; s < nseg_cap; s += DS_THREADS) {
+            uint4 e = make_uint4(0u, 0u, 0u, 0u);
+            uint32_t tb = 0;
+            const uint64_t x0 = (uint64_t)s * DS_SEG;
+            if (x0 < listed) {
+                const uint32_t d0 = lower_bound((uint32_t)x0);
+                const uint64_t x1 = x0 + DS_SEG;
+                const uint32_t d1 = x1 >= listed ? DS_CULL : lower_bound((uint32_t)x1);
+                e = make_uint4(cnt_excl[d0], cnt_excl[d1], d0, d1);
+                tb = tile_excl[d0];
+            }
+            reinterpret_cast<uint4*>(plan)[2 * s] = e;
+            reinterpret_cast<uint4*>(plan)[2 * s + 1] = make_uint4(tb, 0u, 0u, 0u);
+        }
+        return;
+    }
+
+    const uint32_t kmin = frame[2], kmax = frame[3], R32 = frame[0];
+    const int shift = ds_shift(kmin, kmax);
+    // the workgroup's keys are requested first: their trip overlaps the bucket-base prologue below.  Wave w owns the
+    // contiguous run [w * 1024, w * 1024 + 1024) of the workgroup's keys, item r of a lane is key r * 64 + lane of the run
+    const int64_t wave_base = (int64_t)blockIdx.x * DS_ITEMS + (int64_t)w * (64 * DS_IPT);
+    uint32_t key[DS_IPT];
+#pragma unroll
+    for (int r = 0; r < DS_IPT; ++r) {
+        const int64_t idx = wave_base + r * 64 + lane;
+        key[r] = keys[idx < P ? idx : (int64_t)P - 1];
+    }
+    {   // digit_base[d] = (exclusive scan of the bucket totals)[d] + keys of bucket d in earlier workgroups
+        uint32_t v[DS_DPT], bh[DS_DPT];
+        const uint4* tot4 = reinterpret_cast<const uint4*>(cnt_total);
+        const uint4* row4 = reinterpret_cast<const uint4*>(cnt_tab + (int64_t)blockIdx.x * DS_NB);
+        const uint4 a0 = tot4[2 * tid], a1 = tot4[2 * tid + 1], b0 = row4[2 * tid], b1 = row4[2 * tid + 1];
+        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+        bh[0] = b0.x; bh[1] = b0.y; bh[2] = b0.z; bh[3] = b0.w; bh[4] = b1.x; bh[5] = b1.y; bh[6] = b1.z; bh[7] = b1.w;
+        uint32_t run = block_excl_scan<DS_DPT>(v, wsum, lane, w);
+#pragma unroll
+        for (int i = 0; i < DS_DPT; ++i) {
+            const int d = tid * DS_DPT + i;
+            digit_base[d] = run + bh[i];
+#pragma unroll
+            for (int k = 0; k < WG_WAVES; ++k) wave_cnt[k][d] = 0u;
+            run += v[i];
+        }
+    }
+    __syncthreads();
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint32_t rank[DS_IPT], dig[DS_IPT];
+#pragma unroll
+    for (int r = 0; r < DS_IPT; ++r) {
+        const int64_t idx = wave_base + r * 64 + lane;
+        const bool valid = idx < P;
+        const uint32_t d = ds_bucket(key[r], kmin, shift);
+        dig[r] = d;
+        const uint64_t mask = match_digit(d, GSR_DS_BITS, __ballot(valid));
+        const uint32_t prior = valid ? wave_cnt[w][d] : 0u;
+        rank[r] = prior + (uint32_t)__popcll(mask & lt_mask);
+        if (valid && (mask & lt_mask) == 0ull) wave_cnt[w][d] = prior + (uint32_t)__popcll(mask);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // keys of a bucket are few per workgroup (4096 keys over ~1000+ buckets): no LDS staging, every pair goes straight to
+    // its slot; per bucket the waves' counts become exclusive offsets
+#pragma unroll
+    for (int i = 0; i < DS_DPT; ++i) {
+        const int d = tid * DS_DPT + i;
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < WG_WAVES; ++k) {
+            const uint32_t t = wave_cnt[k][d];
+            wave_cnt[k][d] = run;
+            run += t;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < DS_IPT; ++r) {
+        const int64_t idx = wave_base + r * 64 + lane;
+        if (idx < P) {
+            const uint32_t d = dig[r];
+            const uint32_t pos = digit_base[d] + wave_cnt[w][d] + rank[r];
+            if (d != DS_CULL) {
+                pairs[pos] = make_uint2(key[r], (uint32_t)idx);
+            } else {      // no tile: behind every listed Gaussian, in index order; the inclusive scan stays at R
+                order[pos] = (uint32_t)idx;
+                offsets[pos] = R32;
+                rect_sorted[pos] = make_uint2(0u, 0u);
+            }
+        }
+    }
+}
+
+// ---- D4 ------------------------------------------------------------------------------------------------------------
+struct SegLds {
+    uint32_t (*key)[DS_CAP];
+    uint16_t (*idx)[DS_CAP];
+    __device__ __forceinline__ void load(int buf, uint32_t i, uint32_t& k, uint32_t& v) const { k = key[buf][i]; v = idx[buf][i]; }
+    __device__ __forceinline__ void store(int buf, uint32_t i, uint32_t k, uint32_t v) const { key[buf][i] = k; idx[buf][i] = (uint16_t)v; }
+};
+struct SegGlobal {      // the segment's slice of the two pair arrays; keys are rebased on the fly
+    uint2* p[2];
+    uint32_t base_key;
+    __device__ __forceinline__ void load(int buf, uint32_t i, uint32_t& k, uint32_t& v) const {
+        const uint2 t = p[buf][i];
+        k = t.x - base_key; v = t.y;
+    }
+    __device__ __forceinline__ void store(int buf, uint32_t i, uint32_t k, uint32_t v) const { p[buf][i] = make_uint2(k + base_key, v); }
+};
+
+// Stable LSD radix sort of n (key, value) items held in buffer 0 of `m` on the low `nbits` key bits, passes of <= 9 bits,
+// by the whole workgroup.  Returns the buffer that holds the result.  Wave w owns a contiguous quarter of the items; per pass:
+// count (LDS atomics on the wave's own table) -> scan over (bin, wave) -> rank with ballot matching against running counts.
+template <class Mem>
+__device__ __forceinline__ int seg_sort(const Mem& m, uint32_t n, int nbits, uint32_t (*wave_cnt)[DS_PASS_BINS], uint32_t* wsum) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int cur = 0;
+    if (nbits <= 0) return cur;
+    const int npass = (nbits + DS_PASS_BITS - 1) / DS_PASS_BITS;
+    const int pb = (nbits + npass - 1) / npass;
+    const uint32_t q = (((n + 3u) / 4u) + 63u) & ~63u;
+    const uint32_t wbeg = min((uint32_t)w * q, n), wend = min(wbeg + q, n);
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    int sh = 0;
+#pragma unroll 1
+    for (int p = 0; p < npass; ++p, sh += pb) {
+        const int bits = min(pb, nbits - sh);
+        const uint32_t dmask = (1u << bits) - 1u;
+#pragma unroll
+        for (int k = 0; k < WG_WAVES; ++k) {
+            wave_cnt[k][tid] = 0u;
+            wave_cnt[k][tid + DS_THREADS] = 0u;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (uint32_t i = wbeg + lane; i < wend; i += 64u) {
+            uint32_t k, v;
+            m.load(cur, i, k, v);
+            atomicAdd(&wave_cnt[w][(k >> sh) & dmask], 1u);
+        }
+        __syncthreads();
+        {
+            uint32_t tot[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int d = 2 * tid + j;
+                tot[j] = wave_cnt[0][d] + wave_cnt[1][d] + wave_cnt[2][d] + wave_cnt[3][d];
+            }
+            uint32_t run = block_excl_scan<2>(tot, wsum, lane, w);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int d = 2 * tid + j;
+                uint32_t r = run;
+#pragma unroll
+                for (int k = 0; k < WG_WAVES; ++k) {
+                    const uint32_t t = wave_cnt[k][d];
+                    wave_cnt[k][d] = r;
+                    r += t;
+                }
+                run += tot[j];
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t i0 = wbeg; i0 < wend; i0 += 64u) {      // wave-uniform trips
+            const uint32_t i = i0 + (uint32_t)lane;
+            const bool valid = i < wend;
+            uint32_t k = 0, v = 0;
+            if (valid) m.load(cur, i, k, v);
+            const uint32_t d = (k >> sh) & dmask;
+            const uint64_t mask = match_digit(d, bits, __ballot(valid));
+            const uint32_t prior = valid ? wave_cnt[w][d] : 0u;
+            if (valid) {
+                m.store(cur ^ 1, prior + (uint32_t)__popcll(mask & lt_mask), k, v);
+                if ((mask & lt_mask) == 0ull) wave_cnt[w][d] = prior + (uint32_t)__popcll(mask);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    return cur;
+}
+
+__device__ __forceinline__ uint32_t rect_area(const uint2 r) {
+    return ((r.x >> 16) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.y & 0xFFFFu));
+}
+
+// Output of up to 4096 consecutive sorted elements [c0, c0 + m) of the segment: element p of the chunk belongs to thread
+// p % 256, round p / 256 (lane-contiguous stores).  ids[j]: the Gaussian id of element j * 256 + tid.  Returns the number of
+// tile instances of the chunk (every thread).
+__device__ __forceinline__ uint32_t seg_output(const uint32_t (&id)[DS_OUT], uint32_t m, uint32_t gpos0 /*global position of the chunk*/,
+                                              uint32_t tile_base, const uint2* __restrict__ rect, uint32_t* __restrict__ order,
+                                              uint2* __restrict__ rect_sorted, uint32_t* __restrict__ offsets,
+                                              uint2* __restrict__ block_first, uint32_t bf_cap, uint32_t last_listed, bool r_ok,
+                                              uint32_t (*s_wt)[WG_WAVES]) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    uint2 rc[DS_OUT];
+#pragma unroll
+    for (int j = 0; j < DS_OUT; ++j) rc[j] = rect[id[j]];      // (lanes past m carry id 0: a valid address)
+    uint32_t t[DS_OUT], incl[DS_OUT];
+#pragma unroll
+    for (int j = 0; j < DS_OUT; ++j) {
+        const uint32_t p = (uint32_t)j * DS_THREADS + (uint32_t)tid;
+        t[j] = p < m ? rect_area(rc[j]) : 0u;
+        incl[j] = wave_incl_scan_u32(t[j], lane);
+        if (lane == 63) s_wt[j][w] = incl[j];
+    }
+    __syncthreads();
+    uint32_t run = tile_base;
+    constexpr uint32_t IT = GSR_TS_ITEMS;
+#pragma unroll
+    for (int j = 0; j < DS_OUT; ++j) {
+        const uint32_t p = (uint32_t)j * DS_THREADS + (uint32_t)tid;
+        uint32_t wpre = 0, rtot = 0;
+#pragma unroll
+        for (int k = 0; k < WG_WAVES; ++k) {
+            const uint32_t x = s_wt[j][k];
+            if (k < w) wpre += x;
+            rtot += x;
+        }
+        const uint32_t in = run + wpre + incl[j], ex = in - t[j];
+        if (p < m) {
+            const uint32_t g = gpos0 + p;
+            order[g] = id[j];
+            rect_sorted[g] = rc[j];
+            offsets[g] = in;
+            if (t[j] && r_ok) {
+                // block_first[k] = (depth-order index, instances before it) of the Gaussian that owns instance k * IT; one
+                // past the last block: the last Gaussian with tiles (tilesort.hip reads entry b and b + 1)
+                for (uint32_t b = (ex + IT - 1u) / IT; b <= (in - 1u) / IT; ++b)
+                    if (b < bf_cap) block_first[b] = make_uint2(g, ex);
+                if (g == last_listed) {
+                    const uint32_t b = (in + IT - 1u) / IT;
+                    if (b < bf_cap) block_first[b] = make_uint2(g, ex);
+                }
+            }
+        }
+        run += rtot;
+    }
+    __syncthreads();      // s_wt is reused by the next chunk
+    return run - tile_base;
+}
+
+__global__ void __launch_bounds__(DS_THREADS)
+ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame, uint2* pairs0, uint2* pairs1,
+           const uint2* __restrict__ rect, uint32_t* __restrict__ order, uint2* __restrict__ rect_sorted, uint32_t* __restrict__ offsets,
+           uint2* __restrict__ block_first, uint32_t bf_cap, uint32_t* slow_word /*mapped host word or NULL*/) {
+    __shared__ uint32_t s_key[2][DS_CAP];                       // 32 KB
+    __shared__ uint16_t s_idx[2][DS_CAP];                       // 16 KB
+    __shared__ uint32_t wave_cnt[WG_WAVES][DS_PASS_BINS];       //  8 KB
+    __shared__ uint32_t wsum[WG_WAVES];
+    __shared__ uint32_t s_wt[DS_OUT][WG_WAVES];
+    const int tid = threadIdx.x;
+    const uint4 e = reinterpret_cast<const uint4*>(plan)[2 * blockIdx.x];
+    const uint32_t begin = e.x, end = e.y, d0 = e.z, d1 = e.w;
+    if (end <= begin) return;
+    const uint32_t tile_base = plan[8 * blockIdx.x + 4];
+    const uint32_t n = end - begin;
+    const uint32_t kmin = frame[2], kmax = frame[3];
+    const int shift = ds_shift(kmin, kmax);
+    const bool r_ok = frame[1] == 0u && (int32_t)frame[0] >= 0;      // R < 2^31 (else the host refuses the frame: no table writes)
+    // keys of the segment lie in [base_key, base_key + span)
+    const uint32_t base_key = kmin + (d0 << shift);
+    const uint64_t span = (uint64_t)(d1 - d0) << shift;
+    const int nbits = span <= 1ull ? 0 : 64 - __clzll((long long)(span - 1ull));
+    // the last listed Gaussian closes the emission's block table: its global position is (number of listed) - 1 = the end
+    // of the last non-empty segment; only that segment can hold it
+    // (exactly one non-empty segment ends at bucket 2047: the one that runs to the end of the listed Gaussians)
+    const uint32_t last_listed = d1 == DS_CULL ? end - 1u : 0xFFFFFFFFu;
+    if (n <= (uint32_t)DS_CAP) {
+        SegLds m{s_key, s_idx};
+        {   // all loads, then all LDS writes (a load inside "if (p < n) lds[p] = ..." is waited for one by one)
+            uint32_t kk[DS_OUT];
+#pragma unroll
+            for (int j = 0; j < DS_OUT; ++j) {
+                const uint32_t p = (uint32_t)j * DS_THREADS + (uint32_t)tid;
+                kk[j] = pairs0[begin + (p < n ? p : 0u)].x;
+            }
+#pragma unroll
+            for (int j = 0; j < DS_OUT; ++j) {
+                const uint32_t p = (uint32_t)j * DS_THREADS + (uint32_t)tid;
+                if (p < n) {
+                    s_key[0][p] = kk[j] - base_key;
+                    s_idx[0][p] = (uint16_t)p;
+                }
+            }
+        }
+        __syncthreads();
+        const int cur = seg_sort(m, n, nbits, wave_cnt, wsum);
+        uint32_t ix[DS_OUT], id[DS_OUT];
+#pragma unroll
+        for (int j = 0; j < DS_OUT; ++j) {
+            const uint32_t p = (uint32_t)j * DS_THREADS + (uint32_t)tid;
+            ix[j] = p < n ? (uint32_t)s_idx[cur][p] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < DS_OUT; ++j) {
+            const uint32_t p = (uint32_t)j * DS_THREADS + (uint32_t)tid;
+            const uint32_t v = pairs0[begin + ix[j]].y;
+            id[j] = p < n ? v : 0u;
+        }
+        seg_output(id, n, begin, tile_base, rect, order, rect_sorted, offsets, block_first, bf_cap, last_listed, r_ok, s_wt);
+        return;
+    }
+    // ---- oversized segment: the same passes through global memory (pairs0 <-> pairs1), then the output in chunks ----
+    if (slow_word && tid == 0) __hip_atomic_store(slow_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    SegGlobal m{{pairs0 + begin, pairs1 + begin}, base_key};
+    const int cur = seg_sort(m, n, nbits, wave_cnt, wsum);
+    const uint2* sorted = m.p[cur];
+    uint32_t tb = tile_base;
+#pragma unroll 1
+    for (uint32_t c0 = 0; c0 < n; c0 += (uint32_t)DS_CAP) {
+        const uint32_t mm = min((uint32_t)DS_CAP, n - c0);
+        uint32_t id[DS_OUT];
+#pragma unroll
+        for (int j = 0; j < DS_OUT; ++j) {
+            const uint32_t p = (uint32_t)j * DS_THREADS + (uint32_t)tid;
+            const uint32_t v = sorted[c0 + (p < mm ? p : 0u)].y;
+            id[j] = p < mm ? v : 0u;
+        }
+        tb += seg_output(id, mm, begin + c0, tb, rect, order, rect_sorted, offsets, block_first, bf_cap, last_listed, r_ok, s_wt);
+    }
+}
+
+}  // namespace
+
+size_t gsr_depth_bucket_blocks(int P) { return ((size_t)(P > 0 ? P : 1) + DS_ITEMS - 1) / DS_ITEMS; }
+size_t gsr_depth_bucket_segments(int P) { return ((size_t)(P > 0 ? P : 1) + DS_SEG - 1) / DS_SEG + 1; }
+
+// keys[P] (27-bit depth keys, GSR_DEPTH_KEY_CULLED for Gaussians without a tile), tiles[P], rect[P], frame = the words the
+// key-producing kernel's last workgroup wrote (gsr_frame.h)  ->  order[P], rect_sorted[P], offsets[P] (inclusive scan of the
+// tile counts in depth order), block_first[bf_cap]
+void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, const uint2* rect, const uint32_t* frame,
+                                  const GsrDepthSortBufs& b, uint32_t* order, uint2* rect_sorted, uint32_t* offsets, uint2* block_first,
+                                  uint32_t block_first_cap, uint32_t* slow_word, hipStream_t st) {
+    const int nblocks = (int)gsr_depth_bucket_blocks(P);
+    const int nseg_cap = (int)gsr_depth_bucket_segments(P);
+    hipLaunchKernelGGL(ds_hist, dim3(nblocks), dim3(DS_THREADS), 0, st, P, keys, tiles, frame, b.cnt_tab, b.tile_tab);
+    hipLaunchKernelGGL(ds_scan, dim3(DS_NB / 16), dim3(DS_THREADS), 0, st, nblocks, b.cnt_tab, b.tile_tab, b.cnt_total, b.tile_total);
+    hipLaunchKernelGGL(ds_scatter, dim3(nblocks + 1), dim3(DS_THREADS), 0, st, P, nblocks, keys, frame, b.cnt_tab, b.cnt_total,
+                       b.tile_total, b.pairs[0], order, offsets, rect_sorted, b.plan, nseg_cap);
+    hipLaunchKernelGGL(ds_segsort, dim3(nseg_cap), dim3(DS_THREADS), 0, st, b.plan, frame, b.pairs[0], b.pairs[1], rect, order,
+                       rect_sorted, offsets, block_first, block_first_cap, slow_word);
+}

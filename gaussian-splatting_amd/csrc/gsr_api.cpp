@@ -34,15 +34,11 @@ int fail(int code, const std::string& msg) {
 // ---- options / profiling ----
 int g_render_fwd_variant = 0;
 int g_render_bwd_variant = 0;
-int g_depth_sort_mode = 0;      // 0 = hist / scan / scatter per pass, 1 = one kernel per pass ("onesweep", sort.hip)
+int g_depth_sort_mode = 0;      // 0 = automatic (bucket sort, depthsort.hip, up to GSR_DS_MAX_P Gaussians; LSD radix sort beyond, and
+                                // for a while after a frame whose depths crowded one bucket), 1 = always LSD, 2 = always bucket sort
 int g_snug_tiles = 1;           // 1 = bin every Gaussian into its snug tile rectangle (gsr_math.h); 0 = the reference's square (A/B)
 int g_bwd_heavy_first = 1;      // 1 = the blend backward starts its heaviest tiles first (plan kernel, render_bwd.hip); 0 = index order (A/B)
 int g_tile_sort_mode = 0;       // 0 = fused emission + two-level sort (tilesort.hip), 1 = legacy emit + LSD passes (A/B)
-int g_first_hist = 0;           // 1 = the preprocess kernel also produces the histogram of the depth sort's first pass (large P).
-                                // Measured (1 M Gaussians): the sort saves 4.3 us, the preprocess -- one workgroup per 1024
-                                // Gaussians instead of a 2048-wide grid -- loses 4.5 us: no gain, off by default.
-int g_color_overlap = 0;        // 0 = one preprocess kernel; 1 = geometry + colour kernels, same stream; 2 = colour kernel on the
-                                // library's second stream, beside the depth sort / scan / tile sort (joined in front of the blend)
 
 struct PendingEvent { int stage; hipEvent_t a, b; };
 std::mutex g_prof_mu;
@@ -154,13 +150,16 @@ int check_split_sh(const GsrRasterSettings* s, int P, int M, const float* shs, b
 }
 
 // R read-back word: mapped + portable + coherent pinned host memory: [0] = R low word, [1] = sequence number, [2] = R high word,
-// [3] = "a depth key needed more than 27 bits" (set by the key-producing kernel).  Words are LEASED per call from a per-device
-// pool (keyed by device, not by thread -- a host thread that comes and goes leaks nothing, concurrent callers
-// never share a word); 64 bytes each, never freed (the runtime releases them with the context).
-struct HostWord { uint32_t* host = nullptr; uint32_t* dev = nullptr; uint32_t seq = 0; };
+// [3] = "a depth key needed more than 27 bits", [5] = "the bucket depth sort met an oversized segment" (read at the NEXT lease).
+// Written by the last workgroup of the key-producing kernel (gsr_frame.h), which folds the frame's statistics in `state`, a
+// 64-byte block of device memory that is zero between frames.  Words are LEASED per call from a per-device pool (ADVICE r02:
+// keyed by device, not by thread -- a host thread that comes and goes leaks nothing, concurrent callers never share a word);
+// never freed (the runtime releases them with the context).
+struct HostWord { uint32_t* host = nullptr; uint32_t* dev = nullptr; uint32_t* state = nullptr; uint32_t seq = 0; };
 std::mutex g_hw_mu;
 std::vector<HostWord> g_hw_pool[GSR_MAX_DEVICES];
 std::atomic<int64_t> g_last_R[GSR_MAX_DEVICES];      // per device: sizes the speculative binning buffer of the next frame
+std::atomic<int> g_lsd_frames[GSR_MAX_DEVICES];      // per device: frames for which the automatic depth sort stays with the LSD passes
 struct HostWordLease {
     int dev = -1;
     HostWord hw;
@@ -168,7 +167,10 @@ struct HostWordLease {
     bool settled = true;      // false while a kernel that will still write the word may be pending
     ~HostWordLease() {
         if (dev < 0) return;
-        if (!settled) (void)hipStreamSynchronize(st);      // error paths only: never hand a word with a pending writer to the next call
+        if (!settled) {      // error paths only: never hand a word with a pending writer (or a half-filled state block) to the next call
+            (void)hipStreamSynchronize(st);
+            (void)hipMemset(hw.state, 0, 64);
+        }
         std::lock_guard<std::mutex> l(g_hw_mu);
         g_hw_pool[dev].push_back(hw);
     }
@@ -184,9 +186,15 @@ int lease_host_word(HostWordLease& lease, hipStream_t st) {
     if (!lease.hw.host) {
         HIP_OK(hipHostMalloc((void**)&lease.hw.host, 64, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent));
         HIP_OK(hipHostGetDevicePointer((void**)&lease.hw.dev, lease.hw.host, 0));
-        lease.hw.host[0] = lease.hw.host[1] = lease.hw.host[2] = 0;
+        for (int i = 0; i < 16; ++i) lease.hw.host[i] = 0;
+        HIP_OK(hipMalloc((void**)&lease.hw.state, 64));
+        HIP_OK(hipMemset(lease.hw.state, 0, 64));
     }
     lease.hw.host[3] = 0;
+    if (lease.hw.host[5]) {      // the previous frame on this word: thousands of Gaussians in one depth bucket -- its segment went
+        lease.hw.host[5] = 0;    // through global memory.  Stay with the LSD passes for a while, then try again.
+        g_lsd_frames[dev_id].store(64);
+    }
     lease.dev = dev_id;
     lease.st = st;
     return GSR_OK;
@@ -196,11 +204,6 @@ unsigned long long* counters_for_current_device() {
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= GSR_MAX_DEVICES) return nullptr;
     return g_counters_dev[d];
 }
-
-// Second stream (lowest priority, non-blocking) + fork / join events of the overlapped colour kernel, one set per (thread,
-// device) like the host word, so that concurrent host threads never share an event.  Not freed, for the same reason.
-struct AuxStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-thread_local AuxStream g_aux[GSR_MAX_DEVICES];
 
 #if defined(__x86_64__) || defined(__i386__)
 #define GSR_CPU_RELAX() __builtin_ia32_pause()
@@ -243,9 +246,18 @@ GsrGeom gsr_carve_geom(char* base, int P) {
     g.block_first = (uint2*)take(gsr_block_first_cap(P) * 8);
     g.sort_hist = (uint32_t*)take((size_t)GSR_SORT_MAX_DIGITS * (size_t)gsr_sort_blocks((int64_t)n, true) * 4);   // small workgroups: worst case
     g.digit_total = (uint32_t*)take(GSR_SORT_MAX_DIGITS * 4);
-    g.os_scratch = (uint32_t*)take(gsr_onesweep_scratch_bytes((int64_t)n));
+    {
+        const bool ds = P <= GSR_DS_MAX_P;
+        const size_t np = ds ? n : 1, nblk = ds ? gsr_depth_bucket_blocks(P) : 1, nseg = ds ? gsr_depth_bucket_segments(P) : 1;
+        g.ds.pairs[0] = (uint2*)take(np * 8);
+        g.ds.pairs[1] = (uint2*)take(np * 8);
+        g.ds.cnt_tab = (uint32_t*)take(nblk * GSR_DS_BUCKETS * 4);
+        g.ds.tile_tab = (uint32_t*)take(nblk * GSR_DS_BUCKETS * 4);
+        g.ds.cnt_total = (uint32_t*)take(GSR_DS_BUCKETS * 4);
+        g.ds.tile_total = (uint32_t*)take(GSR_DS_BUCKETS * 4);
+        g.ds.plan = (uint32_t*)take(nseg * 32);
+    }
     g.num_rendered = (uint32_t*)take(128);
-    g.key_overflow = nullptr;
     g.bytes = off;
     return g;
 }
@@ -336,29 +348,11 @@ int gsr_set_option(const char* name, int value) {
         return GSR_OK;
     }
     if (!strcmp(name, "depth_sort_mode")) {
-        if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "depth_sort_mode must be 0 (three kernels per pass) or 1 (onesweep)");
-        if (value == 1 && !gsr_onesweep_available()) return fail(GSR_ERR_UNSUPPORTED, "depth_sort_mode 1 needs a -DGSR_AB_VARIANTS build");
+        if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARG, "depth_sort_mode must be 0 (automatic), 1 (LSD radix passes) or 2 (bucket sort)");
         g_depth_sort_mode = value;
         return GSR_OK;
     }
     if (!strcmp(name, "preprocess_grid_cap")) { gsr_set_preprocess_grid_cap(value); return GSR_OK; }
-    if (!strcmp(name, "sh_dma")) {
-        if (value < 0 || value > 3) return fail(GSR_ERR_INVALID_ARG, "sh_dma must be 0..3 (bit 0: forward, bit 1: backward per-Gaussian kernel)");
-        if (!gsr_set_sh_dma(value) && value) return fail(GSR_ERR_UNSUPPORTED, "sh_dma needs a -DGSR_AB_VARIANTS build");
-        return GSR_OK;
-    }
-    if (!strcmp(name, "first_hist_in_preprocess")) {
-        if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "first_hist_in_preprocess must be 0 or 1");
-        if (value && !gsr_preprocess_split_available()) return fail(GSR_ERR_UNSUPPORTED, "first_hist_in_preprocess needs a -DGSR_AB_VARIANTS build");
-        g_first_hist = value;
-        return GSR_OK;
-    }
-    if (!strcmp(name, "color_overlap")) {
-        if (value < 0 || value > 6) return fail(GSR_ERR_INVALID_ARG, "color_overlap must be 0 (fused preprocess), 1 (split, one stream), 2 (split, colour on a second stream) or 3..6 (second stream restricted to 7/8, 3/4, 1/2, 1/4 of the CUs with hipExtStreamCreateWithCUMask)");
-        if (value && !gsr_preprocess_split_available()) return fail(GSR_ERR_UNSUPPORTED, "color_overlap needs a -DGSR_AB_VARIANTS build");
-        g_color_overlap = value;
-        return GSR_OK;
-    }
     if (!strcmp(name, "ssim_variant")) {
         if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "ssim_variant must be 0 (marching waves) or 1 (LDS tiles)");
         gsr_set_ssim_variant(value);
@@ -495,40 +489,61 @@ static int wait_for_R(HostWord& hw, uint32_t seq, hipStream_t st, const uint32_t
     return GSR_OK;
 }
 
-// Everything after the per-Gaussian preprocess: depth sort, scan, R read-back, emission, tile sort, ranges, blend.
-// `g` holds the splat records, band-clamped rectangles / tile counts and the depth keys of all P Gaussians.
-static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& cam, int P, GsrGeom& g, HostWordLease& lease,
+// The statistics block / frame words / host word a key-producing kernel needs (gsr_frame.h)
+static GsrFrameStatsDev frame_stats_for(HostWordLease& lease, GsrGeom& g, uint32_t& seq_out) {
+    seq_out = ++lease.hw.seq;
+    lease.settled = false;
+    GsrFrameStatsDev fs;
+    fs.state = lease.hw.state;
+    fs.frame = g.num_rendered;
+    fs.host_word = lease.hw.dev;
+    fs.seq = seq_out;
+    return fs;
+}
+
+static bool use_bucket_sort(int P, int dev_id) {
+    if (P > GSR_DS_MAX_P || g_depth_sort_mode == 1) return false;
+    if (g_depth_sort_mode == 2) return true;
+    int left = g_lsd_frames[dev_id].load();
+    if (left > 0) { g_lsd_frames[dev_id].store(left - 1); return false; }
+    return true;
+}
+
+// Everything after the key-producing kernel (per-Gaussian preprocess or splat ingest): depth sort + scan, emission, tile sort,
+// ranges, blend.  `g` holds the splat records, band-clamped rectangles / tile counts and the depth keys of all P Gaussians;
+// `seq` is the sequence number that kernel's last workgroup publishes with R.
+static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& cam, int P, GsrGeom& g, HostWordLease& lease, uint32_t seq,
                           GsrResizeFn binning_resize, void* binning_user, GsrResizeFn image_resize, void* image_user,
-                          float* out_color, float* out_invdepth, int32_t* num_rendered, hipStream_t st,
-                          hipEvent_t colors_done = nullptr, bool first_hist_ready = false) {
-    int order_buf;
-    uint32_t* sort_err = nullptr;
-    const bool onesweep = g_depth_sort_mode == 1;
+                          float* out_color, float* out_invdepth, int32_t* num_rendered, hipStream_t st) {
+    const int dev_id = lease.dev;
+    HostWord& hw_slot = lease.hw;
+    const int order_buf = depth_order_buffer_index();
+    const uint32_t bf_cap = (uint32_t)gsr_block_first_cap(P);
+    const bool bucket = use_bucket_sort(P, dev_id);
+    // R = number of (Gaussian, tile) instances sizes the binning buffer and the emission grids, so the host must learn it
+    // mid-pipeline (the reference has the same read-back).  It does not depend on the depth order: the key-producing kernel
+    // has already summed it, and its last workgroup stores it with a sequence number straight into mapped pinned host memory
+    // (gsr_frame.h).  The host queues the whole depth sort FIRST and only then looks at the word, so the read-back, the
+    // callbacks and the emission launches all happen while the GPU sorts -- no idle bubble (rounds 1-3: R came from the
+    // scan, after the sort, and the GPU idled 5-7 us per frame).
     {   StageTimer t(GSR_STAGE_DEPTH_SORT, st);
-        if (onesweep) {      // (measurement build) 4 passes of 8 bits on the 27-bit keys; result in vals[0]
-            gsr_onesweep_depth_sort(g.keys, g.vals, P, g.os_scratch, g.rect, g.rect_sorted, &sort_err, st);
-            order_buf = 0;
+        if (bucket) {
+            gsr_launch_depth_bucket_sort(P, g.keys[0], g.tiles, g.rect, g.num_rendered, g.ds, g.vals[order_buf], g.rect_sorted, g.offsets,
+                                         g.block_first, bf_cap, hw_slot.dev + 5, st);
         } else {
-            order_buf = gsr_radix_sort_pairs(g.keys, g.vals, P, GSR_DEPTH_KEY_BITS, GSR_DEPTH_DIGIT_BITS, g.sort_hist, g.digit_total,
-                                             sort_items(P), st, g.rect, g.rect_sorted, first_hist_ready);
+            const int ob = gsr_radix_sort_pairs(g.keys, g.vals, P, GSR_DEPTH_KEY_BITS, GSR_DEPTH_DIGIT_BITS, g.sort_hist, g.digit_total,
+                                                sort_items(P), st, g.rect, g.rect_sorted);
+            if (ob != order_buf) return fail(GSR_ERR_HIP, "depth sort: unexpected result buffer");
         }
     }
     STAGE_CHECK("depth sort");
-    // R = number of (Gaussian, tile) instances sizes the binning buffer, so the host must learn it mid-pipeline (the
-    // reference has the same read-back).  To keep the GPU-idle bubble short: (1) the scan kernel stores R + a sequence
-    // number straight into mapped pinned host memory (system-scope release) and the host spins on it instead of going
-    // through hipMemcpyAsync + hipStreamSynchronize; (2) the image buffer and a speculative binning buffer (last R + 25 %)
-    // are obtained through the callbacks WHILE the GPU is still working, so in steady state no callback sits in the bubble.
-    const int dev_id = lease.dev;
-    HostWord& hw_slot = lease.hw;
-    uint32_t seq = ++hw_slot.seq;
-    const uint32_t bf_cap = (uint32_t)gsr_block_first_cap(P);
-    lease.settled = false;
-    {   StageTimer t(GSR_STAGE_SCAN, st);
+    if (!bucket) {
+        StageTimer t(GSR_STAGE_SCAN, st);
         gsr_launch_scan_tiles(P, g.vals[order_buf], g.rect, g.rect_sorted, g.offsets, g.block_sums, g.block_first, bf_cap,
-                              g.num_rendered, hw_slot.dev, seq, /*rect_already_sorted=*/true, sort_err, st);
+                              g.num_rendered + 4, nullptr, 0u, /*rect_already_sorted=*/true, st);
     }
-    // (profiling only) the GPU-idle bubble of the R read-back: from the end of the scan to the first launch after the wait
+    // (profiling only) what is left of the read-back on the GPU's time line: from the end of the depth sort / scan to the
+    // first launch after the host has R
     EventPair wait_ev;
     wait_ev.arm(st);
     const int n_tiles = cam.gx * cam.gy;
@@ -536,8 +551,7 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     gsr_tile_sort_plan(n_tiles, P, &plan);
     if (g_tile_sort_mode == 1) plan.fused = false;
     char* ibase = (char*)image_resize(image_user, gsr_image_bytes(cam.W, cam.H));
-    // legacy path: the tile-range table is cleared here, in the shadow of the R read-back (the stream is otherwise idle
-    // while the host waits); the fused path writes every entry of the table itself
+    // legacy path: the tile-range table is cleared here; the fused path writes every entry of the table itself
     if (ibase && !plan.fused)
         HIP_OK(hipMemsetAsync(gsr_carve_image(ibase, cam.W, cam.H).ranges, 0, sizeof(uint2) * (size_t)n_tiles, st));
     char* bbase = nullptr;
@@ -550,23 +564,17 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     int rc = wait_for_R(hw_slot, seq, st, g.num_rendered);
     if (rc != GSR_OK) return rc;
     lease.settled = true;
-    if (hw_slot.host[3] != 0u && !onesweep) {
+    if (hw_slot.host[3] != 0u) {
         // a listed Gaussian lies deeper than 0.2 * 2^16: its 27-bit key was clamped and the depth order above is not
         // trustworthy.  Rare path: full 32-bit keys from the splat records, 4 passes of 8 bits (round 2's sort), result
-        // copied into the buffer the 3-pass sort uses, scan again (R itself does not depend on the order).
+        // copied into the buffer the backward reads, scan again (R itself does not depend on the order).
         gsr_launch_rekey_full(P, g.splats, g.tiles, g.keys[0], g.vals[0], st);
-        const int ob = gsr_radix_sort_pairs(g.keys, g.vals, P, 32, 8, g.sort_hist, g.digit_total, sort_items(P), st, g.rect, g.rect_sorted, false);
+        const int ob = gsr_radix_sort_pairs(g.keys, g.vals, P, 32, 8, g.sort_hist, g.digit_total, sort_items(P), st, g.rect, g.rect_sorted);
         if (ob != order_buf) HIP_OK(hipMemcpyAsync(g.vals[order_buf], g.vals[ob], (size_t)P * 4, hipMemcpyDeviceToDevice, st));
-        seq = ++hw_slot.seq;
-        lease.settled = false;
         gsr_launch_scan_tiles(P, g.vals[order_buf], g.rect, g.rect_sorted, g.offsets, g.block_sums, g.block_first, bf_cap,
-                              g.num_rendered, hw_slot.dev, seq, true, nullptr, st);
-        rc = wait_for_R(hw_slot, seq, st, g.num_rendered);
-        if (rc != GSR_OK) return rc;
-        lease.settled = true;
+                              g.num_rendered + 4, nullptr, 0u, true, st);
     }
     const uint64_t R64 = ((uint64_t)hw_slot.host[2] << 32) | (uint64_t)hw_slot.host[0];
-    if (R64 == ~0ull) return fail(GSR_ERR_HIP, "depth sort: a workgroup timed out waiting for its predecessors");
     if (R64 > 0x7FFFFFFFull) return fail(GSR_ERR_UNSUPPORTED, "more than 2^31-1 tile instances");
     const int64_t R = (int64_t)R64;
     *num_rendered = (int32_t)R;
@@ -623,7 +631,6 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     } else if (plan.fused) {
         HIP_OK(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)n_tiles, st));
     }
-    if (colors_done) HIP_OK(hipStreamWaitEvent(st, colors_done, 0));      // the blend is the first reader of the colours
     {   StageTimer t(GSR_STAGE_RENDER, st);
         gsr_launch_render_forward(cam, im.ranges, b.vals[list_buf], g.splats, settings->no_backward ? nullptr : im.final_T,
                                   settings->no_backward ? nullptr : im.n_contrib, settings->no_backward ? nullptr : im.block_steps,
@@ -665,78 +672,14 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
     HostWordLease lease;
     rc = lease_host_word(lease, st);
     if (rc != GSR_OK) return rc;
-    g.key_overflow = lease.hw.dev + 3;
-
-    if (g_color_overlap == 0 || !shs) {
-        // large P: one preprocess workgroup per workgroup of the depth sort's first pass, which then needs no histogram
-        // kernel of its own (small P keeps the wider grid: a 4-deep loop per workgroup would cost more than the launch)
-        const int items = sort_items(P);
-        const bool first_hist = g_first_hist && g_depth_sort_mode == 0 && GSR_DEPTH_DIGIT_BITS == 8 && ((int64_t)P + items - 1) / items >= 512;
-        {   StageTimer t(GSR_STAGE_PREPROCESS, st);
-            gsr_launch_preprocess(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, st,
-                                  first_hist ? items : 0);
-        }
-        STAGE_CHECK("preprocess");
-        return bin_and_render(settings, cam, P, g, lease, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
-                              num_rendered, st, nullptr, first_hist);
-    }
-    // split form: the binning chain needs only the geometry; the SH evaluation runs beside it on the second stream
+    uint32_t seq;
+    const GsrFrameStatsDev fs = frame_stats_for(lease, g, seq);
     {   StageTimer t(GSR_STAGE_PREPROCESS, st);
-        gsr_launch_preprocess_geom(cam, P, means3D, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, st);
+        gsr_launch_preprocess(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, fs, st);
     }
-    STAGE_CHECK("preprocess (geometry)");
-    hipEvent_t join = nullptr;
-    hipStream_t cst = st;
-    if (g_color_overlap >= 2) {
-        int dev_id = 0;
-        HIP_OK(hipGetDevice(&dev_id));
-        if (dev_id < 0 || dev_id >= GSR_MAX_DEVICES) return fail(GSR_ERR_UNSUPPORTED, "device ordinal out of range");
-        AuxStream& aux = g_aux[dev_id];
-        static thread_local int aux_kind[GSR_MAX_DEVICES] = {0};
-        if (aux.s && aux_kind[dev_id] != g_color_overlap) {      // (measurement build) the option changed: new stream
-            (void)hipStreamDestroy(aux.s);
-            aux.s = nullptr;
-        }
-        if (!aux.s) {
-            if (g_color_overlap == 2) {
-                int least = 0, greatest = 0;
-                HIP_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-                HIP_OK(hipStreamCreateWithPriority(&aux.s, hipStreamNonBlocking, least));
-            } else {
-                // the colour kernel beside the latency-bound depth sort lost in round 2 because the two SHARED
-                // the CUs (the sort's workgroups queued behind streaming workgroups).  Here the colour stream is restricted to a
-                // fraction of the CUs of EVERY XCD (mask bit i <-> CU i; the pattern repeats every 8 bits and again every 64, so
-                // it removes the same share whichever way the runtime interleaves XCDs), the rest stay free for the sort.
-                hipDeviceProp_t prop;
-                HIP_OK(hipGetDeviceProperties(&prop, dev_id));
-                const int ncu = prop.multiProcessorCount;
-                const int keep8 = g_color_overlap == 3 ? 7 : g_color_overlap == 4 ? 6 : g_color_overlap == 5 ? 4 : 2;      // of every 8 CUs
-                std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-                for (int i = 0; i < ncu; ++i)
-                    if (((i >> 3) & 7) < keep8) mask[(size_t)i >> 5] |= 1u << (i & 31);
-                HIP_OK(hipExtStreamCreateWithCUMask(&aux.s, (uint32_t)mask.size(), mask.data()));
-            }
-            aux_kind[dev_id] = g_color_overlap;
-            if (!aux.fork) {
-                HIP_OK(hipEventCreateWithFlags(&aux.fork, hipEventDisableTiming));
-                HIP_OK(hipEventCreateWithFlags(&aux.join, hipEventDisableTiming));
-            }
-        }
-        HIP_OK(hipEventRecord(aux.fork, st));
-        HIP_OK(hipStreamWaitEvent(aux.s, aux.fork, 0));
-        cst = aux.s;
-        join = aux.join;
-    }
-    {   StageTimer t(GSR_STAGE_COLOR, cst);
-        gsr_launch_preprocess_color(cam, P, means3D, shs, g, cst);
-    }
-    if (join) HIP_OK(hipEventRecord(join, cst));
-    if (settings->debug && cst != st) HIP_OK(hipStreamSynchronize(cst));
-    rc = bin_and_render(settings, cam, P, g, lease, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
-                        num_rendered, st, join);
-    // an early return leaves the colour kernel un-joined: the caller may release the geometry buffer, so wait for it here
-    if (rc != GSR_OK && cst != st) (void)hipStreamSynchronize(cst);
-    return rc;
+    STAGE_CHECK("preprocess");
+    return bin_and_render(settings, cam, P, g, lease, seq, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
+                          num_rendered, st);
 }
 
 int gsr_preprocess_forward(const GsrRasterSettings* settings, int P, int M, const float* means3D, const float* shs,
@@ -760,7 +703,9 @@ int gsr_preprocess_forward(const GsrRasterSettings* settings, int P, int M, cons
     GsrGeom g = gsr_carve_geom((char*)geom_scratch, P);
     g.splats = reinterpret_cast<float4*>(splat_records);
     {   StageTimer t(GSR_STAGE_PREPROCESS, st);
-        gsr_launch_preprocess(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, st);
+        GsrFrameStatsDev none;      // nothing is binned here: no frame statistics
+        none.state = nullptr; none.frame = nullptr; none.host_word = nullptr; none.seq = 0;
+        gsr_launch_preprocess(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, none, st);
     }
     STAGE_CHECK("preprocess (shard)");
     HIP_OK(hipGetLastError());
@@ -780,8 +725,21 @@ static int rasterize_from_records(const GsrRasterSettings* settings, int P, cons
     const size_t npix = (size_t)cam.W * cam.H;
     *num_rendered = 0;
     if (P == 0) {
+        // No record reached this rank's band while the scene itself is not empty (the caller renders a band of a sharded frame):
+        // the band's pixels are what the blend leaves where no splat lands -- the BACKGROUND (T = 1), not the zero image of the
+        // reference's P == 0 early-out (with a white or random background the gathered frame, and the loss, differed
+        // from one GPU's).  The blend runs over empty tile ranges.
         HIP_OK(hipMemsetAsync(out_color, 0, npix * 3 * sizeof(float), st));
         if (out_invdepth) HIP_OK(hipMemsetAsync(out_invdepth, 0, npix * sizeof(float), st));
+        if (!image_resize) return fail(GSR_ERR_INVALID_ARG, "resize callbacks are NULL");
+        char* ibase = (char*)image_resize(image_user, gsr_image_bytes(cam.W, cam.H));
+        if (!ibase) return fail(GSR_ERR_ALLOC, "image buffer resize returned NULL");
+        GsrImage im = gsr_carve_image(ibase, cam.W, cam.H);
+        HIP_OK(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)cam.gx * cam.gy, st));
+        const bool nb = settings->no_backward != 0;
+        gsr_launch_render_forward(cam, im.ranges, nullptr, nullptr, nb ? nullptr : im.final_T, nb ? nullptr : im.n_contrib,
+                                  nb ? nullptr : im.block_steps, out_color, out_invdepth, 0, nullptr, st);
+        HIP_OK(hipGetLastError());
         return GSR_OK;
     }
     if (!records) return fail(GSR_ERR_INVALID_ARG, "records pointer is NULL");
@@ -793,14 +751,14 @@ static int rasterize_from_records(const GsrRasterSettings* settings, int P, cons
     HostWordLease lease;
     rc = lease_host_word(lease, st);
     if (rc != GSR_OK) return rc;
-    g.key_overflow = lease.hw.dev + 3;
+    uint32_t seq;
+    const GsrFrameStatsDev fs = frame_stats_for(lease, g, seq);
     {   StageTimer t(GSR_STAGE_PREPROCESS, st);
-        uint32_t* sort_state = gsr_onesweep_available() ? g.os_scratch : nullptr;
-        if (packed) gsr_launch_ingest_packed(P, records, cam.tile_y0, cam.tile_y1, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], sort_state, g.key_overflow, st);
-        else gsr_launch_splat_ingest(P, records, cam.tile_y0, cam.tile_y1, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], sort_state, g.key_overflow, st);
+        if (packed) gsr_launch_ingest_packed(P, records, cam.tile_y0, cam.tile_y1, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], fs, st);
+        else gsr_launch_splat_ingest(P, records, cam.tile_y0, cam.tile_y1, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], fs, st);
     }
     STAGE_CHECK("splat ingest");
-    return bin_and_render(settings, cam, P, g, lease, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
+    return bin_and_render(settings, cam, P, g, lease, seq, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
                           num_rendered, st);
 }
 
@@ -1207,6 +1165,7 @@ int gsr_forward_views(int P, int64_t R, int width, int height, const void* geom_
     out->ranges = (const uint32_t*)im.ranges;
     out->final_T = im.final_T;
     out->n_contrib = im.n_contrib;
+    out->tile_scan = g.offsets;
     return GSR_OK;
 }
 

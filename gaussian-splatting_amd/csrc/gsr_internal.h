@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include "gsr.h"
 #include "gsr_math.h"
+#include "gsr_frame.h"
 
 // ---- per-call camera block handed to kernels by value (matrices are read from device memory) ----
 struct GsrCamDev {
@@ -33,6 +34,24 @@ static inline size_t gsr_align128(size_t x) { return (x + 127) & ~(size_t)127; }
 // frames beyond that get the table from a fallback kernel once R is known (gsr_launch_fill_block_first)
 static inline size_t gsr_block_first_cap(int P) { return (size_t)(P > 0 ? P : 1) / 64 + 66; }
 
+// ---- bucket depth sort (depthsort.hip): one bucket pass over the keys + an LDS sort per segment of buckets ----
+#define GSR_DS_ITEMS 4096        // keys per workgroup of the bucket histogram / scatter
+#define GSR_DS_BITS 11
+#define GSR_DS_BUCKETS 2048      // bucket 2047: Gaussians without a tile (they sort last)
+#define GSR_DS_SEG 2048          // a segment = the buckets that start inside one window of this many elements
+#define GSR_DS_CAP 4096          // largest segment sorted in LDS; beyond: the same passes through global memory (slow, reported)
+#define GSR_DS_MAX_P (3 << 20)   // above: the LSD radix sort (the [workgroup][bucket] tables grow with P)
+struct GsrDepthSortBufs {
+    uint2* pairs[2];             // [P] (key, id) in bucket order / scratch of an oversized segment
+    uint32_t* cnt_tab;           // [workgroups][2048] keys per bucket, then their exclusive prefix over the workgroups
+    uint32_t* tile_tab;          // [workgroups][2048] tile instances per bucket
+    uint32_t* cnt_total;         // [2048]
+    uint32_t* tile_total;        // [2048]
+    uint32_t* plan;              // [segments][8]
+};
+size_t gsr_depth_bucket_blocks(int P);
+size_t gsr_depth_bucket_segments(int P);
+
 struct GsrGeom {                 // P-sized
     float4* splats;              // [4P]  (x,y,conA,conB) (conC,opacity,r,g) (b,depth,tau,1/depth) (rect.x,rect.y,goffset,tiles as bits)
     uint2* rect;                 // [P]   x = minx | maxx<<16 ; y = miny | maxy<<16 (band-clamped)
@@ -44,11 +63,10 @@ struct GsrGeom {                 // P-sized
     uint32_t* offsets;           // [P]   inclusive scan of tiles_touched in depth order
     uint64_t* block_sums;        // [ceil(P/GSR_SCAN_ITEMS)]
     uint2* block_first;          // [gsr_block_first_cap(P)] per 4096-instance block: (depth-order index of its first Gaussian, instances before it)
-    uint32_t* sort_hist;         // [256 * nblocks_small(P)] radix block histograms
-    uint32_t* digit_total;       // [256]
-    uint32_t* os_scratch;        // gsr_onesweep_scratch_bytes(P): tables / descriptor words of the one-kernel-per-pass depth sort
-    uint32_t* num_rendered;      // [2] R as 64 bits
-    uint32_t* key_overflow;      // NOT carved: device address of the host word a kernel sets when a depth key needs > 27 bits (may be NULL)
+    uint32_t* sort_hist;         // [512 * nblocks_small(P)] radix block histograms (LSD depth sort)
+    uint32_t* digit_total;       // [512]
+    GsrDepthSortBufs ds;         // bucket depth sort (depthsort.hip); carved for P <= GSR_DS_MAX_P
+    uint32_t* num_rendered;      // frame words (gsr_frame.h): [0..1] R as 64 bits, [2] smallest, [3] largest depth key of a listed Gaussian
     size_t bytes;
 };
 GsrGeom gsr_carve_geom(char* base, int P);
@@ -63,7 +81,7 @@ GsrGeom gsr_carve_geom(char* base, int P);
 #define GSR_DEPTH_KEY_BASE 0x3E4CCCCDu
 #define GSR_DEPTH_KEY_CULLED ((1u << GSR_DEPTH_KEY_BITS) - 1u)
 #ifdef __HIPCC__
-// `overflow` is a per-thread flag the caller reports ONCE, after its loop, with gsr_report_key_overflow: a store through the
+// `overflow` is a per-thread flag the caller reports ONCE, after its loop, through gsr_frame_stats_commit: a store through an
 // (unrestricted) host-word pointer inside the streaming loop made hipcc serialise the loop's batched loads (ISA audit: the
 // split-SH loader of the preprocess became a 14-long load -> wait chain).
 __device__ __forceinline__ uint32_t gsr_depth_key(float depth, bool listed, bool& overflow) {
@@ -74,9 +92,6 @@ __device__ __forceinline__ uint32_t gsr_depth_key(float depth, bool listed, bool
         k = GSR_DEPTH_KEY_CULLED - 1u;
     }
     return k;
-}
-__device__ __forceinline__ void gsr_report_key_overflow(bool overflow, uint32_t* key_overflow) {
-    if (overflow && key_overflow) __hip_atomic_store(key_overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // the two derived fields of a splat record, written by the preprocess and recomputed bit-identically from (opacity, depth) by the
 // receiver of a packed record (route.hip): tau = gsr_tau(opacity) (gsr_math.h) and 1 / depth, an explicit single rounding
@@ -116,16 +131,7 @@ GsrImage gsr_carve_image(char* base, int W, int H);
 void gsr_launch_preprocess(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,
                            const float* rotations, const float* cov3D_precomp, GsrGeom g, int32_t* radii,
-                           hipStream_t st, int first_hist_items = 0);
-// (also zeroes the first GSR_OS_STATE_WORDS words of g.os_scratch in A/B builds; first_hist_items != 0: one workgroup per
-// first_hist_items Gaussians, which also leaves the histogram of the depth sort's first pass in g.sort_hist)
-// A/B builds only -- split form: geometry (everything the binning chain needs) and colour (SH -> RGB into the splat
-// records); the colour kernel may run on another stream beside the depth sort (gsr_api.cpp).  Measured and rejected.
-int gsr_preprocess_split_available(void);
-void gsr_launch_preprocess_geom(const GsrCamDev& cam, int P, const float* means3D, const float* colors_precomp, const float* opacities,
-                                const float* scales, const float* rotations, const float* cov3D_precomp, GsrGeom g, int32_t* radii,
-                                hipStream_t st);
-void gsr_launch_preprocess_color(const GsrCamDev& cam, int P, const float* means3D, const float* shs, GsrGeom g, hipStream_t st);
+                           const GsrFrameStatsDev& fs, hipStream_t st);
 void gsr_launch_preprocess_backward(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
                                     const float* colors_precomp, const float* opacities, const float* scales,
                                     const float* rotations, const float* cov3D_precomp, const int32_t* radii,
@@ -147,7 +153,6 @@ void gsr_launch_preprocess_backward_sh_adam(const GsrCamDev& cam, int P, const f
                                             float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales,
                                             float* dL_drotations, const GsrShAdamDev& adam, hipStream_t st);
 void gsr_set_preprocess_grid_cap(int cap);      // tuning knob (option preprocess_grid_cap)
-int gsr_set_sh_dma(int mask);     // A/B builds: LDS-DMA staging of the SH block (option sh_dma: bit 0 forward, bit 1 backward); 0 = not in this build
 void gsr_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t st);
 
 // sort.hip: LSD radix sort of (u32 key, u32 value) pairs on bits [0, nbits); returns the index (0/1) of the
@@ -156,16 +161,13 @@ void gsr_launch_mark_visible(int P, const float* means3D, const float* view, uin
 // rect / rect_sorted (optional): the last pass also writes rect_sorted[pos] = rect[value] (depth sort: the tile rectangles
 // in depth order, which the scan and the emission stream afterwards)
 int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
-                         uint32_t* digit_total, int items, hipStream_t st, const uint2* rect = nullptr, uint2* rect_sorted = nullptr,
-                         bool first_hist_ready = false);
+                         uint32_t* digit_total, int items, hipStream_t st, const uint2* rect = nullptr, uint2* rect_sorted = nullptr);
 int gsr_radix_sort_pairs_k16(uint16_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
                              uint32_t* digit_total, int items, hipStream_t st);
-#define GSR_OS_STATE_WORDS 1088      // digit totals [4][256] + tickets [4] + error word (+ pad); zeroed by the key-producing kernel
-// one-kernel-per-pass depth sort (4 x 8 bits) with the rectangle gather fused into the last pass; result in vals[0]
-int gsr_onesweep_available(void);      // measurement builds (-DGSR_AB_VARIANTS) only
-size_t gsr_onesweep_scratch_bytes(int64_t n);
-void gsr_onesweep_depth_sort(uint32_t* keys[2], uint32_t* vals[2], int64_t n, uint32_t* scratch, const uint2* rect,
-                             uint2* rect_sorted, uint32_t** err_word_dev, hipStream_t st);
+// depthsort.hip: depth order + rectangles in depth order + inclusive scan of the tile counts + the emission's block table
+void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, const uint2* rect, const uint32_t* frame,
+                                  const GsrDepthSortBufs& b, uint32_t* order, uint2* rect_sorted, uint32_t* offsets, uint2* block_first,
+                                  uint32_t block_first_cap, uint32_t* slow_word, hipStream_t st);
 // pass plan shared by the sorter and by code that must know which ping-pong buffer holds the result
 int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits /*[8]*/);
 #define GSR_DEPTH_DIGIT_BITS 9      // 27-bit depth keys: 3 passes of 9 bits (round 2: 4 x 8 on 32 bits; 3 x 11 measured slower: 113 vs 91 us)
@@ -180,8 +182,7 @@ static inline int64_t gsr_sort_blocks(int64_t n, bool small_blocks) {
 // host_word (mapped pinned, may be NULL): [0] = R low word, [2] = R high word, [1] = seq (stored last)
 void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint2* rect, uint2* rect_sorted /*[P]*/, uint32_t* offsets,
                            uint64_t* block_sums, uint2* block_first, uint32_t block_first_cap, uint32_t* num_rendered,
-                           uint32_t* host_word, uint32_t seq, bool rect_already_sorted, const uint32_t* sort_err /*device, may be NULL*/,
-                           hipStream_t st);
+                           uint32_t* host_word, uint32_t seq, bool rect_already_sorted, hipStream_t st);
 // legacy emission (frames with more than 65536 tiles): 32-bit tile ids
 void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect_sorted,
                      void* inst_keys, bool key16, uint32_t* inst_vals, float4* splats /*NULL: skip the goffset write*/,
@@ -276,8 +277,7 @@ void gsr_launch_train_loss_backward(int planes, int H, int W, const float* img1,
                                     const float* dm_dmu1, const float* dm_dex2, const float* dm_dexy, float* dL_dimg1, hipStream_t st);
 // binning.hip: gathered splat records -> geometry state of this rank's band (two-axis sharding)
 void gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
-                             uint32_t* keys, uint32_t* vals, uint32_t* sort_state /*zeroed, GSR_OS_STATE_WORDS*/, uint32_t* key_overflow,
-                             hipStream_t st);
+                             uint32_t* keys, uint32_t* vals, const GsrFrameStatsDev& fs, hipStream_t st);
 // binning.hip: full 32-bit depth keys from the splat records (fallback of the 27-bit depth sort)
 void gsr_launch_rekey_full(int P, const float4* splats, const uint32_t* tiles, uint32_t* keys, uint32_t* vals, hipStream_t st);
 
@@ -289,5 +289,5 @@ void gsr_launch_route_count(int P, const float* records, int n_bands, const int3
 void gsr_launch_route_pack(int P, const float* records, int n_bands, const int32_t* bounds, const int64_t* band_offsets,
                            const uint32_t* block_offsets, float* packed, int32_t* send_ids, hipStream_t st);
 void gsr_launch_ingest_packed(int P, const float* packed, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
-                              uint32_t* keys, uint32_t* vals, uint32_t* sort_state, uint32_t* key_overflow, hipStream_t st);
+                              uint32_t* keys, uint32_t* vals, const GsrFrameStatsDev& fs, hipStream_t st);
 void gsr_launch_route_add_rows(int64_t n, const int32_t* ids, const float* rows, float* out, hipStream_t st);

@@ -14,17 +14,11 @@
 // wave-uniform -> scalar loads.
 #include "gsr_internal.h"
 #include "gsr_adam_math.h"
+#include "gsr_frame.h"
 
 namespace {
 
-// experiment (measurement build): ask for 3 waves per SIMD in the two per-Gaussian kernels (costs 25-49 spilled registers)
-#if defined(GSR_AB_VARIANTS) && defined(GSR_PRE_WAVES3)
-#define GSR_PRE_OCC __attribute__((amdgpu_waves_per_eu(3, 3)))
-#elif defined(GSR_AB_VARIANTS) && defined(GSR_PRE_WAVES2)
-#define GSR_PRE_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))
-#else
-#define GSR_PRE_OCC
-#endif
+#define GSR_PRE_OCC      // (3 waves per SIMD via amdgpu_waves_per_eu costs 25-49 spilled registers: measured slower, round 2)
 
 constexpr int SH_ROW = 52;        // LDS row stride in floats for a 48-float SH record (52*l mod 64 hits 16 distinct bank quads)
 
@@ -78,34 +72,6 @@ __device__ __forceinline__ void wave_load_sh16(const float* __restrict__ shs, in
         const int idx = it * 64 + lane;
         const int g = idx / 12, part = idx - g * 12;
         *reinterpret_cast<float4*>(tile + g * SH_ROW + part * 4) = v[it];
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-// gfx950 form of the same copy: global -> LDS directly (global_load_lds_dwordx4, "LDS DMA"): the wave's 12 KB block lands in
-// the tile in memory order -- row stride 48 floats, no padding -- without passing through registers, so the block costs no
-// VGPRs while it is in flight and can stay in flight across the whole projection arithmetic.  `shs` must be 16-byte aligned.
-// Completion is tracked by vmcnt like any load (the compiler waits before the first LDS read that may alias).
-constexpr int SH_ROW_DMA = 48;
-__device__ __forceinline__ void wave_dma_sh16(const float* __restrict__ shs, int64_t i0, int P, int lane, float* tile) {
-    const int nchunk = (int)((P - i0) < 64 ? (P - i0) : 64) * 12;
-    const char* src = reinterpret_cast<const char*>(shs + i0 * 48);
-#pragma unroll
-    for (int it = 0; it < 12; ++it) {
-        const int idx = it * 64 + lane;
-        if (idx < nchunk)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + idx * 16),
-                                             (__attribute__((address_space(3))) void*)(tile + it * 256), 16, 0, 0);
-    }
-}
-// ... and the dense tile back to global memory (every row up to P, zero rows included)
-__device__ __forceinline__ void wave_store_sh16_dense(float* __restrict__ dst_all, int64_t i0, int P, int lane, const float* tile) {
-    float4* dst = reinterpret_cast<float4*>(dst_all + i0 * 48);
-    const int nchunk = (int)((P - i0) < 64 ? (P - i0) : 64) * 12;
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < 12; ++it) {
-        const int idx = it * 64 + lane;
-        if (idx < nchunk) dst[idx] = *reinterpret_cast<const float4*>(tile + idx * 4);
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -216,7 +182,8 @@ __device__ __forceinline__ void wave_store_sh_split_dense(float* __restrict__ d_
     __builtin_amdgcn_wave_barrier();
 }
 // SPLIT = the separate dc / rest form (always staged: the C ABI accepts it only for M == 16 and 16-byte aligned pointers)
-template <bool SPLIT, bool DMA>
+// fs: frame statistics (gsr_frame.h) -- the kernel's last workgroup publishes R and the depth-key range
+template <bool SPLIT>
 __global__ void __launch_bounds__(256) GSR_PRE_OCC
 preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
                       const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
@@ -224,24 +191,8 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
                       const float* __restrict__ cov3D_precomp, float4* __restrict__ splats,
                       uint2* __restrict__ rect, uint32_t* __restrict__ tiles, uint32_t* __restrict__ clamped_out,
                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int32_t* __restrict__ radii,
-                      uint32_t* __restrict__ sort_state /*GSR_OS_STATE_WORDS words zeroed for the depth sort that follows*/,
-                      uint32_t* __restrict__ first_hist, int hist_items, uint32_t* key_overflow) {
+                      GsrFrameStatsDev fs) {
     __shared__ __attribute__((aligned(16))) float s_sh[4][64 * SH_ROW];
-    // first_hist != NULL: workgroup b owns Gaussians [b * hist_items, (b + 1) * hist_items) -- exactly the keys of workgroup
-    // b of the depth sort's first radix pass -- and leaves that pass's digit histogram (low 8 key bits) in
-    // first_hist[d * gridDim.x + b], which saves the pass its histogram kernel (a launch and a read of all keys).
-    // (measurement build only: measured 4.3 us saved in the sort, 4.5 us lost here to the narrower grid)
-#ifdef GSR_AB_VARIANTS
-    constexpr bool HIST = true;
-#else
-    constexpr bool HIST = false;
-#endif
-    __shared__ uint32_t s_hist[HIST ? 256 : 1];
-    if (!HIST) first_hist = nullptr;
-    if (first_hist) s_hist[threadIdx.x] = 0u;
-    if (sort_state && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < GSR_OS_STATE_WORDS; i += 256) sort_state[i] = 0u;
-    if (first_hist) __syncthreads();
     GsrCam cam;
     load_cam(camd, cam);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -251,15 +202,9 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
     // bands of a quarter of the frame or more: still cheaper than a second latency phase (measured: 0.098 ms two-phase vs
     // 0.074 ms speculative for a quarter-frame band at 1 M Gaussians)
     const bool speculative = (cam.tile_y1 - cam.tile_y0) * 4 >= cam.gy;
-    // DMA (chosen by the launcher: fused SH form, M == 16, 16-byte aligned, full-frame band): see wave_dma_sh16
-    constexpr bool dma_sh = DMA && !SPLIT;
-    constexpr int sh_row = dma_sh ? SH_ROW_DMA : SH_ROW;
     // wave-uniform trip count: every lane of a wave runs the same iterations (lanes past P idle inside)
-    const int64_t i_first = first_hist ? (int64_t)blockIdx.x * hist_items + wv * 64 : ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane;
-    const int64_t i_stride = first_hist ? 256 : (int64_t)gridDim.x * blockDim.x;
-    const int64_t i_limit = first_hist ? min((int64_t)P, ((int64_t)blockIdx.x + 1) * hist_items) : (int64_t)P;
-    bool key_ovf = false;
-    for (int64_t i0 = i_first; i0 < i_limit; i0 += i_stride) {
+    GsrFrameAcc acc;
+    for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < P; i0 += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = i0 + lane;
         const bool in_range = i < P;
         GsrSplat sp;
@@ -274,19 +219,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         const bool spec_sh = staged_sh && speculative;
         float4 g_rot = make_float4(0.f, 0.f, 0.f, 0.f);
         float g_s[3] = {0.f, 0.f, 0.f}, g_op = 0.f;
-        if (dma_sh) {
-            // geometry first, the SH block behind it: vmcnt retires in order, so the projection can start as soon as the
-            // geometry has landed while the 12 KB block is still streaming into the tile
-            if (in_range) {
-                mean[0] = means3D[i * 3 + 0]; mean[1] = means3D[i * 3 + 1]; mean[2] = means3D[i * 3 + 2];
-                g_op = opacities[i];
-                if (!cov3D_precomp) {
-                    g_s[0] = scales[i * 3 + 0]; g_s[1] = scales[i * 3 + 1]; g_s[2] = scales[i * 3 + 2];
-                    g_rot = reinterpret_cast<const float4*>(rotations)[i];
-                }
-            }
-            wave_dma_sh16(shs, i0, P, lane, tile);
-        } else if (spec_sh) {
+        if (spec_sh) {
             float4 shreg[12];
             if (!SPLIT) wave_issue_sh16(shs, i0, P, lane, shreg);
             if (in_range) {     // the geometry loads ride in the same latency window
@@ -301,7 +234,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             else wave_commit_sh16(shreg, ~0ull, lane, tile);
         }
         if (in_range) {
-            if (!spec_sh && !dma_sh) {
+            if (!spec_sh) {
                 mean[0] = means3D[i * 3 + 0]; mean[1] = means3D[i * 3 + 1]; mean[2] = means3D[i * 3 + 2];
                 g_op = opacities[i];
             }
@@ -310,7 +243,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
 #pragma unroll
                 for (int k = 0; k < 6; ++k) cov[k] = cov3D_precomp[i * 6 + k];
             } else {
-                if (!spec_sh && !dma_sh) {
+                if (!spec_sh) {
                     g_s[0] = scales[i * 3 + 0]; g_s[1] = scales[i * 3 + 1]; g_s[2] = scales[i * 3 + 2];
                     g_rot = reinterpret_cast<const float4*>(rotations)[i];
                 }
@@ -322,7 +255,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         // colours are needed only by Gaussians that touch this rank's band of tile rows (all visible ones on one GPU):
         // with the screen sharded over N GPUs each rank streams ~1/N of the SH records
         const bool need_color = vis && sp.tiles > 0;
-        if (staged_sh && !dma_sh) {
+        if (staged_sh) {
             const uint64_t rows = __ballot(need_color);
             if (rows) {
                 if (spec_sh) { /* already staged */ }
@@ -341,7 +274,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
                 rgb[0] = colors_precomp[i * 3 + 0]; rgb[1] = colors_precomp[i * 3 + 1]; rgb[2] = colors_precomp[i * 3 + 2];
             } else if (staged_sh) {
                 if (SPLIT) gsr_sh_to_rgb_row(cam.sh_degree, 16, GsrShRowSplit{tile + SPLIT_DC + lane * 3, tile + lane * 45}, mean, cam.campos, rgb, clampbits);
-                else gsr_sh_to_rgb_row(cam.sh_degree, 16, GsrShRowAligned{tile + lane * sh_row}, mean, cam.campos, rgb, clampbits);
+                else gsr_sh_to_rgb_row(cam.sh_degree, 16, GsrShRowAligned{tile + lane * SH_ROW}, mean, cam.campos, rgb, clampbits);
             } else if (!SPLIT) {
                 gsr_sh_to_rgb(cam.sh_degree, cam.M, shs + i * (int64_t)cam.M * 3, mean, cam.campos, rgb, clampbits);
             }
@@ -362,131 +295,14 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         if (clamped_out) clamped_out[i] = clampbits;
         radii[i] = sp.radius;
         // depth-sort key (gsr_internal.h): 27 bits of bits(depth) - bits(0.2f); Gaussians with no tile in the band sort last.
-        const uint32_t key = gsr_depth_key(sp.depth, sp.tiles != 0u, key_ovf);
+        const uint32_t key = gsr_depth_key(sp.depth, sp.tiles != 0u, acc.ovf);
         keys[i] = key;
         vals[i] = (uint32_t)i;
-        if (first_hist) atomicAdd(&s_hist[key & 255u], 1u);
+        acc.add(key, sp.tiles);
     }
-    gsr_report_key_overflow(key_ovf, key_overflow);
-    if (first_hist) {
-        __syncthreads();
-        first_hist[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = s_hist[threadIdx.x];
-    }
+    gsr_frame_stats_commit(fs, acc.tiles, acc.kmin, acc.kmax, acc.ovf);
 }
 
-#ifdef GSR_AB_VARIANTS
-// ------------------------------------------------------------------------------------------------------------------
-// Split form of the forward preprocess: GEOMETRY (projection, tile rectangle, sort key, splat record without colour) and
-// COLOUR (SH -> RGB into the record).  Only the geometry is on the critical path of the binning chain: the depth sort,
-// scan and tile sort that follow need keys and rectangles, not colours, and they are latency-bound kernels that leave most
-// of the GPU idle -- so the library runs the colour kernel on a second HIP stream BESIDE them (gsr_api.cpp) and joins the
-// two streams in front of the blend.  Same arithmetic as the fused kernel, identical outputs.
-// MEASURED AND REJECTED (round 2, 1 M Gaussians @1080p, parity green in both modes): the two kernels cost 41 + 56 us against
-// 74 us fused (the colour kernel's 12-byte writes into 64-byte records are partial-line stores), and with the colour kernel
-// on the second stream the depth sort beside it slows from 95 to 133 us -- its kernels are latency-bound and lose their
-// CUs / memory queue slots to the streaming kernel -- so the frame gets 0.486 ms instead of 0.467.  Measurement build only
-// (option color_overlap = 1 / 2).
-// ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-preprocess_geom_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, const float* __restrict__ colors_precomp,
-                       const float* __restrict__ opacities, const float* __restrict__ scales, const float* __restrict__ rotations,
-                       const float* __restrict__ cov3D_precomp, float4* __restrict__ splats, uint2* __restrict__ rect,
-                       uint32_t* __restrict__ tiles, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                       int32_t* __restrict__ radii, uint32_t* __restrict__ sort_state, uint32_t* key_overflow) {
-    if (sort_state && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < GSR_OS_STATE_WORDS; i += 256) sort_state[i] = 0u;
-    GsrCam cam;
-    load_cam(camd, cam);
-    bool key_ovf = false;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
-        GsrSplat sp;
-        sp.radius = 0; sp.tiles = 0; sp.minx = sp.miny = sp.maxx = sp.maxy = 0; sp.depth = 0.f;
-        const float mean[3] = {means3D[i * 3 + 0], means3D[i * 3 + 1], means3D[i * 3 + 2]};
-        float cov[6];
-        if (cov3D_precomp) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) cov[k] = cov3D_precomp[i * 6 + k];
-        } else {
-            const float sc[3] = {scales[i * 3 + 0], scales[i * 3 + 1], scales[i * 3 + 2]};
-            const float4 q4 = reinterpret_cast<const float4*>(rotations)[i];
-            const float q[4] = {q4.x, q4.y, q4.z, q4.w};
-            gsr_cov3d(sc, cam.scale_modifier, q, cov);
-        }
-        const bool vis = gsr_project(cam, mean, cov, opacities[i], sp);
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-        if (vis) {
-            float rgb[3] = {0.f, 0.f, 0.f};
-            if (colors_precomp && sp.tiles > 0) {
-                rgb[0] = colors_precomp[i * 3 + 0]; rgb[1] = colors_precomp[i * 3 + 1]; rgb[2] = colors_precomp[i * 3 + 2];
-            }
-            q0 = make_float4(sp.px, sp.py, sp.conA, sp.conB);
-            q1 = make_float4(sp.conC, sp.opacity, rgb[0], rgb[1]);
-            q2 = make_float4(rgb[2], sp.depth, sp.tau, gsr_inv_depth(sp.depth));
-        }
-        const uint2 rc = make_uint2(sp.minx | (sp.maxx << 16), sp.miny | (sp.maxy << 16));
-        splats[i * 4 + 0] = q0;
-        splats[i * 4 + 1] = q1;
-        splats[i * 4 + 2] = q2;
-        splats[i * 4 + 3] = make_float4(__uint_as_float(rc.x), __uint_as_float(rc.y), 0.f, __uint_as_float(sp.tiles));
-        rect[i] = rc;
-        tiles[i] = sp.tiles;
-        radii[i] = sp.radius;
-        keys[i] = gsr_depth_key(sp.depth, sp.tiles != 0u, key_ovf);
-        vals[i] = (uint32_t)i;
-    }
-    gsr_report_key_overflow(key_ovf, key_overflow);
-}
-
-// colours of the Gaussians that touch this rank's band (tiles > 0), written into the records the geometry kernel made
-template <bool SPLIT>
-__global__ void __launch_bounds__(256)
-preprocess_color_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
-                        const uint32_t* __restrict__ tiles, float4* __restrict__ splats) {
-    __shared__ __attribute__((aligned(16))) float s_sh[4][64 * SH_ROW];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float* tile = s_sh[wv];
-    const float* dc = SPLIT ? camd.sh_dc : nullptr;
-    const int M = camd.M, deg = camd.sh_degree;
-    const bool staged_sh = M == 16;
-    const bool speculative = (camd.tile_y1 - camd.tile_y0) * 4 >= camd.gy;
-    const float campos[3] = {camd.campos[0], camd.campos[1], camd.campos[2]};
-    for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < P; i0 += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = i0 + lane;
-        const bool in_range = i < P;
-        const bool spec_sh = staged_sh && speculative;
-        float4 shreg[12];
-        if (spec_sh && !SPLIT) wave_issue_sh16(shs, i0, P, lane, shreg);
-        float mean[3] = {0.f, 0.f, 0.f};
-        bool need = false;
-        if (in_range) {
-            need = tiles[i] > 0u;
-            mean[0] = means3D[i * 3 + 0]; mean[1] = means3D[i * 3 + 1]; mean[2] = means3D[i * 3 + 2];
-        }
-        if (staged_sh) {
-            if (spec_sh) {
-                if (SPLIT) wave_load_sh_split_dense(dc, shs, i0, P, ~0ull, lane, tile);
-                else wave_commit_sh16(shreg, ~0ull, lane, tile);
-            } else {
-                const uint64_t rows = __ballot(need);
-                if (rows) {
-                    if (SPLIT) wave_load_sh_split_dense(dc, shs, i0, P, rows, lane, tile);
-                    else wave_load_sh16(shs, i0, P, rows, lane, tile);
-                }
-            }
-        }
-        if (!need) continue;
-        float rgb[3] = {0.f, 0.f, 0.f};
-        uint32_t clampbits = 0;
-        if (staged_sh && SPLIT) gsr_sh_to_rgb_row(deg, 16, GsrShRowSplit{tile + SPLIT_DC + lane * 3, tile + lane * 45}, mean, campos, rgb, clampbits);
-        else if (staged_sh) gsr_sh_to_rgb_row(deg, 16, GsrShRowAligned{tile + lane * SH_ROW}, mean, campos, rgb, clampbits);
-        else if (!SPLIT) gsr_sh_to_rgb(deg, M, shs + i * (int64_t)M * 3, mean, campos, rgb, clampbits);
-        float* rec = reinterpret_cast<float*>(splats + i * 4);
-        *reinterpret_cast<float2*>(rec + 6) = make_float2(rgb[0], rgb[1]);      // q1.zw
-        rec[8] = rgb[2];                                                        // q2.x
-    }
-}
-
-#endif  // GSR_AB_VARIANTS
 
 // The Adam step of the two SH tensors straight from the gradient tile (gsr_backward_preprocess_sh_adam): the gradient never
 // travels to HBM and back, and the parameter rows the kernel loaded a moment ago are re-read from L2.  Same pieces, same 16-byte
@@ -567,9 +383,10 @@ __device__ __forceinline__ void wave_adam_sh_split_dense(const GsrShAdamDev& ad,
     __builtin_amdgcn_wave_barrier();
 }
 
-template <bool SPLIT, bool DMA, bool ADAM = false>
+// `shs` carries no __restrict__: in the ADAM instantiation it is adam.rest, which the kernel also writes (the update in place)
+template <bool SPLIT, bool ADAM = false>
 __global__ void __launch_bounds__(256) GSR_PRE_OCC
-preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
+preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, const float* shs,
                       const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                       const float* __restrict__ scales, const float* __restrict__ rotations,
                       const float* __restrict__ cov3D_precomp, const int32_t* __restrict__ radii,
@@ -586,8 +403,7 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
     const float* dc = SPLIT ? camd.sh_dc : nullptr;     // split form: `shs` / dL_dsh hold coefficients 1..15, dc / dL_ddc coefficient 0
     float* dL_ddc = SPLIT ? camd.dL_dsh_dc : nullptr;
     const bool staged_sh = shs != nullptr && M == 16;
-    constexpr bool dma_sh = DMA && !SPLIT;      // launcher: fused SH form, M == 16, shs / dL_dsh 16-byte aligned
-    constexpr int sh_row = dma_sh ? SH_ROW_DMA : SH_ROW;
+    constexpr int sh_row = SH_ROW;
     for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < P; i0 += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = i0 + lane;
         const bool in_range = i < P;
@@ -619,7 +435,6 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         }
         if (staged_sh) {
             if (SPLIT) wave_load_sh_split_dense(dc, shs, i0, P, ~0ull, lane, tile);
-            else if (dma_sh) wave_dma_sh16(shs, i0, P, lane, tile);      // streams in behind the geometry, costs no registers
             else wave_load_sh16(shs, i0, P, ~0ull, lane, tile);
         }
         const bool vis = in_range && rad > 0;
@@ -639,8 +454,6 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             dm2y = g.dpy * (0.5f * (float)cam.H);
             if (!cov3D_precomp) gsr_cov3d_backward(s, cam.scale_modifier, q, dcov, dscale, drot);
         }
-        // the tile is read AND written below (gradient in place, zero rows): the block must have landed for every lane
-        if (dma_sh) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
         if (vis) {
             if (shs) {
                 // The colour clamp mask is recomputed from the SH record (a few hundred FLOPs on data that is loaded anyway)
@@ -690,7 +503,6 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         if (staged_sh) {
             if (SPLIT && ADAM) wave_adam_sh_split_dense(adam, i0, P, adam.sparse ? __ballot(vis) : ~0ull, lane, tile);
             else if (SPLIT) wave_store_sh_split_dense(dL_ddc, dL_dsh, i0, P, lane, tile);
-            else if (dma_sh) wave_store_sh16_dense(dL_dsh, i0, P, lane, tile);
             else wave_store_sh16(dL_dsh, i0, P, lane, tile);
         }
         if (!in_range) continue;
@@ -717,17 +529,6 @@ mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __res
     }
 }
 
-// option sh_dma (measurement build): SH blocks go global -> LDS directly (global_load_lds_dwordx4) in the forward (bit 0) /
-// backward (bit 1) per-Gaussian kernel.  MEASURED (round 2, 1 M Gaussians, parity green): the forward drops from 187 to 153
-// VGPRs (3 waves/SIMD instead of 2) and gets 2-3 us SLOWER (0.072-0.074 vs 0.069-0.071 ms: the unpadded 192-byte rows cost
-// 4-way LDS bank conflicts and the kernel was not occupancy-bound); the backward gains 1 % (0.137-0.139 vs 0.140 ms).
-// Asking for 3 waves/SIMD with spills (amdgpu_waves_per_eu) loses 35 us in the forward and is a wash in the backward.
-#ifdef GSR_AB_VARIANTS
-int g_sh_dma = 0;
-#else
-constexpr int g_sh_dma = 0;
-#endif
-
 int g_stream_grid_cap = 1024;      // option preprocess_grid_cap (tuning): workgroups of the grid-stride per-Gaussian kernels
                                    // (two interleaved A/B sessions: 1024 -> 0.068 / 0.072 ms, 2048 -> 0.070 / 0.076, 512 -> 0.076, 4096 -> 0.074)
 
@@ -743,50 +544,15 @@ inline int stream_grid(int64_t n) {
 void gsr_launch_preprocess(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
                            const float* colors_precomp, const float* opacities, const float* scales,
                            const float* rotations, const float* cov3D_precomp, GsrGeom g, int32_t* radii,
-                           hipStream_t st, int first_hist_items) {
-    // first_hist_items != 0: one workgroup per workgroup of the depth sort's first pass (see the kernel)
-    const int grid = first_hist_items ? (int)(((int64_t)P + first_hist_items - 1) / first_hist_items) : stream_grid(P);
-    uint32_t* first_hist = first_hist_items ? g.sort_hist : nullptr;
-    // fused SH records of degree-3 storage, 16-byte aligned, full-frame band: the SH block goes global -> LDS directly
-    const bool dma = (g_sh_dma & 1) && !cam.sh_dc && shs && cam.M == 16 && (reinterpret_cast<uintptr_t>(shs) & 15) == 0 &&
-                     (cam.tile_y1 - cam.tile_y0) * 4 >= cam.gy;
-#define GSR_PRE_FWD(SPLIT_, DMA_)                                                                                                     \
-    hipLaunchKernelGGL((preprocess_fwd_kernel<SPLIT_, DMA_>), dim3(grid), dim3(256), 0, st, cam, P, means3D, shs, colors_precomp,        \
+                           const GsrFrameStatsDev& fs, hipStream_t st) {
+#define GSR_PRE_FWD(SPLIT_)                                                                                                            \
+    hipLaunchKernelGGL((preprocess_fwd_kernel<SPLIT_>), dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs, colors_precomp,    \
                        opacities, scales, rotations, cov3D_precomp, g.splats, g.rect, g.tiles,                                         \
-                       /*clamped (recomputed by the backward)*/ nullptr, g.keys[0], g.vals[0], radii,                                 \
-                       gsr_onesweep_available() ? g.os_scratch : nullptr, first_hist, first_hist_items, g.key_overflow)
-    if (cam.sh_dc) GSR_PRE_FWD(true, false);
-#ifdef GSR_AB_VARIANTS
-    else if (dma) GSR_PRE_FWD(false, true);
-#endif
-    else GSR_PRE_FWD(false, false);
+                       /*clamped (recomputed by the backward)*/ nullptr, g.keys[0], g.vals[0], radii, fs)
+    if (cam.sh_dc) GSR_PRE_FWD(true);
+    else GSR_PRE_FWD(false);
 #undef GSR_PRE_FWD
-    (void)dma;
 }
-
-#ifdef GSR_AB_VARIANTS
-int gsr_preprocess_split_available(void) { return 1; }
-void gsr_launch_preprocess_geom(const GsrCamDev& cam, int P, const float* means3D, const float* colors_precomp, const float* opacities,
-                                const float* scales, const float* rotations, const float* cov3D_precomp, GsrGeom g, int32_t* radii,
-                                hipStream_t st) {
-    hipLaunchKernelGGL(preprocess_geom_kernel, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, colors_precomp, opacities, scales,
-                       rotations, cov3D_precomp, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], radii,
-                       gsr_onesweep_available() ? g.os_scratch : nullptr, g.key_overflow);
-}
-
-void gsr_launch_preprocess_color(const GsrCamDev& cam, int P, const float* means3D, const float* shs, GsrGeom g, hipStream_t st) {
-    if (cam.sh_dc)
-        hipLaunchKernelGGL(preprocess_color_kernel<true>, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs, g.tiles, g.splats);
-    else
-        hipLaunchKernelGGL(preprocess_color_kernel<false>, dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs, g.tiles, g.splats);
-}
-
-#else
-int gsr_preprocess_split_available(void) { return 0; }
-void gsr_launch_preprocess_geom(const GsrCamDev&, int, const float*, const float*, const float*, const float*, const float*, const float*,
-                                GsrGeom, int32_t*, hipStream_t) {}
-void gsr_launch_preprocess_color(const GsrCamDev&, int, const float*, const float*, GsrGeom, hipStream_t) {}
-#endif  // GSR_AB_VARIANTS
 
 void gsr_launch_preprocess_backward(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
                                     const float* colors_precomp, const float* opacities, const float* scales,
@@ -794,20 +560,14 @@ void gsr_launch_preprocess_backward(const GsrCamDev& cam, int P, const float* me
                                     GsrGeom g, const float* splat_grads, float* dL_dmeans2D, float* dL_dcolors,
                                     float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                                     float* dL_dscales, float* dL_drotations, hipStream_t st) {
-    const bool dma = (g_sh_dma & 2) && !cam.sh_dc && shs && cam.M == 16 &&
-                     ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(dL_dsh)) & 15) == 0;
-#define GSR_PRE_BWD(SPLIT_, DMA_)                                                                                                     \
-    hipLaunchKernelGGL((preprocess_bwd_kernel<SPLIT_, DMA_>), dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs,             \
+#define GSR_PRE_BWD(SPLIT_)                                                                                                     \
+    hipLaunchKernelGGL((preprocess_bwd_kernel<SPLIT_>), dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs,             \
                        colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g.clamped,                                 \
                        reinterpret_cast<const float4*>(splat_grads), dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D,     \
                        dL_dsh, dL_dscales, dL_drotations, GsrShAdamDev{})
-    if (cam.sh_dc) GSR_PRE_BWD(true, false);
-#ifdef GSR_AB_VARIANTS
-    else if (dma) GSR_PRE_BWD(false, true);
-#endif
-    else GSR_PRE_BWD(false, false);
+    if (cam.sh_dc) GSR_PRE_BWD(true);
+    else GSR_PRE_BWD(false);
 #undef GSR_PRE_BWD
-    (void)dma;
 }
 
 void gsr_launch_preprocess_backward_sh_adam(const GsrCamDev& cam, int P, const float* means3D, const float* opacities,
@@ -816,7 +576,7 @@ void gsr_launch_preprocess_backward_sh_adam(const GsrCamDev& cam, int P, const f
                                             float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales,
                                             float* dL_drotations, const GsrShAdamDev& adam, hipStream_t st) {
     // split-SH form, M == 16: cam.sh_dc / `shs` are adam.dc / adam.rest (read for the colour clamp, then updated in place)
-    hipLaunchKernelGGL((preprocess_bwd_kernel<true, false, true>), dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D,
+    hipLaunchKernelGGL((preprocess_bwd_kernel<true, true>), dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D,
                        (const float*)adam.rest, (const float*)nullptr, opacities, scales, rotations, cov3D_precomp, radii, g.clamped,
                        reinterpret_cast<const float4*>(splat_grads), dL_dmeans2D, (float*)nullptr, dL_dopacity, dL_dmeans3D, dL_dcov3D,
                        (float*)nullptr, dL_dscales, dL_drotations, adam);
@@ -826,10 +586,5 @@ void gsr_launch_mark_visible(int P, const float* means3D, const float* view, uin
     hipLaunchKernelGGL(mark_visible_kernel, dim3(stream_grid(P)), dim3(256), 0, st, P, means3D, view, present);
 }
 
-#ifdef GSR_AB_VARIANTS
-int gsr_set_sh_dma(int mask) { g_sh_dma = mask & 3; return 1; }
-#else
-int gsr_set_sh_dma(int) { return 0; }
-#endif
 
 void gsr_set_preprocess_grid_cap(int cap) { g_stream_grid_cap = cap < 64 ? 64 : cap; }

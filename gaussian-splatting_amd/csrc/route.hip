@@ -16,6 +16,7 @@
 // HBM-streaming kernels; records are read with 16-byte accesses, the 64-byte source records are line-aligned.
 #include "gsr_internal.h"
 #include "gsr_wave.h"
+#include "gsr_frame.h"
 
 namespace {
 
@@ -103,11 +104,8 @@ route_pack(int P, const float4* __restrict__ records, RouteBands rb, RouteOffset
 
 __global__ void __launch_bounds__(256)
 ingest_packed(int P, const float4* __restrict__ packed, int y0, int y1, float4* __restrict__ splats, uint2* __restrict__ rect,
-              uint32_t* __restrict__ tiles, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-              uint32_t* __restrict__ sort_state, uint32_t* key_overflow) {
-    if (sort_state && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < GSR_OS_STATE_WORDS; i += 256) sort_state[i] = 0u;
-    bool key_ovf = false;
+              uint32_t* __restrict__ tiles, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GsrFrameStatsDev fs) {
+    GsrFrameAcc acc;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 q0 = packed[i * 3 + 0], q1 = packed[i * 3 + 1], p2 = packed[i * 3 + 2];
         const uint32_t rx = __float_as_uint(p2.z), ry = __float_as_uint(p2.w);
@@ -123,10 +121,12 @@ ingest_packed(int P, const float4* __restrict__ packed, int y0, int y1, float4* 
         splats[i * 4 + 3] = make_float4(__uint_as_float(rc.x), __uint_as_float(rc.y), 0.f, __uint_as_float(t));
         rect[i] = rc;
         tiles[i] = t;
-        keys[i] = gsr_depth_key(depth, t != 0u, key_ovf);
+        const uint32_t key = gsr_depth_key(depth, t != 0u, acc.ovf);
+        keys[i] = key;
         vals[i] = (uint32_t)i;
+        acc.add(key, t);
     }
-    gsr_report_key_overflow(key_ovf, key_overflow);
+    gsr_frame_stats_commit(fs, acc.tiles, acc.kmin, acc.kmax, acc.ovf);
 }
 
 // out[ids[r]] += rows[r] for r in [0, n): ids are distinct within one launch
@@ -176,12 +176,12 @@ void gsr_launch_route_pack(int P, const float* records, int n_bands, const int32
 }
 
 void gsr_launch_ingest_packed(int P, const float* packed, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
-                              uint32_t* keys, uint32_t* vals, uint32_t* sort_state, uint32_t* key_overflow, hipStream_t st) {
+                              uint32_t* keys, uint32_t* vals, const GsrFrameStatsDev& fs, hipStream_t st) {
     int64_t nb = ((int64_t)P + 255) / 256;
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(ingest_packed, dim3((int)nb), dim3(256), 0, st, P, reinterpret_cast<const float4*>(packed), y0, y1, splats, rect,
-                       tiles, keys, vals, sort_state, key_overflow);
+                       tiles, keys, vals, fs);
 }
 
 void gsr_launch_route_add_rows(int64_t n, const int32_t* ids, const float* rows, float* out, hipStream_t st) {

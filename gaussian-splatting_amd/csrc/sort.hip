@@ -7,8 +7,8 @@
 // order, and the R instances are then sorted STABLY by tile id only (2 passes of ceil(bits/2) bits for <= 65536 tiles).  Stability makes the
 // final order identical to the reference's (tile, depth, emission order).
 //
-// One pass = three launches (a chained-scan "onesweep" pass was rejected: a cross-workgroup hop costs
-// 1-3 us under load on this part, MI355X_MICROARCH.md handoff rows, and the look-back chain is serial):
+// One pass = three launches (a chained-scan "onesweep" pass was built and rejected in round 2 -- 31-50 us per pass against
+// 22 us: a cross-workgroup hop costs 1-3 us under load on this part and the look-back chain is serial; git history):
 //   rs_hist    : per-workgroup digit histogram                          (reads keys)
 //   rs_scan    : one workgroup per digit scans its row over workgroups  (tiny)
 //   rs_scatter : wave64 ballot-match ranking, stable; items are re-ordered in LDS first so that every
@@ -325,221 +325,11 @@ rs_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_i
     }
 }
 
-#ifdef GSR_AB_VARIANTS
-// ------------------------------------------------------------------------------------------------------------------
-// "onesweep" pass for the depth sort (P keys, 8-bit digits): ONE kernel per pass instead of hist + scan + scatter.
-// Every workgroup ranks its 4096 keys locally, PUBLISHES its per-digit counts as flagged 32-bit words
-// (agent-scope stores: the word is data and flag at once -- cdna_hip_programming.md G16 form R2, no fences), then sums the
-// counts of ALL its predecessors (a column sum, not a serial look-back chain: with <= a few hundred workgroups that start
-// together every predecessor publishes at about the same time, and a serial chain of ~1 us hops would dominate) and
-// scatters.  Workgroups beyond 256 are chained through per-group inclusive prefixes.  Order of arrival is made explicit
-// with a TICKET (atomicAdd): a workgroup only ever waits for lower tickets, which have started by construction, so the
-// protocol cannot deadlock whatever the dispatch order or residency.  Every spin is bounded; on expiry an error word is
-// set (the host then reports an error instead of hanging).  Digit totals of all four passes come from one up-front
-// histogram kernel (digit histograms do not depend on the order of the keys).
-// MEASURED AND REJECTED (round 2, 1 M keys, bit-exact results): 31-50 us per pass against 22 us for hist + scan + scatter,
-// whether the look-back waits for 8 or 32 predecessors at a time -- the agent-scope (sc1) descriptor traffic and the
-// ticket / publish / poll chain cost more than the two kernel boundaries they replace (~1.5 us each).  Kept in the
-// measurement build only (-DGSR_AB_VARIANTS, option depth_sort_mode = 1).
-// ------------------------------------------------------------------------------------------------------------------
-constexpr int OS_IPT = 16;
-constexpr int OS_ITEMS = RS_THREADS * OS_IPT;      // 4096 keys per workgroup
-constexpr int OS_GROUP = 256;                      // workgroups per look-back group
-constexpr uint32_t OS_FLAG = 0x80000000u;
-constexpr uint32_t OS_SPIN_LIMIT = 1u << 22;
-
-typedef __attribute__((address_space(1))) uint32_t os_gu32;
-
-__device__ __forceinline__ void os_publish(uint32_t* p, uint32_t v) {
-    __hip_atomic_store((os_gu32*)p, v | OS_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint32_t os_peek(const uint32_t* p) {
-    return __hip_atomic_load((os_gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// sum of the published words col[b * 256] for b in [b0, b1).  32 independent loads are in flight per trip (the first
-// version waited for 8 at a time: 30 serial round trips of ~1 us made the pass slower than the three kernels it replaces).
-__device__ __forceinline__ uint32_t os_column_sum(const uint32_t* col, int b0, int b1, uint32_t* err) {
-    constexpr int CH = 32;
-    uint32_t sum = 0;
-    for (int b = b0; b < b1; b += CH) {
-        uint32_t spins = 0;
-        for (;;) {
-            uint32_t v[CH];
-            bool ok = true;
-#pragma unroll
-            for (int k = 0; k < CH; ++k) v[k] = (b + k < b1) ? os_peek(col + (int64_t)(b + k) * 256) : OS_FLAG;
-#pragma unroll
-            for (int k = 0; k < CH; ++k) ok &= (v[k] & OS_FLAG) != 0u;
-            if (ok) {
-#pragma unroll
-                for (int k = 0; k < CH; ++k) sum += v[k] & ~OS_FLAG;
-                break;
-            }
-            if (++spins > OS_SPIN_LIMIT) { *err = 1u; return sum; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    return sum;
-}
-
-// Digit totals of all four passes: totals[pass * 256 + d] (zeroed by the kernel that produced the keys) receive one global
-// atomic per non-empty (workgroup, pass, digit) bin.  Also resets the descriptor words / group prefixes of the four passes.
-__global__ void __launch_bounds__(RS_THREADS)
-os_hist_all(const uint32_t* __restrict__ keys, int64_t n, uint32_t* __restrict__ totals, int nblk, uint32_t* __restrict__ desc,
-            uint32_t* __restrict__ group_incl, int ngroups) {
-    __shared__ uint32_t h[4][256];
-    const int tid = threadIdx.x, lane = tid & 63;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) h[p][tid] = 0;
-    __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * OS_ITEMS;
-    uint32_t k[OS_IPT];
-#pragma unroll
-    for (int r = 0; r < OS_IPT; ++r) {
-        const int64_t idx = base + (int64_t)r * RS_THREADS + tid;
-        k[r] = idx < n ? keys[idx] : 0u;
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        desc[((int64_t)p * nblk + blockIdx.x) * 256 + tid] = 0u;
-        if ((int)blockIdx.x < ngroups) group_incl[((int64_t)p * ngroups + blockIdx.x) * 256 + tid] = 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < OS_IPT; ++r) {
-        const int64_t idx = base + (int64_t)r * RS_THREADS + tid;
-        const bool valid = idx < n;
-        const uint64_t vm = __ballot(valid);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const uint32_t d = (k[r] >> (8 * p)) & 255u;
-            // the high digits of depth keys are nearly constant: a wave whose valid lanes all agree adds once
-            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
-            const uint64_t same = __ballot(valid && d == d0);
-            if (same == vm) {
-                if (lane == 0 && vm) atomicAdd(&h[p][d0], (uint32_t)__popcll(vm));
-            } else if (valid) {
-                atomicAdd(&h[p][d], 1u);
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const uint32_t c = h[p][tid];
-        if (c) atomicAdd(totals + p * 256 + tid, c);
-    }
-}
-
-// FIRST: values are the item indices (not read); LAST: keys are not written (nobody reads them after the sort) and the
-// tile rectangle of every Gaussian is gathered into depth order (rect_sorted) -- the 8-byte random gather the scan kernel
-// used to do, here hidden behind the other workgroups' ranking.
-template <bool FIRST, bool LAST>
-__global__ void __launch_bounds__(RS_THREADS)
-os_pass(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
-        uint32_t* __restrict__ vals_out, int64_t n, int shift, const uint32_t* __restrict__ totals /*[256] of this pass*/,
-        uint32_t* desc /*[nblk][256]*/, uint32_t* group_incl /*[ngroups][256]*/, uint32_t* ticket, uint32_t* err,
-        const uint2* __restrict__ rect, uint2* __restrict__ rect_sorted) {
-    __shared__ uint32_t wave_cnt[RS_WAVES][256];
-    __shared__ uint32_t digit_base[256];
-    __shared__ uint32_t wsum[RS_WAVES];
-    __shared__ uint32_t s_key[OS_ITEMS];
-    __shared__ uint32_t s_val[OS_ITEMS];
-    __shared__ uint32_t s_vb;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) s_vb = atomicAdd(ticket, 1u);
-#pragma unroll
-    for (int k = 0; k < RS_WAVES; ++k) wave_cnt[k][tid] = 0;
-    uint32_t dtot[1] = {totals[tid]};
-    const uint32_t dstart = block_excl_scan<1>(dtot, wsum, lane, w);      // keys whose digit is smaller (two barriers inside)
-    const int vb = (int)s_vb;                      // virtual workgroup id = arrival order
-    const int64_t wave_base = (int64_t)vb * OS_ITEMS + (int64_t)w * (64 * OS_IPT);
-    uint32_t key[OS_IPT], val[OS_IPT], rank[OS_IPT];
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int r = 0; r < OS_IPT; ++r) {
-        const int64_t idx = wave_base + r * 64 + lane;
-        const bool valid = idx < n;
-        key[r] = valid ? keys_in[idx] : 0u;
-        val[r] = FIRST ? (uint32_t)idx : (valid ? vals_in[idx] : 0u);
-    }
-#pragma unroll
-    for (int r = 0; r < OS_IPT; ++r) {
-        const int64_t idx = wave_base + r * 64 + lane;
-        const bool valid = idx < n;
-        const uint32_t d = (key[r] >> shift) & 255u;
-        uint64_t mask = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
-            mask &= bit ? bal : ~bal;
-        }
-        const uint32_t prior = wave_cnt[w][d];
-        rank[r] = prior + (uint32_t)__popcll(mask & lt_mask);
-        if (valid && (mask & lt_mask) == 0ull) wave_cnt[w][d] = prior + (uint32_t)__popcll(mask);
-        __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    // this workgroup's count of digit `tid`, published at once; local offsets while the others publish
-    uint32_t tot[1] = {wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid]};
-    os_publish(desc + (int64_t)vb * 256 + tid, tot[0]);
-    const uint32_t lbase = block_excl_scan<1>(tot, wsum, lane, w);
-    {
-        uint32_t run = lbase;
-#pragma unroll
-        for (int k = 0; k < RS_WAVES; ++k) {
-            const uint32_t t = wave_cnt[k][tid];
-            wave_cnt[k][tid] = run;
-            run += t;
-        }
-    }
-    // keys with digit `tid` in the workgroups before this one
-    const int g = vb / OS_GROUP, g0 = g * OS_GROUP;
-    uint32_t before = os_column_sum(desc + tid, g0, vb, err);
-    if (g > 0) {
-        uint32_t spins = 0, v;
-        while (((v = os_peek(group_incl + (int64_t)(g - 1) * 256 + tid)) & OS_FLAG) == 0u) {
-            if (++spins > OS_SPIN_LIMIT) { *err = 1u; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        before += v & ~OS_FLAG;
-    }
-    if (vb == g0 + OS_GROUP - 1) os_publish(group_incl + (int64_t)g * 256 + tid, before + tot[0]);   // last of its group
-    digit_base[tid] = dstart + before - lbase;        // global position = digit_base[d] + local slot
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < OS_IPT; ++r) {
-        const int64_t idx = wave_base + r * 64 + lane;
-        if (idx < n) {
-            const uint32_t d = (key[r] >> shift) & 255u;
-            const uint32_t lp = wave_cnt[w][d] + rank[r];
-            s_key[lp] = key[r];
-            s_val[lp] = val[r];
-        }
-    }
-    __syncthreads();
-    const int64_t block_base = (int64_t)vb * OS_ITEMS;
-    const uint32_t nvalid = (uint32_t)((n - block_base) < (int64_t)OS_ITEMS ? (n - block_base) : OS_ITEMS);
-#pragma unroll
-    for (int r = 0; r < OS_IPT; ++r) {
-        const uint32_t i = (uint32_t)r * RS_THREADS + tid;
-        if (i < nvalid) {
-            const uint32_t k = s_key[i], v = s_val[i];
-            const uint32_t pos = digit_base[(k >> shift) & 255u] + i;
-            if (!LAST) keys_out[pos] = k;
-            vals_out[pos] = v;
-            if (LAST) rect_sorted[pos] = rect[v];
-        }
-    }
-}
-
-#endif  // GSR_AB_VARIANTS
 
 template <typename KeyT, int IPT, int BITS>
 void sort_pass(KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vout, int64_t n, int shift, uint32_t* hist,
-               uint32_t* digit_total, int nblocks, const uint2* rect, uint2* rect_sorted, hipStream_t st, bool hist_ready = false) {
-    if (!hist_ready)      // (the producer of the keys may already have left this pass's histogram in `hist`)
-        hipLaunchKernelGGL((rs_hist<KeyT, IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, n, shift, hist, nblocks);
+               uint32_t* digit_total, int nblocks, const uint2* rect, uint2* rect_sorted, hipStream_t st) {
+    hipLaunchKernelGGL((rs_hist<KeyT, IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, n, shift, hist, nblocks);
     hipLaunchKernelGGL(rs_scan, dim3(1 << BITS), dim3(RS_THREADS), 0, st, hist, nblocks, digit_total);
     hipLaunchKernelGGL((rs_scatter<KeyT, IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, vin, kout, vout, n, shift, hist,
                        digit_total, nblocks, rect, rect_sorted);
@@ -547,12 +337,7 @@ void sort_pass(KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vout, int64_t n, 
 
 template <typename KeyT, int IPT>
 void sort_pass_bits(int bits, KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vout, int64_t n, int shift,
-                    uint32_t* hist, uint32_t* digit_total, int nblocks, const uint2* rect, uint2* rect_sorted, hipStream_t st,
-                    bool hist_ready) {
-    if (hist_ready && bits == 8) {
-        sort_pass<KeyT, IPT, 8>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st, true);
-        return;
-    }
+                    uint32_t* hist, uint32_t* digit_total, int nblocks, const uint2* rect, uint2* rect_sorted, hipStream_t st) {
     switch (bits) {
         case 11: sort_pass<KeyT, IPT, 11>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st); break;
         case 10: sort_pass<KeyT, IPT, 10>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st); break;
@@ -567,7 +352,7 @@ void sort_pass_bits(int bits, KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vo
 
 template <typename KeyT>
 int sort_pairs_t(KeyT* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
-                 uint32_t* digit_total, int items, const uint2* rect, uint2* rect_sorted, hipStream_t st, bool first_hist_ready) {
+                 uint32_t* digit_total, int items, const uint2* rect, uint2* rect_sorted, hipStream_t st) {
     int cur = 0;
     if (n <= 0) return cur;
     const int nblocks = (int)((n + items - 1) / items);
@@ -579,16 +364,16 @@ int sort_pairs_t(KeyT* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max
         uint2* rcs = p == passes - 1 ? rect_sorted : nullptr;
         if (items == 1024)
             sort_pass_bits<KeyT, 1024 / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
-                                                    digit_total, nblocks, rc, rcs, st, first_hist_ready && p == 0);
+                                                    digit_total, nblocks, rc, rcs, st);
         else if (items == 2048)
             sort_pass_bits<KeyT, 2048 / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
-                                                    digit_total, nblocks, rc, rcs, st, first_hist_ready && p == 0);
+                                                    digit_total, nblocks, rc, rcs, st);
         else if (items == 8192)
             sort_pass_bits<KeyT, 8192 / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
-                                                    digit_total, nblocks, rc, rcs, st, first_hist_ready && p == 0);
+                                                    digit_total, nblocks, rc, rcs, st);
         else
             sort_pass_bits<KeyT, 4096 / RS_THREADS>(pass_bits[p], keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, hist,
-                                                    digit_total, nblocks, rc, rcs, st, first_hist_ready && p == 0);
+                                                    digit_total, nblocks, rc, rcs, st);
         shift += pass_bits[p];
         cur ^= 1;
     }
@@ -597,42 +382,6 @@ int sort_pairs_t(KeyT* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max
 
 }  // namespace
 
-#ifdef GSR_AB_VARIANTS
-int gsr_onesweep_available(void) { return 1; }
-size_t gsr_onesweep_scratch_bytes(int64_t n) {
-    const size_t nblk = (size_t)((n + OS_ITEMS - 1) / OS_ITEMS), ngroups = (nblk + OS_GROUP - 1) / OS_GROUP;
-    return (4 * nblk * 256 /*desc*/ + 4 * ngroups * 256 /*group prefixes*/ + GSR_OS_STATE_WORDS) * 4;
-}
-
-// Depth sort of n (key, index) pairs, 4 onesweep passes of 8 bits: keys[0] in, vals[0] out (even pass count); vals need not
-// be initialised.  The first GSR_OS_STATE_WORDS words of `scratch` (digit totals [4][256], tickets [4], error word) must
-// have been ZEROED by the kernel that wrote the keys.  rect / rect_sorted: see os_pass<LAST>.  *err_word_dev receives the
-// device address of the error word (non-zero after a spin time-out).
-void gsr_onesweep_depth_sort(uint32_t* keys[2], uint32_t* vals[2], int64_t n, uint32_t* scratch, const uint2* rect,
-                             uint2* rect_sorted, uint32_t** err_word_dev, hipStream_t st) {
-    const int nblk = (int)((n + OS_ITEMS - 1) / OS_ITEMS), ngroups = (nblk + OS_GROUP - 1) / OS_GROUP;
-    uint32_t* totals = scratch;
-    uint32_t* tickets = scratch + 4 * 256;
-    uint32_t* desc = scratch + GSR_OS_STATE_WORDS;
-    uint32_t* group_incl = desc + (size_t)4 * nblk * 256;
-    if (err_word_dev) *err_word_dev = tickets + 4;
-    hipLaunchKernelGGL(os_hist_all, dim3(nblk), dim3(RS_THREADS), 0, st, keys[0], n, totals, nblk, desc, group_incl, ngroups);
-#define GSR_OS_PASS(FIRST_, LAST_, P_, IN_, OUT_)                                                                                   \
-    hipLaunchKernelGGL((os_pass<FIRST_, LAST_>), dim3(nblk), dim3(RS_THREADS), 0, st, keys[IN_], vals[IN_], keys[OUT_], vals[OUT_], n,  \
-                       8 * P_, totals + 256 * P_, desc + (size_t)P_ * nblk * 256, group_incl + (size_t)P_ * ngroups * 256,            \
-                       tickets + P_, tickets + 4, rect, rect_sorted)
-    GSR_OS_PASS(true, false, 0, 0, 1);
-    GSR_OS_PASS(false, false, 1, 1, 0);
-    GSR_OS_PASS(false, false, 2, 0, 1);
-    GSR_OS_PASS(false, true, 3, 1, 0);
-#undef GSR_OS_PASS
-}
-
-#else
-int gsr_onesweep_available(void) { return 0; }
-size_t gsr_onesweep_scratch_bytes(int64_t) { return 0; }
-void gsr_onesweep_depth_sort(uint32_t**, uint32_t**, int64_t, uint32_t*, const uint2*, uint2*, uint32_t**, hipStream_t) {}
-#endif  // GSR_AB_VARIANTS
 
 void gsr_launch_rs_scan(uint32_t* block_hist, int nblocks, int ndigits, uint32_t* digit_total, hipStream_t st) {
     hipLaunchKernelGGL(rs_scan, dim3(ndigits), dim3(RS_THREADS), 0, st, block_hist, nblocks, digit_total);
@@ -655,17 +404,12 @@ int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits) {
 }
 
 int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
-                         uint32_t* digit_total, int items, hipStream_t st, const uint2* rect, uint2* rect_sorted,
-                         bool first_hist_ready) {
-    // first_hist_ready: hist[d * nblocks + b] already holds the first pass's per-workgroup histogram (8-bit digit, same
-    // `items` per workgroup) -- the preprocess kernel counts the low byte of every key it writes
-    int pb[8];
-    if (first_hist_ready && (gsr_sort_plan(nbits, max_digit_bits, pb) < 1 || pb[0] != 8)) first_hist_ready = false;
-    return sort_pairs_t<uint32_t>(keys, vals, n, nbits, max_digit_bits, hist, digit_total, items, rect, rect_sorted, st, first_hist_ready);
+                         uint32_t* digit_total, int items, hipStream_t st, const uint2* rect, uint2* rect_sorted) {
+    return sort_pairs_t<uint32_t>(keys, vals, n, nbits, max_digit_bits, hist, digit_total, items, rect, rect_sorted, st);
 }
 
 // 16-bit keys (tile ids when the frame has <= 65536 tiles): 25 % less traffic per pass than 32-bit keys
 int gsr_radix_sort_pairs_k16(uint16_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
                              uint32_t* digit_total, int items, hipStream_t st) {
-    return sort_pairs_t<uint16_t>(keys, vals, n, nbits, max_digit_bits, hist, digit_total, items, nullptr, nullptr, st, false);
+    return sort_pairs_t<uint16_t>(keys, vals, n, nbits, max_digit_bits, hist, digit_total, items, nullptr, nullptr, st);
 }

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgsr_hip.so")
 
 GSR_OK = 0
-ABI_VERSION = 3
+ABI_VERSION = 4
 STAGES = ["preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "render", "render_bwd", "preprocess_bwd",
           "gather_bwd", "color", "r_wait"]
 
@@ -36,7 +36,7 @@ class GsrRasterSettings(C.Structure):
 class GsrForwardViews(C.Structure):
     _fields_ = [("splats", C.c_void_p), ("tiles_touched", C.c_void_p), ("depth_order", C.c_void_p),
                 ("point_list", C.c_void_p), ("ranges", C.c_void_p), ("final_T", C.c_void_p),
-                ("n_contrib", C.c_void_p)]
+                ("n_contrib", C.c_void_p), ("tile_scan", C.c_void_p)]
 
 
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 3
+#define GSR_ABI_VERSION 4
 
 typedef enum GsrStatus {
     GSR_OK = 0,
@@ -357,6 +357,7 @@ typedef struct GsrForwardViews {
     const uint32_t* ranges;       /* [n_tiles,2] start,end */
     const float* final_T;         /* [H*W] */
     const uint32_t* n_contrib;    /* [H*W] */
+    const uint32_t* tile_scan;    /* [P] inclusive scan of tiles_touched in depth order (ABI 4) */
 } GsrForwardViews;
 int gsr_forward_views(int P, int64_t R, int width, int height,
                       const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
@@ -375,8 +376,8 @@ enum {
     GSR_STAGE_RENDER_BWD = 7,
     GSR_STAGE_PREPROCESS_BWD = 8,
     GSR_STAGE_GATHER_BWD = 9,
-    GSR_STAGE_COLOR = 10,            /* SH -> RGB kernel of the split preprocess (option color_overlap) */
-    GSR_STAGE_R_WAIT = 11,           /* GPU idle between the scan (which publishes R) and the first kernel the host launches after reading R */
+    GSR_STAGE_COLOR = 10,            /* (unused since ABI 4: the split preprocess was removed) */
+    GSR_STAGE_R_WAIT = 11,           /* GPU idle between the depth sort and the first kernel the host launches after reading R */
     GSR_STAGE_COUNT = 12
 };
 int gsr_profile_enable(int on);      /* bit 0: per-stage events; bit 1: work counters (slow the blend kernels: count in a separate pass) */

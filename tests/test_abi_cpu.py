@@ -29,7 +29,7 @@ def test_header_symbols_are_exported(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gsr.h but not exported"
-    assert lib.gsr_abi_version() == 3
+    assert lib.gsr_abi_version() == 4
 
 
 def test_scratch_sizes(lib):
@@ -79,15 +79,19 @@ def test_argument_validation_without_gpu(lib):
     assert lib.gsr_set_option(b"render_fwd_variant", 0) == 0
     # the product library holds the default kernels only: every A/B switch accepts 0 and rejects the measured-and-rejected
     # variants (they exist in the GSR_AB=1 build); the tuning knobs are accepted
-    for name in (b"render_fwd_variant", b"render_bwd_variant", b"depth_sort_mode", b"color_overlap", b"first_hist_in_preprocess",
-                 b"sh_dma"):
+    for name in (b"render_fwd_variant", b"render_bwd_variant"):
         assert lib.gsr_set_option(name, 0) == 0, name
         assert lib.gsr_set_option(name, 1) != 0, name
         assert b"GSR_AB_VARIANTS" in lib.gsr_last_error(), (name, lib.gsr_last_error())
     for name, value in ((b"sort_small_block_threshold", 512 * 1024), (b"sort_mid_block_threshold", 3 * 1024 * 1024),
-                        (b"sort_items_large", 4096), (b"tile_sort_mode", 0), (b"preprocess_grid_cap", 2048), (b"bwd_heavy_first", 1)):
+                        (b"sort_items_large", 4096), (b"tile_sort_mode", 0), (b"preprocess_grid_cap", 2048), (b"bwd_heavy_first", 1),
+                        (b"depth_sort_mode", 2), (b"depth_sort_mode", 1), (b"depth_sort_mode", 0)):
         assert lib.gsr_set_option(name, value) == 0, name
     assert lib.gsr_set_option(b"sort_items_large", 1000) == -1
+    assert lib.gsr_set_option(b"depth_sort_mode", 3) == -1
+    # round-2/3 experiments that were measured, rejected and removed from the sources are not options any more
+    for name in (b"color_overlap", b"first_hist_in_preprocess", b"sh_dma"):
+        assert lib.gsr_set_option(name, 0) == -1, name
 
 
 def test_package_surface_matches_reference_call_site():
@@ -157,4 +161,4 @@ int main(void) {
                            str(src), so, "-Wl,-rpath," + os.path.dirname(so), "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
-    assert "abi 3 ok" in out.stdout
+    assert "abi 4 ok" in out.stdout

@@ -18,7 +18,7 @@ Reference boundary: gaussian_renderer/__init__.py:91-110; bins = SURVEY 8(c)(3) 
 import pytest
 import torch
 
-from helpers import O, make_camera, make_scene, oracle_settings
+from helpers import O, make_camera, make_scene, oracle_settings, reference_tiles
 
 pytestmark = pytest.mark.gpu
 
@@ -31,19 +31,58 @@ CASES = {
     "sort_2048_tier": (524_288 + 1061, 320, 240, 0.004, 5),
     "odd_frame": (50_000, 1001, 337, 0.02, 6),
     "tiles_65536": (6_000, 4096, 4096, 0.03, 7),
+    # depth distributions that select the code paths of the BUCKET depth sort (depthsort.hip):
+    "depth_ties": (30_000, 320, 240, 0.01, 8),        # depths quantised to 64 values: tie order = Gaussian index, in every segment
+    "depth_crowd": (20_000, 320, 240, 0.01, 9),       # 3/4 of the Gaussians inside 1e-5 of the depth range: oversized segments
+    "depth_gap": (30_000, 320, 240, 0.01, 10),        # two clusters 4 orders of magnitude apart: shift 16, sparse buckets
+    "depth_one_key": (9_000, 320, 240, 0.01, 13),     # every visible Gaussian at the SAME depth bits: zero sort passes
 }
 
 
+def _reshape_depths(name, sc, cam, seed):
+    """Move the Gaussians along their view rays (camera at the origin looking down +z: x, y, z scale together, the screen
+    position stays) so that the depth distribution is the one the case is named after."""
+    g = torch.Generator().manual_seed(seed)
+    z = sc.means3D[:, 2].clone()
+    P = z.numel()
+    if name == "depth_ties":
+        znew = 2.0 + torch.randint(0, 64, (P,), generator=g).float() * 0.125
+    elif name == "depth_crowd":
+        znew = z.clone()
+        crowd = torch.rand(P, generator=g) < 0.75
+        znew[crowd] = 5.0 + torch.randint(0, 48, (int(crowd.sum()),), generator=g).float() * 4.76837158203125e-07   # 1 ulp steps at 5.0
+    elif name == "depth_gap":
+        near = torch.rand(P, generator=g) < 0.5
+        znew = torch.where(near, 0.25 + 0.05 * torch.rand(P, generator=g), 3000.0 + 6000.0 * torch.rand(P, generator=g))
+    elif name == "depth_one_key":
+        znew = torch.full_like(z, 4.0)
+    else:
+        return
+    f = (znew / z).unsqueeze(1)
+    sc.means3D.mul_(f)
+    if name == "depth_gap":
+        sc.scales.mul_(f)          # keep the far cluster's splats visible on screen
+
+
+@pytest.mark.parametrize("tiles_mode", ["snug", "reference"])
+@pytest.mark.parametrize("depth_sort_mode", [2, 1], ids=["bucket", "lsd"])
 @pytest.mark.parametrize("name", list(CASES))
-def test_bins_bit_exact_in_every_structural_regime(name):
-    from diff_gaussian_rasterization import GaussianRasterizationSettings
+def test_bins_bit_exact_in_every_structural_regime(name, depth_sort_mode, tiles_mode):
+    """`reference`: the library bins the reference's own tile rectangles (option snug_tiles = 0)
+    and is compared with the oracle in reference mode -- north_star's "tile bin counts bit-exact" on the reference's bins
+    (VERDICT r03 item 2); `snug`: the product's default rectangles against the oracle's restatement of them."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, _lib
     from diff_gaussian_rasterization.debug import forward_with_views
+    import contextlib
+    if tiles_mode == "reference" and depth_sort_mode == 1 and name not in ("single_block", "odd_frame", "depth_ties"):
+        pytest.skip("reference rectangles x LSD sort: three representative cases are enough")
     P, W, H, s_med, seed = CASES[name]
     dev = torch.device("cuda:0")
     cam = make_camera(W, H)
     sc = make_scene(P, cam, seed=seed, s_med=s_med)
+    _reshape_depths(name, sc, cam, seed)
     s = oracle_settings(cam)
-    with torch.no_grad():
+    with (reference_tiles() if tiles_mode == "reference" else contextlib.nullcontext()), torch.no_grad():
         pre = O.preprocess(sc.means3D, sc.opacities, s, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
         bins = O.bin_and_sort(pre)
     V = int((pre["radii"] > 0).sum())
@@ -52,23 +91,64 @@ def test_bins_bit_exact_in_every_structural_regime(name):
     # the case really is in the regime it is named after
     if name == "tiny_splats":
         assert R / V < 3.0 and R > 3 * 4096, (R, V)        # > 1024 Gaussians per 4096 instances, several workgroups
-    if name == "huge_splats":
+    if name == "huge_splats" and tiles_mode == "snug":
         assert R / P > 64.0, (R, P)                         # beyond the scan kernel's block-table capacity
     if name == "tiles_65536":
         assert ((W + 15) // 16) * ((H + 15) // 16) == 65536
+    if name == "depth_crowd":
+        assert V > 12_000
     d = sc.to(dev)
     rs = GaussianRasterizationSettings(H, W, s.tanfovx, s.tanfovy, s.bg.to(dev), s.scale_modifier, s.viewmatrix.to(dev),
                                        s.projmatrix.to(dev), s.sh_degree, s.campos.to(dev), False, False, s.antialiasing)
-    for no_backward in (False, True):
-        out = forward_with_views(rs, d.means3D, d.opacities, shs=d.shs, scales=d.scales, rotations=d.rotations,
-                                 no_backward=no_backward)
-        torch.cuda.synchronize()
-        assert torch.equal(out["radii"].cpu(), pre["radii"].to(torch.int32)), "radii differ"
-        assert torch.equal(out["tiles_touched"].cpu().to(torch.int64), pre["tiles_touched"]), "tiles_touched differ"
-        assert out["R"] == R, f"R {out['R']} != {R}"
-        assert torch.equal(out["point_list"].cpu().to(torch.int64), bins["point_list"]), "sorted point list differs"
-        assert torch.equal(out["ranges"].cpu().to(torch.int64), bins["ranges"]), "tile ranges differ"
-        del out
+    _lib.set_option("depth_sort_mode", depth_sort_mode)
+    _lib.set_option("snug_tiles", 0 if tiles_mode == "reference" else 1)
+    try:
+        for no_backward in (False, True):
+            out = forward_with_views(rs, d.means3D, d.opacities, shs=d.shs, scales=d.scales, rotations=d.rotations,
+                                     no_backward=no_backward)
+            torch.cuda.synchronize()
+            assert torch.equal(out["radii"].cpu(), pre["radii"].to(torch.int32)), "radii differ"
+            assert torch.equal(out["tiles_touched"].cpu().to(torch.int64), pre["tiles_touched"]), "tiles_touched differ"
+            assert out["R"] == R, f"R {out['R']} != {R}"
+            pl = out["point_list"].cpu().to(torch.int64)
+            if not torch.equal(pl, bins["point_list"]):
+                bad = (pl != bins["point_list"]).nonzero().flatten()
+                raise AssertionError(f"sorted point list differs at {bad.numel()} of {pl.numel()} positions, first {bad[:8].tolist()}: "
+                                     f"got {pl[bad[:8]].tolist()} want {bins['point_list'][bad[:8]].tolist()}")
+            assert torch.equal(out["ranges"].cpu().to(torch.int64), bins["ranges"]), "tile ranges differ"
+            del out
+    finally:
+        _lib.set_option("depth_sort_mode", 0)
+        _lib.set_option("snug_tiles", 1)
+
+
+def test_depth_order_and_scan_of_the_bucket_sort_equal_the_lsd_sort():
+    """The two depth sorts leave the same internal state: depth order, rectangles in depth order (listed Gaussians) and
+    the inclusive scan of the tile counts -- the arrays the emission and the backward's reduce read -- on a frame with ties."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, _lib
+    from diff_gaussian_rasterization.debug import forward_with_views
+    dev = torch.device("cuda:0")
+    cam = make_camera(640, 368)
+    sc = make_scene(200_000, cam, seed=21, s_med=0.006)
+    sc.means3D.mul_((torch.round(sc.means3D[:, 2] * 64) / 64 / sc.means3D[:, 2]).unsqueeze(1))      # depth ties
+    s = oracle_settings(cam)
+    d = sc.to(dev)
+    rs = GaussianRasterizationSettings(368, 640, s.tanfovx, s.tanfovy, s.bg.to(dev), s.scale_modifier, s.viewmatrix.to(dev),
+                                       s.projmatrix.to(dev), s.sh_degree, s.campos.to(dev), False, False, s.antialiasing)
+    got = {}
+    try:
+        for mode in (1, 2):
+            _lib.set_option("depth_sort_mode", mode)
+            out = forward_with_views(rs, d.means3D, d.opacities, shs=d.shs, scales=d.scales, rotations=d.rotations)
+            torch.cuda.synchronize()
+            got[mode] = {k: out[k].cpu().clone() for k in ("depth_order", "offsets", "point_list", "ranges")}
+            got[mode]["R"] = out["R"]
+            del out
+    finally:
+        _lib.set_option("depth_sort_mode", 0)
+    assert got[1]["R"] == got[2]["R"]
+    for k in ("depth_order", "offsets", "point_list", "ranges"):
+        assert torch.equal(got[1][k], got[2][k]), f"{k} differs between the LSD and the bucket depth sort"
 
 
 # ------------------------------------------------------------------------------------------------------------------

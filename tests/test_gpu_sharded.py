@@ -200,3 +200,28 @@ def test_depth_keys_beyond_27_bits_take_the_32_bit_fallback():
     (gcol * wc.to(dev)).sum().backward()
     for a, b in zip(Lg, Lc):
         assert (a.grad.cpu() - b.grad).abs().max().item() <= 2e-3 * b.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("no_backward", [True, False])
+def test_band_that_receives_no_record_shows_the_background(no_backward):
+    """a rank whose band receives no record while the scene is not empty must render the BACKGROUND in its
+    band -- what the single-GPU blend writes where no splat lands (T = 1) -- not the zero image of the reference's P == 0
+    early-out; rows outside the band stay zero."""
+    from diff_gaussian_rasterization.parallel import hip_render_packed
+    dev = torch.device("cuda:0")
+    cam = make_camera(200, 120)                      # 13 x 8 tiles, last tile row partial
+    bg = torch.tensor([0.25, 0.5, 0.75])
+    rs = gpu_settings(oracle_settings(cam, bg=bg), dev)
+    recv = torch.empty(0, 12, dtype=torch.float32, device=dev)
+    color, invdepth, (geom, binning, img, nr) = hip_render_packed(rs, (2, 5), recv, no_backward)
+    torch.cuda.synchronize()
+    assert nr == 0
+    want = torch.zeros(3, 120, 200)
+    want[:, 32:80, :] = bg.view(3, 1, 1)
+    assert torch.equal(color.cpu(), want)
+    assert torch.equal(invdepth.cpu(), torch.zeros(1, 120, 200))
+    # the last band reaches the partial tile row at the bottom of the frame
+    color, _, _ = hip_render_packed(rs, (5, 8), recv, no_backward)
+    want = torch.zeros(3, 120, 200)
+    want[:, 80:, :] = bg.view(3, 1, 1)
+    assert torch.equal(color.cpu(), want)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of library options on ONE box (box-to-box variance is larger than most single-kernel gains):
-#   gpurun -- 'bash tools/gpu_ab.sh "color_overlap=0" "color_overlap=2"'            (options of the measurement build)
+#   gpurun -- 'bash tools/gpu_ab.sh "depth_sort_mode=1" "depth_sort_mode=2"'            (options of the measurement build)
 #   GSR_LIB=gaussian-splatting_amd/lib_ab/libgsr_hip.so is set automatically when a lib_ab build exists.
 # Each configuration runs bench.py twice, interleaved; one line per run: Mpix/s, ms/frame, train it/s, stage table.
 #   LIBS="lib lib_prev" bash tools/gpu_ab.sh          compares LIBRARIES instead (tools/build_prev_lib.sh builds lib_prev from

@@ -27,7 +27,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "gaussian-splatting_amd", "csrc")
-UNITS = {"preprocess.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"], "sort.hip": [], "binning.hip": [],
+UNITS = {"preprocess.hip": ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"], "sort.hip": [], "depthsort.hip": [], "binning.hip": [],
          "tilesort.hip": [], "route.hip": [], "render_fwd.hip": ["-ffp-contract=fast", "-fno-slp-vectorize"], "render_bwd.hip": ["-ffp-contract=fast", "-fno-slp-vectorize"],
          "adam.hip": ["-ffp-contract=off"], "ssim.hip": ["-ffp-contract=fast", "-fno-slp-vectorize"], "knn.hip": ["-ffp-contract=off"],
          "density.hip": ["-ffp-contract=off"]}
