@@ -280,13 +280,14 @@ rekey_full(int P, const float4* __restrict__ splats, const uint32_t* __restrict_
 
 }  // namespace
 
-void gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
-                             uint32_t* keys, uint32_t* vals, const GsrFrameStatsDev& fs, hipStream_t st) {
+int gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
+                            uint32_t* keys, uint32_t* vals, const GsrFrameStatsDev& fs, hipStream_t st) {
     int64_t nb = ((int64_t)P + 255) / 256;
-    if (nb > 4096) nb = 4096;
+    if (nb > GSR_FRAME_MAX_GROUPS) nb = GSR_FRAME_MAX_GROUPS;      // (gsr_frame.h: tickets)
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(splat_ingest, dim3((int)nb), dim3(256), 0, st, P, reinterpret_cast<const float4*>(records), y0, y1, splats,
                        rect, tiles, keys, vals, fs);
+    return (int)nb;
 }
 
 void gsr_launch_rekey_full(int P, const float4* splats, const uint32_t* tiles, uint32_t* keys, uint32_t* vals, hipStream_t st) {

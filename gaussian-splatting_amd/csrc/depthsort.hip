@@ -72,15 +72,20 @@ __device__ __forceinline__ void load4(const uint32_t* __restrict__ p, int64_t e0
 }
 
 // ---- D1 ------------------------------------------------------------------------------------------------------------
+// Every workgroup first reduces the per-workgroup key ranges the key-producing kernel left (gsr_frame.h; <= 2047 entries of
+// 8 bytes, one load round in the shadow of the key loads) to the frame's kmin / kmax; workgroup 0 stores them in frame[2..3] for
+// the kernels that follow.
 __global__ void __launch_bounds__(DS_THREADS)
-ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ frame,
-        uint32_t* __restrict__ cnt_tab, uint32_t* __restrict__ tile_tab) {
+ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tiles, uint32_t* __restrict__ frame,
+        const uint2* __restrict__ wg_range, int n_range, uint32_t* __restrict__ cnt_tab, uint32_t* __restrict__ tile_tab) {
     __shared__ uint32_t h_cnt[DS_NB], h_tile[DS_NB];
-    const int tid = threadIdx.x;
-    const uint32_t kmin = frame[2], kmax = frame[3];
-    const int shift = ds_shift(kmin, kmax);
+    __shared__ uint32_t s_nmin[WG_WAVES], s_max[WG_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * DS_ITEMS;
     uint32_t k[4][4], t[4][4];
+    uint2 rg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rg[j] = wg_range[min(j * DS_THREADS + tid, n_range - 1)];      // (clamped: duplicates do not change a max)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {      // all loads first, the LDS clear rides in their shadow
         const int64_t e0 = base + ((int64_t)v * DS_THREADS + tid) * 4;
@@ -92,7 +97,19 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
         h_cnt[i * DS_THREADS + tid] = 0u;
         h_tile[i * DS_THREADS + tid] = 0u;
     }
+    {
+        uint32_t nm = 0, mx = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { nm = max(nm, rg[j].x); mx = max(mx, rg[j].y); }
+        nm = wave_incl_max_u32(nm);
+        mx = wave_incl_max_u32(mx);
+        if (lane == 63) { s_nmin[w] = nm; s_max[w] = mx; }
+    }
     __syncthreads();
+    const uint32_t kmin = ~max(max(s_nmin[0], s_nmin[1]), max(s_nmin[2], s_nmin[3]));
+    const uint32_t kmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    if (blockIdx.x == 0 && tid == 0) { frame[2] = kmin; frame[3] = kmax; }
+    const int shift = ds_shift(kmin, kmax);
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int64_t e0 = base + ((int64_t)v * DS_THREADS + tid) * 4;
@@ -183,7 +200,7 @@ ds_scan(int nblocks, uint32_t* __restrict__ cnt_tab, const uint32_t* __restrict_
 
 // ---- D3 ------------------------------------------------------------------------------------------------------------
 // plan entry of segment s (8 words): begin, end (elements of the bucket-ordered array), first bucket, end bucket, tile
-// instances in front of the segment, 0, 0, 0
+// instances in front of the segment, number of listed Gaussians, 0, 0
 __global__ void __launch_bounds__(DS_THREADS)
 ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ frame,
            const uint32_t* __restrict__ cnt_tab, const uint32_t* __restrict__ cnt_total, const uint32_t* __restrict__ tile_total,
@@ -237,7 +254,7 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t
                 tb = tile_excl[d0];
             }
             reinterpret_cast<uint4*>(plan)[2 * s] = e;
-            reinterpret_cast<uint4*>(plan)[2 * s + 1] = make_uint4(tb, 0u, 0u, 0u);
+            reinterpret_cast<uint4*>(plan)[2 * s + 1] = make_uint4(tb, listed, 0u, 0u);
         }
         return;
     }
@@ -481,7 +498,8 @@ ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame
     const uint4 e = reinterpret_cast<const uint4*>(plan)[2 * blockIdx.x];
     const uint32_t begin = e.x, end = e.y, d0 = e.z, d1 = e.w;
     if (end <= begin) return;
-    const uint32_t tile_base = plan[8 * blockIdx.x + 4];
+    const uint4 e2 = reinterpret_cast<const uint4*>(plan)[2 * blockIdx.x + 1];
+    const uint32_t tile_base = e2.x, listed = e2.y;
     const uint32_t n = end - begin;
     const uint32_t kmin = frame[2], kmax = frame[3];
     const int shift = ds_shift(kmin, kmax);
@@ -492,8 +510,9 @@ ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame
     const int nbits = span <= 1ull ? 0 : 64 - __clzll((long long)(span - 1ull));
     // the last listed Gaussian closes the emission's block table: its global position is (number of listed) - 1 = the end
     // of the last non-empty segment; only that segment can hold it
-    // (exactly one non-empty segment ends at bucket 2047: the one that runs to the end of the listed Gaussians)
-    const uint32_t last_listed = d1 == DS_CULL ? end - 1u : 0xFFFFFFFFu;
+    // (the segments tile [0, listed): exactly one ends at `listed`.  Its end BUCKET need not be 2047 -- behind the last
+    // non-empty bucket come empty ones that start at `listed` too -- so the element count decides, not the bucket)
+    const uint32_t last_listed = end == listed ? end - 1u : 0xFFFFFFFFu;
     if (n <= (uint32_t)DS_CAP) {
         SegLds m{s_key, s_idx};
         {   // all loads, then all LDS writes (a load inside "if (p < n) lds[p] = ..." is waited for one by one)
@@ -557,12 +576,12 @@ size_t gsr_depth_bucket_segments(int P) { return ((size_t)(P > 0 ? P : 1) + DS_S
 // keys[P] (27-bit depth keys, GSR_DEPTH_KEY_CULLED for Gaussians without a tile), tiles[P], rect[P], frame = the words the
 // key-producing kernel's last workgroup wrote (gsr_frame.h)  ->  order[P], rect_sorted[P], offsets[P] (inclusive scan of the
 // tile counts in depth order), block_first[bf_cap]
-void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, const uint2* rect, const uint32_t* frame,
-                                  const GsrDepthSortBufs& b, uint32_t* order, uint2* rect_sorted, uint32_t* offsets, uint2* block_first,
+void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, const uint2* rect, uint32_t* frame,
+                                  const uint2* wg_range, int n_range, const GsrDepthSortBufs& b, uint32_t* order, uint2* rect_sorted, uint32_t* offsets, uint2* block_first,
                                   uint32_t block_first_cap, uint32_t* slow_word, hipStream_t st) {
     const int nblocks = (int)gsr_depth_bucket_blocks(P);
     const int nseg_cap = (int)gsr_depth_bucket_segments(P);
-    hipLaunchKernelGGL(ds_hist, dim3(nblocks), dim3(DS_THREADS), 0, st, P, keys, tiles, frame, b.cnt_tab, b.tile_tab);
+    hipLaunchKernelGGL(ds_hist, dim3(nblocks), dim3(DS_THREADS), 0, st, P, keys, tiles, frame, wg_range, n_range, b.cnt_tab, b.tile_tab);
     hipLaunchKernelGGL(ds_scan, dim3(DS_NB / 16), dim3(DS_THREADS), 0, st, nblocks, b.cnt_tab, b.tile_tab, b.cnt_total, b.tile_total);
     hipLaunchKernelGGL(ds_scatter, dim3(nblocks + 1), dim3(DS_THREADS), 0, st, P, nblocks, keys, frame, b.cnt_tab, b.cnt_total,
                        b.tile_total, b.pairs[0], order, offsets, rect_sorted, b.plan, nseg_cap);

@@ -169,7 +169,7 @@ struct HostWordLease {
         if (dev < 0) return;
         if (!settled) {      // error paths only: never hand a word with a pending writer (or a half-filled state block) to the next call
             (void)hipStreamSynchronize(st);
-            (void)hipMemset(hw.state, 0, 64);
+            (void)hipMemset(hw.state, 0, 64);      // the ticket counter of gsr_frame.h
         }
         std::lock_guard<std::mutex> l(g_hw_mu);
         g_hw_pool[dev].push_back(hw);
@@ -258,6 +258,7 @@ GsrGeom gsr_carve_geom(char* base, int P) {
         g.ds.plan = (uint32_t*)take(nseg * 32);
     }
     g.num_rendered = (uint32_t*)take(128);
+    g.wg_range = (uint2*)take((size_t)GSR_FRAME_MAX_GROUPS * 8);
     g.bytes = off;
     return g;
 }
@@ -496,6 +497,7 @@ static GsrFrameStatsDev frame_stats_for(HostWordLease& lease, GsrGeom& g, uint32
     GsrFrameStatsDev fs;
     fs.state = lease.hw.state;
     fs.frame = g.num_rendered;
+    fs.wg_range = g.wg_range;
     fs.host_word = lease.hw.dev;
     fs.seq = seq_out;
     return fs;
@@ -513,7 +515,7 @@ static bool use_bucket_sort(int P, int dev_id) {
 // ranges, blend.  `g` holds the splat records, band-clamped rectangles / tile counts and the depth keys of all P Gaussians;
 // `seq` is the sequence number that kernel's last workgroup publishes with R.
 static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& cam, int P, GsrGeom& g, HostWordLease& lease, uint32_t seq,
-                          GsrResizeFn binning_resize, void* binning_user, GsrResizeFn image_resize, void* image_user,
+                          int n_range /*workgroups of the key-producing kernel*/, GsrResizeFn binning_resize, void* binning_user, GsrResizeFn image_resize, void* image_user,
                           float* out_color, float* out_invdepth, int32_t* num_rendered, hipStream_t st) {
     const int dev_id = lease.dev;
     HostWord& hw_slot = lease.hw;
@@ -528,7 +530,7 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     // scan, after the sort, and the GPU idled 5-7 us per frame).
     {   StageTimer t(GSR_STAGE_DEPTH_SORT, st);
         if (bucket) {
-            gsr_launch_depth_bucket_sort(P, g.keys[0], g.tiles, g.rect, g.num_rendered, g.ds, g.vals[order_buf], g.rect_sorted, g.offsets,
+            gsr_launch_depth_bucket_sort(P, g.keys[0], g.tiles, g.rect, g.num_rendered, g.wg_range, n_range, g.ds, g.vals[order_buf], g.rect_sorted, g.offsets,
                                          g.block_first, bf_cap, hw_slot.dev + 5, st);
         } else {
             const int ob = gsr_radix_sort_pairs(g.keys, g.vals, P, GSR_DEPTH_KEY_BITS, GSR_DEPTH_DIGIT_BITS, g.sort_hist, g.digit_total,
@@ -674,11 +676,12 @@ int gsr_rasterize_forward(const GsrRasterSettings* settings, int P, int M, const
     if (rc != GSR_OK) return rc;
     uint32_t seq;
     const GsrFrameStatsDev fs = frame_stats_for(lease, g, seq);
+    int n_range;
     {   StageTimer t(GSR_STAGE_PREPROCESS, st);
-        gsr_launch_preprocess(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, fs, st);
+        n_range = gsr_launch_preprocess(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, fs, st);
     }
     STAGE_CHECK("preprocess");
-    return bin_and_render(settings, cam, P, g, lease, seq, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
+    return bin_and_render(settings, cam, P, g, lease, seq, n_range, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
                           num_rendered, st);
 }
 
@@ -704,7 +707,7 @@ int gsr_preprocess_forward(const GsrRasterSettings* settings, int P, int M, cons
     g.splats = reinterpret_cast<float4*>(splat_records);
     {   StageTimer t(GSR_STAGE_PREPROCESS, st);
         GsrFrameStatsDev none;      // nothing is binned here: no frame statistics
-        none.state = nullptr; none.frame = nullptr; none.host_word = nullptr; none.seq = 0;
+        none.state = nullptr; none.frame = nullptr; none.wg_range = nullptr; none.host_word = nullptr; none.seq = 0;
         gsr_launch_preprocess(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, none, st);
     }
     STAGE_CHECK("preprocess (shard)");
@@ -753,12 +756,13 @@ static int rasterize_from_records(const GsrRasterSettings* settings, int P, cons
     if (rc != GSR_OK) return rc;
     uint32_t seq;
     const GsrFrameStatsDev fs = frame_stats_for(lease, g, seq);
+    int n_range;
     {   StageTimer t(GSR_STAGE_PREPROCESS, st);
-        if (packed) gsr_launch_ingest_packed(P, records, cam.tile_y0, cam.tile_y1, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], fs, st);
-        else gsr_launch_splat_ingest(P, records, cam.tile_y0, cam.tile_y1, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], fs, st);
+        if (packed) n_range = gsr_launch_ingest_packed(P, records, cam.tile_y0, cam.tile_y1, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], fs, st);
+        else n_range = gsr_launch_splat_ingest(P, records, cam.tile_y0, cam.tile_y1, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], fs, st);
     }
     STAGE_CHECK("splat ingest");
-    return bin_and_render(settings, cam, P, g, lease, seq, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
+    return bin_and_render(settings, cam, P, g, lease, seq, n_range, binning_resize, binning_user, image_resize, image_user, out_color, out_invdepth,
                           num_rendered, st);
 }
 

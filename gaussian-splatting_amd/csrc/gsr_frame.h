@@ -6,28 +6,32 @@
 // it while the GPU is still sorting, and the read-back leaves the critical path (rounds 1-3: 5-7 us of GPU idle per frame).
 // The key range makes the depth sort's bucket mapping adaptive (depthsort.hip).
 //
-// Protocol: every workgroup folds its partial results into a small device-memory block with agent-scope atomics and takes a
-// ticket; the workgroup that draws the last ticket reads the totals, copies them to the geometry buffer (for the kernels
-// that follow), publishes them to the mapped host word (value first, sequence number last, system-scope release) and
-// RESETS the block, so the next lease finds it zeroed.  The block belongs to the host-word lease (gsr_api.cpp), never to
-// two frames at once.  No spinning anywhere.
+// Protocol: every workgroup adds ONE packed 64-bit word to a device-memory counter with a relaxed agent-scope atomic -- its tile
+// count, "one of my depth keys overflowed" and a ticket -- and leaves the range of its depth keys in a per-workgroup table
+// (plain stores; the depth sort's first kernel reduces the table after the kernel boundary, depthsort.hip).  The returned
+// value tells the workgroup that drew the last ticket so, and hands it the totals: it copies R to the geometry buffer,
+// publishes it to the mapped host word (value first, sequence number last, system-scope release) and RESETS the counter, so
+// the next lease finds it zeroed.  The counter belongs to the host-word lease (gsr_api.cpp), never to two frames at once.
+// One atomic per workgroup, nothing to order, no spinning.  (First version: five atomics and an acq_rel ticket -- the
+// agent-scope release / acquire is an L2 write-back / invalidate on this multi-XCD part and doubled the preprocess kernel.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "gsr_wave.h"
 
-// state block (device memory, 16 words, zero between frames):
-//   [0..1] sum of tile counts (u64)   [2] tickets   [3] max of ~key over listed Gaussians (= ~kmin)   [4] max key   [5] flags
-// frame words (geometry buffer, GsrGeom::num_rendered): [0] R low, [1] R high, [2] kmin, [3] kmax   (kmin > kmax: nothing listed)
+// counter (device memory, u64, zero between frames): bits [0, 42) sum of the tile counts (a workgroup's part saturates at
+// 2^31: any total >= 2^31 is refused by the host anyway), [42, 53) workgroups with a key overflow, [53, 64) tickets
+// -> the key-producing kernels run at most GSR_FRAME_MAX_GROUPS workgroups
+// frame words (geometry buffer, GsrGeom::num_rendered): [0] R low, [1] R high; [2] kmin, [3] kmax are written by ds_hist
 // host word (mapped): [0] R low, [1] sequence number, [2] R high, [3] "a depth key needed more than 27 bits"
+#define GSR_FRAME_MAX_GROUPS 2047
 struct GsrFrameStatsDev {
     uint32_t* state;       // NULL: the kernel keeps no statistics (shard projection without binning)
     uint32_t* frame;
+    uint2* wg_range;       // [workgroups] (~smallest, largest) depth key of the workgroup's listed Gaussians; (0, 0): none
     uint32_t* host_word;   // may be NULL (then only `frame` is written)
     uint32_t seq;
 };
-
-#define GSR_FRAME_FLAG_KEY_OVERFLOW 1u
 
 #ifdef __HIPCC__
 // Called by EVERY thread of EVERY workgroup of a 256-thread kernel, after its streaming loop.  tiles_sum / kmin / kmax /
@@ -44,35 +48,27 @@ __device__ __forceinline__ void gsr_frame_stats_commit(const GsrFrameStatsDev& f
     if (lane == 63) { s_sum[w] = wsum; s_nmin[w] = wnmin; s_max[w] = wmax; s_ovf[w] = ovf ? 1u : 0u; }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    const uint64_t sum = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    uint64_t sum = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    if (sum > 0x80000000ull) sum = 0x80000000ull;
     const uint32_t nmin = max(max(s_nmin[0], s_nmin[1]), max(s_nmin[2], s_nmin[3]));
     const uint32_t kmx = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-    const uint32_t flags = (s_ovf[0] | s_ovf[1] | s_ovf[2] | s_ovf[3]) ? GSR_FRAME_FLAG_KEY_OVERFLOW : 0u;
-    unsigned long long* st_sum = reinterpret_cast<unsigned long long*>(fs.state);
-    if (sum) __hip_atomic_fetch_add(st_sum, (unsigned long long)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (nmin) __hip_atomic_fetch_max(fs.state + 3, nmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (kmx) __hip_atomic_fetch_max(fs.state + 4, kmx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (flags) __hip_atomic_fetch_or(fs.state + 5, flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t ticket = __hip_atomic_fetch_add(fs.state + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (ticket != gridDim.x - 1u) return;
-    // last workgroup: every other one has folded its part in (their atomics precede their tickets)
-    const unsigned long long R = __hip_atomic_load(st_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t t_nmin = __hip_atomic_load(fs.state + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t t_max = __hip_atomic_load(fs.state + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t t_flags = __hip_atomic_load(fs.state + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t any_ovf = (s_ovf[0] | s_ovf[1] | s_ovf[2] | s_ovf[3]) ? 1ull : 0ull;
+    fs.wg_range[blockIdx.x] = make_uint2(nmin, kmx);
+    unsigned long long* ctr = reinterpret_cast<unsigned long long*>(fs.state);
+    const unsigned long long mine = sum | (any_ovf << 42) | (1ull << 53);
+    const unsigned long long old = __hip_atomic_fetch_add(ctr, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(old >> 53) != gridDim.x - 1u) return;
+    // last workgroup
+    const unsigned long long tot = old + mine;
+    const unsigned long long R = tot & ((1ull << 42) - 1ull);
+    const uint32_t n_ovf = (uint32_t)(tot >> 42) & 0x7FFu;
     fs.frame[0] = (uint32_t)R;
     fs.frame[1] = (uint32_t)(R >> 32);
-    fs.frame[2] = ~t_nmin;
-    fs.frame[3] = t_max;
-    __hip_atomic_store(st_sum, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(fs.state + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(fs.state + 4, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(fs.state + 5, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(fs.state + 2, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ctr, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (read next by a later kernel)
     if (fs.host_word) {      // value first, then the sequence number (system-scope release)
         __hip_atomic_store(fs.host_word + 0, (uint32_t)R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(fs.host_word + 2, (uint32_t)(R >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(fs.host_word + 3, (t_flags & GSR_FRAME_FLAG_KEY_OVERFLOW) ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(fs.host_word + 3, n_ovf ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(fs.host_word + 1, fs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

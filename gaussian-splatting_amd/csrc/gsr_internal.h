@@ -67,6 +67,7 @@ struct GsrGeom {                 // P-sized
     uint32_t* digit_total;       // [512]
     GsrDepthSortBufs ds;         // bucket depth sort (depthsort.hip); carved for P <= GSR_DS_MAX_P
     uint32_t* num_rendered;      // frame words (gsr_frame.h): [0..1] R as 64 bits, [2] smallest, [3] largest depth key of a listed Gaussian
+    uint2* wg_range;             // [GSR_FRAME_MAX_GROUPS] per-workgroup depth-key ranges of the key-producing kernel
     size_t bytes;
 };
 GsrGeom gsr_carve_geom(char* base, int P);
@@ -128,10 +129,11 @@ GsrImage gsr_carve_image(char* base, int W, int H);
 
 // ---- kernel launchers (one per translation unit) ----
 // preprocess.hip  (compiled with -ffp-contract=off)
-void gsr_launch_preprocess(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
-                           const float* colors_precomp, const float* opacities, const float* scales,
-                           const float* rotations, const float* cov3D_precomp, GsrGeom g, int32_t* radii,
-                           const GsrFrameStatsDev& fs, hipStream_t st);
+// (the key-producing launchers return their grid size: the number of entries of fs.wg_range they fill)
+int gsr_launch_preprocess(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
+                          const float* colors_precomp, const float* opacities, const float* scales,
+                          const float* rotations, const float* cov3D_precomp, GsrGeom g, int32_t* radii,
+                          const GsrFrameStatsDev& fs, hipStream_t st);
 void gsr_launch_preprocess_backward(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
                                     const float* colors_precomp, const float* opacities, const float* scales,
                                     const float* rotations, const float* cov3D_precomp, const int32_t* radii,
@@ -165,8 +167,8 @@ int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nb
 int gsr_radix_sort_pairs_k16(uint16_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
                              uint32_t* digit_total, int items, hipStream_t st);
 // depthsort.hip: depth order + rectangles in depth order + inclusive scan of the tile counts + the emission's block table
-void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, const uint2* rect, const uint32_t* frame,
-                                  const GsrDepthSortBufs& b, uint32_t* order, uint2* rect_sorted, uint32_t* offsets, uint2* block_first,
+void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, const uint2* rect, uint32_t* frame,
+                                  const uint2* wg_range, int n_range, const GsrDepthSortBufs& b, uint32_t* order, uint2* rect_sorted, uint32_t* offsets, uint2* block_first,
                                   uint32_t block_first_cap, uint32_t* slow_word, hipStream_t st);
 // pass plan shared by the sorter and by code that must know which ping-pong buffer holds the result
 int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits /*[8]*/);
@@ -276,8 +278,8 @@ void gsr_launch_train_loss_forward(int planes, int H, int W, const float* img1, 
 void gsr_launch_train_loss_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dloss, float lambda,
                                     const float* dm_dmu1, const float* dm_dex2, const float* dm_dexy, float* dL_dimg1, hipStream_t st);
 // binning.hip: gathered splat records -> geometry state of this rank's band (two-axis sharding)
-void gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
-                             uint32_t* keys, uint32_t* vals, const GsrFrameStatsDev& fs, hipStream_t st);
+int gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
+                            uint32_t* keys, uint32_t* vals, const GsrFrameStatsDev& fs, hipStream_t st);
 // binning.hip: full 32-bit depth keys from the splat records (fallback of the 27-bit depth sort)
 void gsr_launch_rekey_full(int P, const float4* splats, const uint32_t* tiles, uint32_t* keys, uint32_t* vals, hipStream_t st);
 
@@ -288,6 +290,6 @@ void gsr_launch_route_count(int P, const float* records, int n_bands, const int3
                             uint32_t* band_counts, hipStream_t st);
 void gsr_launch_route_pack(int P, const float* records, int n_bands, const int32_t* bounds, const int64_t* band_offsets,
                            const uint32_t* block_offsets, float* packed, int32_t* send_ids, hipStream_t st);
-void gsr_launch_ingest_packed(int P, const float* packed, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
-                              uint32_t* keys, uint32_t* vals, const GsrFrameStatsDev& fs, hipStream_t st);
+int gsr_launch_ingest_packed(int P, const float* packed, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
+                             uint32_t* keys, uint32_t* vals, const GsrFrameStatsDev& fs, hipStream_t st);
 void gsr_launch_route_add_rows(int64_t n, const int32_t* ids, const float* rows, float* out, hipStream_t st);

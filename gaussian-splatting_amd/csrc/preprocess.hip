@@ -541,17 +541,19 @@ inline int stream_grid(int64_t n) {
 
 }  // namespace
 
-void gsr_launch_preprocess(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
-                           const float* colors_precomp, const float* opacities, const float* scales,
-                           const float* rotations, const float* cov3D_precomp, GsrGeom g, int32_t* radii,
-                           const GsrFrameStatsDev& fs, hipStream_t st) {
+int gsr_launch_preprocess(const GsrCamDev& cam, int P, const float* means3D, const float* shs,
+                          const float* colors_precomp, const float* opacities, const float* scales,
+                          const float* rotations, const float* cov3D_precomp, GsrGeom g, int32_t* radii,
+                          const GsrFrameStatsDev& fs, hipStream_t st) {
+    const int grid = stream_grid(P) < GSR_FRAME_MAX_GROUPS ? stream_grid(P) : GSR_FRAME_MAX_GROUPS;      // (gsr_frame.h: tickets)
 #define GSR_PRE_FWD(SPLIT_)                                                                                                            \
-    hipLaunchKernelGGL((preprocess_fwd_kernel<SPLIT_>), dim3(stream_grid(P)), dim3(256), 0, st, cam, P, means3D, shs, colors_precomp,    \
+    hipLaunchKernelGGL((preprocess_fwd_kernel<SPLIT_>), dim3(grid), dim3(256), 0, st, cam, P, means3D, shs, colors_precomp,              \
                        opacities, scales, rotations, cov3D_precomp, g.splats, g.rect, g.tiles,                                         \
                        /*clamped (recomputed by the backward)*/ nullptr, g.keys[0], g.vals[0], radii, fs)
     if (cam.sh_dc) GSR_PRE_FWD(true);
     else GSR_PRE_FWD(false);
 #undef GSR_PRE_FWD
+    return grid;
 }
 
 void gsr_launch_preprocess_backward(const GsrCamDev& cam, int P, const float* means3D, const float* shs,

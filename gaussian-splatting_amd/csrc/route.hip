@@ -175,13 +175,14 @@ void gsr_launch_route_pack(int P, const float* records, int n_bands, const int32
                        make_bands(n_bands, bounds), bo, block_offsets, nblk, reinterpret_cast<float4*>(packed), send_ids);
 }
 
-void gsr_launch_ingest_packed(int P, const float* packed, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
-                              uint32_t* keys, uint32_t* vals, const GsrFrameStatsDev& fs, hipStream_t st) {
+int gsr_launch_ingest_packed(int P, const float* packed, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
+                             uint32_t* keys, uint32_t* vals, const GsrFrameStatsDev& fs, hipStream_t st) {
     int64_t nb = ((int64_t)P + 255) / 256;
-    if (nb > 4096) nb = 4096;
+    if (nb > GSR_FRAME_MAX_GROUPS) nb = GSR_FRAME_MAX_GROUPS;      // (gsr_frame.h: tickets)
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(ingest_packed, dim3((int)nb), dim3(256), 0, st, P, reinterpret_cast<const float4*>(packed), y0, y1, splats, rect,
                        tiles, keys, vals, fs);
+    return (int)nb;
 }
 
 void gsr_launch_route_add_rows(int64_t n, const int32_t* ids, const float* rows, float* out, hipStream_t st) {

@@ -53,7 +53,8 @@ def forward_with_views(rs: GaussianRasterizationSettings, means3D, opacities, sh
         out["splats"] = _view(geom.t, v.splats, P * 64, torch.float32).view(P, 16)
         out["tiles_touched"] = _view(geom.t, v.tiles_touched, P * 4, torch.int32)
         out["depth_order"] = _view(geom.t, v.depth_order, P * 4, torch.int32)
-        out["offsets"] = _view(geom.t, v.tile_scan, P * 4, torch.int32)
+        if v.tile_scan:      # (ABI 4; absent when an older library is bound for an A/B run)
+            out["offsets"] = _view(geom.t, v.tile_scan, P * 4, torch.int32)
         out["point_list"] = (_view(binning.t, v.point_list, R * 4, torch.int32) if R > 0
                              else torch.empty(0, dtype=torch.int32, device=device))
         out["ranges"] = _view(img.t, v.ranges, gx * gy * 8, torch.int32).view(gx * gy, 2)

@@ -4,9 +4,9 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_bins_sweep.py -q -m gpu --tb=short -x 2>&1 | tail -60 > gpurun_out/r4_bins.log
+timeout 900 python -m pytest tests/test_gpu_bins_sweep.py -q -m gpu --tb=short 2>&1 | tail -60 > gpurun_out/r4_bins.log
 echo "== bins sweep"; tail -40 gpurun_out/r4_bins.log
-if grep -q "failed\|error" gpurun_out/r4_bins.log; then echo "BINS FAILED: stopping"; exit 1; fi
+if grep -q "failed\|error" gpurun_out/r4_bins.log; then echo "BINS FAILED"; fi
 timeout 1500 python -m pytest tests -q -m gpu --tb=short 2>&1 | tail -60 > gpurun_out/r4_pytest.log
 echo "== whole gpu suite"; tail -30 gpurun_out/r4_pytest.log
 GSR_LIB= bash -c 'unset GSR_LIB; for rep in 1 2; do for m in 1 2; do
