@@ -42,10 +42,9 @@ constexpr uint32_t DS_CULL = DS_NB - 1u;
 constexpr int DS_DPT = DS_NB / DS_THREADS;             // 8 buckets per thread
 constexpr int DS_SEG = GSR_DS_SEG;
 constexpr int DS_CAP = GSR_DS_CAP;
-constexpr int DS_OUT = DS_CAP / DS_THREADS;            // 16 elements per thread in the output phase
 constexpr int DS_PASS_BITS = 9;
 constexpr int DS_PASS_BINS = 1 << DS_PASS_BITS;
-static_assert(DS_IPT == 16 && DS_DPT == 8 && DS_OUT == 16, "layout");
+static_assert(DS_IPT == 16 && DS_DPT == 8, "layout");
 
 // smallest shift with (kmax - kmin) >> shift <= 2046 (bucket 2047 is reserved)
 __device__ __forceinline__ int ds_shift(uint32_t kmin, uint32_t kmax) {
@@ -224,12 +223,18 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t
         }
         uint32_t crun = block_excl_scan<DS_DPT>(c, wsum, lane, w);
         uint32_t trun = block_excl_scan<DS_DPT>(t, wsum, lane, w);
+        {
+            uint32_t ce[DS_DPT], te[DS_DPT];
 #pragma unroll
-        for (int i = 0; i < DS_DPT; ++i) {
-            cnt_excl[tid * DS_DPT + i] = crun;
-            tile_excl[tid * DS_DPT + i] = trun;
-            crun += c[i];
-            trun += t[i];
+            for (int i = 0; i < DS_DPT; ++i) {
+                ce[i] = crun; te[i] = trun;
+                crun += c[i];
+                trun += t[i];
+            }
+            reinterpret_cast<uint4*>(cnt_excl)[2 * tid] = make_uint4(ce[0], ce[1], ce[2], ce[3]);
+            reinterpret_cast<uint4*>(cnt_excl)[2 * tid + 1] = make_uint4(ce[4], ce[5], ce[6], ce[7]);
+            reinterpret_cast<uint4*>(tile_excl)[2 * tid] = make_uint4(te[0], te[1], te[2], te[3]);
+            reinterpret_cast<uint4*>(tile_excl)[2 * tid + 1] = make_uint4(te[4], te[5], te[6], te[7]);
         }
         __syncthreads();
         const uint32_t listed = cnt_excl[DS_CULL];
@@ -278,14 +283,21 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t
         v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
         bh[0] = b0.x; bh[1] = b0.y; bh[2] = b0.z; bh[3] = b0.w; bh[4] = b1.x; bh[5] = b1.y; bh[6] = b1.z; bh[7] = b1.w;
         uint32_t run = block_excl_scan<DS_DPT>(v, wsum, lane, w);
+        // LDS accesses of this kernel never use the "thread t owns buckets 8t .. 8t+7" pattern with 32-bit accesses: a lane
+        // stride of 8 words puts 16 lanes on every bank.  The thread's eight bases go out as two 16-byte writes, the count
+        // tables are cleared and scanned with bucket = round * 256 + thread.
+        uint32_t db[DS_DPT];
 #pragma unroll
         for (int i = 0; i < DS_DPT; ++i) {
-            const int d = tid * DS_DPT + i;
-            digit_base[d] = run + bh[i];
-#pragma unroll
-            for (int k = 0; k < WG_WAVES; ++k) wave_cnt[k][d] = 0u;
+            db[i] = run + bh[i];
             run += v[i];
         }
+        reinterpret_cast<uint4*>(digit_base)[2 * tid] = make_uint4(db[0], db[1], db[2], db[3]);
+        reinterpret_cast<uint4*>(digit_base)[2 * tid + 1] = make_uint4(db[4], db[5], db[6], db[7]);
+#pragma unroll
+        for (int i = 0; i < DS_DPT; ++i)
+#pragma unroll
+            for (int k = 0; k < WG_WAVES; ++k) wave_cnt[k][i * DS_THREADS + tid] = 0u;
     }
     __syncthreads();
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -307,7 +319,7 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t
     // its slot; per bucket the waves' counts become exclusive offsets
 #pragma unroll
     for (int i = 0; i < DS_DPT; ++i) {
-        const int d = tid * DS_DPT + i;
+        const int d = i * DS_THREADS + tid;
         uint32_t run = 0;
 #pragma unroll
         for (int k = 0; k < WG_WAVES; ++k) {
@@ -335,6 +347,13 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t
 }
 
 // ---- D4 ------------------------------------------------------------------------------------------------------------
+// 512 threads: the sort is a chain of dependent LDS round trips per wave and pass (key -> ballots -> running count -> store),
+// so the lever is the number of 64-item steps per wave: 8 waves halve it against 4, and two workgroups of 8 waves give every
+// SIMD four waves to interleave.
+constexpr int SG_THREADS = 512;
+constexpr int SG_WAVES = SG_THREADS / 64;
+constexpr int SG_OUT = DS_CAP / SG_THREADS;            // 8 elements per thread in the output phase
+
 struct SegLds {
     uint32_t (*key)[DS_CAP];
     uint16_t (*idx)[DS_CAP];
@@ -342,26 +361,45 @@ struct SegLds {
     __device__ __forceinline__ void store(int buf, uint32_t i, uint32_t k, uint32_t v) const { key[buf][i] = k; idx[buf][i] = (uint16_t)v; }
 };
 struct SegGlobal {      // the segment's slice of the two pair arrays; keys are rebased on the fly
-    uint2* p[2];
+    uint2* p0;
+    uint2* p1;
     uint32_t base_key;
     __device__ __forceinline__ void load(int buf, uint32_t i, uint32_t& k, uint32_t& v) const {
-        const uint2 t = p[buf][i];
+        const uint2 t = buf ? p1[i] : p0[i];
         k = t.x - base_key; v = t.y;
     }
-    __device__ __forceinline__ void store(int buf, uint32_t i, uint32_t k, uint32_t v) const { p[buf][i] = make_uint2(k + base_key, v); }
+    __device__ __forceinline__ void store(int buf, uint32_t i, uint32_t k, uint32_t v) const {
+        const uint2 t = make_uint2(k + base_key, v);
+        if (buf) p1[i] = t; else p0[i] = t;
+    }
 };
 
+// exclusive scan over the 512 threads of the per-thread value; wsum: SG_WAVES words of LDS; two barriers
+__device__ __forceinline__ uint32_t seg_excl_scan(uint32_t v, uint32_t* wsum, int lane, int w) {
+    const uint32_t incl = wave_incl_scan_u32(v, lane);
+    __syncthreads();
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+#pragma unroll
+    for (int k = 0; k < SG_WAVES; ++k)
+        if (k < w) wbase += wsum[k];
+    return wbase + incl - v;
+}
+
 // Stable LSD radix sort of n (key, value) items held in buffer 0 of `m` on the low `nbits` key bits, passes of <= 9 bits,
-// by the whole workgroup.  Returns the buffer that holds the result.  Wave w owns a contiguous quarter of the items; per pass:
+// by the whole workgroup.  Returns the buffer that holds the result.  Wave w owns a contiguous eighth of the items; per pass:
 // count (LDS atomics on the wave's own table) -> scan over (bin, wave) -> rank with ballot matching against running counts.
-template <class Mem>
-__device__ __forceinline__ int seg_sort(const Mem& m, uint32_t n, int nbits, uint32_t (*wave_cnt)[DS_PASS_BINS], uint32_t* wsum) {
+// CntT: uint16_t for segments that fit the LDS buffers (counts and offsets < 65536; two bins share a 32-bit atomic),
+// uint32_t for the oversized ones.
+template <class Mem, typename CntT>
+__device__ __forceinline__ int seg_sort(const Mem& m, uint32_t n, int nbits, CntT (*wave_cnt)[DS_PASS_BINS], uint32_t* wsum) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     int cur = 0;
     if (nbits <= 0) return cur;
     const int npass = (nbits + DS_PASS_BITS - 1) / DS_PASS_BITS;
     const int pb = (nbits + npass - 1) / npass;
-    const uint32_t q = (((n + 3u) / 4u) + 63u) & ~63u;
+    const uint32_t q = (((n + (uint32_t)SG_WAVES - 1u) / (uint32_t)SG_WAVES) + 63u) & ~63u;
     const uint32_t wbeg = min((uint32_t)w * q, n), wend = min(wbeg + q, n);
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     int sh = 0;
@@ -370,38 +408,24 @@ __device__ __forceinline__ int seg_sort(const Mem& m, uint32_t n, int nbits, uin
         const int bits = min(pb, nbits - sh);
         const uint32_t dmask = (1u << bits) - 1u;
 #pragma unroll
-        for (int k = 0; k < WG_WAVES; ++k) {
-            wave_cnt[k][tid] = 0u;
-            wave_cnt[k][tid + DS_THREADS] = 0u;
-        }
+        for (int k = 0; k < SG_WAVES; ++k) wave_cnt[k][tid] = (CntT)0;
         __syncthreads();
 #pragma unroll 2
         for (uint32_t i = wbeg + lane; i < wend; i += 64u) {
             uint32_t k, v;
             m.load(cur, i, k, v);
-            atomicAdd(&wave_cnt[w][(k >> sh) & dmask], 1u);
+            const uint32_t d = (k >> sh) & dmask;
+            if (sizeof(CntT) == 2) atomicAdd(reinterpret_cast<uint32_t*>(wave_cnt[w]) + (d >> 1), 1u << ((d & 1u) * 16u));
+            else atomicAdd(reinterpret_cast<uint32_t*>(wave_cnt[w]) + d, 1u);
         }
         __syncthreads();
-        {
-            uint32_t tot[2];
+        {   // thread t owns bin t: offsets over (bin, wave)
+            uint32_t c[SG_WAVES], tot = 0;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int d = 2 * tid + j;
-                tot[j] = wave_cnt[0][d] + wave_cnt[1][d] + wave_cnt[2][d] + wave_cnt[3][d];
-            }
-            uint32_t run = block_excl_scan<2>(tot, wsum, lane, w);
+            for (int k = 0; k < SG_WAVES; ++k) { c[k] = wave_cnt[k][tid]; tot += c[k]; }
+            uint32_t run = seg_excl_scan(tot, wsum, lane, w);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int d = 2 * tid + j;
-                uint32_t r = run;
-#pragma unroll
-                for (int k = 0; k < WG_WAVES; ++k) {
-                    const uint32_t t = wave_cnt[k][d];
-                    wave_cnt[k][d] = r;
-                    r += t;
-                }
-                run += tot[j];
-            }
+            for (int k = 0; k < SG_WAVES; ++k) { wave_cnt[k][tid] = (CntT)run; run += c[k]; }
         }
         __syncthreads();
 #pragma unroll 1
@@ -412,10 +436,10 @@ __device__ __forceinline__ int seg_sort(const Mem& m, uint32_t n, int nbits, uin
             if (valid) m.load(cur, i, k, v);
             const uint32_t d = (k >> sh) & dmask;
             const uint64_t mask = match_digit(d, bits, __ballot(valid));
-            const uint32_t prior = valid ? wave_cnt[w][d] : 0u;
+            const uint32_t prior = valid ? (uint32_t)wave_cnt[w][d] : 0u;
             if (valid) {
                 m.store(cur ^ 1, prior + (uint32_t)__popcll(mask & lt_mask), k, v);
-                if ((mask & lt_mask) == 0ull) wave_cnt[w][d] = prior + (uint32_t)__popcll(mask);
+                if ((mask & lt_mask) == 0ull) wave_cnt[w][d] = (CntT)(prior + (uint32_t)__popcll(mask));
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -430,21 +454,21 @@ __device__ __forceinline__ uint32_t rect_area(const uint2 r) {
 }
 
 // Output of up to 4096 consecutive sorted elements [c0, c0 + m) of the segment: element p of the chunk belongs to thread
-// p % 256, round p / 256 (lane-contiguous stores).  ids[j]: the Gaussian id of element j * 256 + tid.  Returns the number of
+// p % 512, round p / 512 (lane-contiguous stores).  id[j]: the Gaussian id of element j * 512 + tid.  Returns the number of
 // tile instances of the chunk (every thread).
-__device__ __forceinline__ uint32_t seg_output(const uint32_t (&id)[DS_OUT], uint32_t m, uint32_t gpos0 /*global position of the chunk*/,
+__device__ __forceinline__ uint32_t seg_output(const uint32_t (&id)[SG_OUT], uint32_t m, uint32_t gpos0 /*global position of the chunk*/,
                                               uint32_t tile_base, const uint2* __restrict__ rect, uint32_t* __restrict__ order,
                                               uint2* __restrict__ rect_sorted, uint32_t* __restrict__ offsets,
                                               uint2* __restrict__ block_first, uint32_t bf_cap, uint32_t last_listed, bool r_ok,
-                                              uint32_t (*s_wt)[WG_WAVES]) {
+                                              uint32_t (*s_wt)[SG_WAVES]) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    uint2 rc[DS_OUT];
+    uint2 rc[SG_OUT];
 #pragma unroll
-    for (int j = 0; j < DS_OUT; ++j) rc[j] = rect[id[j]];      // (lanes past m carry id 0: a valid address)
-    uint32_t t[DS_OUT], incl[DS_OUT];
+    for (int j = 0; j < SG_OUT; ++j) rc[j] = rect[id[j]];      // (lanes past m carry id 0: a valid address)
+    uint32_t t[SG_OUT], incl[SG_OUT];
 #pragma unroll
-    for (int j = 0; j < DS_OUT; ++j) {
-        const uint32_t p = (uint32_t)j * DS_THREADS + (uint32_t)tid;
+    for (int j = 0; j < SG_OUT; ++j) {
+        const uint32_t p = (uint32_t)j * SG_THREADS + (uint32_t)tid;
         t[j] = p < m ? rect_area(rc[j]) : 0u;
         incl[j] = wave_incl_scan_u32(t[j], lane);
         if (lane == 63) s_wt[j][w] = incl[j];
@@ -453,11 +477,11 @@ __device__ __forceinline__ uint32_t seg_output(const uint32_t (&id)[DS_OUT], uin
     uint32_t run = tile_base;
     constexpr uint32_t IT = GSR_TS_ITEMS;
 #pragma unroll
-    for (int j = 0; j < DS_OUT; ++j) {
-        const uint32_t p = (uint32_t)j * DS_THREADS + (uint32_t)tid;
+    for (int j = 0; j < SG_OUT; ++j) {
+        const uint32_t p = (uint32_t)j * SG_THREADS + (uint32_t)tid;
         uint32_t wpre = 0, rtot = 0;
 #pragma unroll
-        for (int k = 0; k < WG_WAVES; ++k) {
+        for (int k = 0; k < SG_WAVES; ++k) {
             const uint32_t x = s_wt[j][k];
             if (k < w) wpre += x;
             rtot += x;
@@ -485,15 +509,16 @@ __device__ __forceinline__ uint32_t seg_output(const uint32_t (&id)[DS_OUT], uin
     return run - tile_base;
 }
 
-__global__ void __launch_bounds__(DS_THREADS)
+__global__ void __launch_bounds__(SG_THREADS)
 ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame, uint2* pairs0, uint2* pairs1,
            const uint2* __restrict__ rect, uint32_t* __restrict__ order, uint2* __restrict__ rect_sorted, uint32_t* __restrict__ offsets,
            uint2* __restrict__ block_first, uint32_t bf_cap, uint32_t* slow_word /*mapped host word or NULL*/) {
-    __shared__ uint32_t s_key[2][DS_CAP];                       // 32 KB
+    __shared__ uint32_t s_key[2][DS_CAP];                       // 32 KB (oversized segments: the 32-bit count table instead)
     __shared__ uint16_t s_idx[2][DS_CAP];                       // 16 KB
-    __shared__ uint32_t wave_cnt[WG_WAVES][DS_PASS_BINS];       //  8 KB
-    __shared__ uint32_t wsum[WG_WAVES];
-    __shared__ uint32_t s_wt[DS_OUT][WG_WAVES];
+    __shared__ uint16_t wave_cnt[SG_WAVES][DS_PASS_BINS];       //  8 KB
+    __shared__ uint32_t wsum[SG_WAVES];
+    __shared__ uint32_t s_wt[SG_OUT][SG_WAVES];
+    static_assert(sizeof(uint32_t) * SG_WAVES * DS_PASS_BINS <= sizeof(uint32_t) * 2 * DS_CAP, "count table of the oversized path");
     const int tid = threadIdx.x;
     const uint4 e = reinterpret_cast<const uint4*>(plan)[2 * blockIdx.x];
     const uint32_t begin = e.x, end = e.y, d0 = e.z, d1 = e.w;
@@ -508,23 +533,21 @@ ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame
     const uint32_t base_key = kmin + (d0 << shift);
     const uint64_t span = (uint64_t)(d1 - d0) << shift;
     const int nbits = span <= 1ull ? 0 : 64 - __clzll((long long)(span - 1ull));
-    // the last listed Gaussian closes the emission's block table: its global position is (number of listed) - 1 = the end
-    // of the last non-empty segment; only that segment can hold it
     // (the segments tile [0, listed): exactly one ends at `listed`.  Its end BUCKET need not be 2047 -- behind the last
     // non-empty bucket come empty ones that start at `listed` too -- so the element count decides, not the bucket)
     const uint32_t last_listed = end == listed ? end - 1u : 0xFFFFFFFFu;
     if (n <= (uint32_t)DS_CAP) {
         SegLds m{s_key, s_idx};
         {   // all loads, then all LDS writes (a load inside "if (p < n) lds[p] = ..." is waited for one by one)
-            uint32_t kk[DS_OUT];
+            uint32_t kk[SG_OUT];
 #pragma unroll
-            for (int j = 0; j < DS_OUT; ++j) {
-                const uint32_t p = (uint32_t)j * DS_THREADS + (uint32_t)tid;
+            for (int j = 0; j < SG_OUT; ++j) {
+                const uint32_t p = (uint32_t)j * SG_THREADS + (uint32_t)tid;
                 kk[j] = pairs0[begin + (p < n ? p : 0u)].x;
             }
 #pragma unroll
-            for (int j = 0; j < DS_OUT; ++j) {
-                const uint32_t p = (uint32_t)j * DS_THREADS + (uint32_t)tid;
+            for (int j = 0; j < SG_OUT; ++j) {
+                const uint32_t p = (uint32_t)j * SG_THREADS + (uint32_t)tid;
                 if (p < n) {
                     s_key[0][p] = kk[j] - base_key;
                     s_idx[0][p] = (uint16_t)p;
@@ -532,16 +555,16 @@ ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame
             }
         }
         __syncthreads();
-        const int cur = seg_sort(m, n, nbits, wave_cnt, wsum);
-        uint32_t ix[DS_OUT], id[DS_OUT];
+        const int cur = seg_sort<SegLds, uint16_t>(m, n, nbits, wave_cnt, wsum);
+        uint32_t ix[SG_OUT], id[SG_OUT];
 #pragma unroll
-        for (int j = 0; j < DS_OUT; ++j) {
-            const uint32_t p = (uint32_t)j * DS_THREADS + (uint32_t)tid;
+        for (int j = 0; j < SG_OUT; ++j) {
+            const uint32_t p = (uint32_t)j * SG_THREADS + (uint32_t)tid;
             ix[j] = p < n ? (uint32_t)s_idx[cur][p] : 0u;
         }
 #pragma unroll
-        for (int j = 0; j < DS_OUT; ++j) {
-            const uint32_t p = (uint32_t)j * DS_THREADS + (uint32_t)tid;
+        for (int j = 0; j < SG_OUT; ++j) {
+            const uint32_t p = (uint32_t)j * SG_THREADS + (uint32_t)tid;
             const uint32_t v = pairs0[begin + ix[j]].y;
             id[j] = p < n ? v : 0u;
         }
@@ -550,17 +573,18 @@ ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame
     }
     // ---- oversized segment: the same passes through global memory (pairs0 <-> pairs1), then the output in chunks ----
     if (slow_word && tid == 0) __hip_atomic_store(slow_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    SegGlobal m{{pairs0 + begin, pairs1 + begin}, base_key};
-    const int cur = seg_sort(m, n, nbits, wave_cnt, wsum);
-    const uint2* sorted = m.p[cur];
+    SegGlobal m{pairs0 + begin, pairs1 + begin, base_key};
+    uint32_t (*cnt32)[DS_PASS_BINS] = reinterpret_cast<uint32_t (*)[DS_PASS_BINS]>(&s_key[0][0]);
+    const int cur = seg_sort<SegGlobal, uint32_t>(m, n, nbits, cnt32, wsum);
+    const uint2* sorted = cur ? m.p1 : m.p0;
     uint32_t tb = tile_base;
 #pragma unroll 1
     for (uint32_t c0 = 0; c0 < n; c0 += (uint32_t)DS_CAP) {
         const uint32_t mm = min((uint32_t)DS_CAP, n - c0);
-        uint32_t id[DS_OUT];
+        uint32_t id[SG_OUT];
 #pragma unroll
-        for (int j = 0; j < DS_OUT; ++j) {
-            const uint32_t p = (uint32_t)j * DS_THREADS + (uint32_t)tid;
+        for (int j = 0; j < SG_OUT; ++j) {
+            const uint32_t p = (uint32_t)j * SG_THREADS + (uint32_t)tid;
             const uint32_t v = sorted[c0 + (p < mm ? p : 0u)].y;
             id[j] = p < mm ? v : 0u;
         }
@@ -585,6 +609,6 @@ void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* t
     hipLaunchKernelGGL(ds_scan, dim3(DS_NB / 16), dim3(DS_THREADS), 0, st, nblocks, b.cnt_tab, b.tile_tab, b.cnt_total, b.tile_total);
     hipLaunchKernelGGL(ds_scatter, dim3(nblocks + 1), dim3(DS_THREADS), 0, st, P, nblocks, keys, frame, b.cnt_tab, b.cnt_total,
                        b.tile_total, b.pairs[0], order, offsets, rect_sorted, b.plan, nseg_cap);
-    hipLaunchKernelGGL(ds_segsort, dim3(nseg_cap), dim3(DS_THREADS), 0, st, b.plan, frame, b.pairs[0], b.pairs[1], rect, order,
+    hipLaunchKernelGGL(ds_segsort, dim3(nseg_cap), dim3(SG_THREADS), 0, st, b.plan, frame, b.pairs[0], b.pairs[1], rect, order,
                        rect_sorted, offsets, block_first, block_first_cap, slow_word);
 }

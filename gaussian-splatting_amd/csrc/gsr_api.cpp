@@ -370,6 +370,11 @@ int gsr_set_option(const char* name, int value) {
         g_bwd_heavy_first = value;
         return GSR_OK;
     }
+    if (!strcmp(name, "level2_scan_mode")) {
+        if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARG, "level2_scan_mode must be 0 (automatic), 1 (separate scan launch) or 2 (scan folded into the scatter)");
+        gsr_set_level2_scan_mode(value);
+        return GSR_OK;
+    }
     if (!strcmp(name, "tile_sort_mode")) {
         if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "tile_sort_mode must be 0 (fused) or 1 (legacy LSD)");
         g_tile_sort_mode = value;

@@ -328,7 +328,7 @@ emit_scatter(uint32_t R, int gx, int lb, int hb, const uint2* __restrict__ block
 // bucket, its word range and its first workgroup through LDS (the first version looked the bucket up, then read the two
 // tables again for the match: two dependent trips in front of every level-2 kernel's own loads).
 __device__ __forceinline__ bool bucket_block(int nb1, const uint32_t* __restrict__ bucket_base, const uint32_t* __restrict__ blk2_start,
-                                             int* s_h /*[4]*/, uint32_t& h, uint32_t& begin, uint32_t& end) {
+                                             int* s_h /*[5]*/, uint32_t& h, uint32_t& begin, uint32_t& end) {
     const int tid = threadIdx.x;
     const uint32_t B2 = blockIdx.x;
     const int t = tid < nb1 ? tid : 0;
@@ -336,7 +336,7 @@ __device__ __forceinline__ bool bucket_block(int nb1, const uint32_t* __restrict
     if (tid == 0) s_h[0] = -1;
     __syncthreads();
     if (tid < nb1 && b0 <= B2 && B2 < b1) {      // at most one bucket matches
-        s_h[0] = tid; s_h[1] = (int)b0; s_h[2] = (int)w0; s_h[3] = (int)w1;
+        s_h[0] = tid; s_h[1] = (int)b0; s_h[2] = (int)w0; s_h[3] = (int)w1; s_h[4] = (int)b1;
     }
     __syncthreads();
     const int hh = s_h[0];
@@ -349,14 +349,23 @@ __device__ __forceinline__ bool bucket_block(int nb1, const uint32_t* __restrict
     return true;
 }
 
+// ranges_of_empty != NULL (level 2 without its scan kernel): workgroup 0 also writes the (0, 0) ranges of the buckets that hold no
+// instance at all -- nobody else visits them
 template <typename WordT>
 __global__ void __launch_bounds__(WG_THREADS)
 bucket_hist(int lb, int hb, const WordT* __restrict__ words, const uint32_t* __restrict__ bucket_base,
-            const uint32_t* __restrict__ blk2_start, uint32_t* __restrict__ hist2 /*[blocks][nb2]*/) {
+            const uint32_t* __restrict__ blk2_start, uint32_t* __restrict__ hist2 /*[blocks][nb2]*/, uint2* __restrict__ ranges_of_empty,
+            int n_tiles) {
     __shared__ uint32_t hcnt[WG_WAVES][TS_MAXBINS];
-    __shared__ int s_h[4];
+    __shared__ int s_h[5];
     const int tid = threadIdx.x, w = tid >> 6;
     const int nb1 = 1 << hb, nb2 = 1 << lb;
+    if (ranges_of_empty && blockIdx.x == 0 && tid < nb1 && blk2_start[tid] == blk2_start[tid + 1]) {
+        for (int t = 0; t < nb2; ++t) {
+            const int tile = (tid << lb) | t;
+            if (tile < n_tiles) ranges_of_empty[tile] = make_uint2(0u, 0u);
+        }
+    }
     uint32_t h, begin, end;
     if (!bucket_block(nb1, bucket_base, blk2_start, s_h, h, begin, end)) return;
     if (tid < nb2) {
@@ -422,17 +431,21 @@ bucket_scan(int lb, int n_tiles, const uint32_t* __restrict__ bucket_base, const
     }
 }
 
-template <typename WordT>
+// FUSED_SCAN: there was no bucket_scan launch -- hist2 holds the raw per-workgroup counts and every workgroup sums, for each low
+// digit, the counts of its bucket's workgroups (all of them: the per-tile bases; those before it: its own offsets) in one round
+// of independent loads.  The bucket's first workgroup writes the tile ranges.  Chosen by the host while a bucket has few
+// workgroups (the slab a workgroup reads is workgroups-per-bucket x nb2 x 4 bytes).
+template <typename WordT, bool FUSED_SCAN>
 __global__ void __launch_bounds__(WG_THREADS)
 bucket_scatter(int lb, int hb, const WordT* __restrict__ words, const uint32_t* __restrict__ bucket_base,
                const uint32_t* __restrict__ blk2_start, const uint32_t* __restrict__ hist2,
-               const uint32_t* __restrict__ tile_base, uint32_t* __restrict__ point_list) {
+               const uint32_t* __restrict__ tile_base, uint32_t* __restrict__ point_list, uint2* __restrict__ ranges, int n_tiles) {
     __shared__ uint32_t wave_cnt[WG_WAVES][TS_MAXBINS];
     __shared__ uint32_t digit_base[TS_MAXBINS];
     __shared__ uint32_t wsum[WG_WAVES];
     __shared__ uint32_t s_id[TS_ITEMS];
     __shared__ uint8_t s_dig[TS_ITEMS];
-    __shared__ int s_h[4];
+    __shared__ int s_h[5];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nb1 = 1 << hb, nb2 = 1 << lb;
     uint32_t h, begin, end;
@@ -449,7 +462,51 @@ bucket_scatter(int lb, int hb, const WordT* __restrict__ words, const uint32_t* 
         digit[r] = Pack<WordT>::lo(wd, lomask);
         if (valid) vmask |= 1u << r;
     }
-    const uint32_t my_base = tid < nb2 ? tile_base[h * (uint32_t)nb2 + tid] + hist2[(int64_t)blockIdx.x * nb2 + tid] : 0u;
+    uint32_t my_base = 0u;
+    if (FUSED_SCAN) {
+        const uint32_t bs = (uint32_t)s_h[1], be = (uint32_t)s_h[4], B2 = blockIdx.x;
+        const int G = WG_THREADS >> lb;                      // thread = (low digit t, 1 / G of the bucket's workgroups)
+        const int t = tid & (nb2 - 1), g = tid >> lb;
+        uint32_t tot = 0, pre = 0;
+        uint32_t b = bs + (uint32_t)g;
+        for (; b + 3u * (uint32_t)G < be; b += 4u * (uint32_t)G) {      // four independent loads in flight
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = hist2[(int64_t)(b + (uint32_t)(k * G)) * nb2 + t];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                tot += v[k];
+                if (b + (uint32_t)(k * G) < B2) pre += v[k];
+            }
+        }
+        for (; b < be; b += (uint32_t)G) {
+            const uint32_t v = hist2[(int64_t)b * nb2 + t];
+            tot += v;
+            if (b < B2) pre += v;
+        }
+        uint32_t* s_tot = wave_cnt[0];      // scratch until local_stable_sort takes the table over (behind its own barrier)
+        uint32_t* s_pre = wave_cnt[1];
+        s_tot[tid] = tot;
+        s_pre[tid] = pre;
+        __syncthreads();
+        uint32_t tt[1] = {0u};
+        uint32_t pp = 0;
+        if (tid < nb2) {
+            for (int gg = 0; gg < G; ++gg) {
+                tt[0] += s_tot[gg * nb2 + tid];
+                pp += s_pre[gg * nb2 + tid];
+            }
+        }
+        const uint32_t excl = block_excl_scan<1>(tt, wsum, lane, w);
+        if (tid < nb2) {
+            const uint32_t base = (uint32_t)s_h[2] + excl;      // s_h[2] = bucket_base[h]
+            my_base = base + pp;
+            const uint32_t tile = (h << lb) | (uint32_t)tid;
+            if (B2 == bs && tile < (uint32_t)n_tiles) ranges[tile] = tt[0] ? make_uint2(base, base + tt[0]) : make_uint2(0u, 0u);
+        }
+    } else {
+        my_base = tid < nb2 ? tile_base[h * (uint32_t)nb2 + tid] + hist2[(int64_t)blockIdx.x * nb2 + tid] : 0u;
+    }
     local_stable_sort<uint32_t>(id, digit, vmask, lb, nb2, my_base, wave_cnt, digit_base, wsum, s_id, s_dig);
     const uint32_t nvalid = end - begin;
 #pragma unroll
@@ -510,24 +567,33 @@ void gsr_launch_tile_sort_level1(const GsrTileSortPlan& plan, int64_t R, int gx,
                            offsets, rect_sorted, order, hist1, digit_total, nblk, (uint32_t*)words, bucket_base, blk2_start, splats);
 }
 
+int g_level2_scan_mode = 0;      // option level2_scan_mode: 0 = automatic, 1 = separate bucket_scan launch, 2 = folded into bucket_scatter
+
+void gsr_set_level2_scan_mode(int v) { g_level2_scan_mode = v; }
+
 void gsr_launch_tile_sort_level2(const GsrTileSortPlan& plan, int64_t R, int n_tiles, const void* words, uint32_t* point_list,
                                  const uint32_t* bucket_base, const uint32_t* blk2_start, uint32_t* hist2, uint32_t* tile_base,
                                  uint2* ranges, hipStream_t st) {
     const int nblk = (int)((R + TS_ITEMS - 1) / TS_ITEMS);
     const int nb1 = 1 << plan.hb;
     const int nblk2 = nblk + nb1;       // upper bound of the level-2 workgroups (every bucket rounds up once)
+    // without the scan kernel every level-2 workgroup reads its bucket's slab of the count table: fine while a bucket has a few
+    // dozen workgroups (bench frame: 30), too much traffic when it has hundreds (6 M Gaussians: 180)
+    const bool fused = g_level2_scan_mode == 2 || (g_level2_scan_mode == 0 && nblk <= 64 * nb1);
+    uint2* roe = fused ? ranges : nullptr;
     if (plan.word64)
         hipLaunchKernelGGL(bucket_hist<uint64_t>, dim3(nblk2), dim3(WG_THREADS), 0, st, plan.lb, plan.hb, (const uint64_t*)words,
-                           bucket_base, blk2_start, hist2);
+                           bucket_base, blk2_start, hist2, roe, n_tiles);
     else
         hipLaunchKernelGGL(bucket_hist<uint32_t>, dim3(nblk2), dim3(WG_THREADS), 0, st, plan.lb, plan.hb, (const uint32_t*)words,
-                           bucket_base, blk2_start, hist2);
-    hipLaunchKernelGGL(bucket_scan, dim3(nb1), dim3(WG_THREADS), 0, st, plan.lb, n_tiles, bucket_base, blk2_start, hist2, tile_base,
-                       ranges);
-    if (plan.word64)
-        hipLaunchKernelGGL(bucket_scatter<uint64_t>, dim3(nblk2), dim3(WG_THREADS), 0, st, plan.lb, plan.hb, (const uint64_t*)words,
-                           bucket_base, blk2_start, hist2, tile_base, point_list);
-    else
-        hipLaunchKernelGGL(bucket_scatter<uint32_t>, dim3(nblk2), dim3(WG_THREADS), 0, st, plan.lb, plan.hb, (const uint32_t*)words,
-                           bucket_base, blk2_start, hist2, tile_base, point_list);
+                           bucket_base, blk2_start, hist2, roe, n_tiles);
+    if (!fused)
+        hipLaunchKernelGGL(bucket_scan, dim3(nb1), dim3(WG_THREADS), 0, st, plan.lb, n_tiles, bucket_base, blk2_start, hist2, tile_base,
+                           ranges);
+#define GSR_L2_SCATTER(WORD_, FUSED_)                                                                                               \
+    hipLaunchKernelGGL((bucket_scatter<WORD_, FUSED_>), dim3(nblk2), dim3(WG_THREADS), 0, st, plan.lb, plan.hb, (const WORD_*)words,  \
+                       bucket_base, blk2_start, hist2, tile_base, point_list, ranges, n_tiles)
+    if (plan.word64) { if (fused) GSR_L2_SCATTER(uint64_t, true); else GSR_L2_SCATTER(uint64_t, false); }
+    else { if (fused) GSR_L2_SCATTER(uint32_t, true); else GSR_L2_SCATTER(uint32_t, false); }
+#undef GSR_L2_SCATTER
 }

@@ -102,6 +102,8 @@ def test_bins_bit_exact_in_every_structural_regime(name, depth_sort_mode, tiles_
                                        s.projmatrix.to(dev), s.sh_degree, s.campos.to(dev), False, False, s.antialiasing)
     _lib.set_option("depth_sort_mode", depth_sort_mode)
     _lib.set_option("snug_tiles", 0 if tiles_mode == "reference" else 1)
+    # the level-2 scan rides along: folded into the scatter with the bucket sort, its own launch with the LSD passes
+    _lib.set_option("level2_scan_mode", 2 if depth_sort_mode == 2 else 1)
     try:
         for no_backward in (False, True):
             out = forward_with_views(rs, d.means3D, d.opacities, shs=d.shs, scales=d.scales, rotations=d.rotations,
@@ -120,6 +122,7 @@ def test_bins_bit_exact_in_every_structural_regime(name, depth_sort_mode, tiles_
     finally:
         _lib.set_option("depth_sort_mode", 0)
         _lib.set_option("snug_tiles", 1)
+        _lib.set_option("level2_scan_mode", 0)
 
 
 def test_depth_order_and_scan_of_the_bucket_sort_equal_the_lsd_sort():
