@@ -436,7 +436,11 @@ def _run(a):
             rs_views.append(GaussianRasterizationSettings(H, W, vc.tanfovx, vc.tanfovy, bg, 1.0, vd.world_view_transform,
                                                           vd.full_proj_transform, 3, vd.camera_center, False, False, False))
             gts.append(torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(1 + i)))
+        # "ssim_depth": the depth-supervised step of train.py:128-140 -- the inverse-depth image takes part in the loss, so the
+        # backward runs its HAS_DEPTH build (render_bwd_half<true>: the 1/depth recurrence, a tenth gradient value per pair)
+        inv_gts = [torch.rand(1, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(101 + i)) for i in range(len(rs_views))]
         legs = [("ssim", "dense", fused_train_loss), ("sparse_adam", "sparse", fused_train_loss), ("l1", "dense", l1_loss),
+                ("ssim_depth", "dense", fused_train_loss),
                 ("ssim_unfused_l1", "dense", unfused_l1_train_loss),
                 # opt-in: the Adam step of the two SH tensors applied inside the per-Gaussian backward (separate_sh form)
                 ("sparse_adam_sh_step_in_backward", "sparse+fused", fused_train_loss),
@@ -491,6 +495,8 @@ def _run(a):
                     m, sh, o, s_, r_ = params
                     color, radii, invd = rasterize_gaussians(m, None, sh, None, o, s_, r_, None, rs_views[vi], None)
                 loss = loss_fn(color, gts[vi])
+                if leg == "ssim_depth":      # train.py:131-137: Ll1depth = weight * |invDepth - mono_invdepth| * mask, mean
+                    loss = loss + 0.5 * (invd - inv_gts[vi]).abs().mean()
                 loss.backward()
                 if sparse_opt:
                     opt.step(radii > 0, radii.shape[0])
@@ -546,6 +552,47 @@ def _run(a):
                   "gpu_event_ms": event_stats.get("forward_cycled"),
                   "note": "the headline re-renders view 0 (the frame whose V / R the config names); its 236 MB of parameters fit the 256 MiB "
                           "Infinity Cache, and so do they here -- the views change R, the lists and the scratch sizes, not the residency"}
+
+    # ---- the forward leg over SEVERAL 1 M-Gaussian parameter sets (VERDICT r03 weak #6c / item 3): three scenes of the same
+    # recipe with different seeds, rendered in turn -- 708 MB of parameters, 2.8x the 256 MiB Infinity Cache, so every frame's
+    # preprocess streams its 236 MB from HBM.  The stage table of this leg carries the HBM-resident preprocess figure. ----
+    scene_cycle = None
+    if world == 1 and P <= 2_000_000 and not a.no_other_configs:
+        try:
+            extra = [make_scene(P, cam, seed=a.seed + 1 + i, s_med=a.s_med).to(dev) for i in range(2)]
+            sets = [sc] + extra
+            cyc2 = [0]
+
+            def forward_scene_cycled():
+                s_ = sets[cyc2[0] % len(sets)]
+                cyc2[0] += 1
+                with torch.no_grad():
+                    rasterize_gaussians(s_.means3D, None, s_.shs, None, s_.opacities, s_.scales, s_.rotations, None, rs, None)
+            for _ in range(2 * len(sets)):
+                forward_scene_cycled()
+            nsc = max(a.steps, 2 * len(sets)) // len(sets) * len(sets)
+            sdt = timed_loop(forward_scene_cycled, nsc, "forward_scene_cycled")[0]
+            _lib.profile_reset()
+            _lib.profile_enable(True)
+            for _ in range(2 * len(sets)):
+                forward_scene_cycled()
+            torch.cuda.synchronize()
+            sst = _lib.profile_read()
+            _lib.profile_enable(False)
+            pre_ms = sst["preprocess"]["ms"] / max(1, sst["preprocess"]["launches"])
+            pre_bytes = 236 * P + 88 * P      # designed bytes of the inference preprocess: parameters in, splat record + side arrays out
+            scene_cycle = {"parameter_sets": len(sets), "parameter_bytes_total": int(236 * P * len(sets)), "steps": nsc,
+                           "ms_per_frame": round(sdt / nsc * 1e3, 4), "Mpix_s": round(npix / (sdt / nsc) / 1e6, 1),
+                           "gpu_event_ms": event_stats.get("forward_scene_cycled"),
+                           "stage_ms": {k: round(v["ms"] / v["launches"], 4) for k, v in sst.items() if v["launches"]},
+                           "preprocess_hbm": {"ms": round(pre_ms, 4), "design_bytes": int(pre_bytes),
+                                              "GBs": round(pre_bytes / (pre_ms * 1e-3) / 1e9, 1),
+                                              "frac_of_8TBs": round(pre_bytes / (pre_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                           "note": "three parameter sets (seeds s, s+1, s+2) rendered in turn: the parameters no longer fit the 256 MiB "
+                                   "Infinity Cache, so this preprocess figure is an HBM figure; the headline re-renders one set"}
+            del extra, sets
+        except Exception as ex:      # (a context leg must never cost the headline)
+            scene_cycle = {"error": repr(ex)[:300]}
 
     # ---- train leg WITH density control ("one step = forward + L1/SSIM loss + backward + Adam + amortised densify",
     # train.py:111-186): the reference's statistics every iteration and clone / split / prune every 100 iterations
@@ -774,6 +821,10 @@ def _run(a):
                     for kn in kernel_names:
                         if kn in pk:
                             return pk[kn]
+                    for kn in kernel_names:      # template arguments differ between builds: "render_bwd_half" matches "render_bwd_half<false>"
+                        for have in sorted(pk):
+                            if have.startswith(kn):
+                                return pk[have]
             except Exception:
                 pass
             return None
@@ -873,6 +924,8 @@ def _run(a):
             "gpu_event_note": "per-step HIP-event intervals on the launch stream (median / p10 / p90 / mean) beside the wall-clock mean that "
                               "`value` uses; the host is paced by the per-frame R read-back, so the two agree when nothing stalls",
             "forward_cycled_views": cycled,
+            "forward_cycled_scenes": scene_cycle,
+            "train_iters_per_s_depth_supervised": None if "ssim_depth" not in train else round(1e3 / train["ssim_depth"], 3),
             "frame_parallel_replicas": replicas,
             "train_iters_per_s_sparse_adam": None if "sparse_adam" not in train else round(1e3 / train["sparse_adam"], 3),
             "train_iters_per_s_sh_step_in_backward": {k: round(1e3 / train[k], 3) for k in ("sparse_adam_sh_step_in_backward", "dense_adam_sh_step_in_backward") if k in train}
