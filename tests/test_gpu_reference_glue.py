@@ -200,3 +200,49 @@ def test_reference_render_glue(case):
     na = torch.norm(gi["viewspace_points"][vi[:, 0], :2], dim=-1)
     nb = torch.norm(gh["viewspace_points"][vh[:, 0], :2], dim=-1)
     assert float((na - nb).abs().max()) <= 2e-3 * float(na.max())
+
+
+def test_trained_model_file_loaded_by_the_reference_renders_like_the_same_file_loaded_here():
+    """render.py:48-60 stand-in.  tests/golden/scene_small.ply was loaded ONCE by the reference's own
+    GaussianModel.load_ply + activations in the build container (tests/golden/make_golden_ply.py -> frozen tensors).  Here, on
+    the GPU box, the same file goes through gsr_scene.load_gaussians_ply; both parameter sets are rendered by the operator:
+    identical tensors, bit-identical images / radii / inverse depth, and the image agrees with the oracle."""
+    import os
+    import numpy as np
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from test_ply_io import GOLD, activated_from_ply
+    from helpers import oracle_settings
+    dev = torch.device("cuda:0")
+    ref = np.load(os.path.join(GOLD, "scene_small_reference_loaded.npz"))
+    W, H = int(ref["width"]), int(ref["height"])
+    from_ref = {k: torch.from_numpy(ref[k]).to(dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    ours = activated_from_ply(os.path.join(GOLD, "scene_small.ply"), device=dev)      # activations run on the GPU here
+    cam = make_camera(W, H)
+    s = oracle_settings(cam, bg=torch.tensor([0.1, 0.0, 0.2]))
+    rs = GaussianRasterizationSettings(H, W, s.tanfovx, s.tanfovy, s.bg.to(dev), 1.0, s.viewmatrix.to(dev), s.projmatrix.to(dev), 3,
+                                       s.campos.to(dev), False, False, False)
+    outs = []
+    for prm in (from_ref, ours):
+        with torch.no_grad():
+            outs.append(GaussianRasterizer(rs)(means3D=prm["means3D"], means2D=None, opacities=prm["opacities"], shs=prm["shs"],
+                                               scales=prm["scales"], rotations=prm["rotations"]))
+    torch.cuda.synchronize()
+    # the GPU's exp / sigmoid / normalize may differ from the CPU's by an ulp: the tensors agree to rounding, the un-activated ones exactly
+    for k in ("means3D", "shs"):
+        assert torch.equal(from_ref[k], ours[k]), k
+    for k in ("opacities", "scales", "rotations"):
+        assert torch.allclose(from_ref[k], ours[k], rtol=3e-7, atol=1e-9), k
+    assert torch.equal(outs[0][1], outs[1][1]), "radii differ"
+    assert (outs[0][0] - outs[1][0]).abs().max().item() <= 2e-6, "images differ beyond the activations' rounding"
+    # and CPU-activated parameters (bit-identical to the reference's, tests/test_ply_io.py) render bit-identically
+    cpu_act = {k: v.to(dev) for k, v in activated_from_ply(os.path.join(GOLD, "scene_small.ply"), device="cpu").items()}
+    with torch.no_grad():
+        o3 = GaussianRasterizer(rs)(means3D=cpu_act["means3D"], means2D=None, opacities=cpu_act["opacities"], shs=cpu_act["shs"],
+                                    scales=cpu_act["scales"], rotations=cpu_act["rotations"])
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], o3)), "same tensors, same file: the renders must be bit-identical"
+    col, radii, invd, aux = O.rasterize(from_ref["means3D"].cpu(), torch.zeros(from_ref["means3D"].shape[0], 3), from_ref["opacities"].cpu(), s, shs=from_ref["shs"].cpu(),
+                                        scales=from_ref["scales"].cpu(), rotations=from_ref["rotations"].cpu(), want_fragile=True,
+                                        return_aux=True)
+    assert torch.equal(outs[0][1].cpu(), radii)
+    err = (outs[0][0].cpu() - col).abs().amax(0)
+    assert err[~aux["fragile"]].max().item() <= 1e-5

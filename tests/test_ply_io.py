@@ -131,3 +131,44 @@ def test_reference_gaussian_model_save_and_load_through_the_stand_in(tmp_path):
         sys.path.remove(REF)
         for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.") or k.startswith("scene.")]:
             sys.modules.pop(k, None)
+
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def activated_from_ply(path, device="cpu"):
+    """What gaussian_renderer/__init__.py:56-110 hands to the rasterizer, from a point_cloud.ply, without the reference:
+    gsr_scene.load_gaussians_ply + the activations of scene/gaussian_model.py:39-47 (exp, sigmoid, normalize)."""
+    raw = load_gaussians_ply(path, 3, device=device)
+    return dict(means3D=raw["xyz"], shs=torch.cat((raw["features_dc"], raw["features_rest"]), dim=1),
+                opacities=torch.sigmoid(raw["opacity"]), scales=torch.exp(raw["scaling"]),
+                rotations=torch.nn.functional.normalize(raw["rotation"]))
+
+
+def test_file_loaded_by_the_reference_equals_file_loaded_by_gsr_scene():
+    """tests/golden/scene_small.ply went through the REFERENCE's GaussianModel.load_ply and activations once, in the build
+    container (tests/golden/make_golden_ply.py); the frozen tensors must equal what this repo's loader produces from the same
+    file -- on any box, with no reference tree."""
+    ref = np.load(os.path.join(GOLD, "scene_small_reference_loaded.npz"))
+    ours = activated_from_ply(os.path.join(GOLD, "scene_small.ply"))
+    for k, v in ours.items():
+        assert v.shape == ref[k].shape, k
+        assert np.array_equal(v.numpy(), ref[k]), f"{k}: max diff {np.abs(v.numpy() - ref[k]).max()}"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "scene", "gaussian_model.py")), reason="reference tree not present")
+def test_the_ply_fixture_is_reproducible_from_the_reference(tmp_path):
+    """The committed fixture is what the generating script produces today (build container only)."""
+    import subprocess
+    import shutil
+    work = tmp_path / "golden"
+    work.mkdir()
+    shutil.copy(os.path.join(GOLD, "make_golden_ply.py"), work / "make_golden_ply.py")
+    # the script writes next to itself; point its ROOT at the repo by running a patched copy
+    src = (work / "make_golden_ply.py").read_text().replace('ROOT = os.path.dirname(os.path.dirname(HERE))', f'ROOT = {helpers.ROOT!r}')
+    (work / "make_golden_ply.py").write_text(src)
+    subprocess.check_call([sys.executable, str(work / "make_golden_ply.py")], stdout=subprocess.DEVNULL)
+    assert (work / "scene_small.ply").read_bytes() == open(os.path.join(GOLD, "scene_small.ply"), "rb").read()
+    new, old = np.load(work / "scene_small_reference_loaded.npz"), np.load(os.path.join(GOLD, "scene_small_reference_loaded.npz"))
+    for k in old.files:
+        assert np.array_equal(new[k], old[k]), k
