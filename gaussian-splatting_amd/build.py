@@ -60,6 +60,9 @@ def _stale(target: str, deps) -> bool:
 
 def _headers():
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    ab = os.path.join(CSRC, "ab")      # measured-and-rejected kernel variants, included by the sources under -DGSR_AB_VARIANTS only
+    if os.path.isdir(ab):
+        hs += [os.path.join(ab, f) for f in os.listdir(ab) if f.endswith(".inc")]
     hs.append(os.path.join(ROOT, "include", "gsr.h"))
     hs.append(os.path.abspath(__file__))
     return hs

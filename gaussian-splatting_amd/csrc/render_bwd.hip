@@ -410,265 +410,7 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
 }
 
 #ifdef GSR_AB_VARIANTS
-// ------------------------------------------------------------------------------------------------
-// A/B variant 5 (first version of round 2): one independent wave per 8x8 quadrant, per-(quadrant, instance) records
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
-render_bwd_quad(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                const float4* __restrict__ splats, const float* __restrict__ final_T,
-                const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                const float* __restrict__ dL_dinvdepth, float4* __restrict__ slot_grads /*[4][R] records of 3 float4*/,
-                uint8_t* __restrict__ slot_flags /*[R][4]*/, int64_t R, unsigned long long* __restrict__ counters /*NULL unless profiling*/) {
-    __shared__ float4 s_rec[64 * REC_STRIDE];   // the batch: (x, y, a2, b2 | c2, opacity, r, g | b, 1/depth, -, -)
-    __shared__ float s_grad[64 * 12];           // this quadrant's record of every entry of the batch
-    // XCD-aware mapping as in the forward: the four quadrants of a tile get workgroup ids b, b+8, b+16, b+24 -> same XCD
-    const int b = blockIdx.x;
-    const int grp = b >> 5, r32 = b & 31;
-    const int tile_local = grp * 8 + (r32 & 7);
-    const int quad = r32 >> 3;
-    if (tile_local >= n_band_tiles) return;
-    const int tile = cam.tile_y0 * cam.gx + tile_local;
-    const int tx = tile % cam.gx, ty = tile / cam.gx;
-    const int lane = threadIdx.x;
-    const int bx0 = tx * GSR_TILE + (quad & 1) * 8, by0 = ty * GSR_TILE + (quad >> 1) * 8;
-    if (bx0 >= cam.W || by0 >= cam.H) return;
-    const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
-    const bool inside = px < cam.W && py < cam.H;
-    const float pxf = (float)px, pyf = (float)py;
-    const float x0 = (float)bx0, x1 = (float)min(bx0 + 7, cam.W - 1);
-    const float y0 = (float)by0, y1 = (float)min(by0 + 7, cam.H - 1);
-    const uint2 range = ranges[tile];
-    const int64_t pix = (int64_t)py * cam.W + px;
-    const int64_t HW = (int64_t)cam.H * cam.W;
-    const float T_final = inside ? final_T[pix] : 0.f;
-    const uint32_t last_contrib = inside ? n_contrib[pix] : 0u;
-    const float dLr = inside ? dL_dpix[pix] : 0.f;
-    const float dLg = inside ? dL_dpix[HW + pix] : 0.f;
-    const float dLb = inside ? dL_dpix[2 * HW + pix] : 0.f;
-    const float dLd = (inside && dL_dinvdepth) ? dL_dinvdepth[pix] : 0.f;
-    const float Tf_bg = -T_final * (cam.bg[0] * dLr + cam.bg[1] * dLg + cam.bg[2] * dLb);
-    uint32_t mx = last_contrib;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
-    // entries at list positions >= end contributed to no pixel of this quadrant: no record, flag byte stays 0
-    const uint32_t end = min(range.y - range.x, mx);
-    if (end == 0) return;
-
-    BwdPix s = {T_final, 0.f, 0.f, 0.f};
-    float4* s_grad4 = reinterpret_cast<float4*>(s_grad);
-    float4* slot = slot_grads + (int64_t)quad * R * 3;
-    const int nbatch = (int)((end + 63u) >> 6);
-    // software pipeline over the batches (each needs two dependent global loads, list id -> 64-byte record): ids are
-    // fetched two batches ahead, records one batch ahead; the survivor loop in between touches only LDS
-    auto load_id = [&](int bi) -> uint32_t {
-        const uint32_t e = (uint32_t)bi * 64u + (uint32_t)lane;
-        return (bi >= 0 && e < end) ? point_list[range.x + e] : 0xFFFFFFFFu;
-    };
-    uint32_t id_n = load_id(nbatch - 1);
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 n0 = zero4, n1 = zero4, n2 = zero4, n3 = zero4;
-    if (id_n != 0xFFFFFFFFu) { n0 = splats[id_n * 4 + 0]; n1 = splats[id_n * 4 + 1]; n2 = splats[id_n * 4 + 2]; n3 = splats[id_n * 4 + 3]; }
-    id_n = load_id(nbatch - 2);
-    uint32_t nsteps = 0;        // wave-uniform work counter, reported only while profiling
-    for (int bi = nbatch - 1; bi >= 0; --bi) {
-        const uint32_t base = (uint32_t)bi * 64u;
-        const uint32_t n = min(64u, end - base);
-        const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
-        if (id_n != 0xFFFFFFFFu) { n0 = splats[id_n * 4 + 0]; n1 = splats[id_n * 4 + 1]; n2 = splats[id_n * 4 + 2]; n3 = splats[id_n * 4 + 3]; }
-        id_n = load_id(bi - 2);
-        bool keep = false;
-        uint32_t k_emit = 0;
-        if ((uint32_t)lane < n) {
-            keep = !(min_q_over_box(q0.x, q0.y, q0.z, q0.w, q1.x, x0, x1, y0, y1) > q2.z);     // q2.z = tau
-            k_emit = emission_index(q3, (uint32_t)tx, (uint32_t)ty);
-            // staged entry with the log2-scaled conic: a2 = -0.5 log2(e) A, b2 = -log2(e) B, c2 = -0.5 log2(e) C
-            s_rec[lane * REC_STRIDE + 0] = make_float4(q0.x, q0.y, -0.5f * LOG2E * q0.z, -LOG2E * q0.w);
-            s_rec[lane * REC_STRIDE + 1] = make_float4(-0.5f * LOG2E * q1.x, q1.y, q1.z, q1.w);
-            s_rec[lane * REC_STRIDE + 2] = make_float4(q2.x, q2.w, 0.f, 0.f);
-        }
-        uint64_t mask = __ballot(keep);
-        nsteps += (uint32_t)__popcll(mask);
-        uint64_t touched = 0ull;
-        while (mask) {
-            const int j = 63 - __builtin_clzll(mask);
-            mask &= ~(1ull << j);
-            const uint32_t pos0 = base + (uint32_t)j;          // 0-based list position
-            const float4 r0 = s_rec[j * REC_STRIDE + 0];
-            const float4 r1 = s_rec[j * REC_STRIDE + 1];
-            const float2 r2 = *reinterpret_cast<const float2*>(&s_rec[j * REC_STRIDE + 2]);
-            float g_px, g_py, g_A, g_B, g_C, g_op, g_r, g_g, g_b, g_d;     // g_px .. g_C hold the raw moments
-            const bool active = bwd_step(s, pos0 < last_contrib, pxf, pyf, Tf_bg, dLr, dLg, dLb, dLd, r0.x, r0.y, r0.z,
-                                         r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, g_px, g_py, g_A, g_B, g_C, g_op,
-                                         g_r, g_g, g_b, g_d);
-            if (__builtin_amdgcn_ballot_w64(active) == 0ull) continue;
-            // slots in lanes 15 / 31 / 47 / 63 = first / third / second / fourth argument
-            const float v0 = reduce4(g_px, g_A, g_py, g_B);     // -> slots 0,1,2,3
-            const float v1 = reduce4(g_C, g_r, g_op, g_g);      // -> slots 4,5,6,7
-            const float v2 = reduce2(g_b, g_d);                 // -> slots 8 (lane 31), 9 (lane 63)
-            if ((lane & 15) == 15) {
-                float* o = s_grad + j * 12 + (lane >> 4);
-                o[0] = v0;
-                o[4] = v1;
-                if (lane & 16) s_grad[j * 12 + 8 + (lane >> 5)] = v2;
-            }
-            touched |= 1ull << j;
-        }
-        // flush: the touched entries' records go to this quadrant's slot of their instance (emission index) + flag byte
-        if (touched) {
-            __builtin_amdgcn_wave_barrier();
-            if ((touched >> lane) & 1ull) {
-                float4* dst = slot + (int64_t)k_emit * 3;
-                dst[0] = s_grad4[lane * 3 + 0];
-                dst[1] = s_grad4[lane * 3 + 1];
-                dst[2] = s_grad4[lane * 3 + 2];
-                slot_flags[(int64_t)k_emit * 4 + quad] = 1;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    if (counters && lane == 0) {     // [2] (quadrant, entry) pairs stepped by all 64 lanes, [3] batches of 64 entries box-tested
-        atomicAdd(counters + 2, (unsigned long long)nsteps);
-        atomicAdd(counters + 3, (unsigned long long)nbatch);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// A/B variant 4 (round 1's default): workgroup per tile, per-instance gradient records, no global atomics
-// ------------------------------------------------------------------------------------------------
-// SB = super-batch: list entries staged in LDS at a time (256: one per thread)
-template <int SB>
-__global__ void __launch_bounds__(256)
-render_bwd_tile(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                const float4* __restrict__ splats, const float* __restrict__ final_T,
-                const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                const float* __restrict__ dL_dinvdepth, float4* __restrict__ inst_grads,
-                uint8_t* __restrict__ inst_flag) {
-    __shared__ float4 s_rec[SB * REC_STRIDE];   // 12 KB
-    __shared__ float s_grad[SB * 12];           // 12 KB
-    __shared__ uint32_t s_k[SB];                // emission index of every staged entry
-    __shared__ uint32_t s_touch[SB];            // entry received a contribution from some wave of the tile
-    __shared__ uint32_t s_max[4];
-    const int tid = threadIdx.x, lane = tid & 63, quad = tid >> 6;
-    const int tile = cam.tile_y0 * cam.gx + blockIdx.x;
-    const int tx = tile % cam.gx, ty = tile / cam.gx;
-    const int bx0 = tx * GSR_TILE + (quad & 1) * 8, by0 = ty * GSR_TILE + (quad >> 1) * 8;
-    const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
-    const bool inside = px < cam.W && py < cam.H;
-    const float pxf = (float)px, pyf = (float)py;
-    // box of existing pixels of this quadrant (may be empty at the image border: then nothing survives the test)
-    const float x0 = (float)bx0, x1 = (float)min(bx0 + 7, cam.W - 1);
-    const float y0 = (float)by0, y1 = (float)min(by0 + 7, cam.H - 1);
-    const bool quad_alive = bx0 < cam.W && by0 < cam.H;
-    const uint2 range = ranges[tile];
-    const int64_t pix = (int64_t)py * cam.W + px;
-    const int64_t HW = (int64_t)cam.H * cam.W;
-
-    const float T_final = inside ? final_T[pix] : 0.f;
-    const uint32_t last_contrib = inside ? n_contrib[pix] : 0u;
-    const float dLr = inside ? dL_dpix[pix] : 0.f;
-    const float dLg = inside ? dL_dpix[HW + pix] : 0.f;
-    const float dLb = inside ? dL_dpix[2 * HW + pix] : 0.f;
-    const float dLd = (inside && dL_dinvdepth) ? dL_dinvdepth[pix] : 0.f;
-    const float Tf_bg = -T_final * (cam.bg[0] * dLr + cam.bg[1] * dLg + cam.bg[2] * dLb);
-
-    uint32_t mx = last_contrib;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
-    if (lane == 0) s_max[quad] = mx;
-    __syncthreads();
-    const uint32_t nlist = range.y - range.x;
-    const uint32_t end = min(nlist, max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
-    // Entries at list positions >= end contributed to no pixel of the tile: they get no record (their valid flag stays 0;
-    // looking up the emission index of every tail entry just to store zeros cost a 64-byte gather per entry, 590 MB of
-    // fetches on the 1 M / 1080p frame, and clearing all records by memset another 545 MB of writes).  Records live at
-    // the instance's EMISSION index k (contiguous per Gaussian): k = goffset + (ty - miny) * w + (tx - minx), with the
-    // rectangle and goffset read from the 4th quad of the 64-byte splat record.
-    if (end == 0) return;
-
-    BwdPix s = {T_final, 0.f, 0.f, 0.f};
-    float4* s_grad4 = reinterpret_cast<float4*>(s_grad);
-
-    for (int sb = (int)((end - 1) / SB) * SB; sb >= 0; sb -= SB) {
-        const uint32_t n = min((uint32_t)SB, end - (uint32_t)sb);
-        // ---- stage the super-batch, zero the gradient table ----
-        if ((uint32_t)tid < n) {
-            const uint32_t id = point_list[range.x + sb + tid];
-            const float4 q0 = splats[id * 4 +0];
-            const float4 q1 = splats[id * 4 +1];
-            const float4 q2 = splats[id * 4 +2];
-            // staged entry: (x, y, a2, b2 | c2, opacity, r, g | b, 1/depth, tau, -) with the log2-scaled conic
-            // a2 = -0.5 log2(e) A, b2 = -log2(e) B, c2 = -0.5 log2(e) C (power in base 2 = a2 dx^2 + b2 dx dy + c2 dy^2)
-            s_rec[tid * REC_STRIDE + 0] = make_float4(q0.x, q0.y, -0.5f * LOG2E * q0.z, -LOG2E * q0.w);
-            s_rec[tid * REC_STRIDE + 1] = make_float4(-0.5f * LOG2E * q1.x, q1.y, q1.z, q1.w);
-            s_rec[tid * REC_STRIDE + 2] = make_float4(q2.x, q2.w, q2.z, 0.f);
-            s_k[tid] = emission_index(splats[id * 4 + 3], (uint32_t)tx, (uint32_t)ty);
-        }
-        for (int i = tid; i < SB * 3; i += 256) s_grad4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = tid; i < SB; i += 256) s_touch[i] = 0u;
-        __syncthreads();
-
-        if (quad_alive) {
-            for (int sub = (int)((n - 1) >> 6); sub >= 0; --sub) {
-                if ((uint32_t)sb + (uint32_t)sub * 64u >= mx) continue;      // wholly behind this quadrant's last contributor
-                const uint32_t e = (uint32_t)sub * 64 + lane;
-                bool keep = false;
-                if (e < n) {
-                    const float4 r0 = s_rec[e * REC_STRIDE + 0];
-                    const float c2e = s_rec[e * REC_STRIDE + 1].x;
-                    const float tau = s_rec[e * REC_STRIDE + 2].z;
-                    // plain conic back from the scaled one (the test has a 0.01 margin in tau: the extra rounding is harmless)
-                    const float qmin = min_q_over_box(r0.x, r0.y, r0.z * (-2.0f / LOG2E), r0.w * (-1.0f / LOG2E),
-                                                      c2e * (-2.0f / LOG2E), x0, x1, y0, y1);
-                    // entries at or behind the quadrant's own last contributor touch none of its pixels either (the
-                    // super-batch runs to the TILE's last contributor, which another quadrant may set much deeper)
-                    keep = !(qmin > tau) && ((uint32_t)sb + e < mx);
-                }
-                uint64_t mask = __ballot(keep);
-                // (requesting the NEXT survivor's record before processing the current one -- a software pipeline over
-                // the ds_reads -- measured 8 % slower: 0.517 vs 0.477 ms; LDS returns in order, so the early read also
-                // queues behind this survivor's ds_adds)
-                while (mask) {
-                    const int j = 63 - __builtin_clzll(mask);
-                    mask &= ~(1ull << j);
-                    const uint32_t entry = (uint32_t)sub * 64 + j;
-                    const uint32_t pos0 = (uint32_t)sb + entry;          // 0-based list position
-                    const float4 r0 = s_rec[entry * REC_STRIDE + 0];
-                    const float4 r1 = s_rec[entry * REC_STRIDE + 1];
-                    const float2 r2 = *reinterpret_cast<const float2*>(&s_rec[entry * REC_STRIDE + 2]);
-                    float g_px, g_py, g_A, g_B, g_C, g_op, g_r, g_g, g_b, g_d;     // g_px .. g_C hold the raw moments
-                    const bool active = bwd_step(s, pos0 < last_contrib, pxf, pyf, Tf_bg, dLr, dLg, dLb, dLd, r0.x, r0.y, r0.z,
-                                                 r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, g_px, g_py, g_A, g_B, g_C, g_op,
-                                                 g_r, g_g, g_b, g_d);
-                    if (__builtin_amdgcn_ballot_w64(active) == 0ull) continue;
-                    // slots in lanes 15 / 31 / 47 / 63 = first / third / second / fourth argument
-                    const float v0 = reduce4(g_px, g_A, g_py, g_B);     // -> slots 0,1,2,3
-                    const float v1 = reduce4(g_C, g_r, g_op, g_g);      // -> slots 4,5,6,7
-                    const float v2 = reduce2(g_b, g_d);                 // -> slots 8 (lane 31), 9 (lane 63)
-                    if ((lane & 15) == 15) {
-                        float* o = s_grad + entry * 12 + (lane >> 4);
-                        atomicAdd(o, v0);
-                        atomicAdd(o + 4, v1);
-                        if (lane & 16) atomicAdd(s_grad + entry * 12 + 8 + (lane >> 5), v2);
-                        if (lane == 15) s_touch[entry] = 1u;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        // ---- flush: one 48-byte record per TOUCHED entry, at the entry's emission index (3 lanes per record), plus its
-        // valid flag.  Untouched entries write nothing: the reduce kernel skips records whose flag byte is 0, so neither a
-        // 48 B/instance memset nor zero records are needed (only the 1 B/instance flag array is cleared per backward).
-        for (uint32_t i = tid; i < n * 3; i += 256) {
-            const uint32_t e = i / 3, part = i - e * 3;
-            if (s_touch[e]) {
-                inst_grads[(int64_t)s_k[e] * 3 + part] = s_grad4[i];
-                if (part == 0) inst_flag[(int64_t)s_k[e] * 4] = 1;      // quadrant slot 0 holds the whole tile's record
-            }
-        }
-        __syncthreads();
-    }
-}
-
+#include "ab/render_bwd_quad_superbatch.inc"      // measured-and-rejected variants: measurement build only
 #endif  // GSR_AB_VARIANTS
 
 // splat_grads[g] = sum of the instance records of Gaussian g.  In emission (= depth) order a Gaussian's records are one
@@ -927,95 +669,7 @@ reduce_stitch(int64_t nunits, const uint32_t* __restrict__ order, const float4* 
 }
 
 #ifdef GSR_AB_VARIANTS
-// ------------------------------------------------------------------------------------------------
-// variant 1 (A/B baseline): wave per 8x8 block, DPP full-wave reductions, one global atomic set per (block, Gaussian)
-// into the per-Gaussian record
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
-render_bwd_wave(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ranges,
-                const uint32_t* __restrict__ point_list, const float4* __restrict__ splats,
-                const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-                const float* __restrict__ dL_dpix, const float* __restrict__ dL_dinvdepth, float* __restrict__ grads) {
-    const int b = blockIdx.x;
-    const int grp = b >> 5, r32 = b & 31;
-    const int tile_local = grp * 8 + (r32 & 7);
-    const int quad = r32 >> 3;
-    if (tile_local >= n_band_tiles) return;
-    const int tile = cam.tile_y0 * cam.gx + tile_local;
-    const int tx = tile % cam.gx, ty = tile / cam.gx;
-    const int lane = threadIdx.x;
-    const int bx0 = tx * GSR_TILE + (quad & 1) * 8, by0 = ty * GSR_TILE + (quad >> 1) * 8;
-    if (bx0 >= cam.W || by0 >= cam.H) return;
-    const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
-    const bool inside = px < cam.W && py < cam.H;
-    const float pxf = (float)px, pyf = (float)py;
-    const float x0 = (float)bx0, x1 = (float)min(bx0 + 7, cam.W - 1);
-    const float y0 = (float)by0, y1 = (float)min(by0 + 7, cam.H - 1);
-    const uint2 range = ranges[tile];
-    const int64_t pix = (int64_t)py * cam.W + px;
-    const int64_t HW = (int64_t)cam.H * cam.W;
-    const float T_final = inside ? final_T[pix] : 0.f;
-    const uint32_t last_contrib = inside ? n_contrib[pix] : 0u;
-    const float dLr = inside ? dL_dpix[pix] : 0.f;
-    const float dLg = inside ? dL_dpix[HW + pix] : 0.f;
-    const float dLb = inside ? dL_dpix[2 * HW + pix] : 0.f;
-    const float dLd = (inside && dL_dinvdepth) ? dL_dinvdepth[pix] : 0.f;
-    const float Tf_bg = -T_final * (cam.bg[0] * dLr + cam.bg[1] * dLg + cam.bg[2] * dLb);
-    uint32_t max_contrib = last_contrib;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) max_contrib = max(max_contrib, (uint32_t)__shfl_xor((int)max_contrib, off, 64));
-    const uint32_t end = min(range.y - range.x, max_contrib);
-    if (end == 0) return;
-    BwdPix s = {T_final, 0.f, 0.f, 0.f};
-    for (int bstart = (int)((end - 1) & ~63u); bstart >= 0; bstart -= 64) {
-        const uint32_t n = min(64u, end - (uint32_t)bstart);
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
-        float colb = 0.f, invd = 0.f;
-        uint32_t id = 0;
-        bool keep = false;
-        if ((uint32_t)lane < n) {
-            id = point_list[range.x + bstart + lane];
-            q0 = splats[id * 4 +0];
-            q1 = splats[id * 4 +1];
-            const float4 q2 = splats[id * 4 +2];
-            colb = q2.x;
-            invd = q2.w;
-            keep = !(min_q_over_box(q0.x, q0.y, q0.z, q0.w, q1.x, x0, x1, y0, y1) > q2.z);
-        }
-        uint64_t mask = __ballot(keep);
-        while (mask) {
-            const int j = 63 - __builtin_clzll(mask);
-            mask &= ~(1ull << j);
-            const uint32_t pos0 = (uint32_t)bstart + (uint32_t)j;
-            const float gx_ = bcast(q0.x, j), gy_ = bcast(q0.y, j), cA = bcast(q0.z, j), cB = bcast(q0.w, j);
-            const float cC = bcast(q1.x, j), op = bcast(q1.y, j), cr = bcast(q1.z, j), cg = bcast(q1.w, j);
-            const float cb = bcast(colb, j), idp = bcast(invd, j);
-            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, j);
-            float g_px, g_py, g_A, g_B, g_C, g_op, g_r, g_g, g_b, g_d;
-            const bool active = bwd_step(s, pos0 < last_contrib, pxf, pyf, Tf_bg, dLr, dLg, dLb, dLd, gx_, gy_,
-                                         -0.5f * LOG2E * cA, -LOG2E * cB, -0.5f * LOG2E * cC, op, cr, cg, cb, idp, g_px, g_py,
-                                         g_A, g_B, g_C, g_op, g_r, g_g, g_b, g_d);
-            if (__builtin_amdgcn_ballot_w64(active) == 0ull) continue;
-            g_px = wave_sum_to_lane63(g_px); g_py = wave_sum_to_lane63(g_py);
-            g_A = wave_sum_to_lane63(g_A); g_B = wave_sum_to_lane63(g_B); g_C = wave_sum_to_lane63(g_C);
-            g_op = wave_sum_to_lane63(g_op);
-            g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
-            g_d = wave_sum_to_lane63(g_d);
-            if (lane == 63) {
-                float* o = grads + (int64_t)gid * 12;
-                float4 u0 = make_float4(g_px, g_py, g_A, g_B), u1 = make_float4(g_C, 0.f, 0.f, 0.f);
-                u1.y = g_op;
-                moments_to_grads(cA, cB, cC, op, u0, u1);
-                atomicAdd(o + 0, u0.x); atomicAdd(o + 1, u0.y);
-                atomicAdd(o + 2, u0.z); atomicAdd(o + 3, u0.w); atomicAdd(o + 4, u1.x);
-                atomicAdd(o + 5, u1.y);
-                atomicAdd(o + 6, g_r); atomicAdd(o + 7, g_g); atomicAdd(o + 8, g_b);
-                atomicAdd(o + 9, g_d);
-            }
-        }
-    }
-}
-
+#include "ab/render_bwd_atomics.inc"      // measured-and-rejected variants: measurement build only
 #endif  // GSR_AB_VARIANTS
 
 // ------------------------------------------------------------------------------------------------

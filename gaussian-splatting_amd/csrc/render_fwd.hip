@@ -30,81 +30,7 @@
 namespace {
 
 #ifdef GSR_AB_VARIANTS
-struct PixState {
-    float T, C0, C1, C2, D;
-    uint32_t last;
-    bool done;
-};
-
-// One (pixel, Gaussian) step of Appendix A.4.  pos = 1-based position of the entry in the tile's list.
-__device__ __forceinline__ void blend_step(PixState& s, float pxf, float pyf, float gx_, float gy_, float cA, float cB,
-                                           float cC, float op, float r, float g, float b, float invd, uint32_t pos) {
-    const float dx = gx_ - pxf, dy = gy_ - pyf;
-    const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
-    if (power > 0.0f) return;
-    const float alpha = fminf(GSR_ALPHA_MAX, op * __expf(power));
-    if (alpha < GSR_ALPHA_MIN) return;
-    const float testT = s.T * (1.0f - alpha);
-    if (testT < GSR_T_EPS) { s.done = true; return; }
-    const float w = alpha * s.T;
-    s.C0 += r * w; s.C1 += g * w; s.C2 += b * w; s.D += invd * w;
-    s.T = testT;
-    s.last = pos;
-}
-
-// ------------------------------------------------------------------------------------------------
-// variant 1: workgroup per tile, LDS staging
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-render_fwd_block(GsrCamDev cam, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                 const float4* __restrict__ splats, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                 float* __restrict__ out_color, float* __restrict__ out_invdepth) {
-    __shared__ float4 s_q0[256];
-    __shared__ float4 s_q1[256];
-    __shared__ float2 s_q2[256];
-    const int tid = threadIdx.x;
-    const int tile = cam.tile_y0 * cam.gx + blockIdx.x;
-    const int tx = tile % cam.gx, ty = tile / cam.gx;
-    const int px = tx * GSR_TILE + (tid & 15), py = ty * GSR_TILE + (tid >> 4);
-    const bool inside = px < cam.W && py < cam.H;
-    const float pxf = (float)px, pyf = (float)py;
-    const uint2 range = ranges[tile];
-    PixState s = {1.0f, 0.f, 0.f, 0.f, 0.f, 0u, !inside};
-    for (uint32_t base = range.x; base < range.y; base += 256) {
-        if (__syncthreads_count(s.done) == 256) break;
-        const uint32_t n = min(256u, range.y - base);
-        if ((uint32_t)tid < n) {
-            const uint32_t id = point_list[base + tid];
-            s_q0[tid] = splats[id * 4 +0];
-            s_q1[tid] = splats[id * 4 +1];
-            const float4 q2 = splats[id * 4 +2];
-            s_q2[tid] = make_float2(q2.x, 1.0f / q2.y);
-        }
-        __syncthreads();
-        if (!s.done) {
-            for (uint32_t j = 0; j < n; ++j) {
-                const float4 q0 = s_q0[j];
-                const float4 q1 = s_q1[j];
-                const float2 q2 = s_q2[j];
-                blend_step(s, pxf, pyf, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, base - range.x + j + 1);
-                if (s.done) break;
-            }
-        }
-    }
-    if (inside) {
-        const int64_t pix = (int64_t)py * cam.W + px;
-        const int64_t HW = (int64_t)cam.H * cam.W;
-        if (final_T) {      // NULL in inference mode: only the backward reads these
-            final_T[pix] = s.T;
-            n_contrib[pix] = s.last;
-        }
-        out_color[pix] = s.C0 + s.T * cam.bg[0];
-        out_color[HW + pix] = s.C1 + s.T * cam.bg[1];
-        out_color[2 * HW + pix] = s.C2 + s.T * cam.bg[2];
-        if (out_invdepth) out_invdepth[pix] = s.D;
-    }
-}
-
+#include "ab/render_fwd_block.inc"      // measured-and-rejected variants: measurement build only
 #endif  // GSR_AB_VARIANTS
 
 // ------------------------------------------------------------------------------------------------
