@@ -134,17 +134,11 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
 // ---- D2 ------------------------------------------------------------------------------------------------------------
 // tables are [workgroup][bucket]; a workgroup of this kernel owns 16 buckets, thread = (bucket, 1/16 of the rows): the 16
 // lanes of a row segment read 64 contiguous bytes.  cnt_tab[b][d] <- keys of bucket d in workgroups < b; totals of both tables.
-// Also clears the level-1 histogram of the tile sort (GsrLevel1Hist: [bucket][4096-instance block], filled with atomics by
-// ds_segsort): its size follows from R, which the key-producing kernel left in frame[0..1].
 __global__ void __launch_bounds__(DS_THREADS)
 ds_scan(int nblocks, uint32_t* __restrict__ cnt_tab, const uint32_t* __restrict__ tile_tab, uint32_t* __restrict__ cnt_total,
-        uint32_t* __restrict__ tile_total, const uint32_t* __restrict__ frame, GsrLevel1Hist l1) {
+        uint32_t* __restrict__ tile_total) {
     __shared__ uint32_t s_c[16][16], s_t[16][16];
     const int tid = threadIdx.x, dl = tid & 15, bg = tid >> 4;
-    if (l1.hist) {
-        const uint64_t words = gsr_level1_hist_words(l1, frame);      // 0: the table is not used for this frame
-        for (uint64_t i = (uint64_t)blockIdx.x * DS_THREADS + tid; i < words; i += (uint64_t)gridDim.x * DS_THREADS) l1.hist[i] = 0u;
-    }
     const int d = blockIdx.x * 16 + dl;
     const int chunk = (nblocks + 15) / 16;
     const int lo = min(bg * chunk, nblocks), hi = min(lo + chunk, nblocks);
@@ -466,8 +460,7 @@ __device__ __forceinline__ uint32_t seg_output(const uint32_t (&id)[SG_OUT], uin
                                               uint32_t tile_base, const uint2* __restrict__ rect, uint32_t* __restrict__ order,
                                               uint2* __restrict__ rect_sorted, uint32_t* __restrict__ offsets,
                                               uint2* __restrict__ block_first, uint32_t bf_cap, uint32_t last_listed, bool r_ok,
-                                              uint32_t (*s_wt)[SG_WAVES], const GsrLevel1Hist& l1, uint32_t l1_nblk,
-                                              uint32_t* s_hist /*GSR_L1_LDS_WORDS words of LDS*/) {
+                                              uint32_t (*s_wt)[SG_WAVES]) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     uint2 rc[SG_OUT];
 #pragma unroll
@@ -483,7 +476,6 @@ __device__ __forceinline__ uint32_t seg_output(const uint32_t (&id)[SG_OUT], uin
     __syncthreads();
     uint32_t run = tile_base;
     constexpr uint32_t IT = GSR_TS_ITEMS;
-    uint32_t in_[SG_OUT];
 #pragma unroll
     for (int j = 0; j < SG_OUT; ++j) {
         const uint32_t p = (uint32_t)j * SG_THREADS + (uint32_t)tid;
@@ -495,7 +487,6 @@ __device__ __forceinline__ uint32_t seg_output(const uint32_t (&id)[SG_OUT], uin
             rtot += x;
         }
         const uint32_t in = run + wpre + incl[j], ex = in - t[j];
-        in_[j] = in;
         if (p < m) {
             const uint32_t g = gpos0 + p;
             order[g] = id[j];
@@ -515,63 +506,13 @@ __device__ __forceinline__ uint32_t seg_output(const uint32_t (&id)[SG_OUT], uin
         run += rtot;
     }
     __syncthreads();      // s_wt is reused by the next chunk
-    // ---- level-1 histogram of the tile sort (what the emit_hist launch used to count): hist[d][b] += instances of block b whose
-    // tile id >> lb == d.  The chunk's instances [tile_base, run) span a few consecutive blocks; they are counted in an LDS
-    // window of GSR_L1_LDS_WORDS / nb1 blocks per pass (per rectangle row, cut at bucket boundaries, as emit_hist does) and
-    // every non-zero cell goes to the table with one atomic -- a cell is shared with at most the neighbouring chunks.
-    if (l1_nblk && r_ok && run > tile_base) {
-        constexpr uint32_t IT1 = GSR_TS_ITEMS;
-        const uint32_t nb1 = 1u << l1.hb;
-        const uint32_t win = (uint32_t)GSR_L1_LDS_WORDS >> l1.hb;                       // blocks per window (>= 32)
-        const uint32_t B_first = tile_base / IT1, B_last = (run - 1u) / IT1;
-        for (uint32_t B0 = B_first; B0 <= B_last; B0 += win) {
-            const uint32_t B1 = min(B_last + 1u, B0 + win);                            // window [B0, B1)
-            for (uint32_t c = tid; c < (B1 - B0) * nb1; c += SG_THREADS) s_hist[c] = 0u;
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < SG_OUT; ++j) {
-                if (!t[j]) continue;
-                const uint32_t in = in_[j], ex = in - t[j];
-                const uint32_t lo_all = max(ex, B0 * IT1);
-                const uint32_t hi_all = (uint32_t)min((uint64_t)in, (uint64_t)B1 * IT1);      // (in < 2^31: r_ok)
-                if (hi_all <= lo_all) continue;
-                const uint32_t minx = rc[j].x & 0xFFFFu, wd = (rc[j].x >> 16) - minx, miny = rc[j].y & 0xFFFFu;
-                for (uint32_t b = lo_all / IT1; b <= (hi_all - 1u) / IT1; ++b) {
-                    const uint32_t lo = max(lo_all, b * IT1), hi = (uint32_t)min((uint64_t)hi_all, (uint64_t)(b + 1u) * IT1);
-                    const uint32_t ka = lo - ex, kb = hi - ex;       // the Gaussian's local instances [ka, kb) lie in block b
-                    uint32_t xa, xl;
-                    const uint32_t ra = div_small(ka, wd, xa), rb = div_small(kb - 1u, wd, xl);
-                    uint32_t* hb_row = s_hist + (b - B0) * nb1;
-                    for (uint32_t r = ra; r <= rb; ++r) {
-                        const uint32_t x0 = r == ra ? xa : 0u, x1 = r == rb ? xl + 1u : wd;
-                        uint32_t t0 = (miny + r) * (uint32_t)l1.gx + minx + x0;
-                        const uint32_t t1 = t0 + (x1 - x0);
-                        while (t0 < t1) {                                   // cut the row at bucket boundaries
-                            const uint32_t d = t0 >> l1.lb, tend = min(t1, (d + 1u) << l1.lb);
-                            atomicAdd(&hb_row[d], tend - t0);
-                            t0 = tend;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            for (uint32_t c = tid; c < (B1 - B0) * nb1; c += SG_THREADS) {
-                const uint32_t v = s_hist[c];
-                if (v) {
-                    const uint32_t b = B0 + (c >> l1.hb), d = c & (nb1 - 1u);
-                    __hip_atomic_fetch_add(l1.hist + (uint64_t)d * l1_nblk + b, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            __syncthreads();
-        }
-    }
     return run - tile_base;
 }
 
 __global__ void __launch_bounds__(SG_THREADS)
 ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame, uint2* pairs0, uint2* pairs1,
            const uint2* __restrict__ rect, uint32_t* __restrict__ order, uint2* __restrict__ rect_sorted, uint32_t* __restrict__ offsets,
-           uint2* __restrict__ block_first, uint32_t bf_cap, uint32_t* slow_word /*mapped host word or NULL*/, GsrLevel1Hist l1) {
+           uint2* __restrict__ block_first, uint32_t bf_cap, uint32_t* slow_word /*mapped host word or NULL*/) {
     __shared__ uint32_t s_key[2][DS_CAP];                       // 32 KB (oversized segments: the 32-bit count table instead)
     __shared__ uint16_t s_idx[2][DS_CAP];                       // 16 KB
     __shared__ uint16_t wave_cnt[SG_WAVES][DS_PASS_BINS];       //  8 KB
@@ -588,9 +529,6 @@ ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame
     const uint32_t kmin = frame[2], kmax = frame[3];
     const int shift = ds_shift(kmin, kmax);
     const bool r_ok = frame[1] == 0u && (int32_t)frame[0] >= 0;      // R < 2^31 (else the host refuses the frame: no table writes)
-    const uint32_t l1_nblk = gsr_level1_hist_words(l1, frame) ? (uint32_t)gsr_level1_nblk(frame[0]) : 0u;
-    uint32_t* s_hist = &s_key[0][0];      // free once the sort is done (the output phase reads s_idx only)
-    static_assert(GSR_L1_LDS_WORDS <= 2 * DS_CAP, "level-1 histogram window");
     // keys of the segment lie in [base_key, base_key + span)
     const uint32_t base_key = kmin + (d0 << shift);
     const uint64_t span = (uint64_t)(d1 - d0) << shift;
@@ -630,8 +568,7 @@ ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame
             const uint32_t v = pairs0[begin + ix[j]].y;
             id[j] = p < n ? v : 0u;
         }
-        __syncthreads();      // every thread has read its s_idx entries: the key buffers become the histogram window
-        seg_output(id, n, begin, tile_base, rect, order, rect_sorted, offsets, block_first, bf_cap, last_listed, r_ok, s_wt, l1, l1_nblk, s_hist);
+        seg_output(id, n, begin, tile_base, rect, order, rect_sorted, offsets, block_first, bf_cap, last_listed, r_ok, s_wt);
         return;
     }
     // ---- oversized segment: the same passes through global memory (pairs0 <-> pairs1), then the output in chunks ----
@@ -651,7 +588,7 @@ ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame
             const uint32_t v = sorted[c0 + (p < mm ? p : 0u)].y;
             id[j] = p < mm ? v : 0u;
         }
-        tb += seg_output(id, mm, begin + c0, tb, rect, order, rect_sorted, offsets, block_first, bf_cap, last_listed, r_ok, s_wt, l1, l1_nblk, s_hist);
+        tb += seg_output(id, mm, begin + c0, tb, rect, order, rect_sorted, offsets, block_first, bf_cap, last_listed, r_ok, s_wt);
     }
 }
 
@@ -665,13 +602,13 @@ size_t gsr_depth_bucket_segments(int P) { return ((size_t)(P > 0 ? P : 1) + DS_S
 // tile counts in depth order), block_first[bf_cap]
 void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, const uint2* rect, uint32_t* frame,
                                   const uint2* wg_range, int n_range, const GsrDepthSortBufs& b, uint32_t* order, uint2* rect_sorted, uint32_t* offsets, uint2* block_first,
-                                  uint32_t block_first_cap, uint32_t* slow_word, const GsrLevel1Hist& l1, hipStream_t st) {
+                                  uint32_t block_first_cap, uint32_t* slow_word, hipStream_t st) {
     const int nblocks = (int)gsr_depth_bucket_blocks(P);
     const int nseg_cap = (int)gsr_depth_bucket_segments(P);
     hipLaunchKernelGGL(ds_hist, dim3(nblocks), dim3(DS_THREADS), 0, st, P, keys, tiles, frame, wg_range, n_range, b.cnt_tab, b.tile_tab);
-    hipLaunchKernelGGL(ds_scan, dim3(DS_NB / 16), dim3(DS_THREADS), 0, st, nblocks, b.cnt_tab, b.tile_tab, b.cnt_total, b.tile_total, frame, l1);
+    hipLaunchKernelGGL(ds_scan, dim3(DS_NB / 16), dim3(DS_THREADS), 0, st, nblocks, b.cnt_tab, b.tile_tab, b.cnt_total, b.tile_total);
     hipLaunchKernelGGL(ds_scatter, dim3(nblocks + 1), dim3(DS_THREADS), 0, st, P, nblocks, keys, frame, b.cnt_tab, b.cnt_total,
                        b.tile_total, b.pairs[0], order, offsets, rect_sorted, b.plan, nseg_cap);
     hipLaunchKernelGGL(ds_segsort, dim3(nseg_cap), dim3(SG_THREADS), 0, st, b.plan, frame, b.pairs[0], b.pairs[1], rect, order,
-                       rect_sorted, offsets, block_first, block_first_cap, slow_word, l1);
+                       rect_sorted, offsets, block_first, block_first_cap, slow_word);
 }

@@ -39,7 +39,6 @@ int g_depth_sort_mode = 0;      // 0 = automatic (bucket sort, depthsort.hip, up
 int g_snug_tiles = 1;           // 1 = bin every Gaussian into its snug tile rectangle (gsr_math.h); 0 = the reference's square (A/B)
 int g_bwd_heavy_first = 1;      // 1 = the blend backward starts its heaviest tiles first (plan kernel, render_bwd.hip); 0 = index order (A/B)
 int g_tile_sort_mode = 0;       // 0 = fused emission + two-level sort (tilesort.hip), 1 = legacy emit + LSD passes (A/B)
-int g_l1_hist_in_depth_sort = 1;      // 1 = the bucket depth sort's segment kernel counts the tile sort's level-1 histogram (no emit_hist launch)
 
 struct PendingEvent { int stage; hipEvent_t a, b; };
 std::mutex g_prof_mu;
@@ -257,7 +256,6 @@ GsrGeom gsr_carve_geom(char* base, int P) {
         g.ds.cnt_total = (uint32_t*)take(GSR_DS_BUCKETS * 4);
         g.ds.tile_total = (uint32_t*)take(GSR_DS_BUCKETS * 4);
         g.ds.plan = (uint32_t*)take(nseg * 32);
-        g.ds.l1hist = (uint32_t*)take(ds ? (size_t)256 * gsr_block_first_cap(P) * 4 : 4);
     }
     g.num_rendered = (uint32_t*)take(128);
     g.wg_range = (uint2*)take((size_t)GSR_FRAME_MAX_GROUPS * 8);
@@ -370,11 +368,6 @@ int gsr_set_option(const char* name, int value) {
     if (!strcmp(name, "bwd_heavy_first")) {
         if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "bwd_heavy_first must be 0 (tiles in index order) or 1 (heaviest tiles first)");
         g_bwd_heavy_first = value;
-        return GSR_OK;
-    }
-    if (!strcmp(name, "l1_hist_in_depth_sort")) {
-        if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "l1_hist_in_depth_sort must be 0 or 1");
-        g_l1_hist_in_depth_sort = value;
         return GSR_OK;
     }
     if (!strcmp(name, "level2_scan_mode")) {
@@ -534,15 +527,6 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     const int order_buf = depth_order_buffer_index();
     const uint32_t bf_cap = (uint32_t)gsr_block_first_cap(P);
     const bool bucket = use_bucket_sort(P, dev_id);
-    const int n_tiles = cam.gx * cam.gy;
-    GsrTileSortPlan plan;
-    gsr_tile_sort_plan(n_tiles, P, &plan);
-    if (g_tile_sort_mode == 1) plan.fused = false;
-    // the bucket depth sort's segment kernel also leaves the level-1 histogram of the tile sort (no emit_hist launch)
-    GsrLevel1Hist l1;
-    l1.hist = (bucket && plan.fused && g_l1_hist_in_depth_sort) ? g.ds.l1hist : nullptr;
-    l1.cap_words = (uint64_t)256 * bf_cap;
-    l1.gx = cam.gx; l1.lb = plan.lb; l1.hb = plan.hb;
     // R = number of (Gaussian, tile) instances sizes the binning buffer and the emission grids, so the host must learn it
     // mid-pipeline (the reference has the same read-back).  It does not depend on the depth order: the key-producing kernel
     // has already summed it, and its last workgroup stores it with a sequence number straight into mapped pinned host memory
@@ -552,7 +536,7 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     {   StageTimer t(GSR_STAGE_DEPTH_SORT, st);
         if (bucket) {
             gsr_launch_depth_bucket_sort(P, g.keys[0], g.tiles, g.rect, g.num_rendered, g.wg_range, n_range, g.ds, g.vals[order_buf], g.rect_sorted, g.offsets,
-                                         g.block_first, bf_cap, hw_slot.dev + 5, l1, st);
+                                         g.block_first, bf_cap, hw_slot.dev + 5, st);
         } else {
             const int ob = gsr_radix_sort_pairs(g.keys, g.vals, P, GSR_DEPTH_KEY_BITS, GSR_DEPTH_DIGIT_BITS, g.sort_hist, g.digit_total,
                                                 sort_items(P), st, g.rect, g.rect_sorted);
@@ -569,6 +553,10 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     // first launch after the host has R
     EventPair wait_ev;
     wait_ev.arm(st);
+    const int n_tiles = cam.gx * cam.gy;
+    GsrTileSortPlan plan;
+    gsr_tile_sort_plan(n_tiles, P, &plan);
+    if (g_tile_sort_mode == 1) plan.fused = false;
     char* ibase = (char*)image_resize(image_user, gsr_image_bytes(cam.W, cam.H));
     // legacy path: the tile-range table is cleared here; the fused path writes every entry of the table itself
     if (ibase && !plan.fused)
@@ -615,11 +603,8 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
                 gsr_launch_fill_block_first(P, g.offsets, b.block_first, (uint32_t)(nblk + 2), st);
                 block_first = b.block_first;
             }
-            // (after the 32-bit-key fallback the depth order, hence the block histograms, were redone by the LSD path: count again)
-            const bool l1_ready = hw_slot.host[3] == 0u && gsr_level1_hist_words_R(l1, (uint64_t)R) > 0;
             gsr_launch_tile_sort_level1(plan, R, cam.gx, block_first, g.offsets, g.rect_sorted, g.vals[order_buf], b.keys[0],
-                                        l1_ready ? l1.hist : b.sort_hist, l1_ready, b.digit_total, b.bucket_base, b.blk2_start,
-                                        goffset_splats, st);
+                                        b.sort_hist, b.digit_total, b.bucket_base, b.blk2_start, goffset_splats, st);
         }
         STAGE_CHECK("emit + level-1 sort");
         {   StageTimer t(GSR_STAGE_TILE_SORT, st);

@@ -41,24 +41,6 @@ static inline size_t gsr_block_first_cap(int P) { return (size_t)(P > 0 ? P : 1)
 #define GSR_DS_SEG 2048          // a segment = the buckets that start inside one window of this many elements
 #define GSR_DS_CAP 4096          // largest segment sorted in LDS; beyond: the same passes through global memory (slow, reported)
 #define GSR_DS_MAX_P (3 << 20)   // above: the LSD radix sort (the [workgroup][bucket] tables grow with P)
-// level-1 histogram of the tile sort produced by the segment sort instead of the emit_hist launch: [bucket][4096-instance block]
-#define GSR_L1_LDS_WORDS 8192
-struct GsrLevel1Hist {
-    uint32_t* hist;              // NULL: not wanted (LSD depth sort, more than 65536 tiles)
-    uint64_t cap_words;
-    int gx, lb, hb;
-};
-static inline __host__ __device__ uint64_t gsr_level1_nblk(uint64_t R) { return (R + GSR_TS_ITEMS - 1) / GSR_TS_ITEMS; }
-// words of the table a frame with R instances uses; 0 = the table is not used (too small, empty or refused frame) -- the host and
-// every kernel evaluate the same expression
-static inline __host__ __device__ uint64_t gsr_level1_hist_words_R(const GsrLevel1Hist& l1, uint64_t R) {
-    if (!l1.hist || R == 0 || R > 0x7FFFFFFFull) return 0;
-    const uint64_t w = ((uint64_t)1 << l1.hb) * gsr_level1_nblk(R);
-    return w <= l1.cap_words ? w : 0;
-}
-static inline __host__ __device__ uint64_t gsr_level1_hist_words(const GsrLevel1Hist& l1, const uint32_t* frame) {
-    return gsr_level1_hist_words_R(l1, ((uint64_t)frame[1] << 32) | frame[0]);
-}
 struct GsrDepthSortBufs {
     uint2* pairs[2];             // [P] (key, id) in bucket order / scratch of an oversized segment
     uint32_t* cnt_tab;           // [workgroups][2048] keys per bucket, then their exclusive prefix over the workgroups
@@ -66,7 +48,6 @@ struct GsrDepthSortBufs {
     uint32_t* cnt_total;         // [2048]
     uint32_t* tile_total;        // [2048]
     uint32_t* plan;              // [segments][8]
-    uint32_t* l1hist;            // [256 * gsr_block_first_cap(P)] level-1 histogram of the tile sort (GsrLevel1Hist)
 };
 size_t gsr_depth_bucket_blocks(int P);
 size_t gsr_depth_bucket_segments(int P);
@@ -188,7 +169,7 @@ int gsr_radix_sort_pairs_k16(uint16_t* keys[2], uint32_t* vals[2], int64_t n, in
 // depthsort.hip: depth order + rectangles in depth order + inclusive scan of the tile counts + the emission's block table
 void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, const uint2* rect, uint32_t* frame,
                                   const uint2* wg_range, int n_range, const GsrDepthSortBufs& b, uint32_t* order, uint2* rect_sorted, uint32_t* offsets, uint2* block_first,
-                                  uint32_t block_first_cap, uint32_t* slow_word, const GsrLevel1Hist& l1, hipStream_t st);
+                                  uint32_t block_first_cap, uint32_t* slow_word, hipStream_t st);
 // pass plan shared by the sorter and by code that must know which ping-pong buffer holds the result
 int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits /*[8]*/);
 #define GSR_DEPTH_DIGIT_BITS 9      // 27-bit depth keys: 3 passes of 9 bits (round 2: 4 x 8 on 32 bits; 3 x 11 measured slower: 113 vs 91 us)
@@ -213,10 +194,9 @@ void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offse
 struct GsrTileSortPlan { bool fused; int lb, hb; bool word64; };
 void gsr_tile_sort_plan(int n_tiles, int P, GsrTileSortPlan* plan);
 void gsr_launch_fill_block_first(int P, const uint32_t* offsets, uint2* block_first, uint32_t cap, hipStream_t st);
-// hist_ready: hist1 already holds the block histograms (filled by the depth sort's segment kernel): no emit_hist launch
 void gsr_launch_tile_sort_level1(const GsrTileSortPlan& plan, int64_t R, int gx, const uint2* block_first,
                                  const uint32_t* offsets, const uint2* rect_sorted, const uint32_t* order, void* words,
-                                 uint32_t* hist1, bool hist_ready, uint32_t* digit_total, uint32_t* bucket_base, uint32_t* blk2_start,
+                                 uint32_t* hist1, uint32_t* digit_total, uint32_t* bucket_base, uint32_t* blk2_start,
                                  float4* splats /*NULL: inference*/, hipStream_t st);
 void gsr_launch_tile_sort_level2(const GsrTileSortPlan& plan, int64_t R, int n_tiles, const void* words, uint32_t* point_list,
                                  const uint32_t* bucket_base, const uint32_t* blk2_start, uint32_t* hist2, uint32_t* tile_base,

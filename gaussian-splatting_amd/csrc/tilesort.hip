@@ -551,13 +551,12 @@ void gsr_launch_fill_block_first(int P, const uint32_t* offsets, uint2* block_fi
 
 void gsr_launch_tile_sort_level1(const GsrTileSortPlan& plan, int64_t R, int gx, const uint2* block_first,
                                  const uint32_t* offsets, const uint2* rect_sorted, const uint32_t* order, void* words,
-                                 uint32_t* hist1, bool hist_ready, uint32_t* digit_total, uint32_t* bucket_base, uint32_t* blk2_start,
+                                 uint32_t* hist1, uint32_t* digit_total, uint32_t* bucket_base, uint32_t* blk2_start,
                                  float4* splats, hipStream_t st) {
     const int nblk = (int)((R + TS_ITEMS - 1) / TS_ITEMS);
     const int nb1 = 1 << plan.hb;
     const uint32_t R32 = (uint32_t)R;
-    if (!hist_ready)
-        hipLaunchKernelGGL(emit_hist, dim3(nblk), dim3(WG_THREADS), 0, st, R32, gx, plan.lb, nb1, block_first, offsets, rect_sorted,
+    hipLaunchKernelGGL(emit_hist, dim3(nblk), dim3(WG_THREADS), 0, st, R32, gx, plan.lb, nb1, block_first, offsets, rect_sorted,
                        hist1, nblk);
     gsr_launch_rs_scan(hist1, nblk, nb1, digit_total, st);
     if (plan.word64)
