@@ -14,6 +14,9 @@ finishes in a second or two).  What each case is there for:
   odd_frame         width / height not multiples of 16, partial edge tiles, a one-tile-high last row
   tiles_65536       exactly 65536 tiles: the largest frame of the fused two-level tile sort (one more tile takes the
                     32-bit-key LSD path, covered by test_gpu_parity.py)
+  huge_tiles_65536  the same frame with splats of thousands of tiles each
+  depth_*           depth distributions that select the paths of the bucket depth sort (ties, a crowded bucket -> oversized
+                    segments through global memory, a 4-decade gap, a single key)
 Reference boundary: gaussian_renderer/__init__.py:91-110; bins = SURVEY 8(c)(3) "tile bin counts bit-exact"."""
 import pytest
 import torch
@@ -31,6 +34,8 @@ CASES = {
     "sort_2048_tier": (524_288 + 1061, 320, 240, 0.004, 5),
     "odd_frame": (50_000, 1001, 337, 0.02, 6),
     "tiles_65536": (6_000, 4096, 4096, 0.03, 7),
+    # thousands of tiles per Gaussian on a 65536-tile frame (256 x 256 buckets, Gaussians that own dozens of emission blocks)
+    "huge_tiles_65536": (2_000, 4096, 4096, 0.35, 14),
     # depth distributions that select the code paths of the BUCKET depth sort (depthsort.hip):
     "depth_ties": (30_000, 320, 240, 0.01, 8),        # depths quantised to 64 values: tie order = Gaussian index, in every segment
     "depth_crowd": (20_000, 320, 240, 0.01, 9),       # 3/4 of the Gaussians inside 1e-5 of the depth range: oversized segments

@@ -265,7 +265,8 @@ def test_bench_multi_rank_path_on_one_gpu(mode, nproc):
     assert "error" not in d, d
     assert d["n_gpus"] == nproc and d["value"] > 0 and d["train_iters_per_s"] > 0 and d["scaling"] == "strong"
     assert d["config"]["mode"] == mode and d["config"]["collectives"]["all_to_all_single"]
-    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
+    # (the fraction itself can round to 0.0 here: three processes time-slice one GPU and the stage times are mostly waiting)
+    assert d["roofline"]["frac"] >= 0 and d["blend_work"]["fwd_pair_steps_per_launch"] > 0 and d["cpu_baseline"] is None
 
 
 def test_bench_reports_an_error_line_instead_of_dying_silently():
