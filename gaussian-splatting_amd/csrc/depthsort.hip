@@ -198,43 +198,66 @@ ds_scan(int nblocks, uint32_t* __restrict__ cnt_tab, const uint32_t* __restrict_
 }
 
 // ---- D3 ------------------------------------------------------------------------------------------------------------
+// 512 threads per 4096 keys: with 256 the launch put ONE wave on every SIMD, and a lone wave issues a VALU instruction every
+// ~5 cycles (DESIGN: the measured issue ceiling needs >= 3 waves per SIMD) -- the kernel was bound by the 11 ballots per 64 keys
+// at a fifth of the issue rate.  Eight waves per workgroup halve the rounds per wave and let two waves share every SIMD.
+constexpr int S3_THREADS = 512;
+constexpr int S3_WAVES = S3_THREADS / 64;
+constexpr int S3_IPT = DS_ITEMS / S3_THREADS;          // 8 keys per thread
+constexpr int S3_DPT = DS_NB / S3_THREADS;             // 4 buckets per thread
+static_assert(S3_IPT == 8 && S3_DPT == 4, "layout");
+
+// exclusive scan over the workgroup of the per-thread totals of DPT values (thread t owns entries t*DPT .. t*DPT+DPT-1)
+template <int DPT, int NW>
+__device__ __forceinline__ uint32_t ds_block_excl_scan(const uint32_t (&v)[DPT], uint32_t* wsum, int lane, int w) {
+    uint32_t tsum = 0;
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) tsum += v[i];
+    const uint32_t incl = wave_incl_scan_u32(tsum, lane);
+    __syncthreads();
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k)
+        if (k < w) wbase += wsum[k];
+    return wbase + incl - tsum;
+}
+
 // plan entry of segment s (8 words): begin, end (elements of the bucket-ordered array), first bucket, end bucket, tile
 // instances in front of the segment, number of listed Gaussians, 0, 0
-__global__ void __launch_bounds__(DS_THREADS)
+__global__ void __launch_bounds__(S3_THREADS)
 ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ frame,
            const uint32_t* __restrict__ cnt_tab, const uint32_t* __restrict__ cnt_total, const uint32_t* __restrict__ tile_total,
            uint2* __restrict__ pairs, uint32_t* __restrict__ order, uint32_t* __restrict__ offsets, uint2* __restrict__ rect_sorted,
            uint32_t* __restrict__ plan, int nseg_cap) {
-    __shared__ uint32_t wave_cnt[WG_WAVES][DS_NB];      // 32 KB
-    __shared__ uint32_t digit_base[DS_NB];              //  8 KB
-    __shared__ uint32_t wsum[WG_WAVES];
+    __shared__ __attribute__((aligned(16))) uint16_t wave_cnt[S3_WAVES][DS_NB];      // 32 KB (a wave counts <= 512 keys)
+    __shared__ __attribute__((aligned(16))) uint32_t digit_base[DS_NB];              //  8 KB
+    __shared__ uint32_t wsum[S3_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 
     if ((int)blockIdx.x == nblocks) {
         // ---- the segment plan (one workgroup, beside the scattering ones) ----
-        uint32_t* cnt_excl = wave_cnt[0];      // [2048]; entry 2047 = number of listed Gaussians
-        uint32_t* tile_excl = wave_cnt[1];
-        uint32_t c[DS_DPT], t[DS_DPT];
+        uint32_t* cnt_excl = reinterpret_cast<uint32_t*>(&wave_cnt[0][0]);      // [2048]; entry 2047 = number of listed Gaussians
+        uint32_t* tile_excl = cnt_excl + DS_NB;
+        uint32_t c[S3_DPT], t[S3_DPT];
         {
-            const uint4 a0 = reinterpret_cast<const uint4*>(cnt_total)[2 * tid], a1 = reinterpret_cast<const uint4*>(cnt_total)[2 * tid + 1];
-            const uint4 b0 = reinterpret_cast<const uint4*>(tile_total)[2 * tid], b1 = reinterpret_cast<const uint4*>(tile_total)[2 * tid + 1];
-            c[0] = a0.x; c[1] = a0.y; c[2] = a0.z; c[3] = a0.w; c[4] = a1.x; c[5] = a1.y; c[6] = a1.z; c[7] = a1.w;
-            t[0] = b0.x; t[1] = b0.y; t[2] = b0.z; t[3] = b0.w; t[4] = b1.x; t[5] = b1.y; t[6] = b1.z; t[7] = b1.w;
+            const uint4 a = reinterpret_cast<const uint4*>(cnt_total)[tid], b = reinterpret_cast<const uint4*>(tile_total)[tid];
+            c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w;
+            t[0] = b.x; t[1] = b.y; t[2] = b.z; t[3] = b.w;
         }
-        uint32_t crun = block_excl_scan<DS_DPT>(c, wsum, lane, w);
-        uint32_t trun = block_excl_scan<DS_DPT>(t, wsum, lane, w);
+        uint32_t crun = ds_block_excl_scan<S3_DPT, S3_WAVES>(c, wsum, lane, w);
+        uint32_t trun = ds_block_excl_scan<S3_DPT, S3_WAVES>(t, wsum, lane, w);
         {
-            uint32_t ce[DS_DPT], te[DS_DPT];
+            uint32_t ce[S3_DPT], te[S3_DPT];
 #pragma unroll
-            for (int i = 0; i < DS_DPT; ++i) {
+            for (int i = 0; i < S3_DPT; ++i) {
                 ce[i] = crun; te[i] = trun;
                 crun += c[i];
                 trun += t[i];
             }
-            reinterpret_cast<uint4*>(cnt_excl)[2 * tid] = make_uint4(ce[0], ce[1], ce[2], ce[3]);
-            reinterpret_cast<uint4*>(cnt_excl)[2 * tid + 1] = make_uint4(ce[4], ce[5], ce[6], ce[7]);
-            reinterpret_cast<uint4*>(tile_excl)[2 * tid] = make_uint4(te[0], te[1], te[2], te[3]);
-            reinterpret_cast<uint4*>(tile_excl)[2 * tid + 1] = make_uint4(te[4], te[5], te[6], te[7]);
+            reinterpret_cast<uint4*>(cnt_excl)[tid] = make_uint4(ce[0], ce[1], ce[2], ce[3]);
+            reinterpret_cast<uint4*>(tile_excl)[tid] = make_uint4(te[0], te[1], te[2], te[3]);
         }
         __syncthreads();
         const uint32_t listed = cnt_excl[DS_CULL];
@@ -247,7 +270,7 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t
             }
             return lo;
         };
-        for (int s = tid; s < nseg_cap; s += DS_THREADS) {
+        for (int s = tid; s < nseg_cap; s += S3_THREADS) {
             uint4 e = make_uint4(0u, 0u, 0u, 0u);
             uint32_t tb = 0;
             const uint64_t x0 = (uint64_t)s * DS_SEG;
@@ -267,74 +290,69 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t
     const uint32_t kmin = frame[2], kmax = frame[3], R32 = frame[0];
     const int shift = ds_shift(kmin, kmax);
     // the workgroup's keys are requested first: their trip overlaps the bucket-base prologue below.  Wave w owns the
-    // contiguous run [w * 1024, w * 1024 + 1024) of the workgroup's keys, item r of a lane is key r * 64 + lane of the run
-    const int64_t wave_base = (int64_t)blockIdx.x * DS_ITEMS + (int64_t)w * (64 * DS_IPT);
-    uint32_t key[DS_IPT];
+    // contiguous run [w * 512, w * 512 + 512) of the workgroup's keys, item r of a lane is key r * 64 + lane of the run
+    const int64_t wave_base = (int64_t)blockIdx.x * DS_ITEMS + (int64_t)w * (64 * S3_IPT);
+    uint32_t key[S3_IPT];
 #pragma unroll
-    for (int r = 0; r < DS_IPT; ++r) {
+    for (int r = 0; r < S3_IPT; ++r) {
         const int64_t idx = wave_base + r * 64 + lane;
         key[r] = keys[idx < P ? idx : (int64_t)P - 1];
     }
     {   // digit_base[d] = (exclusive scan of the bucket totals)[d] + keys of bucket d in earlier workgroups
-        uint32_t v[DS_DPT], bh[DS_DPT];
-        const uint4* tot4 = reinterpret_cast<const uint4*>(cnt_total);
-        const uint4* row4 = reinterpret_cast<const uint4*>(cnt_tab + (int64_t)blockIdx.x * DS_NB);
-        const uint4 a0 = tot4[2 * tid], a1 = tot4[2 * tid + 1], b0 = row4[2 * tid], b1 = row4[2 * tid + 1];
-        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-        bh[0] = b0.x; bh[1] = b0.y; bh[2] = b0.z; bh[3] = b0.w; bh[4] = b1.x; bh[5] = b1.y; bh[6] = b1.z; bh[7] = b1.w;
-        uint32_t run = block_excl_scan<DS_DPT>(v, wsum, lane, w);
-        // LDS accesses of this kernel never use the "thread t owns buckets 8t .. 8t+7" pattern with 32-bit accesses: a lane
-        // stride of 8 words puts 16 lanes on every bank.  The thread's eight bases go out as two 16-byte writes, the count
-        // tables are cleared and scanned with bucket = round * 256 + thread.
-        uint32_t db[DS_DPT];
+        uint32_t v[S3_DPT];
+        const uint4 a = reinterpret_cast<const uint4*>(cnt_total)[tid];
+        const uint4 bh = reinterpret_cast<const uint4*>(cnt_tab + (int64_t)blockIdx.x * DS_NB)[tid];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        uint32_t run = ds_block_excl_scan<S3_DPT, S3_WAVES>(v, wsum, lane, w);
+        // LDS accesses of this kernel never use the "thread t owns buckets 4t .. 4t+3" pattern with 32-bit accesses (a lane stride
+        // of several words piles the lanes onto a few banks): the thread's four bases go out as one 16-byte write, the count tables
+        // are cleared with 16-byte writes and scanned with bucket = round * 512 + thread.
+        uint4 db;
+        db.x = run + bh.x; run += v[0];
+        db.y = run + bh.y; run += v[1];
+        db.z = run + bh.z; run += v[2];
+        db.w = run + bh.w;
+        reinterpret_cast<uint4*>(digit_base)[tid] = db;
+        uint4* wc4 = reinterpret_cast<uint4*>(&wave_cnt[0][0]);      // 32 KB = 2048 x 16 bytes
 #pragma unroll
-        for (int i = 0; i < DS_DPT; ++i) {
-            db[i] = run + bh[i];
-            run += v[i];
-        }
-        reinterpret_cast<uint4*>(digit_base)[2 * tid] = make_uint4(db[0], db[1], db[2], db[3]);
-        reinterpret_cast<uint4*>(digit_base)[2 * tid + 1] = make_uint4(db[4], db[5], db[6], db[7]);
-#pragma unroll
-        for (int i = 0; i < DS_DPT; ++i)
-#pragma unroll
-            for (int k = 0; k < WG_WAVES; ++k) wave_cnt[k][i * DS_THREADS + tid] = 0u;
+        for (int i = 0; i < 4; ++i) wc4[i * S3_THREADS + tid] = make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    uint32_t rank[DS_IPT], dig[DS_IPT];
+    uint32_t rank[S3_IPT], dig[S3_IPT];
 #pragma unroll
-    for (int r = 0; r < DS_IPT; ++r) {
+    for (int r = 0; r < S3_IPT; ++r) {
         const int64_t idx = wave_base + r * 64 + lane;
         const bool valid = idx < P;
         const uint32_t d = ds_bucket(key[r], kmin, shift);
         dig[r] = d;
         const uint64_t mask = match_digit(d, GSR_DS_BITS, __ballot(valid));
-        const uint32_t prior = valid ? wave_cnt[w][d] : 0u;
+        const uint32_t prior = valid ? (uint32_t)wave_cnt[w][d] : 0u;
         rank[r] = prior + (uint32_t)__popcll(mask & lt_mask);
-        if (valid && (mask & lt_mask) == 0ull) wave_cnt[w][d] = prior + (uint32_t)__popcll(mask);
+        if (valid && (mask & lt_mask) == 0ull) wave_cnt[w][d] = (uint16_t)(prior + (uint32_t)__popcll(mask));
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     // keys of a bucket are few per workgroup (4096 keys over ~1000+ buckets): no LDS staging, every pair goes straight to
     // its slot; per bucket the waves' counts become exclusive offsets
 #pragma unroll
-    for (int i = 0; i < DS_DPT; ++i) {
-        const int d = i * DS_THREADS + tid;
+    for (int i = 0; i < S3_DPT; ++i) {
+        const int d = i * S3_THREADS + tid;
         uint32_t run = 0;
 #pragma unroll
-        for (int k = 0; k < WG_WAVES; ++k) {
+        for (int k = 0; k < S3_WAVES; ++k) {
             const uint32_t t = wave_cnt[k][d];
-            wave_cnt[k][d] = run;
+            wave_cnt[k][d] = (uint16_t)run;
             run += t;
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < DS_IPT; ++r) {
+    for (int r = 0; r < S3_IPT; ++r) {
         const int64_t idx = wave_base + r * 64 + lane;
         if (idx < P) {
             const uint32_t d = dig[r];
-            const uint32_t pos = digit_base[d] + wave_cnt[w][d] + rank[r];
+            const uint32_t pos = digit_base[d] + (uint32_t)wave_cnt[w][d] + rank[r];
             if (d != DS_CULL) {
                 pairs[pos] = make_uint2(key[r], (uint32_t)idx);
             } else {      // no tile: behind every listed Gaussian, in index order; the inclusive scan stays at R
@@ -607,7 +625,7 @@ void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* t
     const int nseg_cap = (int)gsr_depth_bucket_segments(P);
     hipLaunchKernelGGL(ds_hist, dim3(nblocks), dim3(DS_THREADS), 0, st, P, keys, tiles, frame, wg_range, n_range, b.cnt_tab, b.tile_tab);
     hipLaunchKernelGGL(ds_scan, dim3(DS_NB / 16), dim3(DS_THREADS), 0, st, nblocks, b.cnt_tab, b.tile_tab, b.cnt_total, b.tile_total);
-    hipLaunchKernelGGL(ds_scatter, dim3(nblocks + 1), dim3(DS_THREADS), 0, st, P, nblocks, keys, frame, b.cnt_tab, b.cnt_total,
+    hipLaunchKernelGGL(ds_scatter, dim3(nblocks + 1), dim3(S3_THREADS), 0, st, P, nblocks, keys, frame, b.cnt_tab, b.cnt_total,
                        b.tile_total, b.pairs[0], order, offsets, rect_sorted, b.plan, nseg_cap);
     hipLaunchKernelGGL(ds_segsort, dim3(nseg_cap), dim3(SG_THREADS), 0, st, b.plan, frame, b.pairs[0], b.pairs[1], rect, order,
                        rect_sorted, offsets, block_first, block_first_cap, slow_word);
