@@ -11,6 +11,7 @@ finishes in a second or two).  What each case is there for:
                     (gsr_launch_fill_block_first) instead of coming from the scan kernel
   sort_1024_tier    P just below 512 K  -> 1024-key radix workgroups for the depth sort
   sort_2048_tier    P just above 512 K  -> 2048-key workgroups (ragged last workgroup)
+  bucket_tables_beyond_1M   P = 1.3 M: more than 256 workgroups in the bucket depth sort's tables (ds_scan's re-reading sweep)
   odd_frame         width / height not multiples of 16, partial edge tiles, a one-tile-high last row
   tiles_65536       exactly 65536 tiles: the largest frame of the fused two-level tile sort (one more tile takes the
                     32-bit-key LSD path, covered by test_gpu_parity.py)
@@ -32,6 +33,8 @@ CASES = {
     "huge_splats": (1_500, 800, 608, 0.6, 3),
     "sort_1024_tier": (524_288 - 3, 320, 240, 0.004, 4),
     "sort_2048_tier": (524_288 + 1061, 320, 240, 0.004, 5),
+    # more than 1 M Gaussians: ds_scan walks more than 16 table rows per thread (its second sweep re-reads instead of keeping them)
+    "bucket_tables_beyond_1M": (1_300_000, 320, 240, 0.003, 15),
     "odd_frame": (50_000, 1001, 337, 0.02, 6),
     "tiles_65536": (6_000, 4096, 4096, 0.03, 7),
     # thousands of tiles per Gaussian on a 65536-tile frame (256 x 256 buckets, Gaussians that own dozens of emission blocks)
@@ -81,6 +84,8 @@ def test_bins_bit_exact_in_every_structural_regime(name, depth_sort_mode, tiles_
     import contextlib
     if tiles_mode == "reference" and depth_sort_mode == 1 and name not in ("single_block", "odd_frame", "depth_ties"):
         pytest.skip("reference rectangles x LSD sort: three representative cases are enough")
+    if name == "bucket_tables_beyond_1M" and (tiles_mode == "reference" or depth_sort_mode == 1):
+        pytest.skip("a case for the bucket sort's tables only")
     P, W, H, s_med, seed = CASES[name]
     dev = torch.device("cuda:0")
     cam = make_camera(W, H)
