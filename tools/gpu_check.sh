@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_next_rows.py -q -m gpu --tb=short -x 2>&1 | tail -60 > gpurun_out/c_next.log
 timeout 1200 python -m pytest tests/test_gpu_parity.py -q -m gpu --tb=short 2>&1 | tail -40 > gpurun_out/c_pytest.log
-timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/c_bench.log 2>&1
+timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-full-loop > gpurun_out/c_bench.log 2>&1
 timeout 300 python tools/gpu_knn_time.py > gpurun_out/c_knn.log 2>&1
 echo "== next rows"; tail -30 gpurun_out/c_next.log
 echo "== parity"; tail -15 gpurun_out/c_pytest.log
