@@ -90,7 +90,9 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short forward measurements of configs[3] (1 M @4K) and configs[4] (6 M @1080p)")
     ap.add_argument("--views", type=int, default=32, help="training views cycled by the train legs (1 = the static camera of round 1)")
     ap.add_argument("--densify-iters", type=int, default=600, help="iterations of the train leg with density control every 100 (0 disables it)")
-    ap.add_argument("--mode", default="C", choices=["B", "C"], help="N > 1: C = Gaussian-sharded with the targeted all-to-all (default), B = replicated parameters + bands")
+    ap.add_argument("--mode", default="C", choices=["A", "B", "C"], help="N > 1: C = Gaussian-sharded with the targeted all-to-all (default); A = north_star's wording: "
+                    "Gaussians sharded, all-gather of the projected records, strips all-gathered, reduce-scatter of the per-Gaussian gradients; "
+                    "B = replicated parameters + bands in the forward (train legs as A)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="worker processes of the CPU baseline's blend (0 = all host cores)")
     return ap.parse_args()
 
@@ -228,7 +230,9 @@ def _run(a):
         if mode == "C" and not collectives["all_to_all_single"]:
             mode = "B"
     lo, hi = (P * rank) // world, (P * (rank + 1)) // world
-    shard = None if mode != "C" else tuple(t[lo:hi].contiguous() for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations))
+    shard = None if mode not in ("A", "C") else tuple(t[lo:hi].contiguous() for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations))
+    from diff_gaussian_rasterization.parallel import render_two_axis as _two_axis, padded_shard_size as _pad_size
+    P_pad_fwd = _pad_size(hi - lo) if (world > 1 and mode == "A") else None
 
     # N > 1: frames are pipelined two deep.  Mode C: frame i+1 is projected, routed and its all-to-all launched BEFORE frame i
     # is binned and blended, and the strip all-gather of frame i (RCCL stream) overlaps frame i+1 -- both collectives run
@@ -245,6 +249,8 @@ def _run(a):
                     if len(in_flight) > 1:
                         return in_flight.pop(0).wait()
                 return None
+            if mode == "A":      # record all-gather -> every rank bins its band -> strip all-gather (one frame at a time)
+                return _two_axis(rs, *shard, plan, P_pad_fwd)[0]
             color, radii, invd = rasterize_gaussians(sc.means3D, None, sc.shs, None, sc.opacities, sc.scales,
                                                      sc.rotations, None, rs, band)
             if world > 1:
@@ -689,7 +695,8 @@ def _run(a):
             oplan = BandPlan.uniform(ogy, world) if (a.uniform_bands or world == 1) else BandPlan.balanced(orow, world)
             oband = None if world == 1 else oplan.band(rank)
             olo, ohi = (oP * rank) // world, (oP * (rank + 1)) // world
-            oshard = None if mode != "C" else tuple(t[olo:ohi].contiguous() for t in (osc.means3D, osc.shs, osc.opacities, osc.scales, osc.rotations))
+            oshard = None if mode not in ("A", "C") else tuple(t[olo:ohi].contiguous() for t in (osc.means3D, osc.shs, osc.opacities, osc.scales, osc.rotations))
+            oP_pad = _pad_size(ohi - olo) if (world > 1 and mode == "A") else None
 
             def ostep():
                 with torch.no_grad():
@@ -699,6 +706,9 @@ def _run(a):
                             in_flight.append(sharded_forward_finish(pending.pop(0)))
                             if len(in_flight) > 1:
                                 in_flight.pop(0).wait()
+                        return
+                    if mode == "A":
+                        _two_axis(ors, *oshard, oplan, oP_pad)
                         return
                     color, _, _ = rasterize_gaussians(osc.means3D, None, osc.shs, None, osc.opacities, osc.scales, osc.rotations,
                                                       None, ors, oband)
@@ -918,6 +928,8 @@ def _run(a):
                        "parallelism": ("one GPU" if world == 1 else
                                        ("mode C x%d: Gaussians sharded (P/N per rank) + tile-row bands%s; 48-byte packed splat records sent only to "
                                         "the bands they touch (all_to_all_single), strips all-gathered; frames pipelined two deep" if mode == "C" else
+                                        "mode A x%d: Gaussians sharded (P/N per rank) + tile-row bands%s; all-gather of the projected 64-byte records, strips "
+                                        "all-gathered, reduce-scatter of the 48-byte gradient rows (north_star's partitioning verbatim)" if mode == "A" else
                                         "mode B x%d: replicated parameters, tile-row bands%s, strip all-gather of frame i overlapped with frame i+1")
                                        % (world, " (uniform)" if a.uniform_bands else " (instance-balanced)")),
                        "mode": mode, "collectives": collectives,

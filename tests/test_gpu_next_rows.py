@@ -237,7 +237,7 @@ def test_distcuda2_large_cloud_and_init_scales():
         distCUDA2(torch.zeros(10, 3))
 
 
-@pytest.mark.parametrize("mode,nproc", [("C", 2), ("C", 3), ("B", 2)])
+@pytest.mark.parametrize("mode,nproc", [("C", 2), ("C", 3), ("B", 2), ("A", 2)])
 def test_bench_multi_rank_path_on_one_gpu(mode, nproc):
     """bench.py's N > 1 code path end to end -- first-contact probe of the collectives, band plan, mode C (Gaussian shards,
     route kernels, variable-size all-to-all of packed records forward and of gradient rows backward, pipelined frames) or
@@ -264,7 +264,7 @@ def test_bench_multi_rank_path_on_one_gpu(mode, nproc):
     d = json.loads(lines[0])
     assert "error" not in d, d
     assert d["n_gpus"] == nproc and d["value"] > 0 and d["train_iters_per_s"] > 0 and d["scaling"] == "strong"
-    assert d["config"]["mode"] == mode and d["config"]["collectives"]["all_to_all_single"]
+    assert d["config"]["mode"] == mode and d["config"]["collectives"]["all_to_all_single"]      # (A / B / C as asked: the probe found every collective)
     # (the fraction itself can round to 0.0 here: three processes time-slice one GPU and the stage times are mostly waiting)
     assert d["roofline"]["frac"] >= 0 and d["blend_work"]["fwd_pair_steps_per_launch"] > 0 and d["cpu_baseline"] is None
 
