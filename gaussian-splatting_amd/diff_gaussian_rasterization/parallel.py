@@ -145,12 +145,13 @@ def gather_strips_async(local: torch.Tensor, plan: BandPlan, H: int, group=None,
     if exact is None:
         exact = _exact_strips_default if _exact_strips_default is not None else dist.get_backend(group) == "nccl"
     if exact and len(set(heights)) > 1 and min(heights) > 0:
-        try:
-            bufs = [local.new_empty(C, h, W) for h in heights]
-            work = dist.all_gather(bufs, local[:, a:b].contiguous(), group=group, async_op=True)
-            return _StripGatherList(bufs, rows, work)
-        except Exception:      # backend without unequal all_gather: padded form below
-            pass
+        # No per-rank fallback here: a rank that fell back to the padded collective while its peers issued the
+        # exact one would hang the job, and an asynchronous RCCL failure is not raised at the call site anyway.  Which form is
+        # used is decided ONCE and collectively -- probe_collectives() tries the unequal all_gather on every rank and
+        # all-reduces the outcome, the caller then calls set_exact_strips() -- and an error in the chosen form propagates.
+        bufs = [local.new_empty(C, h, W) for h in heights]
+        work = dist.all_gather(bufs, local[:, a:b].contiguous(), group=group, async_op=True)
+        return _StripGatherList(bufs, rows, work)
     hmax = max(1, max(heights))
     send = local.new_empty(C, hmax, W)          # padding rows are never read back
     send[:, : b - a] = local[:, a:b]
@@ -755,4 +756,17 @@ def probe_collectives(group=None, device=None) -> dict:
     attempt("all_to_all_single", _a2a)
     attempt("all_gather_uneven", _uneven)
     attempt("reduce_scatter", _reduce_scatter)
+    # every rank must come to the SAME verdict (a collective that failed on one rank only is unusable for all): the outcomes
+    # are min-reduced, so that mode and strip-gather form are chosen identically everywhere
+    names = ("all_gather", "all_to_all_single", "all_gather_uneven", "reduce_scatter")
+    if out["all_reduce"]:
+        try:
+            v = torch.tensor([1.0 if out[n] else 0.0 for n in names], device=device)
+            dist.all_reduce(v, op=dist.ReduceOp.MIN, group=group)
+            for n, ok in zip(names, v.tolist()):
+                if out[n] and ok == 0.0:
+                    out["errors"][n] = "failed on another rank"
+                out[n] = bool(ok)
+        except Exception as ex:          # noqa: BLE001
+            out["errors"]["agreement"] = repr(ex)[:300]
     return out

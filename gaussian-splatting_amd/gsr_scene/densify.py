@@ -43,16 +43,22 @@ class DensifyStats:
         accumulate the norm of the screen-space position gradient (the operator's dL/dmeans2D, x and y) of the visible
         Gaussians."""
         g = viewspace_grad
+        P = int(g.shape[0]) if g.dim() == 2 else -1
+        acc = (self.xyz_gradient_accum, self.denom, self.max_radii2D)
+        # the HIP pass reads P mask bytes and P rows of every array: a MASK of exactly P elements (bool / uint8) on the gradient's
+        # device, accumulators of P rows -- an index tensor, a shorter mask or a tensor on another device takes the torch expression
         if (g.is_cuda and g.dtype == torch.float32 and g.dim() == 2 and g.shape[1] == 3 and g.is_contiguous()
-                and (radii is None or (radii.dtype == torch.int32 and radii.is_contiguous()))
-                and self.xyz_gradient_accum.is_contiguous() and self.denom.is_contiguous() and self.max_radii2D.is_contiguous()):
+                and visible.dtype in (torch.bool, torch.uint8) and visible.numel() == P and visible.device == g.device
+                and (radii is None or (radii.dtype == torch.int32 and radii.is_contiguous() and radii.numel() == P and radii.device == g.device))
+                and all(t.is_contiguous() and t.dtype == torch.float32 and t.device == g.device and t.shape[0] == P for t in acc)
+                and self.xyz_gradient_accum.numel() == P and self.denom.numel() == P and self.max_radii2D.numel() == P):
             # one HIP pass (gsr_density_stats): the boolean-mask form below is ~25 kernels and three host synchronisations per
             # training iteration (0.9 ms at 1 M Gaussians)
             import ctypes as C
             from diff_gaussian_rasterization import _lib
             lib = _lib.load()
             vis = visible.contiguous()
-            vis = vis.view(torch.uint8) if vis.dtype == torch.bool else (vis if vis.dtype == torch.uint8 else vis.to(torch.uint8))
+            vis = vis.view(torch.uint8) if vis.dtype == torch.bool else vis
             p = lambda t: None if t is None else C.c_void_p(t.data_ptr())      # noqa: E731
             with torch.cuda.device(g.device):
                 _lib.check(lib.gsr_density_stats(int(g.shape[0]), p(g), p(vis), p(radii), p(self.xyz_gradient_accum), p(self.denom),
