@@ -16,6 +16,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+# where the summaries go: profiles/ (run locally on merged-back raw files) or, on the GPU box, a directory under gpurun_out/ -- the raw
+# counter files of five rocprofv3 passes exceed what gpurun merges back (64 MiB), so tools/gpu_profile.sh summarises there and deletes them
+OUT = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
+os.makedirs(OUT, exist_ok=True)
 
 
 def short(n):
@@ -23,19 +27,21 @@ def short(n):
     return re.sub(r"\(.*", "", n)
 
 
-line = [ln for ln in open(os.path.join(G, "p_bench_default.log")) if ln.startswith("{")][-1]
-json.loads(line)
-open(os.path.join(ROOT, "profiles", f"{tag}_bench_default.json"), "w").write(line)
+line = None
+if os.path.exists(os.path.join(G, "p_bench_default.log")):      # (tools/gpu_profile.sh takes the bench line AFTER the counter passes)
+    line = [ln for ln in open(os.path.join(G, "p_bench_default.log")) if ln.startswith("{")][-1]
+    json.loads(line)
+    open(os.path.join(OUT, f"{tag}_bench_default.json"), "w").write(line)
 
 steady = os.path.join(G, "kernel_stats_steady.csv")
 if os.path.exists(steady):
     # tools/kernel_trace_stats.py: warm-up dispatches dropped, median / p10 / p90 beside the mean
     rows = list(csv.DictReader(open(steady)))
-    open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"), "w").write(open(steady).read())
+    open(os.path.join(OUT, f"{tag}_kernel_stats.csv"), "w").write(open(steady).read())
 else:
     stats = glob.glob(os.path.join(G, "prof_stats", "**", "*kernel_stats.csv"), recursive=True)[0]
     rows = list(csv.DictReader(open(stats)))
-    with open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"), "w") as f:
+    with open(os.path.join(OUT, f"{tag}_kernel_stats.csv"), "w") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in rows:
@@ -62,7 +68,7 @@ SQ_NAMES = ['SQ_WAVES', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_IN
             'SQ_BUSY_CYCLES', 'SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_SCA', 'SQ_ACTIVE_INST_LDS', 'SQ_WAIT_ANY',
             'SQ_WAIT_INST_ANY', 'SQ_LDS_BANK_CONFLICT']
 if sq:
-    with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_sq_per_kernel.csv"), "w") as f:
+    with open(os.path.join(OUT, f"{tag}_pmc_sq_per_kernel.csv"), "w") as f:
         f.write("kernel," + ",".join(SQ_NAMES) + "\n")
         key = lambda k: -sq[k].get('SQ_WAVE_CYCLES', [1, 0])[1] / max(1, sq[k].get('SQ_WAVE_CYCLES', [1, 0])[0])
         for k in sorted(sq, key=key):
@@ -87,12 +93,12 @@ out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separa
                  "(FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950; gather-heavy kernels are over-corrected by up "
                  "to 2x on the read side)",
        "kernels": kern}
-json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
-with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_per_kernel.csv"), "w") as f:
+json.dump(out, open(os.path.join(OUT, "pmc_latest.json"), "w"), indent=1)
+with open(os.path.join(OUT, f"{tag}_pmc_per_kernel.csv"), "w") as f:
     f.write("kernel,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch,hbm_bytes_per_launch_corrected\n")
     for k in sorted(kern, key=lambda k: -kern[k]["hbm_bytes_corrected"]):
         f.write(f"\"{k}\",{kern[k]['FETCH_SIZE_KB_per_launch']},{kern[k]['WRITE_SIZE_KB_per_launch']},{kern[k]['hbm_bytes_corrected']}\n")
-print("bench:", json.loads(line)["value"], "Mpix/s;", len(rows), "kernels in stats;", len(kern), "kernels with PMC")
+print("bench:", json.loads(line)["value"] if line else None, "Mpix/s;", len(rows), "kernels in stats;", len(kern), "kernels with PMC")
 for k in ("render_fwd_wave_bf<true, 1, false>", "render_fwd_wave_bf<true, 1, true>", "render_bwd_half", "preprocess_fwd_kernel<false>", "adam_kernel"):
     if k in kern:
         print(" ", k, kern[k]["hbm_bytes_corrected"] / 1e6, "MB/launch")

@@ -1,18 +1,18 @@
 #!/bin/bash
-# round-end measurement bundle: profiles (default bench line incl. the configs[2] full-loop leg, kernel trace, PMC passes), the two extra
-# configs[2] runs (growth, opt-in fused SH step), the per-rank shard model, the GPU test suite
+# round-end measurement bundle: profiles + default bench line (incl. the configs[2] full-loop leg), the two extra configs[2] runs (growth,
+# opt-in fused SH step), the per-rank shard model, the GPU test suite (its parity numbers land in gpurun_out/parity_report.json)
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-bash tools/gpu_profile.sh > gpurun_out/bundle_profile.log 2>&1
-tail -3 gpurun_out/bundle_profile.log | cut -c1-400
-timeout 900 python tools/train_run.py > gpurun_out/bundle_train_ref.log 2>&1
-tail -1 gpurun_out/bundle_train_ref.log | cut -c1-600
+if [ -z "$SKIP_PROFILE" ]; then bash tools/gpu_profile.sh > gpurun_out/bundle_profile.log 2>&1; tail -6 gpurun_out/bundle_profile.log | cut -c1-400; fi
+if [ -z "$SKIP_TRAIN" ]; then
 timeout 1200 python tools/train_run.py --grad-threshold 0.00002 --tag _growth > gpurun_out/bundle_train_growth.log 2>&1
-tail -1 gpurun_out/bundle_train_growth.log | cut -c1-600
+tail -1 gpurun_out/bundle_train_growth.log | cut -c1-300
 timeout 900 python tools/train_run.py --fuse-sh-step --tag _fused_sh > gpurun_out/bundle_train_fused.log 2>&1
-tail -1 gpurun_out/bundle_train_fused.log | cut -c1-400
-timeout 900 python tools/gpu_shard_model.py > gpurun_out/bundle_shard_model.log 2>&1
-tail -c 600 gpurun_out/bundle_shard_model.log
-timeout 1500 python -m pytest tests -m gpu -q --durations=8 > gpurun_out/bundle_pytest.log 2>&1
-echo "pytest rc=$?"; tail -14 gpurun_out/bundle_pytest.log
+tail -1 gpurun_out/bundle_train_fused.log | cut -c1-300
+timeout 900 python tools/train_run.py > gpurun_out/bundle_train_ref.log 2>&1
+tail -1 gpurun_out/bundle_train_ref.log | cut -c1-300
+fi
+if [ -z "$SKIP_MODEL" ]; then timeout 900 python tools/gpu_shard_model.py > gpurun_out/bundle_shard_model.log 2>&1; tail -c 300 gpurun_out/bundle_shard_model.log; fi
+if [ -z "$SKIP_TESTS" ]; then timeout 1500 python -m pytest tests -m gpu -q --durations=8 > gpurun_out/bundle_pytest.log 2>&1; echo "pytest rc=$?"; tail -14 gpurun_out/bundle_pytest.log; fi
+du -sh gpurun_out
