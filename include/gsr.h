@@ -15,8 +15,10 @@
  *     (tensor.data_ptr()) to contiguous fp32 / int32 data unless stated otherwise.
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream).
  *     gsr_rasterize_forward learns num_rendered (it sizes the binning buffer) mid-pipeline like the reference, but
- *     without hipStreamSynchronize: the scan kernel stores the 64-bit count + a sequence number into a mapped, pinned
- *     host word and the calling thread polls it (200 us of spinning, then sched_yield() between polls).
+ *     without hipStreamSynchronize and -- since ABI 4 -- off the critical path: the count does not depend on the depth
+ *     order, so the per-Gaussian preprocess kernel sums it and its last workgroup stores the 64-bit count + a sequence
+ *     number into a mapped, pinned host word; the calling thread queues the depth sort, then polls the word (200 us of
+ *     spinning, then sched_yield() between polls).
  *   - return value: GSR_OK (0) or a negative GsrStatus; gsr_last_error() gives the message for the
  *     calling thread.  No exception crosses the ABI.
  *   - no device allocation inside: scratch memory is caller-owned and obtained through the three
@@ -392,12 +394,16 @@ int gsr_profile_read(float* ms_out, int32_t* count_out, int n);
 #define GSR_COUNTER_COUNT 6
 int gsr_profile_counters(uint64_t* out, int n, int reset);
 
-/* A/B switches for measurement (0 = the product default everywhere).  The product library accepts the tuning knobs
- * sort_small_block_threshold, sort_mid_block_threshold, sort_items_large and tile_sort_mode (0 fused two-level sort, 1 legacy LSD passes) and value 0
- * of everything else; the measurement build (GSR_AB=1 python build.py -> lib_ab/) also compiles:
- *   render_fwd_variant 1..3, render_bwd_variant 1 / 4 / 5, depth_sort_mode 1 (onesweep), color_overlap 1 / 2 (split
- *   preprocess, colour kernel beside the depth sort), first_hist_in_preprocess 1, sh_dma 1..3 (LDS-DMA staging of the SH
- *   block) -- every one of them measured and rejected, see DESIGN.md.  Unknown names / unavailable values return an error.
+/* Switches.  The product library accepts the tuning knobs sort_small_block_threshold, sort_mid_block_threshold,
+ * sort_items_large, tile_sort_mode (0 fused two-level sort, 1 legacy LSD passes) and
+ *   depth_sort_mode   0 = automatic: the bucket depth sort (4 launches, csrc/depthsort.hip) up to 3 M Gaussians, the LSD radix
+ *                     passes beyond and for 64 frames after a frame whose depths crowded one bucket; 1 = always LSD; 2 = always
+ *                     the bucket sort (all three give bit-identical bins)
+ *   level2_scan_mode  0 = automatic, 1 = the tile sort's level-2 scan as its own launch, 2 = folded into the scatter
+ * The measurement build (GSR_AB=1 python build.py -> lib_ab/, sources in csrc/ab/) also compiles render_fwd_variant 1..3 and
+ * render_bwd_variant 1 / 4 / 5 -- measured and rejected; the product accepts only 0.  (ABI 4 removed the options of experiments
+ * whose code left the sources: onesweep depth sort, color_overlap, first_hist_in_preprocess, sh_dma.)  Unknown names /
+ * unavailable values return an error.
  * Switches of the product library whose default is 1 (both settings give the same results; 0 is the form they replaced):
  *   snug_tiles       1 = a Gaussian is binned into the tiles its alpha >= 1/255 ellipse can reach, 0 = into the reference's square
  *                    of radius 3 sqrt(lambda_max) (same outputs, ~1.4x the instances)
