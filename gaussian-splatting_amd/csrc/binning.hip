@@ -12,7 +12,9 @@ constexpr int SC_IPT = GSR_SCAN_ITEMS / SC_THREADS;   // 4 consecutive items per
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) { return gsrw::wave_incl_scan_u32(v, lane); }
 
-__device__ __forceinline__ uint32_t rect_tiles(const uint4 r) { return gsr_foot_tiles(r); }      // rectangle area, or the mask's population
+__device__ __forceinline__ uint32_t rect_tiles(const uint2 r) {
+    return ((r.x >> 16) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.y & 0xFFFFu));      // <= 2^24 (make_cam limits the grid)
+}
 
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {      // total in every lane: DPP scan, then lane 63's value
     const uint64_t t = gsrw::wave_incl_scan_u64(v, 0);
@@ -27,8 +29,8 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {      // total in 
 // GATHER = false: rect_sorted was already filled by the last pass of the depth sort (sort.hip, os_pass<LAST>)
 template <bool GATHER>
 __global__ void __launch_bounds__(SC_THREADS)
-scan_block_sums(int P, const uint32_t* __restrict__ order, const uint4* __restrict__ rect,
-                uint4* __restrict__ rect_sorted, uint64_t* __restrict__ block_sums) {
+scan_block_sums(int P, const uint32_t* __restrict__ order, const uint2* __restrict__ rect,
+                uint2* __restrict__ rect_sorted, uint64_t* __restrict__ block_sums) {
     __shared__ uint64_t wsum[SC_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * GSR_SCAN_ITEMS + tid * SC_IPT;
@@ -36,7 +38,7 @@ scan_block_sums(int P, const uint32_t* __restrict__ order, const uint4* __restri
     // Loads are unconditional (index clamped to the last Gaussian) and all issued before the first use: with the load inside
     // "if (base + k < P)" the compiler emits load -> s_waitcnt vmcnt(0) per element, SC_IPT serial round trips in a kernel
     // that is nothing but one round trip.
-    uint4 r[SC_IPT];
+    uint2 r[SC_IPT];
     if (GATHER) {
         uint32_t id[SC_IPT];
 #pragma unroll
@@ -64,7 +66,7 @@ scan_block_sums(int P, const uint32_t* __restrict__ order, const uint4* __restri
 // Also fills the per-block table of the fused emission (tilesort.hip): block_first[k] = depth-order index of the
 // Gaussian that owns instance k * GSR_TS_ITEMS, and, one past the last block, the last Gaussian with tiles.
 __global__ void __launch_bounds__(SC_THREADS)
-scan_finish(int P, const uint4* __restrict__ rect_sorted, const uint64_t* __restrict__ block_sums,
+scan_finish(int P, const uint2* __restrict__ rect_sorted, const uint64_t* __restrict__ block_sums,
             uint32_t* __restrict__ offsets, uint2* __restrict__ block_first, uint32_t block_first_cap,
             uint32_t* __restrict__ num_rendered, uint32_t* host_word, uint32_t seq) {
     __shared__ uint64_t wsum[SC_THREADS / 64];
@@ -73,7 +75,7 @@ scan_finish(int P, const uint4* __restrict__ rect_sorted, const uint64_t* __rest
     const int64_t base = (int64_t)blockIdx.x * GSR_SCAN_ITEMS + tid * SC_IPT;
     // every load of the kernel is issued up front, unconditionally (clamped indices): the block sums of the workgroups
     // before this one (four per thread cover 1024 workgroups = 1 M Gaussians; beyond that a loop) and the thread's items
-    uint4 rr[SC_IPT + 1];
+    uint2 rr[SC_IPT + 1];
 #pragma unroll
     for (int k = 0; k <= SC_IPT; ++k) rr[k] = rect_sorted[min(base + k, (int64_t)P - 1)];
     uint64_t bs[4];
@@ -141,7 +143,7 @@ constexpr int EMIT_WAVES = 4;        // waves per 64-Gaussian group (1: 48 us, 4
 template <typename KeyT>
 __global__ void __launch_bounds__(EMIT_WAVES * 64)
 emit_instances(int P, int gx, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
-               const uint4* __restrict__ rect_sorted, KeyT* __restrict__ inst_keys, uint32_t* __restrict__ inst_vals,
+               const uint2* __restrict__ rect_sorted, KeyT* __restrict__ inst_keys, uint32_t* __restrict__ inst_vals,
                float4* __restrict__ splats) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t j0 = (int64_t)blockIdx.x * 64;
@@ -156,7 +158,7 @@ emit_instances(int P, int gx, const uint32_t* __restrict__ order, const uint32_t
     if (j < P) {
         id = order[j];
         incl = offsets[j] - base;
-        const uint4 r = rect_sorted[j];      // (frames that take this path carry no tile masks: gsr_api.cpp)
+        const uint2 r = rect_sorted[j];
         minx = r.x & 0xFFFFu;
         w = (r.x >> 16) - minx;
         miny = r.y & 0xFFFFu;
@@ -241,7 +243,7 @@ tile_ranges(int64_t R, const KeyT* __restrict__ keys, uint2* __restrict__ ranges
 // tile count, depth-sort key (culled / out-of-band Gaussians sort last) -- the same values preprocess_fwd_kernel writes
 // when it runs with the band itself.
 __global__ void __launch_bounds__(256)
-splat_ingest(int P, const float4* __restrict__ records, int y0, int y1, float4* __restrict__ splats, uint4* __restrict__ rect,
+splat_ingest(int P, const float4* __restrict__ records, int y0, int y1, float4* __restrict__ splats, uint2* __restrict__ rect,
              uint32_t* __restrict__ tiles, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GsrFrameStatsDev fs) {
     GsrFrameAcc acc;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
@@ -251,7 +253,7 @@ splat_ingest(int P, const float4* __restrict__ records, int y0, int y1, float4* 
         const int bminy = miny < y0 ? y0 : (miny > y1 ? y1 : miny);
         const int bmaxy = maxy < y0 ? y0 : (maxy > y1 ? y1 : maxy);
         const uint32_t t = full ? (uint32_t)((maxx - minx) * (bmaxy - bminy)) : 0u;
-        const uint4 rc = make_uint4((uint32_t)minx | ((uint32_t)maxx << 16), (uint32_t)bminy | ((uint32_t)bmaxy << 16), 0u, 0u);
+        const uint2 rc = make_uint2((uint32_t)minx | ((uint32_t)maxx << 16), (uint32_t)bminy | ((uint32_t)bmaxy << 16));
         splats[i * 4 + 0] = q0;
         splats[i * 4 + 1] = q1;
         splats[i * 4 + 2] = q2;
@@ -278,7 +280,7 @@ rekey_full(int P, const float4* __restrict__ splats, const uint32_t* __restrict_
 
 }  // namespace
 
-int gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4* splats, uint4* rect, uint32_t* tiles,
+int gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
                             uint32_t* keys, uint32_t* vals, const GsrFrameStatsDev& fs, hipStream_t st) {
     int64_t nb = ((int64_t)P + 255) / 256;
     if (nb > GSR_FRAME_MAX_GROUPS) nb = GSR_FRAME_MAX_GROUPS;      // (gsr_frame.h: tickets)
@@ -295,7 +297,7 @@ void gsr_launch_rekey_full(int P, const float4* splats, const uint32_t* tiles, u
     hipLaunchKernelGGL(rekey_full, dim3((int)nb), dim3(256), 0, st, P, splats, tiles, keys, vals);
 }
 
-void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint4* rect, uint4* rect_sorted, uint32_t* offsets,
+void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint2* rect, uint2* rect_sorted, uint32_t* offsets,
                            uint64_t* block_sums, uint2* block_first, uint32_t block_first_cap, uint32_t* num_rendered,
                            uint32_t* host_word, uint32_t seq, bool rect_already_sorted, hipStream_t st) {
     const int nb = (P + GSR_SCAN_ITEMS - 1) / GSR_SCAN_ITEMS;
@@ -307,7 +309,7 @@ void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint4* rect, uint
                        block_first_cap, num_rendered, host_word, seq);
 }
 
-void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint4* rect,
+void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect,
                      void* inst_keys, bool key16, uint32_t* inst_vals, float4* splats, hipStream_t st) {
     const int nb = (int)(((int64_t)P + 63) / 64);        // one workgroup per 64 Gaussians of the depth order
     if (key16)

@@ -229,7 +229,7 @@ __device__ __forceinline__ uint32_t ds_block_excl_scan(const uint32_t (&v)[DPT],
 __global__ void __launch_bounds__(S3_THREADS)
 ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ frame,
            const uint32_t* __restrict__ cnt_tab, const uint32_t* __restrict__ cnt_total, const uint32_t* __restrict__ tile_total,
-           uint2* __restrict__ pairs, uint32_t* __restrict__ order, uint32_t* __restrict__ offsets, uint4* __restrict__ rect_sorted,
+           uint2* __restrict__ pairs, uint32_t* __restrict__ order, uint32_t* __restrict__ offsets, uint2* __restrict__ rect_sorted,
            uint32_t* __restrict__ plan, int nseg_cap) {
     __shared__ __attribute__((aligned(16))) uint16_t wave_cnt[S3_WAVES][DS_NB];      // 32 KB (a wave counts <= 512 keys)
     __shared__ __attribute__((aligned(16))) uint32_t digit_base[DS_NB];              //  8 KB
@@ -358,7 +358,7 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t
             } else {      // no tile: behind every listed Gaussian, in index order; the inclusive scan stays at R
                 order[pos] = (uint32_t)idx;
                 offsets[pos] = R32;
-                rect_sorted[pos] = make_uint4(0u, 0u, 0u, 0u);
+                rect_sorted[pos] = make_uint2(0u, 0u);
             }
         }
     }
@@ -467,18 +467,20 @@ __device__ __forceinline__ int seg_sort(const Mem& m, uint32_t n, int nbits, Cnt
     return cur;
 }
 
-__device__ __forceinline__ uint32_t rect_area(const uint4 r) { return gsr_foot_tiles(r); }      // rectangle area, or the mask's population
+__device__ __forceinline__ uint32_t rect_area(const uint2 r) {
+    return ((r.x >> 16) - (r.x & 0xFFFFu)) * ((r.y >> 16) - (r.y & 0xFFFFu));
+}
 
 // Output of up to 4096 consecutive sorted elements [c0, c0 + m) of the segment: element p of the chunk belongs to thread
 // p % 512, round p / 512 (lane-contiguous stores).  id[j]: the Gaussian id of element j * 512 + tid.  Returns the number of
 // tile instances of the chunk (every thread).
 __device__ __forceinline__ uint32_t seg_output(const uint32_t (&id)[SG_OUT], uint32_t m, uint32_t gpos0 /*global position of the chunk*/,
-                                              uint32_t tile_base, const uint4* __restrict__ rect, uint32_t* __restrict__ order,
-                                              uint4* __restrict__ rect_sorted, uint32_t* __restrict__ offsets,
+                                              uint32_t tile_base, const uint2* __restrict__ rect, uint32_t* __restrict__ order,
+                                              uint2* __restrict__ rect_sorted, uint32_t* __restrict__ offsets,
                                               uint2* __restrict__ block_first, uint32_t bf_cap, uint32_t last_listed, bool r_ok,
                                               uint32_t (*s_wt)[SG_WAVES]) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    uint4 rc[SG_OUT];
+    uint2 rc[SG_OUT];
 #pragma unroll
     for (int j = 0; j < SG_OUT; ++j) rc[j] = rect[id[j]];      // (lanes past m carry id 0: a valid address)
     uint32_t t[SG_OUT], incl[SG_OUT];
@@ -527,7 +529,7 @@ __device__ __forceinline__ uint32_t seg_output(const uint32_t (&id)[SG_OUT], uin
 
 __global__ void __launch_bounds__(SG_THREADS)
 ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame, uint2* pairs0, uint2* pairs1,
-           const uint4* __restrict__ rect, uint32_t* __restrict__ order, uint4* __restrict__ rect_sorted, uint32_t* __restrict__ offsets,
+           const uint2* __restrict__ rect, uint32_t* __restrict__ order, uint2* __restrict__ rect_sorted, uint32_t* __restrict__ offsets,
            uint2* __restrict__ block_first, uint32_t bf_cap, uint32_t* slow_word /*mapped host word or NULL*/) {
     __shared__ uint32_t s_key[2][DS_CAP];                       // 32 KB (oversized segments: the 32-bit count table instead)
     __shared__ uint16_t s_idx[2][DS_CAP];                       // 16 KB
@@ -616,8 +618,8 @@ size_t gsr_depth_bucket_segments(int P) { return ((size_t)(P > 0 ? P : 1) + DS_S
 // keys[P] (27-bit depth keys, GSR_DEPTH_KEY_CULLED for Gaussians without a tile), tiles[P], rect[P], frame = the words the
 // key-producing kernel's last workgroup wrote (gsr_frame.h)  ->  order[P], rect_sorted[P], offsets[P] (inclusive scan of the
 // tile counts in depth order), block_first[bf_cap]
-void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, const uint4* rect, uint32_t* frame,
-                                  const uint2* wg_range, int n_range, const GsrDepthSortBufs& b, uint32_t* order, uint4* rect_sorted, uint32_t* offsets, uint2* block_first,
+void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, const uint2* rect, uint32_t* frame,
+                                  const uint2* wg_range, int n_range, const GsrDepthSortBufs& b, uint32_t* order, uint2* rect_sorted, uint32_t* offsets, uint2* block_first,
                                   uint32_t block_first_cap, uint32_t* slow_word, hipStream_t st) {
     const int nblocks = (int)gsr_depth_bucket_blocks(P);
     const int nseg_cap = (int)gsr_depth_bucket_segments(P);

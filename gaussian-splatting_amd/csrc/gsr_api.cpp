@@ -233,14 +233,14 @@ GsrGeom gsr_carve_geom(char* base, int P) {
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off = gsr_align128(off + bytes); return p; };
     const size_t n = (size_t)(P > 0 ? P : 1);
     g.splats = (float4*)take(n * 64);
-    g.rect = (uint4*)take(n * 16);
+    g.rect = (uint2*)take(n * 8);
     g.tiles = (uint32_t*)take(n * 4);
     g.clamped = (uint32_t*)take(n * 4);
     g.keys[0] = (uint32_t*)take(n * 4);
     g.keys[1] = (uint32_t*)take(n * 4);
     g.vals[0] = (uint32_t*)take(n * 4);
     g.vals[1] = (uint32_t*)take(n * 4);
-    g.rect_sorted = (uint4*)take(n * 16);
+    g.rect_sorted = (uint2*)take(n * 8);
     g.offsets = (uint32_t*)take(n * 4);
     g.block_sums = (uint64_t*)take(((n + GSR_SCAN_ITEMS - 1) / GSR_SCAN_ITEMS) * 8);
     g.block_first = (uint2*)take(gsr_block_first_cap(P) * 8);

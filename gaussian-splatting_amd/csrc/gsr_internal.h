@@ -12,7 +12,7 @@ struct GsrCamDev {
     int W, H, gx, gy;
     float focal_x, focal_y, limx, limy, scale_modifier;
     int sh_degree, M, antialiasing, tile_y0, tile_y1;
-    int snug;                // gsr_math.h GsrCam::snug (0 reference square, 1 snug rectangle, 2 snug rectangle + tile masks)
+    int snug;                // gsr_math.h GsrCam::snug
     const float* view;
     const float* proj;
     const float* campos;
@@ -54,13 +54,12 @@ size_t gsr_depth_bucket_segments(int P);
 
 struct GsrGeom {                 // P-sized
     float4* splats;              // [4P]  (x,y,conA,conB) (conC,opacity,r,g) (b,depth,tau,1/depth) (rect.x,rect.y,goffset,tiles as bits)
-    uint4* rect;                 // [P]   tile FOOTPRINT: x = minx | maxx<<16 ; y = miny | maxy<<16 (band-clamped); z, w = tile mask
-                                 //       (bit ry*8+rx; 0 / 0: the whole rectangle), gsr_math.h gsr_project
+    uint2* rect;                 // [P]   x = minx | maxx<<16 ; y = miny | maxy<<16 (band-clamped)
     uint32_t* tiles;             // [P]   tiles_touched
     uint32_t* clamped;           // [P]   colour clamp bits
     uint32_t* keys[2];           // [P]x2 depth-sort keys (ping-pong)
     uint32_t* vals[2];           // [P]x2 Gaussian ids   (ping-pong); vals[0] = depth order (4 passes: even)
-    uint4* rect_sorted;          // [P]   footprints in depth order
+    uint2* rect_sorted;          // [P]   tile rectangles in depth order (written by the scan)
     uint32_t* offsets;           // [P]   inclusive scan of tiles_touched in depth order
     uint64_t* block_sums;        // [ceil(P/GSR_SCAN_ITEMS)]
     uint2* block_first;          // [gsr_block_first_cap(P)] per 4096-instance block: (depth-order index of its first Gaussian, instances before it)
@@ -72,37 +71,6 @@ struct GsrGeom {                 // P-sized
     size_t bytes;
 };
 GsrGeom gsr_carve_geom(char* base, int P);
-
-// ---- tile footprint of a Gaussian (rectangle + optional 8 x 8 tile mask) ----
-#define GSR_MASKED_FLAG 0x80000000u      // bit 31 of the first-emission-index word of a splat record: the record carries a mask
-#ifdef __HIPCC__
-__device__ __forceinline__ uint32_t gsr_foot_tiles(const uint4 f) {
-    const uint32_t area = ((f.x >> 16) - (f.x & 0xFFFFu)) * ((f.y >> 16) - (f.y & 0xFFFFu));      // <= 2^24 (make_cam limits the grid)
-    return (f.z | f.w) ? (uint32_t)(__popc(f.z) + __popc(f.w)) : area;
-}
-// index (0..63) of the n-th set bit (n = 0: the lowest) of the 64-bit mask hi:lo; n < popcount
-__device__ __forceinline__ uint32_t gsr_mask_select(uint32_t lo, uint32_t hi, uint32_t n) {
-    const uint32_t cl = (uint32_t)__popc(lo);
-    const bool up = n >= cl;
-    const uint32_t word = up ? hi : lo;
-    n = up ? n - cl : n;
-    const uint32_t c0 = (uint32_t)__popc(word & 0xFFu), c1 = (uint32_t)__popc(word & 0xFFFFu), c2 = (uint32_t)__popc(word & 0xFFFFFFu);
-    const uint32_t bi = (n >= c0 ? 1u : 0u) + (n >= c1 ? 1u : 0u) + (n >= c2 ? 1u : 0u);
-    n -= bi == 0u ? 0u : (bi == 1u ? c0 : (bi == 2u ? c1 : c2));
-    uint32_t byte = (word >> (8u * bi)) & 0xFFu, pos = 0u;
-    uint32_t c = (uint32_t)__popc(byte & 0xFu);
-    if (n >= c) { n -= c; byte >>= 4; pos = 4u; }
-    c = (uint32_t)__popc(byte & 3u);
-    if (n >= c) { n -= c; byte >>= 2; pos += 2u; }
-    if (n >= (byte & 1u)) pos += 1u;
-    return (up ? 32u : 0u) + 8u * bi + pos;
-}
-// number of set bits of hi:lo below bit `bit`
-__device__ __forceinline__ uint32_t gsr_mask_rank(uint32_t lo, uint32_t hi, uint32_t bit) {
-    return bit < 32u ? (uint32_t)__popc(lo & ((1u << bit) - 1u))
-                     : (uint32_t)__popc(lo) + (uint32_t)__popc(hi & ((bit >= 64u ? 0u : (1u << (bit - 32u))) - 1u));
-}
-#endif
 
 // ---- depth-sort keys (round 3): 27 bits instead of 32 -> 3 radix passes of 9 bits instead of 4 of 8 ----
 // Every listed Gaussian passed the near cull view.z > 0.2 (Appendix A.2 step 1), and positive fp32 bit patterns order like the
@@ -192,15 +160,15 @@ void gsr_launch_mark_visible(int P, const float* means3D, const float* view, uin
 // sort.hip: LSD radix sort of (u32 key, u32 value) pairs on bits [0, nbits); returns the index (0/1) of the
 // ping-pong buffer that holds the result.  n is known on the host.  items = keys per workgroup: 1024, 2048 or 4096
 // (hist must hold 2^digit_bits * ceil(n / items) counters).
-// rect / rect_sorted (optional): the last pass also writes rect_sorted[pos] = rect[value] (depth sort: the tile footprints
+// rect / rect_sorted (optional): the last pass also writes rect_sorted[pos] = rect[value] (depth sort: the tile rectangles
 // in depth order, which the scan and the emission stream afterwards)
 int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
-                         uint32_t* digit_total, int items, hipStream_t st, const uint4* rect = nullptr, uint4* rect_sorted = nullptr);
+                         uint32_t* digit_total, int items, hipStream_t st, const uint2* rect = nullptr, uint2* rect_sorted = nullptr);
 int gsr_radix_sort_pairs_k16(uint16_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
                              uint32_t* digit_total, int items, hipStream_t st);
 // depthsort.hip: depth order + rectangles in depth order + inclusive scan of the tile counts + the emission's block table
-void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, const uint4* rect, uint32_t* frame,
-                                  const uint2* wg_range, int n_range, const GsrDepthSortBufs& b, uint32_t* order, uint4* rect_sorted, uint32_t* offsets, uint2* block_first,
+void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, const uint2* rect, uint32_t* frame,
+                                  const uint2* wg_range, int n_range, const GsrDepthSortBufs& b, uint32_t* order, uint2* rect_sorted, uint32_t* offsets, uint2* block_first,
                                   uint32_t block_first_cap, uint32_t* slow_word, hipStream_t st);
 // pass plan shared by the sorter and by code that must know which ping-pong buffer holds the result
 int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits /*[8]*/);
@@ -214,11 +182,11 @@ static inline int64_t gsr_sort_blocks(int64_t n, bool small_blocks) {
 
 // binning.hip: scan of tiles_touched in depth order, instance emission, tile ranges
 // host_word (mapped pinned, may be NULL): [0] = R low word, [2] = R high word, [1] = seq (stored last)
-void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint4* rect, uint4* rect_sorted /*[P]*/, uint32_t* offsets,
+void gsr_launch_scan_tiles(int P, const uint32_t* order, const uint2* rect, uint2* rect_sorted /*[P]*/, uint32_t* offsets,
                            uint64_t* block_sums, uint2* block_first, uint32_t block_first_cap, uint32_t* num_rendered,
                            uint32_t* host_word, uint32_t seq, bool rect_already_sorted, hipStream_t st);
 // legacy emission (frames with more than 65536 tiles): 32-bit tile ids
-void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint4* rect_sorted,
+void gsr_launch_emit(int P, int gx, const uint32_t* order, const uint32_t* offsets, const uint2* rect_sorted,
                      void* inst_keys, bool key16, uint32_t* inst_vals, float4* splats /*NULL: skip the goffset write*/,
                      hipStream_t st);
 
@@ -227,7 +195,7 @@ struct GsrTileSortPlan { bool fused; int lb, hb; bool word64; };
 void gsr_tile_sort_plan(int n_tiles, int P, GsrTileSortPlan* plan);
 void gsr_launch_fill_block_first(int P, const uint32_t* offsets, uint2* block_first, uint32_t cap, hipStream_t st);
 void gsr_launch_tile_sort_level1(const GsrTileSortPlan& plan, int64_t R, int gx, const uint2* block_first,
-                                 const uint32_t* offsets, const uint4* rect_sorted, const uint32_t* order, void* words,
+                                 const uint32_t* offsets, const uint2* rect_sorted, const uint32_t* order, void* words,
                                  uint32_t* hist1, uint32_t* digit_total, uint32_t* bucket_base, uint32_t* blk2_start,
                                  float4* splats /*NULL: inference*/, hipStream_t st);
 void gsr_launch_tile_sort_level2(const GsrTileSortPlan& plan, int64_t R, int n_tiles, const void* words, uint32_t* point_list,
@@ -311,7 +279,7 @@ void gsr_launch_train_loss_forward(int planes, int H, int W, const float* img1, 
 void gsr_launch_train_loss_backward(int planes, int H, int W, const float* img1, const float* img2, const float* dL_dloss, float lambda,
                                     const float* dm_dmu1, const float* dm_dex2, const float* dm_dexy, float* dL_dimg1, hipStream_t st);
 // binning.hip: gathered splat records -> geometry state of this rank's band (two-axis sharding)
-int gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4* splats, uint4* rect, uint32_t* tiles,
+int gsr_launch_splat_ingest(int P, const float* records, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
                             uint32_t* keys, uint32_t* vals, const GsrFrameStatsDev& fs, hipStream_t st);
 // binning.hip: full 32-bit depth keys from the splat records (fallback of the 27-bit depth sort)
 void gsr_launch_rekey_full(int P, const float4* splats, const uint32_t* tiles, uint32_t* keys, uint32_t* vals, hipStream_t st);
@@ -323,6 +291,6 @@ void gsr_launch_route_count(int P, const float* records, int n_bands, const int3
                             uint32_t* band_counts, hipStream_t st);
 void gsr_launch_route_pack(int P, const float* records, int n_bands, const int32_t* bounds, const int64_t* band_offsets,
                            const uint32_t* block_offsets, float* packed, int32_t* send_ids, hipStream_t st);
-int gsr_launch_ingest_packed(int P, const float* packed, int y0, int y1, float4* splats, uint4* rect, uint32_t* tiles,
+int gsr_launch_ingest_packed(int P, const float* packed, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
                              uint32_t* keys, uint32_t* vals, const GsrFrameStatsDev& fs, hipStream_t st);
 void gsr_launch_route_add_rows(int64_t n, const int32_t* ids, const float* rows, float* out, hipStream_t st);

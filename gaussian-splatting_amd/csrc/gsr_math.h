@@ -52,8 +52,7 @@ struct GsrCam {
     float scale_modifier;
     int sh_degree, M;
     int antialiasing;
-    int snug;                 // 1 = snug tile rectangle, 0 = the reference's square (same outputs, longer lists),
-                              // 2 = snug rectangle + per-tile MASK for rectangles of <= 8 x 8 tiles (gsr_project)
+    int snug;                 // 1 = snug tile rectangle (default), 0 = the reference's square (A/B: same outputs, longer lists)
     int tile_y0, tile_y1;     // band of tile rows that is binned
     float view[16];           // flat, as passed (transposed math matrix)
     float proj[16];
@@ -68,14 +67,6 @@ struct GsrCam {
 // restatement (oracle/torch_oracle.py: det_log / tau_of_opacity): no libm -- `logf` differs by an ulp between implementations --
 // but frexp (exact) + the atanh series in fp64, one IEEE rounding per written operation, contraction switched off locally so
 // that translation units built with -ffp-contract=fast (route.hip) get the same bits.
-GSR_HD int gsr_popc32(uint32_t v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __popc(v);
-#else
-    return __builtin_popcount(v);
-#endif
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 GSR_HD double gsr_log_det(double v) {            // ln(v), v finite and > 0
 #if defined(__clang__)
@@ -130,9 +121,7 @@ struct GsrSplat {             // result of the forward preprocess for one Gaussi
     float depth;              // view-space z
     int radius;               // 0 = not visible
     uint32_t minx, miny, maxx, maxy;  // tile rectangle, y already clamped to the band
-    uint32_t tiles;           // (maxx-minx)*(maxy-miny) within the band; with a mask: its population count
-    uint32_t mask_lo, mask_hi;// cam.snug == 2 and a rectangle of <= 8 x 8 tiles: bit (ry * 8 + rx) set = tile (minx + rx, miny + ry)
-                              // can hold a pixel with alpha >= 1/255; 0 / 0 = no mask (the whole rectangle is binned)
+    uint32_t tiles;           // (maxx-minx)*(maxy-miny) within the band
     uint32_t clamped;         // bit c set: colour channel c was clamped at 0
 };
 
@@ -277,60 +266,6 @@ GSR_HD bool gsr_project(const GsrCam& cam, const float* mean, const float* cov, 
     out.miny = (uint32_t)bminy;
     out.maxy = (uint32_t)bmaxy;
     out.tiles = (uint32_t)((smaxx - sminx) * (bmaxy - bminy));
-    out.mask_lo = 0u;
-    out.mask_hi = 0u;
-    // TILE MASK (cam.snug == 2; round 4): the snug rectangle is the bounding box of the ellipse q <= tau -- for a round splat of
-    // 3 x 3 tiles the four corner tiles are outside the ellipse, for a diagonal needle most of the box is.  For rectangles of at
-    // most 8 x 8 tiles (98.5 % of the Gaussians, 89 % of the instances of the bench frame) every tile ROW gets the interval of
-    // tiles the ellipse can reach inside that row's band of pixel rows -- E intersected with a band is convex, so its x-range is an
-    // interval: [min over the band of the left boundary, max of the right boundary], both attained at the band-clamped ordinate of
-    // the ellipse's leftmost / rightmost point (the boundaries are a convex / a concave function of dy).  Same inflation as the
-    // rectangle (1 % + half a pixel), same fp64-from-fp32 arithmetic, one IEEE rounding per written operation: GPU, host build
-    // and oracle (oracle/torch_oracle.py tile_mask) agree on every bit.  78 % of the masked rectangles' tiles survive.
-    {
-#if defined(__clang__)
-#pragma clang fp contract(off)
-#endif
-        const int w = smaxx - sminx, h = smaxy - sminy;
-        const double td = (double)out.tau;
-        const double Ad = (double)out.conA, Bd = (double)out.conB, Cd = (double)out.conC;
-        const double detc = Ad * Cd - Bd * Bd;
-        const bool full_band = cam.tile_y0 <= 0 && cam.tile_y1 >= cam.gy;
-        const bool want = cam.snug == 2 && full_band && w >= 1 && h >= 1 && w <= 8 && h <= 8 && td > 0.0 && td < 1.0e30 && detc > 0.0 &&
-                          Ad > 0.0 && Cd > 0.0;
-        const double sdet = want ? detc : 1.0, st = want ? td : 1.0, sA = want ? Ad : 1.0, sC = want ? Cd : 1.0, sB = want ? Bd : 0.0;
-        const double xmax = sqrt(st * sC / sdet), ymax = sqrt(st * sA / sdet);       // half extents of the ellipse
-        const double dyu = -(sB * xmax) / sC;                                         // ordinate of its rightmost point (leftmost: -dyu)
-        const double cx = (double)pixx, cy = (double)pixy;
-        uint32_t lo = 0u, hi = 0u;
-        bool finite = xmax < 1.0e9 && ymax < 1.0e9;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 1
-#endif
-        for (int r = 0; r < 8; ++r) {
-            const double Y0 = (double)((sminy + r) * 16), Y1 = Y0 + 15.0;             // pixel rows of this tile row
-            const double blo = fmax(((Y0 - 0.5) - cy) / 1.01, -ymax), bhi = fmin(((Y1 + 0.5) - cy) / 1.01, ymax);
-            const double du = fmin(fmax(dyu, blo), bhi), dl = fmin(fmax(-dyu, blo), bhi);
-            const double ru = sqrt(fmax(st * sA - sdet * (du * du), 0.0)), rl = sqrt(fmax(st * sA - sdet * (dl * dl), 0.0));
-            const double xu = (ru - sB * du) / sA, xl = (-rl - sB * dl) / sA;        // right / left boundary at those ordinates
-            const double tl = floor((cx + (xl * 1.01 - 0.5)) / 16.0), th = floor((cx + (xu * 1.01 + 0.5)) / 16.0);
-            const double al = fmin(fmax(tl - (double)sminx, 0.0), 8.0), ah = fmin(fmax(th - (double)sminx, -1.0), (double)(w - 1));
-            const bool row_ok = r < h && blo <= bhi && al <= ah;                      // (NaN compares false: empty row)
-            const int ia = row_ok ? (int)al : 0, ib = row_ok ? (int)ah : -1;
-            const uint32_t bits = row_ok ? (((2u << ib) - 1u) & ~((1u << ia) - 1u)) & 0xFFu : 0u;
-            if (r < 4) lo |= bits << (8 * r);
-            else hi |= bits << (8 * (r - 4));
-        }
-        const bool masked = want && finite;
-        if (masked) {
-            out.mask_lo = lo;
-            out.mask_hi = hi;
-            out.tiles = (uint32_t)(gsr_popc32(lo) + gsr_popc32(hi));
-            // an all-zero mask of a masked Gaussian means "no tile": mark the rectangle empty as well, so that mask == 0 always
-            // reads as "no mask" for a Gaussian that has tiles
-            if (out.tiles == 0u) { out.maxx = out.minx; out.maxy = out.miny; }
-        }
-    }
     return true;
 }
 

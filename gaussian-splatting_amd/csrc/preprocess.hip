@@ -189,7 +189,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
                       const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                       const float* __restrict__ scales, const float* __restrict__ rotations,
                       const float* __restrict__ cov3D_precomp, float4* __restrict__ splats,
-                      uint4* __restrict__ rect, uint32_t* __restrict__ tiles, uint32_t* __restrict__ clamped_out,
+                      uint2* __restrict__ rect, uint32_t* __restrict__ tiles, uint32_t* __restrict__ clamped_out,
                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int32_t* __restrict__ radii,
                       GsrFrameStatsDev fs) {
     __shared__ __attribute__((aligned(16))) float s_sh[4][64 * SH_ROW];
@@ -208,7 +208,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         const int64_t i = i0 + lane;
         const bool in_range = i < P;
         GsrSplat sp;
-        sp.radius = 0; sp.tiles = 0; sp.minx = sp.miny = sp.maxx = sp.maxy = 0; sp.depth = 0.f; sp.mask_lo = sp.mask_hi = 0u;
+        sp.radius = 0; sp.tiles = 0; sp.minx = sp.miny = sp.maxx = sp.maxy = 0; sp.depth = 0.f;
         float mean[3] = {0.f, 0.f, 0.f};
         bool vis = false;
         // full frame on one GPU: nearly every Gaussian needs its colour, so the SH block is requested up front, together
@@ -284,16 +284,12 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             // (box-cull threshold of the blend kernels); 1/depth feeds the inverse-depth image.
             q2 = make_float4(rgb[2], sp.depth, sp.tau, gsr_inv_depth(sp.depth));
         }
-        const uint4 rc = make_uint4(sp.minx | (sp.maxx << 16), sp.miny | (sp.maxy << 16), sp.mask_lo, sp.mask_hi);
+        const uint2 rc = make_uint2(sp.minx | (sp.maxx << 16), sp.miny | (sp.maxy << 16));
         splats[i * 4 + 0] = q0;
         splats[i * 4 + 1] = q1;
         splats[i * 4 + 2] = q2;
-        // 4th quad, as raw bits: tile rectangle, first emission index (filled in by the emission), tiles_touched -- or, for a
-        // Gaussian with a tile mask: rectangle origin, mask low word, GSR_MASKED_FLAG | first emission index, mask high word
-        const bool masked = (sp.mask_lo | sp.mask_hi) != 0u;
-        splats[i * 4 + 3] = masked ? make_float4(__uint_as_float(sp.minx | (sp.miny << 16)), __uint_as_float(sp.mask_lo),
-                                                 __uint_as_float(GSR_MASKED_FLAG), __uint_as_float(sp.mask_hi))
-                                   : make_float4(__uint_as_float(rc.x), __uint_as_float(rc.y), 0.f, __uint_as_float(sp.tiles));
+        // 4th quad: tile rectangle, first emission index (filled in by emit_instances), tiles_touched -- as raw bits
+        splats[i * 4 + 3] = make_float4(__uint_as_float(rc.x), __uint_as_float(rc.y), 0.f, __uint_as_float(sp.tiles));
         rect[i] = rc;
         tiles[i] = sp.tiles;
         if (clamped_out) clamped_out[i] = clampbits;

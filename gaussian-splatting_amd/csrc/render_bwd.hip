@@ -203,16 +203,10 @@ __device__ __forceinline__ void moments_to_grads(float A, float B, float C, floa
 
 constexpr float LOG2E = 1.4426950408889634f;
 
-// q3 of the splat record = (rect.x bits, rect.y bits, first emission index bits, tiles bits) -- or, with GSR_MASKED_FLAG in the
-// third word: (rectangle origin minx | miny << 16, mask low word, flag | first emission index, mask high word); see preprocess.hip.
-// A Gaussian's instances are emitted y-major inside its rectangle -- with a mask: its set bits in ascending order (bit = ry*8 + rx)
+// q3 of the splat record = (rect.x bits, rect.y bits, first emission index bits, tiles bits), see preprocess.hip / binning.hip
 __device__ __forceinline__ uint32_t emission_index(const float4 q3, uint32_t tx, uint32_t ty) {
-    const uint32_t a = __float_as_uint(q3.x), b = __float_as_uint(q3.y), goff = __float_as_uint(q3.z), d = __float_as_uint(q3.w);
-    if (goff & GSR_MASKED_FLAG) {
-        const uint32_t minx = a & 0xFFFFu, miny = a >> 16;
-        return (goff & ~GSR_MASKED_FLAG) + gsr_mask_rank(b, d, (ty - miny) * 8u + (tx - minx));
-    }
-    const uint32_t minx = a & 0xFFFFu, w = (a >> 16) - minx, miny = b & 0xFFFFu;
+    const uint32_t rx = __float_as_uint(q3.x), ry = __float_as_uint(q3.y), goff = __float_as_uint(q3.z);
+    const uint32_t minx = rx & 0xFFFFu, w = (rx >> 16) - minx, miny = ry & 0xFFFFu;
     return goff + (ty - miny) * w + (tx - minx);
 }
 constexpr int REC_STRIDE = 3;      // float4 per staged entry (48 B: 12-word stride, 3 coprime to 16 -> per-lane ds_read_b128 is conflict-free)

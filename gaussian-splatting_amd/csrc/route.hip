@@ -103,7 +103,7 @@ route_pack(int P, const float4* __restrict__ records, RouteBands rb, RouteOffset
 }
 
 __global__ void __launch_bounds__(256)
-ingest_packed(int P, const float4* __restrict__ packed, int y0, int y1, float4* __restrict__ splats, uint4* __restrict__ rect,
+ingest_packed(int P, const float4* __restrict__ packed, int y0, int y1, float4* __restrict__ splats, uint2* __restrict__ rect,
               uint32_t* __restrict__ tiles, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GsrFrameStatsDev fs) {
     GsrFrameAcc acc;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
@@ -113,7 +113,7 @@ ingest_packed(int P, const float4* __restrict__ packed, int y0, int y1, float4* 
         const int bminy = miny < y0 ? y0 : (miny > y1 ? y1 : miny);
         const int bmaxy = maxy < y0 ? y0 : (maxy > y1 ? y1 : maxy);
         const uint32_t t = (uint32_t)((maxx - minx) * (bmaxy - bminy));
-        const uint4 rc = make_uint4((uint32_t)minx | ((uint32_t)maxx << 16), (uint32_t)bminy | ((uint32_t)bmaxy << 16), 0u, 0u);
+        const uint2 rc = make_uint2((uint32_t)minx | ((uint32_t)maxx << 16), (uint32_t)bminy | ((uint32_t)bmaxy << 16));
         const float depth = p2.y, op = q1.y;
         splats[i * 4 + 0] = q0;
         splats[i * 4 + 1] = q1;
@@ -175,7 +175,7 @@ void gsr_launch_route_pack(int P, const float* records, int n_bands, const int32
                        make_bands(n_bands, bounds), bo, block_offsets, nblk, reinterpret_cast<float4*>(packed), send_ids);
 }
 
-int gsr_launch_ingest_packed(int P, const float* packed, int y0, int y1, float4* splats, uint4* rect, uint32_t* tiles,
+int gsr_launch_ingest_packed(int P, const float* packed, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
                              uint32_t* keys, uint32_t* vals, const GsrFrameStatsDev& fs, hipStream_t st) {
     int64_t nb = ((int64_t)P + 255) / 256;
     if (nb > GSR_FRAME_MAX_GROUPS) nb = GSR_FRAME_MAX_GROUPS;      // (gsr_frame.h: tickets)

@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(RS_THREADS)
 rs_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
            KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int shift,
            const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_total, int nblocks,
-           const uint4* __restrict__ rect, uint4* __restrict__ rect_sorted) {
+           const uint2* __restrict__ rect, uint2* __restrict__ rect_sorted) {
     constexpr int NB = 1 << BITS;
     constexpr int DPT = (NB + RS_THREADS - 1) / RS_THREADS;   // digits per thread (1 for <= 256 bins, 8 for 2048)
     __shared__ uint32_t wave_cnt[RS_WAVES][NB];
@@ -303,7 +303,7 @@ rs_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_i
     if (rect_sorted) {
         // last pass of the depth sort: the rectangle gather.  All IPT gathers are issued before the first store -- written
         // as "rect_sorted[pos] = rect[v]" inside the store loop each gather was waited for on its own (IPT serial round trips).
-        uint4 rc[IPT];
+        uint2 rc[IPT];
 #pragma unroll
         for (int r = 0; r < IPT; ++r) {
             const uint32_t i = (uint32_t)r * RS_THREADS + tid;
@@ -328,7 +328,7 @@ rs_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_i
 
 template <typename KeyT, int IPT, int BITS>
 void sort_pass(KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vout, int64_t n, int shift, uint32_t* hist,
-               uint32_t* digit_total, int nblocks, const uint4* rect, uint4* rect_sorted, hipStream_t st) {
+               uint32_t* digit_total, int nblocks, const uint2* rect, uint2* rect_sorted, hipStream_t st) {
     hipLaunchKernelGGL((rs_hist<KeyT, IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, n, shift, hist, nblocks);
     hipLaunchKernelGGL(rs_scan, dim3(1 << BITS), dim3(RS_THREADS), 0, st, hist, nblocks, digit_total);
     hipLaunchKernelGGL((rs_scatter<KeyT, IPT, BITS>), dim3(nblocks), dim3(RS_THREADS), 0, st, kin, vin, kout, vout, n, shift, hist,
@@ -337,7 +337,7 @@ void sort_pass(KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vout, int64_t n, 
 
 template <typename KeyT, int IPT>
 void sort_pass_bits(int bits, KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vout, int64_t n, int shift,
-                    uint32_t* hist, uint32_t* digit_total, int nblocks, const uint4* rect, uint4* rect_sorted, hipStream_t st) {
+                    uint32_t* hist, uint32_t* digit_total, int nblocks, const uint2* rect, uint2* rect_sorted, hipStream_t st) {
     switch (bits) {
         case 11: sort_pass<KeyT, IPT, 11>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st); break;
         case 10: sort_pass<KeyT, IPT, 10>(kin, vin, kout, vout, n, shift, hist, digit_total, nblocks, rect, rect_sorted, st); break;
@@ -352,7 +352,7 @@ void sort_pass_bits(int bits, KeyT* kin, uint32_t* vin, KeyT* kout, uint32_t* vo
 
 template <typename KeyT>
 int sort_pairs_t(KeyT* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
-                 uint32_t* digit_total, int items, const uint4* rect, uint4* rect_sorted, hipStream_t st) {
+                 uint32_t* digit_total, int items, const uint2* rect, uint2* rect_sorted, hipStream_t st) {
     int cur = 0;
     if (n <= 0) return cur;
     const int nblocks = (int)((n + items - 1) / items);
@@ -404,7 +404,7 @@ int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits) {
 }
 
 int gsr_radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], int64_t n, int nbits, int max_digit_bits, uint32_t* hist,
-                         uint32_t* digit_total, int items, hipStream_t st, const uint4* rect, uint4* rect_sorted) {
+                         uint32_t* digit_total, int items, hipStream_t st, const uint2* rect, uint2* rect_sorted) {
     return sort_pairs_t<uint32_t>(keys, vals, n, nbits, max_digit_bits, hist, digit_total, items, rect, rect_sorted, st);
 }
 

@@ -63,9 +63,9 @@ constexpr int TS_NGCAP = 1024;      // Gaussians per block whose record is stage
 
 template <bool WANT_ID>
 __device__ __forceinline__ void generate_instances(uint32_t R, int gx, const uint2* __restrict__ block_first,
-                                                   const uint32_t* __restrict__ offsets, const uint4* __restrict__ rect_sorted,
+                                                   const uint32_t* __restrict__ offsets, const uint2* __restrict__ rect_sorted,
                                                    const uint32_t* __restrict__ order, uint16_t* s_own /*[TS_ITEMS]*/,
-                                                   uint4* s_g4 /*[TS_NGCAP]*/, uint2* s_mk /*[TS_NGCAP] tile masks*/, uint32_t* wsum /*[4]*/, float4* splats,
+                                                   uint4* s_g4 /*[TS_NGCAP]*/, uint32_t* wsum /*[4]*/, float4* splats,
                                                    uint32_t (&tile)[TS_IPT], uint32_t (&id)[TS_IPT], uint32_t& vmask) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t b = blockIdx.x;
@@ -79,18 +79,15 @@ __device__ __forceinline__ void generate_instances(uint32_t R, int gx, const uin
     __syncthreads();
     for (int i = tid; i < nG; i += WG_THREADS) {
         const uint32_t excl = i ? offsets[j_lo + i - 1] : base_excl;
-        const uint4 rc = rect_sorted[j_lo + i];
+        const uint2 rc = rect_sorted[j_lo + i];
         const uint32_t gid = (WANT_ID || splats) ? order[j_lo + i] : 0u;
-        if (i < TS_NGCAP) {
-            s_g4[i] = make_uint4(excl, rc.x, rc.y, gid);
-            s_mk[i] = make_uint2(rc.z, rc.w);
-        }
+        if (i < TS_NGCAP) s_g4[i] = make_uint4(excl, rc.x, rc.y, gid);
         const uint32_t pos = excl > b0 ? excl - b0 : 0u;         // only the first Gaussian can start before the block
         if (pos < (uint32_t)TS_ITEMS) {
             s_own[pos] = (uint16_t)i;
             // first emission index of every Gaussian whose first instance lies in this block -> 4th quad of its splat
             // record (the blend backward writes its per-instance gradient records at emission indices, render_bwd.hip)
-            if (splats && excl >= b0) reinterpret_cast<uint32_t*>(splats + (int64_t)gid * 4 + 3)[2] = excl | ((rc.z | rc.w) ? GSR_MASKED_FLAG : 0u);
+            if (splats && excl >= b0) reinterpret_cast<uint32_t*>(splats + (int64_t)gid * 4 + 3)[2] = excl;
         }
     }
     __syncthreads();
@@ -120,19 +117,11 @@ __device__ __forceinline__ void generate_instances(uint32_t R, int gx, const uin
     __syncthreads();
     const uint32_t s0 = (uint32_t)w * (64u * TS_IPT) + (uint32_t)lane;     // slot of item 0 inside the block
     vmask = 0;
-    auto finish = [&](int r, uint32_t k, const uint4& g, const uint2& mk) {
+    auto finish = [&](int r, uint32_t k, const uint4& g) {
         if (WANT_ID) id[r] = g.w;
         const uint32_t minx = g.y & 0xFFFFu, wd = (g.y >> 16) - minx, miny = g.z & 0xFFFFu;
-        const uint32_t local = (k < R ? k : R - 1u) - g.x;
-        uint32_t rx, ry;
-        if (mk.x | mk.y) {      // a tile mask: the local-th set bit, bit = ry * 8 + rx
-            const uint32_t pop = (uint32_t)(__popc(mk.x) + __popc(mk.y));
-            const uint32_t bit = gsr_mask_select(mk.x, mk.y, local < pop ? local : pop - 1u);      // (slots past R: any valid bit)
-            ry = bit >> 3;
-            rx = bit & 7u;
-        } else {
-            ry = div_small(local, wd ? wd : 1u, rx);
-        }
+        uint32_t rx;
+        const uint32_t ry = div_small((k < R ? k : R - 1u) - g.x, wd ? wd : 1u, rx);
         tile[r] = (miny + ry) * (uint32_t)gx + minx + rx;
     };
     // Two separate loops on a workgroup-uniform condition.  Written as one loop with "i < TS_NGCAP ? LDS record : global
@@ -146,7 +135,7 @@ __device__ __forceinline__ void generate_instances(uint32_t R, int gx, const uin
         for (int r = 0; r < TS_IPT; ++r) {
             const uint32_t k = b0 + s0 + (uint32_t)r * 64u;
             if (k < R) vmask |= 1u << r;
-            finish(r, k, s_g4[own[r]], s_mk[own[r]]);
+            finish(r, k, s_g4[own[r]]);
         }
     } else {            // (more than 1024 Gaussians in 4096 instances: fewer than four tiles each)
 #pragma unroll 1
@@ -156,16 +145,13 @@ __device__ __forceinline__ void generate_instances(uint32_t R, int gx, const uin
             if (k < R) vmask |= 1u << r;
             const uint32_t i = s_own[slot];
             uint4 g;
-            uint2 mk;
             if (i < (uint32_t)TS_NGCAP) {
                 g = s_g4[i];
-                mk = s_mk[i];
             } else {
-                const uint4 rc = rect_sorted[j_lo + i];
+                const uint2 rc = rect_sorted[j_lo + i];
                 g = make_uint4(offsets[j_lo + i - 1], rc.x, rc.y, WANT_ID ? order[j_lo + i] : 0u);
-                mk = make_uint2(rc.z, rc.w);
             }
-            finish(r, k, g, mk);
+            finish(r, k, g);
         }
     }
 }
@@ -177,7 +163,7 @@ __device__ __forceinline__ void generate_instances(uint32_t R, int gx, const uin
 // instances on the bench frame and no owner expansion (the instance-wise version spent 23 us, all VALU).
 __global__ void __launch_bounds__(WG_THREADS)
 emit_hist(uint32_t R, int gx, int lb, int nb1, const uint2* __restrict__ block_first, const uint32_t* __restrict__ offsets,
-          const uint4* __restrict__ rect_sorted, uint32_t* __restrict__ hist, int nblk) {
+          const uint2* __restrict__ rect_sorted, uint32_t* __restrict__ hist, int nblk) {
     __shared__ uint32_t h[TS_MAXBINS];
     const int tid = threadIdx.x;
     if (tid < nb1) h[tid] = 0;
@@ -190,40 +176,11 @@ emit_hist(uint32_t R, int gx, int lb, int nb1, const uint2* __restrict__ block_f
     __syncthreads();
     for (int i = tid; i < nG; i += WG_THREADS) {
         const uint32_t excl = i ? offsets[j_lo + i - 1] : base_excl, incl = offsets[j_lo + i];
-        const uint4 rc = rect_sorted[j_lo + i];
+        const uint2 rc = rect_sorted[j_lo + i];
         const uint32_t minx = rc.x & 0xFFFFu, wd = (rc.x >> 16) - minx, miny = rc.y & 0xFFFFu;
         const uint32_t lo = excl > b0 ? excl : b0, hi = incl < b1 ? incl : b1;
         if (hi <= lo || wd == 0u) continue;
         const uint32_t ka = lo - excl, kb = hi - excl;          // the Gaussian's local instances [ka, kb) lie in this block
-        if (rc.z | rc.w) {
-            // a tile mask: per mask row (<= 8 consecutive tiles) the set bits whose ranks fall into [ka, kb); a row crosses at
-            // most one bucket boundary
-            uint32_t k = 0;
-            for (uint32_t r = 0; r < 8u; ++r) {
-                uint32_t bits = ((r < 4u ? rc.z : rc.w) >> (8u * (r & 3u))) & 0xFFu;
-                const uint32_t c = (uint32_t)__popc(bits);
-                const uint32_t a = (ka > k ? ka : k) - k, b = (kb < k + c ? kb : k + c) - k;      // ranks [a, b) of this row (if a < b)
-                const bool any = c != 0u && ka < k + c && kb > k && a < b;
-                k += c;
-                if (!any) continue;
-                if (a != 0u || b != c) {      // partial row (a block boundary cuts this Gaussian's run): keep the set bits of rank a .. b-1
-                    uint32_t out = 0u, rnk = 0u;
-                    for (uint32_t x = 0; x < 8u; ++x)
-                        if ((bits >> x) & 1u) {
-                            if (rnk >= a && rnk < b) out |= 1u << x;
-                            ++rnk;
-                        }
-                    bits = out;
-                }
-                const uint32_t t0 = (miny + r) * (uint32_t)gx + minx;
-                const uint32_t d = t0 >> lb;
-                const uint32_t xb = ((d + 1u) << lb) - t0;                       // first x of the next bucket
-                const uint32_t lo_bits = xb >= 8u ? bits : bits & ((1u << xb) - 1u);
-                if (lo_bits) atomicAdd(&h[d], (uint32_t)__popc(lo_bits));
-                if (bits != lo_bits) atomicAdd(&h[d + 1u], (uint32_t)__popc(bits & ~lo_bits));
-            }
-            continue;
-        }
         uint32_t xa, xl;
         const uint32_t ra = div_small(ka, wd, xa), rb = div_small(kb - 1u, wd, xl);
         for (uint32_t r = ra; r <= rb; ++r) {
@@ -304,13 +261,13 @@ __device__ __forceinline__ void local_stable_sort(const WordT (&word)[TS_IPT], u
 template <typename WordT>
 __global__ void __launch_bounds__(WG_THREADS)
 emit_scatter(uint32_t R, int gx, int lb, int hb, const uint2* __restrict__ block_first, const uint32_t* __restrict__ offsets,
-             const uint4* __restrict__ rect_sorted, const uint32_t* __restrict__ order, const uint32_t* __restrict__ hist,
+             const uint2* __restrict__ rect_sorted, const uint32_t* __restrict__ order, const uint32_t* __restrict__ hist,
              const uint32_t* __restrict__ digit_total, int nblk, WordT* __restrict__ words_out,
              uint32_t* __restrict__ bucket_base /*[nb1+1]*/, uint32_t* __restrict__ blk2_start /*[nb1+1]*/,
              float4* __restrict__ splats /*NULL: inference, no first-emission write*/) {
     // LDS: the generation phase (owner marks, records of the block's Gaussians) and the sorting phase (words staged in
     // bucket order) never overlap in time, so they share one region
-    constexpr int GEN_BYTES = TS_ITEMS * 2 + TS_NGCAP * 16 + TS_NGCAP * 8;
+    constexpr int GEN_BYTES = TS_ITEMS * 2 + TS_NGCAP * 16;
     constexpr int SORT_BYTES = TS_ITEMS * (int)sizeof(WordT) + TS_ITEMS;
     constexpr int SMEM_BYTES = GEN_BYTES > SORT_BYTES ? GEN_BYTES : SORT_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
@@ -319,7 +276,6 @@ emit_scatter(uint32_t R, int gx, int lb, int hb, const uint2* __restrict__ block
     __shared__ uint32_t wsum[WG_WAVES];
     uint16_t* s_own = reinterpret_cast<uint16_t*>(smem);
     uint4* s_g4 = reinterpret_cast<uint4*>(smem + TS_ITEMS * 2);
-    uint2* s_mk = reinterpret_cast<uint2*>(smem + TS_ITEMS * 2 + TS_NGCAP * 16);
     WordT* s_word = reinterpret_cast<WordT*>(smem);
     uint8_t* s_dig = smem + TS_ITEMS * sizeof(WordT);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -328,7 +284,7 @@ emit_scatter(uint32_t R, int gx, int lb, int hb, const uint2* __restrict__ block
     const uint32_t my_total = tid < nb1 ? digit_total[tid] : 0u;
     const uint32_t my_hist = tid < nb1 ? hist[(int64_t)tid * nblk + blockIdx.x] : 0u;
     uint32_t tile[TS_IPT], id[TS_IPT], vmask;
-    generate_instances<true>(R, gx, block_first, offsets, rect_sorted, order, s_own, s_g4, s_mk, wsum, splats, tile, id, vmask);
+    generate_instances<true>(R, gx, block_first, offsets, rect_sorted, order, s_own, s_g4, wsum, splats, tile, id, vmask);
     // global base of bucket d for this block = exclusive scan of the bucket totals + instances of earlier blocks
     uint32_t tot[1] = {my_total};
     const uint32_t bbase = block_excl_scan<1>(tot, wsum, lane, w);
@@ -594,7 +550,7 @@ void gsr_launch_fill_block_first(int P, const uint32_t* offsets, uint2* block_fi
 }
 
 void gsr_launch_tile_sort_level1(const GsrTileSortPlan& plan, int64_t R, int gx, const uint2* block_first,
-                                 const uint32_t* offsets, const uint4* rect_sorted, const uint32_t* order, void* words,
+                                 const uint32_t* offsets, const uint2* rect_sorted, const uint32_t* order, void* words,
                                  uint32_t* hist1, uint32_t* digit_total, uint32_t* bucket_base, uint32_t* blk2_start,
                                  float4* splats, hipStream_t st) {
     const int nblk = (int)((R + TS_ITEMS - 1) / TS_ITEMS);

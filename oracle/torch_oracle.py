@@ -329,10 +329,7 @@ def preprocess(means3D, opacities, s: Settings, shs=None, colors_precomp=None, s
         visible = in_front & det_ok & (area_full > 0) & (radius_f < 2.0e9)
         radii = torch.where(visible, torch.nan_to_num(radius_f, nan=0.0, posinf=0.0).to(torch.int64),
                             torch.zeros_like(area_full)).to(torch.int32)
-        snug_mode = int(SNUG_TILES if snug is None else snug)      # 0 reference square, 1 snug rectangle, 2 snug rectangle + tile masks
-        mask_lo = torch.zeros(P, dtype=torch.int64)
-        mask_hi = torch.zeros(P, dtype=torch.int64)
-        if snug_mode:
+        if SNUG_TILES if snug is None else snug:
             # the product's snug rectangle (csrc/gsr_math.h gsr_project, same operations in the same order, fp64 from the fp32
             # conic / centre / opacity); `radii` keeps the reference's value
             td = tau_of_opacity((opacities.reshape(P) * aa).detach()).to(torch.float64)
@@ -367,50 +364,6 @@ def preprocess(means3D, opacities, s: Settings, shs=None, colors_precomp=None, s
         bminy = torch.clamp(rminy, tile_y0, tile_y1)
         bmaxy = torch.clamp(rmaxy, tile_y0, tile_y1)
         tiles_touched = torch.where(visible, (rmaxx - rminx) * (bmaxy - bminy), torch.zeros_like(area_full))
-        if snug_mode == 2 and tile_y0 <= 0 and tile_y1 >= gy:
-            # the product's per-tile MASK for rectangles of <= 8 x 8 tiles (csrc/gsr_math.h gsr_project, "TILE MASK": the same
-            # operations in the same order, fp64): per tile row the interval of tiles that the ellipse q <= tau, inflated by 1 % +
-            # half a pixel, can reach inside the row's band of pixel rows
-            w_, h_ = rmaxx - rminx, rmaxy - rminy
-            want = (w_ >= 1) & (h_ >= 1) & (w_ <= 8) & (h_ <= 8) & (td > 0.0) & (td < 1.0e30) & (detc > 0.0) & (Ad > 0.0) & (Cd > 0.0)
-            one, zero = torch.ones_like(detc), torch.zeros_like(detc)
-            sdet, st = torch.where(want, detc, one), torch.where(want, td, one)
-            sA, sC, sB = torch.where(want, Ad, one), torch.where(want, Cd, one), torch.where(want, Bd, zero)
-            xmax, ymax = sqrt64(st * sC / sdet), sqrt64(st * sA / sdet)
-            dyu = -(sB * xmax) / sC
-            finite = (xmax < 1.0e9) & (ymax < 1.0e9)
-            sminx_d, wm1 = rminx.to(torch.float64), (w_ - 1).to(torch.float64)
-            for r in range(8):
-                Y0 = ((rminy + r) * 16).to(torch.float64)
-                Y1 = Y0 + 15.0
-                blo = torch.maximum(((Y0 - 0.5) - cyd) / 1.01, -ymax)
-                bhi = torch.minimum(((Y1 + 0.5) - cyd) / 1.01, ymax)
-                du = torch.minimum(torch.maximum(dyu, blo), bhi)
-                dl = torch.minimum(torch.maximum(-dyu, blo), bhi)
-                ru = sqrt64(torch.clamp_min(st * sA - sdet * (du * du), 0.0))
-                rl = sqrt64(torch.clamp_min(st * sA - sdet * (dl * dl), 0.0))
-                xu = (ru - sB * du) / sA
-                xl = (-rl - sB * dl) / sA
-                tl = torch.floor((cxd + (xl * 1.01 - 0.5)) / 16.0)
-                th = torch.floor((cxd + (xu * 1.01 + 0.5)) / 16.0)
-                al = torch.clamp(tl - sminx_d, 0.0, 8.0)
-                ah = torch.minimum(torch.clamp_min(th - sminx_d, -1.0), wm1)
-                row_ok = (r < h_) & (blo <= bhi) & (al <= ah)          # (a NaN compares false: empty row)
-                ia = torch.where(row_ok, torch.nan_to_num(al, nan=0.0), zero).to(torch.int64)
-                ib = torch.where(row_ok, torch.nan_to_num(ah, nan=0.0), zero).to(torch.int64)
-                bits = torch.where(row_ok, (((2 << ib) - 1) & ~((1 << ia) - 1)) & 0xFF, torch.zeros_like(ia))
-                if r < 4:
-                    mask_lo = mask_lo | (bits << (8 * r))
-                else:
-                    mask_hi = mask_hi | (bits << (8 * (r - 4)))
-            masked = want & finite & visible
-            mask_lo = torch.where(masked, mask_lo, torch.zeros_like(mask_lo))
-            mask_hi = torch.where(masked, mask_hi, torch.zeros_like(mask_hi))
-            pop = _popcount64(mask_lo) + _popcount64(mask_hi)
-            tiles_touched = torch.where(masked, pop, tiles_touched)
-            empty = masked & (pop == 0)
-            rmaxx = torch.where(empty, rminx, rmaxx)
-            bmaxy = torch.where(empty, bminy, bmaxy)
 
     # 9. colour
     if colors_precomp is not None:
@@ -425,16 +378,8 @@ def preprocess(means3D, opacities, s: Settings, shs=None, colors_precomp=None, s
         "cov3D": cov3D, "conic": torch.stack([conA, conB, conC], dim=1), "opacity": opac, "rgb": rgb,
         "clamped": clamped, "tiles_touched": tiles_touched.to(torch.int64),
         "rect": torch.stack([rminx, bminy, rmaxx, bmaxy], dim=1), "grid": (gx, gy),
-        "band": (tile_y0, tile_y1), "tile_mask": mask_lo | (mask_hi << 32),      # 0 = no mask: the whole rectangle is binned
+        "band": (tile_y0, tile_y1),
     }
-
-
-def _popcount64(v: torch.Tensor) -> torch.Tensor:
-    """population count of the low 32 bits of every int64 element"""
-    c = torch.zeros_like(v)
-    for b in range(32):
-        c = c + ((v >> b) & 1)
-    return c
 
 
 def _zero_with_grad(v, k):
@@ -466,22 +411,6 @@ def bin_and_sort(pre):
     w = (rect[:, 2] - rect[:, 0])[idx].clamp_min(1)
     ty = rect[:, 1][idx] + torch.div(local, w, rounding_mode="floor")
     tx = rect[:, 0][idx] + local % w
-    mask = pre.get("tile_mask")
-    if mask is not None and bool((mask != 0).any()):
-        # masked Gaussians emit the set bits of their mask in ascending bit order (bit = ry * 8 + rx: y-major, x ascending)
-        m = mask[idx]
-        has = m != 0
-        bit_of = torch.zeros_like(local)
-        seen = torch.zeros_like(local)
-        found = torch.zeros_like(has)
-        for b in range(64):
-            is_set = ((m >> b) & 1) == 1
-            hit = has & is_set & (seen == local) & ~found
-            bit_of = torch.where(hit, torch.full_like(bit_of, b), bit_of)
-            found = found | hit
-            seen = seen + is_set.to(seen.dtype)
-        ty = torch.where(has, rect[:, 1][idx] + (bit_of >> 3), ty)
-        tx = torch.where(has, rect[:, 0][idx] + (bit_of & 7), tx)
     tile = ty * gx + tx
     key = (tile << 32) | depth_bits(pre["depths"])[idx]
     skey, order = torch.sort(key, stable=True)

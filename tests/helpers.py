@@ -41,7 +41,7 @@ class HostCam(C.Structure):
     _fields_ = [("W", C.c_int), ("H", C.c_int), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
                 ("scale_modifier", C.c_float), ("sh_degree", C.c_int), ("M", C.c_int), ("antialiasing", C.c_int),
                 ("tile_y0", C.c_int), ("tile_y1", C.c_int), ("view", C.c_float * 16), ("proj", C.c_float * 16),
-                ("campos", C.c_float * 3), ("snug", C.c_int)]
+                ("campos", C.c_float * 3)]
 
 
 _host_lib = None
@@ -63,9 +63,8 @@ def host_math_lib():
     return _host_lib
 
 
-def host_cam(s, M, tile_y0=0, tile_y1=0, snug=1):
+def host_cam(s, M, tile_y0=0, tile_y1=0):
     hc = HostCam()
-    hc.snug = int(snug)
     hc.W, hc.H = int(s.image_width), int(s.image_height)
     hc.tanfovx, hc.tanfovy = float(s.tanfovx), float(s.tanfovy)
     hc.scale_modifier = float(s.scale_modifier)

@@ -12,7 +12,6 @@ struct HostCam {
     float tanfovx, tanfovy, scale_modifier;
     int sh_degree, M, antialiasing, tile_y0, tile_y1;
     float view[16], proj[16], campos[3];
-    int snug;      // GsrCam::snug: 0 reference square, 1 snug rectangle, 2 snug rectangle + tile masks
 };
 
 static GsrCam to_cam(const HostCam* h) {
@@ -23,7 +22,7 @@ static GsrCam to_cam(const HostCam* h) {
     c.focal_y = (float)h->H / (2.0f * h->tanfovy);
     c.limx = 1.3f * h->tanfovx; c.limy = 1.3f * h->tanfovy;
     c.scale_modifier = h->scale_modifier;
-    c.sh_degree = h->sh_degree; c.M = h->M; c.antialiasing = h->antialiasing; c.snug = h->snug;
+    c.sh_degree = h->sh_degree; c.M = h->M; c.antialiasing = h->antialiasing; c.snug = 1;
     c.tile_y0 = h->tile_y0; c.tile_y1 = h->tile_y1 <= 0 ? c.gy : h->tile_y1;
     memcpy(c.view, h->view, sizeof(c.view)); memcpy(c.proj, h->proj, sizeof(c.proj));
     memcpy(c.campos, h->campos, sizeof(c.campos));
@@ -35,7 +34,7 @@ void host_tau(int n, const float* opacity, float* out) {
     for (int i = 0; i < n; ++i) out[i] = gsr_tau(opacity[i]);
 }
 
-// out_f[P][12] = px,py,conA,conB,conC,opacity,r,g,b,depth,tau,0 ; out_i[P][10] = radius,minx,miny,maxx,maxy,tiles,clamped,visible,mask_lo,mask_hi
+// out_f[P][12] = px,py,conA,conB,conC,opacity,r,g,b,depth,tau,0 ; out_i[P][8] = radius,minx,miny,maxx,maxy,tiles,clamped,visible
 void host_preprocess(const HostCam* hc, int P, const float* means, const float* scales, const float* rots,
                      const float* cov_pre, const float* opac, const float* shs, const float* colors,
                      float* out_f, int* out_i, float* out_cov) {
@@ -57,9 +56,9 @@ void host_preprocess(const HostCam* hc, int P, const float* means, const float* 
         float* f = out_f + 12 * i;
         f[0] = sp.px; f[1] = sp.py; f[2] = sp.conA; f[3] = sp.conB; f[4] = sp.conC; f[5] = sp.opacity;
         f[6] = rgb[0]; f[7] = rgb[1]; f[8] = rgb[2]; f[9] = sp.depth; f[10] = vis ? sp.tau : 0; f[11] = 0;
-        int* o = out_i + 10 * i;
+        int* o = out_i + 8 * i;
         o[0] = sp.radius; o[1] = sp.minx; o[2] = sp.miny; o[3] = sp.maxx; o[4] = sp.maxy; o[5] = sp.tiles;
-        o[6] = clamped; o[7] = vis ? 1 : 0; o[8] = (int)sp.mask_lo; o[9] = (int)sp.mask_hi;
+        o[6] = clamped; o[7] = vis ? 1 : 0;
     }
 }
 

@@ -10,13 +10,13 @@ import torch
 from helpers import O, host_cam, host_math_lib, fptr, np32, make_camera, look_at_camera, make_scene, make_edge_scene, oracle_settings
 
 
-def run_host_fwd(s, sc, scale_mod=1.0, colors=None, cov=None, tile_rows=(0, 0), snug=1):
+def run_host_fwd(s, sc, scale_mod=1.0, colors=None, cov=None, tile_rows=(0, 0)):
     lib = host_math_lib()
     P = sc.P
     M = sc.shs.shape[1]
-    hc = host_cam(s, M, *tile_rows, snug=snug)
+    hc = host_cam(s, M, *tile_rows)
     out_f = np.zeros((P, 12), np.float32)
-    out_i = np.zeros((P, 10), np.int32)
+    out_i = np.zeros((P, 8), np.int32)
     out_cov = np.zeros((P, 6), np.float32)
     lib.host_preprocess(C.byref(hc), P, fptr(np32(sc.means3D)), fptr(np32(sc.scales)) if cov is None else None,
                         fptr(np32(sc.rotations)) if cov is None else None, fptr(np32(cov)), fptr(np32(sc.opacities)),
@@ -79,61 +79,6 @@ def test_forward_matches_oracle_bitwise(name, mkcam, mkscene, aa):
     cl = pre["clamped"].numpy()
     bits = (cl[:, 0].astype(np.int32) | (cl[:, 1].astype(np.int32) << 1) | (cl[:, 2].astype(np.int32) << 2))
     np.testing.assert_array_equal(out_i[vis][:, 6], bits[vis])
-
-
-@pytest.mark.parametrize("name,mkcam,mkscene,aa", CASES)
-def test_tile_masks_match_oracle_bitwise(name, mkcam, mkscene, aa):
-    """snug mode 2 (round 4): rectangles of <= 8 x 8 tiles carry a per-tile mask -- per tile row the interval of tiles the inflated
-    ellipse reaches inside the row's band.  The host build of the product header and the oracle's restatement must agree on every
-    mask bit, on tiles_touched and on the rectangles; the masks are subsets of the snug rectangles, and no mask drops a tile in which
-    the oracle's own blend arithmetic finds a contributing pixel."""
-    cam = mkcam()
-    sc = mkscene(cam)
-    s = oracle_settings(cam, antialiasing=aa)
-    with torch.no_grad():
-        pre = O.preprocess(sc.means3D, sc.opacities, s, shs=sc.shs, scales=sc.scales, rotations=sc.rotations, snug=2)
-        pre1 = O.preprocess(sc.means3D, sc.opacities, s, shs=sc.shs, scales=sc.scales, rotations=sc.rotations, snug=1)
-    _, out_i, _ = run_host_fwd(s, sc, snug=2)
-    vis = pre["visible"].numpy()
-    m = pre["tile_mask"].numpy()
-    lo, hi = (m & 0xFFFFFFFF).astype(np.uint32), ((m >> 32) & 0xFFFFFFFF).astype(np.uint32)
-    np.testing.assert_array_equal(out_i[:, 8].view(np.uint32), lo)
-    np.testing.assert_array_equal(out_i[:, 9].view(np.uint32), hi)
-    np.testing.assert_array_equal(out_i[:, 5], pre["tiles_touched"].numpy())
-    np.testing.assert_array_equal(out_i[:, 0], pre["radii"].numpy())
-    rect = pre["rect"].numpy()
-    np.testing.assert_array_equal(out_i[vis][:, 1:5], rect[vis])
-    assert (m != 0).sum() > 50, "the case must hold masked Gaussians"
-    t1, t2 = pre1["tiles_touched"].numpy(), pre["tiles_touched"].numpy()
-    assert (t2 <= t1).all() and t2.sum() < t1.sum()
-    # every masked Gaussian: mask inside its rectangle; every tile that holds a pixel with alpha >= 1/255 (the blend's own fp32
-    # expression for q, evaluated on all 256 pixel centres of the tile) is in the mask
-    r1 = pre1["rect"].numpy()
-    con, xy, op = pre["conic"].numpy(), pre["means2D"].numpy(), pre["opacity"].numpy()
-    idx = np.nonzero((m != 0) | ((t2 == 0) & (t1 > 0) & vis))[0]
-    px = np.arange(16, dtype=np.float32)
-    checked = 0
-    for i in idx[:1500]:
-        x0, y0, x1, y1 = r1[i]
-        if x1 - x0 > 8 or y1 - y0 > 8:
-            continue
-        for ry in range(y1 - y0):
-            for rx in range(x1 - x0):
-                bit = (int(m[i]) >> (ry * 8 + rx)) & 1
-                X = (x0 + rx) * 16 + px[None, :]
-                Y = (y0 + ry) * 16 + px[:, None]
-                dx, dy = np.float32(xy[i, 0]) - X, np.float32(xy[i, 1]) - Y
-                power = np.float32(-0.5) * (con[i, 0] * dx * dx + con[i, 2] * dy * dy) - con[i, 1] * dx * dy
-                alpha = np.minimum(np.float32(0.99), op[i] * np.exp(power))
-                reaches = bool(((power <= 0) & (alpha >= np.float32(1.0 / 255.0))).any())
-                assert bit or not reaches, (name, int(i), rx, ry)
-                checked += 1
-        # bits outside the rectangle are never set
-        for ry in range(8):
-            for rx in range(8):
-                if rx >= x1 - x0 or ry >= y1 - y0:
-                    assert not ((int(m[i]) >> (ry * 8 + rx)) & 1)
-    assert checked > 200
 
 
 def test_band_restriction_matches_oracle():

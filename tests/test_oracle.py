@@ -246,45 +246,6 @@ def test_snug_tiles_change_no_output(maker, aa, size):
     assert torch.equal(n0 > 0, n1 > 0)
 
 
-@pytest.mark.parametrize("maker,aa,size", [(lambda c: make_scene(1500, c, seed=2, s_med=0.03), False, (250, 131)),
-                                           (lambda c: make_edge_scene(1200, c, seed=8), True, (333, 200))])
-def test_tile_masks_change_no_output(maker, aa, size):
-    """snug mode 2 (round 4): rectangles of <= 8 x 8 tiles carry a per-tile mask (the tiles of every row that the ellipse reaches).
-    Against the snug rectangles alone: same colour / inverse depth / transmittance / radii, shorter lists, every tile's list a
-    subsequence, the same last contributor per pixel."""
-    cam = look_at_camera(size[0], size[1], (0.2, 0.1, -0.6), (0.0, 0.0, 4.0))
-    sc = maker(cam)
-    s = oracle_settings(cam, antialiasing=aa, bg=torch.tensor([0.2, 0.3, 0.4]))
-    kw = dict(shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
-    outs = {}
-    for snug in (1, 2):
-        with torch.no_grad():
-            pre = O.preprocess(sc.means3D, sc.opacities, s, snug=snug, **kw)
-            bins = O.bin_and_sort(pre)
-            col, invd, fT, ncon, _ = O.render_tiles(pre, bins, s, False)
-        outs[snug] = (pre, bins, col, invd, fT, ncon)
-    (pre1, bins1, col1, invd1, fT1, n1), (pre2, bins2, col2, invd2, fT2, n2) = outs[1], outs[2]
-    assert torch.equal(fT1, fT2)
-    assert (col1 - col2).abs().max().item() <= 1e-6 and (invd1 - invd2).abs().max().item() <= 1e-6 * max(1.0, float(invd1.max()))
-    assert torch.equal(pre1["radii"], pre2["radii"])
-    R1, R2 = int(bins1["R"]), int(bins2["R"])
-    assert R2 < R1, (R1, R2)      # (12 % fewer on the uniform scene, 5 % on the edge scene with its frame-sized splats)
-    assert int(pre2["tiles_touched"].sum()) == R2 and int((pre2["tile_mask"] != 0).sum()) > 100
-    for t in range(0, bins1["ranges"].shape[0], 5):
-        a = bins1["point_list"][bins1["ranges"][t, 0]:bins1["ranges"][t, 1]].tolist()
-        b = bins2["point_list"][bins2["ranges"][t, 0]:bins2["ranges"][t, 1]].tolist()
-        it = iter(a)
-        assert all(x in it for x in b), t
-    assert (n2 <= n1).all() and torch.equal(n1 > 0, n2 > 0)
-    gx = pre1["grid"][0]
-    H, W = size[1], size[0]
-    tid = (torch.arange(H)[:, None] // 16) * gx + torch.arange(W)[None, :] // 16
-    has = n2 > 0
-    g1 = bins1["point_list"][(bins1["ranges"][tid, 0] + n1 - 1)[has]]
-    g2 = bins2["point_list"][(bins2["ranges"][tid, 0] + n2 - 1)[has]]
-    assert torch.equal(g1, g2)
-
-
 def test_deterministic_logarithm_is_a_logarithm():
     """det_log (frexp + atanh series in fp64, the restatement of csrc/gsr_math.h gsr_log_det) against libm over 90 decades, and
     tau = 2 ln(255 opacity) + 0.01 at the edges of its domain."""
