@@ -778,3 +778,45 @@ def test_more_than_65536_tiles_uses_32bit_tile_keys(no_backward):
         d = (gcol[:, ys, xs] - col[:, ys, xs]).abs().max(0).values
         assert float(d[ok].max() if ok.any() else 0.0) <= IMG_TOL
     assert torch.isfinite(out["color"]).all()
+
+
+def test_concurrent_forward_calls_from_two_host_threads():
+    """Round 4 moved R (and the depth-key range) into a per-call device counter + mapped host word that the preprocess kernel's
+    last workgroup publishes (csrc/gsr_frame.h); both are LEASED per call.  Two host threads rendering different scenes on their
+    own streams at the same time must never see each other's counts: every frame of either thread equals the frame the same
+    scene gives when rendered alone (bit for bit), over enough iterations for the leases to be recycled many times."""
+    import threading
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    cams = [make_camera(320, 240), make_camera(400, 208)]
+    scenes = [make_scene(30_000, cams[0], seed=41, s_med=0.02).to(dev), make_scene(9_000, cams[1], seed=42, s_med=0.05).to(dev)]
+    sets = [gpu_settings(oracle_settings(c, bg=torch.tensor([0.1, 0.2, 0.3])), dev) for c in cams]
+
+    def render(i):
+        sc = scenes[i]
+        with torch.no_grad():
+            return GaussianRasterizer(sets[i])(means3D=sc.means3D, means2D=None, opacities=sc.opacities, shs=sc.shs, scales=sc.scales,
+                                               rotations=sc.rotations)
+    want = [tuple(t.clone() for t in render(i)) for i in range(2)]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                for _ in range(60):
+                    got = render(i)
+                    st.synchronize()
+                    for a, b in zip(got, want[i]):
+                        if not torch.equal(a, b):
+                            errors.append(f"thread {i}: a frame differs from the scene rendered alone")
+                            return
+        except Exception as ex:      # noqa: BLE001
+            errors.append(f"thread {i}: {ex!r}")
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
