@@ -4,6 +4,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+if [ -n "$WANT_FAST_BOX" ]; then bash tools/gpu_box_probe.sh || exit 7; fi
 if [ -z "$SKIP_PROFILE" ]; then bash tools/gpu_profile.sh > gpurun_out/bundle_profile.log 2>&1; tail -6 gpurun_out/bundle_profile.log | cut -c1-400; fi
 if [ -z "$SKIP_TRAIN" ]; then
 timeout 1200 python tools/train_run.py --grad-threshold 0.00002 --tag _growth > gpurun_out/bundle_train_growth.log 2>&1
