@@ -85,6 +85,7 @@ def parse():
     ap.add_argument("--sort-items", type=int, default=0, help="keys per workgroup of the large radix passes (1024 / 2048 / 4096; 0 = library default)")
     ap.add_argument("--bwd-variant", type=int, default=None, help="render_bwd_variant (0 default, 1 atomics baseline, 2 128-entry super-batches)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="gsr_set_option(NAME, VALUE) before timing (A/B switches)")
+    ap.add_argument("--no-in-flight", action="store_true", help="skip the extra leg with three independent frames in flight on three HIP streams")
     ap.add_argument("--no-full-loop", action="store_true", help="skip the configs[2] leg: tools/train_run.py, the reference's 30 000-iteration "
                     "training loop with density control on its own schedule (about a minute)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short forward measurements of configs[3] (1 M @4K) and configs[4] (6 M @1080p)")
@@ -352,6 +353,32 @@ def _run(a):
         dt = timed_forward(forward_step_streams)
     ms_per_step = dt / a.steps * 1e3
     mpix_s = npix / (dt / a.steps) / 1e6
+
+    # for context only (NOT `value`): independent frames in flight on three HIP streams -- what a loop over a camera list can do
+    # (render.py:37-46 renders view after view, no frame depends on another).  Half of a frame's 11 launches are small latency-bound
+    # kernels (depth sort, histograms, scans) that leave most CUs idle; with three frames in flight they run beside another
+    # frame's preprocess / blend.  Every frame is rendered completely; the host still waits for every frame's R.  `value` stays
+    # the strictly sequential figure (one frame after the other on one stream = the latency of a frame, what a training step sees).
+    frames_in_flight = None
+    if world == 1 and a.streams == 1 and not a.no_in_flight:
+        fl_streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+        fl_count = [0]
+
+        def forward_step_in_flight():
+            st = fl_streams[fl_count[0] % 3]
+            fl_count[0] += 1
+            with torch.cuda.stream(st):
+                forward_step()
+        for st in fl_streams:
+            st.wait_stream(torch.cuda.current_stream(dev))
+        for _ in range(max(6, a.warmup)):
+            forward_step_in_flight()
+        sync_all()
+        fdt = timed_loop(forward_step_in_flight, a.steps, "forward_in_flight")[0]
+        event_stats.pop("forward_in_flight", None)      # (the loop's events sit on the default stream, not on the frames' streams)
+        frames_in_flight = {"streams": 3, "ms_per_frame": round(fdt / a.steps * 1e3, 4), "Mpix_s": round(npix / (fdt / a.steps) / 1e6, 1),
+                     "note": "independent frames alternating between 3 HIP streams (throughput of a camera-list loop); NOT `value`, which is "
+                             "one frame after the other on one stream"}
 
     # N > 1, for context only (NOT `value`): frame-parallel rendering -- every rank renders whole frames on its own (what
     # render.py does with a camera list split over GPUs): no collective at all, so it scales with N by construction, but it
@@ -961,6 +988,7 @@ def _run(a):
             "gpu_event_note": "per-step HIP-event intervals on the launch stream (median / p10 / p90 / mean) beside the wall-clock mean that "
                               "`value` uses; the host is paced by the per-frame R read-back, so the two agree when nothing stalls",
             "forward_cycled_views": cycled,
+            "forward_frames_in_flight": frames_in_flight,
             "forward_cycled_scenes": scene_cycle,
             "train_iters_per_s_depth_supervised": None if "ssim_depth" not in train else round(1e3 / train["ssim_depth"], 3),
             "frame_parallel_replicas": replicas,

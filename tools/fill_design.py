@@ -52,6 +52,8 @@ def main():
         ("stage times (library's HIP events, ms)", ", ".join(f"{n} {b['stage_ms'][n]:.4f}" for n in ("preprocess", "depth_sort", "emit", "tile_sort", "render", "r_wait"))),
         ("same box, round-3 library", sub["PREV_US"] + " µs per frame (round 3 → round 4)"),
         ("32 cameras cycled / 3 parameter sets cycled", f"{b['forward_cycled_views']['ms_per_frame']:.4f} / {b['forward_cycled_scenes']['ms_per_frame']:.4f} ms per frame"),
+    ] + ([("three independent frames in flight on 3 HIP streams (a camera-list loop; **not** `value`)",
+            f"{b['forward_frames_in_flight']['ms_per_frame']:.4f} ms per frame = {b['forward_frames_in_flight']['Mpix_s']:.0f} Mpix/s")] if b.get("forward_frames_in_flight") else []) + [
         ("train step (fused L1+SSIM loss, fused Adam)", f"**{b['train_iters_per_s']:.1f} it/s** ({b['train_ms_per_iter']:.4f} ms); SparseGaussianAdam + separate-SH form {b['train_iters_per_s_sparse_adam']:.1f}; L1 only {b['train_iters_per_s_l1']:.1f}; depth-supervised {b['train_iters_per_s_depth_supervised']:.1f}; SH step inside the backward {sh['dense_adam_sh_step_in_backward']:.1f} / {sh['sparse_adam_sh_step_in_backward']:.1f} (dense / sparse)"),
         ("backward stages (ms)", ", ".join(f"{n} {b['stage_ms'][n]:.4f}" for n in ("render_bwd", "gather_bwd", "preprocess_bwd"))),
         ("train with density control every 100 it. (P 1.03 → 1.23 M)", f"{b['train_iters_per_s_densify']:.1f} it/s"),

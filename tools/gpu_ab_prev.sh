@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp GSR_ALLOW_ABI_MISMATCH=1
 for rep in 1 2 3; do
   for lib in lib lib_prev; do
-    GSR_LIB="$PWD/gaussian-splatting_amd/$lib/libgsr_hip.so" timeout 300 python bench.py --no-other-configs --no-cpu-baseline --densify-iters 0 --train-steps ${TRAIN_STEPS:-0} $BENCH_EXTRA > gpurun_out/abp_${lib}_$rep.log 2>&1
+    GSR_LIB="$PWD/gaussian-splatting_amd/$lib/libgsr_hip.so" timeout 300 python bench.py --no-other-configs --no-cpu-baseline --no-in-flight --densify-iters 0 --train-steps ${TRAIN_STEPS:-0} $BENCH_EXTRA > gpurun_out/abp_${lib}_$rep.log 2>&1
     python - "$lib" "$rep" "gpurun_out/abp_${lib}_$rep.log" <<'PY'
 import json, sys
 try:

@@ -6,7 +6,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 mkdir -p gpurun_out
 LIMIT="${BOX_PROBE_LIMIT_MS:-0.368}"
-timeout 300 python bench.py --steps 40 --warmup 10 --train-steps 0 --no-cpu-baseline --no-full-loop --no-other-configs --densify-iters 0 --min-warm-seconds 1.0 > gpurun_out/box_probe.json 2> gpurun_out/box_probe.err || { echo "probe failed"; tail -5 gpurun_out/box_probe.err; exit 1; }
+timeout 300 python bench.py --steps 40 --warmup 10 --train-steps 0 --no-cpu-baseline --no-full-loop --no-other-configs --no-in-flight --densify-iters 0 --min-warm-seconds 1.0 > gpurun_out/box_probe.json 2> gpurun_out/box_probe.err || { echo "probe failed"; tail -5 gpurun_out/box_probe.err; exit 1; }
 python - "$LIMIT" <<'PY'
 import json, sys
 line = [l for l in open("gpurun_out/box_probe.json") if l.startswith("{")][-1]

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 R="$PWD"
 cd /tmp
 rm -rf "$R/gpurun_out/prof_k"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_k" -o r1 -- python "$R/bench.py" --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs --densify-iters 0 --train-steps 10 --min-warm-seconds 0.2 $BENCH_EXTRA > "$R/gpurun_out/k_prof.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_k" -o r1 -- python "$R/bench.py" --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs --no-in-flight --densify-iters 0 --train-steps 10 --min-warm-seconds 0.2 $BENCH_EXTRA > "$R/gpurun_out/k_prof.log" 2>&1
 cd "$R"
 python tools/kernel_trace_stats.py gpurun_out/prof_k gpurun_out/kernel_stats_steady.csv 0.25
 python - <<'PY'

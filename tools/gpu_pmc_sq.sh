@@ -4,8 +4,8 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 R="$PWD"
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d "$R/gpurun_out/prof_sq" -o r1 -- python "$R/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-full-loop --train-steps 4 --min-warm-seconds 0.2 > "$R/gpurun_out/p_prof_sq.log" 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_SALU --output-format csv -d "$R/gpurun_out/prof_sq2" -o r1 -- python "$R/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-full-loop --train-steps 4 --min-warm-seconds 0.2 > "$R/gpurun_out/p_prof_sq2.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d "$R/gpurun_out/prof_sq" -o r1 -- python "$R/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-full-loop --no-in-flight --train-steps 4 --min-warm-seconds 0.2 > "$R/gpurun_out/p_prof_sq.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_SALU --output-format csv -d "$R/gpurun_out/prof_sq2" -o r1 -- python "$R/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-full-loop --no-in-flight --train-steps 4 --min-warm-seconds 0.2 > "$R/gpurun_out/p_prof_sq2.log" 2>&1
 cd "$R"
 find gpurun_out/prof_sq gpurun_out/prof_sq2 -name "*kernel_trace*" -delete
 tail -3 gpurun_out/p_prof_sq.log | cut -c1-300; ls gpurun_out/prof_sq gpurun_out/prof_sq2

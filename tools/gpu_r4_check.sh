@@ -10,7 +10,7 @@ if grep -q "failed\|error" gpurun_out/r4_bins.log; then echo "BINS FAILED"; fi
 timeout 1500 python -m pytest tests -q -m gpu --tb=short 2>&1 | tail -60 > gpurun_out/r4_pytest.log
 echo "== whole gpu suite"; tail -30 gpurun_out/r4_pytest.log
 GSR_LIB= bash -c 'unset GSR_LIB; for rep in 1 2; do for m in 1 2; do
-  timeout 300 python bench.py --no-other-configs --no-cpu-baseline --densify-iters 0 --opt depth_sort_mode=$m > gpurun_out/r4_ab_${m}_$rep.log 2>&1
+  timeout 300 python bench.py --no-other-configs --no-cpu-baseline --no-in-flight --densify-iters 0 --opt depth_sort_mode=$m > gpurun_out/r4_ab_${m}_$rep.log 2>&1
   python - "$m" "$rep" "gpurun_out/r4_ab_${m}_$rep.log" <<PY
 import json, sys
 try:

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 R="$PWD"
 cd /tmp
-B="--steps 6 --warmup 2 --no-cpu-baseline --no-other-configs --densify-iters 0 --train-steps 0 --min-warm-seconds 0.2"
+B="--steps 6 --warmup 2 --no-cpu-baseline --no-other-configs --no-in-flight --densify-iters 0 --train-steps 0 --min-warm-seconds 0.2"
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d "$R/gpurun_out/prof_sq" -o r1 -- python "$R/bench.py" $B > "$R/gpurun_out/p_prof_sq.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_SALU --output-format csv -d "$R/gpurun_out/prof_sq2" -o r1 -- python "$R/bench.py" $B > "$R/gpurun_out/p_prof_sq2.log" 2>&1
 cd "$R"
