@@ -85,6 +85,9 @@ def parse():
     ap.add_argument("--sort-items", type=int, default=0, help="keys per workgroup of the large radix passes (1024 / 2048 / 4096; 0 = library default)")
     ap.add_argument("--bwd-variant", type=int, default=None, help="render_bwd_variant (0 default, 1 atomics baseline, 2 128-entry super-batches)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="gsr_set_option(NAME, VALUE) before timing (A/B switches)")
+    ap.add_argument("--exchange", default="exact", choices=["exact", "fixed"], help="N > 1, mode C: exact = count matrix read back by the host + variable-size "
+                    "all-to-all (default); fixed = fixed-capacity segments with the count in a header row, equal-split all-to-all, no count read-back "
+                    "(capacity learned from the first frame; overflow -> that frame repeats in the exact form)")
     ap.add_argument("--no-in-flight", action="store_true", help="skip the extra leg with three independent frames in flight on three HIP streams")
     ap.add_argument("--no-full-loop", action="store_true", help="skip the configs[2] leg: tools/train_run.py, the reference's 30 000-iteration "
                     "training loop with density control on its own schedule (about a minute)")
@@ -230,6 +233,10 @@ def _run(a):
             set_exact_strips(False)
         if mode == "C" and not collectives["all_to_all_single"]:
             mode = "B"
+    exch = None
+    if world > 1 and mode == "C":
+        from diff_gaussian_rasterization.parallel import set_exchange_mode
+        exch = set_exchange_mode(a.exchange)
     lo, hi = (P * rank) // world, (P * (rank + 1)) // world
     shard = None if mode not in ("A", "C") else tuple(t[lo:hi].contiguous() for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations))
     from diff_gaussian_rasterization.parallel import render_two_axis as _two_axis, padded_shard_size as _pad_size
@@ -960,6 +967,8 @@ def _run(a):
                                         "mode B x%d: replicated parameters, tile-row bands%s, strip all-gather of frame i overlapped with frame i+1")
                                        % (world, " (uniform)" if a.uniform_bands else " (instance-balanced)")),
                        "mode": mode, "collectives": collectives,
+                       "exchange": None if exch is None else {"form": exch.mode, "capacity": exch.capacity, "frames_exact": exch.frames_exact,
+                                                              "frames_fixed": exch.frames_fixed, "overflows": exch.overflows},
                        "render_fwd_variant": a.variant or 0, "options": os.environ.get("GSR_OPTIONS", ""),
                        "frame_streams": n_streams,
                        "frame_streams_note": "value = frames / time with consecutive frames alternating between HIP streams "

@@ -721,7 +721,7 @@ int gsr_preprocess_forward(const GsrRasterSettings* settings, int P, int M, cons
 }
 
 // shared body of gsr_rasterize_from_splats (64-byte records) / gsr_rasterize_from_packed (48-byte records)
-static int rasterize_from_records(const GsrRasterSettings* settings, int P, const float* records, bool packed, GsrResizeFn geom_resize,
+static int rasterize_from_records(const GsrRasterSettings* settings, int P, const float* records, bool packed, int seg_rows, GsrResizeFn geom_resize,
                                   void* geom_user, GsrResizeFn binning_resize, void* binning_user, GsrResizeFn image_resize,
                                   void* image_user, float* out_color, float* out_invdepth, int32_t* num_rendered, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -763,7 +763,7 @@ static int rasterize_from_records(const GsrRasterSettings* settings, int P, cons
     const GsrFrameStatsDev fs = frame_stats_for(lease, g, seq);
     int n_range;
     {   StageTimer t(GSR_STAGE_PREPROCESS, st);
-        if (packed) n_range = gsr_launch_ingest_packed(P, records, cam.tile_y0, cam.tile_y1, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], fs, st);
+        if (packed) n_range = gsr_launch_ingest_packed(P, records, cam.tile_y0, cam.tile_y1, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], fs, seg_rows, st);
         else n_range = gsr_launch_splat_ingest(P, records, cam.tile_y0, cam.tile_y1, g.splats, g.rect, g.tiles, g.keys[0], g.vals[0], fs, st);
     }
     STAGE_CHECK("splat ingest");
@@ -774,15 +774,27 @@ static int rasterize_from_records(const GsrRasterSettings* settings, int P, cons
 int gsr_rasterize_from_splats(const GsrRasterSettings* settings, int P, const float* splat_records, GsrResizeFn geom_resize,
                               void* geom_user, GsrResizeFn binning_resize, void* binning_user, GsrResizeFn image_resize,
                               void* image_user, float* out_color, float* out_invdepth, int32_t* num_rendered, void* stream) {
-    return rasterize_from_records(settings, P, splat_records, false, geom_resize, geom_user, binning_resize, binning_user, image_resize,
+    return rasterize_from_records(settings, P, splat_records, false, 0, geom_resize, geom_user, binning_resize, binning_user, image_resize,
                                   image_user, out_color, out_invdepth, num_rendered, stream);
 }
 
 int gsr_rasterize_from_packed(const GsrRasterSettings* settings, int P, const float* packed_records, GsrResizeFn geom_resize,
                               void* geom_user, GsrResizeFn binning_resize, void* binning_user, GsrResizeFn image_resize,
                               void* image_user, float* out_color, float* out_invdepth, int32_t* num_rendered, void* stream) {
-    return rasterize_from_records(settings, P, packed_records, true, geom_resize, geom_user, binning_resize, binning_user, image_resize,
+    return rasterize_from_records(settings, P, packed_records, true, 0, geom_resize, geom_user, binning_resize, binning_user, image_resize,
                                   image_user, out_color, out_invdepth, num_rendered, stream);
+}
+
+int gsr_rasterize_from_segments(const GsrRasterSettings* settings, int n_segments, int capacity, const float* segments,
+                                GsrResizeFn geom_resize, void* geom_user, GsrResizeFn binning_resize, void* binning_user,
+                                GsrResizeFn image_resize, void* image_user, float* out_color, float* out_invdepth,
+                                int32_t* num_rendered, void* stream) {
+    if (n_segments < 1 || n_segments > GSR_MAX_BANDS) return fail(GSR_ERR_INVALID_ARG, "n_segments must be 1..64");
+    if (capacity < 1) return fail(GSR_ERR_INVALID_ARG, "capacity < 1");
+    const int64_t rows = (int64_t)n_segments * ((int64_t)capacity + 1);
+    if (rows > 0x7FFFFFFFll) return fail(GSR_ERR_UNSUPPORTED, "n_segments * (capacity + 1) exceeds 2^31-1 rows");
+    return rasterize_from_records(settings, (int)rows, segments, true, capacity + 1, geom_resize, geom_user, binning_resize, binning_user,
+                                  image_resize, image_user, out_color, out_invdepth, num_rendered, stream);
 }
 
 // ---- Gaussian-sharded exchange (route.hip) ----
@@ -822,7 +834,33 @@ int gsr_route_pack(int P, const float* splat_records, int n_bands, const int32_t
     if (band_offsets[n_bands] == band_offsets[0]) return GSR_OK;      // nothing to send
     if (!splat_records || !scratch || !packed || !send_ids) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
     if (((uintptr_t)splat_records | (uintptr_t)packed) & 15) return fail(GSR_ERR_INVALID_ARG, "splat_records / packed must be 16-byte aligned");
-    gsr_launch_route_pack(P, splat_records, n_bands, band_bounds, band_offsets, (const uint32_t*)scratch, packed, send_ids, st);
+    gsr_launch_route_pack(P, splat_records, n_bands, band_bounds, band_offsets, (const uint32_t*)scratch, packed, send_ids, 0xFFFFFFFFu,
+                          nullptr, st);
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
+}
+
+int gsr_route_pack_fixed(int P, const float* splat_records, int n_bands, const int32_t* band_bounds, int capacity, const void* scratch,
+                         const uint32_t* band_counts, float* packed, int32_t* send_ids, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int rc = check_bands(n_bands, band_bounds);
+    if (rc != GSR_OK) return rc;
+    if (P < 0 || capacity < 1) return fail(GSR_ERR_INVALID_ARG, "P < 0 or capacity < 1");
+    if (!packed || !send_ids) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
+    if ((uintptr_t)packed & 15) return fail(GSR_ERR_INVALID_ARG, "packed must be 16-byte aligned");
+    const size_t seg_rows = (size_t)capacity + 1;
+    // unused rows and header rows carry the id -1 (gsr_route_return skips them)
+    HIP_OK(hipMemsetAsync(send_ids, 0xFF, sizeof(int32_t) * seg_rows * (size_t)n_bands, st));
+    if (P == 0) {      // an empty shard still sends its (zero) headers
+        for (int b = 0; b < n_bands; ++b) HIP_OK(hipMemsetAsync(packed + (size_t)b * seg_rows * 12, 0, 48, st));
+        return GSR_OK;
+    }
+    if (!splat_records || !scratch || !band_counts) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
+    if ((uintptr_t)splat_records & 15) return fail(GSR_ERR_INVALID_ARG, "splat_records must be 16-byte aligned");
+    int64_t off[GSR_MAX_BANDS + 1];
+    for (int b = 0; b <= n_bands; ++b) off[b] = (int64_t)b * (int64_t)seg_rows + 1;      // first record row of segment b
+    gsr_launch_route_pack(P, splat_records, n_bands, band_bounds, off, (const uint32_t*)scratch, packed, send_ids, (uint32_t)capacity,
+                          band_counts, st);
     HIP_OK(hipGetLastError());
     return GSR_OK;
 }

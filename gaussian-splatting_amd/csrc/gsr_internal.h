@@ -290,7 +290,8 @@ size_t gsr_route_scratch_bytes_impl(int P, int n_bands);
 void gsr_launch_route_count(int P, const float* records, int n_bands, const int32_t* bounds, uint32_t* block_counts,
                             uint32_t* band_counts, hipStream_t st);
 void gsr_launch_route_pack(int P, const float* records, int n_bands, const int32_t* bounds, const int64_t* band_offsets,
-                           const uint32_t* block_offsets, float* packed, int32_t* send_ids, hipStream_t st);
+                           const uint32_t* block_offsets, float* packed, int32_t* send_ids, uint32_t cap /*0xFFFFFFFF: no limit*/,
+                           const uint32_t* band_counts /*fixed-capacity form: header rows; else NULL*/, hipStream_t st);
 int gsr_launch_ingest_packed(int P, const float* packed, int y0, int y1, float4* splats, uint2* rect, uint32_t* tiles,
-                             uint32_t* keys, uint32_t* vals, const GsrFrameStatsDev& fs, hipStream_t st);
+                             uint32_t* keys, uint32_t* vals, const GsrFrameStatsDev& fs, int seg_rows /*0 or capacity + 1*/, hipStream_t st);
 void gsr_launch_route_add_rows(int64_t n, const int32_t* ids, const float* rows, float* out, hipStream_t st);

@@ -47,6 +47,7 @@ EXPORTS = [
     "gsr_rasterize_forward", "gsr_rasterize_backward", "gsr_backward_blend", "gsr_backward_preprocess",
     "gsr_preprocess_forward", "gsr_rasterize_from_splats",
     "gsr_route_scratch_bytes", "gsr_route_count", "gsr_route_pack", "gsr_rasterize_from_packed", "gsr_route_return",
+    "gsr_route_pack_fixed", "gsr_rasterize_from_segments",
     "gsr_mark_visible", "gsr_forward_views", "gsr_adam_step", "gsr_adam_step_multi", "gsr_backward_preprocess_sh_adam", "gsr_sparse_adam_step", "gsr_ssim_forward", "gsr_ssim_backward",
     "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_ssim_partial_count", "gsr_ssim_mean_forward", "gsr_ssim_mean_backward",
     "gsr_train_loss_forward", "gsr_train_loss_backward", "gsr_density_stats",
@@ -151,6 +152,13 @@ def load() -> C.CDLL:
                                                   RESIZE_FN, vp, vp, vp, C.POINTER(C.c_int32), vp]
         lib.gsr_route_return.restype = C.c_int
         lib.gsr_route_return.argtypes = [C.c_int, C.c_int, i64p, vp, vp, vp, vp]
+    if not missing or "gsr_route_pack_fixed" not in missing:
+        i32p = C.POINTER(C.c_int32)
+        lib.gsr_route_pack_fixed.restype = C.c_int
+        lib.gsr_route_pack_fixed.argtypes = [C.c_int, vp, C.c_int, i32p, C.c_int, vp, vp, vp, vp, vp]
+        lib.gsr_rasterize_from_segments.restype = C.c_int
+        lib.gsr_rasterize_from_segments.argtypes = [C.POINTER(GsrRasterSettings), C.c_int, C.c_int, vp, RESIZE_FN, vp, RESIZE_FN, vp,
+                                                    RESIZE_FN, vp, vp, vp, C.POINTER(C.c_int32), vp]
     lib.gsr_adam_step.restype = C.c_int
     lib.gsr_adam_step.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, vp]
     lib.gsr_adam_step_multi.restype = C.c_int

@@ -26,7 +26,12 @@ C. GAUSSIAN-SHARDED WITH A DESTINATION-TARGETED EXCHANGE (round 3; `render_gauss
     the band, which the replicated / all-gathered forms A and B cannot do;
   * backward: blend backward on the received set -> the reverse all-to-all of the 48-byte gradient rows ->
     gsr_route_return adds them into the shard's [P,12] record (band order, no atomics) -> per-Gaussian backward;
-  * one host sync per frame: the G x G count matrix (all-gather of G counters) sizes the exchange buffers.
+  * exact form: the G x G count matrix (all-gather of G counters) is read back by the host to size the variable all-to-all;
+  * FIXED-CAPACITY form (round 4, `set_exchange_mode("fixed")`): every (source, band) pair owns a segment of capacity + 1 rows
+    with the count in a header row, so the all-to-all has equal splits and NO count travels to the host.  The capacity is
+    learned from exact frames (largest entry of the count matrix x slack -- the same number on every rank); whether any segment
+    overflowed is all-reduced on the device and reaches the host with the frame's R read-back, which the frame has anyway; an
+    overflowing frame is repeated in the exact form by every rank and raises the capacity (ExchangePolicy).
 
 The band renderer / the two stages are injectable, so the index math and the collectives are tested on CPU with gloo
 and the oracle (tests/test_parallel_gloo.py); `hip_band_renderer` and `_TwoAxisHip` are the product's.
@@ -420,16 +425,161 @@ def exchange_counts(counts: torch.Tensor, group=None) -> Tuple[List[int], List[i
     """counts[G] (this rank's records per destination band, on the collective's device) -> (send_counts, recv_counts) as
     Python lists: ONE all-gather of the G counters gives every rank the G x G matrix, and its read-back is the single host
     sync of a Gaussian-sharded frame (all_to_all_single needs the split sizes on the host)."""
+    mat = exchange_count_matrix(counts, group)
+    rank = dist.get_rank(group) if _world(group) > 1 else 0
+    return mat[rank].tolist(), mat[:, rank].tolist()
+
+
+def exchange_count_matrix(counts: torch.Tensor, group=None) -> torch.Tensor:
+    """counts[G] on the collective's device -> the world x G matrix of all ranks' counts as a host int64 tensor (identical on
+    every rank): one all-gather + the read-back that is the exact form's host synchronisation."""
     world = _world(group)
-    if world == 1:
-        n = int(counts.sum().item())
-        return [n], [n]
-    rank = dist.get_rank(group)
     c = counts.to(torch.int64).contiguous()
+    if world == 1:
+        return c.view(1, -1).cpu()
     mat = torch.empty(world * c.numel(), dtype=torch.int64, device=c.device)
     dist.all_gather_into_tensor(mat, c, group=group)
-    mat = mat.view(world, -1).cpu()
-    return mat[rank].tolist(), mat[:, rank].tolist()
+    return mat.view(world, -1).cpu()
+
+
+class ExchangePolicy:
+    """How mode C moves the packed records.  Every rank of the group must hold the same settings; the state below evolves
+    identically on all of them because it only depends on all-gathered / all-reduced quantities.
+      mode "exact": count matrix read back by the host, variable-size all-to-all (round 3)
+      mode "fixed": fixed-capacity segments with the count in a header row, equal-split all-to-all, no host read-back of counts.
+                    Frames run exact until a capacity is known (and again after every overflow)."""
+
+    def __init__(self, mode: str = "exact", slack: float = 1.25, granule: int = 256):
+        if mode not in ("exact", "fixed"):
+            raise ValueError("exchange mode must be 'exact' or 'fixed'")
+        self.mode, self.slack, self.granule = mode, float(slack), int(granule)
+        self.capacity: Optional[int] = None      # record rows per (source, band) segment
+        self.frames_exact = self.frames_fixed = self.overflows = 0
+
+    def observe(self, max_count: int) -> None:
+        """max_count = the largest entry of the count matrix of an exact frame.  The capacity only grows (the envelope over the
+        cameras seen so far)."""
+        need = -(-int(max_count * self.slack + 1) // self.granule) * self.granule
+        self.capacity = max(self.capacity or 0, need, self.granule)
+
+    def use_fixed(self) -> bool:
+        return self.mode == "fixed" and self.capacity is not None
+
+
+_policies: dict = {}
+
+
+def set_exchange_mode(mode: str, group=None, slack: float = 1.25, granule: int = 256) -> ExchangePolicy:
+    """Select the exchange form of mode C for a process group (call on every rank with the same arguments)."""
+    _policies[group] = ExchangePolicy(mode, slack, granule)
+    return _policies[group]
+
+
+def exchange_policy(group=None) -> ExchangePolicy:
+    if group not in _policies:
+        _policies[group] = ExchangePolicy()
+    return _policies[group]
+
+
+def all_to_all_equal(send: torch.Tensor, group=None, async_op: bool = False):
+    """send[world * n, ...] -> recv of the same shape: block g of `send` goes to rank g, block g of `recv` came from rank g.
+    Returns (recv, work)."""
+    world = _world(group)
+    if world == 1:
+        return send, None
+    send = send.contiguous()
+    recv = torch.empty_like(send)
+    if send.is_cuda and dist.get_backend(group) == "gloo":      # CPU-test backend with device tensors, see all_to_all_rows
+        r_cpu = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(r_cpu, send.cpu(), group=group)
+        recv.copy_(r_cpu)
+        return recv, None
+    work = dist.all_to_all_single(recv, send, group=group, async_op=async_op)
+    return recv, (work if async_op else None)
+
+
+def any_rank_flag(flag: torch.Tensor, group=None) -> torch.Tensor:
+    """flag int32[1] on the collective's device -> max over the ranks, same device; no host synchronisation with RCCL."""
+    if _world(group) == 1:
+        return flag
+    if flag.is_cuda and dist.get_backend(group) == "gloo":
+        f = flag.cpu()
+        dist.all_reduce(f, op=dist.ReduceOp.MAX, group=group)
+        return f.to(flag.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    return flag
+
+
+_flag_ring: dict = {}
+
+
+def _pinned_flag(device) -> torch.Tensor:
+    """A pinned host int32[1] from a small per-device ring (several frames may be in flight)."""
+    ring = _flag_ring.setdefault(device, {"bufs": [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(8)], "next": 0})
+    t = ring["bufs"][ring["next"] % 8]
+    ring["next"] += 1
+    return t
+
+
+# ---- torch restatement of the fixed-capacity layout (CPU tests; the HIP kernels are checked against it on the GPU) ----
+def pack_fixed_torch(rows: torch.Tensor, counts: Sequence[int], capacity: int) -> torch.Tensor:
+    """rows[sum(counts), K] grouped by band -> [G * (capacity + 1), K]: per band a header row (column 0 = the count, column 1 =
+    the capacity, as VALUES -- the HIP form stores the same two numbers as integer bits) + the first min(count, capacity) rows;
+    unused rows are zero."""
+    G, K = len(counts), rows.shape[1]
+    out = rows.new_zeros(G * (capacity + 1), K)
+    pos = 0
+    for b, c in enumerate(counts):
+        base = b * (capacity + 1)
+        out[base, 0], out[base, 1] = float(c), float(capacity)
+        n = min(int(c), capacity)
+        out[base + 1:base + 1 + n] = rows[pos:pos + n]
+        pos += int(c)
+    return out
+
+
+def unpack_fixed_torch(segs: torch.Tensor, n_segments: int, capacity: int) -> Tuple[torch.Tensor, List[int]]:
+    """Inverse on the receiver: ([sum(min(count, capacity)), K] rows in segment order, the header counts)."""
+    parts, counts = [], []
+    for s_ in range(n_segments):
+        base = s_ * (capacity + 1)
+        c = int(segs[base, 0].item())
+        counts.append(c)
+        parts.append(segs[base + 1:base + 1 + min(c, capacity)])
+    return (torch.cat(parts, dim=0) if parts else segs[:0]), counts
+
+
+class _ExchangeRowsFixed(torch.autograd.Function):
+    """Differentiable fixed-capacity exchange of rows (the oracle path of the gloo tests): pack -> equal-split all-to-all -> unpack;
+    backward = the same exchange in reverse with the gradient rows in the same layout."""
+
+    @staticmethod
+    def forward(ctx, rows, counts, capacity, group):
+        world = _world(group)
+        recv_segs, _ = all_to_all_equal(pack_fixed_torch(rows.detach(), counts, capacity), group)
+        recv, rcounts = unpack_fixed_torch(recv_segs, world, capacity)
+        ctx.meta = ([min(int(c), capacity) for c in counts], [min(c, capacity) for c in rcounts], capacity, group, int(rows.shape[0]),
+                    [int(c) for c in counts])
+        return recv.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        kept, rkept, capacity, group, n_rows, counts = ctx.meta
+        back_segs, _ = all_to_all_equal(pack_fixed_torch(g.contiguous(), rkept, capacity), group)
+        out = g.new_zeros(n_rows, g.shape[1])
+        pos = 0
+        for b, (c, k) in enumerate(zip(counts, kept)):
+            base = b * (capacity + 1)
+            out[pos:pos + k] = back_segs[base + 1:base + 1 + k]
+            pos += c
+        return out, None, None, None
+
+
+def exchange_rows_fixed(rows: torch.Tensor, counts: Sequence[int], capacity: int, group=None) -> Tuple[torch.Tensor, bool]:
+    """-> (received rows, overflow anywhere in the group).  On overflow the received set is incomplete: repeat the frame exactly."""
+    flag = torch.tensor([1 if max([int(c) for c in counts] + [0]) > capacity else 0], dtype=torch.int32, device=rows.device)
+    flag = any_rank_flag(flag, group)
+    return _ExchangeRowsFixed.apply(rows, [int(c) for c in counts], int(capacity), group), bool(int(flag.item()))
 
 
 def all_to_all_rows(send: torch.Tensor, send_counts: Sequence[int], recv_counts: Sequence[int], group=None, async_op: bool = False):
@@ -553,6 +703,55 @@ def hip_route_pack(records: torch.Tensor, bounds: Sequence[int], send_counts: Se
     return packed, send_ids, offsets
 
 
+def hip_route_pack_fixed(records: torch.Tensor, bounds: Sequence[int], capacity: int, scratch: torch.Tensor, counts: torch.Tensor):
+    """gsr_route_pack_fixed: (segments[G * (capacity + 1), 12], send_ids int32[G * (capacity + 1)]) -- no host knowledge of the counts."""
+    from . import _lib, _ptr, _stream_ptr
+    lib = _lib.load()
+    device = records.device
+    P, G = int(records.shape[0]), len(bounds) - 1
+    rows = G * (int(capacity) + 1)
+    with torch.cuda.device(device):
+        packed = torch.empty(rows, PACKED_WORDS, dtype=torch.float32, device=device)
+        send_ids = torch.empty(rows, dtype=torch.int32, device=device)
+        _lib.check(lib.gsr_route_pack_fixed(P, _ptr(records), G, _i32_array(bounds), int(capacity), _ptr(scratch), _ptr(counts),
+                                            _ptr(packed), _ptr(send_ids), _stream_ptr(device)), "gsr_route_pack_fixed")
+    return packed, send_ids
+
+
+def hip_render_segments(raster_settings, band, segs: torch.Tensor, n_segments: int, capacity: int, no_backward: bool):
+    """gsr_rasterize_from_segments on this rank's band (see hip_render_packed); the state's Gaussian count is
+    n_segments * (capacity + 1)."""
+    import ctypes as C
+    from . import _lib, _Buffer, _make_settings, _ptr, _stream_ptr
+    lib = _lib.load()
+    device = segs.device
+    H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+    keep: list = []
+    with torch.cuda.device(device):
+        s = _make_settings(raster_settings, keep, band, no_backward)
+        color = torch.zeros(3, H, W, dtype=torch.float32, device=device)
+        invdepth = torch.zeros(1, H, W, dtype=torch.float32, device=device)
+        geom, binning, img = _Buffer(device, "geom"), _Buffer(device, "binning"), _Buffer(device, "image")
+        nr = C.c_int32(0)
+        _lib.check(lib.gsr_rasterize_from_segments(C.byref(s), int(n_segments), int(capacity), _ptr(segs), geom.cb, None, binning.cb,
+                                                   None, img.cb, None, _ptr(color), _ptr(invdepth), C.byref(nr), _stream_ptr(device)),
+                   "gsr_rasterize_from_segments")
+    return color, invdepth, (geom.t, binning.t, img.t, int(nr.value))
+
+
+def _fixed_exchange_forward(records, bounds, counts, rscratch, policy: ExchangePolicy, group, async_op: bool = False):
+    """The fixed-capacity exchange of one frame: -> (received segments, send_ids, pinned overflow flag, work).  The flag is valid on
+    the host once the frame's R read-back has returned (its copy is queued on the stream ahead of the ingest kernel that
+    publishes R)."""
+    cap = int(policy.capacity)
+    packed, send_ids = hip_route_pack_fixed(records, bounds, cap, rscratch, counts)
+    flag = any_rank_flag((counts.to(torch.int64) > cap).any().to(torch.int32).reshape(1), group)
+    host_flag = _pinned_flag(records.device)
+    host_flag.copy_(flag, non_blocking=True)
+    recv, work = all_to_all_equal(packed, group, async_op=async_op)
+    return recv, send_ids, host_flag, work, packed
+
+
 def hip_render_packed(raster_settings, band, recv: torch.Tensor, no_backward: bool):
     """gsr_rasterize_from_packed on this rank's band: (color[3,H,W], invdepth[1,H,W], state) with only the band's rows
     written (zeros elsewhere); state = (geom, binning, img, num_rendered) for gsr_backward_blend."""
@@ -584,13 +783,34 @@ class _GaussianShardedHip(torch.autograd.Function):
         records, radii, M, (m_c, sh_c, op_c, sc_c, rot_c, dc_c) = hip_preprocess_shard(raster_settings, means3D, sh, opacities,
                                                                                       scales, rotations, dc)
         counts, rscratch = hip_route_count(records, bounds)
-        send_counts, recv_counts = exchange_counts(counts, group)                    # the frame's one host sync
-        packed, send_ids, offsets = hip_route_pack(records, bounds, send_counts, rscratch)
-        recv, _ = all_to_all_rows(packed, send_counts, recv_counts, group)
         no_backward = not (any(ctx.needs_input_grad[:6]) or ctx.needs_input_grad[9])
-        color, invdepth, (geom, binning, img, nr) = hip_render_packed(raster_settings, plan.band(rank), recv, no_backward)
+        policy = exchange_policy(group)
+        G = len(bounds) - 1
+        done = False
+        if policy.use_fixed():
+            # fixed-capacity segments: no count reaches the host; the overflow flag arrives with the R read-back inside the render call
+            cap = int(policy.capacity)
+            recv, send_ids, host_flag, _, _ = _fixed_exchange_forward(records, bounds, counts, rscratch, policy, group)
+            color, invdepth, (geom, binning, img, nr) = hip_render_segments(raster_settings, plan.band(rank), recv, G, cap, no_backward)
+            if int(host_flag[0]) == 0:
+                policy.frames_fixed += 1
+                ctx.fixed_capacity = cap
+                ctx.send_counts = ctx.recv_counts = None
+                ctx.offsets = [b * (cap + 1) for b in range(G + 1)]
+                done = True
+            else:
+                policy.overflows += 1      # every rank sees the same flag: all repeat the frame in the exact form
+        if not done:
+            mat = exchange_count_matrix(counts, group)                               # the exact frame's host sync
+            policy.observe(int(mat.max()) if mat.numel() else 0)
+            policy.frames_exact += 1
+            send_counts, recv_counts = mat[rank].tolist(), mat[:, rank].tolist()
+            packed, send_ids, offsets = hip_route_pack(records, bounds, send_counts, rscratch)
+            recv, _ = all_to_all_rows(packed, send_counts, recv_counts, group)
+            color, invdepth, (geom, binning, img, nr) = hip_render_packed(raster_settings, plan.band(rank), recv, no_backward)
+            ctx.fixed_capacity = None
+            ctx.send_counts, ctx.recv_counts, ctx.offsets = send_counts, recv_counts, offsets
         ctx.raster_settings, ctx.band, ctx.group, ctx.M = raster_settings, plan.band(rank), group, M
-        ctx.send_counts, ctx.recv_counts, ctx.offsets = send_counts, recv_counts, offsets
         ctx.P_recv, ctx.num_rendered = int(recv.shape[0]), nr
         ctx.has_means2D, ctx.has_dc = means2D is not None, dc_c is not None
         ctx.op_shape = tuple(opacities.shape)
@@ -636,10 +856,13 @@ class _GaussianShardedHip(torch.autograd.Function):
                 full = scratch[off:off + P_recv * 48].view(torch.float32).view(P_recv, 12)
             else:
                 full = torch.empty(0, 12, **f)
-            returned, _ = all_to_all_rows(full, ctx.recv_counts, ctx.send_counts, ctx.group)      # rows back to their owners
+            if ctx.fixed_capacity is not None:      # same layout back: block g of the gradient rows belongs to rank g
+                returned, _ = all_to_all_equal(full, ctx.group)
+            else:
+                returned, _ = all_to_all_rows(full, ctx.recv_counts, ctx.send_counts, ctx.group)      # rows back to their owners
             if P > 0:
                 mine = torch.empty(P, 12, **f)
-                _lib.check(lib.gsr_route_return(P, len(ctx.send_counts), _i64_array(ctx.offsets), _ptr(send_ids), _ptr(returned),
+                _lib.check(lib.gsr_route_return(P, len(ctx.offsets) - 1, _i64_array(ctx.offsets), _ptr(send_ids), _ptr(returned),
                                                 _ptr(mine), st), "gsr_route_return")
                 _lib.check(lib.gsr_backward_preprocess(C.byref(s), P, M, _ptr(m), _ptr(sh), None, _ptr(op), _ptr(sc), _ptr(rot),
                                                        None, _ptr(radii), None, _ptr(mine), _ptr(d_m2), _ptr(d_col), _ptr(d_op),
@@ -668,7 +891,7 @@ def render_gaussian_sharded(raster_settings, means3D, sh, opacities, scales, rot
 class ShardedFrame:
     """A forward-only mode-C frame in flight (bench.py's pipelined forward): begin() has projected, routed and launched the
     all-to-all; finish() waits for it, renders the band and launches the strip all-gather."""
-    __slots__ = ("rs", "plan", "group", "recv", "work", "radii", "keep")
+    __slots__ = ("rs", "plan", "group", "recv", "work", "radii", "keep", "fixed", "flag", "inputs")
 
 
 def sharded_forward_begin(raster_settings, means3D, sh, opacities, scales, rotations, plan: BandPlan, group=None, dc=None) -> ShardedFrame:
@@ -677,9 +900,20 @@ def sharded_forward_begin(raster_settings, means3D, sh, opacities, scales, rotat
         records, radii, _, keep = hip_preprocess_shard(raster_settings, means3D, sh, opacities, scales, rotations, dc)
         bounds = list(plan.bounds)
         counts, rscratch = hip_route_count(records, bounds)
-        send_counts, recv_counts = exchange_counts(counts, group)
-        packed, _, _ = hip_route_pack(records, bounds, send_counts, rscratch)
-        fr.recv, fr.work = all_to_all_rows(packed, send_counts, recv_counts, group, async_op=True)
+        policy = exchange_policy(group)
+        fr.fixed, fr.flag = None, None
+        if policy.use_fixed():
+            fr.recv, _, fr.flag, fr.work, packed = _fixed_exchange_forward(records, bounds, counts, rscratch, policy, group, async_op=True)
+            fr.fixed = int(policy.capacity)
+            fr.inputs = (means3D, sh, opacities, scales, rotations, dc)      # (an overflowing frame is repeated in the exact form)
+        else:
+            mat = exchange_count_matrix(counts, group)
+            policy.observe(int(mat.max()) if mat.numel() else 0)
+            policy.frames_exact += 1
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+            send_counts, recv_counts = mat[rank].tolist(), mat[:, rank].tolist()
+            packed, _, _ = hip_route_pack(records, bounds, send_counts, rscratch)
+            fr.recv, fr.work = all_to_all_rows(packed, send_counts, recv_counts, group, async_op=True)
         fr.keep = (packed, records)      # alive until the collective has read them
     fr.rs, fr.plan, fr.group, fr.radii = raster_settings, plan, group, radii
     return fr
@@ -691,7 +925,20 @@ def sharded_forward_finish(fr: ShardedFrame):
     with torch.no_grad():
         if fr.work is not None:
             fr.work.wait()
-        color, _, _ = hip_render_packed(fr.rs, fr.plan.band(rank), fr.recv, True)
+        if fr.fixed is not None:
+            policy = exchange_policy(fr.group)
+            color, _, _ = hip_render_segments(fr.rs, fr.plan.band(rank), fr.recv, len(fr.plan.bounds) - 1, fr.fixed, True)
+            if int(fr.flag[0]) != 0:      # a segment overflowed somewhere (every rank reads the same flag): exact form, larger capacity
+                policy.overflows += 1
+                cap, policy.capacity = policy.capacity, None
+                redo = sharded_forward_begin(fr.rs, *fr.inputs[:5], fr.plan, fr.group, fr.inputs[5])
+                policy.capacity = max(policy.capacity or 0, cap)
+                fr.inputs = None
+                return sharded_forward_finish(redo)
+            policy.frames_fixed += 1
+            fr.inputs = None
+        else:
+            color, _, _ = hip_render_packed(fr.rs, fr.plan.band(rank), fr.recv, True)
         fr.keep = None
         return gather_strips_async(color, fr.plan, int(fr.rs.image_height), fr.group)
 

@@ -221,6 +221,28 @@ int gsr_route_return(int P, int n_bands, const int64_t* band_offsets, const int3
                      float* splat_grads, void* stream);
 
 /*
+ * FIXED-CAPACITY form of the same exchange (round 4): no count matrix travels to the host before the records do.
+ * gsr_route_pack_fixed lays the records of band b into a segment of capacity + 1 rows of `packed` (and of `send_ids`):
+ *   row b*(capacity+1)            header: word 0 = band_counts[b] (may exceed capacity), word 1 = capacity, rest 0; send id -1
+ *   rows .. + 1 .. + capacity     the first min(band_counts[b], capacity) records of the band, stable; unused rows: send id -1
+ * Segment sizes do not depend on the counts, so the all-to-all has equal splits.  The receiver passes the n_segments segments it
+ * got (rank order) to gsr_rasterize_from_segments: header rows and rows past a segment's count enter the frame as Gaussians
+ * without tiles (P = n_segments * (capacity + 1) for gsr_backward_blend / gsr_backward_scratch_bytes), so depth ties still resolve
+ * in (source rank, index) order.  The gradient rows go back in the same layout; gsr_route_return with band_offsets[b] =
+ * b*(capacity+1) skips the rows whose send id is negative.  A segment whose count exceeds the capacity has lost records: the
+ * caller compares band_counts with the capacity ON THE DEVICE, agrees on the outcome with the other ranks and repeats the frame
+ * with the exact form (parallel.py does this without an extra host synchronisation).
+ *   band_counts : DEVICE uint32[n_bands] as written by gsr_route_count;  scratch as for gsr_route_pack
+ */
+int gsr_route_pack_fixed(int P, const float* splat_records, int n_bands, const int32_t* band_bounds, int capacity,
+                         const void* scratch, const uint32_t* band_counts, float* packed, int32_t* send_ids, void* stream);
+int gsr_rasterize_from_segments(const GsrRasterSettings* settings, int n_segments, int capacity, const float* segments,
+                                GsrResizeFn geom_resize, void* geom_user,
+                                GsrResizeFn binning_resize, void* binning_user,
+                                GsrResizeFn image_resize, void* image_user,
+                                float* out_color, float* out_invdepth, int32_t* num_rendered, void* stream);
+
+/*
  * OPT-IN fusion of the optimizer into the backward (no reference counterpart): gsr_backward_preprocess for the split-SH form
  * (settings->sh_dc = coefficient 0 [P,1,3], shs_rest = coefficients 1..15 [P,15,3], M = 16) that does NOT write the two SH
  * gradients but applies their Adam step in place, from the gradient tile in LDS: the gradient (204 B per Gaussian) never travels

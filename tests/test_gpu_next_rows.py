@@ -237,7 +237,7 @@ def test_distcuda2_large_cloud_and_init_scales():
         distCUDA2(torch.zeros(10, 3))
 
 
-@pytest.mark.parametrize("mode,nproc", [("C", 2), ("C", 3), ("B", 2), ("A", 2)])
+@pytest.mark.parametrize("mode,nproc", [("C", 2), ("C", 3), ("B", 2), ("A", 2), ("C-fixed", 2), ("C-fixed", 3)])
 def test_bench_multi_rank_path_on_one_gpu(mode, nproc):
     """bench.py's N > 1 code path end to end -- first-contact probe of the collectives, band plan, mode C (Gaussian shards,
     route kernels, variable-size all-to-all of packed records forward and of gradient rows backward, pipelined frames) or
@@ -256,7 +256,11 @@ def test_bench_multi_rank_path_on_one_gpu(mode, nproc):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc),
            "--steps", "3", "--warmup", "1", "--P", "60000", "--width", "640", "--height", "368", "--no-cpu-baseline",
-           "--min-warm-seconds", "0.2", "--mode", mode]
+           "--min-warm-seconds", "0.2", "--mode", mode.split("-")[0]]
+    fixed = mode.endswith("-fixed")      # the fixed-capacity form of mode C's exchange (no count matrix on the host)
+    if fixed:
+        cmd += ["--exchange", "fixed"]
+        mode = "C"
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -267,6 +271,9 @@ def test_bench_multi_rank_path_on_one_gpu(mode, nproc):
     assert d["config"]["mode"] == mode and d["config"]["collectives"]["all_to_all_single"]      # (A / B / C as asked: the probe found every collective)
     # (the fraction itself can round to 0.0 here: three processes time-slice one GPU and the stage times are mostly waiting)
     assert d["roofline"]["frac"] >= 0 and d["blend_work"]["fwd_pair_steps_per_launch"] > 0 and d["cpu_baseline"] is None
+    if fixed:
+        ex = d["config"]["exchange"]
+        assert ex["form"] == "fixed" and ex["capacity"] > 0 and ex["frames_fixed"] > ex["frames_exact"] >= 1, ex
 
 
 def test_bench_reports_an_error_line_instead_of_dying_silently():

@@ -225,3 +225,156 @@ def test_band_that_receives_no_record_shows_the_background(no_backward):
     want = torch.zeros(3, 120, 200)
     want[:, 80:, :] = bg.view(3, 1, 1)
     assert torch.equal(color.cpu(), want)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# fixed-capacity form of the exchange (round 4): segments with the count in a header row
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("P,bounds,capacity", [(5001, [0, 5, 13], 4096), (5001, [0, 5, 13], 700), (20000, [0, 2, 2, 9, 13], 8192),
+                                               (4097, [0, 1, 2, 3, 4, 5, 6, 7, 13], 300)])
+def test_fixed_capacity_pack_matches_the_exact_pack(P, bounds, capacity):
+    """gsr_route_pack_fixed lays the records of band b into rows b*(capacity+1)+1.. of the segment buffer: the header row carries
+    (count, capacity) as integer bits, the first min(count, capacity) records are those of gsr_route_pack bit for bit in the same
+    order, the send ids of header rows and unused rows are -1 (also when a band overflows the capacity)."""
+    from diff_gaussian_rasterization.parallel import hip_preprocess_shard, hip_route_count, hip_route_pack, hip_route_pack_fixed
+    dev = torch.device("cuda:0")
+    cam = make_camera(336, 200)
+    sc = make_scene(P, cam, seed=5, s_med=0.04).to(dev)
+    rs = gpu_settings(oracle_settings(cam), dev)
+    records, radii, M, _ = hip_preprocess_shard(rs, sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)
+    counts, scratch = hip_route_count(records, bounds)
+    want_counts = counts.cpu().tolist()
+    packed, send_ids, offsets = hip_route_pack(records, bounds, want_counts, scratch)
+    segs, seg_ids = hip_route_pack_fixed(records, bounds, capacity, scratch, counts)
+    torch.cuda.synchronize()
+    G = len(bounds) - 1
+    assert segs.shape == (G * (capacity + 1), 12) and seg_ids.shape == (G * (capacity + 1),)
+    overflowed = False
+    for b in range(G):
+        base = b * (capacity + 1)
+        hdr = segs[base].view(torch.int32).cpu().tolist()
+        assert hdr[0] == want_counts[b] and hdr[1] == capacity and all(v == 0 for v in hdr[2:])
+        n = min(want_counts[b], capacity)
+        overflowed |= want_counts[b] > capacity
+        assert int(seg_ids[base]) == -1
+        assert torch.equal(seg_ids[base + 1:base + 1 + n], send_ids[offsets[b]:offsets[b] + n])
+        assert bool((seg_ids[base + 1 + n:base + capacity + 1] == -1).all())
+        assert torch.equal(segs[base + 1:base + 1 + n].view(torch.int32), packed[offsets[b]:offsets[b] + n].view(torch.int32))
+    assert overflowed == (capacity < max(want_counts))
+
+
+def test_fixed_capacity_pieces_three_shards_three_bands_on_one_gpu():
+    """The fixed-capacity pieces driven by hand for 3 Gaussian shards x 3 bands on one GPU (the equal-split all-to-all replaced by
+    slicing + concatenation in rank order): header rows and unused rows enter a band's frame as Gaussians without tiles, so every
+    band still renders bit-identically to the fused operator; the gradient rows go back in the same layout and
+    gsr_route_return (which skips the rows with id -1) gives every shard its [P,12] record -> parameter gradients."""
+    from diff_gaussian_rasterization import _lib, _make_settings, _ptr, _stream_ptr
+    from diff_gaussian_rasterization.parallel import (hip_preprocess_shard, hip_route_count, hip_route_pack_fixed, hip_render_segments,
+                                                     _i64_array)
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    W, H = 336, 200
+    cam = make_camera(W, H)
+    sc = make_edge_scene(6001, cam, seed=17).to(dev)
+    rs = gpu_settings(oracle_settings(cam, bg=torch.tensor([0.3, 0.1, 0.2])), dev)
+    g = torch.Generator().manual_seed(9)
+    wgt, wd = torch.randn(3, H, W, generator=g).to(dev), torch.randn(1, H, W, generator=g).to(dev)
+    col, radii, invd, ref = _fused_reference(rs, sc, wgt, wd, dev)
+    cuts, bounds = [0, 1900, 1900 + 2500, 6001], [0, 4, 9, 13]
+    G, cap = 3, 2560
+    seg = cap + 1
+    st = _stream_ptr(dev)
+    shards = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        t = [x[a:b].contiguous() for x in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+        records, rad, M, _ = hip_preprocess_shard(rs, *t)
+        counts, scratch = hip_route_count(records, bounds)
+        assert int(counts.max()) <= cap
+        segs, seg_ids = hip_route_pack_fixed(records, bounds, cap, scratch, counts)
+        shards.append(dict(t=t, rad=rad, segs=segs, ids=seg_ids, a=a, b=b))
+    image = torch.zeros(3, H, W, device=dev)
+    depth = torch.zeros(1, H, W, device=dev)
+    returned = [[None] * G for _ in range(G)]
+    for band in range(G):
+        recv = torch.cat([sh["segs"][band * seg:(band + 1) * seg] for sh in shards], dim=0).contiguous()      # = the all-to-all
+        color, invdp, (geom, binning, img, nr) = hip_render_segments(rs, (bounds[band], bounds[band + 1]), recv, G, cap, False)
+        rows = slice(bounds[band] * 16, min(bounds[band + 1] * 16, H))
+        image[:, rows], depth[:, rows] = color[:, rows], invdp[:, rows]
+        gc, gd = torch.zeros_like(wgt), torch.zeros_like(wd)
+        gc[:, rows], gd[:, rows] = wgt[:, rows], wd[:, rows]
+        keep = []
+        s = _make_settings(rs, keep, (bounds[band], bounds[band + 1]))
+        P_recv = G * seg
+        scr = torch.empty(int(lib.gsr_backward_scratch_bytes(P_recv, nr)), dtype=torch.uint8, device=dev)
+        rp = C.c_void_p(0)
+        _lib.check(lib.gsr_backward_blend(C.byref(s), P_recv, nr, _ptr(geom), _ptr(binning), _ptr(img), _ptr(gc), _ptr(gd),
+                                          _ptr(scr), C.byref(rp), st), "gsr_backward_blend")
+        off = int(rp.value) - scr.data_ptr()
+        full = scr[off:off + P_recv * 48].view(torch.float32).view(P_recv, 12).clone()
+        for src in range(G):
+            returned[src][band] = full[src * seg:(src + 1) * seg]
+    torch.cuda.synchronize()
+    assert torch.equal(image, col) and torch.equal(depth, invd)
+    f = dict(dtype=torch.float32, device=dev)
+    for src, sh in enumerate(shards):
+        P = sh["b"] - sh["a"]
+        back = torch.cat(returned[src], dim=0).contiguous()
+        mine = torch.empty(P, 12, **f)
+        _lib.check(lib.gsr_route_return(P, G, _i64_array([bnd * seg for bnd in range(G + 1)]), _ptr(sh["ids"]), _ptr(back), _ptr(mine), st),
+                   "gsr_route_return")
+        want = torch.zeros(P, 12, **f)
+        for band in range(G):
+            ids = sh["ids"][band * seg:(band + 1) * seg].long()
+            ok = ids >= 0
+            want.index_add_(0, ids[ok], returned[src][band][ok])
+        assert torch.equal(mine, want)
+        outs = [torch.empty(P, 3, **f), torch.empty(P, 3, **f), torch.empty(P, 1, **f), torch.empty(P, 3, **f), torch.empty(P, 6, **f),
+                torch.empty(P, 16, 3, **f), torch.empty(P, 3, **f), torch.empty(P, 4, **f)]
+        keep = []
+        s = _make_settings(rs, keep, None)
+        t = sh["t"]
+        _lib.check(lib.gsr_backward_preprocess(C.byref(s), P, 16, _ptr(t[0]), _ptr(t[1]), None, _ptr(t[2]), _ptr(t[3]), _ptr(t[4]), None,
+                                               _ptr(sh["rad"]), None, _ptr(mine), *[_ptr(o) for o in outs], st), "gsr_backward_preprocess")
+        torch.cuda.synchronize()
+        d_m2, _, d_op, d_m3, _, d_sh, d_sc, d_rot = outs
+        a, b = sh["a"], sh["b"]
+        for got, w in zip([d_m3, d_sh, d_op, d_sc, d_rot, d_m2], ref):
+            assert (got.view(-1) - w[a:b].reshape(-1)).abs().max().item() <= 5e-5 * w.abs().max().item()
+
+
+def test_gaussian_sharded_fixed_mode_learns_the_capacity_and_falls_back_on_overflow():
+    """render_gaussian_sharded with set_exchange_mode("fixed") on one rank: the first frame runs the exact form and teaches the
+    policy its capacity, the following frames use fixed-capacity segments (no count read-back) and reproduce the fused operator --
+    image / radii / inverse depth bit for bit, gradients to rounding; a capacity that has become too small (another camera) is
+    noticed through the overflow flag, the frame is repeated in the exact form and the capacity grows."""
+    from diff_gaussian_rasterization.parallel import BandPlan, render_gaussian_sharded, set_exchange_mode
+    dev = torch.device("cuda:0")
+    cam = make_camera(320, 208)
+    sc = make_scene(6000, cam, seed=31, s_med=0.03).to(dev)
+    rs = gpu_settings(oracle_settings(cam, bg=torch.tensor([0.1, 0.3, 0.2])), dev)
+    g = torch.Generator().manual_seed(3)
+    wgt, wd = torch.randn(3, 208, 320, generator=g).to(dev), torch.randn(1, 208, 320, generator=g).to(dev)
+    col, radii, invd, ref = _fused_reference(rs, sc, wgt, wd, dev)
+    plan = BandPlan.uniform(13, 1)
+    policy = set_exchange_mode("fixed")
+    try:
+        for frame in range(3):
+            L = [t.detach().clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+            m2 = torch.zeros(sc.P, 3, device=dev, requires_grad=True)
+            c2, r2, d2 = render_gaussian_sharded(rs, L[0], L[1], L[2], L[3], L[4], plan, means2D=m2)
+            assert torch.equal(c2, col) and torch.equal(r2, radii) and torch.equal(d2, invd), f"frame {frame}"
+            ((c2 * wgt).sum() + (d2 * wd).sum()).backward()
+            for got, want in zip([t.grad for t in L] + [m2.grad], ref):
+                assert (got - want).abs().max().item() <= 5e-5 * want.abs().max().item(), f"frame {frame}"
+        assert (policy.frames_exact, policy.frames_fixed, policy.overflows) == (1, 2, 0)
+        learned = policy.capacity
+        policy.capacity = 256                                   # far below the ~5 000 records of the band
+        with torch.no_grad():
+            c3, r3, d3 = render_gaussian_sharded(rs, sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations, plan)
+        assert torch.equal(c3, col) and torch.equal(d3, invd)
+        assert policy.overflows == 1 and policy.frames_exact == 2 and policy.capacity == learned
+        with torch.no_grad():
+            c4, _, _ = render_gaussian_sharded(rs, sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations, plan)
+        assert torch.equal(c4, col) and policy.frames_fixed == 3
+    finally:
+        set_exchange_mode("exact")

@@ -348,3 +348,88 @@ def test_gaussian_sharded_equals_single_device(world):
             ba, bb = (int(v) for v in o["bins"]["ranges"][t])
             assert rb - ra == bb - ba
             assert torch.equal(o["bins"]["point_gid"][ba:bb], aux["point_list"][ra:rb])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# mode C, fixed-capacity form of the exchange (round 4): no count matrix on the host, overflow agreed through an all-reduced flag
+# ------------------------------------------------------------------------------------------------------------------
+def _fixed_exchange_worker(rank, world, port, path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from diff_gaussian_rasterization.parallel import (BandPlan, ExchangePolicy, exchange_count_matrix, exchange_rows, exchange_rows_fixed,
+                                                     route_plan_torch)
+    cam = make_camera(112, 96)
+    sc = make_edge_scene(500, cam, seed=33)
+    s = oracle_settings(cam)
+    plan = {2: BandPlan([0, 2, 6]), 3: BandPlan([0, 1, 4, 6]), 4: BandPlan([0, 1, 3, 3, 6])}[world]
+    cuts = {2: [0, 230, 500], 3: [0, 100, 333, 500], 4: [0, 100, 100, 333, 500]}[world]
+    a, b = cuts[rank], cuts[rank + 1]
+    pre = O.preprocess(sc.means3D[a:b], sc.opacities[a:b], s, shs=sc.shs[a:b], scales=sc.scales[a:b], rotations=sc.rotations[a:b])
+    rows = torch.cat([pre["means2D"], pre["conic"], pre["depths"][:, None], (torch.arange(a, b, dtype=torch.float32))[:, None]], dim=1)
+    send_index, counts = route_plan_torch(pre["rect"][:, 1], pre["rect"][:, 3], pre["tiles_touched"], plan.bounds)
+    send = rows.index_select(0, send_index).clone().requires_grad_(True)
+    # exact frame: the policy learns the capacity from the all-gathered matrix (the same number on every rank)
+    policy = ExchangePolicy("fixed", slack=1.25, granule=8)
+    assert not policy.use_fixed()
+    mat = exchange_count_matrix(torch.tensor(counts, dtype=torch.int64))
+    policy.observe(int(mat.max()))
+    exact = exchange_rows(send, mat[rank].tolist(), mat[:, rank].tolist())
+    w = torch.randn(exact.shape, generator=torch.Generator().manual_seed(5 + rank))
+    (exact * w).sum().backward()
+    g_exact = send.grad.clone()
+    send.grad = None
+    # fixed frame with the learned capacity: same rows in the same order, same gradient rows back, no overflow
+    assert policy.use_fixed() and policy.capacity >= int(mat.max()) and policy.capacity % 8 == 0
+    fixed, ovf = exchange_rows_fixed(send, counts, policy.capacity)
+    assert not ovf and torch.equal(fixed, exact)
+    (fixed * w).sum().backward()
+    assert torch.equal(send.grad, g_exact)
+    # a capacity below the largest segment: EVERY rank must learn of the overflow, also the ones whose own segments fit
+    small = max(1, int(mat.max()) - 1)
+    _, ovf2 = exchange_rows_fixed(send.detach(), counts, small)
+    own_fits = max(counts + [0]) <= small and int(mat[:, rank].max()) <= small
+    torch.save({"capacity": policy.capacity, "max": int(mat.max()), "ovf2": ovf2, "own_fits": own_fits}, path % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_fixed_capacity_exchange_equals_exact_and_agrees_on_overflow(world):
+    """The fixed-capacity exchange (segments of capacity + 1 rows with the count in a header row, equal-split all-to-all) delivers
+    exactly the rows of the variable-size exchange, in the same order, forward and backward; the capacity a policy learns from the
+    count matrix is the same on every rank; an overflow anywhere is seen by every rank (uneven shards / bands, an empty shard and
+    an empty band at world 4)."""
+    import tempfile
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "rank%d.pt")
+        procs = [ctx.Process(target=_fixed_exchange_worker, args=(r, world, port, path)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        outs = [torch.load(path % r) for r in range(world)]
+    assert len({o["capacity"] for o in outs}) == 1 and len({o["max"] for o in outs}) == 1
+    assert all(o["ovf2"] for o in outs)
+    assert any(o["own_fits"] for o in outs) or world == 2      # some rank only knows through the all-reduce
+
+
+def test_exchange_policy_capacity_only_grows():
+    from diff_gaussian_rasterization.parallel import ExchangePolicy
+    p = ExchangePolicy("fixed", slack=1.25, granule=256)
+    assert not p.use_fixed()
+    p.observe(1000)
+    assert p.capacity == 1280 and p.use_fixed()
+    p.observe(10)
+    assert p.capacity == 1280
+    p.observe(2000)
+    assert p.capacity == 2560
+    q = ExchangePolicy("exact")
+    q.observe(5)
+    assert not q.use_fixed()
+    with pytest.raises(ValueError):
+        ExchangePolicy("sometimes")

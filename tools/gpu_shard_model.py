@@ -20,6 +20,10 @@ Reported per G: the slowest rank's GPU time, the collectives, and two speed-ups 
     serial     = T1 / (GPU time + both collectives + count sync)         (one frame, nothing overlapped: the latency view)
 
     python tools/gpu_shard_model.py            # configs[1], [3], [4] stand-ins + the clustered scene
+Round 4: the FIXED-CAPACITY form of the exchange (no count matrix on the host; segments of capacity + 1 rows, capacity = what
+parallel.ExchangePolicy learns from the frame's own count matrix, x 1.25 rounded up to 256) is measured beside it: route_fixed /
+band_fixed per rank (the padding rows enter the band's frame as tile-less Gaussians), the all-to-all modelled on capacity x 48 B per
+peer, and the two speed-ups without COUNT_SYNC_US ("*_fixed").
 Output: one JSON document on stdout (also gpurun_out/shard_model.json)."""
 import json
 import os
@@ -32,8 +36,8 @@ import torch
 from gsr_synth import make_camera, make_scene, make_clustered_scene
 from diff_gaussian_rasterization import GaussianRasterizationSettings, rasterize_gaussians, _lib
 from diff_gaussian_rasterization.debug import forward_with_views
-from diff_gaussian_rasterization.parallel import (BandPlan, row_costs_from_ranges, hip_preprocess_shard, hip_route_count, hip_route_pack,
-                                                 hip_render_packed)
+from diff_gaussian_rasterization.parallel import (BandPlan, ExchangePolicy, row_costs_from_ranges, hip_preprocess_shard, hip_route_count,
+                                                 hip_route_pack, hip_route_pack_fixed, hip_render_packed, hip_render_segments)
 
 dev = torch.device("cuda:0")
 LINKS, LINK_GBS, HOP_US, COUNT_SYNC_US = 7, 153.0, 15.0, 25.0
@@ -90,6 +94,15 @@ for name, P, W, H, kind in (("configs[1] 1M@1080p", 1_000_000, 1920, 1080, "unif
                 packed, _, offs = hip_route_pack(records, bounds, sc_counts, scratch)
                 shards.append(t)
                 packs.append((packed, offs, sc_counts))
+        pol = ExchangePolicy("fixed")
+        pol.observe(max(max(pk[2]) for pk in packs))
+        cap = int(pol.capacity)
+        fixed_segs = []
+        with torch.no_grad():
+            for g in range(G):
+                records, _, _, _ = hip_preprocess_shard(rs, *shards[g])
+                counts, scratch = hip_route_count(records, bounds)
+                fixed_segs.append(hip_route_pack_fixed(records, bounds, cap, scratch, counts)[0])
         per = []
         for g in range(G):
             t = shards[g]
@@ -108,9 +121,22 @@ for name, P, W, H, kind in (("configs[1] 1M@1080p", 1_000_000, 1920, 1080, "unif
             def band():
                 with torch.no_grad():
                     hip_render_packed(rs, plan.band(g), recv, True)
+
+            def route_fixed():
+                with torch.no_grad():
+                    c, scr = hip_route_count(holder["rec"], bounds)
+                    hip_route_pack_fixed(holder["rec"], bounds, cap, scr, c)
+            recv_fixed = torch.cat([fixed_segs[src][g * (cap + 1):(g + 1) * (cap + 1)] for src in range(G)], dim=0).contiguous()
+
+            def band_fixed():
+                with torch.no_grad():
+                    hip_render_segments(rs, plan.band(g), recv_fixed, G, cap, True)
             ms_project = median_ms(project)
             ms_route = median_ms(route)
             ms_band = median_ms(band)
+            ms_route_fixed = median_ms(route_fixed)
+            ms_band_fixed = median_ms(band_fixed)
+            del recv_fixed
             _lib.profile_reset(); _lib.profile_enable(True)
             for _ in range(5):
                 band()
@@ -124,17 +150,26 @@ for name, P, W, H, kind in (("configs[1] 1M@1080p", 1_000_000, 1920, 1080, "unif
             per.append({"rank": g, "band": plan.band(g), "P_shard": cuts[g + 1] - cuts[g], "P_received": int(recv.shape[0]),
                         "rows_sent_to_others": int(sum(sent) - sent[g]), "project_ms": round(ms_project, 4), "route_ms": round(ms_route, 4),
                         "band_ms": round(ms_band, 4), "gpu_ms": round(ms_project + ms_route + ms_band, 4), "band_stage_ms": stage,
+                        "route_fixed_ms": round(ms_route_fixed, 4), "band_fixed_ms": round(ms_band_fixed, 4),
+                        "gpu_fixed_ms": round(ms_project + ms_route_fixed + ms_band_fixed, 4),
                         "all_to_all_model_us": round(a2a_us, 1)})
             del recv
         gpu = max(p["gpu_ms"] for p in per)
         a2a = max(p["all_to_all_model_us"] for p in per)
         strips_us = HOP_US + strip_bytes * (G - 1) / G / (min(G - 1, LINKS) * LINK_GBS * 1e3)
         total_rows = sum(sum(pk[2]) for pk in packs)
+        gpu_f = max(p["gpu_fixed_ms"] for p in per)
+        a2a_f = HOP_US + (cap + 1) * 48 / (LINK_GBS * 1e3)
         res[str(G)] = {"slowest_rank_gpu_ms": round(gpu, 4), "all_to_all_model_us": a2a, "strip_allgather_model_us": round(strips_us, 1),
                        "count_sync_us": COUNT_SYNC_US, "rows_exchanged_over_visible": round(total_rows / max(1, V), 3),
                        "speedup_pipelined": round(t1 / max(gpu, a2a * 1e-3, strips_us * 1e-3), 2),
-                       "speedup_serial": round(t1 / (gpu + (a2a + strips_us + COUNT_SYNC_US) * 1e-3), 2), "ranks": per}
-        del shards, packs
+                       "speedup_serial": round(t1 / (gpu + (a2a + strips_us + COUNT_SYNC_US) * 1e-3), 2),
+                       "fixed_exchange": {"capacity": cap, "rows_padded_over_rows_exact": round(G * G * (cap + 1) / max(1, total_rows), 3),
+                                          "slowest_rank_gpu_ms": round(gpu_f, 4), "all_to_all_model_us": round(a2a_f, 1),
+                                          "speedup_pipelined": round(t1 / max(gpu_f, a2a_f * 1e-3, strips_us * 1e-3), 2),
+                                          "speedup_serial": round(t1 / (gpu_f + (a2a_f + strips_us) * 1e-3), 2)},
+                       "ranks": per}
+        del shards, packs, fixed_segs
         torch.cuda.empty_cache()
     out[name] = res
     del sc
