@@ -68,6 +68,20 @@ def main():
         ("roofline (blend backward)", f"{rt['achieved']:.1f} TFLOP/s = {rt['frac']:.3f}; PMC traffic {(rt['traffic'] or 0) / 1e6:.0f} MB / launch"),
         ("CPU baseline (oracle, same frame)", f"{cpu['value']:.4f} Mpix/s on {cpu['cores']} cores ({cpu['seconds_per_frame']:.1f} s per frame)"),
     ]
+    sm_path = os.path.join(ROOT, "profiles", f"{TAG}_shard_model.json")
+    if os.path.exists(sm_path):
+        sm = json.load(open(sm_path))
+        for name, cfg in sm.items():
+            parts = []
+            for G in ("2", "4", "8"):
+                e = cfg.get(G)
+                if not e:
+                    continue
+                t = f"{G} GPUs {e['speedup_pipelined']:.2f}× / {e['speedup_serial']:.2f}×"
+                if "fixed_exchange" in e:
+                    t += f" (fixed-capacity exchange {e['fixed_exchange']['speedup_pipelined']:.2f}× / {e['fixed_exchange']['speedup_serial']:.2f}×)"
+                parts.append(t)
+            rows.append((f"multi-GPU **model** from per-rank times measured on one GPU, {name} (pipelined / serial speed-up)", "; ".join(parts)))
     sub["RESULTS_TABLE"] = "| | |\n|---|---|\n" + "\n".join(f"| {a} | {c} |" for a, c in rows)
     text = open(os.path.join(ROOT, "docs", "DESIGN.template.md")).read()
     for key in sorted(sub, key=len, reverse=True):
