@@ -37,7 +37,10 @@ int g_render_bwd_variant = 0;
 int g_depth_sort_mode = 0;      // 0 = automatic (bucket sort, depthsort.hip, up to GSR_DS_MAX_P Gaussians; LSD radix sort beyond, and
                                 // for a while after a frame whose depths crowded one bucket), 1 = always LSD, 2 = always bucket sort
 int g_snug_tiles = 1;           // 1 = bin every Gaussian into its snug tile rectangle (gsr_math.h); 0 = the reference's square (A/B)
-int g_bwd_heavy_first = 1;      // 1 = the blend backward starts its heaviest tiles first (plan kernel, render_bwd.hip); 0 = index order (A/B)
+int g_bwd_heavy_first = 2;      // launch order of the blend backward (plan kernel, render_bwd.hip): 0 = tiles in index order, 1 = heaviest tiles first (sum of
+                                // the four blocks: round 3), 2 = tiles by their heaviest half (default: blend backward 0.343 -> 0.324 ms on the bench frame),
+                                // 3 = every half tile (= wave) on its own, heaviest first (0.325; slower than 2 on the clustered scene: the two halves of
+                                // a tile no longer share their gathered records in one XCD's L2)
 int g_tile_sort_mode = 0;       // 0 = fused emission + two-level sort (tilesort.hip), 1 = legacy emit + LSD passes (A/B)
 
 struct PendingEvent { int stage; hipEvent_t a, b; };
@@ -313,7 +316,7 @@ GsrImage gsr_carve_image(char* base, int W, int H) {
     im.n_contrib = (uint32_t*)take(npix * 4);
     im.ranges = (uint2*)take(nt * 8);
     im.block_steps = (uint32_t*)take(nt * 16);
-    im.tile_order = (uint32_t*)take(nt * 4);
+    im.tile_order = (uint32_t*)take(nt * 8);      // one entry per half tile (the backward's launch order)
     im.bytes = off;
     return im;
 }
@@ -366,7 +369,7 @@ int gsr_set_option(const char* name, int value) {
         return GSR_OK;
     }
     if (!strcmp(name, "bwd_heavy_first")) {
-        if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "bwd_heavy_first must be 0 (tiles in index order) or 1 (heaviest tiles first)");
+        if (value < 0 || value > 3) return fail(GSR_ERR_INVALID_ARG, "bwd_heavy_first must be 0 (tiles in index order), 1 (heaviest tiles first), 2 (tiles by their heaviest half) or 3 (half tiles, heaviest first)");
         g_bwd_heavy_first = value;
         return GSR_OK;
     }
@@ -385,15 +388,34 @@ int gsr_set_option(const char* name, int value) {
 
 int gsr_profile_enable(int on) {
     std::lock_guard<std::mutex> l(g_prof_mu);
-    g_count_on = (on & 2) != 0;
+    const bool trace = (on & 4) != 0;
+    g_count_on = (on & 2) != 0 || trace;
     int d = 0;
-    if (g_count_on && hipGetDevice(&d) == hipSuccess && d >= 0 && d < GSR_MAX_DEVICES && !g_counters_dev[d]) {
-        // measurement only (the product path never allocates): one counter block per device ordinal, on the CURRENT device
-        if (hipMalloc((void**)&g_counters_dev[d], GSR_COUNTER_COUNT * sizeof(unsigned long long)) != hipSuccess) g_counters_dev[d] = nullptr;
-        else (void)hipMemset(g_counters_dev[d], 0, GSR_COUNTER_COUNT * sizeof(unsigned long long));
+    if (g_count_on && hipGetDevice(&d) == hipSuccess && d >= 0 && d < GSR_MAX_DEVICES) {
+        if (!g_counters_dev[d]) {
+            // measurement only (the product path never allocates): one block per device ordinal, on the CURRENT device -- the six work
+            // counters, the mode word and the per-wave trace area (gsr_internal.h)
+            if (hipMalloc((void**)&g_counters_dev[d], GSR_MEASURE_WORDS * sizeof(unsigned long long)) != hipSuccess) g_counters_dev[d] = nullptr;
+            else (void)hipMemset(g_counters_dev[d], 0, GSR_MEASURE_WORDS * sizeof(unsigned long long));
+        }
+        if (g_counters_dev[d]) {
+            const unsigned long long mode = trace ? 1ull : 0ull;
+            (void)hipMemcpy(g_counters_dev[d] + GSR_TRACE_MODE_WORD, &mode, sizeof(mode), hipMemcpyHostToDevice);
+        }
     }
     g_prof_on = (on & 1) != 0;
     return GSR_OK;
+}
+int gsr_profile_trace(uint64_t* out, int max_waves) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    if (!out || max_waves <= 0) return 0;
+    unsigned long long* ctr = counters_for_current_device();
+    if (!ctr) return 0;
+    const int n = max_waves < GSR_TRACE_WAVES ? max_waves : GSR_TRACE_WAVES;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(out, ctr + GSR_TRACE_BASE, (size_t)n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    (void)hipMemset(ctr + GSR_TRACE_BASE, 0, (size_t)GSR_TRACE_WAVES * 4 * sizeof(unsigned long long));
+    return n;
 }
 int gsr_profile_counters(uint64_t* out, int n, int reset) {
     std::lock_guard<std::mutex> l(g_prof_mu);
@@ -915,13 +937,13 @@ int gsr_backward_blend(const GsrRasterSettings* settings, int P, int32_t num_ren
             HIP_OK(hipMemsetAsync(sg, 0, (size_t)P * 12 * sizeof(float), st));
             if (num_rendered > 0)
                 gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib, im.block_steps, nullptr,
-                                           dL_dout_color, dL_dout_invdepth, sg, nullptr, nullptr, num_rendered, 1, nullptr, st);
+                                           dL_dout_color, dL_dout_invdepth, sg, nullptr, nullptr, num_rendered, 1, 0, nullptr, st);
         } else {
             // (the flag words of the instances are cleared by the launcher: in the plan kernel's launch, or with a fill)
             gsr_launch_render_backward(cam, im.ranges, b.vals[list_buf], g.splats, im.final_T, im.n_contrib, im.block_steps,
                                        g_bwd_heavy_first ? im.tile_order : nullptr,
                                        dL_dout_color, dL_dout_invdepth, nullptr, w.inst_grads, w.inst_flag, num_rendered,
-                                       g_render_bwd_variant, g_count_on ? counters_for_current_device() : nullptr, st);
+                                       g_render_bwd_variant, g_bwd_heavy_first, g_count_on ? counters_for_current_device() : nullptr, st);
         }
     }
     STAGE_CHECK("render backward blend");

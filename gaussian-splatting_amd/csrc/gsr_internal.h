@@ -208,6 +208,28 @@ void gsr_launch_ranges(int64_t R, int n_tiles, const void* sorted_keys, bool key
                        hipStream_t st);
 
 // render_fwd.hip / render_bwd.hip
+// ---- measurement block of the blend kernels (device memory, allocated by gsr_profile_enable only) -------------------------------------
+// [0..5] work counters (include/gsr.h), [6] mode: 0 = counters (atomics at the end of every wave), 1 = per-wave trace, [8 + 4 w ..] trace
+// entry of wave w: start, end (s_memrealtime), placement | kernel << 40, steps.
+#define GSR_TRACE_MODE_WORD 6
+#define GSR_TRACE_BASE 8
+#define GSR_MEASURE_WORDS (GSR_TRACE_BASE + 4 * (size_t)GSR_TRACE_WAVES)
+#ifdef __HIPCC__
+__device__ __forceinline__ bool gsr_trace_mode(const unsigned long long* counters) {
+    return __builtin_nontemporal_load(counters + GSR_TRACE_MODE_WORD) != 0ull;
+}
+__device__ __forceinline__ void gsr_trace_wave(unsigned long long* counters, unsigned long long t0, uint32_t wave, uint32_t kernel, uint32_t steps) {
+    if (wave >= (uint32_t)GSR_TRACE_WAVES) return;
+    const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);         // HW_REG_HW_ID: wave [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);        // HW_REG_XCC_ID [3:0]
+    unsigned long long* e = counters + GSR_TRACE_BASE + (size_t)wave * 4;
+    e[0] = t0;
+    e[1] = wall_clock64();
+    e[2] = (unsigned long long)hw | ((unsigned long long)(xcc & 15u) << 32) | ((unsigned long long)kernel << 40);
+    e[3] = steps;
+}
+#endif
+
 void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,
                                const float4* splats, float* final_T, uint32_t* n_contrib, uint32_t* block_steps /*NULL unless tracking*/,
                                float* out_color, float* out_invdepth, int variant,
@@ -221,6 +243,7 @@ void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const
                                 const uint32_t* block_steps, uint32_t* tile_order /*NULL: tiles in index order*/,
                                 const float* dL_dpix, const float* dL_dinvdepth, float* splat_grads /*[P,12] variant 1*/,
                                 float* inst_grads /*[4][R,12]*/, uint32_t* inst_flag /*[R]*/, int64_t R, int variant,
+                                int order_mode /*plan kernel: 1 tiles by the sum of their blocks, 2 tiles by their heaviest half, 3 half tiles (waves)*/,
                                 unsigned long long* counters, hipStream_t st);
 size_t gsr_reduce_units(int64_t R);      // units of 1024 instance records the reduce works in
 void gsr_launch_reduce_instances(int P, int64_t R, const uint32_t* order, const uint32_t* offsets, const float4* splats,

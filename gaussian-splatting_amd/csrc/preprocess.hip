@@ -18,7 +18,15 @@
 
 namespace {
 
-#define GSR_PRE_OCC      // (3 waves per SIMD via amdgpu_waves_per_eu costs 25-49 spilled registers: measured slower, round 2)
+// occupancy attributes of the two per-Gaussian kernels (tuning builds: GSR_EXTRA_FLAGS=-DGSR_PRE_OCC_FWD=__attribute__((amdgpu_waves_per_eu(3,3)))).
+// Default: none -- the kernels take 177-212 VGPRs = two waves per SIMD.  Three waves per SIMD (168 VGPRs; three 53 KB workgroups also fill
+// the CU's LDS exactly) cost 25-49 spilled registers in round 2 (measured slower) and 8-36 with the round-4 kernels.
+#ifndef GSR_PRE_OCC_FWD
+#define GSR_PRE_OCC_FWD
+#endif
+#ifndef GSR_PRE_OCC_BWD
+#define GSR_PRE_OCC_BWD
+#endif
 
 constexpr int SH_ROW = 52;        // LDS row stride in floats for a 48-float SH record (52*l mod 64 hits 16 distinct bank quads)
 
@@ -184,7 +192,7 @@ __device__ __forceinline__ void wave_store_sh_split_dense(float* __restrict__ d_
 // SPLIT = the separate dc / rest form (always staged: the C ABI accepts it only for M == 16 and 16-byte aligned pointers)
 // fs: frame statistics (gsr_frame.h) -- the kernel's last workgroup publishes R and the depth-key range
 template <bool SPLIT>
-__global__ void __launch_bounds__(256) GSR_PRE_OCC
+__global__ void __launch_bounds__(256) GSR_PRE_OCC_FWD
 preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, const float* __restrict__ shs,
                       const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                       const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -385,7 +393,7 @@ __device__ __forceinline__ void wave_adam_sh_split_dense(const GsrShAdamDev& ad,
 
 // `shs` carries no __restrict__: in the ADAM instantiation it is adam.rest, which the kernel also writes (the update in place)
 template <bool SPLIT, bool ADAM = false>
-__global__ void __launch_bounds__(256) GSR_PRE_OCC
+__global__ void __launch_bounds__(256) GSR_PRE_OCC_BWD
 preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, const float* shs,
                       const float* __restrict__ colors_precomp, const float* __restrict__ opacities,
                       const float* __restrict__ scales, const float* __restrict__ rotations,

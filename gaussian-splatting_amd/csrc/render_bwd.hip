@@ -242,17 +242,29 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
                 const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                 const float* __restrict__ dL_dinvdepth, float4* __restrict__ slot_grads /*[4][R] records of 3 float4*/,
                 uint8_t* __restrict__ slot_flags /*[R][4]*/, int64_t R, const uint32_t* __restrict__ tile_order /*NULL: index order*/,
-                unsigned long long* __restrict__ counters) {
+                int wave_order /*tile_order lists (tile << 1 | half) per WAVE, heaviest first*/, unsigned long long* __restrict__ counters) {
     __shared__ float4 s_rec[64 * REC_STRIDE];
     __shared__ float s_grad[64 * 12];
     // the two halves of a tile get workgroup ids b and b + 16 -> same XCD -> they share the gathered records in L2;
     // workgroups are dispatched in id order, and tile_order lists the heaviest tiles first (bwd_plan_kernel below)
     const int b = blockIdx.x;
-    const int grp = b >> 5, r32 = b & 31;
-    const int turn = grp * 16 + (r32 & 15);
-    const int half = r32 >> 4;
-    if (turn >= n_band_tiles) return;
-    const int tile_local = tile_order ? (int)tile_order[turn] : turn;
+    int tile_local, half;
+    if (wave_order) {
+        // every half tile has its own place in the launch: the waves that start last are the lightest ones of the whole frame, so the
+        // launch drains in the time of a light wave (plan kernel below; the two halves of a tile weigh about the same and still start
+        // within a few hundred workgroups of each other)
+        if (b >= 2 * n_band_tiles) return;
+        const uint32_t e = tile_order[b];
+        tile_local = (int)(e >> 1);
+        half = (int)(e & 1u);
+    } else {
+        const int grp = b >> 5, r32 = b & 31;
+        const int turn = grp * 16 + (r32 & 15);
+        half = r32 >> 4;
+        if (turn >= n_band_tiles) return;
+        tile_local = tile_order ? (int)tile_order[turn] : turn;
+    }
+    const unsigned long long t_start = counters ? wall_clock64() : 0ull;      // (measurement only: per-wave trace, gsr_profile_trace)
     const int tile = cam.tile_y0 * cam.gx + tile_local;
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const int lane = threadIdx.x;
@@ -402,7 +414,9 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
             __builtin_amdgcn_wave_barrier();
         }
     }
-    if (counters && lane == 0) {
+    if (counters && gsr_trace_mode(counters)) {
+        if (lane == 0) gsr_trace_wave(counters, t_start, (uint32_t)blockIdx.x, 2u, nsteps);
+    } else if (counters && lane == 0) {
         atomicAdd(counters + 2, (unsigned long long)nsteps);
         atomicAdd(counters + 3, (unsigned long long)nbatch);
         atomicMax(counters + 5, (unsigned long long)nsteps);      // the heaviest wave
@@ -693,9 +707,21 @@ __device__ __forceinline__ int plan_bin(uint32_t w) {       // monotone; 8-step 
 // The same launch clears the instance flags (R bytes per record slot: 32 MB on the bench frame): workgroup 0 plans, the others
 // fill -- the plan's 9 us of dependent phases and the fill's 8 us run side by side instead of one after the other, one launch
 // boundary less.
+// mode 1: tiles by the sum of their four blocks' steps (round 3); 2: tiles by their heaviest half; 3: HALF TILES (= waves) by their own
+// steps, max of the two blocks a half covers -- measured against the backward's own step counts: correlation 0.98-0.998, the union of the
+// two blocks' survivors is 1.00-1.06 x the larger block (tools/gpu_wave_trace.py).  Finer bins than round 3's (a half tile of the bench
+// frame blends ~110 entries: eight-step bins put a third of the frame into one bin).
+__device__ __forceinline__ int plan_bin_fine(uint32_t w) {       // monotone: 1-step bins below 384, 64-step bins above
+    return w < 384u ? (int)w : min(PLAN_BINS - 1, 384 + (int)((w - 384u) >> 6));
+}
+__device__ __forceinline__ int plan_key(const uint4& v, int mode, int half) {
+    if (mode == 1) return plan_bin(v.x + v.y + v.z + v.w);
+    if (mode == 2) return plan_bin_fine(max(max(v.x, v.y), max(v.z, v.w)));
+    return plan_bin_fine(half ? max(v.z, v.w) : max(v.x, v.y));
+}
 __global__ void __launch_bounds__(PLAN_THREADS)
 bwd_plan_kernel(int tile0, int n_band_tiles, const uint4* __restrict__ block_steps, uint32_t* __restrict__ tile_order,
-                uint4* __restrict__ flags16, int64_t n16) {
+                uint4* __restrict__ flags16, int64_t n16, int mode) {
     if (blockIdx.x > 0) {
         const int64_t stride = (int64_t)(gridDim.x - 1) * PLAN_THREADS;
         for (int64_t i = (int64_t)(blockIdx.x - 1) * PLAN_THREADS + threadIdx.x; i < n16; i += stride) flags16[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -704,11 +730,13 @@ bwd_plan_kernel(int tile0, int n_band_tiles, const uint4* __restrict__ block_ste
     __shared__ uint32_t s_bin[PLAN_WAVES][PLAN_BINS];       // 32 KB
     __shared__ uint32_t s_wsum[PLAN_WAVES];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int n_items = mode == 3 ? 2 * n_band_tiles : n_band_tiles;
+    const int sh = mode == 3 ? 1 : 0;
     for (int k = t; k < PLAN_WAVES * PLAN_BINS; k += PLAN_THREADS) (&s_bin[0][0])[k] = 0u;
     __syncthreads();
-    for (int i = t; i < n_band_tiles; i += PLAN_THREADS) {
-        const uint4 v = block_steps[tile0 + i];
-        atomicAdd(&s_bin[wv][plan_bin(v.x + v.y + v.z + v.w)], 1u);
+    for (int i = t; i < n_items; i += PLAN_THREADS) {
+        const uint4 v = block_steps[tile0 + (i >> sh)];
+        atomicAdd(&s_bin[wv][plan_key(v, mode, i & sh)], 1u);
     }
     __syncthreads();
     // thread t < PLAN_BINS owns the t-th heaviest bin: its total over the copies, then (after the scan over bins) a cursor per copy
@@ -735,9 +763,9 @@ bwd_plan_kernel(int tile0, int n_band_tiles, const uint4* __restrict__ block_ste
         }
     }
     __syncthreads();
-    for (int i = t; i < n_band_tiles; i += PLAN_THREADS) {      // (a wave sees the tiles it counted)
-        const uint4 v = block_steps[tile0 + i];
-        tile_order[atomicAdd(&s_bin[wv][plan_bin(v.x + v.y + v.z + v.w)], 1u)] = (uint32_t)i;
+    for (int i = t; i < n_items; i += PLAN_THREADS) {      // (a wave sees the items it counted)
+        const uint4 v = block_steps[tile0 + (i >> sh)];
+        tile_order[atomicAdd(&s_bin[wv][plan_key(v, mode, i & sh)], 1u)] = (uint32_t)i;
     }
 }
 
@@ -755,7 +783,7 @@ void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const
                                 const float4* splats, const float* final_T, const uint32_t* n_contrib,
                                 const uint32_t* block_steps, uint32_t* tile_order,
                                 const float* dL_dpix, const float* dL_dinvdepth, float* splat_grads, float* inst_grads,
-                                uint32_t* inst_flag, int64_t R, int variant, unsigned long long* counters, hipStream_t st) {
+                                uint32_t* inst_flag, int64_t R, int variant, int order_mode, unsigned long long* counters, hipStream_t st) {
     const int n_band_tiles = cam.gx * (cam.tile_y1 - cam.tile_y0);
     if (n_band_tiles <= 0) return;
     const int groups = (n_band_tiles + 7) / 8;
@@ -787,19 +815,20 @@ void gsr_launch_render_backward(const GsrCamDev& cam, const uint2* ranges, const
     if (tile_order && block_steps) {
         const int fill_blocks = (int)std::min<int64_t>(2048, (n16 + PLAN_THREADS - 1) / PLAN_THREADS);
         hipLaunchKernelGGL(bwd_plan_kernel, dim3(1 + fill_blocks), dim3(PLAN_THREADS), 0, st, cam.tile_y0 * cam.gx, n_band_tiles,
-                           reinterpret_cast<const uint4*>(block_steps), tile_order, reinterpret_cast<uint4*>(inst_flag), n16);
+                           reinterpret_cast<const uint4*>(block_steps), tile_order, reinterpret_cast<uint4*>(inst_flag), n16, order_mode);
     } else {
         tile_order = nullptr;
         (void)hipMemsetAsync(inst_flag, 0, (size_t)R * 4, st);
     }
+    const int wave_order = (tile_order && order_mode == 3) ? 1 : 0;
     if (dL_dinvdepth)
         hipLaunchKernelGGL(render_bwd_half<true>, dim3(groups16 * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list, splats,
                            final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads),
-                           reinterpret_cast<uint8_t*>(inst_flag), R, tile_order, counters);
+                           reinterpret_cast<uint8_t*>(inst_flag), R, tile_order, wave_order, counters);
     else
         hipLaunchKernelGGL(render_bwd_half<false>, dim3(groups16 * 32), dim3(64), 0, st, cam, n_band_tiles, ranges, point_list, splats,
                            final_T, n_contrib, dL_dpix, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads),
-                           reinterpret_cast<uint8_t*>(inst_flag), R, tile_order, counters);
+                           reinterpret_cast<uint8_t*>(inst_flag), R, tile_order, wave_order, counters);
 }
 
 size_t gsr_reduce_units(int64_t R) { return (size_t)((R + RU - 1) / RU); }

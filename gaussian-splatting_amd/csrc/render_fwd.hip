@@ -132,6 +132,7 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
         quad = threadIdx.x >> 6;
     }
     if (tile_local >= n_band_tiles) return;
+    const unsigned long long t_start = counters ? wall_clock64() : 0ull;      // (measurement only: per-wave trace, gsr_profile_trace)
     const int tile = cam.tile_y0 * cam.gx + tile_local;
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const int lane = threadIdx.x & 63;
@@ -223,7 +224,9 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
         }
         if (__ballot(Tl != 0.0f) == 0ull) break;
     }
-    if (counters && lane == 0) {     // [0] (8x8 block, entry) pairs blended by all 64 lanes, [1] batches of 64 entries box-tested
+    if (counters && gsr_trace_mode(counters)) {
+        if (lane == 0) gsr_trace_wave(counters, t_start, (uint32_t)(blockIdx.x * WPB + (threadIdx.x >> 6)), 1u, nsteps);
+    } else if (counters && lane == 0) {     // [0] (8x8 block, entry) pairs blended by all 64 lanes, [1] batches of 64 entries box-tested
         atomicAdd(counters + 0, (unsigned long long)nsteps);
         atomicAdd(counters + 1, (unsigned long long)nbatches);
         atomicMax(counters + 4, (unsigned long long)nsteps);      // the heaviest wave (tail of the launch: max / mean)

@@ -51,7 +51,7 @@ EXPORTS = [
     "gsr_mark_visible", "gsr_forward_views", "gsr_adam_step", "gsr_adam_step_multi", "gsr_backward_preprocess_sh_adam", "gsr_sparse_adam_step", "gsr_ssim_forward", "gsr_ssim_backward",
     "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_ssim_partial_count", "gsr_ssim_mean_forward", "gsr_ssim_mean_backward",
     "gsr_train_loss_forward", "gsr_train_loss_backward", "gsr_density_stats",
-    "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_profile_counters", "gsr_set_option",
+    "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_profile_counters", "gsr_profile_trace", "gsr_set_option",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -221,9 +221,23 @@ def set_option(name: str, value: int) -> None:
     check(load().gsr_set_option(name.encode(), int(value)), "gsr_set_option")
 
 
-def profile_enable(on, counters: bool = False) -> None:
-    """on: per-stage HIP events; counters: the blend kernels' work counters (they slow the kernels: use a separate pass)."""
-    load().gsr_profile_enable((1 if on else 0) | (2 if counters else 0))
+def profile_enable(on, counters: bool = False, trace: bool = False) -> None:
+    """on: per-stage HIP events; counters: the blend kernels' work counters (they slow the kernels: use a separate pass);
+    trace: per-wave start / end / placement records of the blend kernels instead of the counters (profile_trace)."""
+    load().gsr_profile_enable((1 if on else 0) | (2 if counters else 0) | (4 if trace else 0))
+
+
+def profile_trace(max_waves: int = 65536):
+    """[n, 4] uint64: start, end (100 MHz ticks), placement (HW_ID | XCC << 32 | kernel << 40), steps of the most recent blend launches' waves."""
+    import numpy as np
+    lib = load()
+    lib.gsr_profile_trace.restype = C.c_int
+    lib.gsr_profile_trace.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    buf = np.zeros((max_waves, 4), dtype=np.uint64)
+    n = lib.gsr_profile_trace(buf.ctypes.data_as(C.POINTER(C.c_uint64)), int(max_waves))
+    if n < 0:
+        raise GsrError("gsr_profile_trace failed")
+    return buf[:n]
 
 
 def profile_reset() -> None:

@@ -404,7 +404,8 @@ enum {
     GSR_STAGE_R_WAIT = 11,           /* GPU idle between the depth sort and the first kernel the host launches after reading R */
     GSR_STAGE_COUNT = 12
 };
-int gsr_profile_enable(int on);      /* bit 0: per-stage events; bit 1: work counters (slow the blend kernels: count in a separate pass) */
+int gsr_profile_enable(int on);      /* bit 0: per-stage events; bit 1: work counters (slow the blend kernels: count in a separate pass);
+                                      * bit 2: per-wave trace of the blend kernels instead of the counters (gsr_profile_trace) */
 int gsr_profile_reset(void);
 /* Resolves pending events (synchronises them) and returns accumulated ms and launch counts per stage. */
 int gsr_profile_read(float* ms_out, int32_t* count_out, int n);
@@ -415,6 +416,13 @@ int gsr_profile_read(float* ms_out, int32_t* count_out, int n);
  * tail of a launch, slowest wave / mean wave, which is what clustered scenes stress. */
 #define GSR_COUNTER_COUNT 6
 int gsr_profile_counters(uint64_t* out, int n, int reset);
+/* Per-wave trace of the two blend kernels (measurement only; gsr_profile_enable(4)): entry w of the most recent launch's wave w is four
+ * 64-bit words -- start and end time (100 MHz constant clock, s_memrealtime), placement (HW_ID bits 0-31, XCC id bits 32-35,
+ * kernel bits 40-41: 1 forward, 2 backward) and the wave's blend steps.  Waves that left early (nothing to blend) keep a zero entry.
+ * Copies min(max_waves, GSR_TRACE_WAVES) entries to `out`, clears the device copy, returns the number copied (negative: error).
+ * This is how the tail of a blend launch was measured (tools/gpu_wave_trace.py). */
+#define GSR_TRACE_WAVES 65536
+int gsr_profile_trace(uint64_t* out, int max_waves);
 
 /* Switches.  The product library accepts the tuning knobs sort_small_block_threshold, sort_mid_block_threshold,
  * sort_items_large, tile_sort_mode (0 fused two-level sort, 1 legacy LSD passes) and
@@ -426,10 +434,12 @@ int gsr_profile_counters(uint64_t* out, int n, int reset);
  * render_bwd_variant 1 / 4 / 5 -- measured and rejected; the product accepts only 0.  (ABI 4 removed the options of experiments
  * whose code left the sources: onesweep depth sort, color_overlap, first_hist_in_preprocess, sh_dma.)  Unknown names /
  * unavailable values return an error.
- * Switches of the product library whose default is 1 (both settings give the same results; 0 is the form they replaced):
+ * Switches of the product library (every setting gives the same results; 0 is the form they replaced):
  *   snug_tiles       1 = a Gaussian is binned into the tiles its alpha >= 1/255 ellipse can reach, 0 = into the reference's square
  *                    of radius 3 sqrt(lambda_max) (same outputs, ~1.4x the instances)
- *   bwd_heavy_first  1 = the blend backward starts its heaviest tiles first (planned from the forward's per-block step counts)
+ *   bwd_heavy_first  launch order of the blend backward, planned from the forward's per-block step counts: 2 (default) = tiles by
+ *                    their heaviest half, 1 = tiles by the sum of their four blocks (round 3), 3 = every half tile on its own,
+ *                    0 = index order; scheduling only -- the gradients are the same bits in every order
  * and ssim_variant (0 = marching-wave SSIM / training-loss kernels, 1 = the LDS-tiled form), ssim_target_waves (launch shape of
  * the marching form), preprocess_grid_cap. */
 int gsr_set_option(const char* name, int value);

@@ -84,11 +84,12 @@ def test_argument_validation_without_gpu(lib):
         assert lib.gsr_set_option(name, 1) != 0, name
         assert b"GSR_AB_VARIANTS" in lib.gsr_last_error(), (name, lib.gsr_last_error())
     for name, value in ((b"sort_small_block_threshold", 512 * 1024), (b"sort_mid_block_threshold", 3 * 1024 * 1024),
-                        (b"sort_items_large", 4096), (b"tile_sort_mode", 0), (b"preprocess_grid_cap", 2048), (b"bwd_heavy_first", 1),
+                        (b"sort_items_large", 4096), (b"tile_sort_mode", 0), (b"preprocess_grid_cap", 2048), (b"bwd_heavy_first", 1), (b"bwd_heavy_first", 3), (b"bwd_heavy_first", 2),
                         (b"depth_sort_mode", 2), (b"depth_sort_mode", 1), (b"depth_sort_mode", 0)):
         assert lib.gsr_set_option(name, value) == 0, name
     assert lib.gsr_set_option(b"sort_items_large", 1000) == -1
     assert lib.gsr_set_option(b"depth_sort_mode", 3) == -1
+    assert lib.gsr_set_option(b"bwd_heavy_first", 4) == -1
     # round-2/3 experiments that were measured, rejected and removed from the sources are not options any more
     for name in (b"color_overlap", b"first_hist_in_preprocess", b"sh_dma"):
         assert lib.gsr_set_option(name, 0) == -1, name

@@ -326,13 +326,15 @@ def test_backward_is_bit_reproducible_and_variants_agree():
         assert torch.equal(x, y), "default backward is not bit-reproducible"
     # the order in which the blend backward starts its tiles (heaviest first, planned from the forward's step counts) is
     # scheduling only: every wave writes its own slots, so the gradients are the same bits in either order
-    _lib.set_option("bwd_heavy_first", 0)
-    try:
-        c = grads(0)
-    finally:
-        _lib.set_option("bwd_heavy_first", 1)
-    for x, z in zip(a, c):
-        assert torch.equal(x, z), "tile order of the blend backward changed a gradient"
+    # (0 index order, 1 tiles by the sum of their blocks, 2 tiles by their heaviest half -- the default --, 3 every half tile on its own)
+    for order in (0, 1, 3):
+        _lib.set_option("bwd_heavy_first", order)
+        try:
+            c = grads(0)
+        finally:
+            _lib.set_option("bwd_heavy_first", 2)
+        for x, z in zip(a, c):
+            assert torch.equal(x, z), f"launch order {order} of the blend backward changed a gradient"
     for variant, tol in ((1, 2e-4), (4, 5e-5), (5, 5e-5)):
         try:
             c = grads(variant)

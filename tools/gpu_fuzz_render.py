@@ -1,0 +1,288 @@
+"""Randomised parity check of the WHOLE operator on the GPU against the CPU oracle: N random small frames -- frame shape (ragged, smaller
+than a tile, one pixel wide), field of view, camera pose, scene kind (SURVEY 8(d) cloud / edge-case scene / a few huge splats / a
+needle pile / one Gaussian), P from 1 to a few thousand, SH degree and storage, background, scale modifier, antialiasing, call form
+(shs | colors_precomp) x (scales + rotations | cov3D_precomp) x (fused SH tensor | the reference's separate dc / rest tensors),
+with or without a gradient on the inverse-depth image -- each rendered forward AND backward through `GaussianRasterizer` and through
+`oracle.rasterize` + autograd.  Bars are the parity suite's: integers (radii, tiles_touched, R, point list, ranges, n_contrib off
+fragile pixels) bit-exact, image / inverse depth 1e-5 + what the cancellation inside an anisotropic splat's exponent lets fp32 resolve
+(`conditioning`) off fragile pixels and one alpha quantum on them, gradients 1e-4 of max |grad|
+(99.9th percentile 1e-5; the degenerate kinds keep the 2e-3 / 1e-4 bar of the parity suite).
+
+    python tools/gpu_fuzz_render.py [frames] [seed]        -> one JSON summary line (also gpurun_out/fuzz_render.json)
+
+Test infrastructure (imports oracle/ through tests/helpers.py), not product code."""
+import json
+import math
+import os
+import random
+import sys
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from helpers import O, make_camera, look_at_camera, make_scene, make_edge_scene, oracle_settings
+DRY = not torch.cuda.is_available()      # build container: only the scene generation and the oracle side run (a syntax / shape check)
+if not DRY:
+    from test_gpu_parity import gpu_settings, check_forward
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from diff_gaussian_rasterization.debug import forward_with_views
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = random.Random(SEED)
+dev = torch.device("cpu" if DRY else "cuda:0")
+stats = {"frames": 0, "backward_checked": 0, "kinds": {}, "forms": {}, "max_P": 0, "max_R": 0, "worst_image_err": 0.0,
+         "worst_grad_err": 0.0, "failures": []}
+t0 = time.time()
+
+
+GAMMA = 4.0 * 2.0 ** -23      # a few fp32 roundings of the quadratic form, relative to the size of its TERMS
+
+
+def conditioning(aux, s_):
+    """What fp32 can resolve at every pixel.  The exponent of a pair is -(A dx^2 + C dy^2)/2 - B dx dy: for an anisotropic splat its terms
+    are orders of magnitude larger than their sum, so two correct fp32 evaluations (other association, FMA contraction -- the reference's
+    nvcc build contracts too) differ by ~GAMMA * M with M = (|A| dx^2 + |C| dy^2)/2 + |B dx dy|.  First-order propagation through the
+    compositing sum: |d image| <= 2 cmax GAMMA sum_i w_i M_i (w_i = alpha_i T_i), |d T| <= T sum_i alpha_i/(1-alpha_i) GAMMA M_i.
+    Returns per pixel: the image bound's sum_i w_i M_i, the relative T bound, and a flag "a hard threshold of an evaluated pair is within
+    that noise" (alpha vs 1/255, power vs 0, T vs 1e-4) -- there either branch is a correct fp32 result."""
+    H_, W_ = int(s_.image_height), int(s_.image_width)
+    gx_, gy_ = aux["grid"]
+    B = torch.zeros(H_, W_, dtype=torch.float64)
+    E = torch.zeros(H_, W_, dtype=torch.float64)
+    flag = torch.zeros(H_, W_, dtype=torch.bool)
+    xy, con, opa = aux["means2D"].double(), aux["conic"].double(), aux["opacity"].double().reshape(-1)
+    pl, rng_ = aux["point_list"], aux["ranges"]
+    for t in range(gx_ * gy_):
+        a, b = int(rng_[t, 0]), int(rng_[t, 1])
+        if b <= a:
+            continue
+        ty, tx = divmod(t, gx_)
+        x0, y0 = tx * 16, ty * 16
+        x1, y1 = min(x0 + 16, W_), min(y0 + 16, H_)
+        ys, xs = torch.meshgrid(torch.arange(y0, y1), torch.arange(x0, x1), indexing="ij")
+        px, py = xs.reshape(-1).double(), ys.reshape(-1).double()
+        ids = pl[a:b]
+        dx = xy[ids, 0][None, :] - px[:, None]
+        dy = xy[ids, 1][None, :] - py[:, None]
+        A_, B_, C_ = con[ids, 0][None, :], con[ids, 1][None, :], con[ids, 2][None, :]
+        power = -0.5 * (A_ * dx * dx + C_ * dy * dy) - B_ * dx * dy
+        M = 0.5 * (A_.abs() * dx * dx + C_.abs() * dy * dy) + (B_ * dx * dy).abs()
+        alpha = torch.clamp(opa[ids][None, :] * torch.exp(power), max=0.99)
+        keep = (power <= 0) & (alpha >= 1.0 / 255.0)
+        ae = torch.where(keep, alpha, torch.zeros_like(alpha))
+        Tincl = torch.cumprod(1.0 - ae, dim=1)
+        Texcl = torch.cat([torch.ones(len(px), 1, dtype=torch.float64), Tincl[:, :-1]], dim=1)
+        dead = torch.cumsum((keep & (Tincl < 1e-4)).to(torch.int32), dim=1) > 0
+        evaluated = ~torch.cat([torch.zeros(len(px), 1, dtype=torch.bool), dead[:, :-1]], dim=1)      # pairs the loop reaches
+        w = torch.where(keep & ~dead, ae * Texcl, torch.zeros_like(ae))
+        noise = GAMMA * M
+        relT = torch.cumsum(torch.where(keep, ae / (1.0 - ae) * noise, torch.zeros_like(ae)), dim=1)
+        near = evaluated & (((alpha - 1.0 / 255.0).abs() <= 2.0 * alpha * noise + 1e-12) & (power <= noise)
+                            | ((power.abs() <= noise) & (alpha >= 0.5 / 255.0))
+                            | (keep & ((Tincl - 1e-4).abs() <= Tincl * (relT + 1e-6) + 1e-12)))
+        B[y0:y1, x0:x1] = (w * M).sum(dim=1).reshape(y1 - y0, x1 - x0)
+        E[y0:y1, x0:x1] = torch.where(evaluated, relT, torch.zeros_like(relT)).amax(dim=1).reshape(y1 - y0, x1 - x0)
+        flag[y0:y1, x0:x1] = near.any(dim=1).reshape(y1 - y0, x1 - x0)
+    return B, E, flag
+
+
+def build(it):
+    W, H = rng.choice([(64, 48), (17, 9), (1, 40), (300, 2), (250, 131), (333, 200), (16, 16), (129, 65), (480, 270), (31, 257)])
+    fov = rng.choice([25.0, 45.0, 60.0, 90.0, 110.0])
+    if rng.random() < 0.5:
+        cam = make_camera(W, H, fovx_deg=fov)
+    else:
+        eye = (rng.uniform(-0.6, 0.6), rng.uniform(-0.6, 0.6), rng.uniform(-1.5, 0.5))
+        cam = look_at_camera(W, H, eye, (rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), 3.0), fovx_deg=fov)
+    kind = rng.choice(["cloud", "cloud", "edge", "huge", "needles", "extreme_needles", "single"])
+    P = {"single": 1, "huge": rng.randint(2, 40)}.get(kind, int(10 ** rng.uniform(0.3, 3.3)))
+    max_deg = rng.choice([3, 3, 3, 0, 1, 2])
+    if kind == "edge":
+        sc = make_edge_scene(max(P, 8), cam, seed=100 + it)
+        max_deg = 3
+    else:
+        sc = make_scene(P, cam, seed=100 + it, s_med=10 ** rng.uniform(-2.2, -0.9), max_sh_degree=max_deg)
+    g = torch.Generator().manual_seed(it)
+    if kind == "huge":          # splats much larger than the frame (radius clamps, every tile touched)
+        sc.scales.mul_(rng.choice([30.0, 100.0]))
+    elif kind == "needles":     # one axis 10-40x the others: rectangles mostly empty
+        sc.scales[:, 0].mul_(rng.choice([5.0, 20.0]))
+        sc.scales[:, 1:].mul_(0.5)
+    elif kind == "extreme_needles":     # 250-1500x: conics with condition numbers of 1e5 and more -- bins bit-exact, image / gradients only loosely
+        sc.scales[:, 0].mul_(rng.choice([50.0, 300.0]))
+        sc.scales[:, 1:].mul_(0.2)
+    return cam, sc, kind, max_deg, g
+
+
+BUDGET_S = float(os.environ.get("FUZZ_SECONDS", "1e9"))      # stop (and report) after this much wall clock
+for it in range(N):
+    if time.time() - t0 > BUDGET_S:
+        stats["stopped_after_seconds"] = BUDGET_S
+        break
+    desc = {"it": it}
+    try:
+        cam, sc, kind, max_deg, g = build(it)
+        P = sc.P
+        H, W = cam.image_height, cam.image_width
+        deg = rng.randint(0, max_deg)
+        opts = dict(bg=torch.rand(3, generator=g) if rng.random() < 0.7 else None, sh_degree=deg,
+                    scale_modifier=rng.choice([1.0, 1.0, 0.5, 1.7]), antialiasing=rng.random() < 0.4)
+        s = oracle_settings(cam, **opts)
+        colors_form = rng.random() < 0.25
+        cov_form = rng.random() < 0.25
+        split_form = (not colors_form) and rng.random() < 0.4
+        use_depth = rng.random() < 0.5
+        form = ("colors" if colors_form else ("split_sh" if split_form else "shs")) + ("+cov" if cov_form else "")
+        desc.update(kind=kind, P=P, W=W, H=H, form=form, deg=deg, max_deg=max_deg, aa=opts["antialiasing"], depth=use_depth,
+                    scale_modifier=opts["scale_modifier"])
+        colors = torch.rand(P, 3, generator=g) if colors_form else None
+        cov = O.compute_cov3d(sc.scales, sc.rotations, s.scale_modifier, torch.float32) if cov_form else None
+
+        # ---- forward: integers bit-exact, image within the bar (whole frame, the oracle's fragile mask) ----
+        with torch.no_grad():
+            col, radii, invd, aux = O.rasterize(sc.means3D, None, sc.opacities, s, shs=None if colors_form else sc.shs, colors_precomp=colors,
+                                                scales=None if cov_form else sc.scales, rotations=None if cov_form else sc.rotations,
+                                                cov3D_precomp=cov, want_fragile=True, return_aux=True)
+        d = sc.to(dev)
+        cond = None
+        if DRY:
+            cond = conditioning(aux, s)
+            desc["cond"] = [float(cond[0].max()), float(cond[1].max()), float(cond[2].float().mean())]
+            stats.setdefault("dry_cond", []).append([kind] + [round(x, 6) for x in desc["cond"]])
+        for nb in (() if DRY else (False, True)):
+            out = forward_with_views(gpu_settings(s, dev), d.means3D, d.opacities, shs=None if colors_form else d.shs,
+                                     colors_precomp=None if colors is None else colors.to(dev), scales=None if cov_form else d.scales,
+                                     rotations=None if cov_form else d.rotations, cov3D_precomp=None if cov is None else cov.to(dev),
+                                     no_backward=nb)
+            torch.cuda.synchronize()
+            # integers: bit-exact, always
+            assert torch.equal(out["radii"].cpu(), radii), "radii differ"
+            assert torch.equal(out["tiles_touched"].cpu().to(torch.int64), aux["tiles_touched"]), "tiles_touched differ"
+            assert out["R"] == aux["R"], f"R {out['R']} != {aux['R']}"
+            assert torch.equal(out["point_list"].cpu().to(torch.int64), aux["point_list"]), "sorted point list differs"
+            assert torch.equal(out["ranges"].cpu().to(torch.int64), aux["ranges"]), "tile ranges differ"
+            if cond is None:
+                cond = conditioning(aux, s)
+            cB, cE, cflag = cond
+            fr = aux["fragile"] | cflag
+            ok = ~fr
+            cmax = max(1.0, float(aux["rgb"].abs().max()), float(s.bg.abs().max()))
+            dmax = max(1.0, float(invd.abs().max()))
+            g_col, g_inv = out["color"].cpu(), out["invdepth"].cpu()
+            assert torch.isfinite(g_col).all() and torch.isfinite(g_inv).all(), "non-finite pixel"
+            err = (g_col - col).abs().amax(dim=0).double()
+            ierr = (g_inv - invd).abs()[0].double()
+            bar_img = 1e-5 + 2.0 * cmax * GAMMA * cB            # = 1e-5 for round splats; grows with the cancellation inside the exponent
+            bar_inv = 1e-5 * dmax + 2.0 * dmax * GAMMA * cB
+            over = (err / bar_img)[ok]
+            iover = (ierr / bar_inv)[ok]
+            m = {"img": float(err[ok].max()) if ok.any() else 0.0, "img_over_bar": float(over.max()) if ok.any() else 0.0,
+                 "invd_over_bar": float(iover.max()) if ok.any() else 0.0, "bar_img_max": float(bar_img.max()),
+                 "img_fragile": float(err[fr].max()) if fr.any() else 0.0, "fragile_frac": float(aux["fragile"].float().mean()),
+                 "conditioning_flag_frac": float(cflag.float().mean())}
+            if not nb:
+                nc_bad = (out["n_contrib"].cpu().to(torch.int64) != aux["n_contrib"]) & ok
+                m["n_contrib_mismatch_px"] = int(nc_bad.sum())
+                terr = (out["final_T"].cpu() - aux["final_T"]).abs().double()
+                bar_T = 5e-6 + 2.0 * cE
+                m["final_T_over_bar"] = float((terr / bar_T)[ok].max()) if ok.any() else 0.0
+            desc["metrics"] = m
+            assert m["img_over_bar"] <= 1.0, f"image error {m['img']:.3e} = {m['img_over_bar']:.2f} x its bar"
+            assert m["invd_over_bar"] <= 1.0, f"inverse-depth error {m['invd_over_bar']:.2f} x its bar"
+            assert m["img_fragile"] <= cmax / 255.0 * 1.01 + float(bar_img.max()), f"fragile-pixel error {m['img_fragile']:.3e}"
+            if not nb:
+                assert m["n_contrib_mismatch_px"] == 0, f"n_contrib differs at {m['n_contrib_mismatch_px']} pixels off every threshold"
+                assert m["final_T_over_bar"] <= 1.0, f"final_T error {m['final_T_over_bar']:.2f} x its bar"
+            if float(bar_img.max()) <= 2e-5:
+                stats["worst_image_err"] = max(stats["worst_image_err"], m["img"])
+            stats["worst_img_over_bar"] = max(stats.get("worst_img_over_bar", 0.0), m["img_over_bar"])
+            stats["max_flagged_frac"] = max(stats.get("max_flagged_frac", 0.0), float(fr.float().mean()))
+        stats["max_R"] = max(stats["max_R"], int(aux["R"]))
+
+        # ---- backward through the operator's public call ----
+        wc = torch.randn(3, H, W, generator=g)
+        wd = torch.randn(1, H, W, generator=g) * 0.3 if use_depth else None
+
+        def leaves(where):
+            L = {"means3D": sc.means3D, "opacities": sc.opacities}
+            if colors_form:
+                L["colors_precomp"] = colors
+            elif split_form:
+                L["dc"], L["shs"] = sc.shs[:, :1].contiguous(), sc.shs[:, 1:].contiguous()
+            else:
+                L["shs"] = sc.shs
+            if cov_form:
+                L["cov3D_precomp"] = cov
+            else:
+                L["scales"], L["rotations"] = sc.scales, sc.rotations
+            L = {k: v.detach().clone().to(where).requires_grad_(True) for k, v in L.items()}
+            L["means2D"] = torch.zeros(P, 3, device=where, requires_grad=True)
+            return L
+
+        Lc = leaves("cpu")
+        kw = {k: v for k, v in Lc.items() if k not in ("means3D", "means2D", "opacities", "dc")}
+        if split_form:
+            kw["shs"] = torch.cat([Lc["dc"], Lc["shs"]], dim=1)
+        ocol, oradii, oinvd = O.rasterize(Lc["means3D"], Lc["means2D"], Lc["opacities"], s, **kw)
+        oloss = (ocol * wc).sum() + ((oinvd * wd).sum() if use_depth else 0.0)
+        if oloss.requires_grad:      # (nothing visible: the oracle's image is a constant, every gradient is zero)
+            oloss.backward()
+        if DRY:
+            stats["frames"] += 1
+            stats["kinds"][kind] = stats["kinds"].get(kind, 0) + 1
+            stats["forms"][form] = stats["forms"].get(form, 0) + 1
+            continue
+        Lg = leaves(dev)
+        kwg = {k: v for k, v in Lg.items() if k not in ("means3D", "means2D", "opacities")}
+        gcol, gradii, ginvd = GaussianRasterizer(raster_settings=gpu_settings(s, dev))(means3D=Lg["means3D"], means2D=Lg["means2D"],
+                                                                                      opacities=Lg["opacities"], **kwg)
+        ((gcol * wc.to(dev)).sum() + ((ginvd * wd.to(dev)).sum() if use_depth else 0.0)).backward()
+        torch.cuda.synchronize()
+        assert torch.equal(gradii.cpu(), oradii), "radii (backward call) differ"
+        degenerate = kind in ("edge", "huge", "needles", "extreme_needles")
+        bar_max, bar_p = (2e-3, 1e-4) if degenerate else (1e-4, 1e-5)
+        gm = {}
+        for k in Lc:
+            a = Lg[k].grad
+            b = Lc[k].grad
+            if b is None and a is not None and k != "means2D":
+                b = torch.zeros_like(Lc[k])
+            if b is None or b.numel() == 0:
+                continue
+            if kind == "extreme_needles":
+                assert a is not None and torch.isfinite(a).all(), f"{k}: non-finite gradient"
+                continue
+            assert a is not None, f"{k}: no gradient from the operator"
+            a, b = a.cpu().double(), b.double()
+            assert torch.isfinite(a).all(), f"{k}: non-finite gradient"
+            scale = b.abs().max().item()
+            if scale == 0.0:
+                assert a.abs().max().item() <= 1e-12, f"{k}: oracle gradient is zero, operator's is not"
+                continue
+            dd = (a - b).abs() / scale
+            q = torch.quantile(dd.flatten()[:4_000_000], 0.999).item() if dd.numel() > 1000 else 0.0
+            gm[k] = [float(f"{dd.max().item():.3e}"), float(f"{q:.3e}")]
+            desc["grad_metrics"] = gm
+            stats["worst_grad_err"] = max(stats["worst_grad_err"], dd.max().item() if not degenerate else 0.0)
+            assert dd.max().item() < bar_max, f"{k}: max grad err {dd.max().item():.3e} of max |grad| (bar {bar_max})"
+            assert q < bar_p, f"{k}: 99.9th pct grad err {q:.3e} (bar {bar_p})"
+        stats["backward_checked"] += 1
+        stats["frames"] += 1
+        stats["kinds"][kind] = stats["kinds"].get(kind, 0) + 1
+        stats["forms"][form] = stats["forms"].get(form, 0) + 1
+        stats["max_P"] = max(stats["max_P"], P)
+    except Exception as ex:      # noqa: BLE001 -- every failure is recorded with what reproduces it
+        desc["error"] = f"{type(ex).__name__}: {str(ex)[:300]}"
+        desc["where"] = traceback.format_exc().strip().splitlines()[-3][:200]
+        stats["failures"].append(desc)
+        if len(stats["failures"]) >= 25:
+            break
+stats["seconds"] = round(time.time() - t0, 1)
+stats["seed"] = SEED
+line = json.dumps(stats)
+print(line)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+open(os.path.join(ROOT, "gpurun_out", f"fuzz_render_{SEED}.json"), "w").write(line + "\n")
