@@ -218,7 +218,13 @@ void gsr_launch_ranges(int64_t R, int n_tiles, const void* sorted_keys, bool key
 __device__ __forceinline__ bool gsr_trace_mode(const unsigned long long* counters) {
     return __builtin_nontemporal_load(counters + GSR_TRACE_MODE_WORD) != 0ull;
 }
-__device__ __forceinline__ void gsr_trace_wave(unsigned long long* counters, unsigned long long t0, uint32_t wave, uint32_t kernel, uint32_t steps) {
+// steps: bits 0-15 blend steps; in trace mode the kernels also pack the time (10 ns ticks, saturating at 65535) they spent walking survivors
+// (bits 16-31), getting batches ready -- waiting for the gathered records, box tests, staging -- (bits 32-47) and storing (bits 48-63)
+__device__ __forceinline__ unsigned long long gsr_trace_pack(uint32_t steps, unsigned long long walk, unsigned long long prep, unsigned long long store) {
+    auto sat = [](unsigned long long v) { return v > 65535ull ? 65535ull : v; };
+    return (unsigned long long)(steps > 65535u ? 65535u : steps) | (sat(walk) << 16) | (sat(prep) << 32) | (sat(store) << 48);
+}
+__device__ __forceinline__ void gsr_trace_wave(unsigned long long* counters, unsigned long long t0, uint32_t wave, uint32_t kernel, unsigned long long steps) {
     if (wave >= (uint32_t)GSR_TRACE_WAVES) return;
     const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);         // HW_REG_HW_ID: wave [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]
     const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);        // HW_REG_XCC_ID [3:0]

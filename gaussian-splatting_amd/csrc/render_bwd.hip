@@ -265,6 +265,8 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
         tile_local = tile_order ? (int)tile_order[turn] : turn;
     }
     const unsigned long long t_start = counters ? wall_clock64() : 0ull;      // (measurement only: per-wave trace, gsr_profile_trace)
+    const bool tracing = counters && gsr_trace_mode(counters);
+    unsigned long long t_mark = t_start, t_walk = 0ull, t_prep = 0ull, t_store = 0ull;
     const int tile = cam.tile_y0 * cam.gx + tile_local;
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const int lane = threadIdx.x;
@@ -335,6 +337,7 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
         uint64_t mask = maskA | maskB;
         nsteps += (uint32_t)__popcll(mask);
         uint64_t touched = 0ull;
+        if (tracing) { const unsigned long long t = wall_clock64(); t_prep += t - t_mark; t_mark = t; }
         while (mask) {
             const int j = 63 - __builtin_clzll(mask);
             mask &= ~(1ull << j);
@@ -402,6 +405,7 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
             }
             touched |= 1ull << j;
         }
+        if (tracing) { const unsigned long long t = wall_clock64(); t_walk += t - t_mark; t_mark = t; }
         if (touched) {
             __builtin_amdgcn_wave_barrier();
             if ((touched >> lane) & 1ull) {
@@ -413,9 +417,10 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
             }
             __builtin_amdgcn_wave_barrier();
         }
+        if (tracing) { const unsigned long long t = wall_clock64(); t_store += t - t_mark; t_mark = t; }
     }
-    if (counters && gsr_trace_mode(counters)) {
-        if (lane == 0) gsr_trace_wave(counters, t_start, (uint32_t)blockIdx.x, 2u, nsteps);
+    if (tracing) {
+        if (lane == 0) gsr_trace_wave(counters, t_start, (uint32_t)blockIdx.x, 2u, gsr_trace_pack(nsteps, t_walk, t_prep, t_store));
     } else if (counters && lane == 0) {
         atomicAdd(counters + 2, (unsigned long long)nsteps);
         atomicAdd(counters + 3, (unsigned long long)nbatch);

@@ -133,6 +133,8 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
     }
     if (tile_local >= n_band_tiles) return;
     const unsigned long long t_start = counters ? wall_clock64() : 0ull;      // (measurement only: per-wave trace, gsr_profile_trace)
+    const bool tracing = counters && gsr_trace_mode(counters);
+    unsigned long long t_mark = t_start, t_walk = 0ull, t_prep = 0ull;
     const int tile = cam.tile_y0 * cam.gx + tile_local;
     const int tx = tile % cam.gx, ty = tile / cam.gx;
     const int lane = threadIdx.x & 63;
@@ -186,6 +188,7 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
         }
         uint64_t mask = __ballot(keep);
         ++nbatches;
+        if (tracing) { const unsigned long long t = wall_clock64(); t_prep += t - t_mark; t_mark = t; }
         const uint32_t pos_base = base - range.x + 1;
         // one surviving entry: pop the lowest set bit of `mask`, blend
         auto one_step = [&]() {
@@ -222,10 +225,11 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
             }
             if (__ballot(Tl != 0.0f) == 0ull) break;
         }
+        if (tracing) { const unsigned long long t = wall_clock64(); t_walk += t - t_mark; t_mark = t; }
         if (__ballot(Tl != 0.0f) == 0ull) break;
     }
-    if (counters && gsr_trace_mode(counters)) {
-        if (lane == 0) gsr_trace_wave(counters, t_start, (uint32_t)(blockIdx.x * WPB + (threadIdx.x >> 6)), 1u, nsteps);
+    if (tracing) {
+        if (lane == 0) gsr_trace_wave(counters, t_start, (uint32_t)(blockIdx.x * WPB + (threadIdx.x >> 6)), 1u, gsr_trace_pack(nsteps, t_walk, t_prep, 0ull));
     } else if (counters && lane == 0) {     // [0] (8x8 block, entry) pairs blended by all 64 lanes, [1] batches of 64 entries box-tested
         atomicAdd(counters + 0, (unsigned long long)nsteps);
         atomicAdd(counters + 1, (unsigned long long)nbatches);

@@ -38,7 +38,7 @@ stats = {"frames": 0, "backward_checked": 0, "kinds": {}, "forms": {}, "max_P": 
 t0 = time.time()
 
 
-GAMMA = 4.0 * 2.0 ** -23      # a few fp32 roundings of the quadratic form, relative to the size of its TERMS
+GAMMA = 2.0 ** -22      # two fp32 ulps of the quadratic form's TERMS (measured: the worst pixel of 345 frames sits at 0.1 of 2^-21)
 
 
 def conditioning(aux, s_):
@@ -263,7 +263,7 @@ for it in range(N):
                 assert a.abs().max().item() <= 1e-12, f"{k}: oracle gradient is zero, operator's is not"
                 continue
             dd = (a - b).abs() / scale
-            q = torch.quantile(dd.flatten()[:4_000_000], 0.999).item() if dd.numel() > 1000 else 0.0
+            q = torch.quantile(dd.flatten()[:4_000_000], 0.999).item() if dd.numel() >= 20000 else 0.0      # (below that it IS the maximum)
             gm[k] = [float(f"{dd.max().item():.3e}"), float(f"{q:.3e}")]
             desc["grad_metrics"] = gm
             stats["worst_grad_err"] = max(stats["worst_grad_err"], dd.max().item() if not degenerate else 0.0)

@@ -34,7 +34,9 @@ def analyse(tr, kernel):
     t0, t1 = tr[:, 0].astype(np.int64), tr[:, 1].astype(np.int64)
     base = t0.min()
     t0, t1 = t0 - base, t1 - base
-    steps = tr[:, 3].astype(np.float64)
+    w3 = tr[:, 3]
+    steps = (w3 & np.uint64(0xFFFF)).astype(np.float64)
+    walk, prep, store = [((w3 >> np.uint64(sh)) & np.uint64(0xFFFF)).astype(np.float64) for sh in (16, 32, 48)]
     hw = tr[:, 2]
     simd = ((hw >> np.uint64(32)) & np.uint64(15)).astype(np.int64) * 4096 + ((hw >> np.uint64(8)) & np.uint64(0xFF)).astype(np.int64) * 4 + \
            ((hw >> np.uint64(4)) & np.uint64(3)).astype(np.int64)      # (XCC, SE|SH|CU, SIMD)
@@ -65,6 +67,12 @@ def analyse(tr, kernel):
             "waves_per_simd_min_mean_max": [int(per_simd_waves.min()), round(float(per_simd_waves.mean()), 2), int(per_simd_waves.max())],
             "steps": int(steps.sum()), "heaviest_over_mean_steps": round(float(steps.max() / steps.mean()), 3),
             "wave_us_mean_max": [round(float(dur.mean()) * TICK_US, 2), round(float(dur.max()) * TICK_US, 2)],
+            # where a wave's lifetime goes (means over the waves, us): walking survivors / getting batches ready (waiting for the gathered
+            # records, box tests, staging) / storing the per-instance records / the rest (prologue loads, epilogue)
+            "wave_phase_us_mean": {"walk": round(float(walk.mean()) * TICK_US, 2), "batch_prep": round(float(prep.mean()) * TICK_US, 2),
+                                   "store": round(float(store.mean()) * TICK_US, 2),
+                                   "rest": round(float((dur - walk - prep - store).mean()) * TICK_US, 2)},
+            "walk_us_per_step": round(float(walk.sum() / max(steps.sum(), 1.0)) * TICK_US, 4),
             "rate_mid_steps_per_us": round(rate_mid / TICK_US, 1), "balanced_span_us": round(float(balanced) * TICK_US, 2),
             "tail_loss": round(float(span / balanced) - 1.0, 4),
             "rate_by_decile_of_span": [round(float(rate[int(span * k / 10): int(span * (k + 1) / 10)].mean()) / max(rate_mid, 1e-9), 3) for k in range(10)]}
