@@ -429,6 +429,7 @@ def _run(a):
     # the TRACKING build of the forward (what a training iteration runs: final_T / n_contrib / first-emission indices are
     # written for the backward), timed beside the inference build the headline uses
     track_ms = None
+    blend_timeline = None
     if world == 1:
         req = [t.detach().clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
 
@@ -445,6 +446,34 @@ def _run(a):
         tr = _lib.profile_read()
         _lib.profile_enable(False)
         stage_ms["render_track"] = tr["render"]["ms"] / max(1, tr["render"]["launches"])
+        # ---- measured timeline of the two blend launches (per-wave trace, own pass: gsr_profile_enable(4)): how much of each launch is
+        # its tail -- the drain after the last wave has started -- and where a wave's lifetime goes
+        try:
+            from diff_gaussian_rasterization.debug import wave_timeline
+            wc_tl = torch.randn(3, H, W, device=dev)
+            _lib.profile_enable(False, trace=True)
+            _lib.profile_trace()
+            with torch.no_grad():
+                forward_step()
+            tl_f = wave_timeline(_lib.profile_trace(), 1)
+            col_tl = rasterize_gaussians(req[0], None, req[1], None, req[2], req[3], req[4], None, rs, None)[0]
+            _lib.profile_trace()
+            col_tl.backward(wc_tl)
+            tl_b = wave_timeline(_lib.profile_trace(), 2)
+            for t_ in req:
+                t_.grad = None
+            del col_tl, wc_tl
+            keep_tl = ("waves", "span_us", "drain_frac", "simd_idle_frac", "mean_resident_waves_per_simd", "resident_mid_launch_per_simd",
+                       "wave_us_mean_max", "wave_phase_us_mean", "heaviest_over_mean_steps", "rate_mid_steps_per_us", "balanced_span_us", "tail_loss")
+            blend_timeline = {"forward": {k_: tl_f.get(k_) for k_ in keep_tl}, "backward": {k_: tl_b.get(k_) for k_ in keep_tl},
+                              "note": "per-wave start / end / SIMD / steps records of one launch each (the traced launch runs a few percent slower than "
+                                      "the timed ones); tail_loss = span / (steps / mid-launch step rate) - 1: what a perfectly balanced launch could "
+                                      "gain at most.  The backward starts its tiles by their heaviest half (planned from the forward's step counts); "
+                                      "the forward has no estimate of a block's work before it blends"}
+        except Exception as ex_tl:      # noqa: BLE001 -- measurement extra: never fatal
+            blend_timeline = {"error": f"{type(ex_tl).__name__}: {ex_tl}"}
+        finally:
+            _lib.profile_enable(False)
         del req
 
     # ---- train legs: forward + loss + backward + optimizer over all parameters (train.py:111-186 without densification; the
@@ -1022,6 +1051,7 @@ def _run(a):
                            "bwd_pair_steps_per_launch": None if not bwd_counters else int(bwd_counters["bwd_steps"]),
                            "bwd_batches_per_launch": None if not bwd_counters else int(bwd_counters["bwd_batches"]),
                            "listed_instance_blocks": 4 * R},
+            "blend_timeline": blend_timeline,
             "other_configs_forward": other,
             "roofline": roof,
             "roofline_train": roof_train,

@@ -822,3 +822,45 @@ def test_concurrent_forward_calls_from_two_host_threads():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_wave_trace_of_the_blend_launches_accounts_for_every_step():
+    """gsr_profile_enable(4) / gsr_profile_trace (measurement only): one record per wave of the blend kernels.  The records' steps add up to the
+    work counters' totals, every traced wave ends after it starts, and tracing changes no output bit."""
+    from diff_gaussian_rasterization import _lib, rasterize_gaussians
+    from diff_gaussian_rasterization.debug import wave_timeline
+    dev = torch.device("cuda:0")
+    cam = make_camera(640, 360)
+    sc = make_scene(60000, cam, seed=17, s_med=0.02).to(dev)
+    s = oracle_settings(cam, bg=torch.tensor([0.1, 0.2, 0.3]))
+    rs = gpu_settings(s, dev)
+    wc = torch.randn(3, 360, 640, generator=torch.Generator().manual_seed(0)).to(dev)
+
+    def run():
+        L = [t.detach().clone().requires_grad_(True) for t in (sc.means3D, sc.shs, sc.opacities, sc.scales, sc.rotations)]
+        col, _, _ = rasterize_gaussians(L[0], None, L[1], None, L[2], L[3], L[4], None, rs)
+        fw = _lib.profile_trace() if tracing[0] else None
+        col.backward(wc)
+        torch.cuda.synchronize()
+        bw = _lib.profile_trace() if tracing[0] else None
+        return col.detach(), [t.grad for t in L], fw, bw
+
+    tracing = [False]
+    _lib.profile_enable(False, counters=True)
+    _lib.profile_counters(reset=True)
+    col0, g0, _, _ = run()
+    cnt = _lib.profile_counters(reset=True)
+    tracing[0] = True
+    _lib.profile_enable(False, trace=True)
+    try:
+        _lib.profile_trace()
+        col1, g1, fw, bw = run()
+    finally:
+        _lib.profile_enable(False)
+    assert torch.equal(col0, col1) and all(torch.equal(a, b) for a, b in zip(g0, g1)), "tracing changed an output"
+    for tr, kernel, total in ((fw, 1, cnt["fwd_steps"]), (bw, 2, cnt["bwd_steps"])):
+        t = tr[(tr[:, 1] != 0) & (((tr[:, 2] >> np.uint64(40)) & np.uint64(3)) == np.uint64(kernel))]
+        assert len(t) > 0 and (t[:, 1] >= t[:, 0]).all()
+        assert int((t[:, 3] & np.uint64(0xFFFF)).sum()) == total, (kernel, int((t[:, 3] & np.uint64(0xFFFF)).sum()), total)
+        tl = wave_timeline(tr, kernel)
+        assert tl["waves"] == len(t) and tl["span_us"] > 0 and -0.5 < tl["tail_loss"] < 2.0

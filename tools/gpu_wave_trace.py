@@ -27,55 +27,7 @@ W, H = 1920, 1080
 TICK_US = 0.01
 
 
-def analyse(tr, kernel):
-    tr = tr[(tr[:, 1] != 0) & (((tr[:, 2] >> np.uint64(40)) & np.uint64(3)) == np.uint64(kernel))]
-    if len(tr) == 0:
-        return {"waves": 0}
-    t0, t1 = tr[:, 0].astype(np.int64), tr[:, 1].astype(np.int64)
-    base = t0.min()
-    t0, t1 = t0 - base, t1 - base
-    w3 = tr[:, 3]
-    steps = (w3 & np.uint64(0xFFFF)).astype(np.float64)
-    walk, prep, store = [((w3 >> np.uint64(sh)) & np.uint64(0xFFFF)).astype(np.float64) for sh in (16, 32, 48)]
-    hw = tr[:, 2]
-    simd = ((hw >> np.uint64(32)) & np.uint64(15)).astype(np.int64) * 4096 + ((hw >> np.uint64(8)) & np.uint64(0xFF)).astype(np.int64) * 4 + \
-           ((hw >> np.uint64(4)) & np.uint64(3)).astype(np.int64)      # (XCC, SE|SH|CU, SIMD)
-    span = int(t1.max())
-    keys, inv = np.unique(simd, return_inverse=True)
-    nsimd = len(keys)
-    last_end = np.zeros(nsimd, np.int64)
-    np.maximum.at(last_end, inv, t1)
-    dur = np.maximum(t1 - t0, 1)
-    # step rate over time: every wave's steps spread evenly over its lifetime, on a 1-tick grid
-    rate = np.zeros(span + 2)
-    np.add.at(rate, t0, steps / dur)
-    np.add.at(rate, t1, -steps / dur)
-    rate = np.cumsum(rate)[:span]
-    res_w = np.zeros(span + 2)
-    np.add.at(res_w, t0, 1.0)
-    np.add.at(res_w, t1, -1.0)
-    res_w = np.cumsum(res_w)[:span]
-    mid = rate[span // 4: 3 * span // 4]
-    rate_mid = float(np.median(mid))
-    balanced = steps.sum() / max(rate_mid, 1e-9)
-    per_simd_waves = np.bincount(inv, minlength=nsimd)
-    return {"waves": int(len(tr)), "simds_seen": int(nsimd), "span_us": round(span * TICK_US, 2),
-            "drain_frac": round(float(span - t0.max()) / span, 4),
-            "simd_idle_frac": round(float((span - last_end).mean()) / span, 4),
-            "mean_resident_waves_per_simd": round(float(dur.sum()) / (span * nsimd), 3),
-            "resident_mid_launch_per_simd": round(float(np.median(res_w[span // 4: 3 * span // 4])) / nsimd, 3),
-            "waves_per_simd_min_mean_max": [int(per_simd_waves.min()), round(float(per_simd_waves.mean()), 2), int(per_simd_waves.max())],
-            "steps": int(steps.sum()), "heaviest_over_mean_steps": round(float(steps.max() / steps.mean()), 3),
-            "wave_us_mean_max": [round(float(dur.mean()) * TICK_US, 2), round(float(dur.max()) * TICK_US, 2)],
-            # where a wave's lifetime goes (means over the waves, us): walking survivors / getting batches ready (waiting for the gathered
-            # records, box tests, staging) / storing the per-instance records / the rest (prologue loads, epilogue)
-            "wave_phase_us_mean": {"walk": round(float(walk.mean()) * TICK_US, 2), "batch_prep": round(float(prep.mean()) * TICK_US, 2),
-                                   "store": round(float(store.mean()) * TICK_US, 2),
-                                   "rest": round(float((dur - walk - prep - store).mean()) * TICK_US, 2)},
-            "walk_us_per_step": round(float(walk.sum() / max(steps.sum(), 1.0)) * TICK_US, 4),
-            "rate_mid_steps_per_us": round(rate_mid / TICK_US, 1), "balanced_span_us": round(float(balanced) * TICK_US, 2),
-            "tail_loss": round(float(span / balanced) - 1.0, 4),
-            "rate_by_decile_of_span": [round(float(rate[int(span * k / 10): int(span * (k + 1) / 10)].mean()) / max(rate_mid, 1e-9), 3) for k in range(10)]}
+from diff_gaussian_rasterization.debug import wave_timeline as analyse      # noqa: E402
 
 
 def run(name, sc):
