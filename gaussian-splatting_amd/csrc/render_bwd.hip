@@ -235,8 +235,12 @@ struct BwdPix2 {
     v2f T, acc;
 };
 
+// occupancy attribute of the walk kernel (tuning builds: GSR_EXTRA_FLAGS='-DGSR_BWD_OCC=__attribute__((amdgpu_waves_per_eu(8,8)))')
+#ifndef GSR_BWD_OCC
+#define GSR_BWD_OCC
+#endif
 template <bool HAS_DEPTH>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) GSR_BWD_OCC
 render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                 const float4* __restrict__ splats, const float* __restrict__ final_T,
                 const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
