@@ -292,16 +292,19 @@ def _run(a):
 
     event_stats = {}
 
+    # The timed region holds the K steps and nothing else.  Rounds 1-4 also recorded a HIP event after every step inside it; an event is
+    # a barrier packet on the stream, and with one per frame the forward loop measured 0.3801 against 0.3751 ms per frame without them
+    # (tools/gpu_hiccup_probe.py, same process, 400 frames each) -- measurement overhead in the headline.  The per-step event statistics
+    # (GPU events on the launch stream) now come from a SECOND pass of the same K steps, which `value` does not see.
+    EVENT_PASS_LEGS = ("forward", "forward_track", "train_ssim", "forward_cycled", "forward_scene_cycled")
+
     def timed_loop(step, n, name, stall_check=True):
         for attempt in range(2 if stall_check else 1):
             sync_all()
-            evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
             t0 = time.perf_counter()
             stamps = [t0]
-            evs[0].record()
             for i in range(n):
                 step()
-                evs[i + 1].record()           # GPU-side time stamp on the stream the step was enqueued on (SURVEY 8(d): event timing)
                 stamps.append(time.perf_counter())
             sync_all()
             dt = time.perf_counter() - t0
@@ -313,7 +316,15 @@ def _run(a):
             if float(flag.item()) == 0.0 or attempt == 1:
                 break
             retimed[name] = retimed.get(name, 0) + 1
-        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n))
+        per = []
+        if n > 0 and (name in EVENT_PASS_LEGS or name.startswith("other_configs")):      # the instrumented pass (not part of any reported rate)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+            evs[0].record()
+            for i in range(n):
+                step()
+                evs[i + 1].record()           # GPU-side time stamp on the stream the step was enqueued on (SURVEY 8(d): event timing)
+            sync_all()
+            per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n))
         if per:
             event_stats[name] = {"median_ms": round(per[len(per) // 2], 4), "p10_ms": round(per[len(per) // 10], 4),
                                  "p90_ms": round(per[min(len(per) - 1, (len(per) * 9) // 10)], 4), "mean_ms": round(sum(per) / len(per), 4)}
@@ -1023,7 +1034,9 @@ def _run(a):
             "train_densify": densify_leg,
             "train_iters_per_s_ssim_unfused_l1": None if "ssim_unfused_l1" not in train else round(1e3 / train["ssim_unfused_l1"], 3),
             "gpu_event_ms": event_stats,
-            "gpu_event_note": "per-step HIP-event intervals on the launch stream (median / p10 / p90 / mean) beside the wall-clock mean that "
+            "gpu_event_note": "taken in a SECOND pass of the same K steps with one HIP event per step (the timed pass that `value` / the it/s figures come from "
+                              "records no events: one barrier packet per frame cost the forward loop 1.3 %); "
+                              "per-step HIP-event intervals on the launch stream (median / p10 / p90 / mean) beside the wall-clock mean that "
                               "`value` uses; the host is paced by the per-frame R read-back, so the two agree when nothing stalls",
             "forward_cycled_views": cycled,
             "forward_frames_in_flight": frames_in_flight,
