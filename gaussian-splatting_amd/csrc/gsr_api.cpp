@@ -383,6 +383,13 @@ int gsr_set_option(const char* name, int value) {
         g_tile_sort_mode = value;
         return GSR_OK;
     }
+#ifdef GSR_AB_VARIANTS
+    if (!strcmp(name, "emit_scatter_mode")) {      // measurement build only: 1 = the level-1 scatter ranks row pieces (csrc/ab/emit_scatter_segments.inc)
+        if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "emit_scatter_mode must be 0 (instances) or 1 (row pieces)");
+        gsr_set_emit_scatter_mode(value);
+        return GSR_OK;
+    }
+#endif
     return fail(GSR_ERR_INVALID_ARG, std::string("unknown option ") + name);
 }
 
