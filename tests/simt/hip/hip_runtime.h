@@ -1,0 +1,63 @@
+// SIMT-on-CPU shim (TEST INFRASTRUCTURE, build container only): just enough of the HIP device language to run the INTEGER kernels of csrc/ --
+// 256-thread workgroups, wave64 ballots, DPP moves, LDS, barriers -- lane by lane on a CPU, so that kernel source can be brought up and
+// regression-tested without a GPU (tests/test_simt_tilesort_cpu.py).  Found ahead of the real <hip/hip_runtime.h> through -Itests/simt.
+//
+// Execution model (tests/simt/simt_runtime.h): one workgroup at a time, every lane a fiber (ucontext) on ONE OS thread.  A lane runs until it
+// reaches a workgroup barrier or a wave-level operation (ballot, DPP move, wave barrier), where it waits for the other lanes.  Between two such
+// points the lanes of a wave run one after the other FROM LANE 63 DOWN TO LANE 0 -- not in lock step: a kernel that lets one lane read what
+// another lane of the same wave writes must have a wave-level operation in between (the csrc/ kernels use __builtin_amdgcn_wave_barrier there).
+// The descending order makes the one lock-step idiom of the ranking loops come out as on the hardware: every lane reads a counter, then the
+// LOWEST matching lane writes it back (`prior = cnt[d]; ...; if (leader) cnt[d] = prior + n;`) -- the writer runs after its readers.
+// Not modelled: timing, bank conflicts, exec-masked wave operations (every live lane of a wave must take part in every wave-level operation).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define GSR_SIMT_SHIM 1
+
+struct uint2 { uint32_t x, y; };
+struct alignas(16) uint4 { uint32_t x, y, z, w; };
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return {x, y}; }
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return {x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return {x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+#define hipLaunchKernelGGL(...) do { } while (0)      /* the launchers of csrc/ are not used under the shim: tests call the kernels themselves */
+static inline hipError_t hipMemsetAsync(void*, int, size_t, hipStream_t) { return 0; }
+
+namespace simt {
+struct Idx { unsigned x, y, z; };
+void syncthreads();
+uint64_t ballot(bool pred);
+int dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl);
+void wave_barrier();
+}  // namespace simt
+extern simt::Idx threadIdx, blockIdx, blockDim, gridDim;
+
+#define __syncthreads() simt::syncthreads()
+#define __ballot(p) simt::ballot((bool)(p))
+#define __builtin_amdgcn_ballot_w64(p) simt::ballot((bool)(p))
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) simt::dpp((int)(old), (int)(src), (ctrl), (rm), (bm), (bc))
+#define __builtin_amdgcn_wave_barrier() simt::wave_barrier()
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __popcll(x) __builtin_popcountll((unsigned long long)(x))
+#define __popc(x) __builtin_popcount((unsigned)(x))
+
+using std::max;
+using std::min;
+static inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }      // one OS thread: atomic by construction
+static inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }

@@ -1,0 +1,144 @@
+// Runtime of the SIMT-on-CPU shim (tests/simt/hip/hip_runtime.h): fibers, workgroup barrier, wave-level rendezvous.  Include ONCE, in the
+// harness translation unit, after the kernels.  TEST INFRASTRUCTURE.
+#pragma once
+#include <ucontext.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <functional>
+#include <vector>
+
+simt::Idx threadIdx, blockIdx, blockDim, gridDim;
+
+namespace simt {
+constexpr int WAVE = 64;
+constexpr size_t STACK_BYTES = 256 * 1024;
+struct Wave {
+    int alive = 0, count = 0;
+    unsigned phase = 0;
+    uint64_t val[2][WAVE];
+};
+struct State {
+    int nthreads = 0, alive = 0, cur = -1;
+    std::vector<ucontext_t> ctx;
+    std::vector<char> done;
+    std::vector<char> stacks;
+    ucontext_t sched;
+    int bar_count = 0;
+    unsigned bar_phase = 0;
+    std::vector<Wave> waves;
+    std::function<void()> body;
+    const char* error = nullptr;
+} g;
+
+static void yield() { swapcontext(&g.ctx[g.cur], &g.sched); }
+
+void syncthreads() {
+    const unsigned ph = g.bar_phase;
+    if (++g.bar_count == g.alive) { g.bar_count = 0; ++g.bar_phase; yield(); return; }      // (the last thread waits for its turn too)
+    while (g.bar_phase == ph) yield();
+}
+
+// deposit v, wait for the live lanes of the wave; returns the buffer holding every lane's value (dead lanes: 0)
+static const uint64_t* exchange(uint64_t v) {
+    const int t = g.cur, w = t / WAVE, lane = t % WAVE;
+    Wave& wv = g.waves[w];
+    const unsigned ph = wv.phase;
+    uint64_t* buf = wv.val[ph & 1u];
+    buf[lane] = v;
+    if (++wv.count == wv.alive) {
+        wv.count = 0;
+        ++wv.phase;
+        yield();      // the last lane to arrive (lane 0 in a descending sweep) must not run ahead of the others: it continues in its turn of the next sweep
+    } else {
+        while (wv.phase == ph) yield();
+    }
+    return buf;
+}
+
+uint64_t ballot(bool pred) {
+    const uint64_t* b = exchange(pred ? 1u : 0u);
+    uint64_t m = 0;
+    for (int l = 0; l < WAVE; ++l) m |= (uint64_t)(b[l] & 1u) << l;
+    return m;
+}
+
+void wave_barrier() { (void)exchange(0); }
+
+int dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    const uint64_t* b = exchange((uint32_t)src);
+    const int lane = g.cur % WAVE, row = lane >> 4, bank = (lane >> 2) & 3;
+    if (!((row_mask >> row) & 1) || !((bank_mask >> bank) & 1)) return old;
+    int from = -1;
+    if (ctrl >= 0x111 && ctrl <= 0x11F) {                    // row_shr:n
+        const int n = ctrl & 0xF;
+        if ((lane & 15) >= n) from = lane - n;
+    } else if (ctrl == 0x138) {                              // wave_shr:1
+        if (lane >= 1) from = lane - 1;
+    } else if (ctrl == 0x142) {                              // row_bcast:15 -- lane 15 of a row to every lane of the next row
+        if (row >= 1) from = row * 16 - 1;
+    } else if (ctrl == 0x143) {                              // row_bcast:31 -- lane 31 to rows 2 and 3
+        if (row >= 2) from = 31;
+    } else {
+        g.error = "simt::dpp: control code not modelled";
+        return old;
+    }
+    if (from < 0) return bound_ctrl ? 0 : old;
+    return (int)(uint32_t)b[from];
+}
+
+static void trampoline() {
+    g.body();
+    const int t = g.cur, w = t / WAVE;
+    g.done[t] = 1;
+    // a lane that has left no longer takes part in barriers / wave operations (the csrc/ kernels only leave workgroup-uniformly)
+    --g.alive;
+    --g.waves[w].alive;
+    g.waves[w].val[0][t % WAVE] = g.waves[w].val[1][t % WAVE] = 0;
+    swapcontext(&g.ctx[t], &g.sched);
+}
+
+// run `body` as ONE workgroup of `nthreads` threads (multiple of 64) with blockIdx.x = block; false: deadlock or unmodelled operation
+static bool run_block(unsigned block, unsigned grid, int nthreads, const std::function<void()>& body) {
+    g.nthreads = g.alive = nthreads;
+    g.ctx.assign(nthreads, ucontext_t());
+    g.done.assign(nthreads, 0);
+    if (g.stacks.size() != (size_t)nthreads * STACK_BYTES) g.stacks.assign((size_t)nthreads * STACK_BYTES, 0);
+    g.waves.assign(nthreads / WAVE, Wave());
+    for (auto& w : g.waves) { w.alive = WAVE; memset(w.val, 0, sizeof(w.val)); }
+    g.bar_count = 0;
+    g.bar_phase = 0;
+    g.body = body;
+    g.error = nullptr;
+    blockIdx = {block, 0, 0};
+    gridDim = {grid, 1, 1};
+    blockDim = {(unsigned)nthreads, 1, 1};
+    for (int t = 0; t < nthreads; ++t) {
+        getcontext(&g.ctx[t]);
+        g.ctx[t].uc_stack.ss_sp = g.stacks.data() + (size_t)t * STACK_BYTES;
+        g.ctx[t].uc_stack.ss_size = STACK_BYTES;
+        g.ctx[t].uc_link = &g.sched;
+        makecontext(&g.ctx[t], trampoline, 0);
+    }
+    long idle_sweeps = 0;
+    while (g.alive > 0) {
+        const int alive_before = g.alive;
+        const unsigned bar_before = g.bar_phase;
+        unsigned long phases_before = 0;
+        for (auto& w : g.waves) phases_before += w.phase;
+        for (int w = 0; w < nthreads / WAVE; ++w)
+            for (int lane = WAVE - 1; lane >= 0; --lane) {          // lanes of a wave: 63 down to 0 (see hip_runtime.h)
+                const int t = w * WAVE + lane;
+                if (g.done[t]) continue;
+                g.cur = t;
+                threadIdx = {(unsigned)t, 0, 0};
+                swapcontext(&g.sched, &g.ctx[t]);
+            }
+        unsigned long phases_after = 0;
+        for (auto& w : g.waves) phases_after += w.phase;
+        if (g.alive == alive_before && g.bar_phase == bar_before && phases_after == phases_before) {
+            if (++idle_sweeps > 4) { g.error = "simt: deadlock (a barrier or wave-level operation that not every live lane reaches)"; return false; }
+        } else idle_sweeps = 0;
+    }
+    return g.error == nullptr;
+}
+}  // namespace simt

@@ -143,6 +143,8 @@ def make_frame(rng, P, gx, gy, kind):
             w, h = rng.integers(1, 5), rng.integers(1, 5)
         elif kind == "ones":
             w, h = 1, 1
+        elif kind == "columns":      # one tile wide, four high: 1024 Gaussians per block, 4096 one-tile pieces (> SEG_PCAP with nG <= TS_NGCAP)
+            w, h = 1, 4
         elif kind == "wide":
             w, h = rng.integers(1, gx + 1), rng.integers(1, 4)
         elif kind == "huge":
@@ -158,7 +160,7 @@ def make_frame(rng, P, gx, gy, kind):
 
 
 @pytest.mark.parametrize("kind,P,gx,gy", [("mixed", 3000, 120, 68), ("small", 6000, 120, 68), ("wide", 900, 120, 68), ("huge", 700, 120, 68),
-                                          ("ones", 9000, 37, 21), ("mixed", 2500, 250, 131), ("small", 5, 8, 8)])
+                                          ("ones", 9000, 37, 21), ("columns", 4000, 120, 68), ("mixed", 2500, 250, 131), ("small", 5, 8, 8)])
 def test_piece_ranking_restatement_equals_a_stable_sort_by_bucket(kind, P, gx, gy):
     rng = np.random.default_rng(zlib.crc32(f"{kind}-{P}-{gx}-{gy}".encode()))
     rects4 = make_frame(rng, P, gx, gy, kind)
@@ -217,7 +219,7 @@ def test_piece_ranking_restatement_equals_a_stable_sort_by_bucket(kind, P, gx, g
                 assert got[pos] == -1, "two instances at one position"
                 got[pos] = word
     assert np.array_equal(got, ref_words)
-    if kind != "ones":
+    if kind not in ("ones", "columns"):
         assert n_piece_blocks > 0, "the piece path was never taken"
     else:
-        assert n_piece_blocks < nblk, "a block of > 3072 one-tile pieces must take the instance-wise path"
+        assert n_piece_blocks < nblk, "a block of > 1024 Gaussians / > 3072 pieces must take the instance-wise path"
