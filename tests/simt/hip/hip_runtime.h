@@ -61,3 +61,16 @@ using std::min;
 static inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }      // one OS thread: atomic by construction
 static inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
+
+// further device-language pieces of the integer kernels (depthsort.hip)
+#define __ATOMIC_RELAXED_SHIM 0
+#define __HIP_MEMORY_SCOPE_SYSTEM 0
+#define __HIP_MEMORY_SCOPE_AGENT 1
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __clz(x) ((x) ? __builtin_clz((unsigned)(x)) : 32)
+#define __clzll(x) ((x) ? __builtin_clzll((unsigned long long)(x)) : 64)
+#define __ffsll(x) __builtin_ffsll((long long)(x))
+static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
