@@ -10,6 +10,7 @@
 simt::Idx threadIdx, blockIdx, blockDim, gridDim;
 
 namespace simt {
+const char* launch_error = nullptr;
 constexpr int WAVE = 64;
 constexpr size_t STACK_BYTES = 256 * 1024;
 struct Wave {
@@ -98,7 +99,7 @@ static void trampoline() {
 }
 
 // run `body` as ONE workgroup of `nthreads` threads (multiple of 64) with blockIdx.x = block; false: deadlock or unmodelled operation
-static bool run_block(unsigned block, unsigned grid, int nthreads, const std::function<void()>& body) {
+bool run_block(unsigned block, unsigned grid, int nthreads, const std::function<void()>& body) {
     g.nthreads = g.alive = nthreads;
     g.ctx.assign(nthreads, ucontext_t());
     g.done.assign(nthreads, 0);
@@ -136,9 +137,10 @@ static bool run_block(unsigned block, unsigned grid, int nthreads, const std::fu
         unsigned long phases_after = 0;
         for (auto& w : g.waves) phases_after += w.phase;
         if (g.alive == alive_before && g.bar_phase == bar_before && phases_after == phases_before) {
-            if (++idle_sweeps > 4) { g.error = "simt: deadlock (a barrier or wave-level operation that not every live lane reaches)"; return false; }
+            if (++idle_sweeps > 4) { launch_error = g.error = "simt: deadlock (a barrier or wave-level operation that not every live lane reaches)"; return false; }
         } else idle_sweeps = 0;
     }
+    if (g.error) launch_error = g.error;
     return g.error == nullptr;
 }
 }  // namespace simt

@@ -1,8 +1,10 @@
-"""The level-1 kernels of csrc/tilesort.hip EXECUTED on the CPU, lane by lane, through the SIMT shim (tests/simt/: 256 fibers per workgroup,
-wave64 ballots, DPP moves, LDS, barriers; the shim's header states what it does not model) -- the shipped `fill_block_first`, `emit_hist` and
-`emit_scatter`, and the measurement build's `emit_scatter_seg` (csrc/ab/emit_scatter_segments.inc: ranks row pieces instead of instances, not
-yet run on a GPU) -- against a plain stable sort of the frame's instances by level-1 bucket.  The kernel SOURCE is what is compiled here (g++,
--Itests/simt ahead of the real HIP headers); the algorithm of the segment kernel is pinned separately by tests/test_emit_segments_numpy.py.
+"""The fused emission + two-level tile sort of csrc/tilesort.hip EXECUTED on the CPU, lane by lane, through the SIMT shim (tests/simt/: 256 fibers
+per workgroup, wave64 ballots, DPP moves, LDS, barriers; the shim's header states what it does not model) and through ITS OWN LAUNCHERS
+(`hipLaunchKernelGGL` runs the grid): `fill_block_first`, `emit_hist`, `emit_scatter`, `bucket_hist`, `bucket_scan`, `bucket_scatter` -- and the
+measurement build's `emit_scatter_seg` (csrc/ab/emit_scatter_segments.inc: ranks row pieces instead of instances, not yet run on a GPU) --
+against plain stable sorts of the frame's instances: packed words by level-1 bucket, then the reference's (tile, depth, index) list and the
+tile ranges.  The kernel SOURCE is what is compiled here (g++, -Itests/simt ahead of the real HIP headers); the algorithm of the segment kernel
+is pinned separately by tests/test_emit_segments_numpy.py.
 
 Test infrastructure: tests/_build/libsimt_tilesort.so is never part of the product."""
 import ctypes as C
@@ -80,22 +82,26 @@ def test_level1_kernels_on_the_cpu_equal_a_stable_sort_by_bucket(lib, kind, P, g
     for b in range(nblk):
         j = int(np.searchsorted(incl, b * TS_ITEMS, side="right"))
         assert tuple(block_first[b]) == (j, int(incl[j] - tiles[j])), (b, block_first[b], j)
-    # ---- emit_hist on the CPU == the histogram of the reference ----
-    hist = np.zeros(nb1 * nblk, dtype=np.uint32)
-    assert lib.simt_emit_hist(R, gx, lb, hb, ptr(block_first), ptr(offsets), ptr(rect_sorted), ptr(hist)) == 0, lib.simt_last_error()
-    assert np.array_equal(hist.reshape(nb1, nblk).astype(np.int64), ref_hist), "emit_hist differs from the reference histogram"
-    # what rs_scan leaves: per (bucket, block) the instances of earlier blocks, and the bucket totals
-    before = (np.cumsum(ref_hist, axis=1) - ref_hist).astype(np.uint32).reshape(-1)
+    # the launcher's own plan for this frame
+    plb, phb, pw64 = C.c_int(), C.c_int(), C.c_int()
+    lib.simt_tile_sort_plan(n_tiles, P, C.byref(plb), C.byref(phb), C.byref(pw64))
+    assert (plb.value, phb.value, pw64.value) == (lb, hb, 0)
+    # ---- level 1 through gsr_launch_tile_sort_level1 (emit_hist, the scan of the block histograms, the scatter), both scatters ----
+    ref_before = (np.cumsum(ref_hist, axis=1) - ref_hist).astype(np.uint32)
     total = ref_hist.sum(axis=1).astype(np.uint32)
     res = {}
     for mode in (0, 1):
         words = np.full(R, 0xFFFFFFFF, dtype=np.uint32)
+        hist1 = np.zeros(nb1 * nblk, dtype=np.uint32)
+        digit_total = np.zeros(nb1, dtype=np.uint32)
         bucket_base = np.zeros(nb1 + 1, dtype=np.uint32)
         blk2_start = np.zeros(nb1 + 1, dtype=np.uint32)
         splats = np.zeros((P, 16), dtype=np.float32)
-        rc = lib.simt_emit_scatter(mode, 0, R, gx, lb, hb, ptr(block_first), ptr(offsets), ptr(rect_sorted), ptr(order), ptr(before), ptr(total),
-                                   ptr(words), ptr(bucket_base), ptr(blk2_start), ptr(splats))
+        rc = lib.simt_level1(mode, 0, C.c_int64(R), gx, lb, hb, ptr(block_first), ptr(offsets), ptr(rect_sorted), ptr(order), ptr(words), ptr(hist1),
+                             ptr(digit_total), ptr(bucket_base), ptr(blk2_start), ptr(splats))
         assert rc == 0, lib.simt_last_error()
+        assert np.array_equal(hist1.reshape(nb1, nblk), ref_before), "emit_hist (+ scan) differs from the reference histogram"
+        assert np.array_equal(digit_total, total)
         if not np.array_equal(words, ref_words):
             bad = np.nonzero(words != ref_words)[0]
             raise AssertionError(f"mode {mode}: {bad.size} of {R} packed words differ, first at {bad[:6].tolist()}: got {words[bad[:6]].tolist()} want {ref_words[bad[:6]].tolist()}")
@@ -112,15 +118,15 @@ def test_level1_kernels_on_the_cpu_equal_a_stable_sort_by_bucket(lib, kind, P, g
     cnt = np.bincount(inst_tile, minlength=n_tiles)
     starts = np.concatenate([[0], np.cumsum(cnt)])[:-1]
     ref_ranges = np.stack([np.where(cnt > 0, starts, 0), np.where(cnt > 0, starts + cnt, 0)], axis=1).astype(np.uint32)
-    for fused in (1, 0):
+    for scan_mode in (2, 1, 0):      # folded into the scatter / its own launch / the launcher's choice
         hist2 = np.zeros((nblk + 256 + nb1) * 256, dtype=np.uint32)
         tile_base = np.zeros(65536, dtype=np.uint32)
         point_list = np.full(R, 0xFFFFFFFF, dtype=np.uint32)
         ranges = np.full((n_tiles, 2), 0xFFFFFFFF, dtype=np.uint32)
-        rc = lib.simt_level2(0, fused, R, n_tiles, lb, hb, ptr(res[0][0]), ptr(bucket_base), ptr(blk2_start), ptr(hist2), ptr(tile_base), ptr(point_list), ptr(ranges))
+        rc = lib.simt_level2(0, scan_mode, C.c_int64(R), n_tiles, lb, hb, ptr(res[0][0]), ptr(bucket_base), ptr(blk2_start), ptr(hist2), ptr(tile_base), ptr(point_list), ptr(ranges))
         assert rc == 0, lib.simt_last_error()
-        assert np.array_equal(point_list, ref_list), f"level 2 (fused scan {fused}): sorted point list differs"
-        assert np.array_equal(ranges, ref_ranges), f"level 2 (fused scan {fused}): tile ranges differ"
+        assert np.array_equal(point_list, ref_list), f"level 2 (scan mode {scan_mode}): sorted point list differs"
+        assert np.array_equal(ranges, ref_ranges), f"level 2 (scan mode {scan_mode}): tile ranges differ"
 
 
 def test_level1_scatter_with_64_bit_words_on_the_cpu(lib):
@@ -150,13 +156,21 @@ def test_level1_scatter_with_64_bit_words_on_the_cpu(lib):
     np.add.at(ref_hist, (bucket, np.arange(R) // TS_ITEMS), 1)
     block_first = np.zeros((nblk + 2, 2), dtype=np.uint32)
     assert lib.simt_fill_block_first(P, ptr(offsets), ptr(block_first), nblk + 2) == 0
-    before = (np.cumsum(ref_hist, axis=1) - ref_hist).astype(np.uint32).reshape(-1)
-    total = ref_hist.sum(axis=1).astype(np.uint32)
     for mode in (0, 1):
         words = np.zeros(R, dtype=np.uint64)
+        hist1 = np.zeros(nb1 * nblk, dtype=np.uint32)
+        digit_total = np.zeros(nb1, dtype=np.uint32)
         bucket_base = np.zeros(nb1 + 1, dtype=np.uint32)
         blk2_start = np.zeros(nb1 + 1, dtype=np.uint32)
-        rc = lib.simt_emit_scatter(mode, 1, R, gx, lb, hb, ptr(block_first), ptr(offsets), ptr(rect_sorted), ptr(order), ptr(before), ptr(total),
-                                   ptr(words), ptr(bucket_base), ptr(blk2_start), None)
+        rc = lib.simt_level1(mode, 1, C.c_int64(R), gx, lb, hb, ptr(block_first), ptr(offsets), ptr(rect_sorted), ptr(order), ptr(words), ptr(hist1),
+                             ptr(digit_total), ptr(bucket_base), ptr(blk2_start), None)
         assert rc == 0, lib.simt_last_error()
         assert np.array_equal(words, ref_words), f"mode {mode}"
+    # level 2 on the wide words
+    o2 = np.argsort(inst_tile, kind="stable")
+    hist2 = np.zeros((nblk + 256 + nb1) * 256, dtype=np.uint32)
+    tile_base = np.zeros(65536, dtype=np.uint32)
+    point_list = np.zeros(R, dtype=np.uint32)
+    ranges = np.zeros((gx * gy, 2), dtype=np.uint32)
+    assert lib.simt_level2(1, 0, C.c_int64(R), gx * gy, lb, hb, ptr(words), ptr(bucket_base), ptr(blk2_start), ptr(hist2), ptr(tile_base), ptr(point_list), ptr(ranges)) == 0, lib.simt_last_error()
+    assert np.array_equal(point_list, inst_id[o2].astype(np.uint32))
