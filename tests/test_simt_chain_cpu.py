@@ -90,3 +90,48 @@ def test_binning_chain_source_on_the_cpu_equals_the_oracle_bins(lib, name):
     assert np.array_equal(ranges, bins["ranges"].numpy().astype(np.uint32)), "tile ranges differ"
     V = int((tiles > 0).sum())
     assert np.array_equal(order[:V].astype(np.int64), np.argsort(np.where(tiles > 0, depth_bits, 1 << 40), kind="stable")[:V]), "depth order differs"
+
+
+def _run_rects(lib, w, h, minx, miny, keys, gx, gy):
+    P = len(w)
+    tiles = (w * h).astype(np.uint32)
+    R = int(tiles.sum())
+    rect = np.stack([minx | ((minx + w) << 16), miny | ((miny + h) << 16)], axis=1).astype(np.uint32)
+    rect[tiles == 0] = 0
+    keys = np.where(tiles > 0, keys, CULLED).astype(np.uint32)
+    listed = tiles > 0
+    wg = np.array([[(~np.uint32(keys[listed].min())) & np.uint32(0xFFFFFFFF), keys[listed].max()]], dtype=np.uint32)
+    order = np.zeros(P, dtype=np.uint32)
+    pl = np.full(R, 0xFFFFFFFF, dtype=np.uint32)
+    rg = np.full((gx * gy, 2), 0xFFFFFFFF, dtype=np.uint32)
+    assert lib.simt_bin(P, gx, gy, ptr(keys), ptr(tiles), ptr(rect), ptr(wg), 1, R, ptr(order), ptr(pl), ptr(rg)) == R, lib.simt_chain_last_error()
+    it, ii = [], []
+    for j in np.argsort(keys.astype(np.int64), kind="stable"):
+        if tiles[j]:
+            ys, xs = np.meshgrid(np.arange(miny[j], miny[j] + h[j]), np.arange(minx[j], minx[j] + w[j]), indexing="ij")
+            it.append((ys * gx + xs).reshape(-1))
+            ii.append(np.full(int(tiles[j]), j))
+    it, ii = np.concatenate(it), np.concatenate(ii)
+    assert np.array_equal(pl, ii[np.argsort(it, kind="stable")].astype(np.uint32)), "sorted point list differs"
+    cnt = np.bincount(it, minlength=gx * gy)
+    st = np.concatenate([[0], np.cumsum(cnt)])[:-1]
+    assert np.array_equal(rg, np.stack([np.where(cnt > 0, st, 0), np.where(cnt > 0, st + cnt, 0)], axis=1).astype(np.uint32)), "tile ranges differ"
+    return R
+
+
+def test_binning_chain_source_at_emission_block_boundaries(lib):
+    """R an exact multiple of the 4096-instance emission block (the table entry one past the last block), with and without a tile-less tail,
+    one Gaussian that is exactly one block, block boundaries that coincide with Gaussian boundaries."""
+    rng = np.random.default_rng(5)
+    gx, gy = 120, 68
+    for k in (1, 2, 5):
+        P = 256 * k                                        # 16 tiles each
+        assert _run_rects(lib, np.full(P, 4), np.full(P, 4), rng.integers(0, gx - 4, P), rng.integers(0, gy - 4, P), 0x00400000 + rng.integers(0, 1 << 16, P), gx, gy) == 4096 * k
+    P = 512 + 100
+    w = np.concatenate([np.full(512, 4), np.zeros(100, dtype=np.int64)])
+    assert _run_rects(lib, w, np.full(P, 4), rng.integers(0, gx - 4, P), rng.integers(0, gy - 4, P), 0x00400000 + rng.integers(0, 1 << 16, P), gx, gy) == 8192
+    assert _run_rects(lib, np.array([64]), np.array([64]), np.array([3]), np.array([2]), np.array([0x00400000]), gx, gy) == 4096
+    assert _run_rects(lib, np.array([64, 1, 64, 2]), np.array([64, 1, 64, 3]), np.array([0, 5, 10, 7]), np.array([0, 1, 2, 3]), 0x00400000 + np.array([5, 6, 7, 8]), gx, gy) == 8199
+    # degenerate grids
+    assert _run_rects(lib, np.array([1, 1, 1]), np.array([1, 1, 1]), np.zeros(3, dtype=np.int64), np.zeros(3, dtype=np.int64), 0x00400000 + np.array([9, 3, 3]), 1, 1) == 3
+    assert _run_rects(lib, np.array([3, 2]), np.array([200, 7]), np.array([0, 1]), np.array([0, 50]), 0x00400000 + np.array([2, 1]), 3, 200) == 614
