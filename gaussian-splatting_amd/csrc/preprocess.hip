@@ -45,6 +45,9 @@ __device__ __forceinline__ void load_cam(const GsrCamDev& c, GsrCam& cam) {
 // memory operation, so the IR optimiser may sink every load across it, next to its LDS write -- which it did in the split-SH
 // forward the moment the surrounding kernel changed (13 x load -> s_waitcnt vmcnt(0) -> ds_write_b128, tools/isa_audit.py).
 // One empty asm statement that names ALL the loaded registers as operands can only be placed after the last load was issued.
+#ifdef GSR_SIMT_SHIM      // (tests/simt/: the kernel source compiled for the host; a compiler-scheduling fence has no meaning there)
+__device__ __forceinline__ void fence_loaded12(float4 (&)[12]) {}
+#else
 typedef float gsr_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void fence_loaded12(float4 (&v)[12]) {
     gsr_v4f r[12];
@@ -56,6 +59,7 @@ __device__ __forceinline__ void fence_loaded12(float4 (&v)[12]) {
     for (int k = 0; k < 12; ++k) v[k] = make_float4(r[k].x, r[k].y, r[k].z, r[k].w);
     __builtin_amdgcn_sched_barrier(0);
 }
+#endif
 
 // Cooperative, coalesced copy of the SH rows of the wave's 64 Gaussians [i0, i0+64) from global memory into the wave's
 // LDS tile.  Only rows whose bit is set in `rows` are fetched (16 bytes at a time).  M == 16 only.

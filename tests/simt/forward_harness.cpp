@@ -1,0 +1,98 @@
+// The default FORWARD of the operator from the product's kernel source, on the CPU: per-Gaussian kernel (csrc/preprocess.hip, with its frame
+// statistics), bucket depth sort (depthsort.hip), fused emission + two-level tile sort (tilesort.hip), blend (render_fwd.hip) -- eleven launches in
+// the order of gsr_rasterize_forward / bin_and_render (csrc/gsr_api.cpp), every one through the product's own launcher, every lane a fiber of the
+// SIMT shim (tests/simt/).  Built with g++ -ffp-contract=off (the flag preprocess.hip ships with; the blend then runs without FMA contraction and
+// with libm's exp2f instead of v_exp_f32: the image is compared within the parity suite's tolerance, the integers bit for bit).
+// TEST INFRASTRUCTURE (tests/test_simt_forward_cpu.py): a checker of the kernel source, never part of libgsr_hip.so.
+#define __HIPCC__ 1
+#include "hip/hip_runtime.h"
+#include "preprocess.hip"
+#include "depthsort.hip"
+#include "tilesort.hip"
+#include "render_fwd.hip"
+#include "simt_runtime.h"
+#include <vector>
+
+void gsr_launch_rs_scan(uint32_t* block_hist, int nblocks, int ndigits, uint32_t* digit_total, hipStream_t) {      // sort.hip's rs_scan, restated
+    for (int d = 0; d < ndigits; ++d) {
+        uint32_t run = 0;
+        for (int b = 0; b < nblocks; ++b) {
+            const uint32_t c = block_hist[(size_t)d * nblocks + b];
+            block_hist[(size_t)d * nblocks + b] = run;
+            run += c;
+        }
+        digit_total[d] = run;
+    }
+}
+
+static char g_err[256];
+
+extern "C" {
+
+const char* simt_fwd_last_error(void) { return g_err; }
+
+// settings as GsrRasterSettings (include/gsr.h) with HOST pointers; fused [P,16,3] SH tensor or colors_precomp; scales + rotations.
+// Outputs: radii[P], tiles[P], out_color[3HW], out_invdepth[HW]; point_list (capacity r_cap), ranges[gx*gy]; track != 0: final_T[HW], n_contrib[HW].
+// Returns R (>= 0) or -1.
+int64_t simt_forward(const GsrRasterSettings* s, int snug, int P, int M, const float* means3D, const float* shs, const float* colors_precomp,
+                     const float* opacities, const float* scales, const float* rotations, int32_t* radii, uint32_t* tiles_out, float* out_color,
+                     float* out_invdepth, uint32_t* point_list, int64_t r_cap, uint2* ranges, int track, float* final_T, uint32_t* n_contrib) {
+    GsrCamDev c;
+    c.W = s->image_width; c.H = s->image_height;
+    c.gx = (c.W + GSR_TILE - 1) / GSR_TILE; c.gy = (c.H + GSR_TILE - 1) / GSR_TILE;
+    c.focal_x = (float)c.W / (2.0f * s->tanfovx); c.focal_y = (float)c.H / (2.0f * s->tanfovy);      // (make_cam, csrc/gsr_api.cpp)
+    c.limx = 1.3f * s->tanfovx; c.limy = 1.3f * s->tanfovy;
+    c.scale_modifier = s->scale_modifier; c.sh_degree = s->sh_degree; c.M = M; c.antialiasing = s->antialiasing ? 1 : 0; c.snug = snug;
+    c.tile_y0 = 0; c.tile_y1 = c.gy;
+    c.view = s->viewmatrix; c.proj = s->projmatrix; c.campos = s->campos; c.bg = s->bg; c.sh_dc = nullptr; c.dL_dsh_dc = nullptr;
+    const int n_tiles = c.gx * c.gy;
+    const size_t n = (size_t)P + 64;
+    std::vector<float4> splats(4 * n);
+    std::vector<uint2> rect(n), rect_sorted(n), wg_range(GSR_FRAME_MAX_GROUPS + 1), pairs0(n), pairs1(n);
+    std::vector<uint32_t> tiles(n), keys0(n), keys1(n), vals0(n), vals1(n), offsets(n), frame(64, 0u), state(16, 0u);
+    const size_t nblocks = gsr_depth_bucket_blocks(P), nseg = gsr_depth_bucket_segments(P);
+    std::vector<uint32_t> cnt_tab(nblocks * GSR_DS_BUCKETS), tile_tab(nblocks * GSR_DS_BUCKETS), cnt_total(GSR_DS_BUCKETS), tile_total(GSR_DS_BUCKETS), plan(nseg * 8 + 8);
+    GsrGeom g{};
+    g.splats = splats.data(); g.rect = rect.data(); g.tiles = tiles.data(); g.clamped = nullptr;
+    g.keys[0] = keys0.data(); g.keys[1] = keys1.data(); g.vals[0] = vals0.data(); g.vals[1] = vals1.data();
+    g.rect_sorted = rect_sorted.data(); g.offsets = offsets.data(); g.num_rendered = frame.data(); g.wg_range = wg_range.data();
+    g.ds.pairs[0] = pairs0.data(); g.ds.pairs[1] = pairs1.data(); g.ds.cnt_tab = cnt_tab.data(); g.ds.tile_tab = tile_tab.data();
+    g.ds.cnt_total = cnt_total.data(); g.ds.tile_total = tile_total.data(); g.ds.plan = plan.data();
+    GsrFrameStatsDev fs;
+    fs.state = state.data(); fs.frame = frame.data(); fs.wg_range = wg_range.data(); fs.host_word = nullptr; fs.seq = 1;
+    auto bail = [&]() -> int64_t { snprintf(g_err, sizeof(g_err), "%s", simt::launch_error ? simt::launch_error : "?"); simt::launch_error = nullptr; return -1; };
+    const int n_range = gsr_launch_preprocess(c, P, means3D, shs, colors_precomp, opacities, scales, rotations, nullptr, g, radii, fs, nullptr);
+    if (simt::launch_error) return bail();
+    const uint64_t R64 = ((uint64_t)frame[1] << 32) | frame[0];
+    if (state[0] != 0u || state[1] != 0u) { snprintf(g_err, sizeof(g_err), "the frame-statistics counter was not reset by the last workgroup"); return -1; }
+    if ((int64_t)R64 > r_cap) { snprintf(g_err, sizeof(g_err), "R = %llu exceeds the caller's capacity", (unsigned long long)R64); return -1; }
+    for (int i = 0; i < P; ++i) tiles_out[i] = tiles[i];
+    const uint32_t R = (uint32_t)R64;
+    const uint32_t bf_cap = (uint32_t)gsr_block_first_cap(P);
+    const int64_t nblk = ((int64_t)R + GSR_TS_ITEMS - 1) / GSR_TS_ITEMS;
+    std::vector<uint2> block_first(std::max<size_t>(bf_cap, (size_t)nblk + 2));
+    gsr_launch_depth_bucket_sort(P, g.keys[0], g.tiles, g.rect, frame.data(), wg_range.data(), n_range, g.ds, g.vals[1], g.rect_sorted, g.offsets,
+                                 block_first.data(), bf_cap, nullptr, nullptr);
+    if (simt::launch_error) return bail();
+    std::vector<uint64_t> words((size_t)R + 16);
+    if (R > 0) {
+        GsrTileSortPlan tp;
+        gsr_tile_sort_plan(n_tiles, P, &tp);
+        if ((uint64_t)nblk + 1 > (uint64_t)bf_cap) gsr_launch_fill_block_first(P, g.offsets, block_first.data(), (uint32_t)(nblk + 2), nullptr);
+        std::vector<uint32_t> hist1((size_t)256 * (nblk + 1)), digit_total(256), bucket_base(257), blk2_start(257), hist2((size_t)(nblk + 512) * 256), tile_base(65536);
+        gsr_launch_tile_sort_level1(tp, R, c.gx, block_first.data(), g.offsets, g.rect_sorted, g.vals[1], words.data(), hist1.data(), digit_total.data(),
+                                    bucket_base.data(), blk2_start.data(), track ? g.splats : nullptr, nullptr);
+        if (simt::launch_error) return bail();
+        gsr_launch_tile_sort_level2(tp, R, n_tiles, words.data(), point_list, bucket_base.data(), blk2_start.data(), hist2.data(), tile_base.data(), ranges, nullptr);
+        if (simt::launch_error) return bail();
+    } else {
+        for (int t = 0; t < n_tiles; ++t) ranges[t] = make_uint2(0u, 0u);
+    }
+    std::vector<uint32_t> block_steps((size_t)n_tiles * 4 + 16);
+    gsr_launch_render_forward(c, ranges, point_list, g.splats, track ? final_T : nullptr, track ? n_contrib : nullptr, track ? block_steps.data() : nullptr,
+                              out_color, out_invdepth, 0, nullptr, nullptr);
+    if (simt::launch_error) return bail();
+    return (int64_t)R;
+}
+
+}  // extern "C"

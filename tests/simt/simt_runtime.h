@@ -65,6 +65,8 @@ uint64_t ballot(bool pred) {
 
 void wave_barrier() { (void)exchange(0); }
 
+uint32_t readlane(uint32_t v, int lane) { return (uint32_t)exchange(v)[lane & 63]; }
+
 int dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     const uint64_t* b = exchange((uint32_t)src);
     const int lane = g.cur % WAVE, row = lane >> 4, bank = (lane >> 2) & 3;

@@ -1,0 +1,100 @@
+"""The operator's default FORWARD, from the product's kernel source, against the oracle -- in the build container, without a GPU.
+csrc/preprocess.hip (+ its frame statistics), depthsort.hip, tilesort.hip and render_fwd.hip are compiled with g++ against the SIMT shim of
+tests/simt/ (fibers, wave64 ballots, DPP moves, readlane, LDS, barriers; -ffp-contract=off) and run through the product's own launchers in the
+order of gsr_rasterize_forward: eleven launches, every lane executed.  The scenes, the oracle call and the bars are those of the GPU parity suite
+(`tests/test_gpu_parity.py::test_forward_parity`: radii, tiles_touched, R, sorted point list, tile ranges and n_contrib bit-exact, image /
+inverse depth 1e-5 off the oracle's fragile pixels, final_T 5e-6), both builds of the blend (tracking / inference) and both rectangle modes.
+Differences to the GPU build: no FMA contraction in the blend, libm's exp2f for v_exp_f32 -- inside the same bars.
+
+Test infrastructure: a checker of the kernel SOURCE (tests/_build/libsimt_forward.so is never shipped); the product has no CPU path."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import reference_tiles
+import test_gpu_parity as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "_build", "libsimt_forward.so")
+sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting_amd"))
+
+pytestmark = pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    src = os.path.join(ROOT, "tests", "simt", "forward_harness.cpp")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "tests", "simt"),
+                           "-I" + os.path.join(ROOT, "gaussian-splatting_amd", "csrc"), "-I" + os.path.join(ROOT, "include"), "-x", "c++", src, "-o", OUT])
+    h = C.CDLL(OUT)
+    h.simt_fwd_last_error.restype = C.c_char_p
+    h.simt_forward.restype = C.c_int64
+    return h
+
+
+def f32(t):
+    return np.ascontiguousarray(t.detach().to(torch.float32).numpy())
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def run_simt(lib, s, sc, track, snug=1, colors=None):
+    from diff_gaussian_rasterization._lib import GsrRasterSettings
+    H, W = int(s.image_height), int(s.image_width)
+    bg, view, proj, campos = f32(s.bg), f32(s.viewmatrix), f32(s.projmatrix), f32(s.campos)
+    rs = GsrRasterSettings(H, W, float(s.tanfovx), float(s.tanfovy), ptr(bg).value, float(s.scale_modifier), ptr(view).value, ptr(proj).value,
+                           int(s.sh_degree), ptr(campos).value, 0, 0, 1 if s.antialiasing else 0, 0, 0, 0 if track else 1, None, None)
+    P = sc.P
+    m, op, scl, rot = f32(sc.means3D), f32(sc.opacities), f32(sc.scales), f32(sc.rotations)
+    shs = None if colors is not None else f32(sc.shs)
+    col_in = f32(colors) if colors is not None else None
+    M = 0 if colors is not None else sc.shs.shape[1]
+    radii = np.zeros(P, dtype=np.int32)
+    tiles = np.zeros(P, dtype=np.uint32)
+    color = np.zeros((3, H, W), dtype=np.float32)
+    invd = np.zeros((1, H, W), dtype=np.float32)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    r_cap = 4_000_000
+    point_list = np.zeros(r_cap, dtype=np.uint32)
+    ranges = np.zeros((gx * gy, 2), dtype=np.uint32)
+    final_T = np.zeros((H, W), dtype=np.float32)
+    n_contrib = np.zeros((H, W), dtype=np.uint32)
+    R = lib.simt_forward(C.byref(rs), snug, P, M, ptr(m), ptr(shs), ptr(col_in), ptr(op), ptr(scl), ptr(rot), ptr(radii), ptr(tiles), ptr(color),
+                         ptr(invd), ptr(point_list), C.c_int64(r_cap), ptr(ranges), 1 if track else 0, ptr(final_T), ptr(n_contrib))
+    assert R >= 0, lib.simt_fwd_last_error()
+    out = {"radii": torch.from_numpy(radii), "tiles_touched": torch.from_numpy(tiles.astype(np.int64)), "R": int(R),
+           "point_list": torch.from_numpy(point_list[:R].astype(np.int64)), "ranges": torch.from_numpy(ranges.astype(np.int64)),
+           "color": torch.from_numpy(color), "invdepth": torch.from_numpy(invd)}
+    if track:
+        out["n_contrib"] = torch.from_numpy(n_contrib.astype(np.int64))
+        out["final_T"] = torch.from_numpy(final_T)
+    return out
+
+
+@pytest.mark.parametrize("track", [True, False], ids=["track", "inference"])
+@pytest.mark.parametrize("name", ["c1", "odd_aa", "edge_lookat", "edge_aa_scale", "deg1", "deg0_dense"])
+def test_forward_of_the_kernel_source_on_the_cpu_against_the_oracle(lib, name, track):
+    cam, sc, opts = G.mk(name)
+    s, col, radii, invd, aux = G.run_oracle(cam, sc, opts)
+    assert (radii > 0).sum() > 100
+    out = run_simt(lib, s, sc, track)
+    G.check_forward(s, col, radii, invd, aux, out)
+
+
+def test_forward_of_the_kernel_source_with_the_reference_rectangles_and_precomputed_colours(lib):
+    """snug = 0: the reference's own tile squares (Appendix A.2 step 8) -- bins against the oracle in reference mode; colors_precomp call form."""
+    cam, sc, opts = G.mk("edge_lookat")
+    colors = torch.rand(sc.P, 3, generator=torch.Generator().manual_seed(1))
+    with reference_tiles():
+        s, col, radii, invd, aux = G.run_oracle(cam, sc, opts, colors=colors)
+    out = run_simt(lib, s, sc, True, snug=0, colors=colors)
+    G.check_forward(s, col, radii, invd, aux, out)
