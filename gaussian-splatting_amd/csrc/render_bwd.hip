@@ -39,7 +39,11 @@
 
 namespace {
 
+#ifdef GSR_SIMT_SHIM      // (tests/simt/: the kernel source compiled for the host, where the two swap builtins are functions of the shim)
+typedef uint2 uint2v;
+#else
 typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+#endif
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_add(float v) {

@@ -1,5 +1,6 @@
-// The default FORWARD of the operator from the product's kernel source, on the CPU: per-Gaussian kernel (csrc/preprocess.hip, with its frame
-// statistics), bucket depth sort (depthsort.hip), fused emission + two-level tile sort (tilesort.hip), blend (render_fwd.hip) -- eleven launches in
+// The default FORWARD (and, on request, BACKWARD) of the operator from the product's kernel source, on the CPU: per-Gaussian kernel (csrc/preprocess.hip, with its frame
+// statistics), bucket depth sort (depthsort.hip), fused emission + two-level tile sort (tilesort.hip), blend (render_fwd.hip) -- eleven launches --, then the blend backward (render_bwd.hip: plan, walk, the three reduce kernels) and the fused
+// per-Gaussian backward (preprocess.hip), in
 // the order of gsr_rasterize_forward / bin_and_render (csrc/gsr_api.cpp), every one through the product's own launcher, every lane a fiber of the
 // SIMT shim (tests/simt/).  Built with g++ -ffp-contract=off (the flag preprocess.hip ships with; the blend then runs without FMA contraction and
 // with libm's exp2f instead of v_exp_f32: the image is compared within the parity suite's tolerance, the integers bit for bit).
@@ -10,6 +11,9 @@
 #include "depthsort.hip"
 #include "tilesort.hip"
 #include "render_fwd.hip"
+namespace tu_bwd {      // (render_fwd.hip and render_bwd.hip both define min_q_over_box / bcast in their anonymous namespaces)
+#include "render_bwd.hip"
+}  // namespace tu_bwd
 #include "simt_runtime.h"
 #include <vector>
 
@@ -36,7 +40,11 @@ const char* simt_fwd_last_error(void) { return g_err; }
 // Returns R (>= 0) or -1.
 int64_t simt_forward(const GsrRasterSettings* s, int snug, int P, int M, const float* means3D, const float* shs, const float* colors_precomp,
                      const float* opacities, const float* scales, const float* rotations, int32_t* radii, uint32_t* tiles_out, float* out_color,
-                     float* out_invdepth, uint32_t* point_list, int64_t r_cap, uint2* ranges, int track, float* final_T, uint32_t* n_contrib) {
+                     float* out_invdepth, uint32_t* point_list, int64_t r_cap, uint2* ranges, int track, float* final_T, uint32_t* n_contrib,
+                     // backward (dL_dcolor != NULL, track != 0): blend backward (plan + walk), reduce, per-Gaussian backward -- the launches of
+                     // gsr_backward_blend / gsr_backward_preprocess.  dL_dinvdepth may be NULL (no depth supervision).  dL_dsh: [P,M,3] or, with colors_precomp, [P,3]
+                     const float* dL_dcolor, const float* dL_dinvdepth, float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dopacity, float* dL_dsh,
+                     float* dL_dscales, float* dL_drotations) {
     GsrCamDev c;
     c.W = s->image_width; c.H = s->image_height;
     c.gx = (c.W + GSR_TILE - 1) / GSR_TILE; c.gy = (c.H + GSR_TILE - 1) / GSR_TILE;
@@ -92,6 +100,23 @@ int64_t simt_forward(const GsrRasterSettings* s, int snug, int P, int M, const f
     gsr_launch_render_forward(c, ranges, point_list, g.splats, track ? final_T : nullptr, track ? n_contrib : nullptr, track ? block_steps.data() : nullptr,
                               out_color, out_invdepth, 0, nullptr, nullptr);
     if (simt::launch_error) return bail();
+    if (dL_dcolor && track) {
+        const size_t nr = (size_t)(R > 0 ? R : 1), nu = tu_bwd::gsr_reduce_units((int64_t)nr);
+        std::vector<float> splat_grads((size_t)P * 12 + 16, 0.f), inst_grads(nr * 12 * GSR_BWD_SLOTS + 16), unit_piece(nu * 24 + 32);
+        std::vector<uint32_t> inst_flag(nr + 16), tile_order((size_t)n_tiles * 2 + 16);
+        std::vector<uint2> unit_first(nu + 16);
+        if (R > 0) {
+            tu_bwd::gsr_launch_render_backward(c, ranges, point_list, g.splats, final_T, n_contrib, block_steps.data(), tile_order.data(), dL_dcolor, dL_dinvdepth,
+                                               nullptr, inst_grads.data(), inst_flag.data(), (int64_t)R, 0, 2, nullptr, nullptr);
+            if (simt::launch_error) return bail();
+            tu_bwd::gsr_launch_reduce_instances(P, (int64_t)R, g.vals[1], g.offsets, g.splats, inst_grads.data(), inst_flag.data(), splat_grads.data(),
+                                                unit_first.data(), unit_piece.data(), nullptr);
+            if (simt::launch_error) return bail();
+        }
+        gsr_launch_preprocess_backward(c, P, means3D, shs, colors_precomp, opacities, scales, rotations, nullptr, radii, g, splat_grads.data(), dL_dmeans2D,
+                                       colors_precomp ? dL_dsh : nullptr, dL_dopacity, dL_dmeans3D, nullptr, shs ? dL_dsh : nullptr, dL_dscales, dL_drotations, nullptr);
+        if (simt::launch_error) return bail();
+    }
     return (int64_t)R;
 }
 

@@ -35,7 +35,7 @@ struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned 
 typedef void* hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
-static inline hipError_t hipMemsetAsync(void*, int, size_t, hipStream_t) { return 0; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }      // (launches run synchronously: so does this)
 
 namespace simt {
 struct Idx { unsigned x, y, z; };
@@ -103,3 +103,10 @@ static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; 
 namespace simt { uint32_t readlane(uint32_t v, int lane); }
 #define __builtin_amdgcn_readlane(v, lane) ((int)simt::readlane((uint32_t)(v), (lane)))
 static inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; if (v > o) *p = v; return o; }
+
+// v_permlane32_swap / v_permlane16_swap: (new first operand, new second operand) after swapping the first operand's upper half (odd rows) with the
+// second operand's lower half (even rows); __shfl_xor
+namespace simt { uint2 permlane32_swap(uint32_t a, uint32_t b); uint2 permlane16_swap(uint32_t a, uint32_t b); uint32_t shfl_xor(uint32_t v, int m); }
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) simt::permlane32_swap((a), (b))
+#define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) simt::permlane16_swap((a), (b))
+static inline int __shfl_xor(int v, int m, int = 64) { return (int)simt::shfl_xor((uint32_t)v, m); }

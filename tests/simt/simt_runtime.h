@@ -47,6 +47,9 @@ static const uint64_t* exchange(uint64_t v) {
     uint64_t* buf = wv.val[ph & 1u];
     buf[lane] = v;
     if (++wv.count == wv.alive) {
+        if (wv.alive < WAVE)      // lanes that have left the kernel contribute 0 (their slots may hold values of earlier operations)
+            for (int l = 0; l < WAVE; ++l)
+                if (g.done[w * WAVE + l]) buf[l] = 0;
         wv.count = 0;
         ++wv.phase;
         yield();      // the last lane to arrive (lane 0 in a descending sweep) must not run ahead of the others: it continues in its turn of the next sweep
@@ -67,6 +70,25 @@ void wave_barrier() { (void)exchange(0); }
 
 uint32_t readlane(uint32_t v, int lane) { return (uint32_t)exchange(v)[lane & 63]; }
 
+uint32_t shfl_xor(uint32_t v, int m) { return (uint32_t)exchange(v)[(g.cur % WAVE) ^ (m & 63)]; }
+
+// both operands travel in one exchange (a in the low, b in the high word)
+uint2 permlane32_swap(uint32_t a, uint32_t b) {
+    const uint64_t* buf = exchange((uint64_t)a | ((uint64_t)b << 32));
+    const int lane = g.cur % WAVE;
+    auto A = [&](int l) { return (uint32_t)buf[l]; };
+    auto B = [&](int l) { return (uint32_t)(buf[l] >> 32); };
+    return lane < 32 ? make_uint2(A(lane), A(lane + 32)) : make_uint2(B(lane - 32), B(lane));
+}
+uint2 permlane16_swap(uint32_t a, uint32_t b) {
+    const uint64_t* buf = exchange((uint64_t)a | ((uint64_t)b << 32));
+    const int lane = g.cur % WAVE, row = lane >> 4;
+    auto A = [&](int l) { return (uint32_t)buf[l]; };
+    auto B = [&](int l) { return (uint32_t)(buf[l] >> 32); };
+    // odd rows of the first operand <-> even rows of the second
+    return (row & 1) ? make_uint2(B(lane - 16), B(lane)) : make_uint2(A(lane), A(lane + 16));
+}
+
 int dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     const uint64_t* b = exchange((uint32_t)src);
     const int lane = g.cur % WAVE, row = lane >> 4, bank = (lane >> 2) & 3;
@@ -77,12 +99,16 @@ int dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl
         if ((lane & 15) >= n) from = lane - n;
     } else if (ctrl == 0x138) {                              // wave_shr:1
         if (lane >= 1) from = lane - 1;
+    } else if (ctrl == 0x130) {                              // wave_shl:1 -- the next lane's value
+        if (lane < WAVE - 1) from = lane + 1;
     } else if (ctrl == 0x142) {                              // row_bcast:15 -- lane 15 of a row to every lane of the next row
         if (row >= 1) from = row * 16 - 1;
     } else if (ctrl == 0x143) {                              // row_bcast:31 -- lane 31 to rows 2 and 3
         if (row >= 2) from = 31;
     } else {
-        g.error = "simt::dpp: control code not modelled";
+        static char msg[64];
+        snprintf(msg, sizeof(msg), "simt::dpp: control code 0x%x not modelled", ctrl);
+        g.error = msg;
         return old;
     }
     if (from < 0) return bound_ctrl ? 0 : old;
@@ -95,8 +121,7 @@ static void trampoline() {
     g.done[t] = 1;
     // a lane that has left no longer takes part in barriers / wave operations (the csrc/ kernels only leave workgroup-uniformly)
     --g.alive;
-    --g.waves[w].alive;
-    g.waves[w].val[0][t % WAVE] = g.waves[w].val[1][t % WAVE] = 0;
+    --g.waves[w].alive;      // (its slots in the exchange buffers stay as they are: other lanes may not have read the last operation's result yet)
     swapcontext(&g.ctx[t], &g.sched);
 }
 

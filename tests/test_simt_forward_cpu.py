@@ -1,10 +1,12 @@
-"""The operator's default FORWARD, from the product's kernel source, against the oracle -- in the build container, without a GPU.
+"""The operator's default FORWARD and BACKWARD, from the product's kernel source, against the oracle -- in the build container, without a GPU.
 csrc/preprocess.hip (+ its frame statistics), depthsort.hip, tilesort.hip and render_fwd.hip are compiled with g++ against the SIMT shim of
 tests/simt/ (fibers, wave64 ballots, DPP moves, readlane, LDS, barriers; -ffp-contract=off) and run through the product's own launchers in the
 order of gsr_rasterize_forward: eleven launches, every lane executed.  The scenes, the oracle call and the bars are those of the GPU parity suite
 (`tests/test_gpu_parity.py::test_forward_parity`: radii, tiles_touched, R, sorted point list, tile ranges and n_contrib bit-exact, image /
 inverse depth 1e-5 off the oracle's fragile pixels, final_T 5e-6), both builds of the blend (tracking / inference) and both rectangle modes.
-Differences to the GPU build: no FMA contraction in the blend, libm's exp2f for v_exp_f32 -- inside the same bars.
+The backward -- blend backward (plan kernel, the two-pixels-per-lane walk, the three reduce kernels) + the fused per-Gaussian backward -- is held
+to the bars of the GPU suite's `_backward_case` against autograd through the oracle.
+Differences to the GPU build: no FMA contraction in the blend kernels, libm's exp2f for v_exp_f32, an exact 1/x for v_rcp_f32 -- inside the same bars.
 
 Test infrastructure: a checker of the kernel SOURCE (tests/_build/libsimt_forward.so is never shipped); the product has no CPU path."""
 import ctypes as C
@@ -69,7 +71,8 @@ def run_simt(lib, s, sc, track, snug=1, colors=None):
     final_T = np.zeros((H, W), dtype=np.float32)
     n_contrib = np.zeros((H, W), dtype=np.uint32)
     R = lib.simt_forward(C.byref(rs), snug, P, M, ptr(m), ptr(shs), ptr(col_in), ptr(op), ptr(scl), ptr(rot), ptr(radii), ptr(tiles), ptr(color),
-                         ptr(invd), ptr(point_list), C.c_int64(r_cap), ptr(ranges), 1 if track else 0, ptr(final_T), ptr(n_contrib))
+                         ptr(invd), ptr(point_list), C.c_int64(r_cap), ptr(ranges), 1 if track else 0, ptr(final_T), ptr(n_contrib),
+                         None, None, None, None, None, None, None, None)      # (no backward)
     assert R >= 0, lib.simt_fwd_last_error()
     out = {"radii": torch.from_numpy(radii), "tiles_touched": torch.from_numpy(tiles.astype(np.int64)), "R": int(R),
            "point_list": torch.from_numpy(point_list[:R].astype(np.int64)), "ranges": torch.from_numpy(ranges.astype(np.int64)),
@@ -98,3 +101,51 @@ def test_forward_of_the_kernel_source_with_the_reference_rectangles_and_precompu
         s, col, radii, invd, aux = G.run_oracle(cam, sc, opts, colors=colors)
     out = run_simt(lib, s, sc, True, snug=0, colors=colors)
     G.check_forward(s, col, radii, invd, aux, out)
+
+
+@pytest.mark.parametrize("name,n,seed,use_depth", [("c1", 1000, 0, True), ("edge_aa_scale", 1500, 3, True), ("odd_aa", 1200, 4, False)])
+def test_backward_of_the_kernel_source_on_the_cpu_against_the_oracles_autograd(lib, name, n, seed, use_depth):
+    """The blend backward (plan kernel, the two-pixels-per-lane walk with its DPP / permlane transpose-reduce, the three reduce kernels) and the
+    fused per-Gaussian backward, run from the kernel source through the shim, against autograd through the oracle: the scenes, the loss and the
+    bars of tests/test_gpu_parity.py::_backward_case (max 1e-4, 99.9th percentile 1e-5 of max |grad|), with and without a gradient on the
+    inverse-depth image (the HAS_DEPTH build of the walk)."""
+    import copy
+    from helpers import O, oracle_settings
+    cam, sc, opts = G.mk(name)
+    idx = torch.arange(min(n, sc.P))
+    sc = copy.copy(sc)
+    sc.means3D, sc.scales, sc.rotations, sc.opacities, sc.shs = sc.means3D[idx], sc.scales[idx], sc.rotations[idx], sc.opacities[idx], sc.shs[idx]
+    s = oracle_settings(cam, bg=opts.get("bg"), sh_degree=opts.get("sh_degree", 3), scale_modifier=opts.get("scale_modifier", 1.0),
+                        antialiasing=opts.get("antialiasing", False))
+    H, W = cam.image_height, cam.image_width
+    wc, wd = G._loss_weights(H, W, seed)
+    L = {k: v.detach().clone().requires_grad_(True) for k, v in dict(means3D=sc.means3D, opacities=sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations).items()}
+    L["means2D"] = torch.zeros(sc.P, 3, requires_grad=True)
+    col, radii, invd = O.rasterize(L["means3D"], L["means2D"], L["opacities"], s, shs=L["shs"], scales=L["scales"], rotations=L["rotations"])
+    ((col * wc).sum() + ((invd * wd).sum() if use_depth else 0.0)).backward()
+    # the kernel source
+    from diff_gaussian_rasterization._lib import GsrRasterSettings
+    bg, view, proj, campos = f32(s.bg), f32(s.viewmatrix), f32(s.projmatrix), f32(s.campos)
+    rs = GsrRasterSettings(H, W, float(s.tanfovx), float(s.tanfovy), ptr(bg).value, float(s.scale_modifier), ptr(view).value, ptr(proj).value,
+                           int(s.sh_degree), ptr(campos).value, 0, 0, 1 if s.antialiasing else 0, 0, 0, 0, None, None)
+    P, M = sc.P, sc.shs.shape[1]
+    m, op, scl, rot, shs = f32(sc.means3D), f32(sc.opacities), f32(sc.scales), f32(sc.rotations), f32(sc.shs)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    r_cap = 4_000_000
+    bufs = dict(radii=np.zeros(P, np.int32), tiles=np.zeros(P, np.uint32), color=np.zeros((3, H, W), np.float32), invd=np.zeros((1, H, W), np.float32),
+                pl=np.zeros(r_cap, np.uint32), ranges=np.zeros((gx * gy, 2), np.uint32), final_T=np.zeros((H, W), np.float32), n_contrib=np.zeros((H, W), np.uint32))
+    g = dict(means2D=np.zeros((P, 3), np.float32), means3D=np.zeros((P, 3), np.float32), opacities=np.zeros((P, 1), np.float32),
+             shs=np.zeros((P, M, 3), np.float32), scales=np.zeros((P, 3), np.float32), rotations=np.zeros((P, 4), np.float32))
+    dcol, dinv = f32(wc), (f32(wd) if use_depth else None)
+    R = lib.simt_forward(C.byref(rs), 1, P, M, ptr(m), ptr(shs), None, ptr(op), ptr(scl), ptr(rot), ptr(bufs["radii"]), ptr(bufs["tiles"]), ptr(bufs["color"]),
+                         ptr(bufs["invd"]), ptr(bufs["pl"]), C.c_int64(r_cap), ptr(bufs["ranges"]), 1, ptr(bufs["final_T"]), ptr(bufs["n_contrib"]),
+                         ptr(dcol), ptr(dinv), ptr(g["means2D"]), ptr(g["means3D"]), ptr(g["opacities"]), ptr(g["shs"]), ptr(g["scales"]), ptr(g["rotations"]))
+    assert R > 0, lib.simt_fwd_last_error()
+    assert np.array_equal(bufs["radii"], radii.numpy().astype(np.int32))
+    for k in L:
+        a, b = torch.from_numpy(g[k]).double(), L[k].grad.double()
+        scale = b.abs().max().item() + 1e-30
+        d = (a - b).abs() / scale
+        assert b.abs().max().item() > 0, f"{k}: oracle gradient is identically zero"
+        assert d.max().item() < 1e-4, f"{k}: max err {d.max().item():.3e} (rel. to max |grad|)"
+        assert torch.quantile(d.flatten()[:4_000_000], 0.999).item() < 1e-5, f"{k}: 99.9th pct err too large"
