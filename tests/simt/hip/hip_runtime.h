@@ -110,3 +110,25 @@ namespace simt { uint2 permlane32_swap(uint32_t a, uint32_t b); uint2 permlane16
 #define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) simt::permlane32_swap((a), (b))
 #define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) simt::permlane16_swap((a), (b))
 static inline int __shfl_xor(int v, int m, int = 64) { return (int)simt::shfl_xor((uint32_t)v, m); }
+static inline uint32_t __shfl_xor(uint32_t v, int m, int = 64) { return simt::shfl_xor(v, m); }
+static inline float __shfl_xor(float v, int m, int = 64) { uint32_t u; memcpy(&u, &v, 4); u = simt::shfl_xor(u, m); memcpy(&v, &u, 4); return v; }
+
+// ---- shuffles / further atomics / explicit-rounding intrinsics (binning.hip, knn.hip, density.hip) ----
+namespace simt { uint32_t shfl(uint32_t v, int src); uint32_t shfl_up(uint32_t v, int delta); }
+static inline uint32_t __shfl(uint32_t v, int src, int = 64) { return simt::shfl(v, src); }
+static inline int __shfl(int v, int src, int = 64) { return (int)simt::shfl((uint32_t)v, src); }
+static inline float __shfl(float v, int src, int = 64) { return __uint_as_float(simt::shfl(__float_as_uint(v), src)); }
+static inline uint32_t __shfl_up(uint32_t v, int d, int = 64) { return simt::shfl_up(v, d); }
+static inline int __shfl_up(int v, int d, int = 64) { return (int)simt::shfl_up((uint32_t)v, d); }
+static inline float __shfl_up(float v, int d, int = 64) { return __uint_as_float(simt::shfl_up(__float_as_uint(v), d)); }
+static inline uint32_t atomicMin(uint32_t* p, uint32_t v) { const uint32_t o = *p; if (v < o) *p = v; return o; }
+static inline uint32_t atomicMax(uint32_t* p, uint32_t v) { const uint32_t o = *p; if (v > o) *p = v; return o; }
+static inline int atomicMin(int* p, int v) { const int o = *p; if (v < o) *p = v; return o; }
+static inline int atomicMax(int* p, int v) { const int o = *p; if (v > o) *p = v; return o; }
+static inline uint32_t atomicOr(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o | v; return o; }
+static inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
+#define __fmul_rn(a, b) ((float)(a) * (float)(b))
+#define __fadd_rn(a, b) ((float)(a) + (float)(b))
+#define __fsub_rn(a, b) ((float)(a) - (float)(b))
+#define __fsqrt_rn(a) sqrtf(a)
+#define __frcp_rn(a) (1.0f / (a))

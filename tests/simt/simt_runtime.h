@@ -70,6 +70,8 @@ void wave_barrier() { (void)exchange(0); }
 
 uint32_t readlane(uint32_t v, int lane) { return (uint32_t)exchange(v)[lane & 63]; }
 
+uint32_t shfl(uint32_t v, int src) { return (uint32_t)exchange(v)[src & 63]; }
+uint32_t shfl_up(uint32_t v, int delta) { const uint64_t* b = exchange(v); const int lane = g.cur % WAVE; return lane >= delta ? (uint32_t)b[lane - delta] : v; }
 uint32_t shfl_xor(uint32_t v, int m) { return (uint32_t)exchange(v)[(g.cur % WAVE) ^ (m & 63)]; }
 
 // both operands travel in one exchange (a in the low, b in the high word)
