@@ -149,3 +149,45 @@ def test_backward_of_the_kernel_source_on_the_cpu_against_the_oracles_autograd(l
         assert b.abs().max().item() > 0, f"{k}: oracle gradient is identically zero"
         assert d.max().item() < 1e-4, f"{k}: max err {d.max().item():.3e} (rel. to max |grad|)"
         assert torch.quantile(d.flatten()[:4_000_000], 0.999).item() < 1e-5, f"{k}: 99.9th pct err too large"
+
+
+@pytest.mark.parametrize("name,bounds", [("c1", [0, 5, 11, 16]), ("edge_aa_scale", [0, 3, 3, 9]), ("odd_aa", [0, 9]), ("c1", [0, 1, 2, 3, 16])])
+def test_gaussian_sharded_forward_of_the_kernel_source_equals_the_single_device_forward(lib, name, bounds):
+    """Mode C of the multi-GPU renderer (parallel.py; no multi-GPU hardware in any round): G contiguous shards of Gaussians and G bands of tile
+    rows, every rank's kernels run one after the other -- per-Gaussian kernel with full-frame rectangles, route_count + scan, the stable
+    48-byte pack, then per band the records of all shards in rank order through ingest_packed (which recomputes tau and 1 / depth), depth sort,
+    tile sort and the blend of the band's rows.  The assembled frame must be THE SAME BITS as the single-device forward of the same source,
+    the per-(shard, band) counts those of parallel.route_plan_torch; an empty band (bounds 3, 3) shows the background."""
+    from diff_gaussian_rasterization._lib import GsrRasterSettings
+    from diff_gaussian_rasterization.parallel import route_plan_torch
+    from helpers import O
+    cam, sc, opts = G.mk(name)
+    s, col, radii, invd, aux = G.run_oracle(cam, sc, opts)
+    H, W = int(s.image_height), int(s.image_width)
+    gy = (H + 15) // 16
+    bounds = [min(b, gy) for b in bounds[:-1]] + [gy]
+    single = run_simt(lib, s, sc, False)
+    bg, view, proj, campos = f32(s.bg), f32(s.viewmatrix), f32(s.projmatrix), f32(s.campos)
+    rs = GsrRasterSettings(H, W, float(s.tanfovx), float(s.tanfovy), ptr(bg).value, float(s.scale_modifier), ptr(view).value, ptr(proj).value,
+                           int(s.sh_degree), ptr(campos).value, 0, 0, 1 if s.antialiasing else 0, 0, 0, 1, None, None)
+    P, M = sc.P, sc.shs.shape[1]
+    m, op, scl, rot, shs = f32(sc.means3D), f32(sc.opacities), f32(sc.scales), f32(sc.rotations), f32(sc.shs)
+    ng = len(bounds) - 1
+    b32 = np.array(bounds, dtype=np.int32)
+    radii_s = np.zeros(P, dtype=np.int32)
+    color = np.zeros((3, H, W), dtype=np.float32)
+    invd_s = np.zeros((1, H, W), dtype=np.float32)
+    counts = np.zeros(ng * ng, dtype=np.uint32)
+    lib.simt_forward_sharded.restype = C.c_int64
+    R = lib.simt_forward_sharded(C.byref(rs), 1, ng, ptr(b32), P, M, ptr(m), ptr(shs), ptr(op), ptr(scl), ptr(rot), ptr(radii_s), ptr(color), ptr(invd_s), ptr(counts))
+    assert R >= 0, lib.simt_fwd_last_error()
+    assert np.array_equal(radii_s, single["radii"].numpy())
+    assert np.array_equal(color, single["color"].numpy()), "sharded frame differs from the single-device frame"
+    assert np.array_equal(invd_s, single["invdepth"].numpy())
+    # the counts of the exchange = the torch restatement on the oracle's full-frame rectangles
+    with torch.no_grad():
+        pre = O.preprocess(sc.means3D, sc.opacities, s, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+    for g in range(ng):
+        lo, hi = P * g // ng, P * (g + 1) // ng
+        _, want = route_plan_torch(pre["rect"][lo:hi, 1], pre["rect"][lo:hi, 3], pre["tiles_touched"][lo:hi], bounds)
+        assert counts[g * ng:(g + 1) * ng].tolist() == want, (g, counts[g * ng:(g + 1) * ng].tolist(), want)
