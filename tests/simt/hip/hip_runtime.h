@@ -132,3 +132,17 @@ static inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + 
 #define __fsub_rn(a, b) ((float)(a) - (float)(b))
 #define __fsqrt_rn(a) sqrtf(a)
 #define __frcp_rn(a) (1.0f / (a))
+
+// ---- raw buffer access (ssim.hip): a buffer resource = base + size in bytes; out-of-range loads return 0, out-of-range stores are dropped ----
+struct __amdgpu_buffer_rsrc_t { char* base; uint32_t bytes; };
+static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, int /*stride*/, int num, int /*flags*/) { return {(char*)p, (uint32_t)num}; }
+static inline int __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+    const uint32_t o = (uint32_t)voff + (uint32_t)soff;
+    int v = 0;
+    if ((uint64_t)o + 4 <= r.bytes) memcpy(&v, r.base + o, 4);
+    return v;
+}
+static inline void __builtin_amdgcn_raw_buffer_store_b32(int v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+    const uint32_t o = (uint32_t)voff + (uint32_t)soff;
+    if ((uint64_t)o + 4 <= r.bytes) memcpy(r.base + o, &v, 4);
+}
