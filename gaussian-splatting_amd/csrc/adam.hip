@@ -21,6 +21,10 @@ __device__ __forceinline__ void adam4(float4& p, const float4& g, float4& m, flo
     adam1(p.z, g.z, m.z, v.z, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
     adam1(p.w, g.w, m.w, v.w, om_b1, b2, om_b2, step_size, inv_bc2_sqrt, eps);
 }
+#ifdef GSR_SIMT_SHIM      // (tests/simt/: the kernel source compiled for the host, where a cache hint has no meaning)
+__device__ __forceinline__ float4 ntload4(const float4* p) { return *p; }
+__device__ __forceinline__ void ntstore4(float4* p, const float4& v) { *p = v; }
+#else
 typedef float float4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ntload4(const float4* p) {
     const float4v t = __builtin_nontemporal_load(reinterpret_cast<const float4v*>(p));
@@ -30,6 +34,7 @@ __device__ __forceinline__ void ntstore4(float4* p, const float4& v) {
     float4v t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<float4v*>(p));
 }
+#endif
 
 // one tensor, walked by `nthreads` threads of which this one is number `tid0`
 __device__ __forceinline__ void adam_walk(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,

@@ -1,13 +1,14 @@
 // The kernels around the default path, compiled for the HOST through the SIMT-on-CPU shim and run through their own launchers
 // (tests/test_simt_rows_cpu.py): the LSD radix sort (csrc/sort.hip: the depth sort's fall-back, the tile sort of frames beyond 65536 tiles, the
 // Morton sort of the k-NN), the legacy binning path (csrc/binning.hip: tile scan, instance emission, tile ranges), distCUDA2 (csrc/knn.hip) and
-// the density-control statistics (csrc/density.hip).  TEST INFRASTRUCTURE, never part of libgsr_hip.so.
+// the density-control statistics (csrc/density.hip), the fused / sparse Adam steps (csrc/adam.hip).  TEST INFRASTRUCTURE, never part of libgsr_hip.so.
 #define __HIPCC__ 1
 #include "hip/hip_runtime.h"
 #include "sort.hip"
 #include "binning.hip"
 #include "knn.hip"
 #include "density.hip"
+#include "adam.hip"
 #include "simt_runtime.h"
 #include <vector>
 
@@ -79,6 +80,20 @@ int simt_knn(int N, const float* points, float* out) {
 int simt_density_stats(int P, const float* grad, const uint8_t* visible, const int32_t* radii, float* accum, float* denom, float* max_radii) {
     gsr_launch_density_stats(P, grad, visible, radii, accum, denom, max_radii, nullptr);
     return finish("density stats");
+}
+
+// fused dense Adam over several tensors in one launch (gsr_adam_step_multi) / one tensor (gsr_adam_step); SparseGaussianAdam's row-sparse step
+int simt_adam_multi(const GsrAdamTensor* tensors, int count) {
+    gsr_launch_adam_multi(tensors, count, nullptr);
+    return finish("adam multi");
+}
+int simt_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double b1, double b2, double eps, int step) {
+    gsr_launch_adam(p, g, m, v, n, lr, b1, b2, eps, step, nullptr);
+    return finish("adam");
+}
+int simt_sparse_adam(float* p, const float* g, float* m, float* v, const uint8_t* visible, int64_t N, int64_t M, double lr, double b1, double b2, double eps) {
+    gsr_launch_sparse_adam(p, g, m, v, visible, N, M, lr, b1, b2, eps, nullptr);
+    return finish("sparse adam");
 }
 
 }  // extern "C"

@@ -24,11 +24,8 @@ pytestmark = pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not ava
 
 @pytest.fixture(scope="module")
 def lib():
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    src = os.path.join(ROOT, "tests", "simt", "chain_harness.cpp")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "tests", "simt"),
-                           "-I" + os.path.join(ROOT, "gaussian-splatting_amd", "csrc"), "-I" + os.path.join(ROOT, "include"), "-x", "c++", src, "-o", OUT])
-    h = C.CDLL(OUT)
+    from simt_build import build
+    h = build("chain")
     h.simt_chain_last_error.restype = C.c_char_p
     h.simt_bin.restype = C.c_int64
     return h

@@ -22,11 +22,8 @@ pytestmark = pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not ava
 
 @pytest.fixture(scope="module")
 def lib():
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    src = os.path.join(ROOT, "tests", "simt", "depthsort_harness.cpp")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "tests", "simt"),
-                           "-I" + os.path.join(ROOT, "gaussian-splatting_amd", "csrc"), "-I" + os.path.join(ROOT, "include"), "-x", "c++", src, "-o", OUT])
-    h = C.CDLL(OUT)
+    from simt_build import build
+    h = build("depthsort")
     h.simt_ds_last_error.restype = C.c_char_p
     return h
 

@@ -23,11 +23,8 @@ pytestmark = pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not ava
 
 @pytest.fixture(scope="module")
 def lib():
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "tests", "simt"),
-                           "-I" + os.path.join(ROOT, "gaussian-splatting_amd", "csrc"), "-I" + os.path.join(ROOT, "include"), "-x", "c++",
-                           os.path.join(ROOT, "tests", "simt", "loss_harness.cpp"), "-o", OUT])
-    h = C.CDLL(OUT)
+    from simt_build import build
+    h = build("loss", fp_contract_off=True)
     h.simt_loss_last_error.restype = C.c_char_p
     return h
 

@@ -22,11 +22,8 @@ pytestmark = pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not ava
 
 @pytest.fixture(scope="module")
 def lib():
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "tests", "simt"),
-                           "-I" + os.path.join(ROOT, "gaussian-splatting_amd", "csrc"), "-I" + os.path.join(ROOT, "include"), "-x", "c++",
-                           os.path.join(ROOT, "tests", "simt", "rows_harness.cpp"), "-o", OUT])
-    h = C.CDLL(OUT)
+    from simt_build import build
+    h = build("rows", fp_contract_off=True)
     h.simt_rows_last_error.restype = C.c_char_p
     h.simt_legacy_bins.restype = C.c_int64
     return h
@@ -129,3 +126,60 @@ def test_density_statistics_on_the_cpu(lib):
     assert np.allclose(a[:, 0], np.where(vis, accum[:, 0] + norm, accum[:, 0]), rtol=1e-6)
     assert np.array_equal(d[:, 0], np.where(vis, denom[:, 0] + 1, denom[:, 0]))
     assert np.array_equal(m, np.where(vis, np.maximum(maxr, radii.astype(np.float32)), maxr))
+
+
+def test_fused_adam_source_on_the_cpu_equals_torch_adam(lib):
+    """gsr_adam_step_multi (one launch over the tensors of a 3DGS model: ragged sizes, an unaligned view) and gsr_adam_step against
+    torch.optim.Adam with the reference's settings (eps 1e-15, scene/gaussian_model.py:178-211), three steps."""
+    import torch
+
+    class T(C.Structure):
+        _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_int64),
+                    ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int32), ("reserved", C.c_int32)]
+    g = torch.Generator().manual_seed(3)
+    shapes, lrs = [(1000, 3), (1000, 15, 3), (1000, 1), (1000, 4), (7,), (4099,)], [1.6e-4, 1.25e-4, 2.5e-2, 1e-3, 5e-3, 1e-2]
+    params = [torch.randn(s, generator=g) for s in shapes]
+    ref = [p.clone().requires_grad_(True) for p in params]
+    opt = torch.optim.Adam([{"params": [r], "lr": lr} for r, lr in zip(ref, lrs)], lr=0.0, eps=1e-15)
+    mine = [np.ascontiguousarray(p.numpy().copy()) for p in params]
+    m = [np.zeros_like(x) for x in mine]
+    v = [np.zeros_like(x) for x in mine]
+    for step in (1, 2, 3):
+        grads = [torch.randn(s, generator=g) * (0.1 if i % 2 else 10.0) for i, s in enumerate(shapes)]
+        for r, gr in zip(ref, grads):
+            r.grad = gr.clone()
+        opt.step()
+        gn = [np.ascontiguousarray(gr.numpy()) for gr in grads]
+        arr = (T * len(mine))(*[T(ptr(mine[i]).value, ptr(gn[i]).value, ptr(m[i]).value, ptr(v[i]).value, mine[i].size, lrs[i], 0.9, 0.999, 1e-15, step, 0) for i in range(len(mine))])
+        assert lib.simt_adam_multi(arr, len(mine)) == 0, lib.simt_rows_last_error()
+        for x, r in zip(mine, ref):
+            assert np.allclose(x, r.detach().numpy(), rtol=2e-6, atol=1e-9), float(np.abs(x - r.detach().numpy()).max())
+    # single-tensor entry point, starting at an address that is not 16-byte aligned (scalar path)
+    base = np.zeros(1001, dtype=np.float32)
+    p1, g1, m1, v1 = base[1:].copy(), np.random.default_rng(0).normal(size=1000).astype(np.float32), np.zeros(1000, np.float32), np.zeros(1000, np.float32)
+    r1 = torch.from_numpy(p1.copy()).requires_grad_(True)
+    o1 = torch.optim.Adam([r1], lr=1e-3, eps=1e-15)
+    r1.grad = torch.from_numpy(g1.copy())
+    o1.step()
+    assert lib.simt_adam(ptr(p1), ptr(g1), ptr(m1), ptr(v1), C.c_int64(1000), C.c_double(1e-3), C.c_double(0.9), C.c_double(0.999), C.c_double(1e-15), 1) == 0
+    assert np.allclose(p1, r1.detach().numpy(), rtol=2e-6, atol=1e-9)
+
+
+def test_sparse_adam_source_on_the_cpu(lib):
+    """SparseGaussianAdam.step(visible, N) [RECALLED semantics, csrc/adam.hip]: rows of invisible Gaussians keep parameter AND moments; visible
+    rows take m = b1 m + (1 - b1) g, v = b2 v + (1 - b2) g^2, p -= lr m / (sqrt(v) + eps) -- no bias correction."""
+    rng = np.random.default_rng(9)
+    for N, M in ((3000, 3), (3000, 45), (777, 1), (513, 4)):
+        p, g = rng.normal(size=(N, M)).astype(np.float32), rng.normal(size=(N, M)).astype(np.float32)
+        m, v = rng.normal(size=(N, M)).astype(np.float32) * 0.1, rng.random((N, M)).astype(np.float32) * 0.01
+        vis = (rng.random(N) < 0.6).astype(np.uint8)
+        p0, m0, v0 = p.copy(), m.copy(), v.copy()
+        lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-15
+        assert lib.simt_sparse_adam(ptr(p), ptr(g), ptr(m), ptr(v), ptr(vis), C.c_int64(N), C.c_int64(M), C.c_double(lr), C.c_double(b1), C.c_double(b2), C.c_double(eps)) == 0
+        mm = (np.float32(b1) * m0 + np.float32(1 - b1) * g).astype(np.float32)
+        vv = (np.float32(b2) * v0 + np.float32(1 - b2) * g * g).astype(np.float32)
+        pp = (p0 - np.float32(lr) * mm / (np.sqrt(vv) + np.float32(eps))).astype(np.float32)
+        sel = vis.astype(bool)[:, None]
+        assert np.allclose(m, np.where(sel, mm, m0), rtol=1e-6, atol=1e-12) and np.allclose(v, np.where(sel, vv, v0), rtol=1e-6, atol=1e-12)
+        assert np.allclose(p, np.where(sel, pp, p0), rtol=2e-6, atol=1e-9)
+        assert np.array_equal(p[~vis.astype(bool)], p0[~vis.astype(bool)])

@@ -13,9 +13,6 @@ pytestmark = pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not ava
 
 
 def test_shim_primitives():
-    out = os.path.join(ROOT, "tests", "_build", "libsimt_selftest.so")
-    os.makedirs(os.path.dirname(out), exist_ok=True)
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "tests", "simt"),
-                           "-I" + os.path.join(ROOT, "gaussian-splatting_amd", "csrc"), "-I" + os.path.join(ROOT, "include"), "-x", "c++",
-                           os.path.join(ROOT, "tests", "simt", "selftest.cpp"), "-o", out])
-    assert C.CDLL(out).simt_selftest() == 0
+    src = os.path.join(ROOT, "tests", "simt", "selftest_harness.cpp")
+    from simt_build import build
+    assert build("selftest", fp_contract_off=True).simt_selftest() == 0
