@@ -25,6 +25,12 @@ extern "C" {
 
 const char* simt_fwd_last_error(void) { return g_err; }
 
+// the reference's separate_sh call form (GsrRasterSettings.sh_dc / dL_dsh_dc): coefficient 0 as [P,1,3]; `shs` / dL_dsh of the next simt_forward
+// call then hold coefficients 1..15 as [P,15,3] (M stays 16).  NULL switches back to the fused [P,16,3] tensor.
+static const float* g_sh_dc = nullptr;
+static float* g_dL_dsh_dc = nullptr;
+void simt_set_split_sh(const float* dc, float* dL_ddc) { g_sh_dc = dc; g_dL_dsh_dc = dL_ddc; }
+
 // settings as GsrRasterSettings (include/gsr.h) with HOST pointers; fused [P,16,3] SH tensor or colors_precomp; scales + rotations.
 // Outputs: radii[P], tiles[P], out_color[3HW], out_invdepth[HW]; point_list (capacity r_cap), ranges[gx*gy]; track != 0: final_T[HW], n_contrib[HW].
 // Returns R (>= 0) or -1.
@@ -42,7 +48,7 @@ int64_t simt_forward(const GsrRasterSettings* s, int snug, int P, int M, const f
     c.limx = 1.3f * s->tanfovx; c.limy = 1.3f * s->tanfovy;
     c.scale_modifier = s->scale_modifier; c.sh_degree = s->sh_degree; c.M = M; c.antialiasing = s->antialiasing ? 1 : 0; c.snug = snug;
     c.tile_y0 = 0; c.tile_y1 = c.gy;
-    c.view = s->viewmatrix; c.proj = s->projmatrix; c.campos = s->campos; c.bg = s->bg; c.sh_dc = nullptr; c.dL_dsh_dc = nullptr;
+    c.view = s->viewmatrix; c.proj = s->projmatrix; c.campos = s->campos; c.bg = s->bg; c.sh_dc = g_sh_dc; c.dL_dsh_dc = g_dL_dsh_dc;
     const int n_tiles = c.gx * c.gy;
     const size_t n = (size_t)P + 64;
     std::vector<float4> splats(4 * n);

@@ -188,3 +188,48 @@ def test_gaussian_sharded_forward_of_the_kernel_source_equals_the_single_device_
         lo, hi = P * g // ng, P * (g + 1) // ng
         _, want = route_plan_torch(pre["rect"][lo:hi, 1], pre["rect"][lo:hi, 3], pre["tiles_touched"][lo:hi], bounds)
         assert counts[g * ng:(g + 1) * ng].tolist() == want, (g, counts[g * ng:(g + 1) * ng].tolist(), want)
+
+
+def test_separate_sh_call_form_of_the_kernel_source_equals_the_fused_form(lib):
+    """The reference's accelerated call form (gaussian_renderer/__init__.py:82-100: dc [P,1,3] and rest [P,15,3] as separate tensors) through the
+    split-SH instantiations of the per-Gaussian kernels: same image and radii as the fused [P,16,3] tensor bit for bit, the same gradients, with
+    dL/ddc and dL/drest the two parts of dL/dshs."""
+    from diff_gaussian_rasterization._lib import GsrRasterSettings
+    from helpers import oracle_settings
+    cam, sc, opts = G.mk("c1")
+    s = oracle_settings(cam)
+    H, W = cam.image_height, cam.image_width
+    wc, _ = G._loss_weights(H, W, 7)
+    bg, view, proj, campos = f32(s.bg), f32(s.viewmatrix), f32(s.projmatrix), f32(s.campos)
+    rs = GsrRasterSettings(H, W, float(s.tanfovx), float(s.tanfovy), ptr(bg).value, float(s.scale_modifier), ptr(view).value, ptr(proj).value,
+                           int(s.sh_degree), ptr(campos).value, 0, 0, 0, 0, 0, 0, None, None)
+    P, M = sc.P, 16
+    m, op, scl, rot, shs = f32(sc.means3D), f32(sc.opacities), f32(sc.scales), f32(sc.rotations), f32(sc.shs)
+    dc, rest = np.ascontiguousarray(shs[:, :1]), np.ascontiguousarray(shs[:, 1:])
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    r_cap = 4_000_000
+    dcol = f32(wc)
+
+    def run(split):
+        b = dict(radii=np.zeros(P, np.int32), tiles=np.zeros(P, np.uint32), color=np.zeros((3, H, W), np.float32), invd=np.zeros((1, H, W), np.float32),
+                 pl=np.zeros(r_cap, np.uint32), ranges=np.zeros((gx * gy, 2), np.uint32), final_T=np.zeros((H, W), np.float32), n_contrib=np.zeros((H, W), np.uint32))
+        g = dict(means2D=np.zeros((P, 3), np.float32), means3D=np.zeros((P, 3), np.float32), opacities=np.zeros((P, 1), np.float32),
+                 shs=np.zeros((P, 15 if split else 16, 3), np.float32), scales=np.zeros((P, 3), np.float32), rotations=np.zeros((P, 4), np.float32))
+        ddc = np.zeros((P, 1, 3), np.float32)
+        lib.simt_set_split_sh(ptr(dc) if split else None, ptr(ddc) if split else None)
+        try:
+            R = lib.simt_forward(C.byref(rs), 1, P, M, ptr(m), ptr(rest if split else shs), None, ptr(op), ptr(scl), ptr(rot), ptr(b["radii"]), ptr(b["tiles"]),
+                                 ptr(b["color"]), ptr(b["invd"]), ptr(b["pl"]), C.c_int64(r_cap), ptr(b["ranges"]), 1, ptr(b["final_T"]), ptr(b["n_contrib"]),
+                                 ptr(dcol), None, ptr(g["means2D"]), ptr(g["means3D"]), ptr(g["opacities"]), ptr(g["shs"]), ptr(g["scales"]), ptr(g["rotations"]))
+        finally:
+            lib.simt_set_split_sh(None, None)
+        assert R > 0, lib.simt_fwd_last_error()
+        return b, g, ddc
+
+    bf, gf, _ = run(False)
+    bs, gs, ddc = run(True)
+    assert np.array_equal(bf["color"], bs["color"]) and np.array_equal(bf["radii"], bs["radii"]) and np.array_equal(bf["invd"], bs["invd"])
+    for k in ("means2D", "means3D", "opacities", "scales", "rotations"):
+        assert np.array_equal(gf[k], gs[k]), k
+    assert np.array_equal(gf["shs"][:, :1], ddc) and np.array_equal(gf["shs"][:, 1:], gs["shs"])
+    assert np.abs(gf["shs"]).max() > 0
