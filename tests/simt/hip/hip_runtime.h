@@ -146,3 +146,30 @@ static inline void __builtin_amdgcn_raw_buffer_store_b32(int v, __amdgpu_buffer_
     const uint32_t o = (uint32_t)voff + (uint32_t)soff;
     if ((uint64_t)o + 4 <= r.bytes) memcpy(r.base + o, &v, 4);
 }
+
+// ---- the slice of the HIP RUNTIME API that csrc/gsr_api.cpp uses: one "device" whose memory is host memory, launches that have completed when
+// hipLaunchKernelGGL returns (so every stream / event synchronisation is a no-op and a "mapped" host word is simply the same address) ----
+#include <stdlib.h>
+#include <time.h>
+typedef struct simt_event* hipEvent_t;
+struct simt_event { double ms; };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+#define hipHostMallocMapped 1u
+#define hipHostMallocPortable 2u
+#define hipHostMallocCoherent 4u
+static inline const char* hipGetErrorString(hipError_t) { return simt::launch_error ? simt::launch_error : "SIMT shim"; }
+static inline hipError_t hipGetLastError() { return simt::launch_error ? 719 : hipSuccess; }      // a workgroup that dead-locked / used an unmodelled operation
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : 2; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : 2; }
+static inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
+static inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+static inline double simt_now_ms() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)calloc(1, sizeof(simt_event)); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->ms = simt_now_ms(); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->ms - a->ms); return hipSuccess; }

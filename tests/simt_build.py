@@ -17,3 +17,32 @@ def build(name: str, fp_contract_off: bool = False) -> C.CDLL:
            "-I" + os.path.join(ROOT, "include")] + (["-ffp-contract=off"] if fp_contract_off else []) + os.environ.get("GSR_SIMT_EXTRA_FLAGS", "").split()
     subprocess.check_call(cmd + ["-x", "c++", os.path.join(ROOT, "tests", "simt", f"{name}_harness.cpp"), "-o", out])
     return C.CDLL(out)
+
+
+def build_library() -> str:
+    """The WHOLE library -- every translation unit of gaussian-splatting_amd/build.py incl. the C-ABI host code of csrc/gsr_api.cpp -- compiled for the
+    host against the shim (its slice of the HIP runtime API included: one device whose memory is host memory, launches complete on return) into
+    tests/_build/libgsr_simt.so: the same exported C ABI as libgsr_hip.so, every kernel lane a fiber.  Returns the path."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gsr_build_units", os.path.join(ROOT, "gaussian-splatting_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out_dir = os.path.join(ROOT, "tests", "_build", "simt_lib")
+    os.makedirs(out_dir, exist_ok=True)
+    csrc = os.path.join(ROOT, "gaussian-splatting_amd", "csrc")
+    common = ["g++", "-O1", "-std=c++17", "-fPIC", "-ffp-contract=off", "-D__HIPCC__=1", "-I" + os.path.join(ROOT, "tests", "simt"), "-I" + csrc,
+              "-I" + os.path.join(ROOT, "include")] + os.environ.get("GSR_SIMT_EXTRA_FLAGS", "").split()
+    objs, procs = [], []
+    rt = os.path.join(out_dir, "simt_rt.cpp")
+    open(rt, "w").write('#include "hip/hip_runtime.h"\n#include "simt_runtime.h"\n')
+    for src in [u[0] for u in mod.UNITS] + [rt]:
+        path = src if os.path.isabs(src) else os.path.join(csrc, src)
+        obj = os.path.join(out_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        objs.append(obj)
+        procs.append(subprocess.Popen(common + ["-x", "c++", "-c", path, "-o", obj]))
+    for pr in procs:
+        if pr.wait() != 0:
+            raise RuntimeError("g++ failed on a translation unit of the shim build of the library")
+    lib = os.path.join(ROOT, "tests", "_build", "libgsr_simt.so")
+    subprocess.check_call(["g++", "-shared", "-o", lib] + objs + os.environ.get("GSR_SIMT_EXTRA_FLAGS", "").split())
+    return lib
