@@ -5,29 +5,41 @@ GSR_SIMT_EXTRA_FLAGS adds compiler flags -- e.g. the kernel source under Address
 (round 4: the whole shim suite is clean under it).  Test infrastructure."""
 import ctypes as C
 import os
+import shutil
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# Every build here defines the same exported names as libgsr_hip.so (gsr_launch_*, the C ABI).  The package loads the product library RTLD_GLOBAL, so without
+# this flag a host build loaded later in the same process would have its INTERNAL calls resolved to the product library's functions (ELF interposition).
+BSYM = "-Wl,-Bsymbolic"
 
 
 def build(name: str, fp_contract_off: bool = False) -> C.CDLL:
     out = os.path.join(ROOT, "tests", "_build", f"libsimt_{name}.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    cmd = ["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "tests", "simt"), "-I" + os.path.join(ROOT, "gaussian-splatting_amd", "csrc"),
+    cmd = ["g++", "-O1", "-std=c++17", "-shared", "-fPIC", BSYM, "-I" + os.path.join(ROOT, "tests", "simt"), "-I" + os.path.join(ROOT, "gaussian-splatting_amd", "csrc"),
            "-I" + os.path.join(ROOT, "include")] + (["-ffp-contract=off"] if fp_contract_off else []) + os.environ.get("GSR_SIMT_EXTRA_FLAGS", "").split()
-    subprocess.check_call(cmd + ["-x", "c++", os.path.join(ROOT, "tests", "simt", f"{name}_harness.cpp"), "-o", out])
+    tmp = f"{out}.{os.getpid()}.tmp"      # written aside and renamed: a process that has the previous file mapped keeps its own copy
+    subprocess.check_call(cmd + ["-x", "c++", os.path.join(ROOT, "tests", "simt", f"{name}_harness.cpp"), "-o", tmp])
+    os.replace(tmp, out)
     return C.CDLL(out)
+
+
+_library = None
 
 
 def build_library() -> str:
     """The WHOLE library -- every translation unit of gaussian-splatting_amd/build.py incl. the C-ABI host code of csrc/gsr_api.cpp -- compiled for the
     host against the shim (its slice of the HIP runtime API included: one device whose memory is host memory, launches complete on return) into
     tests/_build/libgsr_simt.so: the same exported C ABI as libgsr_hip.so, every kernel lane a fiber.  Returns the path."""
+    global _library
+    if _library is not None:      # once per test process
+        return _library
     import importlib.util
     spec = importlib.util.spec_from_file_location("gsr_build_units", os.path.join(ROOT, "gaussian-splatting_amd", "build.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    out_dir = os.path.join(ROOT, "tests", "_build", "simt_lib")
+    out_dir = os.path.join(ROOT, "tests", "_build", f"simt_lib.{os.getpid()}")
     os.makedirs(out_dir, exist_ok=True)
     csrc = os.path.join(ROOT, "gaussian-splatting_amd", "csrc")
     common = ["g++", "-O1", "-std=c++17", "-fPIC", "-ffp-contract=off", "-D__HIPCC__=1", "-I" + os.path.join(ROOT, "tests", "simt"), "-I" + csrc,
@@ -44,5 +56,8 @@ def build_library() -> str:
         if pr.wait() != 0:
             raise RuntimeError("g++ failed on a translation unit of the shim build of the library")
     lib = os.path.join(ROOT, "tests", "_build", "libgsr_simt.so")
-    subprocess.check_call(["g++", "-shared", "-o", lib] + objs + os.environ.get("GSR_SIMT_EXTRA_FLAGS", "").split())
+    subprocess.check_call(["g++", "-shared", BSYM, "-o", lib + f".{os.getpid()}.tmp"] + objs + os.environ.get("GSR_SIMT_EXTRA_FLAGS", "").split())
+    os.replace(lib + f".{os.getpid()}.tmp", lib)      # (see build())
+    shutil.rmtree(out_dir, ignore_errors=True)
+    _library = lib
     return lib
