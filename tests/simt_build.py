@@ -2,7 +2,9 @@
 GSR_SIMT_EXTRA_FLAGS adds compiler flags -- e.g. the kernel source under AddressSanitizer:
     GSR_SIMT_EXTRA_FLAGS="-fsanitize=address -g" LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 \\
         python -m pytest tests -q -k simt
-(round 4: the whole shim suite is clean under it).  Test infrastructure."""
+(round 4: the whole shim suite -- kernels, the C-ABI host code of gsr_api.cpp, the Python package and the gloo workers above it -- is clean under it, and
+under "-fsanitize=undefined -fno-sanitize-recover=undefined" and "-fsanitize=float-cast-overflow,float-divide-by-zero" (run those with pytest -s: the
+reports go to stderr): no out-of-range float -> int conversion, shift or signed overflow anywhere on the tested paths).  Test infrastructure."""
 import ctypes as C
 import os
 import shutil
