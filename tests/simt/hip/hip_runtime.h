@@ -49,12 +49,22 @@ extern simt::Idx threadIdx, blockIdx, blockDim, gridDim;
 // hipLaunchKernelGGL runs the grid HERE, one workgroup after the other (tests/simt/simt_runtime.h), so the launchers of csrc/ -- grids, argument
 // lists, launch order -- are exercised as they stand.  A workgroup that dead-locks or uses an unmodelled operation sets simt::launch_error.
 #include <functional>
+#include <vector>
 namespace simt {
 bool run_block(unsigned block, unsigned grid, int nthreads, const std::function<void()>& body);
+bool schedule_shuffled();
+uint32_t schedule_random();
 extern const char* launch_error;
 }  // namespace simt
 template <class K, class... A>
 static inline void simt_launch(K kernel, dim3 grid, dim3 block, A... args) {
+    if (simt::schedule_shuffled()) {      // SIMT_SCHEDULE: the workgroups of the grid in a random order (simt_runtime.h)
+        std::vector<unsigned> order(grid.x);
+        for (unsigned b = 0; b < grid.x; ++b) order[b] = b;
+        for (unsigned i = grid.x; i > 1; --i) std::swap(order[i - 1], order[simt::schedule_random() % i]);
+        for (unsigned k = 0; k < grid.x && !simt::launch_error; ++k) (void)simt::run_block(order[k], grid.x, (int)block.x, [&] { kernel(args...); });
+        return;
+    }
     for (unsigned b = 0; b < grid.x && !simt::launch_error; ++b) (void)simt::run_block(b, grid.x, (int)block.x, [&] { kernel(args...); });
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) simt_launch(kernel, dim3(grid), dim3(block), __VA_ARGS__)

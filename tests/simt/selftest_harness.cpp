@@ -71,3 +71,27 @@ extern "C" int simt_selftest(void) {
     }
     return bad;
 }
+
+// ---- what SIMT_SCHEDULE is for: two kernels that are WRONG on a GPU and right in the shim's default order ----
+static uint32_t o_racy[256], o_chain[64];
+static void racy_handover() {      // wave 0 hands a value to the other waves through LDS -- without the barrier
+    __shared__ uint32_t box;
+    const int tid = threadIdx.x;
+    if (tid == 0) box = 0;
+    __syncthreads();
+    if (tid == 63) box = 42;       // (lane 63 of wave 0: the first lane the default sweep runs)
+    o_racy[tid] = box;             // missing __syncthreads()
+}
+static void block_chain(uint32_t* cell) {      // every workgroup assumes its predecessor has already run
+    if (threadIdx.x == 0) { o_chain[blockIdx.x] = *cell; *cell = blockIdx.x + 1; }
+}
+extern "C" int simt_selftest_detects_order_dependence(void) {
+    if (!simt::run_block(0, 1, 256, [] { racy_handover(); })) return -1;
+    int wrong = 0;
+    for (int t = 0; t < 256; ++t) wrong += o_racy[t] != 42;
+    uint32_t cell = 0;
+    hipLaunchKernelGGL(block_chain, 64, 64, 0, nullptr, &cell);
+    int out_of_order = 0;
+    for (int b = 0; b < 64; ++b) out_of_order += o_chain[b] != (uint32_t)b;
+    return (wrong ? 1 : 0) | (out_of_order ? 2 : 0);
+}

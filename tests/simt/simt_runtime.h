@@ -33,6 +33,27 @@ struct State {
 
 static void yield() { swapcontext(&g.ctx[g.cur], &g.sched); }
 
+// SIMT_SCHEDULE=<seed> (non-zero): a poor man's race detector.  The waves of a workgroup are swept in a random order and a random half of them sits out each
+// sweep (so a wave runs many wave-level steps ahead of another unless a barrier holds it), and the workgroups of a grid run in a random order.  A kernel
+// whose result depends on either -- an LDS hand-over without its barrier, a block that assumes its predecessor has run -- then fails the same parity tests
+// that pass in the default order (waves 0..n-1 in step, blocks 0..grid-1).  Lanes inside a wave keep their order: a wave is lock-step on the hardware.
+static uint64_t sched_state = 0;
+static bool sched_on = false, sched_read = false;
+bool schedule_shuffled() {
+    if (!sched_read) {
+        sched_read = true;
+        const char* e = getenv("SIMT_SCHEDULE");
+        const unsigned long long seed = e ? strtoull(e, nullptr, 10) : 0;
+        sched_on = seed != 0;
+        sched_state = seed * 0x9E3779B97F4A7C15ull + 1;
+    }
+    return sched_on;
+}
+uint32_t schedule_random() {
+    sched_state = sched_state * 6364136223846793005ull + 1442695040888963407ull;
+    return (uint32_t)(sched_state >> 33);
+}
+
 void syncthreads() {
     const unsigned ph = g.bar_phase;
     if (++g.bar_count == g.alive) { g.bar_count = 0; ++g.bar_phase; yield(); return; }      // (the last thread waits for its turn too)
@@ -150,12 +171,20 @@ bool run_block(unsigned block, unsigned grid, int nthreads, const std::function<
         makecontext(&g.ctx[t], trampoline, 0);
     }
     long idle_sweeps = 0;
+    const bool shuffled = schedule_shuffled();
+    const int nw = nthreads / WAVE;
+    std::vector<int> order(nw);
+    for (int w = 0; w < nw; ++w) order[w] = w;
     while (g.alive > 0) {
         const int alive_before = g.alive;
         const unsigned bar_before = g.bar_phase;
         unsigned long phases_before = 0;
         for (auto& w : g.waves) phases_before += w.phase;
-        for (int w = 0; w < nthreads / WAVE; ++w)
+        if (shuffled)
+            for (int i = nw - 1; i > 0; --i) std::swap(order[i], order[schedule_random() % (unsigned)(i + 1)]);
+        for (int k = 0; k < nw; ++k) {
+            const int w = order[k];
+            if (shuffled && k > 0 && (schedule_random() & 1u)) continue;      // (the first wave of the sweep always runs)
             for (int lane = WAVE - 1; lane >= 0; --lane) {          // lanes of a wave: 63 down to 0 (see hip_runtime.h)
                 const int t = w * WAVE + lane;
                 if (g.done[t]) continue;
@@ -163,10 +192,11 @@ bool run_block(unsigned block, unsigned grid, int nthreads, const std::function<
                 threadIdx = {(unsigned)t, 0, 0};
                 swapcontext(&g.sched, &g.ctx[t]);
             }
+        }
         unsigned long phases_after = 0;
         for (auto& w : g.waves) phases_after += w.phase;
         if (g.alive == alive_before && g.bar_phase == bar_before && phases_after == phases_before) {
-            if (++idle_sweeps > 4) { launch_error = g.error = "simt: deadlock (a barrier or wave-level operation that not every live lane reaches)"; return false; }
+            if (++idle_sweeps > (shuffled ? 4096 : 4)) { launch_error = g.error = "simt: deadlock (a barrier or wave-level operation that not every live lane reaches)"; return false; }
         } else idle_sweeps = 0;
     }
     if (g.error) launch_error = g.error;

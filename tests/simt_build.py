@@ -4,7 +4,9 @@ GSR_SIMT_EXTRA_FLAGS adds compiler flags -- e.g. the kernel source under Address
         python -m pytest tests -q -k simt
 (round 4: the whole shim suite -- kernels, the C-ABI host code of gsr_api.cpp, the Python package and the gloo workers above it -- is clean under it, and
 under "-fsanitize=undefined -fno-sanitize-recover=undefined" and "-fsanitize=float-cast-overflow,float-divide-by-zero" (run those with pytest -s: the
-reports go to stderr): no out-of-range float -> int conversion, shift or signed overflow anywhere on the tested paths).  Test infrastructure."""
+reports go to stderr): no out-of-range float -> int conversion, shift or signed overflow anywhere on the tested paths).
+SIMT_SCHEDULE=<seed> shuffles the wave interleaving inside a workgroup and the order of the workgroups of a grid (tests/simt/simt_runtime.h): the suite
+passes under it, i.e. no result depends on either.  Test infrastructure."""
 import ctypes as C
 import os
 import shutil
