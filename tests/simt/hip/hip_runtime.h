@@ -19,7 +19,15 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
+// LDS: one copy per process is enough (one workgroup runs at a time).  Every __shared__ array lands in the ELF section "simt_lds", which run_block()
+// fills with a poison pattern before each workgroup: LDS holds garbage when a workgroup starts on the hardware, not zeros or the previous block's values.
+// (clang only: g++ refuses to put the statics of inline / template functions and of plain functions into one named section -- there LDS keeps what the
+// previous workgroup left, zeros at first.)
+#ifdef __clang__
+#define __shared__ static __attribute__((section("simt_lds")))
+#else
 #define __shared__ static
+#endif
 #define __launch_bounds__(...)
 #define GSR_SIMT_SHIM 1
 

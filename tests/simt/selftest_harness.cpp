@@ -95,3 +95,19 @@ extern "C" int simt_selftest_detects_order_dependence(void) {
     for (int b = 0; b < 64; ++b) out_of_order += o_chain[b] != (uint32_t)b;
     return (wrong ? 1 : 0) | (out_of_order ? 2 : 0);
 }
+
+// ---- LDS holds garbage when a workgroup starts (the "simt_lds" section is poisoned before every workgroup), not what the previous workgroup left ----
+static uint32_t o_lds[2][64];
+static int lds_round = 0;
+static void lds_fresh() {
+    __shared__ uint32_t a[64];
+    o_lds[lds_round][threadIdx.x] = a[threadIdx.x];
+    a[threadIdx.x] = 0;
+}
+extern "C" int simt_selftest_lds_is_garbage(void) {
+    for (lds_round = 0; lds_round < 2; ++lds_round)
+        if (!simt::run_block((unsigned)lds_round, 2, 64, [] { lds_fresh(); })) return -1;
+    int zeros = 0, same = 0;
+    for (int t = 0; t < 64; ++t) { zeros += (o_lds[0][t] == 0) + (o_lds[1][t] == 0); same += o_lds[0][t] == o_lds[1][t]; }
+    return zeros + same;      // 0: garbage both times, and different garbage
+}

@@ -148,6 +148,12 @@ static void trampoline() {
     swapcontext(&g.ctx[t], &g.sched);
 }
 
+extern "C" char __start_simt_lds[] __attribute__((weak)), __stop_simt_lds[] __attribute__((weak));      // bounds of the "simt_lds" section (GNU ld)
+static void poison_lds(unsigned block) {
+    if (!__start_simt_lds) return;
+    memset(__start_simt_lds, (int)(((0x5Au + block * 37u) | 1u) & 0xFFu), (size_t)(__stop_simt_lds - __start_simt_lds));      // (a whole library has megabytes of LDS arrays: memset speed matters)
+}
+
 // run `body` as ONE workgroup of `nthreads` threads (multiple of 64) with blockIdx.x = block; false: deadlock or unmodelled operation
 bool run_block(unsigned block, unsigned grid, int nthreads, const std::function<void()>& body) {
     g.nthreads = g.alive = nthreads;
@@ -160,6 +166,7 @@ bool run_block(unsigned block, unsigned grid, int nthreads, const std::function<
     g.bar_phase = 0;
     g.body = body;
     g.error = nullptr;
+    poison_lds(block);
     blockIdx = {block, 0, 0};
     gridDim = {grid, 1, 1};
     blockDim = {(unsigned)nthreads, 1, 1};

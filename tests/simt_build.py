@@ -16,12 +16,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # Every build here defines the same exported names as libgsr_hip.so (gsr_launch_*, the C ABI).  The package loads the product library RTLD_GLOBAL, so without
 # this flag a host build loaded later in the same process would have its INTERNAL calls resolved to the product library's functions (ELF interposition).
 BSYM = "-Wl,-Bsymbolic"
+# Host compiler: the ROCm tree's clang++ as a plain x86 compiler where it exists (it accepts the LDS section of tests/simt/hip/hip_runtime.h, so LDS is
+# poisoned before every workgroup), else g++.  GSR_SIMT_CXX=g++ runs the suite with the other compiler (round 4: same results, bit-exact comparisons included).
+_CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+CXX = os.environ.get("GSR_SIMT_CXX", _CLANG if os.path.exists(_CLANG) else "g++")
 
 
 def build(name: str, fp_contract_off: bool = False) -> C.CDLL:
     out = os.path.join(ROOT, "tests", "_build", f"libsimt_{name}.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    cmd = ["g++", "-O1", "-std=c++17", "-shared", "-fPIC", BSYM, "-I" + os.path.join(ROOT, "tests", "simt"), "-I" + os.path.join(ROOT, "gaussian-splatting_amd", "csrc"),
+    cmd = [CXX, "-O1", "-std=c++17", "-shared", "-fPIC", BSYM, "-I" + os.path.join(ROOT, "tests", "simt"), "-I" + os.path.join(ROOT, "gaussian-splatting_amd", "csrc"),
            "-I" + os.path.join(ROOT, "include")] + (["-ffp-contract=off"] if fp_contract_off else []) + os.environ.get("GSR_SIMT_EXTRA_FLAGS", "").split()
     tmp = f"{out}.{os.getpid()}.tmp"      # written aside and renamed: a process that has the previous file mapped keeps its own copy
     subprocess.check_call(cmd + ["-x", "c++", os.path.join(ROOT, "tests", "simt", f"{name}_harness.cpp"), "-o", tmp])
@@ -46,7 +50,7 @@ def build_library() -> str:
     out_dir = os.path.join(ROOT, "tests", "_build", f"simt_lib.{os.getpid()}")
     os.makedirs(out_dir, exist_ok=True)
     csrc = os.path.join(ROOT, "gaussian-splatting_amd", "csrc")
-    common = ["g++", "-O1", "-std=c++17", "-fPIC", "-ffp-contract=off", "-D__HIPCC__=1", "-I" + os.path.join(ROOT, "tests", "simt"), "-I" + csrc,
+    common = [CXX, "-O1", "-std=c++17", "-fPIC", "-ffp-contract=off", "-D__HIPCC__=1", "-I" + os.path.join(ROOT, "tests", "simt"), "-I" + csrc,
               "-I" + os.path.join(ROOT, "include")] + os.environ.get("GSR_SIMT_EXTRA_FLAGS", "").split()
     objs, procs = [], []
     rt = os.path.join(out_dir, "simt_rt.cpp")
@@ -60,7 +64,7 @@ def build_library() -> str:
         if pr.wait() != 0:
             raise RuntimeError("g++ failed on a translation unit of the shim build of the library")
     lib = os.path.join(ROOT, "tests", "_build", "libgsr_simt.so")
-    subprocess.check_call(["g++", "-shared", BSYM, "-o", lib + f".{os.getpid()}.tmp"] + objs + os.environ.get("GSR_SIMT_EXTRA_FLAGS", "").split())
+    subprocess.check_call([CXX, "-shared", BSYM, "-o", lib + f".{os.getpid()}.tmp"] + objs + os.environ.get("GSR_SIMT_EXTRA_FLAGS", "").split())
     os.replace(lib + f".{os.getpid()}.tmp", lib)      # (see build())
     shutil.rmtree(out_dir, ignore_errors=True)
     _library = lib

@@ -15,7 +15,9 @@ pytestmark = pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not ava
 def test_shim_primitives():
     src = os.path.join(ROOT, "tests", "simt", "selftest_harness.cpp")
     from simt_build import build
-    assert build("selftest", fp_contract_off=True).simt_selftest() == 0
+    lib = build("selftest", fp_contract_off=True)
+    assert lib.simt_selftest() == 0
+    assert lib.simt_selftest_lds_is_garbage() == 0, "a workgroup must not see zeros or its predecessor's values in LDS"
 
 
 def test_shuffled_schedule_exposes_a_missing_barrier_and_a_block_order_assumption():
