@@ -85,6 +85,17 @@ struct PixAcc {
 // three conditions need no "not done yet" term, and termination costs one select instead of a flag update and a test.
 // Arithmetic on the contributing path is unchanged (w = alpha * T, T' = T - alpha * T): results are bit-identical.
 // TRACK: the contributor index is only needed by the backward (n_contrib); inference builds drop it.
+#ifndef GSR_FWD_TL_DECAY
+#define GSR_FWD_TL_DECAY 0
+#endif
+#ifndef GSR_FWD_COMPACT
+#define GSR_FWD_COMPACT 0
+#endif
+#if GSR_FWD_TL_DECAY
+#define GSR_FWD_LIVE(Tl_) ((Tl_) >= GSR_T_EPS)
+#else
+#define GSR_FWD_LIVE(Tl_) ((Tl_) != 0.0f)
+#endif
 template <bool TRACK>
 __device__ __forceinline__ void blend_step_bf(PixAcc& s, float& Tl, float pxf, float pyf, float gx_, float gy_, float a2,
                                               float b2, float c2, float op, float r, float g, float b, float invd,
@@ -103,7 +114,14 @@ __device__ __forceinline__ void blend_step_bf(PixAcc& s, float& Tl, float pxf, f
     s.C2 = fmaf(b, w, s.C2);
     s.D = fmaf(invd, w, s.D);
     s.T = contrib ? testT : s.T;
+#if GSR_FWD_TL_DECAY
+    // Candidate (not yet measured on a GPU, off by default): the live transmittance simply follows every valid entry.  A terminated lane then keeps a
+    // value below GSR_T_EPS (it only shrinks), so every later valid entry is the terminator again and adds nothing -- the zeroing select goes
+    // (24 -> 23 VALU per step in the inference build); "live" becomes Tl >= GSR_T_EPS in the wave's exit ballots.  Outputs are the same bits.
+    Tl = valid ? testT : Tl;
+#else
     Tl = contrib ? testT : (term ? 0.0f : Tl);               // an invalid entry must leave a terminated lane at 0
+#endif
     if (TRACK) s.last = contrib ? pos : s.last;
 }
 
@@ -181,6 +199,53 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
             q0.w *= -LOG2E;
             q1.x *= -0.5f * LOG2E;
         }
+#if GSR_FWD_COMPACT
+        // Candidate (not yet measured on a GPU, off by default): the survivors are parked COMPACTED, in list order (slot = survivors on lower lanes), with
+        // their list position in the record's spare word.  The walk then reads consecutive records -- constant ds_read offsets from one base register inside
+        // the eight-deep unrolled body instead of s_ff1 / s_mul / v_mov per step, a counter instead of the 64-bit mask pop: 24 -> 22 VALU and 11 -> 4 SALU
+        // per step in the inference build.  Same survivors in the same order through the same blend_step_bf: outputs are the same bits.
+        static_assert(USE_LDS, "the compacted walk reads the batch from LDS");
+        const uint64_t mask = __ballot(keep);
+        if (keep) {
+            const int slot = (int)__popcll(mask & ((1ull << lane) - 1ull));
+            s_rec[slot * 3 + 0] = q0;
+            s_rec[slot * 3 + 1] = q1;
+            s_rec[slot * 3 + 2] = make_float4(colb, invd, __uint_as_float((uint32_t)lane), 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();      // (no instruction: the wave's LDS accesses stay in program order; the lanes read each other's records)
+        uint32_t left = (uint32_t)__popcll(mask);
+        ++nbatches;
+        if (tracing) { const unsigned long long t = wall_clock64(); t_prep += t - t_mark; t_mark = t; }
+        const uint32_t pos_base = base - range.x + 1;
+        const float4* rp = s_rec;
+        auto step_at = [&](int u) {
+            const float4 r0 = rp[u * 3 + 0];
+            const float4 r1 = rp[u * 3 + 1];
+            if (TRACK) {
+                const float4 r2 = rp[u * 3 + 2];
+                blend_step_bf<TRACK>(s, Tl, pxf, pyf, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, pos_base + __float_as_uint(r2.z));
+            } else {
+                const float2 r2 = *reinterpret_cast<const float2*>(&rp[u * 3 + 2]);
+                blend_step_bf<TRACK>(s, Tl, pxf, pyf, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, 0u);
+            }
+        };
+#ifndef GSR_FWD_CHECK_EVERY
+#define GSR_FWD_CHECK_EVERY 8
+#endif
+        while (left) {
+            const uint32_t todo = min(left, (uint32_t)GSR_FWD_CHECK_EVERY);
+            step_at(0);
+#pragma unroll
+            for (int u = 1; u < GSR_FWD_CHECK_EVERY; ++u) {
+                if ((uint32_t)u >= todo) break;
+                step_at(u);
+            }
+            nsteps += todo;
+            left -= todo;
+            rp += 3 * GSR_FWD_CHECK_EVERY;
+            if (__ballot(GSR_FWD_LIVE(Tl)) == 0ull) break;
+        }
+#else
         if (USE_LDS) {
             s_rec[lane * 3 + 0] = q0;
             s_rec[lane * 3 + 1] = q1;
@@ -223,10 +288,11 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
                 if (!mask) break;
                 one_step();
             }
-            if (__ballot(Tl != 0.0f) == 0ull) break;
+            if (__ballot(GSR_FWD_LIVE(Tl)) == 0ull) break;
         }
+#endif  // GSR_FWD_COMPACT
         if (tracing) { const unsigned long long t = wall_clock64(); t_walk += t - t_mark; t_mark = t; }
-        if (__ballot(Tl != 0.0f) == 0ull) break;
+        if (__ballot(GSR_FWD_LIVE(Tl)) == 0ull) break;
     }
     if (tracing) {
         if (lane == 0) gsr_trace_wave(counters, t_start, (uint32_t)(blockIdx.x * WPB + (threadIdx.x >> 6)), 1u, gsr_trace_pack(nsteps, t_walk, t_prep, 0ull));

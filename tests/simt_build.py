@@ -22,11 +22,13 @@ _CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 CXX = os.environ.get("GSR_SIMT_CXX", _CLANG if os.path.exists(_CLANG) else "g++")
 
 
-def build(name: str, fp_contract_off: bool = False) -> C.CDLL:
-    out = os.path.join(ROOT, "tests", "_build", f"libsimt_{name}.so")
+def build(name: str, fp_contract_off: bool = False, defines=(), tag: str = "") -> C.CDLL:
+    """tests/simt/<name>_harness.cpp -> tests/_build/libsimt_<name><tag>.so.  `defines` (-D flags, with a `tag` for the file name) builds the same
+    harness over a candidate form of the kernel source (the macros of csrc/ that are off in the product)."""
+    out = os.path.join(ROOT, "tests", "_build", f"libsimt_{name}{tag}.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     cmd = [CXX, "-O1", "-std=c++17", "-shared", "-fPIC", BSYM, "-I" + os.path.join(ROOT, "tests", "simt"), "-I" + os.path.join(ROOT, "gaussian-splatting_amd", "csrc"),
-           "-I" + os.path.join(ROOT, "include")] + (["-ffp-contract=off"] if fp_contract_off else []) + os.environ.get("GSR_SIMT_EXTRA_FLAGS", "").split()
+           "-I" + os.path.join(ROOT, "include")] + (["-ffp-contract=off"] if fp_contract_off else []) + list(defines) + os.environ.get("GSR_SIMT_EXTRA_FLAGS", "").split()
     tmp = f"{out}.{os.getpid()}.tmp"      # written aside and renamed: a process that has the previous file mapped keeps its own copy
     subprocess.check_call(cmd + ["-x", "c++", os.path.join(ROOT, "tests", "simt", f"{name}_harness.cpp"), "-o", tmp])
     os.replace(tmp, out)
