@@ -236,7 +236,7 @@ def test_separate_sh_call_form_of_the_kernel_source_equals_the_fused_form(lib):
 
 
 # ---- candidate forms of the forward blend (macros of csrc/render_fwd.hip, off in the product; not yet measured on a GPU) ----
-@pytest.mark.parametrize("defines,tag", [(("-DGSR_FWD_TL_DECAY=1", "-DGSR_FWD_COMPACT=1"), "_tl_compact"), (("-DGSR_FWD_COMPACT=1",), "_compact")])
+@pytest.mark.parametrize("defines,tag", [(("-DGSR_FWD_TL_DECAY=1", "-DGSR_FWD_COMPACT=1"), "_tl_compact")])
 def test_candidate_forms_of_the_forward_blend_change_no_bit(lib, defines, tag):
     """GSR_FWD_TL_DECAY (the live transmittance follows every valid entry; no zeroing select) and GSR_FWD_COMPACT (survivors parked compacted, walked with
     constant LDS offsets and a counter) reorganise the walk only: image, inverse depth, final_T and n_contrib of both builds of the blend must be the bits
@@ -245,7 +245,7 @@ def test_candidate_forms_of_the_forward_blend_change_no_bit(lib, defines, tag):
     cand = build("forward", fp_contract_off=True, defines=defines, tag=tag)
     cand.simt_fwd_last_error.restype = C.c_char_p
     cand.simt_forward.restype = C.c_int64
-    for name in ["c1", "edge_aa_scale", "deg0_dense"]:
+    for name in ["c1", "deg0_dense"]:
         cam, sc, opts = G.mk(name)
         s = G.run_oracle(cam, sc, opts)[0]      # (the settings record of the scene)
         for track in (True, False):
