@@ -75,6 +75,42 @@ def audit(path: str, flags, extra):
     return rows
 
 
+def forward_walk_step(extra=()):
+    """Instruction mix of ONE step of the forward blend's survivor walk in the inference build (render_fwd_wave_bf<true, 1, false>): the first unrolled
+    copy of the inner loop's body, from the loop header to its closing branch -> {"valu": n, "salu": n, "ds": n}.  The kernel is bound by issue slots
+    (DESIGN 4), so this count IS its cost model; tests/test_isa_audit_cpu.py pins it for the shipped form and for the candidate forms."""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-S", "--cuda-device-only",
+               "-o", out, os.path.join(CSRC, "render_fwd.hip")] + UNITS["render_fwd.hip"] + list(extra)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr[-2000:])
+        s = open(out).read()
+    m = re.search(r"^_ZN12_GLOBAL__N_118render_fwd_wave_bfILb1ELi1ELb0EEE\w+: ; @.*?\n(.*?)^\.Lfunc_end", s, re.S | re.M)
+    if not m:
+        raise RuntimeError("render_fwd_wave_bf<true, 1, false> not found")
+    body = m.group(1)
+    body = body[body.index("This Inner Loop Header"):]
+    mix = {"valu": 0, "salu": 0, "ds": 0}
+    seen_fma = 0
+    for line in body.split("\n")[1:]:
+        t = line.strip().split()
+        if not t or t[0].startswith((";", ".")):
+            continue
+        op = t[0]
+        if op.startswith("v_"):
+            mix["valu"] += 1
+            seen_fma += op.startswith("v_fmac_f32")
+        elif op.startswith("ds_"):
+            mix["ds"] += 1
+        elif op.startswith("s_") and op not in ("s_waitcnt", "s_nop"):
+            mix["salu"] += 1
+            if op.startswith("s_cbranch") and seen_fma >= 6:      # the branch that closes the step (two FMAs of the exponent, four of the accumulators)
+                break
+    return mix
+
+
 def main():
     files = [a for a in sys.argv[1:] if a.endswith(".hip")]
     extra = [a for a in sys.argv[1:] if a.startswith("-")]
