@@ -100,6 +100,28 @@ def test_forward_of_the_kernel_source_with_the_reference_rectangles_and_precompu
     G.check_forward(s, col, radii, invd, aux, out)
 
 
+def run_simt_backward(lib, s, sc, H, W, wc, wd, use_depth):
+    """forward (tracking build) + blend backward + per-Gaussian backward of the kernel source -> (radii, {input name: gradient array})"""
+    from diff_gaussian_rasterization._lib import GsrRasterSettings
+    bg, view, proj, campos = f32(s.bg), f32(s.viewmatrix), f32(s.projmatrix), f32(s.campos)
+    rs = GsrRasterSettings(H, W, float(s.tanfovx), float(s.tanfovy), ptr(bg).value, float(s.scale_modifier), ptr(view).value, ptr(proj).value,
+                           int(s.sh_degree), ptr(campos).value, 0, 0, 1 if s.antialiasing else 0, 0, 0, 0, None, None)
+    P, M = sc.P, sc.shs.shape[1]
+    m, op, scl, rot, shs = f32(sc.means3D), f32(sc.opacities), f32(sc.scales), f32(sc.rotations), f32(sc.shs)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    r_cap = 4_000_000
+    bufs = dict(radii=np.zeros(P, np.int32), tiles=np.zeros(P, np.uint32), color=np.zeros((3, H, W), np.float32), invd=np.zeros((1, H, W), np.float32),
+                pl=np.zeros(r_cap, np.uint32), ranges=np.zeros((gx * gy, 2), np.uint32), final_T=np.zeros((H, W), np.float32), n_contrib=np.zeros((H, W), np.uint32))
+    g = dict(means2D=np.zeros((P, 3), np.float32), means3D=np.zeros((P, 3), np.float32), opacities=np.zeros((P, 1), np.float32),
+             shs=np.zeros((P, M, 3), np.float32), scales=np.zeros((P, 3), np.float32), rotations=np.zeros((P, 4), np.float32))
+    dcol, dinv = f32(wc), (f32(wd) if use_depth else None)
+    R = lib.simt_forward(C.byref(rs), 1, P, M, ptr(m), ptr(shs), None, ptr(op), ptr(scl), ptr(rot), ptr(bufs["radii"]), ptr(bufs["tiles"]), ptr(bufs["color"]),
+                         ptr(bufs["invd"]), ptr(bufs["pl"]), C.c_int64(r_cap), ptr(bufs["ranges"]), 1, ptr(bufs["final_T"]), ptr(bufs["n_contrib"]),
+                         ptr(dcol), ptr(dinv), ptr(g["means2D"]), ptr(g["means3D"]), ptr(g["opacities"]), ptr(g["shs"]), ptr(g["scales"]), ptr(g["rotations"]))
+    assert R > 0, lib.simt_fwd_last_error()
+    return bufs["radii"], g
+
+
 @pytest.mark.parametrize("name,n,seed,use_depth", [("c1", 1000, 0, True), ("edge_aa_scale", 700, 3, True), ("odd_aa", 1200, 4, False)])
 def test_backward_of_the_kernel_source_on_the_cpu_against_the_oracles_autograd(lib, name, n, seed, use_depth):
     """The blend backward (plan kernel, the two-pixels-per-lane walk with its DPP / permlane transpose-reduce, the three reduce kernels) and the
@@ -120,25 +142,8 @@ def test_backward_of_the_kernel_source_on_the_cpu_against_the_oracles_autograd(l
     L["means2D"] = torch.zeros(sc.P, 3, requires_grad=True)
     col, radii, invd = O.rasterize(L["means3D"], L["means2D"], L["opacities"], s, shs=L["shs"], scales=L["scales"], rotations=L["rotations"])
     ((col * wc).sum() + ((invd * wd).sum() if use_depth else 0.0)).backward()
-    # the kernel source
-    from diff_gaussian_rasterization._lib import GsrRasterSettings
-    bg, view, proj, campos = f32(s.bg), f32(s.viewmatrix), f32(s.projmatrix), f32(s.campos)
-    rs = GsrRasterSettings(H, W, float(s.tanfovx), float(s.tanfovy), ptr(bg).value, float(s.scale_modifier), ptr(view).value, ptr(proj).value,
-                           int(s.sh_degree), ptr(campos).value, 0, 0, 1 if s.antialiasing else 0, 0, 0, 0, None, None)
-    P, M = sc.P, sc.shs.shape[1]
-    m, op, scl, rot, shs = f32(sc.means3D), f32(sc.opacities), f32(sc.scales), f32(sc.rotations), f32(sc.shs)
-    gx, gy = (W + 15) // 16, (H + 15) // 16
-    r_cap = 4_000_000
-    bufs = dict(radii=np.zeros(P, np.int32), tiles=np.zeros(P, np.uint32), color=np.zeros((3, H, W), np.float32), invd=np.zeros((1, H, W), np.float32),
-                pl=np.zeros(r_cap, np.uint32), ranges=np.zeros((gx * gy, 2), np.uint32), final_T=np.zeros((H, W), np.float32), n_contrib=np.zeros((H, W), np.uint32))
-    g = dict(means2D=np.zeros((P, 3), np.float32), means3D=np.zeros((P, 3), np.float32), opacities=np.zeros((P, 1), np.float32),
-             shs=np.zeros((P, M, 3), np.float32), scales=np.zeros((P, 3), np.float32), rotations=np.zeros((P, 4), np.float32))
-    dcol, dinv = f32(wc), (f32(wd) if use_depth else None)
-    R = lib.simt_forward(C.byref(rs), 1, P, M, ptr(m), ptr(shs), None, ptr(op), ptr(scl), ptr(rot), ptr(bufs["radii"]), ptr(bufs["tiles"]), ptr(bufs["color"]),
-                         ptr(bufs["invd"]), ptr(bufs["pl"]), C.c_int64(r_cap), ptr(bufs["ranges"]), 1, ptr(bufs["final_T"]), ptr(bufs["n_contrib"]),
-                         ptr(dcol), ptr(dinv), ptr(g["means2D"]), ptr(g["means3D"]), ptr(g["opacities"]), ptr(g["shs"]), ptr(g["scales"]), ptr(g["rotations"]))
-    assert R > 0, lib.simt_fwd_last_error()
-    assert np.array_equal(bufs["radii"], radii.numpy().astype(np.int32))
+    radii_k, g = run_simt_backward(lib, s, sc, H, W, wc, wd, use_depth)
+    assert np.array_equal(radii_k, radii.numpy().astype(np.int32))
     for k in L:
         a, b = torch.from_numpy(g[k]).double(), L[k].grad.double()
         scale = b.abs().max().item() + 1e-30
@@ -254,3 +259,25 @@ def test_candidate_forms_of_the_forward_blend_change_no_bit(lib, defines, tag):
             for k in a:
                 if k != "R":
                     assert torch.equal(a[k], b[k]), f"{name} / track={track}: {k} differs from the shipped form"
+
+
+def test_candidate_form_of_the_backward_walks_reductions_changes_no_bit(lib):
+    """GSR_BWD_DPP_FUSE (csrc/render_bwd.hip: the walk's three cross-lane reductions stage by stage, DPP moves with the full row mask and bound_ctrl so that
+    every one fuses into its add) must leave every gradient the bits of the shipped form -- both builds of the walk (with / without a gradient on the
+    inverse-depth image), the kernel source lane by lane."""
+    import copy
+    from helpers import oracle_settings
+    from simt_build import build
+    cand = build("forward", fp_contract_off=True, defines=("-DGSR_BWD_DPP_FUSE=1",), tag="_dppfuse")
+    cand.simt_fwd_last_error.restype = C.c_char_p
+    cand.simt_forward.restype = C.c_int64
+    cam, sc, opts = G.mk("c1")
+    s = oracle_settings(cam, bg=opts.get("bg"), sh_degree=opts.get("sh_degree", 3), scale_modifier=opts.get("scale_modifier", 1.0), antialiasing=opts.get("antialiasing", False))
+    H, W = cam.image_height, cam.image_width
+    wc, wd = G._loss_weights(H, W, 0)
+    for use_depth in (False, True):
+        ra, ga = run_simt_backward(lib, s, sc, H, W, wc, wd, use_depth)
+        rb, gb = run_simt_backward(cand, s, sc, H, W, wc, wd, use_depth)
+        assert np.array_equal(ra, rb)
+        for k in ga:
+            assert np.abs(ga[k]).max() > 0 and np.array_equal(ga[k], gb[k]), f"use_depth={use_depth}: d{k} differs from the shipped form"
