@@ -69,7 +69,24 @@ __device__ __forceinline__ uint32_t div_small(uint32_t a, uint32_t b, uint32_t& 
 }
 
 // 64-bit mask of the lanes whose `digit` (low `bits` bits significant) equals this lane's, among the lanes in `valid_mask`
+// Candidate (GSR_MATCH_BITOP3, off by default; not yet measured on a GPU): the shipped loop compiles to EIGHT VALU instructions per bit (v_and, two v_cmp,
+// v_cndmask 0 / -1, two v_xor, two v_and); with the bit sign-extended by one v_bfe_i32 and "mask & ~(ballot ^ bit)" as one v_bitop3_b32 per half it is FOUR
+// (v_bfe_i32, v_cmp, 2 x v_bitop3: truth table 0x90 = a & ~(b ^ c)).  Every ranking kernel of the forward's binning chain spends most of its VALU here
+// (emit_scatter: 16 items x 7 bits per thread and block; bucket_scatter 16 x 6; ds_scatter 16 x 11; ds_segsort 2-3 passes x 9).  Same masks, bit for bit.
+#ifndef GSR_MATCH_BITOP3
+#define GSR_MATCH_BITOP3 0
+#endif
 __device__ __forceinline__ uint64_t match_digit(uint32_t digit, int bits, uint64_t valid_mask) {
+#if GSR_MATCH_BITOP3
+    uint32_t lo = (uint32_t)valid_mask, hi = (uint32_t)(valid_mask >> 32);
+    for (int b = 0; b < bits; ++b) {            // wave-uniform trip count
+        const int sx = __builtin_amdgcn_sbfe((int)digit, (unsigned)b, 1u);      // 0 / -1
+        const uint64_t bal = __ballot(sx != 0);
+        lo = __builtin_amdgcn_bitop3_b32(lo, (uint32_t)bal, (uint32_t)sx, 0x90);
+        hi = __builtin_amdgcn_bitop3_b32(hi, (uint32_t)(bal >> 32), (uint32_t)sx, 0x90);
+    }
+    return ((uint64_t)hi << 32) | lo;
+#endif
     uint64_t mask = valid_mask;
     for (int b = 0; b < bits; ++b) {            // wave-uniform trip count
         const bool bit = (digit >> b) & 1u;

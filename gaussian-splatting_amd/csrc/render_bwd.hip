@@ -333,7 +333,13 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
         mxA = max(mxA, (uint32_t)__shfl_xor((int)mxA, off, 64));
         mxB = max(mxB, (uint32_t)__shfl_xor((int)mxB, off, 64));
     }
+#if GSR_BWD_DPP_FUSE
+    // (the butterfly leaves the same maximum in every lane, which the compiler cannot know: as a scalar the batch counter, the list position of a step and
+    // the loop tests move to the SALU)
+    const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)min(range.y - range.x, max(mxA, mxB)), 0);
+#else
     const uint32_t end = min(range.y - range.x, max(mxA, mxB));
+#endif
     if (end == 0) return;
 
     BwdPix2 s = {T_final, {0.f, 0.f}};

@@ -84,6 +84,16 @@ static inline void simt_launch(K kernel, dim3 grid, dim3 block, A... args) {
 #define __builtin_amdgcn_wave_barrier() simt::wave_barrier()
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __popcll(x) __builtin_popcountll((unsigned long long)(x))
+// v_bitop3_b32: bit i of the result = truth table entry (a_i << 2 | b_i << 1 | c_i); v_bfe_i32: sign-extended bit field
+static inline uint32_t __builtin_amdgcn_bitop3_b32(uint32_t a, uint32_t b, uint32_t c, unsigned tt) {
+    uint32_t r = 0;
+    for (int i = 0; i < 32; ++i) r |= ((tt >> ((((a >> i) & 1u) << 2) | (((b >> i) & 1u) << 1) | ((c >> i) & 1u))) & 1u) << i;
+    return r;
+}
+static inline int __builtin_amdgcn_sbfe(int v, unsigned off, unsigned width) {
+    const uint32_t f = ((uint32_t)v >> off) & ((1u << width) - 1u);
+    return (int)(f ^ (1u << (width - 1))) - (int)(1u << (width - 1));
+}
 #define __popc(x) __builtin_popcount((unsigned)(x))
 
 using std::max;
