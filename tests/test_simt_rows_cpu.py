@@ -29,12 +29,27 @@ def lib():
     return h
 
 
+@pytest.fixture(scope="module")
+def lib_bitop3():
+    """the same harness over the candidate form of rs_scatter's digit matching (csrc/gsr_wave.h match_digit, GSR_MATCH_BITOP3: off in the product)"""
+    from simt_build import build
+    h = build("rows", fp_contract_off=True, defines=("-DGSR_MATCH_BITOP3=1",), tag="_bitop3")
+    h.simt_rows_last_error.restype = C.c_char_p
+    return h
+
+
+@pytest.fixture(params=["shipped", "bitop3"])
+def sort_lib(request):
+    return request.getfixturevalue("lib" if request.param == "shipped" else "lib_bitop3")
+
+
 def ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
 @pytest.mark.parametrize("n,nbits,digit,items", [(10_000, 27, 9, 1024), (9_001, 27, 9, 2048), (20_000, 27, 9, 4096), (5_000, 32, 8, 1024), (300, 13, 8, 1024), (1, 27, 9, 1024)])
-def test_lsd_radix_sort_pairs_on_the_cpu(lib, n, nbits, digit, items):
+def test_lsd_radix_sort_pairs_on_the_cpu(sort_lib, n, nbits, digit, items):
+    lib = sort_lib
     rng = np.random.default_rng(n + nbits)
     keys = rng.integers(0, 1 << nbits, n, dtype=np.uint64).astype(np.uint32)
     keys[rng.random(n) < 0.3] = keys[0]                        # ties: stability
@@ -48,7 +63,8 @@ def test_lsd_radix_sort_pairs_on_the_cpu(lib, n, nbits, digit, items):
     assert np.array_equal(rect_sorted, rect[ref]), "the last pass's rectangle gather"
 
 
-def test_lsd_radix_sort_with_16_bit_keys_on_the_cpu(lib):
+def test_lsd_radix_sort_with_16_bit_keys_on_the_cpu(sort_lib):
+    lib = sort_lib
     rng = np.random.default_rng(3)
     n = 30_000
     keys = rng.integers(0, 8160, n).astype(np.uint16)
