@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 bring-up of the candidates that round 4 left written, CPU-verified and UNMEASURED, in one gpurun call:
 #   * lib_next_fwd = the product sources with -DGSR_FWD_TL_DECAY=1 -DGSR_FWD_COMPACT=1 (forward blend: 24 -> 22 VALU and 11 -> 4 SALU per step; csrc/render_fwd.hip)
-#   * lib_next_bins = the product sources with -DGSR_MATCH_BITOP3=1 (digit matching of ds_scatter / ds_segsort / emit_scatter / bucket_scatter: 8 -> 4 VALU per bit; csrc/gsr_wave.h)
+#   * lib_next_bins = the product sources with -DGSR_MATCH_BITOP3=1 (digit matching of ds_scatter / ds_segsort / emit_scatter / bucket_scatter and the LSD fallback's rs_scatter: 8 -> 4 VALU per bit; csrc/gsr_wave.h)
 #   * lib_next_bwd = the product sources with -DGSR_BWD_DPP_FUSE=1 (blend backward: every cross-lane add one v_add_f32_dpp, 103 -> 95 VALU per step; csrc/render_bwd.hip)
 #   * lib_ab    = measurement build; option emit_scatter_mode=1 (level-1 scatter ranking row segments; csrc/ab/emit_scatter_segments.inc)
 # Build both HERE first (no GPU needed), they travel with the snapshot:
