@@ -4,6 +4,7 @@
 #   * lib_next_bins = the product sources with -DGSR_MATCH_BITOP3=1 (digit matching of ds_scatter / ds_segsort / emit_scatter / bucket_scatter and the LSD fallback's rs_scatter: 8 -> 4 VALU per bit; csrc/gsr_wave.h)
 #   * lib_next_bwd = the product sources with -DGSR_BWD_DPP_FUSE=1 (blend backward: every cross-lane add one v_add_f32_dpp, 103 -> 95 VALU per step; csrc/render_bwd.hip)
 #   * lib_ab    = measurement build; option emit_scatter_mode=1 (level-1 scatter ranking row segments; csrc/ab/emit_scatter_segments.inc)
+# CPU pins of the candidate forms first:  GSR_TEST_CANDIDATES=1 python -m pytest tests -q -m "not gpu" -k "candidate or bitop3"
 # Build both HERE first (no GPU needed), they travel with the snapshot:
 #   GSR_OUT=lib_next_fwd GSR_EXTRA_FLAGS="-DGSR_FWD_TL_DECAY=1 -DGSR_FWD_COMPACT=1" python gaussian-splatting_amd/build.py
 #   GSR_OUT=lib_next_bins GSR_EXTRA_FLAGS="-DGSR_MATCH_BITOP3=1" python gaussian-splatting_amd/build.py
