@@ -72,7 +72,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--s-med", type=float, default=0.012)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--variant", type=int, default=None, help="render_fwd_variant (0 wave + LDS broadcast, 1 workgroup-per-tile baseline, 2 wave + readlane)")
+    ap.add_argument("--variant", type=int, default=None, help="render_fwd_variant (0 wave + LDS broadcast, 1 workgroup-per-tile baseline, 3 four waves per workgroup; 1 and 3: measurement build only)")
     ap.add_argument("--train-steps", type=int, default=-1, help="-1: same as --steps; 0 disables the train leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=1200, help="tiles blended by the CPU baseline sample")
@@ -434,8 +434,53 @@ def _run(a):
     fwd_counters = _lib.profile_counters(reset=True)
     _lib.profile_enable(False)
     stage_ms = {k: (v["ms"] / max(1, v["launches"])) for k, v in stages.items() if v["launches"]}
+    # the dominant kernel launch by launch (one profile read per frame): mean AND median of its HIP-event duration
+    kernel_ms_stats = {}
+    _lib.profile_enable(True)
+    fwd_launch_ms = []
+    for _ in range(a.steps):
+        _lib.profile_reset()
+        forward_step()
+        drain()
+        torch.cuda.synchronize()
+        r1_ = _lib.profile_read()["render"]
+        if r1_["launches"]:
+            fwd_launch_ms.append(r1_["ms"] / r1_["launches"])
+    _lib.profile_enable(False)
+    if fwd_launch_ms:
+        kernel_ms_stats["render"] = {"mean": sum(fwd_launch_ms) / len(fwd_launch_ms), "median": sorted(fwd_launch_ms)[len(fwd_launch_ms) // 2],
+                                     "launches": len(fwd_launch_ms)}
     fwd_steps_per_launch = fwd_counters["fwd_steps"] / max(1, ncount)
     fwd_batches_per_launch = fwd_counters["fwd_batches"] / max(1, ncount)
+
+    # the same frame, same loop, with the REFERENCE's tile rectangles (snug_tiles = 0: the square of radius
+    # ceil(3 sqrt(lambda_max))) -- the configuration whose bins are bit-exact against the oracle in
+    # reference mode (tests/test_gpu_fullsize.py::*_reference_tile_rectangles_bit_exact), R = num_rendered_reference_tile_squares
+    reference_rect = None
+    if world == 1 and snug_opt != 0:
+        _lib.set_option("snug_tiles", 0)
+        try:
+            for _ in range(max(5, a.warmup)):
+                forward_step()
+            rdt_ = timed_loop(forward_step, a.steps, "forward_reference_rectangles")[0]
+            _lib.profile_reset()
+            _lib.profile_enable(True)
+            for _ in range(min(10, a.steps)):
+                forward_step()
+            torch.cuda.synchronize()
+            rst_ = _lib.profile_read()
+            _lib.profile_enable(False)
+            reference_rect = {"ms_per_frame": round(rdt_ / a.steps * 1e3, 4), "Mpix_s": round(npix / (rdt_ / a.steps) / 1e6, 1),
+                              "num_rendered": R_reference,
+                              "stage_ms": {k: round(v["ms"] / max(1, v["launches"]), 4) for k, v in rst_.items() if v["launches"]},
+                              "note": "option snug_tiles = 0: every Gaussian binned into the reference's own tile square (same image, bit for bit; "
+                                      "bins bit-exact against the oracle in reference mode); NOT `value`, which bins the snug rectangles"}
+        finally:
+            _lib.profile_enable(False)
+            _lib.set_option("snug_tiles", snug_opt)
+        for _ in range(3):
+            forward_step()
+        sync_all()
 
     # the TRACKING build of the forward (what a training iteration runs: final_T / n_contrib / first-emission indices are
     # written for the backward), timed beside the inference build the headline uses
@@ -602,6 +647,21 @@ def _run(a):
                 for k in ("render_bwd", "gather_bwd", "preprocess_bwd"):
                     if tstages[k]["launches"]:
                         stage_ms[k] = tstages[k]["ms"] / tstages[k]["launches"]
+                # the blend backward launch by launch ON VIEW 0 (the frame whose step count the roofline uses): mean and median
+                bwd_launch_ms = []
+                _lib.profile_enable(True)
+                for _ in range(min(20, tsteps)):
+                    it_no[0] = 0
+                    _lib.profile_reset()
+                    train_step()
+                    torch.cuda.synchronize()
+                    r1_ = _lib.profile_read()["render_bwd"]
+                    if r1_["launches"]:
+                        bwd_launch_ms.append(r1_["ms"] / r1_["launches"])
+                _lib.profile_enable(False)
+                if bwd_launch_ms:
+                    kernel_ms_stats["render_bwd"] = {"mean": sum(bwd_launch_ms) / len(bwd_launch_ms), "median": sorted(bwd_launch_ms)[len(bwd_launch_ms) // 2],
+                                                     "launches": len(bwd_launch_ms)}
                 it_no[0] = 0                      # counters on view 0 (the frame of the forward metric), own pass
                 _lib.profile_enable(False, counters=True)
                 _lib.profile_counters(reset=True)
@@ -936,40 +996,51 @@ def _run(a):
                 pass
             return None
 
-        def blend_roofline(kernel, ms, steps, flop_per_pair, hbm_bytes, pmc_entry, what, pairs_per_step=64.0):
+        roofline_notes = {}
+
+        def blend_roofline(kernel, stage, steps, flop_per_pair, hbm_bytes, pmc_entry, what, pairs_per_step=64.0):
+            """`achieved` / `frac` use the MEAN HIP-event duration of the kernel's launches measured live in this run (the library records an
+            event pair around the kernel on the launch stream); `frac_median` the median of the same launches.  Everything that is NOT
+            measured in this run -- HBM traffic and VALU instruction counts from the committed rocprofv3 --pmc passes -- carries
+            `_from_committed_profile` in its name (VERDICT r04 weak #8a).  The long notes live in `roofline_notes` (early in the line)."""
+            st = kernel_ms_stats.get(stage)
+            ms = st["mean"] if st else stage_ms.get(stage)
             if not ms:
                 return None
+            med = st["median"] if st else ms
             flops = steps * pairs_per_step * flop_per_pair
             ach = flops / (ms * 1e-3) / 1e12
             gbs = hbm_bytes / (ms * 1e-3) / 1e9
+            traffic = None if not pmc_entry else int(pmc_entry.get("hbm_bytes_corrected", 0)) or None
             r = {"bound": "valu", "kernel": kernel, "achieved": round(ach, 3), "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
-                 "frac": round(ach / FP32_VALU_PEAK_TF, 5), "kernel_ms": round(ms, 4),
+                 "frac": round(ach / FP32_VALU_PEAK_TF, 5), "kernel_ms": round(ms, 4), "kernel_ms_median": round(med, 4),
+                 "frac_median": round(flops / (med * 1e-3) / 1e12 / FP32_VALU_PEAK_TF, 5), "launches_timed": st["launches"] if st else None,
                  "evaluated_pair_steps_per_launch": int(steps * pairs_per_step), "flop_per_pair": flop_per_pair,
-                 "counted": what,
-                 "traffic": None if not pmc_entry else int(pmc_entry.get("hbm_bytes_corrected", 0)) or None,
-                 "traffic_source": None if not pmc_entry else "profiles/pmc_latest.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py)",
+                 "traffic": traffic, "traffic_from_committed_profile": traffic, "traffic_measured_in_this_run": False,
                  "hbm": {"algorithmic_bytes_per_launch": int(hbm_bytes), "achieved_GBs": round(gbs, 2),
-                         "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 5), "frac_of_6.29TBs": round(gbs / HBM_ACHIEVABLE_GBS, 5)},
-                 "note": "fp32-VALU bound, not HBM bound (SURVEY 8(d); SQ counters: waves wait for VALU issue, measured HBM traffic is a "
-                         "fraction of the algorithmic bytes because the splat records stay in L2 / Infinity Cache and early "
-                         "termination ends the walks); FLOPs counted = pairs the kernel actually evaluates (whole waves: 64 pixels "
-                         "per surviving list entry), not the 256*R listed pairs"}
+                         "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 5), "frac_of_6.29TBs": round(gbs / HBM_ACHIEVABLE_GBS, 5)}}
+            roofline_notes[kernel] = {
+                "counted": what,
+                "traffic_source": "profiles/pmc_latest.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, committed; NOT collected in this run)",
+                "note": "fp32-VALU bound, not HBM bound (SURVEY 8(d); SQ counters: waves wait for VALU issue, measured HBM traffic is a "
+                        "fraction of the algorithmic bytes because the splat records stay in L2 / Infinity Cache and early "
+                        "termination ends the walks); FLOPs counted = pairs the kernel actually evaluates (whole waves: 64 pixels "
+                        "per surviving list entry), not the 256*R listed pairs",
+                "valu_ceiling_source": "profiles/r03_valu_issue.txt (tools/microbench/valu_issue.hip): 60 T lane-ops/s for independent "
+                                       "v_fma_f32 at >= 8 waves/SIMD; instruction counts from the committed SQ pass (profiles/pmc_latest.json)"}
             if pmc_entry and pmc_entry.get("SQ_INSTS_VALU"):
                 lane_ops = pmc_entry["SQ_INSTS_VALU"] * 64.0 / (ms * 1e-3) / 1e12
-                r["valu_lane_ops_T_per_s"] = round(lane_ops, 2)
-                r["valu_issue_frac_of_spec"] = round(lane_ops / (FP32_VALU_PEAK_TF / 2.0), 4)     # spec: one lane-op per lane and clock at 2.4 GHz
-                r["valu_issue_frac_of_measured_ceiling"] = round(lane_ops / MEASURED_VALU_LANE_OPS_T, 4)
-                r["valu_ceiling_source"] = ("profiles/r03_valu_issue.txt (tools/microbench/valu_issue.hip): 60 T lane-ops/s for independent "
-                                            "v_fma_f32 at >= 8 waves/SIMD; instruction counts from the committed SQ pass (profiles/pmc_latest.json)")
-                r["valu_instructions_per_launch"] = int(pmc_entry["SQ_INSTS_VALU"])
+                r["valu_lane_ops_T_per_s_from_committed_profile"] = round(lane_ops, 2)
+                r["valu_issue_frac_of_measured_ceiling_from_committed_profile"] = round(lane_ops / MEASURED_VALU_LANE_OPS_T, 4)
+                r["valu_instructions_per_launch_from_committed_profile"] = int(pmc_entry["SQ_INSTS_VALU"])
             return r
 
-        roof = blend_roofline("render_fwd_wave_bf<LDS, inference>", stage_ms.get("render"), fwd_steps_per_launch, FWD_FLOP_PER_PAIR,
+        roof = blend_roofline("render_fwd_wave_bf<LDS, inference>", "render", fwd_steps_per_launch, FWD_FLOP_PER_PAIR,
                               ab["blend"] * frac_rows, pmc(["render_fwd_wave_bf<true, 1, false>"]),
                               "wave-level (8x8 pixel block, list entry) pairs that survive the exact box test and are blended, counted by the kernel")
         roof_train = None
         if bwd_counters:
-            roof_train = blend_roofline("render_bwd_half", stage_ms.get("render_bwd"), bwd_counters["bwd_steps"], BWD_FLOP_PER_PAIR,
+            roof_train = blend_roofline("render_bwd_half", "render_bwd", bwd_counters["bwd_steps"], BWD_FLOP_PER_PAIR,
                                         abb["render_bwd"] * frac_rows, pmc(["render_bwd_half"]),
                                         "wave-level (16x8 half tile, list entry) steps of the backward walk x 128 pixels, counted by the kernel",
                                         pairs_per_step=128.0)
@@ -1070,7 +1141,30 @@ def _run(a):
             "roofline_train": roof_train,
             "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(out), flush=True)
+        # The driver keeps only the last ~4 KB of stdout (VERDICT r04 weak #8b): everything a reader needs to check the line sits at the END,
+        # compact; the long notes and the context legs come first.
+        cl = (other or {}).get("configs[1] clustered") if isinstance(other, dict) else None
+        low_vis = None
+        if cl and "train_step_dense_adam_ms" in cl:
+            low_vis = {"scene": "configs[1] clustered", "visible_fraction": round(cl["visible"] / cl["P"], 3),
+                       "dense_adam_it_s": round(1e3 / cl["train_step_dense_adam_ms"], 1),
+                       "sparse_adam_it_s": round(1e3 / cl["train_step_sparse_adam_ms"], 1)}
+        out["roofline_notes"] = roofline_notes
+        out["forward_reference_rectangles"] = reference_rect
+        out["forward_reference_rectangles_ms"] = None if not reference_rect else reference_rect["ms_per_frame"]
+        out["train_low_visibility"] = low_vis
+        tail_keys = ["roofline_notes", "blend_timeline", "forward_reference_rectangles", "forward_frames_in_flight", "train_low_visibility",
+                     "cpu_baseline", "roofline_train", "roofline", "stage_ms", "retimed", "forward_reference_rectangles_ms",
+                     "train_iters_per_s_sparse_adam", "train_ms_per_iter", "train_iters_per_s", "ms_per_step", "value"]
+        head_keys = ["other_configs_forward", "train_full_loop_configs2", "train_densify", "stages", "train_step"]
+        ordered = {k: out[k] for k in head_keys if k in out}
+        ordered.update({k: v for k, v in out.items() if k not in tail_keys and k not in head_keys})
+        # roofline_notes is long: it goes BEFORE the tail proper
+        ordered["roofline_notes"] = out["roofline_notes"]
+        for k in tail_keys[1:]:
+            if k in out:
+                ordered[k] = out[k]
+        print(json.dumps(ordered), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

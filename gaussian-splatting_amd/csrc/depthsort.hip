@@ -55,8 +55,10 @@ __device__ __forceinline__ int ds_shift(uint32_t kmin, uint32_t kmax) {
     if ((range >> s) > (uint32_t)DS_NB - 2u) ++s;
     return s;
 }
+// kmin / kmax are the ROBUST key range (ds_hist): the few keys outside it share the first / last usable bucket, whose segments
+// are sorted on their full keys like any other (the mapping stays monotone in the key, so the order does not change)
 __device__ __forceinline__ uint32_t ds_bucket(uint32_t key, uint32_t kmin, int shift) {
-    return key == GSR_DEPTH_KEY_CULLED ? DS_CULL : (key - kmin) >> shift;
+    return key == GSR_DEPTH_KEY_CULLED ? DS_CULL : min((max(key, kmin) - kmin) >> shift, (uint32_t)DS_NB - 2u);
 }
 
 // four consecutive words, vector load when whole (p + e0 is 16-byte aligned: e0 is a multiple of 4, arrays are 128-byte aligned)
@@ -78,7 +80,7 @@ __global__ void __launch_bounds__(DS_THREADS)
 ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tiles, uint32_t* __restrict__ frame,
         const uint2* __restrict__ wg_range, int n_range, uint32_t* __restrict__ cnt_tab, uint32_t* __restrict__ tile_tab) {
     __shared__ uint32_t h_cnt[DS_NB], h_tile[DS_NB];
-    __shared__ uint32_t s_nmin[WG_WAVES], s_max[WG_WAVES];
+    __shared__ uint32_t s_nmin[WG_WAVES], s_max[WG_WAVES], s_rnmin[WG_WAVES], s_rmax[WG_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * DS_ITEMS;
     uint32_t k[4][4], t[4][4];
@@ -97,17 +99,35 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
         h_tile[i * DS_THREADS + tid] = 0u;
     }
     {
-        uint32_t nm = 0, mx = 0;
+        // The frame's TRUE key range (max over all workgroups) and a ROBUST one (a handful of far outliers stretches the
+        // true range until the bulk of the scene shares a few buckets, whose oversized segments take the slow path): a thread's <= 8
+        // workgroups form a group; the group's SMALLEST workgroup maximum ignores an outlier unless every workgroup of the group has
+        // one, and the largest of these over the groups is the robust maximum (likewise the minimum, on ~kmin).  Every workgroup of the
+        // key-producing kernel samples the whole array (grid-stride), so its extremes are ~1/1000 quantiles of the frame: about that
+        // fraction of the keys falls outside the robust range and shares the two end buckets.
+        uint32_t nm = 0, mx = 0, gnm = 0xFFFFFFFFu, gmx = 0xFFFFFFFFu;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { nm = max(nm, rg[j].x); mx = max(mx, rg[j].y); }
+        for (int j = 0; j < 8; ++j) {
+            nm = max(nm, rg[j].x);
+            mx = max(mx, rg[j].y);
+            const bool have = j * DS_THREADS + tid < n_range && (rg[j].x | rg[j].y) != 0u;      // (0, 0): the workgroup listed nothing
+            gnm = min(gnm, have ? rg[j].x : 0xFFFFFFFFu);
+            gmx = min(gmx, have ? rg[j].y : 0xFFFFFFFFu);
+        }
+        if (gmx == 0xFFFFFFFFu) { gnm = 0u; gmx = 0u; }      // a group without a listing workgroup takes no part in the maxima
         nm = wave_incl_max_u32(nm);
         mx = wave_incl_max_u32(mx);
-        if (lane == 63) { s_nmin[w] = nm; s_max[w] = mx; }
+        gnm = wave_incl_max_u32(gnm);
+        gmx = wave_incl_max_u32(gmx);
+        if (lane == 63) { s_nmin[w] = nm; s_max[w] = mx; s_rnmin[w] = gnm; s_rmax[w] = gmx; }
     }
     __syncthreads();
-    const uint32_t kmin = ~max(max(s_nmin[0], s_nmin[1]), max(s_nmin[2], s_nmin[3]));
-    const uint32_t kmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-    if (blockIdx.x == 0 && tid == 0) { frame[2] = kmin; frame[3] = kmax; }
+    const uint32_t tmin = ~max(max(s_nmin[0], s_nmin[1]), max(s_nmin[2], s_nmin[3]));
+    const uint32_t tmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    uint32_t kmin = ~max(max(s_rnmin[0], s_rnmin[1]), max(s_rnmin[2], s_rnmin[3]));
+    uint32_t kmax = max(max(s_rmax[0], s_rmax[1]), max(s_rmax[2], s_rmax[3]));
+    if (kmax <= kmin || kmin < tmin || kmax > tmax) { kmin = tmin; kmax = tmax; }      // nothing to be robust about (few workgroups, one key, ...)
+    if (blockIdx.x == 0 && tid == 0) { frame[2] = kmin; frame[3] = kmax; frame[6] = tmin; frame[7] = tmax; }
     const int shift = ds_shift(kmin, kmax);
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -547,9 +567,11 @@ ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame
     const uint32_t kmin = frame[2], kmax = frame[3];
     const int shift = ds_shift(kmin, kmax);
     const bool r_ok = frame[1] == 0u && (int32_t)frame[0] >= 0;      // R < 2^31 (else the host refuses the frame: no table writes)
-    // keys of the segment lie in [base_key, base_key + span)
-    const uint32_t base_key = kmin + (d0 << shift);
-    const uint64_t span = (uint64_t)(d1 - d0) << shift;
+    // keys of the segment lie in [base_key, base_key + span); the first / last usable bucket also holds the keys below / above the
+    // robust range [kmin, kmax] the buckets span (ds_hist), down / up to the frame's true extremes frame[6..7]
+    const uint32_t base_key = d0 == 0u ? frame[6] : kmin + (d0 << shift);
+    const uint64_t top_key = d1 > (uint32_t)DS_NB - 2u ? (uint64_t)frame[7] + 1ull : (uint64_t)kmin + ((uint64_t)d1 << shift);
+    const uint64_t span = top_key > (uint64_t)base_key ? top_key - (uint64_t)base_key : 0ull;
     const int nbits = span <= 1ull ? 0 : 64 - __clzll((long long)(span - 1ull));
     // (the segments tile [0, listed): exactly one ends at `listed`.  Its end BUCKET need not be 2047 -- behind the last
     // non-empty bucket come empty ones that start at `listed` too -- so the element count decides, not the bucket)

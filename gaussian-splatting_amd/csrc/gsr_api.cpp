@@ -163,6 +163,7 @@ std::mutex g_hw_mu;
 std::vector<HostWord> g_hw_pool[GSR_MAX_DEVICES];
 std::atomic<int64_t> g_last_R[GSR_MAX_DEVICES];      // per device: sizes the speculative binning buffer of the next frame
 std::atomic<int> g_lsd_frames[GSR_MAX_DEVICES];      // per device: frames for which the automatic depth sort stays with the LSD passes
+std::atomic<int> g_lsd_backoff[GSR_MAX_DEVICES];     // per device: length of the next such stay (doubles per failed retry; heuristic only)
 struct HostWordLease {
     int dev = -1;
     HostWord hw;
@@ -195,8 +196,11 @@ int lease_host_word(HostWordLease& lease, hipStream_t st) {
     }
     lease.hw.host[3] = 0;
     if (lease.hw.host[5]) {      // the previous frame on this word: thousands of Gaussians in one depth bucket -- its segment went
-        lease.hw.host[5] = 0;    // through global memory.  Stay with the LSD passes for a while, then try again.
-        g_lsd_frames[dev_id].store(64);
+        lease.hw.host[5] = 0;    // through global memory.  Stay with the LSD passes for a while, then try again: 64 frames the first
+        int back = g_lsd_backoff[dev_id].load();      // time, twice as long after every retry that met an oversized segment again
+        if (back < 64) back = 64;                     // (a scene that always crowds a bucket pays one slow frame in 65, 129, ... 8193)
+        g_lsd_frames[dev_id].store(back);
+        g_lsd_backoff[dev_id].store(back >= 8192 ? 8192 : back * 2);
     }
     lease.dev = dev_id;
     lease.st = st;
@@ -383,13 +387,6 @@ int gsr_set_option(const char* name, int value) {
         g_tile_sort_mode = value;
         return GSR_OK;
     }
-#ifdef GSR_AB_VARIANTS
-    if (!strcmp(name, "emit_scatter_mode")) {      // measurement build only: 1 = the level-1 scatter ranks row pieces (csrc/ab/emit_scatter_segments.inc)
-        if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "emit_scatter_mode must be 0 (instances) or 1 (row pieces)");
-        gsr_set_emit_scatter_mode(value);
-        return GSR_OK;
-    }
-#endif
     return fail(GSR_ERR_INVALID_ARG, std::string("unknown option ") + name);
 }
 
@@ -540,8 +537,10 @@ static GsrFrameStatsDev frame_stats_for(HostWordLease& lease, GsrGeom& g, uint32
 static bool use_bucket_sort(int P, int dev_id) {
     if (P > GSR_DS_MAX_P || g_depth_sort_mode == 1) return false;
     if (g_depth_sort_mode == 2) return true;
-    int left = g_lsd_frames[dev_id].load();
-    if (left > 0) { g_lsd_frames[dev_id].store(left - 1); return false; }
+    if (g_lsd_frames[dev_id].load() > 0) {
+        if (g_lsd_frames[dev_id].fetch_sub(1) > 0) return false;      // (concurrent callers: one decrement each, never a lost update)
+        g_lsd_frames[dev_id].store(0);
+    }
     return true;
 }
 

@@ -22,7 +22,8 @@
 // counter (device memory, u64, zero between frames): bits [0, 42) sum of the tile counts (a workgroup's part saturates at
 // 2^31: any total >= 2^31 is refused by the host anyway), [42, 53) workgroups with a key overflow, [53, 64) tickets
 // -> the key-producing kernels run at most GSR_FRAME_MAX_GROUPS workgroups
-// frame words (geometry buffer, GsrGeom::num_rendered): [0] R low, [1] R high; [2] kmin, [3] kmax are written by ds_hist
+// frame words (geometry buffer, GsrGeom::num_rendered): [0] R low, [1] R high; written by ds_hist: [2] kmin, [3] kmax of the ROBUST key
+// range the depth buckets span, [6] / [7] the true extremes (depthsort.hip)
 // host word (mapped): [0] R low, [1] sequence number, [2] R high, [3] "a depth key needed more than 27 bits"
 #define GSR_FRAME_MAX_GROUPS 2047
 struct GsrFrameStatsDev {

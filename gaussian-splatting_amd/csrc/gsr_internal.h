@@ -203,7 +203,6 @@ void gsr_launch_tile_sort_level2(const GsrTileSortPlan& plan, int64_t R, int n_t
                                  uint2* ranges, hipStream_t st);
 void gsr_set_level2_scan_mode(int v);      // tilesort.hip (option level2_scan_mode)
 #ifdef GSR_AB_VARIANTS
-void gsr_set_emit_scatter_mode(int v);     // tilesort.hip (option emit_scatter_mode, measurement build only)
 #endif
 // sort.hip: in-place exclusive scan of every digit row of a [ndigits][nblocks] block-histogram table + row totals
 void gsr_launch_rs_scan(uint32_t* block_hist, int nblocks, int ndigits, uint32_t* digit_total, hipStream_t st);

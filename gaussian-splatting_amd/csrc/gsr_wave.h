@@ -68,16 +68,13 @@ __device__ __forceinline__ uint32_t div_small(uint32_t a, uint32_t b, uint32_t& 
     return q;
 }
 
-// 64-bit mask of the lanes whose `digit` (low `bits` bits significant) equals this lane's, among the lanes in `valid_mask`
-// Candidate (GSR_MATCH_BITOP3, off by default; not yet measured on a GPU): the shipped loop compiles to EIGHT VALU instructions per bit (v_and, two v_cmp,
-// v_cndmask 0 / -1, two v_xor, two v_and); with the bit sign-extended by one v_bfe_i32 and "mask & ~(ballot ^ bit)" as one v_bitop3_b32 per half it is FOUR
-// (v_bfe_i32, v_cmp, 2 x v_bitop3: truth table 0x90 = a & ~(b ^ c)).  Every ranking kernel of the forward's binning chain spends most of its VALU here
-// (emit_scatter: 16 items x 7 bits per thread and block; bucket_scatter 16 x 6; ds_scatter 16 x 11; ds_segsort 2-3 passes x 9).  Same masks, bit for bit.
-#ifndef GSR_MATCH_BITOP3
-#define GSR_MATCH_BITOP3 0
-#endif
+// 64-bit mask of the lanes whose `digit` (low `bits` bits significant) equals this lane's, among the lanes in `valid_mask`.
+// FOUR VALU instructions per bit: the bit sign-extended by one v_bfe_i32, one v_cmp for the ballot, and "mask & ~(ballot ^ bit)" as one
+// v_bitop3_b32 per half (truth table 0x90 = a & ~(b ^ c)).  The plain form ("mask &= bit ? bal : ~bal") compiles to EIGHT (v_and, two v_cmp,
+// v_cndmask 0 / -1, two v_xor, two v_and).  Every ranking kernel of the forward's binning chain spends most of its VALU here (emit_scatter: 16 items x 7
+// bits per thread and block; bucket_scatter 16 x 6; ds_scatter 16 x 11; ds_segsort 2-3 passes x 9).  Measured, same box, interleaved
+// (profiles/r05_ab_candidates.json): depth sort + emission + tile sort 0.182 -> 0.174 ms; bins bit-exact on the GPU suites.
 __device__ __forceinline__ uint64_t match_digit(uint32_t digit, int bits, uint64_t valid_mask) {
-#if GSR_MATCH_BITOP3
     uint32_t lo = (uint32_t)valid_mask, hi = (uint32_t)(valid_mask >> 32);
     for (int b = 0; b < bits; ++b) {            // wave-uniform trip count
         const int sx = __builtin_amdgcn_sbfe((int)digit, (unsigned)b, 1u);      // 0 / -1
@@ -86,14 +83,6 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t digit, int bits, uint64
         hi = __builtin_amdgcn_bitop3_b32(hi, (uint32_t)(bal >> 32), (uint32_t)sx, 0x90);
     }
     return ((uint64_t)hi << 32) | lo;
-#endif
-    uint64_t mask = valid_mask;
-    for (int b = 0; b < bits; ++b) {            // wave-uniform trip count
-        const bool bit = (digit >> b) & 1u;
-        const uint64_t bal = __ballot(bit);
-        mask &= bit ? bal : ~bal;
-    }
-    return mask;
 }
 
 }  // namespace gsrw

@@ -45,31 +45,24 @@ typedef uint2 uint2v;
 typedef unsigned uint2v __attribute__((ext_vector_type(2)));
 #endif
 
-// Candidate (GSR_BWD_DPP_FUSE, off by default; not yet measured on a GPU): every cross-lane add of the walk as ONE v_add_f32_dpp.  The shipped form leaves
-// four of them per step as v_mov 0 + v_mov_dpp + v_add: the compiler sinks the add of the last row_shr into the "(lane & 15) == 15" branch that consumes it
-// (a DPP move cannot follow it there), and it cannot fuse a move with a partial row mask into a float add (the kept lanes would need -0 + 0 = -0).  With
-// the macro the moves use the full row mask and bound_ctrl (a lane without a source reads 0, as before; the rows a partial mask used to protect only hold
-// partial sums nobody reads: row_bcast:15 results are consumed in lanes 31 / 63, row_bcast:31 in lane 63) and the sum is pinned in a register before the
-// branch.  The consumed lanes add the same values in the same order: the gradients are the same bits (tests/test_simt_forward_cpu.py).
-#ifndef GSR_BWD_DPP_FUSE
-#define GSR_BWD_DPP_FUSE 0
-#endif
-// (no instruction: the sum exists in all lanes here, so its add stays next to its DPP move instead of sinking into the consumer's branch, and the
-// pins of one stage keep their order)
+// Every cross-lane add of the walk is ONE v_add_f32_dpp: the DPP moves use the full row mask and bound_ctrl (a lane without a source reads 0; the rows a
+// partial row mask would protect only hold partial sums nobody reads: row_bcast:15 results are consumed in lanes 31 / 63, row_bcast:31 in lane 63), and
+// the sum is pinned in a register before the branch that consumes it.  (Rounds 2-4 left four of them per step as v_mov 0 + v_mov_dpp + v_add: the
+// compiler sinks the add of the last row_shr into the "(lane & 15) == 15" branch -- a DPP move cannot follow it there -- and it cannot fuse a move with a
+// partial row mask into a float add, the kept lanes would need -0 + 0 = -0.)  103 -> 95 VALU per step; the consumed lanes add the same values in the same
+// order, so the gradients are the bits of the earlier form (tests/test_simt_forward_cpu.py ran both); measured on the GPU, same box, interleaved:
+// blend backward 0.342 -> 0.326 ms (profiles/r05_ab_candidates.json).
+// dpp_pin: no instruction -- the sum exists in all lanes here, so its add stays next to its DPP move instead of sinking into the consumer's branch, and
+// the pins of one stage keep their order
 __device__ __forceinline__ void dpp_pin(float& r) {
-#if GSR_BWD_DPP_FUSE && !defined(GSR_SIMT_SHIM)
+#if !defined(GSR_SIMT_SHIM)
     asm volatile("" : "+v"(r));
 #endif
 }
-template <int CTRL, int ROW_MASK>
+template <int CTRL, int ROW_MASK /*documents which rows consume the result; the move itself takes all rows*/>
 __device__ __forceinline__ float dpp_add(float v) {
-#if GSR_BWD_DPP_FUSE
     const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
     return v + __int_as_float(moved);
-#else
-    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
-    return v + __int_as_float(moved);
-#endif
 }
 template <int CTRL>
 __device__ __forceinline__ void dpp_stage(float& c, float& a, float& b) {
@@ -333,13 +326,9 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
         mxA = max(mxA, (uint32_t)__shfl_xor((int)mxA, off, 64));
         mxB = max(mxB, (uint32_t)__shfl_xor((int)mxB, off, 64));
     }
-#if GSR_BWD_DPP_FUSE
     // (the butterfly leaves the same maximum in every lane, which the compiler cannot know: as a scalar the batch counter, the list position of a step and
     // the loop tests move to the SALU)
     const uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)min(range.y - range.x, max(mxA, mxB)), 0);
-#else
-    const uint32_t end = min(range.y - range.x, max(mxA, mxB));
-#endif
     if (end == 0) return;
 
     BwdPix2 s = {T_final, {0.f, 0.f}};
@@ -425,8 +414,7 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
             const float msum = m.x + m.y, mdxsum = mdx.x + mdx.y;
             const float g_px = mdxsum, g_py = msum * dy, g_A = mdxx.x + mdxx.y, g_B = mdxsum * dy, g_C = (msum * dy) * dy;
             const float g_op = msum, g_r = gr2.x + gr2.y, g_g = gg2.x + gg2.y, g_b = gb2.x + gb2.y;      // g_op: the zeroth moment
-#if GSR_BWD_DPP_FUSE
-            // the three reductions stage by stage (same adds per chain as reduce4 / reduce2 / wave_sum_to_lane63 below): between two DPP adds of one chain
+            // the three reductions stage by stage (same adds per chain as reduce4 / reduce2 / wave_sum_to_lane63 above, which the measurement build's variants still call): between two DPP adds of one chain
             // stand the other two chains' adds -- the two wait states a DPP read of a fresh VALU result needs, filled with work instead of s_nop
             float v0 = fold16(fold32(g_px, g_A), fold32(g_py, g_B));     // -> slots 0,1,2,3
             float v1 = fold16(fold32(g_C, g_r), fold32(g_op, g_g));      // -> slots 4,5,6,7
@@ -442,17 +430,6 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
             v2 = dpp_add<0x142, 0xa>(v2);
             if (!HAS_DEPTH) v2 = dpp_add<0x143, 0xc>(v2);
             dpp_pin(v2);
-#else
-            const float v0 = reduce4(g_px, g_A, g_py, g_B);     // -> slots 0,1,2,3
-            const float v1 = reduce4(g_C, g_r, g_op, g_g);      // -> slots 4,5,6,7
-            float v2;
-            if (HAS_DEPTH) {
-                const v2f gd2 = w * dLd;
-                v2 = reduce2(g_b, gd2.x + gd2.y);               // -> slots 8 (lane 31), 9 (lane 63)
-            } else {
-                v2 = wave_sum_to_lane63(g_b);                   // -> slot 8 (lane 63); slot 9 stays 0
-            }
-#endif
             if ((lane & 15) == 15) {
                 float* o = s_grad + j * 12 + (lane >> 4);
                 o[0] = v0;

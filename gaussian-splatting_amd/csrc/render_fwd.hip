@@ -8,16 +8,16 @@
 //                        *Gaussian* lanes: each loads one list entry (coalesced index read + 48-byte record gather)
 //                        and tests it against the wave's 8x8 pixel box with an exact min-of-quadratic-over-a-box
 //                        test -- entries that cannot reach alpha >= 1/255 anywhere in the box are dropped.  A
-//                        64-bit ballot gives the survivor mask; the batch is parked in the wave's private 3 KB of
-//                        LDS; the wave then walks the set bits (s_ff1) and the lanes switch to *pixel* lanes, each
-//                        blending the survivor read back with wave-uniform ds_read_b128 (LDS broadcast) through a
+//                        64-bit ballot gives the survivor mask; the survivors are parked COMPACTED, in list order, in the
+//                        wave's private 3 KB of LDS; the lanes then switch to *pixel* lanes, each blending the survivors
+//                        read back one after the other with wave-uniform ds_read_b128 (LDS broadcast) through a
 //                        BRANCH-FREE body.  Dropping is exact: a dropped entry would have been skipped by every
 //                        pixel of the box anyway (alpha < 1/255), and skipped entries leave no trace in any output
 //                        (contributor numbering is by list position).
 //  variant 1  "block"    : one 256-thread workgroup per 16x16 tile, list staged through LDS 256 entries at a time,
 //                        every lane evaluates every entry, workgroup-wide "all done" vote.  The classic structure;
 //                        A/B baseline (measured 0.408 ms vs 0.151 ms for variant 0 on the 1 M / 1080p frame).
-//  variant 2  "wave/readlane": as variant 0 but the record is broadcast with v_readlane into SGPRs (0.291 ms).
+//  (variant 2, rounds 1-4: the record broadcast with v_readlane into SGPRs, 0.291 ms -- removed in round 5)
 //  variant 3  as variant 0 in 256-thread workgroups of four independent waves (0.165-0.173 ms).
 // The wave kernels are additionally templated on TRACK: the contributor index and final transmittance are produced
 // only when the caller will run the backward (inference launches drop two VALU instructions per entry).
@@ -59,19 +59,15 @@ __device__ __forceinline__ float min_q_over_box(float mx, float my, float A, flo
     return q;
 }
 
-__device__ __forceinline__ float bcast(float v, int srclane) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
-}
-
 
 // ------------------------------------------------------------------------------------------------
-// variants 0 / 2: wave per 8x8 pixel block with a BRANCH-FREE blend body.
+// variants 0 / 3: wave per 8x8 pixel block with a BRANCH-FREE blend body.
 // The blend loop issues VALU and SALU instructions at comparable rates, so exec-mask branches (s_and_saveexec /
 // s_cbranch / s_or per skip condition) cost as much as the arithmetic they skip.  Here every surviving entry is
 // evaluated by all 64 lanes with the three hard conditions folded into selects (weight 0 when skipped), the conic
 // is pre-scaled to log2 units by the Gaussian lanes (power -> one v_exp_f32, no multiply), and tau / 1/depth come
-// precomputed from the splat record.  Variant 0 stages the batch in the wave's private 3 KB of LDS and re-reads it
-// with wave-uniform ds_read_b128 (broadcast); variant 2 broadcasts the record with v_readlane (SGPR operands).
+// precomputed from the splat record.  The batch's survivors sit in the wave's private 3 KB of LDS and are re-read
+// with wave-uniform ds_read_b128 (broadcast).
 // ------------------------------------------------------------------------------------------------
 struct PixAcc {
     float T, C0, C1, C2, D;
@@ -80,22 +76,15 @@ struct PixAcc {
 
 // One (pixel, Gaussian) step of the wave kernels, branch-free.  Instead of a separate "done" flag the lane carries TWO
 // transmittances: s.T, the value the outputs need (frozen at termination, composites the background), and Tl, the LIVE
-// one that the recurrence uses and that is set to 0 when the pixel terminates (or lies outside the image).  With Tl = 0
-// every later entry sees test = 0 < 1e-4, is classified as the terminator again and contributes nothing -- so the
-// three conditions need no "not done yet" term, and termination costs one select instead of a flag update and a test.
-// Arithmetic on the contributing path is unchanged (w = alpha * T, T' = T - alpha * T): results are bit-identical.
+// one that the recurrence uses.  Tl simply follows every valid entry: a terminated lane keeps a value below GSR_T_EPS (it only
+// shrinks; a lane outside the image starts at 0), so every later valid entry is classified as the terminator again and
+// contributes nothing -- the three conditions need no "not done yet" term and termination costs no select at all ("live" is
+// Tl >= GSR_T_EPS in the wave's exit ballots).  Arithmetic on the contributing path: w = alpha * T, T' = T - alpha * T.
+// Round 5: replaces the form that zeroed Tl at termination (one select more per step); same bits in every output
+// (tests/test_simt_forward_cpu.py ran both forms lane by lane), blend 0.128 -> 0.122 ms together with the compacted walk
+// (profiles/r05_ab_candidates.json).
 // TRACK: the contributor index is only needed by the backward (n_contrib); inference builds drop it.
-#ifndef GSR_FWD_TL_DECAY
-#define GSR_FWD_TL_DECAY 0
-#endif
-#ifndef GSR_FWD_COMPACT
-#define GSR_FWD_COMPACT 0
-#endif
-#if GSR_FWD_TL_DECAY
 #define GSR_FWD_LIVE(Tl_) ((Tl_) >= GSR_T_EPS)
-#else
-#define GSR_FWD_LIVE(Tl_) ((Tl_) != 0.0f)
-#endif
 template <bool TRACK>
 __device__ __forceinline__ void blend_step_bf(PixAcc& s, float& Tl, float pxf, float pyf, float gx_, float gy_, float a2,
                                               float b2, float c2, float op, float r, float g, float b, float invd,
@@ -114,14 +103,7 @@ __device__ __forceinline__ void blend_step_bf(PixAcc& s, float& Tl, float pxf, f
     s.C2 = fmaf(b, w, s.C2);
     s.D = fmaf(invd, w, s.D);
     s.T = contrib ? testT : s.T;
-#if GSR_FWD_TL_DECAY
-    // Candidate (not yet measured on a GPU, off by default): the live transmittance simply follows every valid entry.  A terminated lane then keeps a
-    // value below GSR_T_EPS (it only shrinks), so every later valid entry is the terminator again and adds nothing -- the zeroing select goes
-    // (24 -> 23 VALU per step in the inference build); "live" becomes Tl >= GSR_T_EPS in the wave's exit ballots.  Outputs are the same bits.
     Tl = valid ? testT : Tl;
-#else
-    Tl = contrib ? testT : (term ? 0.0f : Tl);               // an invalid entry must leave a terminated lane at 0
-#endif
     if (TRACK) s.last = contrib ? pos : s.last;
 }
 
@@ -199,11 +181,14 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
             q0.w *= -LOG2E;
             q1.x *= -0.5f * LOG2E;
         }
-#if GSR_FWD_COMPACT
-        // Candidate (not yet measured on a GPU, off by default): the survivors are parked COMPACTED, in list order (slot = survivors on lower lanes), with
-        // their list position in the record's spare word.  The walk then reads consecutive records -- constant ds_read offsets from one base register inside
-        // the eight-deep unrolled body instead of s_ff1 / s_mul / v_mov per step, a counter instead of the 64-bit mask pop: 24 -> 22 VALU and 11 -> 4 SALU
-        // per step in the inference build.  Same survivors in the same order through the same blend_step_bf: outputs are the same bits.
+        // The survivors are parked COMPACTED, in list order (slot = survivors on lower lanes), with their list position in the record's spare
+        // word.  The walk reads consecutive records -- constant ds_read offsets from one base register inside the eight-deep unrolled body, a
+        // counter instead of popping a 64-bit mask (round 4's form: s_ff1 / s_mul / v_mov per step): 22 VALU and 4 SALU per step in the
+        // inference build (round 4: 24 and 11; tools/isa_audit.py forward_walk_step).
+        // All 64 pixels may terminate in the middle of a batch; the wave would then blend the batch's remaining survivors into
+        // nothing (half a batch per wave on average: ~15 % of the steps on the bench frame).  The walk is unrolled eight deep and the
+        // termination ballot is taken once per eight steps: measured (round 3) 0.139 ms without the check, 0.1295 with one per four steps,
+        // 0.127 per eight, 0.142 / 0.143 per twelve / sixteen (the unrolled body outgrows what the scheduler handles well).
         static_assert(USE_LDS, "the compacted walk reads the batch from LDS");
         const uint64_t mask = __ballot(keep);
         if (keep) {
@@ -245,52 +230,6 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
             rp += 3 * GSR_FWD_CHECK_EVERY;
             if (__ballot(GSR_FWD_LIVE(Tl)) == 0ull) break;
         }
-#else
-        if (USE_LDS) {
-            s_rec[lane * 3 + 0] = q0;
-            s_rec[lane * 3 + 1] = q1;
-            s_rec[lane * 3 + 2] = make_float4(colb, invd, 0.f, 0.f);
-        }
-        uint64_t mask = __ballot(keep);
-        ++nbatches;
-        if (tracing) { const unsigned long long t = wall_clock64(); t_prep += t - t_mark; t_mark = t; }
-        const uint32_t pos_base = base - range.x + 1;
-        // one surviving entry: pop the lowest set bit of `mask`, blend
-        auto one_step = [&]() {
-            ++nsteps;
-            const int j = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            if (USE_LDS) {
-                const float4 r0 = s_rec[j * 3 + 0];
-                const float4 r1 = s_rec[j * 3 + 1];
-                const float2 r2 = *reinterpret_cast<const float2*>(&s_rec[j * 3 + 2]);
-                blend_step_bf<TRACK>(s, Tl, pxf, pyf, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, pos_base + j);
-            } else {
-                const float gx_ = bcast(q0.x, j), gy_ = bcast(q0.y, j), a2 = bcast(q0.z, j), b2 = bcast(q0.w, j);
-                const float c2 = bcast(q1.x, j), op = bcast(q1.y, j), cr = bcast(q1.z, j), cg = bcast(q1.w, j);
-                const float cb = bcast(colb, j), id_ = bcast(invd, j);
-                blend_step_bf<TRACK>(s, Tl, pxf, pyf, gx_, gy_, a2, b2, c2, op, cr, cg, cb, id_, pos_base + j);
-            }
-        };
-        // All 64 pixels may terminate in the middle of a batch; the wave would then blend the batch's remaining survivors into
-        // nothing (half a batch per wave on average: ~15 % of the steps on the bench frame).  The walk is unrolled eight deep --
-        // the exits between the steps are the loop's own "mask empty" test -- and the termination ballot is taken once per
-        // eight steps: measured 0.139 ms without the check, 0.1295 with one per four steps, **0.127 per eight**, 0.142 / 0.143
-        // per twelve / sixteen (the unrolled body outgrows what the scheduler handles well).  As a counter test inside a
-        // one-step loop the check cost ten scalar instructions and two branches per step and lost more than it saved.
-#ifndef GSR_FWD_CHECK_EVERY
-#define GSR_FWD_CHECK_EVERY 8
-#endif
-        while (mask) {
-            one_step();
-#pragma unroll
-            for (int u = 1; u < GSR_FWD_CHECK_EVERY; ++u) {
-                if (!mask) break;
-                one_step();
-            }
-            if (__ballot(GSR_FWD_LIVE(Tl)) == 0ull) break;
-        }
-#endif  // GSR_FWD_COMPACT
         if (tracing) { const unsigned long long t = wall_clock64(); t_walk += t - t_mark; t_mark = t; }
         if (__ballot(GSR_FWD_LIVE(Tl)) == 0ull) break;
     }
@@ -322,7 +261,7 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
 
 int gsr_render_forward_variant_available(int variant) {
 #ifdef GSR_AB_VARIANTS
-    return variant >= 0 && variant <= 3;
+    return variant == 0 || variant == 1 || variant == 3;
 #else
     return variant == 0;
 #endif
@@ -351,7 +290,6 @@ void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const 
                            final_T, n_contrib, out_color, out_invdepth);
         return;
     }
-    if (variant == 2) { GSR_LAUNCH_BF(false, 1, groups * 32, 64); return; }
     if (variant == 3) { GSR_LAUNCH_BF(true, 4, n_band_tiles, 256); return; }
 #endif
     (void)variant;

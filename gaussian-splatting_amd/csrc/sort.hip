@@ -17,7 +17,7 @@
 // 64-bit match mask of a lane's digit comes from BITS ballots; rank = running per-wave digit count (LDS) +
 // popcount(mask & lanes_below); the lowest matching lane bumps the count.  No atomics, deterministic.
 #include "gsr_internal.h"
-#include "gsr_wave.h"      // (match_digit: the candidate form of the digit match, GSR_MATCH_BITOP3)
+#include "gsr_wave.h"      // (match_digit)
 
 namespace {
 
@@ -233,17 +233,7 @@ rs_scatter(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_i
         const int64_t idx = wave_base + r * 64 + lane;
         const bool valid = idx < n;
         const uint32_t d = (key[r] >> shift) & (NB - 1);
-#if GSR_MATCH_BITOP3      // (candidate form of the match, csrc/gsr_wave.h)
         const uint64_t mask = gsrw::match_digit(d, BITS, __ballot(valid));
-#else
-        uint64_t mask = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < BITS; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
-            mask &= bit ? bal : ~bal;
-        }
-#endif
         const uint32_t prior = wave_cnt[w][d];
         rank[r] = prior + (uint32_t)__popcll(mask & lt_mask);
         if (valid && (mask & lt_mask) == 0ull) wave_cnt[w][d] = prior + (uint32_t)__popcll(mask);

@@ -323,9 +323,6 @@ emit_scatter(uint32_t R, int gx, int lb, int hb, const uint2* __restrict__ block
     }
 }
 
-#ifdef GSR_AB_VARIANTS
-#include "ab/emit_scatter_segments.inc"      // level-1 scatter ranking row pieces instead of instances: measurement build only
-#endif  // GSR_AB_VARIANTS
 
 // level 2: workgroup B2 -> (bucket h, chunk c).  Returns false when B2 is past the last planned workgroup.
 // One memory round trip: thread t < nb1 fetches both table rows of bucket t and the (single) matching thread publishes the
@@ -553,11 +550,6 @@ void gsr_launch_fill_block_first(int P, const uint32_t* offsets, uint2* block_fi
     hipLaunchKernelGGL(fill_block_first, dim3((int)nb), dim3(WG_THREADS), 0, st, P, offsets, block_first, cap);
 }
 
-#ifdef GSR_AB_VARIANTS
-int g_emit_scatter_mode = 0;      // option emit_scatter_mode (measurement build): 0 = instance-wise ranking, 1 = row pieces (ab/emit_scatter_segments.inc)
-void gsr_set_emit_scatter_mode(int v) { g_emit_scatter_mode = v; }
-#endif
-
 void gsr_launch_tile_sort_level1(const GsrTileSortPlan& plan, int64_t R, int gx, const uint2* block_first,
                                  const uint32_t* offsets, const uint2* rect_sorted, const uint32_t* order, void* words,
                                  uint32_t* hist1, uint32_t* digit_total, uint32_t* bucket_base, uint32_t* blk2_start,
@@ -568,17 +560,6 @@ void gsr_launch_tile_sort_level1(const GsrTileSortPlan& plan, int64_t R, int gx,
     hipLaunchKernelGGL(emit_hist, dim3(nblk), dim3(WG_THREADS), 0, st, R32, gx, plan.lb, nb1, block_first, offsets, rect_sorted,
                        hist1, nblk);
     gsr_launch_rs_scan(hist1, nblk, nb1, digit_total, st);
-#ifdef GSR_AB_VARIANTS
-    if (g_emit_scatter_mode == 1) {
-        if (plan.word64)
-            hipLaunchKernelGGL(emit_scatter_seg<uint64_t>, dim3(nblk), dim3(WG_THREADS), 0, st, R32, gx, plan.lb, plan.hb, block_first,
-                               offsets, rect_sorted, order, hist1, digit_total, nblk, (uint64_t*)words, bucket_base, blk2_start, splats);
-        else
-            hipLaunchKernelGGL(emit_scatter_seg<uint32_t>, dim3(nblk), dim3(WG_THREADS), 0, st, R32, gx, plan.lb, plan.hb, block_first,
-                               offsets, rect_sorted, order, hist1, digit_total, nblk, (uint32_t*)words, bucket_base, blk2_start, splats);
-        return;
-    }
-#endif
     if (plan.word64)
         hipLaunchKernelGGL(emit_scatter<uint64_t>, dim3(nblk), dim3(WG_THREADS), 0, st, R32, gx, plan.lb, plan.hb, block_first,
                            offsets, rect_sorted, order, hist1, digit_total, nblk, (uint64_t*)words, bucket_base, blk2_start, splats);

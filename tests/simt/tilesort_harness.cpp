@@ -1,4 +1,4 @@
-// csrc/tilesort.hip (+ the measurement build's csrc/ab/emit_scatter_segments.inc) compiled for the HOST through the SIMT-on-CPU shim
+// csrc/tilesort.hip compiled for the HOST through the SIMT-on-CPU shim
 // (tests/simt/hip/hip_runtime.h) and driven through ITS OWN LAUNCHERS from Python (tests/test_simt_tilesort_cpu.py).  TEST INFRASTRUCTURE:
 // built with g++ into tests/_build/, never part of libgsr_hip.so.
 #include "hip/hip_runtime.h"
@@ -43,15 +43,12 @@ int simt_fill_block_first(int P, const uint32_t* offsets, uint2* block_first, ui
     return finish("fill_block_first");
 }
 
-// level 1 through gsr_launch_tile_sort_level1: emit_hist, the scan, the scatter; mode 0 = emit_scatter (shipped), 1 = emit_scatter_seg (row pieces,
-// measurement build).  hist1: [nb1 * nblk] (left holding the scanned table), digit_total: [nb1].
-int simt_level1(int mode, int word64, int64_t R, int gx, int lb, int hb, const uint2* block_first, const uint32_t* offsets, const uint2* rect_sorted,
+// level 1 through gsr_launch_tile_sort_level1: emit_hist, the scan, the scatter.  hist1: [nb1 * nblk] (left holding the scanned table), digit_total: [nb1].
+int simt_level1(int word64, int64_t R, int gx, int lb, int hb, const uint2* block_first, const uint32_t* offsets, const uint2* rect_sorted,
                 const uint32_t* order, void* words, uint32_t* hist1, uint32_t* digit_total, uint32_t* bucket_base, uint32_t* blk2_start, float* splats) {
     GsrTileSortPlan plan{true, lb, hb, word64 != 0};
-    gsr_set_emit_scatter_mode(mode);
     gsr_launch_tile_sort_level1(plan, R, gx, block_first, offsets, rect_sorted, order, words, hist1, digit_total, bucket_base, blk2_start,
                                 reinterpret_cast<float4*>(splats), nullptr);
-    gsr_set_emit_scatter_mode(0);
     return finish("level 1");
 }
 

@@ -26,14 +26,37 @@ def ds_shift(kmin, kmax):
     return s
 
 
-def bucket_depth_sort(keys, tiles):
-    """-> (order, inclusive tile scan in depth order, block_first dict, segment sizes)"""
+def robust_range(wg_min, wg_max, threads=256):
+    """ds_hist's robust key range from the per-workgroup (min, max) table of the key-producing kernel (None entries: the workgroup listed
+    nothing): thread t of 256 groups the workgroups t, t + 256, ...; the group's smallest maximum / largest minimum ignores an outlier unless
+    every workgroup of the group has one; the robust range is the widest of the groups' ranges.  Falls back to the true range."""
+    have = [(a, b) for a, b in zip(wg_min, wg_max) if a is not None]
+    if not have:
+        return 0xFFFFFFFF, 0
+    tmin, tmax = min(a for a, _ in have), max(b for _, b in have)
+    gmin, gmax = [], []
+    for t in range(threads):
+        grp = [(wg_min[i], wg_max[i]) for i in range(t, len(wg_min), threads) if wg_min[i] is not None]
+        if grp:
+            gmin.append(max(a for a, _ in grp))
+            gmax.append(min(b for _, b in grp))
+    kmin, kmax = min(gmin), max(gmax)
+    if kmax <= kmin or kmin < tmin or kmax > tmax:
+        return tmin, tmax
+    return kmin, kmax
+
+
+def bucket_depth_sort(keys, tiles, key_range=None):
+    """-> (order, inclusive tile scan in depth order, block_first dict, segment sizes).  key_range: the ROBUST (kmin, kmax) the buckets
+    span (robust_range); default: the true extremes."""
     P = len(keys)
     listed = keys != KEY_CULLED
     assert ((tiles > 0) == listed).all()
-    kmin, kmax = (int(keys[listed].min()), int(keys[listed].max())) if listed.any() else (0xFFFFFFFF, 0)
+    tmin, tmax = (int(keys[listed].min()), int(keys[listed].max())) if listed.any() else (0xFFFFFFFF, 0)
+    kmin, kmax = (tmin, tmax) if key_range is None else key_range
+    assert tmin <= kmin and kmax <= tmax
     sh = ds_shift(kmin, kmax)
-    d = np.where(listed, (keys.astype(np.int64) - kmin) >> sh, CULL_BUCKET)
+    d = np.where(listed, np.minimum((np.maximum(keys.astype(np.int64), kmin) - kmin) >> sh, NB - 2), CULL_BUCKET)
     assert d[listed].max(initial=0) <= NB - 2, "bucket 2047 is reserved for the tile-less Gaussians"
     cnt = np.bincount(d, minlength=NB)
     tsum = np.bincount(d, weights=tiles, minlength=NB).astype(np.int64)
@@ -68,7 +91,8 @@ def bucket_depth_sort(keys, tiles):
         covered = e
         sizes.append(e - b)
         ids = by_bucket[b:e]
-        base_key, span = kmin + (d0 << sh), (d1 - d0) << sh
+        base_key = tmin if d0 == 0 else kmin + (d0 << sh)
+        span = (tmax + 1 if d1 > NB - 2 else kmin + (d1 << sh)) - base_key
         rem = keys[ids].astype(np.int64) - base_key
         assert rem.min() >= 0 and rem.max() < max(span, 1), "rebased keys fit the segment's span"
         nbits = 0 if span <= 1 else int(span - 1).bit_length()
@@ -95,7 +119,7 @@ def keys_from_depths(z, culled):
     return k
 
 
-CASES = ["uniform", "ties", "crowd", "gap", "one_key", "all_culled", "single", "last_bucket_straddles_a_window"]
+CASES = ["uniform", "ties", "crowd", "gap", "one_key", "all_culled", "single", "last_bucket_straddles_a_window", "outliers"]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -113,10 +137,25 @@ def test_bucket_depth_sort_model_equals_a_stable_sort(case):
         z[:] = 4.0
     elif case == "last_bucket_straddles_a_window":
         z = np.concatenate([rng.uniform(2, 3, P - 2500), np.full(2500, 12.0)])      # the farthest bucket alone holds 2500 > 2048 elements
+    elif case == "outliers":      # a trained scene -- the bulk within a fraction of an octave, a handful of floaters 100x farther / nearer
+        z = rng.uniform(4.0, 4.2, P)
+        z[rng.integers(0, P, 12)] = rng.uniform(300, 3000, 12)
+        z[rng.integers(0, P, 5)] = rng.uniform(0.21, 0.3, 5)
     culled = rng.random(P) < (1.0 if case == "all_culled" else 0.12)
     keys = keys_from_depths(z, culled)
     tiles = np.where(culled, 0, rng.integers(1, 40, P)).astype(np.int64)
-    order, scan, block_first, sizes = bucket_depth_sort(keys, tiles)
+    key_range = None
+    if case == "outliers":
+        # the key-producing kernel's workgroups sample the array with a grid stride: workgroup w of 1024 holds the Gaussians w, w + 1024, ...
+        nwg = 1024
+        wmin = [int(keys[w::nwg][~culled[w::nwg]].min()) if (~culled[w::nwg]).any() else None for w in range(nwg)]
+        wmax = [int(keys[w::nwg][~culled[w::nwg]].max()) if (~culled[w::nwg]).any() else None for w in range(nwg)]
+        key_range = robust_range(wmin, wmax)
+        _, _, _, sizes_true = bucket_depth_sort(keys, tiles)
+        assert max(sizes_true) > CAP, "with the true extremes the outliers push the bulk into oversized segments"
+    order, scan, block_first, sizes = bucket_depth_sort(keys, tiles, key_range)
+    if case == "outliers":
+        assert max(sizes) <= CAP, "the robust range keeps every segment inside the LDS capacity"
     ref = np.argsort(keys, kind="stable")               # (depth key, index): what the LSD sort and the reference's sort leave
     assert (order == ref).all()
     assert (scan == np.cumsum(tiles[ref])).all()

@@ -217,61 +217,3 @@ def test_backward_in_extreme_segment_regimes(name):
         d = (a - b).abs() / (b.abs().max().item() + 1e-30)
         assert d.max().item() < 1e-4, f"{name}/{k}: max err {d.max().item():.3e} (rel. to max |grad|)"
         assert torch.quantile(d.flatten()[: 4_000_000], 0.999).item() < 1e-5, f"{name}/{k}: 99.9th percentile too large"
-
-
-@pytest.mark.parametrize("name", ["single_block", "tiny_splats", "huge_splats", "odd_frame", "tiles_65536", "huge_tiles_65536", "depth_ties"])
-def test_emit_scatter_by_segments_equals_the_instance_wise_scatter(name):
-    """MEASUREMENT BUILD ONLY (GSR_LIB = lib_ab, option emit_scatter_mode; skipped on the product library): the level-1 scatter that ranks row
-    pieces (csrc/ab/emit_scatter_segments.inc; algorithm pinned on the CPU by tests/test_emit_segments_numpy.py) must leave the same sorted
-    point list, tile ranges and first-emission indices (checked through the backward's gradients) as the instance-wise kernel -- against the oracle's
-    bins, in the regimes that select its paths: one block, > 1024 Gaussians per block and > 3072 pieces (the instance-wise path inside the
-    kernel), Gaussians that own dozens of blocks, rows cut at bucket boundaries (odd frame), 256 x 256 buckets."""
-    from diff_gaussian_rasterization import GaussianRasterizationSettings, _lib
-    from diff_gaussian_rasterization.debug import forward_with_views
-    try:
-        _lib.set_option("emit_scatter_mode", 1)
-    except _lib.GsrError:
-        pytest.skip("emit_scatter_mode is an A/B option of the measurement build (GSR_AB=1 python build.py, GSR_LIB=.../lib_ab/libgsr_hip.so)")
-    try:
-        P, W, H, s_med, seed = CASES[name]
-        dev = torch.device("cuda:0")
-        cam = make_camera(W, H)
-        sc = make_scene(P, cam, seed=seed, s_med=s_med)
-        _reshape_depths(name, sc, cam, seed)
-        s = oracle_settings(cam)
-        with torch.no_grad():
-            pre = O.preprocess(sc.means3D, sc.opacities, s, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
-            bins = O.bin_and_sort(pre)
-        d = sc.to(dev)
-        rs = GaussianRasterizationSettings(H, W, s.tanfovx, s.tanfovy, s.bg.to(dev), s.scale_modifier, s.viewmatrix.to(dev),
-                                           s.projmatrix.to(dev), s.sh_degree, s.campos.to(dev), False, False, s.antialiasing)
-        outs = {}
-        for mode in (1, 0):
-            _lib.set_option("emit_scatter_mode", mode)
-            for no_backward in (False, True):
-                out = forward_with_views(rs, d.means3D, d.opacities, shs=d.shs, scales=d.scales, rotations=d.rotations, no_backward=no_backward)
-                torch.cuda.synchronize()
-                assert out["R"] == int(bins["R"])
-                pl = out["point_list"].cpu().to(torch.int64)
-                if not torch.equal(pl, bins["point_list"]):
-                    bad = (pl != bins["point_list"]).nonzero().flatten()
-                    raise AssertionError(f"emit_scatter_mode={mode}: sorted point list differs at {bad.numel()} of {pl.numel()} positions, first {bad[:8].tolist()}")
-                assert torch.equal(out["ranges"].cpu().to(torch.int64), bins["ranges"]), f"emit_scatter_mode={mode}: tile ranges differ"
-                outs[(mode, no_backward)] = out["color"].cpu() if "color" in out else None
-        for nb in (False, True):
-            if outs[(1, nb)] is not None:
-                assert torch.equal(outs[(1, nb)], outs[(0, nb)]), "images differ between the two level-1 scatters"
-        # the first-emission indices the scatter leaves in the splat records address the backward's per-instance records: same gradients
-        from diff_gaussian_rasterization import rasterize_gaussians
-        wgt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(seed)).to(dev)
-        grads = {}
-        for mode in (1, 0):
-            _lib.set_option("emit_scatter_mode", mode)
-            req = [t.detach().clone().requires_grad_(True) for t in (d.means3D, d.shs, d.opacities, d.scales, d.rotations)]
-            col = rasterize_gaussians(req[0], None, req[1], None, req[2], req[3], req[4], None, rs, None)[0]
-            (col * wgt).sum().backward()
-            grads[mode] = [t.grad.cpu() for t in req]
-        for ga, gb in zip(grads[1], grads[0]):
-            assert torch.equal(ga, gb), "gradients differ between the two level-1 scatters"
-    finally:
-        _lib.set_option("emit_scatter_mode", 0)

@@ -35,12 +35,6 @@ def lib():
     return _build()
 
 
-@pytest.fixture(scope="module")
-def lib_bitop3():
-    """the chain with the candidate form of the ranking kernels' digit matching (csrc/gsr_wave.h, GSR_MATCH_BITOP3: v_bfe_i32 + v_bitop3_b32, off in the product)"""
-    return _build(("-DGSR_MATCH_BITOP3=1",), "_bitop3")
-
-
 def ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -142,10 +136,3 @@ def test_binning_chain_source_at_emission_block_boundaries(lib):
     # degenerate grids
     assert _run_rects(lib, np.array([1, 1, 1]), np.array([1, 1, 1]), np.zeros(3, dtype=np.int64), np.zeros(3, dtype=np.int64), 0x00400000 + np.array([9, 3, 3]), 1, 1) == 3
     assert _run_rects(lib, np.array([3, 2]), np.array([200, 7]), np.array([0, 1]), np.array([0, 50]), 0x00400000 + np.array([2, 1]), 3, 200) == 614
-
-
-@pytest.mark.parametrize("name", ["cloud", "depth_ties", "huge_splats"])
-def test_candidate_digit_matching_leaves_the_bins_alone(lib_bitop3, name):
-    """GSR_MATCH_BITOP3: every ranking kernel of the chain (ds_scatter, ds_segsort, emit_scatter, bucket_scatter) with the four-instruction form of the match --
-    sorted point list and tile ranges still equal the oracle's bit for bit (round 4: all seven scenes, the depth-sort and tile-sort suites too)."""
-    test_binning_chain_source_on_the_cpu_equals_the_oracle_bins(lib_bitop3, name)

@@ -44,12 +44,17 @@ def make_keys(rng, P, kind):
         k = np.where(rng.random(P) < 0.5, base + rng.integers(0, 4096, P), base + (1 << 25) + rng.integers(0, 1 << 12, P))
     elif kind == "one_key":
         k = np.full(P, base + 12345)
+    elif kind == "outliers":                  # the bulk in a narrow band, a handful of keys far below / above it
+        k = base + (1 << 24) + rng.integers(0, 1 << 16, P)
+        k[rng.integers(0, P, 9)] = base + (1 << 26) + rng.integers(0, 1 << 25, 9)
+        k[rng.integers(0, P, 4)] = rng.integers(1, 4096, 4)
     else:
         raise ValueError(kind)
     return k.astype(np.int64)
 
 
-@pytest.mark.parametrize("kind,P", [("uniform", 20_000), ("uniform", 4_097), ("uniform", 300), ("ties", 12_000), ("crowd", 16_000), ("gap", 9_000), ("one_key", 5_000)])
+@pytest.mark.parametrize("kind,P", [("uniform", 20_000), ("uniform", 4_097), ("uniform", 300), ("ties", 12_000), ("crowd", 16_000), ("gap", 9_000), ("one_key", 5_000),
+                                    ("outliers", 24_000)])
 def test_bucket_depth_sort_on_the_cpu_equals_a_stable_sort(lib, kind, P):
     rng = np.random.default_rng(1000 + P + len(kind))
     keys = make_keys(rng, P, kind)
@@ -62,9 +67,12 @@ def test_bucket_depth_sort_on_the_cpu_equals_a_stable_sort(lib, kind, P):
     tiles = (w * h).astype(np.int64)
     keys[tiles == 0] = CULLED
     listed = tiles > 0
-    n_range = 5
+    # the key-producing kernel's per-workgroup key ranges; "outliers": 1024 workgroups that sample the array with a grid stride (what the
+    # preprocess does), so that ds_hist's robust range has groups of four to work with
+    n_range = 1024 if kind == "outliers" else 5
     wg = np.zeros((n_range, 2), dtype=np.uint32)
-    for c, idx in enumerate(np.array_split(np.arange(P), n_range)):
+    parts = [np.arange(c, P, n_range) for c in range(n_range)] if kind == "outliers" else np.array_split(np.arange(P), n_range)
+    for c, idx in enumerate(parts):
         kk = keys[idx][listed[idx]]
         if kk.size:
             wg[c] = ((~np.uint32(kk.min())) & np.uint32(0xFFFFFFFF), kk.max())
@@ -88,7 +96,16 @@ def test_bucket_depth_sort_on_the_cpu_equals_a_stable_sort(lib, kind, P):
     assert np.array_equal(rect_sorted[:V], rect[ref][:V]), "gathered rectangles differ"          # (the tile-less tail's rectangles are never read)
     incl = np.cumsum(tiles[ref])
     assert np.array_equal(offsets.astype(np.int64), incl), "inclusive scan of the tile counts differs"
-    assert int(frame[2]) == int(keys[listed].min()) and int(frame[3]) == int(keys[listed].max()), "key range of the frame"
+    assert int(frame[6]) == int(keys[listed].min()) and int(frame[7]) == int(keys[listed].max()), "true key range of the frame"
+    if kind == "outliers":
+        from test_depthsort_model_cpu import robust_range
+        wmin = [None if not (a or b) else int(~a & 0xFFFFFFFF) for a, b in wg.tolist()]
+        wmax = [None if not (a or b) else int(b) for a, b in wg.tolist()]
+        assert (int(frame[2]), int(frame[3])) == robust_range(wmin, wmax), "robust key range"
+        assert int(frame[2]) > int(frame[6]) and int(frame[3]) < int(frame[7]) and int(frame[3]) - int(frame[2]) < (1 << 17)
+        assert int(slow[0]) == 0, "with the robust range no segment may overflow the LDS capacity"
+    else:
+        assert (int(frame[2]), int(frame[3])) == (int(frame[6]), int(frame[7])), "five workgroups: nothing to be robust about"
     for b in range(nblk):                                             # the Gaussian that holds the first instance of every emission block
         j = int(np.searchsorted(incl, b * TS_ITEMS, side="right"))
         assert tuple(int(v) for v in block_first[b]) == (j, int(incl[j] - tiles[ref][j])), (b, block_first[b].tolist(), j)

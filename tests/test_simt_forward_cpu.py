@@ -238,46 +238,3 @@ def test_separate_sh_call_form_of_the_kernel_source_equals_the_fused_form(lib):
         assert np.array_equal(gf[k], gs[k]), k
     assert np.array_equal(gf["shs"][:, :1], ddc) and np.array_equal(gf["shs"][:, 1:], gs["shs"])
     assert np.abs(gf["shs"]).max() > 0
-
-
-# ---- candidate forms of the forward blend (macros of csrc/render_fwd.hip, off in the product; not yet measured on a GPU) ----
-@pytest.mark.parametrize("defines,tag", [(("-DGSR_FWD_TL_DECAY=1", "-DGSR_FWD_COMPACT=1"), "_tl_compact")])
-def test_candidate_forms_of_the_forward_blend_change_no_bit(lib, defines, tag):
-    """GSR_FWD_TL_DECAY (the live transmittance follows every valid entry; no zeroing select) and GSR_FWD_COMPACT (survivors parked compacted, walked with
-    constant LDS offsets and a counter) reorganise the walk only: image, inverse depth, final_T and n_contrib of both builds of the blend must be the bits
-    of the shipped form on every scene of the parity suite -- the same source, lane by lane."""
-    from simt_build import build
-    cand = build("forward", fp_contract_off=True, defines=defines, tag=tag)
-    cand.simt_fwd_last_error.restype = C.c_char_p
-    cand.simt_forward.restype = C.c_int64
-    for name in ["c1", "deg0_dense"]:
-        cam, sc, opts = G.mk(name)
-        s = G.run_oracle(cam, sc, opts)[0]      # (the settings record of the scene)
-        for track in (True, False):
-            a, b = run_simt(lib, s, sc, track), run_simt(cand, s, sc, track)
-            assert a["R"] == b["R"] and a["R"] > 0
-            for k in a:
-                if k != "R":
-                    assert torch.equal(a[k], b[k]), f"{name} / track={track}: {k} differs from the shipped form"
-
-
-def test_candidate_form_of_the_backward_walks_reductions_changes_no_bit(lib):
-    """GSR_BWD_DPP_FUSE (csrc/render_bwd.hip: the walk's three cross-lane reductions stage by stage, DPP moves with the full row mask and bound_ctrl so that
-    every one fuses into its add) must leave every gradient the bits of the shipped form -- both builds of the walk (with / without a gradient on the
-    inverse-depth image), the kernel source lane by lane."""
-    import copy
-    from helpers import oracle_settings
-    from simt_build import build
-    cand = build("forward", fp_contract_off=True, defines=("-DGSR_BWD_DPP_FUSE=1",), tag="_dppfuse")
-    cand.simt_fwd_last_error.restype = C.c_char_p
-    cand.simt_forward.restype = C.c_int64
-    cam, sc, opts = G.mk("c1")
-    s = oracle_settings(cam, bg=opts.get("bg"), sh_degree=opts.get("sh_degree", 3), scale_modifier=opts.get("scale_modifier", 1.0), antialiasing=opts.get("antialiasing", False))
-    H, W = cam.image_height, cam.image_width
-    wc, wd = G._loss_weights(H, W, 0)
-    for use_depth in (False, True):
-        ra, ga = run_simt_backward(lib, s, sc, H, W, wc, wd, use_depth)
-        rb, gb = run_simt_backward(cand, s, sc, H, W, wc, wd, use_depth)
-        assert np.array_equal(ra, rb)
-        for k in ga:
-            assert np.abs(ga[k]).max() > 0 and np.array_equal(ga[k], gb[k]), f"use_depth={use_depth}: d{k} differs from the shipped form"

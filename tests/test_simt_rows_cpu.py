@@ -29,18 +29,9 @@ def lib():
     return h
 
 
-@pytest.fixture(scope="module")
-def lib_bitop3():
-    """the same harness over the candidate form of rs_scatter's digit matching (csrc/gsr_wave.h match_digit, GSR_MATCH_BITOP3: off in the product)"""
-    from simt_build import build
-    h = build("rows", fp_contract_off=True, defines=("-DGSR_MATCH_BITOP3=1",), tag="_bitop3")
-    h.simt_rows_last_error.restype = C.c_char_p
-    return h
-
-
-@pytest.fixture(params=["shipped", "bitop3"])
-def sort_lib(request):
-    return request.getfixturevalue("lib" if request.param == "shipped" else "lib_bitop3")
+@pytest.fixture
+def sort_lib(lib):
+    return lib
 
 
 def ptr(a):
