@@ -42,6 +42,10 @@ int g_bwd_heavy_first = 2;      // launch order of the blend backward (plan kern
                                 // 3 = every half tile (= wave) on its own, heaviest first (0.325; slower than 2 on the clustered scene: the two halves of
                                 // a tile no longer share their gathered records in one XCD's L2)
 int g_tile_sort_mode = 0;       // 0 = fused emission + two-level sort (tilesort.hip), 1 = legacy emit + LSD passes (A/B)
+#ifdef GSR_AB_VARIANTS
+int g_fwd_bands = 1;            // MEASUREMENT BUILD ONLY (measured and rejected, profiles/r05_ab_fwd_bands_occupancy.json): bands of level-1 buckets (= runs of
+                                // tile rows) whose level-2 sort + blend are issued band by band on two HIP streams (bin_and_render)
+#endif
 
 struct PendingEvent { int stage; hipEvent_t a, b; };
 std::mutex g_prof_mu;
@@ -153,17 +157,28 @@ int check_split_sh(const GsrRasterSettings* s, int P, int M, const float* shs, b
 }
 
 // R read-back word: mapped + portable + coherent pinned host memory: [0] = R low word, [1] = sequence number, [2] = R high word,
-// [3] = "a depth key needed more than 27 bits", [5] = "the bucket depth sort met an oversized segment" (read at the NEXT lease).
+// [3] = "a depth key needed more than 27 bits".  ("The bucket depth sort met an oversized segment" is NOT part of the leased slot
+// (the segment sort may still be running when the slot goes back to the pool): it is a per-device mapped word, g_slow_word.)
 // Written by the last workgroup of the key-producing kernel (gsr_frame.h), which folds the frame's statistics in `state`, a
 // 64-byte block of device memory that is zero between frames.  Words are LEASED per call from a per-device pool (ADVICE r02:
 // keyed by device, not by thread -- a host thread that comes and goes leaks nothing, concurrent callers never share a word);
 // never freed (the runtime releases them with the context).
-struct HostWord { uint32_t* host = nullptr; uint32_t* dev = nullptr; uint32_t* state = nullptr; uint32_t seq = 0; };
+constexpr int GSR_MAX_FWD_BANDS = 4;
+struct HostWord {
+    uint32_t* host = nullptr; uint32_t* dev = nullptr; uint32_t* state = nullptr; uint32_t seq = 0;
+    // band-pipelined forward only (created on first use, they stay with the slot): the second stream and the events that order the bands
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_l2[GSR_MAX_FWD_BANDS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_done = nullptr;
+};
 std::mutex g_hw_mu;
 std::vector<HostWord> g_hw_pool[GSR_MAX_DEVICES];
 std::atomic<int64_t> g_last_R[GSR_MAX_DEVICES];      // per device: sizes the speculative binning buffer of the next frame
 std::atomic<int> g_lsd_frames[GSR_MAX_DEVICES];      // per device: frames for which the automatic depth sort stays with the LSD passes
 std::atomic<int> g_lsd_backoff[GSR_MAX_DEVICES];     // per device: length of the next such stay (doubles per failed retry; heuristic only)
+uint32_t* g_slow_word[GSR_MAX_DEVICES] = {nullptr};  // per device, mapped host memory: set (1) by ds_segsort when a segment overflowed the LDS capacity;
+                                                     // read and cleared by the next lease on that device.  A heuristic flag: a store that races the
+                                                     // clear is at worst seen one frame later or lost once, never attributed to another device
 struct HostWordLease {
     int dev = -1;
     HostWord hw;
@@ -172,8 +187,8 @@ struct HostWordLease {
     ~HostWordLease() {
         if (dev < 0) return;
         if (!settled) {      // error paths only: never hand a word with a pending writer (or a half-filled state block) to the next call
+            (void)hipMemsetAsync(hw.state, 0, 64, st);      // the ticket counter of gsr_frame.h (behind whatever kernel may still add to it)
             (void)hipStreamSynchronize(st);
-            (void)hipMemset(hw.state, 0, 64);      // the ticket counter of gsr_frame.h
         }
         std::lock_guard<std::mutex> l(g_hw_mu);
         g_hw_pool[dev].push_back(hw);
@@ -187,16 +202,33 @@ int lease_host_word(HostWordLease& lease, hipStream_t st) {
         std::lock_guard<std::mutex> l(g_hw_mu);
         if (!g_hw_pool[dev_id].empty()) { lease.hw = g_hw_pool[dev_id].back(); g_hw_pool[dev_id].pop_back(); }
     }
-    if (!lease.hw.host) {
-        HIP_OK(hipHostMalloc((void**)&lease.hw.host, 64, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent));
-        HIP_OK(hipHostGetDevicePointer((void**)&lease.hw.dev, lease.hw.host, 0));
-        for (int i = 0; i < 16; ++i) lease.hw.host[i] = 0;
-        HIP_OK(hipMalloc((void**)&lease.hw.state, 64));
-        HIP_OK(hipMemset(lease.hw.state, 0, 64));
+    if (!lease.hw.host) {      // a new slot (first call on this device, or one more concurrent caller): 64 B mapped host + 64 B device, kept for good
+        HostWord nw;
+        hipError_t e = hipHostMalloc((void**)&nw.host, 64, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent);
+        if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&nw.dev, nw.host, 0);
+        if (e == hipSuccess) e = hipMalloc((void**)&nw.state, 64);
+        if (e == hipSuccess) e = hipMemset(nw.state, 0, 64);
+        if (e != hipSuccess) {      // (nothing half-made is leaked or pooled)
+            if (nw.state) (void)hipFree(nw.state);
+            if (nw.host) (void)hipHostFree(nw.host);
+            return fail(GSR_ERR_HIP, std::string("control block allocation: ") + hipGetErrorString(e));
+        }
+        for (int i = 0; i < 16; ++i) nw.host[i] = 0;
+        lease.hw = nw;
+    }
+    {
+        std::lock_guard<std::mutex> l(g_hw_mu);
+        if (!g_slow_word[dev_id]) {
+            uint32_t* w = nullptr;
+            HIP_OK(hipHostMalloc((void**)&w, 64, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent));
+            for (int i = 0; i < 16; ++i) w[i] = 0;
+            g_slow_word[dev_id] = w;
+        }
     }
     lease.hw.host[3] = 0;
-    if (lease.hw.host[5]) {      // the previous frame on this word: thousands of Gaussians in one depth bucket -- its segment went
-        lease.hw.host[5] = 0;    // through global memory.  Stay with the LSD passes for a while, then try again: 64 frames the first
+    volatile uint32_t* slow = g_slow_word[dev_id];
+    if (slow[0]) {               // a recent frame on this device: thousands of Gaussians in one depth bucket -- its segment went
+        slow[0] = 0;             // through global memory.  Stay with the LSD passes for a while, then try again: 64 frames the first
         int back = g_lsd_backoff[dev_id].load();      // time, twice as long after every retry that met an oversized segment again
         if (back < 64) back = 64;                     // (a scene that always crowds a bucket pays one slow frame in 65, 129, ... 8193)
         g_lsd_frames[dev_id].store(back);
@@ -205,6 +237,11 @@ int lease_host_word(HostWordLease& lease, hipStream_t st) {
     lease.dev = dev_id;
     lease.st = st;
     return GSR_OK;
+}
+uint32_t* slow_word_dev(int dev_id) {      // device-side address of the device's "oversized segment" flag (mapped host memory)
+    uint32_t* d = nullptr;
+    if (!g_slow_word[dev_id] || hipHostGetDevicePointer((void**)&d, g_slow_word[dev_id], 0) != hipSuccess) return nullptr;
+    return d;
 }
 unsigned long long* counters_for_current_device() {
     int d = 0;
@@ -382,6 +419,18 @@ int gsr_set_option(const char* name, int value) {
         gsr_set_level2_scan_mode(value);
         return GSR_OK;
     }
+#ifdef GSR_AB_VARIANTS
+    if (!strcmp(name, "render_fwd_lds_pad")) {
+        if (value < 0 || value > 60000) return fail(GSR_ERR_INVALID_ARG, "render_fwd_lds_pad must be 0..60000 bytes");
+        gsr_set_render_fwd_lds_pad(value);
+        return GSR_OK;
+    }
+    if (!strcmp(name, "fwd_bands")) {
+        if (value < 1 || value > GSR_MAX_FWD_BANDS) return fail(GSR_ERR_INVALID_ARG, "fwd_bands must be 1..4");
+        g_fwd_bands = value;
+        return GSR_OK;
+    }
+#endif
     if (!strcmp(name, "tile_sort_mode")) {
         if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "tile_sort_mode must be 0 (fused) or 1 (legacy LSD)");
         g_tile_sort_mode = value;
@@ -511,10 +560,11 @@ static int wait_for_R(HostWord& hw, uint32_t seq, hipStream_t st, const uint32_t
     if (!got) {
         HIP_OK(hipStreamSynchronize(st));
         if (w[1] != seq) {
-            uint32_t r2[2] = {0, 0};
-            HIP_OK(hipMemcpy(r2, num_rendered_dev, sizeof(r2), hipMemcpyDeviceToHost));
-            hw.host[0] = r2[0];
-            hw.host[2] = r2[1];
+            uint32_t r9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // frame words: [0..1] R, [8] "a depth key overflowed" (gsr_frame.h)
+            HIP_OK(hipMemcpy(r9, num_rendered_dev, sizeof(r9), hipMemcpyDeviceToHost));
+            hw.host[0] = r9[0];
+            hw.host[2] = r9[1];
+            hw.host[3] = r9[8] ? 1u : 0u;      // (the fallback recovers the key-overflow flag too, not only R)
         }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -564,7 +614,7 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     {   StageTimer t(GSR_STAGE_DEPTH_SORT, st);
         if (bucket) {
             gsr_launch_depth_bucket_sort(P, g.keys[0], g.tiles, g.rect, g.num_rendered, g.wg_range, n_range, g.ds, g.vals[order_buf], g.rect_sorted, g.offsets,
-                                         g.block_first, bf_cap, hw_slot.dev + 5, st);
+                                         g.block_first, bf_cap, slow_word_dev(dev_id), st);
         } else {
             const int ob = gsr_radix_sort_pairs(g.keys, g.vals, P, GSR_DEPTH_KEY_BITS, GSR_DEPTH_DIGIT_BITS, g.sort_hist, g.digit_total,
                                                 sort_items(P), st, g.rect, g.rect_sorted);
@@ -635,6 +685,46 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
                                         b.sort_hist, b.digit_total, b.bucket_base, b.blk2_start, goffset_splats, st);
         }
         STAGE_CHECK("emit + level-1 sort");
+#ifdef GSR_AB_VARIANTS
+        // ---- band-pipelined level 2 + blend -- MEASURED AND REJECTED (profiles/r05_ab_fwd_bands_occupancy.json: 0.362 ms per frame
+        // in one launch, 0.388 / 0.393 / 0.422 with 2 / 3 / 4 bands: every cross-stream dependency costs more than the level-2 work it hides, every extra
+        // blend launch has its own ramp and drain); kept in the measurement build with its bit-identity tests.  Level-1 buckets are runs of 2^lb consecutive tiles, and the level-2 sort and the
+        // blend of different buckets are independent.  The blend's launch loses a quarter of its span to its drain, and the level-2 kernels
+        // are latency / VALU bound with most CUs idle: with B bands, band k's level-2 sort + blend go to stream k & 1, every level-2 sort waits for the
+        // previous band's (so it runs UNDER the previous band's blend, not beside its sort), the blends overlap each other's tails, and the second
+        // stream is joined back into the caller's before the call returns.  Same kernels on the same data: every output is the same bits.
+        // Not while stages are timed or waves traced (those passes measure the kernels one after the other), nor in debug mode.
+        int nbands = (g_prof_on || g_count_on || settings->debug || g_render_fwd_variant != 0) ? 1 : g_fwd_bands;
+        const int T0 = cam.tile_y0 * cam.gx, T1 = cam.tile_y1 * cam.gx;      // the tiles this call renders
+        const int nb1 = 1 << plan.hb;
+        const int hb0 = T1 > T0 ? (T0 >> plan.lb) : 0, hb1 = T1 > T0 ? (((T1 - 1) >> plan.lb) + 1) : 0;
+        if (hb1 - hb0 < 2 * nbands) nbands = 1;
+        if (nbands > 1) {
+            if (!hw_slot.aux) {
+                HIP_OK(hipStreamCreateWithFlags(&hw_slot.aux, hipStreamNonBlocking));
+                for (int k = 0; k < GSR_MAX_FWD_BANDS; ++k) HIP_OK(hipEventCreateWithFlags(&hw_slot.ev_l2[k], hipEventDisableTiming));
+                HIP_OK(hipEventCreateWithFlags(&hw_slot.ev_done, hipEventDisableTiming));
+            }
+            for (int k = 0; k < nbands; ++k) {
+                hipStream_t sk = (k & 1) ? hw_slot.aux : st;
+                // buckets [h0, h1) of band k; the first / last band also take the buckets in front of / behind the rendered tiles (their ranges are written)
+                const int h0 = k == 0 ? 0 : hb0 + (int)(((int64_t)(hb1 - hb0) * k) / nbands);
+                const int h1 = k == nbands - 1 ? nb1 : hb0 + (int)(((int64_t)(hb1 - hb0) * (k + 1)) / nbands);
+                if (k > 0) HIP_OK(hipStreamWaitEvent(sk, hw_slot.ev_l2[k - 1], 0));      // (through it: level 1, and everything earlier on `st`)
+                gsr_launch_tile_sort_level2(plan, R, n_tiles, b.keys[0], b.vals[0], b.bucket_base, b.blk2_start, b.hist2, b.tile_base, im.ranges, sk, h0, h1);
+                if (k + 1 < nbands) HIP_OK(hipEventRecord(hw_slot.ev_l2[k], sk));
+                const int t0 = k == 0 ? T0 : (h0 << plan.lb) > T0 ? (h0 << plan.lb) : T0;
+                const int t1 = k == nbands - 1 ? T1 : (h1 << plan.lb) < T1 ? (h1 << plan.lb) : T1;
+                gsr_launch_render_forward(cam, im.ranges, b.vals[0], g.splats, settings->no_backward ? nullptr : im.final_T,
+                                          settings->no_backward ? nullptr : im.n_contrib, settings->no_backward ? nullptr : im.block_steps,
+                                          out_color, out_invdepth, 0, nullptr, sk, t0 - T0, t1 - t0);
+            }
+            HIP_OK(hipEventRecord(hw_slot.ev_done, hw_slot.aux));
+            HIP_OK(hipStreamWaitEvent(st, hw_slot.ev_done, 0));
+            HIP_OK(hipGetLastError());
+            return GSR_OK;
+        }
+#endif  // GSR_AB_VARIANTS
         {   StageTimer t(GSR_STAGE_TILE_SORT, st);
             gsr_launch_tile_sort_level2(plan, R, n_tiles, b.keys[0], b.vals[0], b.bucket_base, b.blk2_start, b.hist2, b.tile_base,
                                         im.ranges, st);

@@ -23,7 +23,7 @@
 // 2^31: any total >= 2^31 is refused by the host anyway), [42, 53) workgroups with a key overflow, [53, 64) tickets
 // -> the key-producing kernels run at most GSR_FRAME_MAX_GROUPS workgroups
 // frame words (geometry buffer, GsrGeom::num_rendered): [0] R low, [1] R high; written by ds_hist: [2] kmin, [3] kmax of the ROBUST key
-// range the depth buckets span, [6] / [7] the true extremes (depthsort.hip)
+// range the depth buckets span, [6] / [7] the true extremes (depthsort.hip); [8] "a depth key needed more than 27 bits" (a copy of host word [3])
 // host word (mapped): [0] R low, [1] sequence number, [2] R high, [3] "a depth key needed more than 27 bits"
 #define GSR_FRAME_MAX_GROUPS 2047
 struct GsrFrameStatsDev {
@@ -65,6 +65,7 @@ __device__ __forceinline__ void gsr_frame_stats_commit(const GsrFrameStatsDev& f
     const uint32_t n_ovf = (uint32_t)(tot >> 42) & 0x7FFu;
     fs.frame[0] = (uint32_t)R;
     fs.frame[1] = (uint32_t)(R >> 32);
+    fs.frame[8] = n_ovf ? 1u : 0u;      // (read by the host only when the mapped word did not arrive: gsr_api.cpp wait_for_R)
     __hip_atomic_store(ctr, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (read next by a later kernel)
     if (fs.host_word) {      // value first, then the sequence number (system-scope release)
         __hip_atomic_store(fs.host_word + 0, (uint32_t)R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

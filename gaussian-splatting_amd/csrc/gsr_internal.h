@@ -200,10 +200,8 @@ void gsr_launch_tile_sort_level1(const GsrTileSortPlan& plan, int64_t R, int gx,
                                  float4* splats /*NULL: inference*/, hipStream_t st);
 void gsr_launch_tile_sort_level2(const GsrTileSortPlan& plan, int64_t R, int n_tiles, const void* words, uint32_t* point_list,
                                  const uint32_t* bucket_base, const uint32_t* blk2_start, uint32_t* hist2, uint32_t* tile_base,
-                                 uint2* ranges, hipStream_t st);
+                                 uint2* ranges, hipStream_t st, int h0 = 0, int h1 = 0 /*level-1 buckets [h0, h1) of a band; (0, 0) = all*/);
 void gsr_set_level2_scan_mode(int v);      // tilesort.hip (option level2_scan_mode)
-#ifdef GSR_AB_VARIANTS
-#endif
 // sort.hip: in-place exclusive scan of every digit row of a [ndigits][nblocks] block-histogram table + row totals
 void gsr_launch_rs_scan(uint32_t* block_hist, int nblocks, int ndigits, uint32_t* digit_total, hipStream_t st);
 void gsr_launch_ranges(int64_t R, int n_tiles, const void* sorted_keys, bool key16, uint2* ranges, bool already_zeroed,
@@ -241,7 +239,9 @@ __device__ __forceinline__ void gsr_trace_wave(unsigned long long* counters, uns
 void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,
                                const float4* splats, float* final_T, uint32_t* n_contrib, uint32_t* block_steps /*NULL unless tracking*/,
                                float* out_color, float* out_invdepth, int variant,
-                               unsigned long long* counters /*NULL or [4] work counters*/, hipStream_t st);
+                               unsigned long long* counters /*NULL or [4] work counters*/, hipStream_t st,
+                               int tile_off = 0, int tile_cnt = -1 /*the launch blends tiles [tile_off, tile_off + tile_cnt) of the band (multiple of 8; -1 = all)*/);
+void gsr_set_render_fwd_lds_pad(int bytes);      // render_fwd.hip (tuning option render_fwd_lds_pad)
 // variant: 0 = default (independent quadrant waves); 1 (global atomics) and 4 (round 1's workgroup-per-tile kernel) exist
 // only in builds with -DGSR_AB_VARIANTS
 int gsr_render_backward_variant_available(int variant);

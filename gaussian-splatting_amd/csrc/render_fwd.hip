@@ -112,7 +112,7 @@ __device__ __forceinline__ void blend_step_bf(PixAcc& s, float& Tl, float pxf, f
 // which lifts the resident-wave count when the per-CU workgroup limit, not registers/LDS, caps occupancy.
 template <bool USE_LDS, int WPB, bool TRACK>
 __global__ void __launch_bounds__(64 * WPB)
-render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ranges,
+render_fwd_wave_bf(GsrCamDev cam, int tile_off, int n_band_tiles /*tiles [tile_off, n_band_tiles) of the band*/, const uint2* __restrict__ ranges,
                    const uint32_t* __restrict__ point_list, const float4* __restrict__ splats,
                    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ block_steps,
                    float* __restrict__ out_color, float* __restrict__ out_invdepth,
@@ -125,10 +125,10 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
         // list, so they get ids b, b+8, b+16, b+24 -> same XCD -> same L2.
         const int b = blockIdx.x;
         const int grp = b >> 5, r32 = b & 31;
-        tile_local = grp * 8 + (r32 & 7);
+        tile_local = tile_off + grp * 8 + (r32 & 7);
         quad = r32 >> 3;
     } else {
-        tile_local = blockIdx.x;
+        tile_local = tile_off + blockIdx.x;
         quad = threadIdx.x >> 6;
     }
     if (tile_local >= n_band_tiles) return;
@@ -259,6 +259,16 @@ render_fwd_wave_bf(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ ra
 
 }  // namespace
 
+// measurement build's option render_fwd_lds_pad: bytes of dynamic LDS added to every workgroup of the wave kernels -- caps the resident waves per CU
+// (3 KB static per wave: 8 per SIMD fit; 10 KB -> 4 per SIMD).  Measured (profiles/r05_ab_fwd_bands_occupancy.json): blend 0.122 ms at 8 waves per SIMD,
+// 0.133 / 0.149 / 0.183 at fewer -- shorter-lived waves do not shrink the launch's drain.
+#ifdef GSR_AB_VARIANTS
+int g_render_fwd_lds_pad = 0;
+void gsr_set_render_fwd_lds_pad(int bytes) { g_render_fwd_lds_pad = bytes < 0 ? 0 : bytes; }
+#else
+constexpr int g_render_fwd_lds_pad = 0;
+#endif
+
 int gsr_render_forward_variant_available(int variant) {
 #ifdef GSR_AB_VARIANTS
     return variant == 0 || variant == 1 || variant == 3;
@@ -269,18 +279,22 @@ int gsr_render_forward_variant_available(int variant) {
 
 void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const uint32_t* point_list,
                                const float4* splats, float* final_T, uint32_t* n_contrib, uint32_t* block_steps,
-                               float* out_color, float* out_invdepth, int variant, unsigned long long* counters, hipStream_t st) {
-    const int n_band_tiles = cam.gx * (cam.tile_y1 - cam.tile_y0);
-    if (n_band_tiles <= 0) return;
-    const int groups = (n_band_tiles + 7) / 8;
+                               float* out_color, float* out_invdepth, int variant, unsigned long long* counters, hipStream_t st,
+                               int tile_off, int tile_cnt) {
+    int n_band_tiles = cam.gx * (cam.tile_y1 - cam.tile_y0);
+    if (tile_off < 0 || tile_cnt < 0) { tile_off = 0; tile_cnt = n_band_tiles; }      // the whole band in one launch
+    if (tile_off + tile_cnt < n_band_tiles) n_band_tiles = tile_off + tile_cnt;
+    const int n_launch = n_band_tiles - tile_off;
+    if (n_launch <= 0) return;
+    const int groups = (n_launch + 7) / 8;
     const bool track = final_T != nullptr && n_contrib != nullptr && block_steps != nullptr;
 #define GSR_LAUNCH_BF(USE_LDS_, WPB_, GRID_, BLOCK_)                                                                              \
     do {                                                                                                                          \
         if (track)                                                                                                                \
-            hipLaunchKernelGGL((render_fwd_wave_bf<USE_LDS_, WPB_, true>), dim3(GRID_), dim3(BLOCK_), 0, st, cam, n_band_tiles,    \
+            hipLaunchKernelGGL((render_fwd_wave_bf<USE_LDS_, WPB_, true>), dim3(GRID_), dim3(BLOCK_), g_render_fwd_lds_pad, st, cam, tile_off, n_band_tiles,    \
                                ranges, point_list, splats, final_T, n_contrib, block_steps, out_color, out_invdepth, counters);  \
         else                                                                                                                      \
-            hipLaunchKernelGGL((render_fwd_wave_bf<USE_LDS_, WPB_, false>), dim3(GRID_), dim3(BLOCK_), 0, st, cam, n_band_tiles,   \
+            hipLaunchKernelGGL((render_fwd_wave_bf<USE_LDS_, WPB_, false>), dim3(GRID_), dim3(BLOCK_), g_render_fwd_lds_pad, st, cam, tile_off, n_band_tiles,   \
                                ranges, point_list, splats, final_T, n_contrib, block_steps, out_color, out_invdepth, counters);  \
     } while (0)
 #ifdef GSR_AB_VARIANTS
@@ -290,7 +304,7 @@ void gsr_launch_render_forward(const GsrCamDev& cam, const uint2* ranges, const 
                            final_T, n_contrib, out_color, out_invdepth);
         return;
     }
-    if (variant == 3) { GSR_LAUNCH_BF(true, 4, n_band_tiles, 256); return; }
+    if (variant == 3) { GSR_LAUNCH_BF(true, 4, n_launch, 256); return; }
 #endif
     (void)variant;
     GSR_LAUNCH_BF(true, 1, groups * 32, 64);

@@ -328,15 +328,17 @@ emit_scatter(uint32_t R, int gx, int lb, int hb, const uint2* __restrict__ block
 // One memory round trip: thread t < nb1 fetches both table rows of bucket t and the (single) matching thread publishes the
 // bucket, its word range and its first workgroup through LDS (the first version looked the bucket up, then read the two
 // tables again for the match: two dependent trips in front of every level-2 kernel's own loads).
-__device__ __forceinline__ bool bucket_block(int nb1, const uint32_t* __restrict__ bucket_base, const uint32_t* __restrict__ blk2_start,
-                                             int* s_h /*[5]*/, uint32_t& h, uint32_t& begin, uint32_t& end) {
+// A launch covers the buckets [h0, h1) (the whole table, or one band of a band-pipelined frame: gsr_api.cpp): its workgroup 0 is the first
+// workgroup of bucket h0, B2 = blockIdx.x + blk2_start[h0] is the workgroup's index in the frame's level-2 plan (hist2 rows are indexed by it).
+__device__ __forceinline__ bool bucket_block(int nb1, int h0, int h1, const uint32_t* __restrict__ bucket_base, const uint32_t* __restrict__ blk2_start,
+                                             int* s_h /*[5]*/, uint32_t& h, uint32_t& begin, uint32_t& end, uint32_t& B2) {
     const int tid = threadIdx.x;
-    const uint32_t B2 = blockIdx.x;
+    B2 = blockIdx.x + blk2_start[h0];      // (wave-uniform load beside the table rows below)
     const int t = tid < nb1 ? tid : 0;
     const uint32_t b0 = blk2_start[t], b1 = blk2_start[t + 1], w0 = bucket_base[t], w1 = bucket_base[t + 1];
     if (tid == 0) s_h[0] = -1;
     __syncthreads();
-    if (tid < nb1 && b0 <= B2 && B2 < b1) {      // at most one bucket matches
+    if (tid >= h0 && tid < h1 && b0 <= B2 && B2 < b1) {      // at most one bucket matches
         s_h[0] = tid; s_h[1] = (int)b0; s_h[2] = (int)w0; s_h[3] = (int)w1; s_h[4] = (int)b1;
     }
     __syncthreads();
@@ -354,21 +356,21 @@ __device__ __forceinline__ bool bucket_block(int nb1, const uint32_t* __restrict
 // instance at all -- nobody else visits them
 template <typename WordT>
 __global__ void __launch_bounds__(WG_THREADS)
-bucket_hist(int lb, int hb, const WordT* __restrict__ words, const uint32_t* __restrict__ bucket_base,
+bucket_hist(int lb, int hb, int h0, int h1, const WordT* __restrict__ words, const uint32_t* __restrict__ bucket_base,
             const uint32_t* __restrict__ blk2_start, uint32_t* __restrict__ hist2 /*[blocks][nb2]*/, uint2* __restrict__ ranges_of_empty,
             int n_tiles) {
     __shared__ uint32_t hcnt[WG_WAVES][TS_MAXBINS];
     __shared__ int s_h[5];
     const int tid = threadIdx.x, w = tid >> 6;
     const int nb1 = 1 << hb, nb2 = 1 << lb;
-    if (ranges_of_empty && blockIdx.x == 0 && tid < nb1 && blk2_start[tid] == blk2_start[tid + 1]) {
+    if (ranges_of_empty && blockIdx.x == 0 && tid >= h0 && tid < h1 && blk2_start[tid] == blk2_start[tid + 1]) {
         for (int t = 0; t < nb2; ++t) {
             const int tile = (tid << lb) | t;
             if (tile < n_tiles) ranges_of_empty[tile] = make_uint2(0u, 0u);
         }
     }
-    uint32_t h, begin, end;
-    if (!bucket_block(nb1, bucket_base, blk2_start, s_h, h, begin, end)) return;
+    uint32_t h, begin, end, B2;
+    if (!bucket_block(nb1, h0, h1, bucket_base, blk2_start, s_h, h, begin, end, B2)) return;
     if (tid < nb2) {
 #pragma unroll
         for (int k = 0; k < WG_WAVES; ++k) hcnt[k][tid] = 0;
@@ -388,18 +390,18 @@ bucket_hist(int lb, int hb, const WordT* __restrict__ words, const uint32_t* __r
         if (i < end) atomicAdd(&hcnt[w][Pack<WordT>::lo(wd[r], lomask)], 1u);
     }
     __syncthreads();
-    if (tid < nb2) hist2[(int64_t)blockIdx.x * nb2 + tid] = hcnt[0][tid] + hcnt[1][tid] + hcnt[2][tid] + hcnt[3][tid];
+    if (tid < nb2) hist2[(int64_t)B2 * nb2 + tid] = hcnt[0][tid] + hcnt[1][tid] + hcnt[2][tid] + hcnt[3][tid];
 }
 
 // one workgroup per bucket: per-block exclusive offsets of every low digit (in place), the per-tile bases and the
 // tile ranges (tile = bucket << lb | low digit)
 __global__ void __launch_bounds__(WG_THREADS)
-bucket_scan(int lb, int n_tiles, const uint32_t* __restrict__ bucket_base, const uint32_t* __restrict__ blk2_start,
+bucket_scan(int lb, int h0, int n_tiles, const uint32_t* __restrict__ bucket_base, const uint32_t* __restrict__ blk2_start,
             uint32_t* __restrict__ hist2, uint32_t* __restrict__ tile_base /*[nb1 * nb2]*/, uint2* __restrict__ ranges) {
     __shared__ uint32_t wsum[WG_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nb2 = 1 << lb;
-    const uint32_t h = blockIdx.x;
+    const uint32_t h = blockIdx.x + (uint32_t)h0;
     const uint32_t s = blk2_start[h], e = blk2_start[h + 1];
     uint32_t tot[1] = {0u};
     if (tid < nb2) {
@@ -438,7 +440,7 @@ bucket_scan(int lb, int n_tiles, const uint32_t* __restrict__ bucket_base, const
 // workgroups (the slab a workgroup reads is workgroups-per-bucket x nb2 x 4 bytes).
 template <typename WordT, bool FUSED_SCAN>
 __global__ void __launch_bounds__(WG_THREADS)
-bucket_scatter(int lb, int hb, const WordT* __restrict__ words, const uint32_t* __restrict__ bucket_base,
+bucket_scatter(int lb, int hb, int h0, int h1, const WordT* __restrict__ words, const uint32_t* __restrict__ bucket_base,
                const uint32_t* __restrict__ blk2_start, const uint32_t* __restrict__ hist2,
                const uint32_t* __restrict__ tile_base, uint32_t* __restrict__ point_list, uint2* __restrict__ ranges, int n_tiles) {
     __shared__ uint32_t wave_cnt[WG_WAVES][TS_MAXBINS];
@@ -449,8 +451,8 @@ bucket_scatter(int lb, int hb, const WordT* __restrict__ words, const uint32_t* 
     __shared__ int s_h[5];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nb1 = 1 << hb, nb2 = 1 << lb;
-    uint32_t h, begin, end;
-    if (!bucket_block(nb1, bucket_base, blk2_start, s_h, h, begin, end)) return;
+    uint32_t h, begin, end, B2;
+    if (!bucket_block(nb1, h0, h1, bucket_base, blk2_start, s_h, h, begin, end, B2)) return;
     const uint32_t lomask = (uint32_t)nb2 - 1u;
     uint32_t id[TS_IPT], digit[TS_IPT], vmask = 0;
     const uint32_t wbase = begin + (uint32_t)w * (64u * TS_IPT) + (uint32_t)lane;
@@ -465,7 +467,7 @@ bucket_scatter(int lb, int hb, const WordT* __restrict__ words, const uint32_t* 
     }
     uint32_t my_base = 0u;
     if (FUSED_SCAN) {
-        const uint32_t bs = (uint32_t)s_h[1], be = (uint32_t)s_h[4], B2 = blockIdx.x;
+        const uint32_t bs = (uint32_t)s_h[1], be = (uint32_t)s_h[4];
         const int G = WG_THREADS >> lb;                      // thread = (low digit t, 1 / G of the bucket's workgroups)
         const int t = tid & (nb2 - 1), g = tid >> lb;
         uint32_t tot = 0, pre = 0;
@@ -506,7 +508,7 @@ bucket_scatter(int lb, int hb, const WordT* __restrict__ words, const uint32_t* 
             if (B2 == bs && tile < (uint32_t)n_tiles) ranges[tile] = tt[0] ? make_uint2(base, base + tt[0]) : make_uint2(0u, 0u);
         }
     } else {
-        my_base = tid < nb2 ? tile_base[h * (uint32_t)nb2 + tid] + hist2[(int64_t)blockIdx.x * nb2 + tid] : 0u;
+        my_base = tid < nb2 ? tile_base[h * (uint32_t)nb2 + tid] + hist2[(int64_t)B2 * nb2 + tid] : 0u;
     }
     local_stable_sort<uint32_t>(id, digit, vmask, lb, nb2, my_base, wave_cnt, digit_base, wsum, s_id, s_dig);
     const uint32_t nvalid = end - begin;
@@ -574,25 +576,30 @@ void gsr_set_level2_scan_mode(int v) { g_level2_scan_mode = v; }
 
 void gsr_launch_tile_sort_level2(const GsrTileSortPlan& plan, int64_t R, int n_tiles, const void* words, uint32_t* point_list,
                                  const uint32_t* bucket_base, const uint32_t* blk2_start, uint32_t* hist2, uint32_t* tile_base,
-                                 uint2* ranges, hipStream_t st) {
+                                 uint2* ranges, hipStream_t st, int h0, int h1) {
     const int nblk = (int)((R + TS_ITEMS - 1) / TS_ITEMS);
     const int nb1 = 1 << plan.hb;
-    const int nblk2 = nblk + nb1;       // upper bound of the level-2 workgroups (every bucket rounds up once)
+    if (h1 <= 0 || h1 > nb1) h1 = nb1;      // default: every bucket
+    if (h0 < 0) h0 = 0;
+    if (h0 >= h1) return;
+    // upper bound of the launch's level-2 workgroups (every bucket rounds up once); a band's share of the instances is not known to the host,
+    // so a band launch keeps the frame's bound and its surplus workgroups -- the LAST of its grid -- leave after one load
+    const int nblk2 = nblk + (h1 - h0);
     // without the scan kernel every level-2 workgroup reads its bucket's slab of the count table: fine while a bucket has a few
     // dozen workgroups (bench frame: 30), too much traffic when it has hundreds (6 M Gaussians: 180)
     const bool fused = g_level2_scan_mode == 2 || (g_level2_scan_mode == 0 && nblk <= 64 * nb1);
     uint2* roe = fused ? ranges : nullptr;
     if (plan.word64)
-        hipLaunchKernelGGL(bucket_hist<uint64_t>, dim3(nblk2), dim3(WG_THREADS), 0, st, plan.lb, plan.hb, (const uint64_t*)words,
+        hipLaunchKernelGGL(bucket_hist<uint64_t>, dim3(nblk2), dim3(WG_THREADS), 0, st, plan.lb, plan.hb, h0, h1, (const uint64_t*)words,
                            bucket_base, blk2_start, hist2, roe, n_tiles);
     else
-        hipLaunchKernelGGL(bucket_hist<uint32_t>, dim3(nblk2), dim3(WG_THREADS), 0, st, plan.lb, plan.hb, (const uint32_t*)words,
+        hipLaunchKernelGGL(bucket_hist<uint32_t>, dim3(nblk2), dim3(WG_THREADS), 0, st, plan.lb, plan.hb, h0, h1, (const uint32_t*)words,
                            bucket_base, blk2_start, hist2, roe, n_tiles);
     if (!fused)
-        hipLaunchKernelGGL(bucket_scan, dim3(nb1), dim3(WG_THREADS), 0, st, plan.lb, n_tiles, bucket_base, blk2_start, hist2, tile_base,
+        hipLaunchKernelGGL(bucket_scan, dim3(h1 - h0), dim3(WG_THREADS), 0, st, plan.lb, h0, n_tiles, bucket_base, blk2_start, hist2, tile_base,
                            ranges);
 #define GSR_L2_SCATTER(WORD_, FUSED_)                                                                                               \
-    hipLaunchKernelGGL((bucket_scatter<WORD_, FUSED_>), dim3(nblk2), dim3(WG_THREADS), 0, st, plan.lb, plan.hb, (const WORD_*)words,  \
+    hipLaunchKernelGGL((bucket_scatter<WORD_, FUSED_>), dim3(nblk2), dim3(WG_THREADS), 0, st, plan.lb, plan.hb, h0, h1, (const WORD_*)words,  \
                        bucket_base, blk2_start, hist2, tile_base, point_list, ranges, n_tiles)
     if (plan.word64) { if (fused) GSR_L2_SCATTER(uint64_t, true); else GSR_L2_SCATTER(uint64_t, false); }
     else { if (fused) GSR_L2_SCATTER(uint32_t, true); else GSR_L2_SCATTER(uint32_t, false); }

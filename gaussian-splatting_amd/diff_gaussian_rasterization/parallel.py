@@ -513,6 +513,21 @@ def any_rank_flag(flag: torch.Tensor, group=None) -> torch.Tensor:
 _flag_ring: dict = {}
 
 
+class _HostFlag:
+    """The pinned overflow flag of one frame + the event recorded behind its device-to-host copy.  Reading it (`flag[0]`) first waits for that
+    event (the R read-back that normally orders the read lives on the stream handed to the library -- which is torch's current stream
+    today, but the read must not depend on that)."""
+
+    def __init__(self, t: torch.Tensor, event=None):
+        self.t, self.event = t, event
+
+    def __getitem__(self, i):
+        if self.event is not None:
+            self.event.synchronize()
+            self.event = None
+        return self.t[i]
+
+
 def _pinned_flag(device) -> torch.Tensor:
     """A pinned host int32[1] from a small per-device ring (several frames may be in flight)."""
     ring = _flag_ring.setdefault(device, {"bufs": [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(8)], "next": 0})
@@ -740,16 +755,20 @@ def hip_render_segments(raster_settings, band, segs: torch.Tensor, n_segments: i
 
 
 def _fixed_exchange_forward(records, bounds, counts, rscratch, policy: ExchangePolicy, group, async_op: bool = False):
-    """The fixed-capacity exchange of one frame: -> (received segments, send_ids, pinned overflow flag, work).  The flag is valid on
-    the host once the frame's R read-back has returned (its copy is queued on the stream ahead of the ingest kernel that
-    publishes R)."""
+    """The fixed-capacity exchange of one frame: -> (received segments, send_ids, overflow flag (_HostFlag), work, packed send buffer).
+    The flag's copy to pinned memory is queued on the current stream ahead of the ingest kernel that publishes R, so it has normally
+    arrived when the frame's R read-back returns; `flag[0]` waits for the event recorded behind the copy in any case."""
     cap = int(policy.capacity)
     packed, send_ids = hip_route_pack_fixed(records, bounds, cap, rscratch, counts)
     flag = any_rank_flag((counts.to(torch.int64) > cap).any().to(torch.int32).reshape(1), group)
-    host_flag = _pinned_flag(records.device)
-    host_flag.copy_(flag, non_blocking=True)
+    pinned = _pinned_flag(records.device)
+    pinned.copy_(flag, non_blocking=True)
+    event = None
+    if flag.is_cuda:
+        event = torch.cuda.Event()
+        event.record(torch.cuda.current_stream(flag.device))
     recv, work = all_to_all_equal(packed, group, async_op=async_op)
-    return recv, send_ids, host_flag, work, packed
+    return recv, send_ids, _HostFlag(pinned, event), work, packed
 
 
 def hip_render_packed(raster_settings, band, recv: torch.Tensor, no_backward: bool):

@@ -21,10 +21,15 @@
  *     spinning, then sched_yield() between polls).
  *   - return value: GSR_OK (0) or a negative GsrStatus; gsr_last_error() gives the message for the
  *     calling thread.  No exception crosses the ABI.
- *   - no device allocation inside: scratch memory is caller-owned and obtained through the three
+ *   - no per-frame device allocation inside: scratch memory is caller-owned and obtained through the three
  *     resize callbacks (geometry / binning / image state), exactly like the reference's
  *     resizeFunctional lambdas; forward returns with the three buffers populated and the caller keeps
- *     them alive for gsr_rasterize_backward.
+ *     them alive for gsr_rasterize_backward.  The library itself owns only a few 64-byte CONTROL BLOCKS per device,
+ *     created the first time a device (or one more concurrent caller on it) is seen and kept for the life of the
+ *     process: the mapped host word of the read-back above, a 64-byte device counter beside it, one mapped
+ *     "oversized depth bucket" flag, and -- only when option fwd_bands > 1 -- one auxiliary HIP stream with five
+ *     events.  Their creation (hipHostMalloc / hipMalloc / hipStreamCreate) synchronises the device once; do the
+ *     first call outside a stream capture.
  */
 #ifndef GSR_H
 #define GSR_H

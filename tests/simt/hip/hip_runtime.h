@@ -193,6 +193,8 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; 
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : 2; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : 2; }
 static inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
@@ -200,4 +202,9 @@ static inline double simt_now_ms() { timespec t; clock_gettime(CLOCK_MONOTONIC, 
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)calloc(1, sizeof(simt_event)); return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->ms = simt_now_ms(); return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+#define hipStreamNonBlocking 1u
+#define hipEventDisableTiming 2u
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)calloc(1, 8); return hipSuccess; }      // (launches complete inline: a second stream is a name)
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->ms - a->ms); return hipSuccess; }

@@ -363,6 +363,12 @@ def test_config4_6M_1080p_backward_on_sampled_tiles():
     _backward_case(6_000_000, 1920, 1080, 24, "configs[4] 6M@1080p")
 
 
+def test_config4_6M_1080p_whole_frame_without_a_mask():
+    """configs[4] (6 M Gaussians, R = 47.6 M), all 8 160 tiles blended by the oracle -- the last full-size config that was
+    only sampled."""
+    _whole_frame_case(6_000_000, 1920, 1080, "configs[4] 6M@1080p")
+
+
 def test_config4_6M_1080p_reference_tile_rectangles_bit_exact():
     _reference_bins_case(6_000_000, 1920, 1080, 16, "configs[4] 6M@1080p")
     _cache.clear()
