@@ -44,6 +44,10 @@ CASES = {
     "depth_crowd": (20_000, 320, 240, 0.01, 9),       # 3/4 of the Gaussians inside 1e-5 of the depth range: oversized segments
     "depth_gap": (30_000, 320, 240, 0.01, 10),        # two clusters 4 orders of magnitude apart: shift 16, sparse buckets
     "depth_one_key": (9_000, 320, 240, 0.01, 13),     # every visible Gaussian at the SAME depth bits: zero sort passes
+    # round 5: the bulk inside 5 % of an octave + a few floaters 100x farther / 10x nearer -- the buckets span ds_hist's ROBUST key
+    # range, the floaters share the end buckets, whose segments sort on the full keys; 300 K Gaussians = 293 workgroups of the projection kernel,
+    # so the robust range has groups of two workgroups to work with
+    "depth_outliers": (300_000, 320, 240, 0.004, 16),
 }
 
 
@@ -64,12 +68,17 @@ def _reshape_depths(name, sc, cam, seed):
         znew = torch.where(near, 0.25 + 0.05 * torch.rand(P, generator=g), 3000.0 + 6000.0 * torch.rand(P, generator=g))
     elif name == "depth_one_key":
         znew = torch.full_like(z, 4.0)
+    elif name == "depth_outliers":
+        znew = 4.0 + 0.15 * torch.rand(P, generator=g)
+        far, near = torch.randperm(P, generator=g)[:9], torch.randperm(P, generator=g)[:4]
+        znew[far] = 400.0 + 2000.0 * torch.rand(9, generator=g)
+        znew[near] = 0.3 + 0.2 * torch.rand(4, generator=g)
     else:
         return
     f = (znew / z).unsqueeze(1)
     sc.means3D.mul_(f)
-    if name == "depth_gap":
-        sc.scales.mul_(f)          # keep the far cluster's splats visible on screen
+    if name in ("depth_gap", "depth_outliers"):
+        sc.scales.mul_(f)          # keep the far cluster's / the floaters' splats visible on screen
 
 
 @pytest.mark.parametrize("tiles_mode", ["snug", "reference"])

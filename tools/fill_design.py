@@ -9,7 +9,7 @@ import os
 import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 
 
 def main():
@@ -22,8 +22,7 @@ def main():
                 return us
         raise KeyError(prefix)
 
-    ab_path = os.path.join(ROOT, "profiles", f"{TAG}_ab_round3.json")
-    ab = json.load(open(ab_path)) if os.path.exists(ab_path) else None
+    ab = None
     rf, rt = b["roofline"], b["roofline_train"]
     fwd_steps, bwd_steps = b["blend_work"]["fwd_pair_steps_per_launch"], b["blend_work"]["bwd_pair_steps_per_launch"]
     chain = [k(n) for n in ("ds_hist", "ds_scan", "ds_scatter", "ds_segsort", "emit_hist", "rs_scan", "emit_scatter", "bucket_hist", "bucket_scatter")]
@@ -34,14 +33,17 @@ def main():
         "ES_US": f"{k('emit_scatter'):.1f}", "BH_US": f"{k('bucket_hist'):.1f}", "BS_US": f"{k('bucket_scatter'):.1f}",
         "RF_US": f"{k('render_fwd_wave_bf<true, 1, false>'):.1f}",
         "FRAME_US": f"{b['ms_per_step'] * 1e3:.1f}",
-        "PREV_US": (f"{ab['round3_ms_per_frame_median'] * 1e3:.1f} against {ab['round4_ms_per_frame_median'] * 1e3:.1f} in the interleaved A/B of `profiles/{TAG}_ab_round3.json`"
-                    if ab else "385.5 against 353 on a fast box, 404–425 against 384 on a slow one"),
         "FWD_STEPS": f"{fwd_steps:,}".replace(",", " "), "FWD_GFLOP": f"{fwd_steps * 64 * 25 / 1e9:.2f}",
         "FWD_TF": f"{rf['achieved']:.1f}", "FWD_FRAC": f"{rf['frac']:.3f}", "TRAF_MB": f"{(rf['traffic'] or 0) / 1e6:.0f}",
         "BWD_STEPS": f"{bwd_steps:,}".replace(",", " "), "BWD_US": f"{rt['kernel_ms'] * 1e3:.0f}", "BWD_TF": f"{rt['achieved']:.1f}", "BWD_FRAC": f"{rt['frac']:.3f}",
         "WF_TBS": f"{b['whole_forward']['achieved_GBs'] / 1e3:.2f}", "WF_FRAC": f"{b['whole_forward']['frac_of_8TBs']:.3f}",
         "PREH_US": f"{cs['ms'] * 1e3:.1f}", "PREH_TBS": f"{cs['GBs'] / 1e3:.2f}", "PREH_FRAC": f"{cs['frac_of_8TBs']:.3f}",
         "CHAIN_US": f"{sum(chain):.0f}",
+        "FWD_VALU_M": f"{(rf.get('valu_instructions_per_launch_from_committed_profile') or 0) / 1e6:.1f}",
+        "FWD_VALU_PER_STEP": f"{(rf.get('valu_instructions_per_launch_from_committed_profile') or 0) / max(1, fwd_steps):.1f}",
+        "FWD_ISSUE_FRAC": f"{rf.get('valu_issue_frac_of_measured_ceiling_from_committed_profile') or 0:.2f}",
+        "FWD_ISSUE": f"{rf.get('valu_lane_ops_T_per_s_from_committed_profile') or 0:.1f}",
+        "WHOLE6M": os.environ.get("GSR_WHOLE6M", "(see `profiles/r05_parity_report.json`)"),
     }
     oc = b["other_configs_forward"]
     fl = b["train_full_loop_configs2"]
@@ -50,7 +52,8 @@ def main():
     rows = [
         ("**forward, configs[1] stand-in (`value`)**", f"**{b['value']:.0f} Mpix/s — {b['ms_per_step']:.4f} ms per frame** (HIP-event median {b['gpu_event_ms']['forward']['median_ms']:.4f}); tracking build {b['forward_builds_ms'][[x for x in b['forward_builds_ms'] if x.startswith('tracking')][0]]:.4f} ms"),
         ("stage times (library's HIP events, ms)", ", ".join(f"{n} {b['stage_ms'][n]:.4f}" for n in ("preprocess", "depth_sort", "emit", "tile_sort", "render", "r_wait"))),
-        ("same box, round-3 library", sub["PREV_US"] + " µs per frame (round 3 → round 4)"),
+        ("the same frame with the REFERENCE's tile rectangles (`snug_tiles = 0`: the configuration whose bins are bit-exact against the oracle in reference mode)",
+         f"{b['forward_reference_rectangles']['ms_per_frame']:.4f} ms per frame = {b['forward_reference_rectangles']['Mpix_s']:.0f} Mpix/s (R = {b['forward_reference_rectangles']['num_rendered']:,})".replace(",", " ")),
         ("32 cameras cycled / 3 parameter sets cycled", f"{b['forward_cycled_views']['ms_per_frame']:.4f} / {b['forward_cycled_scenes']['ms_per_frame']:.4f} ms per frame"),
     ] + ([("three independent frames in flight on 3 HIP streams (a camera-list loop; **not** `value`)",
             f"{b['forward_frames_in_flight']['ms_per_frame']:.4f} ms per frame = {b['forward_frames_in_flight']['Mpix_s']:.0f} Mpix/s")] if b.get("forward_frames_in_flight") else []) + [
@@ -64,10 +67,13 @@ def main():
         o = oc[name]
         rows.append((label, f"{o['ms_per_frame']:.4f} ms = {o['Mpix_s']:.0f} Mpix/s (R = {o['num_rendered']:,})".replace(",", " ")))
     rows += [
-        ("roofline (forward blend)", f"{rf['achieved']:.1f} TFLOP/s = {rf['frac']:.3f} of 157.3 (fp32 VALU); issue rate {rf['valu_lane_ops_T_per_s']:.1f} T lane-ops/s = {rf['valu_issue_frac_of_measured_ceiling']:.2f} of the measured ceiling; PMC traffic {sub['TRAF_MB']} MB / launch"),
-        ("roofline (blend backward)", f"{rt['achieved']:.1f} TFLOP/s = {rt['frac']:.3f}; PMC traffic {(rt['traffic'] or 0) / 1e6:.0f} MB / launch"),
-        ("CPU baseline (oracle, same frame)", f"{cpu['value']:.4f} Mpix/s on {cpu['cores']} cores ({cpu['seconds_per_frame']:.1f} s per frame)"),
+        ("roofline (forward blend; kernel duration = mean / median of the launches of this run)", f"{rf['achieved']:.1f} TFLOP/s = {rf['frac']:.3f} of 157.3 (fp32 VALU) on the mean {rf['kernel_ms'] * 1e3:.1f} µs, {rf['frac_median']:.3f} on the median {rf['kernel_ms_median'] * 1e3:.1f} µs; issue rate {rf.get('valu_lane_ops_T_per_s_from_committed_profile') or 0:.1f} T lane-ops/s = {rf.get('valu_issue_frac_of_measured_ceiling_from_committed_profile') or 0:.2f} of the measured ceiling; PMC traffic {sub['TRAF_MB']} MB / launch (counters: the committed rocprofv3 --pmc passes of the same command)"),
+        ("roofline (blend backward)", f"{rt['achieved']:.1f} TFLOP/s = {rt['frac']:.3f} (mean {rt['kernel_ms'] * 1e3:.0f} µs), {rt['frac_median']:.3f} (median {rt['kernel_ms_median'] * 1e3:.0f} µs); PMC traffic {(rt['traffic'] or 0) / 1e6:.0f} MB / launch"),
+        ("CPU baseline (oracle, same frame, same run)", f"{cpu['value']:.4f} Mpix/s on {cpu['cores']} cores ({cpu['seconds_per_frame']:.1f} s per frame)"),
     ]
+    lv = b.get("train_low_visibility")
+    if lv:
+        rows.insert(-3, (f"train step where {lv['visible_fraction'] * 100:.0f} % of the Gaussians are visible (clustered scene): dense fused Adam / SparseGaussianAdam", f"{lv['dense_adam_it_s']:.1f} / {lv['sparse_adam_it_s']:.1f} it/s"))
     sm_path = os.path.join(ROOT, "profiles", f"{TAG}_shard_model.json")
     if os.path.exists(sm_path):
         sm = json.load(open(sm_path))

@@ -30,7 +30,7 @@ for it in range(N):
     P = int(10 ** (rng.uniform(5.0, 6.45) if os.environ.get("FUZZ_BIG") else rng.uniform(0.5, 5.6)))
     W, H = rng.choice([(64, 48), (200, 120), (320, 240), (641, 359), (1280, 720), (1920, 1080)])
     s_med = 10 ** rng.uniform(-2.6, -0.7) * (0.3 if P > 100_000 else 1.0)
-    kind = rng.choice(["plain", "plain", "ties", "crowd", "gap", "one_key"])
+    kind = rng.choice(["plain", "plain", "ties", "crowd", "gap", "one_key", "outliers", "outliers"])
     snug = rng.choice([1, 1, 0])
     cam = make_camera(W, H)
     sc = make_scene(P, cam, seed=1000 + it, s_med=s_med)
@@ -48,10 +48,17 @@ for it in range(N):
         znew = torch.where(near, 0.25 + 0.05 * torch.rand(P, generator=g), 2000.0 + 6000.0 * torch.rand(P, generator=g))
     elif kind == "one_key":
         znew = torch.full_like(z, rng.choice([0.3, 4.0, 900.0]))
+    elif kind == "outliers":      # round 5: a narrow bulk + a few floaters far behind / in front of it (the robust key range of ds_hist)
+        lo = rng.choice([0.5, 4.0, 60.0])
+        znew = lo * (1.0 + rng.choice([0.01, 0.05, 0.5]) * torch.rand(P, generator=g))
+        n_far, n_near = rng.choice([1, 7, 40, 400]), rng.choice([0, 3, 30])
+        znew[torch.randperm(P, generator=g)[:min(P, n_far)]] = lo * (20.0 + 400.0 * torch.rand(min(P, n_far), generator=g))
+        if n_near:
+            znew[torch.randperm(P, generator=g)[:min(P, n_near)]] = torch.clamp(lo * (0.02 + 0.3 * torch.rand(min(P, n_near), generator=g)), min=0.21)
     if znew is not None:
         f = (znew / z).unsqueeze(1)
         sc.means3D.mul_(f)
-        if kind == "gap":
+        if kind in ("gap", "outliers"):
             sc.scales.mul_(f)
     s = oracle_settings(cam)
     rs = gpu_settings(s, dev)
