@@ -83,11 +83,9 @@ def main():
                 e = cfg.get(G)
                 if not e:
                     continue
-                t = f"{G} GPUs {e['speedup_pipelined']:.2f}× / {e['speedup_serial']:.2f}×"
-                if "fixed_exchange" in e:
-                    t += f" (fixed-capacity exchange {e['fixed_exchange']['speedup_pipelined']:.2f}× / {e['fixed_exchange']['speedup_serial']:.2f}×)"
+                t = (f"{G} GPUs **{e['speedup_back_to_back']:.2f}×**" if "speedup_back_to_back" in e else f"{G} GPUs") + f" ({e['speedup_pipelined']:.2f}× / {e['speedup_serial']:.2f}×)"
                 parts.append(t)
-            rows.append((f"multi-GPU **model** from per-rank times measured on one GPU, {name} (pipelined / serial speed-up)", "; ".join(parts)))
+            rows.append((f"multi-GPU **model** from per-rank kernels measured on one GPU + modelled xGMI collectives, {name}: speed-up with every rank's frames queued back to back, as `bench.py` times them (in brackets: every piece timed on its own with a synchronisation — pipelined / serial, round 4's method)", "; ".join(parts)))
     sub["RESULTS_TABLE"] = "| | |\n|---|---|\n" + "\n".join(f"| {a} | {c} |" for a, c in rows)
     text = open(os.path.join(ROOT, "docs", "DESIGN.template.md")).read()
     for key in sorted(sub, key=len, reverse=True):

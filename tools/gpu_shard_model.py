@@ -59,6 +59,23 @@ def median_ms(fn, steps=12, warm=4):
     return ts[len(ts) // 2]
 
 
+def throughput_ms(fn, steps=30, warm=6):
+    """ms per call of fn when the calls follow each other on the stream WITHOUT a synchronisation in between (the host queues ahead of the GPU,
+    as bench.py's timed loops and a pipelined multi-GPU run do) -- median_ms above times every call on its own and so adds the launch latency
+    of its first kernel and the host's Python time to every piece, which inflates short pieces (a 250 K-Gaussian projection: 42 us that way,
+    about half of it latency) much more than the single-GPU frame they are compared with."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
 out = {}
 for name, P, W, H, kind in (("configs[1] 1M@1080p", 1_000_000, 1920, 1080, "uniform"), ("configs[3] 1M@4K", 1_000_000, 3840, 2160, "uniform"),
                             ("configs[4] 6M@1080p", 6_000_000, 1920, 1080, "uniform"), ("configs[1] clustered", 1_000_000, 1920, 1080, "clustered")):
@@ -78,7 +95,8 @@ for name, P, W, H, kind in (("configs[1] 1M@1080p", 1_000_000, 1920, 1080, "unif
         with torch.no_grad():
             rasterize_gaussians(sc.means3D, None, sc.shs, None, sc.opacities, sc.scales, sc.rotations, None, rs, None)
     t1 = median_ms(full_frame, steps=20, warm=8)
-    res = {"P": P, "W": W, "H": H, "kind": kind, "visible": V, "R": R, "1": {"frame_ms": round(t1, 4)}}
+    t1_thr = throughput_ms(full_frame)
+    res = {"P": P, "W": W, "H": H, "kind": kind, "visible": V, "R": R, "1": {"frame_ms": round(t1, 4), "frame_back_to_back_ms": round(t1_thr, 4)}}
     strip_bytes = 3 * W * H * 4
     for G in (2, 4, 8):
         plan = BandPlan.balanced(row_cost, G)
@@ -136,6 +154,14 @@ for name, P, W, H, kind in (("configs[1] 1M@1080p", 1_000_000, 1920, 1080, "unif
             ms_band = median_ms(band)
             ms_route_fixed = median_ms(route_fixed)
             ms_band_fixed = median_ms(band_fixed)
+
+            def chain():          # what rank g queues per frame, back to back (the all-to-all sits between route and band: modelled)
+                project(); route(); band()
+
+            def chain_fixed():
+                project(); route_fixed(); band_fixed()
+            ms_chain = throughput_ms(chain)
+            ms_chain_fixed = throughput_ms(chain_fixed)
             del recv_fixed
             _lib.profile_reset(); _lib.profile_enable(True)
             for _ in range(5):
@@ -152,6 +178,7 @@ for name, P, W, H, kind in (("configs[1] 1M@1080p", 1_000_000, 1920, 1080, "unif
                         "band_ms": round(ms_band, 4), "gpu_ms": round(ms_project + ms_route + ms_band, 4), "band_stage_ms": stage,
                         "route_fixed_ms": round(ms_route_fixed, 4), "band_fixed_ms": round(ms_band_fixed, 4),
                         "gpu_fixed_ms": round(ms_project + ms_route_fixed + ms_band_fixed, 4),
+                        "chain_back_to_back_ms": round(ms_chain, 4), "chain_fixed_back_to_back_ms": round(ms_chain_fixed, 4),
                         "all_to_all_model_us": round(a2a_us, 1)})
             del recv
         gpu = max(p["gpu_ms"] for p in per)
@@ -160,10 +187,16 @@ for name, P, W, H, kind in (("configs[1] 1M@1080p", 1_000_000, 1920, 1080, "unif
         total_rows = sum(sum(pk[2]) for pk in packs)
         gpu_f = max(p["gpu_fixed_ms"] for p in per)
         a2a_f = HOP_US + (cap + 1) * 48 / (LINK_GBS * 1e3)
+        chain = max(p["chain_back_to_back_ms"] for p in per)
+        chain_f = max(p["chain_fixed_back_to_back_ms"] for p in per)
         res[str(G)] = {"slowest_rank_gpu_ms": round(gpu, 4), "all_to_all_model_us": a2a, "strip_allgather_model_us": round(strips_us, 1),
                        "count_sync_us": COUNT_SYNC_US, "rows_exchanged_over_visible": round(total_rows / max(1, V), 3),
                        "speedup_pipelined": round(t1 / max(gpu, a2a * 1e-3, strips_us * 1e-3), 2),
                        "speedup_serial": round(t1 / (gpu + (a2a + strips_us + COUNT_SYNC_US) * 1e-3), 2),
+                       # the throughput view: frames back to back on every rank (what bench.py times), against the single GPU's back-to-back frames
+                       "slowest_rank_chain_back_to_back_ms": round(chain, 4),
+                       "speedup_back_to_back": round(t1_thr / max(chain, a2a * 1e-3, strips_us * 1e-3), 2),
+                       "speedup_back_to_back_fixed_exchange": round(t1_thr / max(chain_f, a2a_f * 1e-3, strips_us * 1e-3), 2),
                        "fixed_exchange": {"capacity": cap, "rows_padded_over_rows_exact": round(G * G * (cap + 1) / max(1, total_rows), 3),
                                           "slowest_rank_gpu_ms": round(gpu_f, 4), "all_to_all_model_us": round(a2a_f, 1),
                                           "speedup_pipelined": round(t1 / max(gpu_f, a2a_f * 1e-3, strips_us * 1e-3), 2),
