@@ -31,6 +31,9 @@ using namespace gsrw;
 
 namespace {
 
+// (Both ranking kernels run at four waves per SIMD -- 126 / 107 VGPRs -- and spend half of their wave-cycles waiting (SQ_WAIT_ANY).  Forcing five / six
+// with amdgpu_waves_per_eu spills 6-25 registers inside the ranking loops: emission 0.053 -> 0.076 ms, tile sort 0.042 -> 0.051 / 0.059 ms,
+// profiles/r05_ab_ranking_occupancy.json.)
 constexpr int TS_ITEMS = GSR_TS_ITEMS;              // instances per workgroup
 constexpr int TS_IPT = TS_ITEMS / WG_THREADS;       // 16 per thread
 constexpr int TS_MAXBINS = 256;
