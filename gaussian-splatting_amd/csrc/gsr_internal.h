@@ -28,7 +28,8 @@ static inline size_t gsr_align128(size_t x) { return (x + 127) & ~(size_t)127; }
 #define GSR_SORT_ITEMS_SMALL 1024
 #define GSR_SCAN_ITEMS 1024      // items per workgroup in the tiles_touched scan
 #ifndef GSR_TS_ITEMS
-#define GSR_TS_ITEMS 4096        // instances per workgroup of the fused emission / tile sort (tilesort.hip); tuning builds: -DGSR_TS_ITEMS=2048
+#define GSR_TS_ITEMS 4096        // instances per workgroup of the fused emission / tile sort (tilesort.hip).  (Round 3 tuned it with -DGSR_TS_ITEMS=2048 builds; the
+                                 // block tables of depthsort.hip / gsr_api.cpp have since been sized for 4096 and a 2048 build aborts: not a supported switch any more.)
 #endif
 // capacity of the per-block "first Gaussian" table the scan kernel fills: enough for 64 tiles per Gaussian on average;
 // frames beyond that get the table from a fallback kernel once R is known (gsr_launch_fill_block_first)
