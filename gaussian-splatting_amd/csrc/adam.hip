@@ -126,18 +126,17 @@ __device__ __forceinline__ void sparse_adam1(float& p, float g, float& m, float&
     gsr_sparse_adam1(p, g, m, v, lr, b1, om_b1, b2, om_b2, eps);
 }
 
-__global__ void __launch_bounds__(256)
-sparse_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                   const uint8_t* __restrict__ visible, int64_t N, uint32_t M, float lr, float b1, float om_b1, float b2,
-                   float om_b2, float eps, int vec) {
+// one tensor, walked by the threads tid0, tid0 + stride, ... (its own launch, or its block range of the multi-tensor launch)
+__device__ __forceinline__ void sparse_adam_walk(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                 const uint8_t* __restrict__ visible, int64_t N, uint32_t M, float lr, float b1, float om_b1, float b2,
+                                                 float om_b2, float eps, int vec, int64_t tid0, int64_t stride) {
     const int64_t n = N * (int64_t)M;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t n4 = vec ? (n >> 2) : 0;
     float4* p4 = reinterpret_cast<float4*>(p);
     const float4* g4 = reinterpret_cast<const float4*>(g);
     float4* m4 = reinterpret_cast<float4*>(m);
     float4* v4 = reinterpret_cast<float4*>(v);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    for (int64_t i = tid0; i < n4; i += stride) {
         const uint64_t e0 = (uint64_t)i << 2;
         // n < 2^32 for every tensor of a 3DGS model below 89 M Gaussians: one 32-bit division per four elements
         const uint64_t row0 = (e0 >> 32) ? e0 / M : (uint64_t)((uint32_t)e0 / M);
@@ -159,12 +158,49 @@ sparse_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __
         if (vis[3]) sparse_adam1(pp.w, gg.w, mm.w, vv.w, lr, b1, om_b1, b2, om_b2, eps);
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
     }
-    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    for (int64_t i = (n4 << 2) + tid0; i < n; i += stride) {
         if (!visible[i / M]) continue;
         float pp = p[i], mm = m[i], vv = v[i];
         sparse_adam1(pp, g[i], mm, vv, lr, b1, om_b1, b2, om_b2, eps);
         p[i] = pp; m[i] = mm; v[i] = vv;
     }
+}
+
+__global__ void __launch_bounds__(256)
+sparse_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                   const uint8_t* __restrict__ visible, int64_t N, uint32_t M, float lr, float b1, float om_b1, float b2,
+                   float om_b2, float eps, int vec) {
+    sparse_adam_walk(p, g, m, v, visible, N, M, lr, b1, om_b1, b2, om_b2, eps, vec, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
+                     (int64_t)gridDim.x * blockDim.x);
+}
+
+// Round 5: the six parameter tensors of a 3DGS model in ONE launch (gsr_sparse_adam_step_multi) -- SparseGaussianAdam.step used to issue one
+// launch (and one ctypes call) per parameter group; at P ~ 100 K the whole training iteration is bound by the host's launch rate, and at 1 M
+// five launch gaps of ~4 us separate kernels of 8-30 us.  Every tensor gets the block range [block_begin, next block_begin) and is walked exactly
+// as by its own launch: results are the bits of gsr_sparse_adam_step on every tensor.
+struct SparseAdamTensorDev {
+    float* p; const float* g; float* m; float* v;
+    uint32_t M;
+    float lr, eps;
+    int vec, block_begin;
+};
+struct SparseAdamBatchDev {
+    SparseAdamTensorDev t[GSR_ADAM_MAX_TENSORS];
+    const uint8_t* visible;
+    int64_t N;
+    float b1, om_b1, b2, om_b2;
+    int count, total_blocks;
+};
+__global__ void __launch_bounds__(256)
+sparse_adam_multi_kernel(SparseAdamBatchDev b) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < GSR_ADAM_MAX_TENSORS; ++j)
+        if (j < b.count && (int)blockIdx.x >= b.t[j].block_begin) k = j;
+    const SparseAdamTensorDev& t = b.t[k];
+    const int end = k + 1 < b.count ? b.t[k + 1].block_begin : b.total_blocks;
+    sparse_adam_walk(t.p, t.g, t.m, t.v, b.visible, b.N, t.M, t.lr, b.b1, b.om_b1, b.b2, b.om_b2, t.eps, t.vec,
+                     (int64_t)((int)blockIdx.x - t.block_begin) * blockDim.x + threadIdx.x, (int64_t)(end - t.block_begin) * blockDim.x);
 }
 
 }  // namespace
@@ -179,6 +215,32 @@ void gsr_launch_sparse_adam(float* p, const float* g, float* m, float* v, const 
     if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(sparse_adam_kernel, dim3((int)nb), dim3(256), 0, st, p, g, m, v, visible, N, (uint32_t)M, (float)lr,
                        (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, vec);
+}
+
+void gsr_launch_sparse_adam_multi(const GsrSparseAdamTensor* tensors, int count, const uint8_t* visible, int64_t N, double beta1, double beta2,
+                                  hipStream_t st) {
+    SparseAdamBatchDev b;
+    b.count = 0;
+    int blocks = 0;
+    for (int i = 0; i < count && b.count < GSR_ADAM_MAX_TENSORS; ++i) {
+        const GsrSparseAdamTensor& a = tensors[i];
+        const int64_t n = N * a.M;
+        if (n <= 0) continue;
+        SparseAdamTensorDev& t = b.t[b.count++];
+        t.p = a.param; t.g = a.grad; t.m = a.exp_avg; t.v = a.exp_avg_sq; t.M = (uint32_t)a.M;
+        t.lr = (float)a.lr; t.eps = (float)a.eps;
+        t.vec = ((((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0 && a.M < (1ll << 31)) ? 1 : 0;
+        const int64_t work = t.vec ? (n + 3) / 4 : n;
+        int64_t nb = (work + 255) / 256;
+        if (nb > 8192) nb = 8192;      // (the single-tensor launcher's cap: the same walk per tensor)
+        t.block_begin = blocks;
+        blocks += (int)nb;
+    }
+    if (b.count == 0) return;
+    b.visible = visible; b.N = N;
+    b.b1 = (float)beta1; b.om_b1 = (float)(1.0 - beta1); b.b2 = (float)beta2; b.om_b2 = (float)(1.0 - beta2);
+    b.total_blocks = blocks;
+    hipLaunchKernelGGL(sparse_adam_multi_kernel, dim3(blocks), dim3(256), 0, st, b);
 }
 
 void gsr_launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,

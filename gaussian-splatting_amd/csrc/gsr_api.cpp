@@ -1196,6 +1196,25 @@ int gsr_sparse_adam_step(float* param, const float* grad, float* exp_avg, float*
     return GSR_OK;
 }
 
+int gsr_sparse_adam_step_multi(const GsrSparseAdamTensor* tensors, int32_t count, const uint8_t* visible, int64_t N, double beta1, double beta2,
+                               void* stream) {
+    if (count < 0 || N < 0) return fail(GSR_ERR_INVALID_ARG, "count < 0 or N < 0");
+    if (count == 0 || N == 0) return GSR_OK;
+    if (!tensors || !visible) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
+    if (N >= (1ll << 31)) return fail(GSR_ERR_UNSUPPORTED, "sparse Adam: N and M must be below 2^31 (the kernel indexes rows and columns with 32 bits)");
+    for (int i = 0; i < count; ++i) {
+        const GsrSparseAdamTensor& a = tensors[i];
+        if (a.M < 0) return fail(GSR_ERR_INVALID_ARG, "M < 0");
+        if (a.M >= (1ll << 31)) return fail(GSR_ERR_UNSUPPORTED, "sparse Adam: N and M must be below 2^31 (the kernel indexes rows and columns with 32 bits)");
+        if (a.M > 0 && (!a.param || !a.grad || !a.exp_avg || !a.exp_avg_sq)) return fail(GSR_ERR_INVALID_ARG, "NULL pointer");
+    }
+    for (int i = 0; i < count; i += GSR_ADAM_MAX_TENSORS)
+        gsr_launch_sparse_adam_multi(tensors + i, count - i < GSR_ADAM_MAX_TENSORS ? count - i : GSR_ADAM_MAX_TENSORS, visible, N, beta1, beta2,
+                                     (hipStream_t)stream);
+    HIP_OK(hipGetLastError());
+    return GSR_OK;
+}
+
 int gsr_density_stats(int P, const float* viewspace_grad, const uint8_t* visible, const int32_t* radii, float* grad_accum, float* denom,
                       float* max_radii2D, void* stream) {
     if (P < 0) return fail(GSR_ERR_INVALID_ARG, "P < 0");

@@ -288,6 +288,8 @@ void gsr_launch_ssim_backward(int planes, int H, int W, const float* img1, const
 
 // adam.hip: sparse step (rows of M elements, skipped entirely when visible[row] == 0)
 void gsr_launch_adam_multi(const GsrAdamTensor* tensors, int count /*<= GSR_ADAM_MAX_TENSORS*/, hipStream_t st);
+void gsr_launch_sparse_adam_multi(const GsrSparseAdamTensor* tensors, int count, const uint8_t* visible, int64_t N, double beta1, double beta2,
+                                  hipStream_t st);
 void gsr_launch_sparse_adam(float* p, const float* g, float* m, float* v, const uint8_t* visible, int64_t N, int64_t M,
                             double lr, double beta1, double beta2, double eps, hipStream_t st);
 // density.hip: per-iteration density-control statistics

@@ -465,7 +465,7 @@ class GaussianRasterizer(nn.Module):
 class SparseGaussianAdam(torch.optim.Adam):
     """`SparseGaussianAdam(params, lr, eps).step(visibility, N)` (scene/gaussian_model.py:194-196, train.py:180-183):
     Adam that updates only the rows of Gaussians that were visible in this iteration; parameter and both moments of the
-    others stay untouched.  One fused HIP kernel per parameter group (gsr_sparse_adam_step).  State layout
+    others stay untouched.  One fused HIP launch for all parameter groups (gsr_sparse_adam_step_multi; round 5 -- one launch per group before).  State layout
     (`step`, `exp_avg`, `exp_avg_sq`) is torch.optim.Adam's, so the optimizer-state surgery of
     scene/gaussian_model.py:316-405 (prune / cat / replace) works unchanged.
     [RECALLED -- the accelerated rasterizer's source is not vendored] betas are fixed at (0.9, 0.999) and there is no
@@ -484,6 +484,7 @@ class SparseGaussianAdam(torch.optim.Adam):
         elif vis.dtype != torch.uint8:
             vis = vis.to(torch.uint8)
         vis = vis.contiguous()
+        by_device: dict = {}      # device -> [(param, grad, state, M, lr, eps)]: ONE launch per device (gsr_sparse_adam_step_multi)
         for group in self.param_groups:
             lr, eps = group["lr"], group["eps"]
             assert len(group["params"]) == 1, "more than one tensor in group"
@@ -502,7 +503,10 @@ class SparseGaussianAdam(torch.optim.Adam):
             if N > 0 and (param.numel() != N * M or vis.numel() != N):
                 raise GsrError(f"parameter of {param.numel()} elements / visibility of {vis.numel()} do not match N = {N}")
             g = param.grad if param.grad.is_contiguous() else param.grad.contiguous()
-            with torch.cuda.device(param.device):
-                _lib.check(lib.gsr_sparse_adam_step(_ptr(param), _ptr(g), _ptr(state["exp_avg"]), _ptr(state["exp_avg_sq"]),
-                                                    _ptr(vis), N, M, float(lr), 0.9, 0.999, float(eps),
-                                                    _stream_ptr(param.device)), "gsr_sparse_adam_step")
+            by_device.setdefault(param.device, []).append((param, g, state, M, float(lr), float(eps)))
+        for dev, items in by_device.items():
+            arr = (_lib.SparseAdamTensor * len(items))()
+            for k, (param, g, state, M, lr, eps) in enumerate(items):
+                arr[k] = _lib.SparseAdamTensor(param.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(), M, lr, eps)
+            with torch.cuda.device(dev):
+                _lib.check(lib.gsr_sparse_adam_step_multi(arr, len(items), _ptr(vis), N, 0.9, 0.999, _stream_ptr(dev)), "gsr_sparse_adam_step_multi")

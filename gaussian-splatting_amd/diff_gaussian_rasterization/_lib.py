@@ -48,7 +48,7 @@ EXPORTS = [
     "gsr_preprocess_forward", "gsr_rasterize_from_splats",
     "gsr_route_scratch_bytes", "gsr_route_count", "gsr_route_pack", "gsr_rasterize_from_packed", "gsr_route_return",
     "gsr_route_pack_fixed", "gsr_rasterize_from_segments",
-    "gsr_mark_visible", "gsr_forward_views", "gsr_adam_step", "gsr_adam_step_multi", "gsr_backward_preprocess_sh_adam", "gsr_sparse_adam_step", "gsr_ssim_forward", "gsr_ssim_backward",
+    "gsr_mark_visible", "gsr_forward_views", "gsr_adam_step", "gsr_adam_step_multi", "gsr_backward_preprocess_sh_adam", "gsr_sparse_adam_step", "gsr_sparse_adam_step_multi", "gsr_ssim_forward", "gsr_ssim_backward",
     "gsr_knn_scratch_bytes", "gsr_knn_mean_dist2", "gsr_ssim_partial_count", "gsr_ssim_mean_forward", "gsr_ssim_mean_backward",
     "gsr_train_loss_forward", "gsr_train_loss_backward", "gsr_density_stats",
     "gsr_profile_enable", "gsr_profile_reset", "gsr_profile_read", "gsr_profile_counters", "gsr_profile_trace", "gsr_set_option",
@@ -78,6 +78,12 @@ class AdamTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_int64),
                 ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int32),
                 ("reserved", C.c_int32)]
+
+class SparseAdamTensor(C.Structure):
+    """GsrSparseAdamTensor of include/gsr.h (gsr_sparse_adam_step_multi)."""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("M", C.c_int64),
+                ("lr", C.c_double), ("eps", C.c_double)]
+
 
 def load() -> C.CDLL:
     """Load libgsr_hip.so.  torch must own the HIP runtime: torch bundles its own libamdhip64.so (SONAME
@@ -166,6 +172,8 @@ def load() -> C.CDLL:
     lib.gsr_sparse_adam_step.restype = C.c_int
     lib.gsr_sparse_adam_step.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double,
                                          C.c_double, vp]
+    lib.gsr_sparse_adam_step_multi.restype = C.c_int
+    lib.gsr_sparse_adam_step_multi.argtypes = [C.POINTER(SparseAdamTensor), C.c_int32, vp, C.c_int64, C.c_double, C.c_double, vp]
     lib.gsr_knn_scratch_bytes.restype = C.c_size_t
     lib.gsr_knn_scratch_bytes.argtypes = [C.c_int]
     lib.gsr_knn_mean_dist2.restype = C.c_int

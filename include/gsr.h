@@ -309,6 +309,20 @@ int gsr_adam_step_multi(const GsrAdamTensor* tensors, int32_t count, void* strea
  */
 int gsr_sparse_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* visible,
                          int64_t N, int64_t M, double lr, double beta1, double beta2, double eps, void* stream);
+/* The same step for all parameter groups of one `SparseGaussianAdam.step(visibility, N)` call (the six tensors of
+ * scene/gaussian_model.py:183-190, one group each) in ONE launch: tensor i is N rows of tensors[i].M elements with its own lr / eps;
+ * visibility, N and the betas are shared.  Up to GSR_ADAM_MAX_TENSORS tensors per launch, longer lists are split.  Bit-identical to
+ * gsr_sparse_adam_step on every tensor.  (Added in round 5; additive, the ABI version stays 4.) */
+typedef struct GsrSparseAdamTensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t M;               /* elements per row (Gaussian) */
+    double lr, eps;
+} GsrSparseAdamTensor;
+int gsr_sparse_adam_step_multi(const GsrSparseAdamTensor* tensors, int32_t count, const uint8_t* visible, int64_t N, double beta1,
+                               double beta2, void* stream);
 
 /*
  * Per-iteration statistics of adaptive density control: GaussianModel.add_densification_stats

@@ -91,6 +91,10 @@ int simt_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr
     gsr_launch_adam(p, g, m, v, n, lr, b1, b2, eps, step, nullptr);
     return finish("adam");
 }
+int simt_sparse_adam_multi(const GsrSparseAdamTensor* tensors, int count, const uint8_t* visible, int64_t N, double b1, double b2) {
+    gsr_launch_sparse_adam_multi(tensors, count, visible, N, b1, b2, nullptr);
+    return finish("sparse adam multi");
+}
 int simt_sparse_adam(float* p, const float* g, float* m, float* v, const uint8_t* visible, int64_t N, int64_t M, double lr, double b1, double b2, double eps) {
     gsr_launch_sparse_adam(p, g, m, v, visible, N, M, lr, b1, b2, eps, nullptr);
     return finish("sparse adam");

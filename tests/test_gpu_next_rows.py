@@ -132,6 +132,37 @@ def test_split_sh_degree0_model_with_empty_rest():
     assert rest.grad is not None and rest.grad.shape == (600, 0, 3)
 
 
+def test_sparse_adam_one_launch_for_all_groups_equals_one_launch_per_group():
+    """Round 5: SparseGaussianAdam.step issues ONE launch for all parameter groups (gsr_sparse_adam_step_multi).  Every tensor must come out the
+    bits gsr_sparse_adam_step (one launch per group, rounds 2-4) leaves: the six tensors of scene/gaussian_model.py:183-190, shared visibility."""
+    import ctypes as C
+    from diff_gaussian_rasterization import SparseGaussianAdam, _lib
+    dev = torch.device("cuda:0")
+    N = 100_003
+    g = torch.Generator(device="cpu").manual_seed(3)
+    shapes = {"xyz": (N, 3), "f_dc": (N, 1, 3), "f_rest": (N, 15, 3), "opacity": (N, 1), "scaling": (N, 3), "rotation": (N, 4)}
+    lrs = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 1.25e-4, "opacity": 0.025, "scaling": 5e-3, "rotation": 1e-3}
+    params = {k: torch.randn(*shp, generator=g).to(dev).requires_grad_(True) for k, shp in shapes.items()}
+    single = {k: [v.detach().clone(), torch.zeros_like(v), torch.zeros_like(v)] for k, v in params.items()}      # param, exp_avg, exp_avg_sq
+    opt = SparseGaussianAdam([{"params": [params[k]], "lr": lrs[k], "name": k} for k in shapes], lr=0.0, eps=1e-15)
+    lib = _lib.load()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    for it in range(3):
+        vis = torch.rand(N, generator=g) < (0.05, 0.5, 1.0)[it]
+        visd = vis.to(dev)
+        for k, p in params.items():
+            p.grad = torch.randn(*shapes[k], generator=g).to(dev)
+        opt.step(visd, N)
+        v8 = visd.view(torch.uint8)
+        for k, (p1, m1, v1) in single.items():
+            M = p1.numel() // N
+            _lib.check(lib.gsr_sparse_adam_step(vp(p1), vp(params[k].grad), vp(m1), vp(v1), vp(v8), N, M, lrs[k], 0.9, 0.999, 1e-15, None), "gsr_sparse_adam_step")
+        torch.cuda.synchronize()
+        for k, (p1, m1, v1) in single.items():
+            st = opt.state[params[k]]
+            assert torch.equal(params[k].detach(), p1) and torch.equal(st["exp_avg"], m1) and torch.equal(st["exp_avg_sq"], v1), (it, k)
+
+
 def test_sparse_gaussian_adam_updates_only_visible_rows():
     """SparseGaussianAdam(params, lr, eps).step(visibility, N) (train.py:180-183): rows of invisible Gaussians keep
     parameter and moments; visible rows follow m = b1 m + (1-b1) g, v = b2 v + (1-b2) g^2, p -= lr m / (sqrt(v) + eps)."""

@@ -190,3 +190,33 @@ def test_sparse_adam_source_on_the_cpu(lib):
         assert np.allclose(m, np.where(sel, mm, m0), rtol=1e-6, atol=1e-12) and np.allclose(v, np.where(sel, vv, v0), rtol=1e-6, atol=1e-12)
         assert np.allclose(p, np.where(sel, pp, p0), rtol=2e-6, atol=1e-9)
         assert np.array_equal(p[~vis.astype(bool)], p0[~vis.astype(bool)])
+
+
+def test_sparse_adam_multi_tensor_launch_equals_the_single_tensor_launches(lib):
+    """gsr_sparse_adam_step_multi (round 5: the six parameter groups of SparseGaussianAdam.step in ONE launch) leaves every tensor the bits the
+    single-tensor launch leaves -- the 3DGS row widths (3, 3, 45, 1, 3, 4), an unaligned view (scalar walk), per-tensor lr / eps, one shared mask."""
+    class T(C.Structure):
+        _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("M", C.c_int64),
+                    ("lr", C.c_double), ("eps", C.c_double)]
+    rng = np.random.default_rng(11)
+    N = 2500
+    vis = (rng.random(N) < 0.4).astype(np.uint8)
+    widths, lrs = (3, 3, 45, 1, 3, 4), (1.6e-4, 2.5e-3, 1.25e-4, 0.025, 5e-3, 1e-3)
+    a, b = [], []
+    for k, M in enumerate(widths):
+        base = [rng.normal(size=N * M + 1).astype(np.float32) for _ in range(2)] + [rng.random(N * M + 1).astype(np.float32) * 0.01 for _ in range(2)]
+        off = 1 if k == 4 else 0      # one tensor starts 4 bytes off the 16-byte grid: the scalar walk
+        a.append([x[off:off + N * M].copy() if not off else x[off:off + N * M] for x in [y.copy() for y in base]])
+        b.append([x[off:off + N * M].copy() if not off else x[off:off + N * M] for x in [y.copy() for y in base]])
+    arr = (T * len(widths))()
+    for k, M in enumerate(widths):
+        p, g, m, v = a[k]
+        arr[k] = T(p.ctypes.data, g.ctypes.data, m.ctypes.data, v.ctypes.data, M, lrs[k], 1e-15)
+    assert lib.simt_sparse_adam_multi(arr, len(widths), ptr(vis), C.c_int64(N), C.c_double(0.9), C.c_double(0.999)) == 0, lib.simt_rows_last_error()
+    for k, M in enumerate(widths):
+        p, g, m, v = b[k]
+        assert lib.simt_sparse_adam(ptr(p), ptr(g), ptr(m), ptr(v), ptr(vis), C.c_int64(N), C.c_int64(M), C.c_double(lrs[k]), C.c_double(0.9), C.c_double(0.999),
+                                    C.c_double(1e-15)) == 0
+        for x, y, name in zip(a[k], b[k], ("param", "grad", "exp_avg", "exp_avg_sq")):
+            assert np.array_equal(x, y), f"tensor {k} ({M} per row): {name} differs between the multi-tensor and the single-tensor launch"
+        assert not np.array_equal(a[k][0].reshape(N, M)[vis.astype(bool)], 0 * a[k][0].reshape(N, M)[vis.astype(bool)])
