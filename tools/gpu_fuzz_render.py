@@ -52,6 +52,7 @@ def conditioning(aux, s_):
     gx_, gy_ = aux["grid"]
     B = torch.zeros(H_, W_, dtype=torch.float64)
     E = torch.zeros(H_, W_, dtype=torch.float64)
+    J = torch.zeros(H_, W_, dtype=torch.float64)
     flag = torch.zeros(H_, W_, dtype=torch.bool)
     xy, con, opa = aux["means2D"].double(), aux["conic"].double(), aux["opacity"].double().reshape(-1)
     pl, rng_ = aux["point_list"], aux["ranges"]
@@ -83,10 +84,15 @@ def conditioning(aux, s_):
         near = evaluated & (((alpha - 1.0 / 255.0).abs() <= 2.0 * alpha * noise + 1e-12) & (power <= noise)
                             | ((power.abs() <= noise) & (alpha >= 0.5 / 255.0))
                             | (keep & ((Tincl - 1e-4).abs() <= Tincl * (relT + 1e-6) + 1e-12)))
+        # Round 5: a flipped SIGN TEST of the exponent (power > 0: the entry is skipped) is not an alpha-quantum event -- the entry sits at the splat's
+        # centre line, alpha = opacity * exp(~0) can be anything up to 0.99.  Only needles reach it (|power| within the cancellation noise of its terms);
+        # the jump such a flip may cause at the pixel is bounded by sum alpha_i T_i over the pairs whose sign is within noise (seed 71, frame 78).
+        near_sign = evaluated & (power.abs() <= noise) & (alpha >= 0.5 / 255.0)
+        J[y0:y1, x0:x1] = torch.where(near_sign, alpha * Texcl, torch.zeros_like(alpha)).sum(dim=1).reshape(y1 - y0, x1 - x0)
         B[y0:y1, x0:x1] = (w * M).sum(dim=1).reshape(y1 - y0, x1 - x0)
         E[y0:y1, x0:x1] = torch.where(evaluated, relT, torch.zeros_like(relT)).amax(dim=1).reshape(y1 - y0, x1 - x0)
         flag[y0:y1, x0:x1] = near.any(dim=1).reshape(y1 - y0, x1 - x0)
-    return B, E, flag
+    return B, E, flag, J
 
 
 def build(it):
@@ -166,7 +172,7 @@ for it in range(N):
             assert torch.equal(out["ranges"].cpu().to(torch.int64), aux["ranges"]), "tile ranges differ"
             if cond is None:
                 cond = conditioning(aux, s)
-            cB, cE, cflag = cond
+            cB, cE, cflag, cJ = cond
             fr = aux["fragile"] | cflag
             ok = ~fr
             cmax = max(1.0, float(aux["rgb"].abs().max()), float(s.bg.abs().max()))
@@ -192,7 +198,10 @@ for it in range(N):
             desc["metrics"] = m
             assert m["img_over_bar"] <= 1.0, f"image error {m['img']:.3e} = {m['img_over_bar']:.2f} x its bar"
             assert m["invd_over_bar"] <= 1.0, f"inverse-depth error {m['invd_over_bar']:.2f} x its bar"
-            assert m["img_fragile"] <= cmax / 255.0 * 1.01 + float(bar_img.max()), f"fragile-pixel error {m['img_fragile']:.3e}"
+            frag_bar = cmax / 255.0 * 1.01 + float(bar_img.max()) + 2.0 * cmax * cJ      # one alpha quantum, + the entries whose exponent's SIGN is within noise
+            m["img_fragile_over_bar"] = float((err / frag_bar)[fr].max()) if fr.any() else 0.0
+            m["sign_flip_pixels"] = int((cJ > 0).sum())
+            assert m["img_fragile_over_bar"] <= 1.0, f"fragile-pixel error {m['img_fragile']:.3e} = {m['img_fragile_over_bar']:.2f} x its bar"
             if not nb:
                 assert m["n_contrib_mismatch_px"] == 0, f"n_contrib differs at {m['n_contrib_mismatch_px']} pixels off every threshold"
                 assert m["final_T_over_bar"] <= 1.0, f"final_T error {m['final_T_over_bar']:.2f} x its bar"
