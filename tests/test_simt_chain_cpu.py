@@ -48,6 +48,9 @@ CASES = {
     "odd_frame": ("cloud", 5000, 250, 131, 0.03, 5, False),
     "edge_scene": ("edge", 3000, 250, 131, 0.0, 6, False),
     "depth_ties": ("ties", 8000, 320, 240, 0.01, 7, False),
+    # round 5: a narrow bulk + floaters far behind / in front of it, with the per-workgroup key ranges of a 274-workgroup projection launch: ds_hist's
+    # ROBUST key range is narrower than the true one (the floaters sit in workgroups whose group partner has none), the end buckets hold the floaters
+    "depth_outliers": ("outliers", 70000, 320, 240, 0.002, 8, False),
 }
 
 
@@ -63,6 +66,19 @@ def test_binning_chain_source_on_the_cpu_equals_the_oracle_bins(lib, name):
         sc.means3D[:, 0] *= zq / z
         sc.means3D[:, 1] *= zq / z
         sc.means3D[:, 2] = zq
+    if kind == "outliers":
+        g = torch.Generator().manual_seed(seed)
+        z = sc.means3D[:, 2].clone()
+        zn = 4.0 + 0.2 * torch.rand(P, generator=g)
+        far = torch.tensor([3 * 256 + 5, 3 * 256 + 77, 7 * 256 + 1, 260 * 256 + 9, 260 * 256 + 200])      # chunks 3, 7, 260 of 256 Gaussians
+        near = torch.tensor([7 * 256 + 100, 260 * 256 + 30])
+        zn[far] = torch.tensor([900.0, 350.0, 2000.0, 1200.0, 500.0])
+        zn[near] = torch.tensor([0.3, 0.45])
+        f = (zn / z).unsqueeze(1)
+        sc.means3D.mul_(f)
+        sc.scales.mul_(f)
+        sc.opacities[far] = 0.9
+        sc.opacities[near] = 0.9
     s = oracle_settings(cam)
     with (reference_tiles() if ref_rects else contextlib.nullcontext()), torch.no_grad():
         pre = O.preprocess(sc.means3D, sc.opacities, s, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
@@ -79,10 +95,22 @@ def test_binning_chain_source_on_the_cpu_equals_the_oracle_bins(lib, name):
     assert keys[tiles > 0].min() >= 0 and keys[tiles > 0].max() < CULLED - 1, "a listed depth outside the 27-bit key range (the host then re-keys: not this test)"
     keys = keys.astype(np.uint32)
     wg = np.array([[(~np.uint32(keys[tiles > 0].min())) & np.uint32(0xFFFFFFFF), keys[tiles > 0].max()]], dtype=np.uint32)
+    if kind == "outliers":      # what the projection kernel leaves: workgroup w of ceil(P / 256) holds the Gaussians [256 w, 256 w + 256)
+        nwg = (P + 255) // 256
+        wg = np.zeros((nwg, 2), dtype=np.uint32)
+        for w in range(nwg):
+            kk = keys[256 * w:256 * w + 256][tiles[256 * w:256 * w + 256] > 0]
+            if kk.size:
+                wg[w] = ((~np.uint32(kk.min())) & np.uint32(0xFFFFFFFF), kk.max())
+        from test_depthsort_model_cpu import robust_range
+        listed = keys[tiles > 0]
+        rr = robust_range([None if not (a or b) else int(~a & 0xFFFFFFFF) for a, b in wg.tolist()], [None if not (a or b) else int(b) for a, b in wg.tolist()])
+        assert rr[0] > int(listed.min()) and rr[1] < int(listed.max()), "the case must exercise a robust range narrower than the true one"
+        assert ((listed < rr[0]) | (listed > rr[1])).sum() >= 5, "and keys outside it"
     order = np.zeros(P, dtype=np.uint32)
     point_list = np.full(R, 0xFFFFFFFF, dtype=np.uint32)
     ranges = np.full((gx * gy, 2), 0xFFFFFFFF, dtype=np.uint32)
-    got = lib.simt_bin(P, gx, gy, ptr(keys), ptr(tiles), ptr(rect), ptr(wg), 1, R, ptr(order), ptr(point_list), ptr(ranges))
+    got = lib.simt_bin(P, gx, gy, ptr(keys), ptr(tiles), ptr(rect), ptr(wg), int(wg.shape[0]), R, ptr(order), ptr(point_list), ptr(ranges))
     assert got == R, lib.simt_chain_last_error()
     ref_list = bins["point_list"].numpy().astype(np.uint32)
     if not np.array_equal(point_list, ref_list):
