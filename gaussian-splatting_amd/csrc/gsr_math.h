@@ -125,15 +125,19 @@ struct GsrSplat {             // result of the forward preprocess for one Gaussi
     uint32_t clamped;         // bit c set: colour channel c was clamped at 0
 };
 
-GSR_HD void gsr_cov3d(const float* s, float mod, const float* q, float* cov) {
-    const float s0 = mod * s[0], s1 = mod * s[1], s2 = mod * s[2];
-    const float r = q[0], x = q[1], y = q[2], z = q[3];
-    const float R00 = 1.0f - 2.0f * (y * y + z * z), R01 = 2.0f * (x * y - r * z), R02 = 2.0f * (x * z + r * y);
-    const float R10 = 2.0f * (x * y + r * z), R11 = 1.0f - 2.0f * (x * x + z * z), R12 = 2.0f * (y * z - r * x);
-    const float R20 = 2.0f * (x * z - r * y), R21 = 2.0f * (y * z + r * x), R22 = 1.0f - 2.0f * (x * x + y * y);
-    const float M00 = R00 * s0, M01 = R01 * s1, M02 = R02 * s2;
-    const float M10 = R10 * s0, M11 = R11 * s1, M12 = R12 * s2;
-    const float M20 = R20 * s0, M21 = R21 * s1, M22 = R22 * s2;
+// R = the arithmetic type: float in the forward (the oracle's fp32 expression tree, bit for bit), double in the backward's
+// recomputation (see gsr_project_backward).
+template <class R>
+GSR_HD void gsr_cov3d_r(const float* s, float mod, const float* q, R* cov) {
+    const R s0 = (R)mod * (R)s[0], s1 = (R)mod * (R)s[1], s2 = (R)mod * (R)s[2];
+    const R r = q[0], x = q[1], y = q[2], z = q[3];
+    const R one = 1, two = 2;
+    const R R00 = one - two * (y * y + z * z), R01 = two * (x * y - r * z), R02 = two * (x * z + r * y);
+    const R R10 = two * (x * y + r * z), R11 = one - two * (x * x + z * z), R12 = two * (y * z - r * x);
+    const R R20 = two * (x * z - r * y), R21 = two * (y * z + r * x), R22 = one - two * (x * x + y * y);
+    const R M00 = R00 * s0, M01 = R01 * s1, M02 = R02 * s2;
+    const R M10 = R10 * s0, M11 = R11 * s1, M12 = R12 * s2;
+    const R M20 = R20 * s0, M21 = R21 * s1, M22 = R22 * s2;
     cov[0] = M00 * M00 + M01 * M01 + M02 * M02;
     cov[1] = M00 * M10 + M01 * M11 + M02 * M12;
     cov[2] = M00 * M20 + M01 * M21 + M02 * M22;
@@ -141,6 +145,7 @@ GSR_HD void gsr_cov3d(const float* s, float mod, const float* q, float* cov) {
     cov[4] = M10 * M20 + M11 * M21 + M12 * M22;
     cov[5] = M20 * M20 + M21 * M21 + M22 * M22;
 }
+GSR_HD void gsr_cov3d(const float* s, float mod, const float* q, float* cov) { gsr_cov3d_r<float>(s, mod, q, cov); }
 
 // Everything that depends on the Gaussian's position / covariance.  Returns false when the Gaussian is
 // culled (near plane, singular Sigma2D, empty tile rectangle); out.radius/out.tiles are 0 then.
@@ -418,70 +423,89 @@ struct GsrSplatGrad {          // what the render backward accumulates per Gauss
 };
 
 // Inputs: the forward inputs of this Gaussian; Outputs: accumulated into dmean[3], dcov[6], dopacity_in.
-// Returns false if the Gaussian was culled by the near plane (nothing written).
-GSR_HD void gsr_project_backward(const GsrCam& cam, const float* mean, const float* cov, float opacity_in,
-                                 const GsrSplatGrad& g, float* dmean, float* dcov, float& dopacity_in) {
+//
+// R = the arithmetic type of the covariance chain (view-space position -> J -> T -> Sigma2D -> conic and back).  The product
+// instantiates R = double (round 6): the chain is a sequence of cancelling sums on an anisotropic splat -- det = a c - b^2 loses
+// log2(condition number) bits, the 2x2 inverse derivative subtracts terms ~ (a, b, c)^2 / det^2 that are `condition number` times
+// their sum, and Sigma3D's gradient is contracted with the needle's long axis, which cancels again -- so that in fp32 a needle of
+// condition number ~ 1e3 came back with a rotation gradient 2.4e-3 of max |grad| from the fp64 oracle (fuzz seed 71, frame 109,
+// tests/golden/hard_frames.npz) and a scale gradient 8e-4.  In fp64 from the SAME fp32 inputs and the same fp32 per-pair sums of
+// the blend backward the frame is at 6e-5.  The kernel streams 500+ bytes per Gaussian: the extra ALU time hides under the loads.
+// The two frustum-clamp decisions are taken on the fp32 quotients, exactly as the forward took them.
+template <class R>
+GSR_HD void gsr_project_backward_r(const GsrCam& cam, const float* mean, const R* cov, float opacity_in,
+                                   const GsrSplatGrad& g, float* dmean, R* dcov, float& dopacity_in) {
     const float* vm = cam.view;
     const float* pm = cam.proj;
     const float x = mean[0], y = mean[1], z = mean[2];
-    const float pvx = vm[0] * x + vm[4] * y + vm[8] * z + vm[12];
-    const float pvy = vm[1] * x + vm[5] * y + vm[9] * z + vm[13];
-    const float pvz = vm[2] * x + vm[6] * y + vm[10] * z + vm[14];
-    const float txtz = pvx / pvz, tytz = pvy / pvz;
-    const float inx = (txtz < -cam.limx || txtz > cam.limx) ? 0.0f : 1.0f;
-    const float iny = (tytz < -cam.limy || tytz > cam.limy) ? 0.0f : 1.0f;
-    const float tx = fminf(cam.limx, fmaxf(-cam.limx, txtz)) * pvz;
-    const float ty = fminf(cam.limy, fmaxf(-cam.limy, tytz)) * pvz;
-    const float tz = pvz;
-    const float tz2 = tz * tz;
-    const float itz = 1.0f / tz, itz2 = 1.0f / tz2;
-    const float fx = cam.focal_x, fy = cam.focal_y;
-    const float J00 = fx * itz, J02 = -(fx * tx) * itz2, J11 = fy * itz, J12 = -(fy * ty) * itz2;
-    const float W00 = vm[0], W01 = vm[4], W02 = vm[8];
-    const float W10 = vm[1], W11 = vm[5], W12 = vm[9];
-    const float W20 = vm[2], W21 = vm[6], W22 = vm[10];
-    const float T00 = J00 * W00 + J02 * W20, T01 = J00 * W01 + J02 * W21, T02 = J00 * W02 + J02 * W22;
-    const float T10 = J11 * W10 + J12 * W20, T11 = J11 * W11 + J12 * W21, T12 = J11 * W12 + J12 * W22;
-    const float S00 = cov[0], S01 = cov[1], S02 = cov[2], S11 = cov[3], S12 = cov[4], S22 = cov[5];
-    const float u0 = S00 * T00 + S01 * T01 + S02 * T02;
-    const float u1 = S01 * T00 + S11 * T01 + S12 * T02;
-    const float u2 = S02 * T00 + S12 * T01 + S22 * T02;
-    const float v0 = S00 * T10 + S01 * T11 + S02 * T12;
-    const float v1 = S01 * T10 + S11 * T11 + S12 * T12;
-    const float v2 = S02 * T10 + S12 * T11 + S22 * T12;
-    const float a0 = T00 * u0 + T01 * u1 + T02 * u2;
-    const float b = T10 * u0 + T11 * u1 + T12 * u2;
-    const float c0 = T10 * v0 + T11 * v1 + T12 * v2;
-    const float det0 = a0 * c0 - b * b;
-    const float a = a0 + GSR_LOWPASS, c = c0 + GSR_LOWPASS;
-    const float det = a * c - b * b;
+    // the forward's own clamp decisions (fp32, same expression tree as gsr_project)
+    const float pvx32 = vm[0] * x + vm[4] * y + vm[8] * z + vm[12];
+    const float pvy32 = vm[1] * x + vm[5] * y + vm[9] * z + vm[13];
+    const float pvz32 = vm[2] * x + vm[6] * y + vm[10] * z + vm[14];
+    const float txtz32 = pvx32 / pvz32, tytz32 = pvy32 / pvz32;
+    const bool inside_x = !(txtz32 < -cam.limx || txtz32 > cam.limx);
+    const bool inside_y = !(tytz32 < -cam.limy || tytz32 > cam.limy);
+    const R zero = 0, one = 1, two = 2;
+    const R inx = inside_x ? one : zero, iny = inside_y ? one : zero;
+    const R pvx = (R)vm[0] * x + (R)vm[4] * y + (R)vm[8] * z + (R)vm[12];
+    const R pvy = (R)vm[1] * x + (R)vm[5] * y + (R)vm[9] * z + (R)vm[13];
+    const R pvz = (R)vm[2] * x + (R)vm[6] * y + (R)vm[10] * z + (R)vm[14];
+    const R limx = cam.limx, limy = cam.limy;
+    const R cx = inside_x ? pvx / pvz : (txtz32 < 0.0f ? -limx : limx);
+    const R cy = inside_y ? pvy / pvz : (tytz32 < 0.0f ? -limy : limy);
+    const R tx = cx * pvz;
+    const R ty = cy * pvz;
+    const R tz = pvz;
+    const R tz2 = tz * tz;
+    const R itz = one / tz, itz2 = one / tz2;
+    const R fx = cam.focal_x, fy = cam.focal_y;
+    const R J00 = fx * itz, J02 = -(fx * tx) * itz2, J11 = fy * itz, J12 = -(fy * ty) * itz2;
+    const R W00 = vm[0], W01 = vm[4], W02 = vm[8];
+    const R W10 = vm[1], W11 = vm[5], W12 = vm[9];
+    const R W20 = vm[2], W21 = vm[6], W22 = vm[10];
+    const R T00 = J00 * W00 + J02 * W20, T01 = J00 * W01 + J02 * W21, T02 = J00 * W02 + J02 * W22;
+    const R T10 = J11 * W10 + J12 * W20, T11 = J11 * W11 + J12 * W21, T12 = J11 * W12 + J12 * W22;
+    const R S00 = cov[0], S01 = cov[1], S02 = cov[2], S11 = cov[3], S12 = cov[4], S22 = cov[5];
+    const R u0 = S00 * T00 + S01 * T01 + S02 * T02;
+    const R u1 = S01 * T00 + S11 * T01 + S12 * T02;
+    const R u2 = S02 * T00 + S12 * T01 + S22 * T02;
+    const R v0 = S00 * T10 + S01 * T11 + S02 * T12;
+    const R v1 = S01 * T10 + S11 * T11 + S12 * T12;
+    const R v2 = S02 * T10 + S12 * T11 + S22 * T12;
+    const R a0 = T00 * u0 + T01 * u1 + T02 * u2;
+    const R b = T10 * u0 + T11 * u1 + T12 * u2;
+    const R c0 = T10 * v0 + T11 * v1 + T12 * v2;
+    const R det0 = a0 * c0 - b * b;
+    const R a = a0 + (R)GSR_LOWPASS, c = c0 + (R)GSR_LOWPASS;
+    const R det = a * c - b * b;
 
     // --- opacity * aa ---
-    float da = 0.0f, db = 0.0f, dc = 0.0f;   // dL/d(a,b,c) of the low-passed Sigma2D (b = off-diagonal entry)
-    float aa = 1.0f;
+    R da = 0, db = 0, dc = 0;   // dL/d(a,b,c) of the low-passed Sigma2D (b = off-diagonal entry)
+    R aa = 1;
     if (cam.antialiasing) {
-        const float ratio = det0 / det;
-        aa = sqrtf(fmaxf(ratio, GSR_AA_FLOOR));
-        if (ratio > GSR_AA_FLOOR) {
+        const R ratio = det0 / det;
+        const R floor_ = (R)GSR_AA_FLOOR;
+        aa = sqrt(ratio > floor_ ? ratio : floor_);
+        if (ratio > floor_) {
             // opacity = o * sqrt(det0/det): d/d(ratio) = o * 0.5 / aa
-            const float dratio = g.dopacity * opacity_in * 0.5f / aa;
-            const float ddet0 = dratio / det;
-            const float ddet = -dratio * det0 / (det * det);
+            const R dratio = (R)g.dopacity * (R)opacity_in * (R)0.5 / aa;
+            const R ddet0 = dratio / det;
+            const R ddet = -dratio * det0 / (det * det);
             // det0 = a0 c0 - b^2 ; det = a c - b^2 ; a = a0 + h, c = c0 + h
             da += ddet0 * c0 + ddet * c;
             dc += ddet0 * a0 + ddet * a;
-            db += -2.0f * b * (ddet0 + ddet);
+            db += -two * b * (ddet0 + ddet);
         }
     }
-    dopacity_in = g.dopacity * aa;
+    dopacity_in = (float)((R)g.dopacity * aa);
 
     // --- conic = inverse(Sigma2D), reference uses 1/(det^2 + 1e-7) ---
     {
-        const float d2 = 1.0f / (det * det + 1e-7f);
-        const float gA = g.dconA, gB = g.dconB, gC = g.dconC;
+        const R d2 = one / (det * det + (R)1e-7f);
+        const R gA = g.dconA, gB = g.dconB, gC = g.dconC;
         da += d2 * (-c * c * gA + b * c * gB + (det - a * c) * gC);
         dc += d2 * (-a * a * gC + a * b * gB + (det - a * c) * gA);
-        db += d2 * (2.0f * b * c * gA - (det + 2.0f * b * b) * gB + 2.0f * a * b * gC);
+        db += d2 * (two * b * c * gA - (det + two * b * b) * gB + two * a * b * gC);
     }
 
     // --- Sigma2D = T Sigma T^T  (a = T0.S.T0, b = T1.S.T0, c = T1.S.T1) ---
@@ -489,26 +513,26 @@ GSR_HD void gsr_project_backward(const GsrCam& cam, const float* mean, const flo
     dcov[0] += T00 * T00 * da + T00 * T10 * db + T10 * T10 * dc;
     dcov[3] += T01 * T01 * da + T01 * T11 * db + T11 * T11 * dc;
     dcov[5] += T02 * T02 * da + T02 * T12 * db + T12 * T12 * dc;
-    dcov[1] += 2.0f * T00 * T01 * da + (T00 * T11 + T01 * T10) * db + 2.0f * T10 * T11 * dc;
-    dcov[2] += 2.0f * T00 * T02 * da + (T00 * T12 + T02 * T10) * db + 2.0f * T10 * T12 * dc;
-    dcov[4] += 2.0f * T01 * T02 * da + (T01 * T12 + T02 * T11) * db + 2.0f * T11 * T12 * dc;
+    dcov[1] += two * T00 * T01 * da + (T00 * T11 + T01 * T10) * db + two * T10 * T11 * dc;
+    dcov[2] += two * T00 * T02 * da + (T00 * T12 + T02 * T10) * db + two * T10 * T12 * dc;
+    dcov[4] += two * T01 * T02 * da + (T01 * T12 + T02 * T11) * db + two * T11 * T12 * dc;
     // dL/dT: a = sum T0j u_j (u = S T0): da/dT0j = 2 u_j ; b = sum T1j u_j: db/dT1j = u_j, db/dT0j = v_j ; dc/dT1j = 2 v_j
-    const float dT00 = 2.0f * u0 * da + v0 * db, dT01 = 2.0f * u1 * da + v1 * db, dT02 = 2.0f * u2 * da + v2 * db;
-    const float dT10 = 2.0f * v0 * dc + u0 * db, dT11 = 2.0f * v1 * dc + u1 * db, dT12 = 2.0f * v2 * dc + u2 * db;
+    const R dT00 = two * u0 * da + v0 * db, dT01 = two * u1 * da + v1 * db, dT02 = two * u2 * da + v2 * db;
+    const R dT10 = two * v0 * dc + u0 * db, dT11 = two * v1 * dc + u1 * db, dT12 = two * v2 * dc + u2 * db;
     // T0j = J00 W0j + J02 W2j ; T1j = J11 W1j + J12 W2j
-    const float dJ00 = W00 * dT00 + W01 * dT01 + W02 * dT02;
-    const float dJ02 = W20 * dT00 + W21 * dT01 + W22 * dT02;
-    const float dJ11 = W10 * dT10 + W11 * dT11 + W12 * dT12;
-    const float dJ12 = W20 * dT10 + W21 * dT11 + W22 * dT12;
+    const R dJ00 = W00 * dT00 + W01 * dT01 + W02 * dT02;
+    const R dJ02 = W20 * dT00 + W21 * dT01 + W22 * dT02;
+    const R dJ11 = W10 * dT10 + W11 * dT11 + W12 * dT12;
+    const R dJ12 = W20 * dT10 + W21 * dT11 + W22 * dT12;
     // J00 = fx/tz, J02 = -fx tx/tz^2, J11 = fy/tz, J12 = -fy ty/tz^2 ; tx, ty constant w.r.t. tz when clamped
-    const float itz3 = itz2 * itz;
-    float dtx = inx * (-fx * itz2 * dJ02);
-    float dty = iny * (-fy * itz2 * dJ12);
-    float dtz = -fx * itz2 * dJ00 - fy * itz2 * dJ11 + 2.0f * fx * tx * itz3 * dJ02 + 2.0f * fy * ty * itz3 * dJ12;
+    const R itz3 = itz2 * itz;
+    const R dtx = inx * (-fx * itz2 * dJ02);
+    const R dty = iny * (-fy * itz2 * dJ12);
+    R dtz = -fx * itz2 * dJ00 - fy * itz2 * dJ11 + two * fx * tx * itz3 * dJ02 + two * fy * ty * itz3 * dJ12;
     // inverse depth image: D += (1/depth) w  => dL/d(depth) = -dinvdepth / tz^2
-    dtz += -g.dinvdepth * itz2;
+    dtz += -(R)g.dinvdepth * itz2;
 
-    // --- pixel centre through the perspective divide of the full projection ---
+    // --- pixel centre through the perspective divide of the full projection (fp32: no cancellation here) ---
     const float hx = pm[0] * x + pm[4] * y + pm[8] * z + pm[12];
     const float hy = pm[1] * x + pm[5] * y + pm[9] * z + pm[13];
     const float hw = pm[3] * x + pm[7] * y + pm[11] * z + pm[15];
@@ -521,9 +545,14 @@ GSR_HD void gsr_project_backward(const GsrCam& cam, const float* mean, const flo
     dmean[1] += pm[4] * dhx + pm[5] * dhy + pm[7] * dhw;
     dmean[2] += pm[8] * dhx + pm[9] * dhy + pm[11] * dhw;
     // --- view-space position t = W p + t0 ---
-    dmean[0] += W00 * dtx + W10 * dty + W20 * dtz;
-    dmean[1] += W01 * dtx + W11 * dty + W21 * dtz;
-    dmean[2] += W02 * dtx + W12 * dty + W22 * dtz;
+    dmean[0] += (float)(W00 * dtx + W10 * dty + W20 * dtz);
+    dmean[1] += (float)(W01 * dtx + W11 * dty + W21 * dtz);
+    dmean[2] += (float)(W02 * dtx + W12 * dty + W22 * dtz);
+}
+// the all-fp32 form (rounds 1-5; kept for the tests that hold it against the fp32 oracle's autograd operation by operation)
+GSR_HD void gsr_project_backward(const GsrCam& cam, const float* mean, const float* cov, float opacity_in,
+                                 const GsrSplatGrad& g, float* dmean, float* dcov, float& dopacity_in) {
+    gsr_project_backward_r<float>(cam, mean, cov, opacity_in, g, dmean, dcov, dopacity_in);
 }
 
 // SH backward, streaming in groups of 4 coefficients (12 floats = three 16-byte accesses): drgb = dL/d(rgb after clamp).
@@ -611,42 +640,50 @@ GSR_HD void gsr_sh_backward(int deg, int M, const float* sh, const float* mean, 
 
 // Sigma3D = (R S)(R S)^T backward: dcov (independent packed entries) -> dscale[3], drot[4]
 // (w.r.t. the quaternion as given, no normalisation backward).
-GSR_HD void gsr_cov3d_backward(const float* s, float mod, const float* q, const float* dcov, float* dscale, float* drot) {
-    const float s0 = mod * s[0], s1 = mod * s[1], s2 = mod * s[2];
-    const float r = q[0], x = q[1], y = q[2], z = q[3];
-    const float R[3][3] = {{1.0f - 2.0f * (y * y + z * z), 2.0f * (x * y - r * z), 2.0f * (x * z + r * y)},
-                           {2.0f * (x * y + r * z), 1.0f - 2.0f * (x * x + z * z), 2.0f * (y * z - r * x)},
-                           {2.0f * (x * z - r * y), 2.0f * (y * z + r * x), 1.0f - 2.0f * (x * x + y * y)}};
-    const float sv[3] = {s0, s1, s2};
-    float Mm[3][3];
+template <class R>
+GSR_HD void gsr_cov3d_backward_r(const float* s, float mod, const float* q, const R* dcov, float* dscale, float* drot) {
+    const R one = 1, two = 2, four = 4, half = (R)0.5;
+    const R s0 = (R)mod * (R)s[0], s1 = (R)mod * (R)s[1], s2 = (R)mod * (R)s[2];
+    const R r = q[0], x = q[1], y = q[2], z = q[3];
+    const R Rm[3][3] = {{one - two * (y * y + z * z), two * (x * y - r * z), two * (x * z + r * y)},
+                        {two * (x * y + r * z), one - two * (x * x + z * z), two * (y * z - r * x)},
+                        {two * (x * z - r * y), two * (y * z + r * x), one - two * (x * x + y * y)}};
+    const R sv[3] = {s0, s1, s2};
+    R Mm[3][3];
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) Mm[i][j] = R[i][j] * sv[j];
+        for (int j = 0; j < 3; ++j) Mm[i][j] = Rm[i][j] * sv[j];
     // full symmetric gradient matrix G with G_ij = dL/dSigma_ij counting each off-diagonal independent
     // entry once split over both positions: Sigma = M M^T => dL/dM = (G + G^T) M with G upper-packed/2
-    const float G[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
-                           {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
-                           {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
-    float dM[3][3];
+    const R G[3][3] = {{dcov[0], half * dcov[1], half * dcov[2]},
+                       {half * dcov[1], dcov[3], half * dcov[4]},
+                       {half * dcov[2], half * dcov[4], dcov[5]}};
+    R dM[3][3];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
-            float acc = 0.0f;
-            for (int k = 0; k < 3; ++k) acc += 2.0f * G[i][k] * Mm[k][j];
+            R acc = 0;
+            for (int k = 0; k < 3; ++k) acc += two * G[i][k] * Mm[k][j];
             dM[i][j] = acc;
         }
-    float dR[3][3];
+    R dR[3][3];
     for (int j = 0; j < 3; ++j) {
-        float acc = 0.0f;
+        R acc = 0;
         for (int i = 0; i < 3; ++i) {
-            acc += dM[i][j] * R[i][j];
+            acc += dM[i][j] * Rm[i][j];
             dR[i][j] = dM[i][j] * sv[j];
         }
-        dscale[j] = acc * mod;
+        dscale[j] = (float)(acc * (R)mod);
     }
-    drot[0] = 2.0f * (z * (dR[1][0] - dR[0][1]) + y * (dR[0][2] - dR[2][0]) + x * (dR[2][1] - dR[1][2]));
-    drot[1] = 2.0f * (y * (dR[0][1] + dR[1][0]) + z * (dR[0][2] + dR[2][0]) + r * (dR[2][1] - dR[1][2])) -
-              4.0f * x * (dR[1][1] + dR[2][2]);
-    drot[2] = 2.0f * (x * (dR[0][1] + dR[1][0]) + r * (dR[0][2] - dR[2][0]) + z * (dR[1][2] + dR[2][1])) -
-              4.0f * y * (dR[0][0] + dR[2][2]);
-    drot[3] = 2.0f * (r * (dR[1][0] - dR[0][1]) + x * (dR[0][2] + dR[2][0]) + y * (dR[1][2] + dR[2][1])) -
-              4.0f * z * (dR[0][0] + dR[1][1]);
+    drot[0] = (float)(two * (z * (dR[1][0] - dR[0][1]) + y * (dR[0][2] - dR[2][0]) + x * (dR[2][1] - dR[1][2])));
+    drot[1] = (float)(two * (y * (dR[0][1] + dR[1][0]) + z * (dR[0][2] + dR[2][0]) + r * (dR[2][1] - dR[1][2])) -
+                      four * x * (dR[1][1] + dR[2][2]));
+    drot[2] = (float)(two * (x * (dR[0][1] + dR[1][0]) + r * (dR[0][2] - dR[2][0]) + z * (dR[1][2] + dR[2][1])) -
+                      four * y * (dR[0][0] + dR[2][2]));
+    drot[3] = (float)(two * (r * (dR[1][0] - dR[0][1]) + x * (dR[0][2] + dR[2][0]) + y * (dR[1][2] + dR[2][1])) -
+                      four * z * (dR[0][0] + dR[1][1]));
 }
+GSR_HD void gsr_cov3d_backward(const float* s, float mod, const float* q, const float* dcov, float* dscale, float* drot) {
+    gsr_cov3d_backward_r<float>(s, mod, q, dcov, dscale, drot);
+}
+
+// The arithmetic type of the per-Gaussian backward's covariance chain in the product (gsr_project_backward_r's header comment).
+typedef double GsrBwdReal;

@@ -24,8 +24,14 @@ namespace {
 #ifndef GSR_PRE_OCC_FWD
 #define GSR_PRE_OCC_FWD
 #endif
+// Round 6: the backward's covariance chain runs in fp64 (gsr_math.h gsr_project_backward_r); left alone the split-SH instantiation
+// allocates 259 registers = ONE wave per SIMD.  Pinned at two waves per SIMD every instantiation fits 256 without a spill.
 #ifndef GSR_PRE_OCC_BWD
+#ifdef GSR_SIMT_SHIM      // (tests/simt: the kernel source compiled for the host)
 #define GSR_PRE_OCC_BWD
+#else
+#define GSR_PRE_OCC_BWD __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 #endif
 
 constexpr int SH_ROW = 52;        // LDS row stride in floats for a 48-float SH record (52*l mod 64 hits 16 distinct bank quads)
@@ -420,7 +426,7 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         const int64_t i = i0 + lane;
         const bool in_range = i < P;
         float dmean[3] = {0.f, 0.f, 0.f};
-        float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // (what is stored; the chain itself runs in GsrBwdReal, gsr_math.h)
         float dscale[3] = {0.f, 0.f, 0.f};
         float drot[4] = {0.f, 0.f, 0.f, 0.f};
         float dop = 0.f;
@@ -456,15 +462,21 @@ preprocess_bwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
             g.dconC = g1.x; g.dopacity = g1.y; g.dr = g1.z; g.dg = g1.w;
             g.db = g2.x; g.dinvdepth = g2.y;
             drgb[0] = g.dr; drgb[1] = g.dg; drgb[2] = g.db;
+            GsrBwdReal covr[6], dcovr[6] = {0, 0, 0, 0, 0, 0};
             if (!cov3D_precomp) {
                 q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
-                gsr_cov3d(s, cam.scale_modifier, q, cov);
+                gsr_cov3d_r<GsrBwdReal>(s, cam.scale_modifier, q, covr);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) covr[k] = cov[k];
             }
-            gsr_project_backward(cam, mean, cov, op_in, g, dmean, dcov, dop);
+            gsr_project_backward_r<GsrBwdReal>(cam, mean, covr, op_in, g, dmean, dcovr, dop);
             // the returned means2D gradient is in NDC-scaled units (SURVEY A.5 units trap)
             dm2x = g.dpx * (0.5f * (float)cam.W);
             dm2y = g.dpy * (0.5f * (float)cam.H);
-            if (!cov3D_precomp) gsr_cov3d_backward(s, cam.scale_modifier, q, dcov, dscale, drot);
+            if (!cov3D_precomp) gsr_cov3d_backward_r<GsrBwdReal>(s, cam.scale_modifier, q, dcovr, dscale, drot);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dcov[k] = (float)dcovr[k];
         }
         if (vis) {
             if (shs) {

@@ -78,13 +78,15 @@ void host_preprocess_backward(const HostCam* hc, int P, const float* means, cons
             g.dpx = gi[0]; g.dpy = gi[1]; g.dconA = gi[2]; g.dconB = gi[3]; g.dconC = gi[4]; g.dopacity = gi[5];
             g.dr = gi[6]; g.dg = gi[7]; g.db = gi[8]; g.dinvdepth = gi[9];
             drgb[0] = g.dr; drgb[1] = g.dg; drgb[2] = g.db;
-            float cov[6];
-            if (cov_pre) memcpy(cov, cov_pre + 6 * i, sizeof(cov));
-            else gsr_cov3d(scales + 3 * i, cam.scale_modifier, rots + 4 * i, cov);
-            gsr_project_backward(cam, means + 3 * i, cov, opac[i], g, dmean, dcov, dop);
+            // the product's arithmetic (csrc/preprocess.hip preprocess_bwd_kernel): covariance chain in GsrBwdReal
+            GsrBwdReal cov[6], dcovr[6] = {0, 0, 0, 0, 0, 0};
+            if (cov_pre) for (int k = 0; k < 6; ++k) cov[k] = cov_pre[6 * i + k];
+            else gsr_cov3d_r<GsrBwdReal>(scales + 3 * i, cam.scale_modifier, rots + 4 * i, cov);
+            gsr_project_backward_r<GsrBwdReal>(cam, means + 3 * i, cov, opac[i], g, dmean, dcovr, dop);
             dm2x = g.dpx * (0.5f * (float)cam.W);
             dm2y = g.dpy * (0.5f * (float)cam.H);
-            if (!cov_pre) gsr_cov3d_backward(scales + 3 * i, cam.scale_modifier, rots + 4 * i, dcov, dscale, drot);
+            if (!cov_pre) gsr_cov3d_backward_r<GsrBwdReal>(scales + 3 * i, cam.scale_modifier, rots + 4 * i, dcovr, dscale, drot);
+            for (int k = 0; k < 6; ++k) dcov[k] = (float)dcovr[k];
             if (shs) {
                 gsr_sh_backward(cam.sh_degree, cam.M, shs + (size_t)i * cam.M * 3, means + 3 * i, cam.campos, clamped[i], drgb,
                                 dsh + (size_t)i * cam.M * 3, dmean);

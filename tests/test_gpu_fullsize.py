@@ -209,13 +209,16 @@ def test_config1_1M_1080p_backward_on_sampled_tiles():
     _backward_case(1_000_000, 1920, 1080, 96, "configs[1] 1M@1080p")
 
 
+MAX_ADJUDICATED = 8      # pixels per frame that may differ from the fp32 oracle by more than 1e-5 OUTSIDE its fragile mask; each must be within 1e-5 of its fp64 blend
+
+
 def _fp64_adjudicate(pre, bins, pixels, hip_color, oracle_color, s):
     """Blend the tiles of `pixels` ([k, 2] rows of (y, x)) in fp64 from the oracle's fp32 per-Gaussian outputs; per pixel the distance
     of the kernel's and of the fp32 oracle's colour from the fp64 colour (max over channels)."""
     gx = pre["grid"][0]
     res = []
     bg = s.bg.detach().cpu().double().reshape(3)
-    for y, x in pixels.tolist()[:8]:
+    for y, x in pixels.tolist():
         t = (y // 16) * gx + x // 16
         a, b = int(bins["ranges"][t, 0]), int(bins["ranges"][t, 1])
         ids = bins["point_list"][a:b]
@@ -259,11 +262,14 @@ def _whole_frame_case(P, W, H, name, kind="uniform"):
     # and the fp32 oracle (torch's blocked .sum() over the list) is closer to it is the better fp32 evaluation; the 1e-5 bar is held
     # against the fp64 value.
     outside = torch.nonzero(over & ~frag)
+    # (the budget is on the pixels FOUND, and every one of them is adjudicated -- round 5 looked at the first 8 in raster
+    # order and asserted the length of that list, which let any number of others through.  Measured: 0 / 0 / 0 / 1 on the four configs.)
+    assert outside.shape[0] <= MAX_ADJUDICATED, f"{outside.shape[0]} pixels beyond 1e-5 outside the fragile mask (budget {MAX_ADJUDICATED})"
     if outside.numel():
         m["fp64_adjudication"] = _fp64_adjudicate(pre, bins, outside, out["color"].cpu(), col, s)
     _report(f"{name}/whole frame", **m)
     if outside.numel():
-        assert len(m["fp64_adjudication"]) <= 8
+        assert len(m["fp64_adjudication"]) == outside.shape[0]
         for a in m["fp64_adjudication"]:
             assert a["hip_minus_fp64"] <= IMG_TOL, f"pixel {a['pixel']}: kernel is {a['hip_minus_fp64']:.3e} from the fp64 blend"
     else:

@@ -1,0 +1,124 @@
+"""The frames the randomised whole-operator cross-check reported as hard (round 5), frozen in tests/golden/hard_frames.npz
+(tests/golden/make_golden_hard_frames.py): needle piles where fp32 stops resolving the blend.  The operator's gradients are held against
+the ORACLE'S AUTOGRAD EVALUATED IN FP64 on the same fp32 inputs:
+
+    |grad - grad64| <= max(1e-3, 1.5 x the fp32 oracle's own distance from grad64) x max |grad64|        per input tensor
+
+-- i.e. 1e-3 wherever fp32 can resolve the frame at all (the fp32 oracle is within 6.7e-4), and never worse than 1.5 x what an fp32
+evaluation of the same algorithm loses.  Frame 71_109 is the one round 5's library FAILED (rotation gradient 2.4e-3 from fp64, fp32 oracle
+3.2e-4): the per-Gaussian backward's covariance chain now runs in fp64 (csrc/gsr_math.h gsr_project_backward_r).
+
+GPU leg: through the shipped package on cuda:0.  CPU leg (`-m "not gpu"`): the same kernel source through tests/simt on the two small
+frames -- a checker of the source in the build container, not a CPU path of the product."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import O, parity_report
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hard_frames.npz")
+_z = None
+
+
+def _gold():
+    global _z
+    if _z is None:
+        _z = np.load(GOLD, allow_pickle=False)
+    return _z
+
+
+def frame_keys():
+    return [str(k) for k in _gold()["frames"]]
+
+
+def load_frame(key):
+    z = _gold()
+    pre = key + "/"
+    st = {k[len(pre) + 9:]: z[k] for k in z.files if k.startswith(pre + "settings/")}
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))      # noqa: E731
+    s = O.Settings(int(st["image_height"]), int(st["image_width"]), float(st["tanfovx"]), float(st["tanfovy"]), t(st["bg"]),
+                   float(st["scale_modifier"]), t(st["viewmatrix"]), t(st["projmatrix"]), int(st["sh_degree"]), t(st["campos"]),
+                   bool(st["prefiltered"]), bool(st["debug"]), bool(st["antialiasing"]))
+    ins = {k[len(pre) + 3:]: t(z[k]) for k in z.files if k.startswith(pre + "in/")}
+    g64 = {k[len(pre) + 7:]: t(z[k]) for k in z.files if k.startswith(pre + "grad64/")}
+    o32 = {k[len(pre) + 8:]: float(z[k]) for k in z.files if k.startswith(pre + "o32_err/")}
+    wd = t(z[pre + "wd"]) if bool(z[pre + "use_depth"]) else None
+    return dict(s=s, ins=ins, grad64=g64, o32_err=o32, wc=t(z[pre + "wc"]), wd=wd, radii=t(z[pre + "radii"]), kind=str(z[pre + "kind"]),
+                form=str(z[pre + "form"]))
+
+
+def operator_gradients(fr, settings_cls, rasterizer_cls, dev):
+    """The frame through the operator's public call (gaussian_renderer/__init__.py:91-110's keyword form) + loss.backward()."""
+    s = fr["s"]
+    rs = settings_cls(s.image_height, s.image_width, s.tanfovx, s.tanfovy, s.bg.to(dev), s.scale_modifier, s.viewmatrix.to(dev),
+                      s.projmatrix.to(dev), s.sh_degree, s.campos.to(dev), False, True, s.antialiasing)
+    L = {k: v.clone().to(dev).requires_grad_(True) for k, v in fr["ins"].items()}
+    L["means2D"] = torch.zeros(L["means3D"].shape[0], 3, device=dev, requires_grad=True)
+    kw = {k: v for k, v in L.items() if k not in ("means3D", "means2D", "opacities")}
+    col, radii, invd = rasterizer_cls(raster_settings=rs)(means3D=L["means3D"], means2D=L["means2D"], opacities=L["opacities"], **kw)
+    loss = (col * fr["wc"].to(dev)).sum()
+    if fr["wd"] is not None:
+        loss = loss + (invd * fr["wd"].to(dev)).sum()
+    loss.backward()
+    return L, radii
+
+
+def hold_to_fp64(key, fr, L, radii, where):
+    assert torch.equal(radii.cpu().to(torch.int32), fr["radii"]), "radii differ from the oracle's"
+    report = {}
+    for k, v in L.items():
+        assert v.grad is not None and torch.isfinite(v.grad).all(), f"{k}: missing or non-finite gradient"
+    for k, g64 in fr["grad64"].items():
+        a = L[k].grad
+        assert a is not None, f"{k}: no gradient from the operator"
+        a = a.detach().cpu().double()
+        assert torch.isfinite(a).all(), f"{k}: non-finite gradient"
+        scale = g64.abs().max().item()
+        if scale == 0.0:
+            assert a.abs().max().item() <= 1e-12, f"{k}: the oracle's gradient is zero, the operator's is not"
+            continue
+        e = ((a - g64).abs().max() / scale).item()
+        report[k] = (float(f"{e:.3e}"), float(f"{fr['o32_err'][k]:.3e}"))
+        if fr["kind"] == "extreme_needles":
+            continue      # (condition numbers >= 1e5: bins bit-exact, gradients finite -- the fuzzer's contract for this kind)
+        bar = max(1e-3, 1.5 * fr["o32_err"][k])
+        assert e <= bar, f"{key} {k}: {e:.3e} of max |grad| from the fp64 oracle (bar {bar:.3e}; the fp32 oracle: {fr['o32_err'][k]:.3e})"
+    parity_report(f"hard_frame_{key}_{where}", kind=fr["kind"], form=fr["form"], kernel_vs_fp64__fp32_oracle_vs_fp64=report)
+    return report
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", frame_keys())
+def test_hard_frame_gradients_against_the_fp64_oracle_on_the_gpu(key):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    fr = load_frame(key)
+    L, radii = operator_gradients(fr, GaussianRasterizationSettings, GaussianRasterizer, torch.device("cuda:0"))
+    torch.cuda.synchronize()
+    rep = hold_to_fp64(key, fr, L, radii, "gpu")
+    if key == "71_109":      # round 5's recorded failure: now well inside 1e-3 on every tensor
+        assert max(v[0] for v in rep.values()) <= 1e-3
+
+
+@pytest.mark.parametrize("key", ["71_109", "71_32"])
+def test_hard_frame_gradients_against_the_fp64_oracle_kernel_source_on_the_cpu(key):
+    import simt_build
+    from test_simt_package_cpu import package_on_the_cpu
+    fr = load_frame(key)
+    with package_on_the_cpu(simt_build.build_library()) as pkg:
+        L, radii = operator_gradients(fr, pkg.GaussianRasterizationSettings, pkg.GaussianRasterizer, torch.device("cpu"))
+    rep = hold_to_fp64(key, fr, L, radii, "simt_cpu")
+    if key == "71_109":
+        assert max(v[0] for v in rep.values()) <= 1e-3
+
+
+def test_fixture_is_what_the_generator_makes():
+    """The stored inputs are the fuzzer's frames (tests/fuzz_frames.py replays its draws): the small frame is rebuilt and compared."""
+    import fuzz_frames as F
+    f = F.frame(71, 109)
+    fr = load_frame("71_109")
+    assert fr["kind"] == f.kind == "needles" and fr["form"] == f.form
+    assert torch.equal(fr["ins"]["scales"], f.sc.scales) and torch.equal(fr["ins"]["rotations"], f.sc.rotations)
+    assert torch.equal(fr["wc"], f.wc) and torch.equal(fr["wd"], f.wd)
+    assert torch.equal(fr["s"].viewmatrix, f.s.viewmatrix) and fr["s"].scale_modifier == f.s.scale_modifier

@@ -14,7 +14,6 @@ Test infrastructure (imports oracle/ through tests/helpers.py), not product code
 import json
 import math
 import os
-import random
 import sys
 import time
 import traceback
@@ -22,7 +21,8 @@ import traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
-from helpers import O, make_camera, look_at_camera, make_scene, make_edge_scene, oracle_settings
+from helpers import O
+from fuzz_frames import FrameStream
 DRY = not torch.cuda.is_available()      # build container: only the scene generation and the oracle side run (a syntax / shape check)
 if not DRY:
     from test_gpu_parity import gpu_settings, check_forward
@@ -31,7 +31,6 @@ if not DRY:
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-rng = random.Random(SEED)
 dev = torch.device("cpu" if DRY else "cuda:0")
 stats = {"frames": 0, "backward_checked": 0, "kinds": {}, "forms": {}, "max_P": 0, "max_R": 0, "worst_image_err": 0.0,
          "worst_grad_err": 0.0, "failures": [], "adjudicated_by_fp64": []}
@@ -95,57 +94,21 @@ def conditioning(aux, s_):
     return B, E, flag, J
 
 
-def build(it):
-    W, H = rng.choice([(64, 48), (17, 9), (1, 40), (300, 2), (250, 131), (333, 200), (16, 16), (129, 65), (480, 270), (31, 257)])
-    fov = rng.choice([25.0, 45.0, 60.0, 90.0, 110.0])
-    if rng.random() < 0.5:
-        cam = make_camera(W, H, fovx_deg=fov)
-    else:
-        eye = (rng.uniform(-0.6, 0.6), rng.uniform(-0.6, 0.6), rng.uniform(-1.5, 0.5))
-        cam = look_at_camera(W, H, eye, (rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), 3.0), fovx_deg=fov)
-    kind = rng.choice(["cloud", "cloud", "edge", "huge", "needles", "extreme_needles", "single"])
-    P = {"single": 1, "huge": rng.randint(2, 40)}.get(kind, int(10 ** rng.uniform(0.3, 3.3)))
-    max_deg = rng.choice([3, 3, 3, 0, 1, 2])
-    if kind == "edge":
-        sc = make_edge_scene(max(P, 8), cam, seed=100 + it)
-        max_deg = 3
-    else:
-        sc = make_scene(P, cam, seed=100 + it, s_med=10 ** rng.uniform(-2.2, -0.9), max_sh_degree=max_deg)
-    g = torch.Generator().manual_seed(it)
-    if kind == "huge":          # splats much larger than the frame (radius clamps, every tile touched)
-        sc.scales.mul_(rng.choice([30.0, 100.0]))
-    elif kind == "needles":     # one axis 10-40x the others: rectangles mostly empty
-        sc.scales[:, 0].mul_(rng.choice([5.0, 20.0]))
-        sc.scales[:, 1:].mul_(0.5)
-    elif kind == "extreme_needles":     # 250-1500x: conics with condition numbers of 1e5 and more -- bins bit-exact, image / gradients only loosely
-        sc.scales[:, 0].mul_(rng.choice([50.0, 300.0]))
-        sc.scales[:, 1:].mul_(0.2)
-    return cam, sc, kind, max_deg, g
-
-
 BUDGET_S = float(os.environ.get("FUZZ_SECONDS", "1e9"))      # stop (and report) after this much wall clock
+stream = FrameStream(SEED)      # tests/fuzz_frames.py: the frame generator (replayable: a reported (seed, it) can be rebuilt anywhere)
 for it in range(N):
     if time.time() - t0 > BUDGET_S:
         stats["stopped_after_seconds"] = BUDGET_S
         break
     desc = {"it": it}
     try:
-        cam, sc, kind, max_deg, g = build(it)
-        P = sc.P
-        H, W = cam.image_height, cam.image_width
-        deg = rng.randint(0, max_deg)
-        opts = dict(bg=torch.rand(3, generator=g) if rng.random() < 0.7 else None, sh_degree=deg,
-                    scale_modifier=rng.choice([1.0, 1.0, 0.5, 1.7]), antialiasing=rng.random() < 0.4)
-        s = oracle_settings(cam, **opts)
-        colors_form = rng.random() < 0.25
-        cov_form = rng.random() < 0.25
-        split_form = (not colors_form) and rng.random() < 0.4
-        use_depth = rng.random() < 0.5
-        form = ("colors" if colors_form else ("split_sh" if split_form else "shs")) + ("+cov" if cov_form else "")
+        fr_ = next(stream)
+        cam, sc, kind, max_deg, g = fr_.cam, fr_.sc, fr_.kind, fr_.max_deg, fr_.g
+        P, H, W, deg, opts, s = fr_.P, fr_.H, fr_.W, fr_.deg, fr_.opts, fr_.s
+        colors_form, cov_form, split_form, use_depth, form = fr_.colors_form, fr_.cov_form, fr_.split_form, fr_.use_depth, fr_.form
         desc.update(kind=kind, P=P, W=W, H=H, form=form, deg=deg, max_deg=max_deg, aa=opts["antialiasing"], depth=use_depth,
                     scale_modifier=opts["scale_modifier"])
-        colors = torch.rand(P, 3, generator=g) if colors_form else None
-        cov = O.compute_cov3d(sc.scales, sc.rotations, s.scale_modifier, torch.float32) if cov_form else None
+        colors, cov = fr_.colors, fr_.cov
 
         # ---- forward: integers bit-exact, image within the bar (whole frame, the oracle's fragile mask) ----
         with torch.no_grad():
