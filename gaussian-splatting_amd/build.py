@@ -96,9 +96,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
+    linked = bool(jobs or force or _stale(LIB, objs))
+    if linked:
         run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs +
             ["-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
+    if verbose:
+        print(f"[build] {os.path.relpath(LIB, ROOT)}: compiled {len(jobs)} of {len(UNITS)} translation units for {ARCH}"
+              f" ({', '.join(os.path.basename(c[-3]) for c in jobs) or 'all objects up to date'}); {'linked' if linked else 'library up to date'}", flush=True)
     return LIB
 
 

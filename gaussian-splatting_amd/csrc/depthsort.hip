@@ -7,8 +7,13 @@
 // peak, 12 us more for the scan).  Bytes are irrelevant; the number of dependent launches is the cost.
 //
 //   ds_hist     per workgroup of 4096 keys: histogram over 2048 depth buckets of (a) the keys, (b) their tile counts.
-//               The bucket of a key is (key - kmin) >> shift with kmin / kmax from the key-producing kernel (gsr_frame.h), so
-//               the 2046 usable buckets always span exactly the frame's depth range; Gaussians without a tile take
+//               The bucket of a key comes from a HISTOGRAM-EQUALISED table (round 6): the key space is cut into 1024 coarse bins
+//               (64 per octave of depth); the key-producing kernel's first 16 workgroups leave the coarse histogram of their keys
+//               (a regular sample of the frame, gsr_frame.h); every coarse bin inside the frame's true key range gets one bucket and
+//               the rest of the 2046 usable ones are handed out in proportion to the sampled mass; inside a coarse bin the buckets
+//               are uniform.  Buckets then hold about P / 2046 keys whatever the depth distribution is -- floaters 100x behind the
+//               scene, a wall, a cluster (rounds 4-5: uniform buckets over the key range, then over a "robust" range; a trained
+//               scene still crowded a bucket on every frame and lived on the LSD fallback).  Gaussians without a tile take
 //               bucket 2047 and end up behind everything else, as in the LSD sort.
 //   ds_scan     per bucket: exclusive prefix of the counts over the workgroups (in place) + the bucket totals of both tables
 //   ds_scatter  stable scatter (wave64 ballot ranking, no atomics) of (key, id) pairs into bucket order; the tile-less
@@ -46,19 +51,26 @@ constexpr int DS_PASS_BITS = 9;
 constexpr int DS_PASS_BINS = 1 << DS_PASS_BITS;
 static_assert(DS_IPT == 16 && DS_DPT == 8, "layout");
 
-// smallest shift with (kmax - kmin) >> shift <= 2046 (bucket 2047 is reserved)
-__device__ __forceinline__ int ds_shift(uint32_t kmin, uint32_t kmax) {
-    if (kmax <= kmin) return 0;
-    const uint32_t range = kmax - kmin;
-    int s = 32 - __clz((int)range) - GSR_DS_BITS;
-    if (s < 0) s = 0;
-    if ((range >> s) > (uint32_t)DS_NB - 2u) ++s;
-    return s;
+// eq[b] = first bucket | buckets << 16 of coarse bin b (LDS, GSR_EQ_BINS words).  Monotone in the key; every key inside the frame's true
+// range lies in a coarse bin that owns at least one bucket.
+__device__ __forceinline__ uint32_t ds_bucket(uint32_t key, const uint32_t* eq) {
+    if (key == GSR_DEPTH_KEY_CULLED) return DS_CULL;
+    const uint32_t e = eq[key >> GSR_EQ_SHIFT];
+    return (e & 0xFFFFu) + (((key & ((1u << GSR_EQ_SHIFT) - 1u)) * (e >> 16)) >> GSR_EQ_SHIFT);
 }
-// kmin / kmax are the ROBUST key range (ds_hist): the few keys outside it share the first / last usable bucket, whose segments
-// are sorted on their full keys like any other (the mapping stays monotone in the key, so the order does not change)
-__device__ __forceinline__ uint32_t ds_bucket(uint32_t key, uint32_t kmin, int shift) {
-    return key == GSR_DEPTH_KEY_CULLED ? DS_CULL : min((max(key, kmin) - kmin) >> shift, (uint32_t)DS_NB - 2u);
+// smallest key that maps to bucket d (d below the number of buckets in use): binary search for the coarse bin that owns d
+__device__ __forceinline__ uint32_t ds_bucket_first_key(uint32_t d, const uint32_t* eq) {
+    uint32_t lo = 0, hi = GSR_EQ_BINS;      // first coarse bin whose first bucket is > d
+#pragma unroll 1
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((eq[mid] & 0xFFFFu) > d) hi = mid; else lo = mid + 1;
+    }
+    const uint32_t b = lo - 1u;             // (the last bin that starts at or before d: it owns buckets, the empty ones behind it start later)
+    const uint32_t e = eq[b], nb = e >> 16, j = d - (e & 0xFFFFu);
+    // smallest x with (x * nb) >> SHIFT >= j
+    const uint32_t x = nb ? ((j << GSR_EQ_SHIFT) + nb - 1u) / nb : 0u;
+    return (b << GSR_EQ_SHIFT) + x;
 }
 
 // four consecutive words, vector load when whole (p + e0 is 16-byte aligned: e0 is a multiple of 4, arrays are 128-byte aligned)
@@ -74,19 +86,28 @@ __device__ __forceinline__ void load4(const uint32_t* __restrict__ p, int64_t e0
 
 // ---- D1 ------------------------------------------------------------------------------------------------------------
 // Every workgroup first reduces the per-workgroup key ranges the key-producing kernel left (gsr_frame.h; <= 2047 entries of
-// 8 bytes, one load round in the shadow of the key loads) to the frame's kmin / kmax; workgroup 0 stores them in frame[2..3] for
-// the kernels that follow.
+// 8 bytes) to the frame's true key range and sums the <= 16 coarse sample histograms (<= 32 KB, 16-byte loads) into the
+// equalised bucket table -- one load round in the shadow of the key loads, the same integers in every workgroup; workgroup 0
+// stores range and table for the kernels that follow.
 __global__ void __launch_bounds__(DS_THREADS)
 ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tiles, uint32_t* __restrict__ frame,
-        const uint2* __restrict__ wg_range, int n_range, uint32_t* __restrict__ cnt_tab, uint32_t* __restrict__ tile_tab) {
+        const uint2* __restrict__ wg_range, int n_range, const uint16_t* __restrict__ sample_hist, uint32_t* __restrict__ eq_tab,
+        uint32_t* __restrict__ cnt_tab, uint32_t* __restrict__ tile_tab) {
     __shared__ uint32_t h_cnt[DS_NB], h_tile[DS_NB];
-    __shared__ uint32_t s_nmin[WG_WAVES], s_max[WG_WAVES], s_rnmin[WG_WAVES], s_rmax[WG_WAVES];
+    __shared__ __attribute__((aligned(16))) uint32_t s_eq[GSR_EQ_BINS];
+    __shared__ uint32_t s_nmin[WG_WAVES], s_max[WG_WAVES], s_w[WG_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * DS_ITEMS;
+    static_assert(GSR_EQ_BINS == 4 * DS_THREADS, "thread t owns the coarse bins 4t .. 4t+3");
     uint32_t k[4][4], t[4][4];
     uint2 rg[8];
+    uint2 sh[GSR_EQ_SAMPLE_WGS];
+    const int n_samp = n_range < GSR_EQ_SAMPLE_WGS ? n_range : GSR_EQ_SAMPLE_WGS;
 #pragma unroll
     for (int j = 0; j < 8; ++j) rg[j] = wg_range[min(j * DS_THREADS + tid, n_range - 1)];      // (clamped: duplicates do not change a max)
+#pragma unroll
+    for (int j = 0; j < GSR_EQ_SAMPLE_WGS; ++j)      // four 16-bit counts per row (clamped row: masked below)
+        sh[j] = reinterpret_cast<const uint2*>(sample_hist + (size_t)min(j, n_samp - 1) * GSR_EQ_BINS)[tid];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {      // all loads first, the LDS clear rides in their shadow
         const int64_t e0 = base + ((int64_t)v * DS_THREADS + tid) * 4;
@@ -98,44 +119,79 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
         h_cnt[i * DS_THREADS + tid] = 0u;
         h_tile[i * DS_THREADS + tid] = 0u;
     }
-    {
-        // The frame's TRUE key range (max over all workgroups) and a ROBUST one (a handful of far outliers stretches the
-        // true range until the bulk of the scene shares a few buckets, whose oversized segments take the slow path): a thread's <= 8
-        // workgroups form a group; the group's SMALLEST workgroup maximum ignores an outlier unless every workgroup of the group has
-        // one, and the largest of these over the groups is the robust maximum (likewise the minimum, on ~kmin).  Every workgroup of the
-        // key-producing kernel samples the whole array (grid-stride), so its extremes are ~1/1000 quantiles of the frame: about that
-        // fraction of the keys falls outside the robust range and shares the two end buckets.
-        uint32_t nm = 0, mx = 0, gnm = 0xFFFFFFFFu, gmx = 0xFFFFFFFFu;
+    {   // the frame's true key range
+        uint32_t nm = 0, mx = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             nm = max(nm, rg[j].x);
             mx = max(mx, rg[j].y);
-            const bool have = j * DS_THREADS + tid < n_range && (rg[j].x | rg[j].y) != 0u;      // (0, 0): the workgroup listed nothing
-            gnm = min(gnm, have ? rg[j].x : 0xFFFFFFFFu);
-            gmx = min(gmx, have ? rg[j].y : 0xFFFFFFFFu);
         }
-        if (gmx == 0xFFFFFFFFu) { gnm = 0u; gmx = 0u; }      // a group without a listing workgroup takes no part in the maxima
         nm = wave_incl_max_u32(nm);
         mx = wave_incl_max_u32(mx);
-        gnm = wave_incl_max_u32(gnm);
-        gmx = wave_incl_max_u32(gmx);
-        if (lane == 63) { s_nmin[w] = nm; s_max[w] = mx; s_rnmin[w] = gnm; s_rmax[w] = gmx; }
+        if (lane == 63) { s_nmin[w] = nm; s_max[w] = mx; }
     }
     __syncthreads();
     const uint32_t tmin = ~max(max(s_nmin[0], s_nmin[1]), max(s_nmin[2], s_nmin[3]));
     const uint32_t tmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-    uint32_t kmin = ~max(max(s_rnmin[0], s_rnmin[1]), max(s_rnmin[2], s_rnmin[3]));
-    uint32_t kmax = max(max(s_rmax[0], s_rmax[1]), max(s_rmax[2], s_rmax[3]));
-    if (kmax <= kmin || kmin < tmin || kmax > tmax) { kmin = tmin; kmax = tmax; }      // nothing to be robust about (few workgroups, one key, ...)
-    if (blockIdx.x == 0 && tid == 0) { frame[2] = kmin; frame[3] = kmax; frame[6] = tmin; frame[7] = tmax; }
-    const int shift = ds_shift(kmin, kmax);
+    {   // equalised table: coarse bin b in [b_lo, b_hi] gets 1 + floor(spare * c[b] / C) buckets, c = sampled keys of the bin
+        const bool any = tmax >= tmin;      // (nothing listed: tmin = 0xFFFFFFFF, tmax = 0)
+        const uint32_t b_lo = any ? tmin >> GSR_EQ_SHIFT : 0u, b_hi = any ? min(tmax >> GSR_EQ_SHIFT, (uint32_t)GSR_EQ_BINS - 1u) : 0u;
+        uint32_t c[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < GSR_EQ_SAMPLE_WGS; ++j) {
+            if (j < n_samp) {
+                c[0] += sh[j].x & 0xFFFFu; c[1] += sh[j].x >> 16;
+                c[2] += sh[j].y & 0xFFFFu; c[3] += sh[j].y >> 16;
+            }
+        }
+        uint32_t csum = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t b = 4u * (uint32_t)tid + (uint32_t)i;
+            if (b < b_lo || b > b_hi) c[i] = 0u;      // (a sampled key outside the range cannot exist; an unwritten row could)
+            csum += c[i];
+        }
+        const uint32_t cincl = wave_incl_scan_u32(csum, lane);
+        if (lane == 63) s_w[w] = cincl;
+        __syncthreads();
+        const uint32_t C = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        const uint32_t nbins = b_hi - b_lo + 1u, spare = (uint32_t)DS_NB - 2u - nbins;      // >= 1022
+        uint32_t nb[4], nsum = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t b = 4u * (uint32_t)tid + (uint32_t)i;
+            const bool in = b >= b_lo && b <= b_hi;
+            // (spare * c <= 2046 * 16 * 65535 < 2^32)
+            nb[i] = in ? 1u + (C ? (spare * c[i]) / C : spare / nbins) : 0u;
+            nsum += nb[i];
+        }
+        const uint32_t nincl = wave_incl_scan_u32(nsum, lane);
+        __syncthreads();
+        if (lane == 63) s_w[w] = nincl;
+        __syncthreads();
+        uint32_t run = nincl - nsum;
+#pragma unroll
+        for (int k2 = 0; k2 < WG_WAVES; ++k2)
+            if (k2 < w) run += s_w[k2];
+        uint4 e;
+        e.x = run | (nb[0] << 16); run += nb[0];
+        e.y = run | (nb[1] << 16); run += nb[1];
+        e.z = run | (nb[2] << 16); run += nb[2];
+        e.w = run | (nb[3] << 16);
+        reinterpret_cast<uint4*>(s_eq)[tid] = e;
+        if (blockIdx.x == 0) {
+            reinterpret_cast<uint4*>(eq_tab)[tid] = e;
+            if (tid == 0) { frame[2] = tmin; frame[3] = tmax; frame[6] = tmin; frame[7] = tmax; }
+        }
+    }
+    __syncthreads();
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int64_t e0 = base + ((int64_t)v * DS_THREADS + tid) * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (e0 + j < P) {
-                const uint32_t d = ds_bucket(k[v][j], kmin, shift);
+                const uint32_t d = ds_bucket(k[v][j], s_eq);
                 atomicAdd(&h_cnt[d], 1u);
                 if (t[v][j]) atomicAdd(&h_tile[d], t[v][j]);
             }
@@ -245,16 +301,19 @@ __device__ __forceinline__ uint32_t ds_block_excl_scan(const uint32_t (&v)[DPT],
 }
 
 // plan entry of segment s (8 words): begin, end (elements of the bucket-ordered array), first bucket, end bucket, tile
-// instances in front of the segment, number of listed Gaussians, 0, 0
+// instances in front of the segment, number of listed Gaussians, smallest key the segment's buckets can hold, one past the largest
 __global__ void __launch_bounds__(S3_THREADS)
-ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ frame,
+ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ frame, const uint32_t* __restrict__ eq_tab,
            const uint32_t* __restrict__ cnt_tab, const uint32_t* __restrict__ cnt_total, const uint32_t* __restrict__ tile_total,
            uint2* __restrict__ pairs, uint32_t* __restrict__ order, uint32_t* __restrict__ offsets, uint2* __restrict__ rect_sorted,
            uint32_t* __restrict__ plan, int nseg_cap) {
     __shared__ __attribute__((aligned(16))) uint16_t wave_cnt[S3_WAVES][DS_NB];      // 32 KB (a wave counts <= 512 keys)
     __shared__ __attribute__((aligned(16))) uint32_t digit_base[DS_NB];              //  8 KB
+    __shared__ __attribute__((aligned(16))) uint32_t s_eq[GSR_EQ_BINS];              //  4 KB equalised bucket table (ds_hist)
     __shared__ uint32_t wsum[S3_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    static_assert(GSR_EQ_BINS == 2 * S3_THREADS, "one 8-byte load per thread");
+    reinterpret_cast<uint2*>(s_eq)[tid] = reinterpret_cast<const uint2*>(eq_tab)[tid];      // (the barriers below publish it)
 
     if ((int)blockIdx.x == nblocks) {
         // ---- the segment plan (one workgroup, beside the scattering ones) ----
@@ -281,6 +340,8 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t
         }
         __syncthreads();
         const uint32_t listed = cnt_excl[DS_CULL];
+        const uint32_t tmin = frame[6], tmax = frame[7];
+        const uint32_t used = (s_eq[GSR_EQ_BINS - 1] & 0xFFFFu) + (s_eq[GSR_EQ_BINS - 1] >> 16);      // buckets the table hands out
         auto lower_bound = [&](uint32_t x) {      // first bucket in [0, 2047] whose first element is >= x (2047 if none)
             uint32_t lo = 0, hi = DS_CULL;
 #pragma unroll 1
@@ -292,7 +353,7 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t
         };
         for (int s = tid; s < nseg_cap; s += S3_THREADS) {
             uint4 e = make_uint4(0u, 0u, 0u, 0u);
-            uint32_t tb = 0;
+            uint32_t tb = 0, key_lo = 0, key_hi = 0;
             const uint64_t x0 = (uint64_t)s * DS_SEG;
             if (x0 < listed) {
                 const uint32_t d0 = lower_bound((uint32_t)x0);
@@ -300,15 +361,17 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t
                 const uint32_t d1 = x1 >= listed ? DS_CULL : lower_bound((uint32_t)x1);
                 e = make_uint4(cnt_excl[d0], cnt_excl[d1], d0, d1);
                 tb = tile_excl[d0];
+                // the keys of buckets [d0, d1): [first key of d0, first key of d1), inside the frame's true range (keys < 2^27: no overflow)
+                key_lo = max(tmin, ds_bucket_first_key(d0, s_eq));
+                key_hi = d1 >= used ? tmax + 1u : min(tmax + 1u, ds_bucket_first_key(d1, s_eq));
             }
             reinterpret_cast<uint4*>(plan)[2 * s] = e;
-            reinterpret_cast<uint4*>(plan)[2 * s + 1] = make_uint4(tb, listed, 0u, 0u);
+            reinterpret_cast<uint4*>(plan)[2 * s + 1] = make_uint4(tb, listed, key_lo, key_hi);
         }
         return;
     }
 
-    const uint32_t kmin = frame[2], kmax = frame[3], R32 = frame[0];
-    const int shift = ds_shift(kmin, kmax);
+    const uint32_t R32 = frame[0];
     // the workgroup's keys are requested first: their trip overlaps the bucket-base prologue below.  Wave w owns the
     // contiguous run [w * 512, w * 512 + 512) of the workgroup's keys, item r of a lane is key r * 64 + lane of the run
     const int64_t wave_base = (int64_t)blockIdx.x * DS_ITEMS + (int64_t)w * (64 * S3_IPT);
@@ -344,7 +407,7 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t
     for (int r = 0; r < S3_IPT; ++r) {
         const int64_t idx = wave_base + r * 64 + lane;
         const bool valid = idx < P;
-        const uint32_t d = ds_bucket(key[r], kmin, shift);
+        const uint32_t d = ds_bucket(key[r], s_eq);
         dig[r] = d;
         const uint64_t mask = match_digit(d, GSR_DS_BITS, __ballot(valid));
         const uint32_t prior = valid ? (uint32_t)wave_cnt[w][d] : 0u;
@@ -564,15 +627,13 @@ ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame
     const uint4 e2 = reinterpret_cast<const uint4*>(plan)[2 * blockIdx.x + 1];
     const uint32_t tile_base = e2.x, listed = e2.y;
     const uint32_t n = end - begin;
-    const uint32_t kmin = frame[2], kmax = frame[3];
-    const int shift = ds_shift(kmin, kmax);
     const bool r_ok = frame[1] == 0u && (int32_t)frame[0] >= 0;      // R < 2^31 (else the host refuses the frame: no table writes)
-    // keys of the segment lie in [base_key, base_key + span); the first / last usable bucket also holds the keys below / above the
-    // robust range [kmin, kmax] the buckets span (ds_hist), down / up to the frame's true extremes frame[6..7]
-    const uint32_t base_key = d0 == 0u ? frame[6] : kmin + (d0 << shift);
-    const uint64_t top_key = d1 > (uint32_t)DS_NB - 2u ? (uint64_t)frame[7] + 1ull : (uint64_t)kmin + ((uint64_t)d1 << shift);
-    const uint64_t span = top_key > (uint64_t)base_key ? top_key - (uint64_t)base_key : 0ull;
-    const int nbits = span <= 1ull ? 0 : 64 - __clzll((long long)(span - 1ull));
+    // keys of the segment lie in [base_key, top_key): the key span of its buckets under the equalised mapping (the plan workgroup of
+    // ds_scatter inverted the table)
+    const uint32_t base_key = e2.z, top_key = e2.w;
+    const uint32_t span = top_key > base_key ? top_key - base_key : 0u;
+    const int nbits = span <= 1u ? 0 : 32 - __clz((int)(span - 1u));
+    (void)d0; (void)d1;
     // (the segments tile [0, listed): exactly one ends at `listed`.  Its end BUCKET need not be 2047 -- behind the last
     // non-empty bucket come empty ones that start at `listed` too -- so the element count decides, not the bucket)
     const uint32_t last_listed = end == listed ? end - 1u : 0xFFFFFFFFu;
@@ -638,16 +699,16 @@ size_t gsr_depth_bucket_blocks(int P) { return ((size_t)(P > 0 ? P : 1) + DS_ITE
 size_t gsr_depth_bucket_segments(int P) { return ((size_t)(P > 0 ? P : 1) + DS_SEG - 1) / DS_SEG + 1; }
 
 // keys[P] (27-bit depth keys, GSR_DEPTH_KEY_CULLED for Gaussians without a tile), tiles[P], rect[P], frame = the words the
-// key-producing kernel's last workgroup wrote (gsr_frame.h)  ->  order[P], rect_sorted[P], offsets[P] (inclusive scan of the
+// key-producing kernel's last workgroup wrote, wg_range / sample_hist = what its workgroups left (gsr_frame.h)  ->  order[P], rect_sorted[P], offsets[P] (inclusive scan of the
 // tile counts in depth order), block_first[bf_cap]
 void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, const uint2* rect, uint32_t* frame,
-                                  const uint2* wg_range, int n_range, const GsrDepthSortBufs& b, uint32_t* order, uint2* rect_sorted, uint32_t* offsets, uint2* block_first,
-                                  uint32_t block_first_cap, uint32_t* slow_word, hipStream_t st) {
+                                  const uint2* wg_range, int n_range, const uint16_t* sample_hist, const GsrDepthSortBufs& b, uint32_t* order, uint2* rect_sorted,
+                                  uint32_t* offsets, uint2* block_first, uint32_t block_first_cap, uint32_t* slow_word, hipStream_t st) {
     const int nblocks = (int)gsr_depth_bucket_blocks(P);
     const int nseg_cap = (int)gsr_depth_bucket_segments(P);
-    hipLaunchKernelGGL(ds_hist, dim3(nblocks), dim3(DS_THREADS), 0, st, P, keys, tiles, frame, wg_range, n_range, b.cnt_tab, b.tile_tab);
+    hipLaunchKernelGGL(ds_hist, dim3(nblocks), dim3(DS_THREADS), 0, st, P, keys, tiles, frame, wg_range, n_range, sample_hist, b.eq_tab, b.cnt_tab, b.tile_tab);
     hipLaunchKernelGGL(ds_scan, dim3(DS_NB / 16), dim3(DS_THREADS), 0, st, nblocks, b.cnt_tab, b.tile_tab, b.cnt_total, b.tile_total);
-    hipLaunchKernelGGL(ds_scatter, dim3(nblocks + 1), dim3(S3_THREADS), 0, st, P, nblocks, keys, frame, b.cnt_tab, b.cnt_total,
+    hipLaunchKernelGGL(ds_scatter, dim3(nblocks + 1), dim3(S3_THREADS), 0, st, P, nblocks, keys, frame, b.eq_tab, b.cnt_tab, b.cnt_total,
                        b.tile_total, b.pairs[0], order, offsets, rect_sorted, b.plan, nseg_cap);
     hipLaunchKernelGGL(ds_segsort, dim3(nseg_cap), dim3(SG_THREADS), 0, st, b.plan, frame, b.pairs[0], b.pairs[1], rect, order,
                        rect_sorted, offsets, block_first, block_first_cap, slow_word);

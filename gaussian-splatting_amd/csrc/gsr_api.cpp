@@ -176,6 +176,8 @@ std::vector<HostWord> g_hw_pool[GSR_MAX_DEVICES];
 std::atomic<int64_t> g_last_R[GSR_MAX_DEVICES];      // per device: sizes the speculative binning buffer of the next frame
 std::atomic<int> g_lsd_frames[GSR_MAX_DEVICES];      // per device: frames for which the automatic depth sort stays with the LSD passes
 std::atomic<int> g_lsd_backoff[GSR_MAX_DEVICES];     // per device: length of the next such stay (doubles per failed retry; heuristic only)
+std::atomic<int> g_lsd_probation[GSR_MAX_DEVICES];   // per device: clean bucket-sort frames still needed after a stay before the back-off is forgotten
+uint32_t* g_slow_word_dev[GSR_MAX_DEVICES] = {nullptr};      // its device-side address
 uint32_t* g_slow_word[GSR_MAX_DEVICES] = {nullptr};  // per device, mapped host memory: set (1) by ds_segsort when a segment overflowed the LDS capacity;
                                                      // read and cleared by the next lease on that device.  A heuristic flag: a store that races the
                                                      // clear is at worst seen one frame later or lost once, never attributed to another device
@@ -220,8 +222,17 @@ int lease_host_word(HostWordLease& lease, hipStream_t st) {
         std::lock_guard<std::mutex> l(g_hw_mu);
         if (!g_slow_word[dev_id]) {
             uint32_t* w = nullptr;
-            HIP_OK(hipHostMalloc((void**)&w, 64, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent));
+            uint32_t* wd = nullptr;
+            hipError_t e = hipHostMalloc((void**)&w, 64, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent);
+            if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&wd, w, 0);
+            if (e != hipSuccess) {      // (the slot leased above goes back to the pool -- lease.dev is set first -- nothing leaks)
+                if (w) (void)hipHostFree(w);
+                lease.dev = dev_id;
+                lease.st = st;
+                return fail(GSR_ERR_HIP, std::string("slow-word allocation: ") + hipGetErrorString(e));
+            }
             for (int i = 0; i < 16; ++i) w[i] = 0;
+            g_slow_word_dev[dev_id] = wd;
             g_slow_word[dev_id] = w;
         }
     }
@@ -233,15 +244,18 @@ int lease_host_word(HostWordLease& lease, hipStream_t st) {
         if (back < 64) back = 64;                     // (a scene that always crowds a bucket pays one slow frame in 65, 129, ... 8193)
         g_lsd_frames[dev_id].store(back);
         g_lsd_backoff[dev_id].store(back >= 8192 ? 8192 : back * 2);
+        g_lsd_probation[dev_id].store(0);
+    } else if (g_lsd_probation[dev_id].load() > 0 && g_lsd_frames[dev_id].load() == 0) {
+        //  the stay is over and bucket-sort frames come back clean: after three of them (the flag is written by a kernel that
+        // may still be running when the next lease looks) the doubling is forgotten -- isolated crowded frames of a long run no longer add up
+        if (g_lsd_probation[dev_id].fetch_sub(1) == 1) g_lsd_backoff[dev_id].store(64);
     }
     lease.dev = dev_id;
     lease.st = st;
     return GSR_OK;
 }
-uint32_t* slow_word_dev(int dev_id) {      // device-side address of the device's "oversized segment" flag (mapped host memory)
-    uint32_t* d = nullptr;
-    if (!g_slow_word[dev_id] || hipHostGetDevicePointer((void**)&d, g_slow_word[dev_id], 0) != hipSuccess) return nullptr;
-    return d;
+uint32_t* slow_word_dev(int dev_id) {      // device-side address of the device's "oversized segment" flag (mapped host memory; cached with it)
+    return g_slow_word[dev_id] ? g_slow_word_dev[dev_id] : nullptr;
 }
 unsigned long long* counters_for_current_device() {
     int d = 0;
@@ -300,9 +314,11 @@ GsrGeom gsr_carve_geom(char* base, int P) {
         g.ds.cnt_total = (uint32_t*)take(GSR_DS_BUCKETS * 4);
         g.ds.tile_total = (uint32_t*)take(GSR_DS_BUCKETS * 4);
         g.ds.plan = (uint32_t*)take(nseg * 32);
+        g.ds.eq_tab = (uint32_t*)take((size_t)GSR_EQ_BINS * 4);
     }
     g.num_rendered = (uint32_t*)take(128);
     g.wg_range = (uint2*)take((size_t)GSR_FRAME_MAX_GROUPS * 8);
+    g.sample_hist = (uint16_t*)take((size_t)GSR_EQ_SAMPLE_WGS * GSR_EQ_BINS * 2);
     g.bytes = off;
     return g;
 }
@@ -579,6 +595,7 @@ static GsrFrameStatsDev frame_stats_for(HostWordLease& lease, GsrGeom& g, uint32
     fs.state = lease.hw.state;
     fs.frame = g.num_rendered;
     fs.wg_range = g.wg_range;
+    fs.sample_hist = g.sample_hist;
     fs.host_word = lease.hw.dev;
     fs.seq = seq_out;
     return fs;
@@ -588,7 +605,11 @@ static bool use_bucket_sort(int P, int dev_id) {
     if (P > GSR_DS_MAX_P || g_depth_sort_mode == 1) return false;
     if (g_depth_sort_mode == 2) return true;
     if (g_lsd_frames[dev_id].load() > 0) {
-        if (g_lsd_frames[dev_id].fetch_sub(1) > 0) return false;      // (concurrent callers: one decrement each, never a lost update)
+        const int left = g_lsd_frames[dev_id].fetch_sub(1);
+        if (left > 0) {                                               // (concurrent callers: one decrement each, never a lost update)
+            if (left == 1) g_lsd_probation[dev_id].store(3);          // the stay ends with this frame: the next ones are on probation
+            return false;
+        }
         g_lsd_frames[dev_id].store(0);
     }
     return true;
@@ -613,7 +634,7 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     // scan, after the sort, and the GPU idled 5-7 us per frame).
     {   StageTimer t(GSR_STAGE_DEPTH_SORT, st);
         if (bucket) {
-            gsr_launch_depth_bucket_sort(P, g.keys[0], g.tiles, g.rect, g.num_rendered, g.wg_range, n_range, g.ds, g.vals[order_buf], g.rect_sorted, g.offsets,
+            gsr_launch_depth_bucket_sort(P, g.keys[0], g.tiles, g.rect, g.num_rendered, g.wg_range, n_range, g.sample_hist, g.ds, g.vals[order_buf], g.rect_sorted, g.offsets,
                                          g.block_first, bf_cap, slow_word_dev(dev_id), st);
         } else {
             const int ob = gsr_radix_sort_pairs(g.keys, g.vals, P, GSR_DEPTH_KEY_BITS, GSR_DEPTH_DIGIT_BITS, g.sort_hist, g.digit_total,
@@ -830,7 +851,7 @@ int gsr_preprocess_forward(const GsrRasterSettings* settings, int P, int M, cons
     g.splats = reinterpret_cast<float4*>(splat_records);
     {   StageTimer t(GSR_STAGE_PREPROCESS, st);
         GsrFrameStatsDev none;      // nothing is binned here: no frame statistics
-        none.state = nullptr; none.frame = nullptr; none.wg_range = nullptr; none.host_word = nullptr; none.seq = 0;
+        none.state = nullptr; none.frame = nullptr; none.wg_range = nullptr; none.sample_hist = nullptr; none.host_word = nullptr; none.seq = 0;
         gsr_launch_preprocess(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, none, st);
     }
     STAGE_CHECK("preprocess (shard)");

@@ -19,6 +19,16 @@
 #include <stdint.h>
 #include "gsr_wave.h"
 
+// Histogram-equalised bucket mapping of the depth sort (round 6, depthsort.hip): the 27-bit key space is cut into GSR_EQ_BINS coarse bins of
+// 2^GSR_EQ_SHIFT keys (64 per octave of depth); the first GSR_EQ_SAMPLE_WGS workgroups of the key-producing kernel leave the coarse histogram
+// of THEIR keys -- a regular sample of the frame, every workgroup's loop strides over the whole array -- and ds_hist turns the summed sample
+// into a (first bucket, buckets) table per coarse bin: one bucket for every coarse bin inside the frame's key range, the rest of the 2046
+// handed out in proportion to the sampled mass, so that the buckets hold about the same number of keys whatever the depth distribution is.
+#define GSR_EQ_SHIFT 17
+#define GSR_EQ_BINS 1024         // 2^(27 - GSR_EQ_SHIFT)
+#define GSR_EQ_SAMPLE_WGS 16
+#define GSR_FRAME_KEY_CULLED ((1u << 27) - 1u)      // == GSR_DEPTH_KEY_CULLED (gsr_internal.h, checked there)
+
 // counter (device memory, u64, zero between frames): bits [0, 42) sum of the tile counts (a workgroup's part saturates at
 // 2^31: any total >= 2^31 is refused by the host anyway), [42, 53) workgroups with a key overflow, [53, 64) tickets
 // -> the key-producing kernels run at most GSR_FRAME_MAX_GROUPS workgroups
@@ -30,6 +40,7 @@ struct GsrFrameStatsDev {
     uint32_t* state;       // NULL: the kernel keeps no statistics (shard projection without binning)
     uint32_t* frame;
     uint2* wg_range;       // [workgroups] (~smallest, largest) depth key of the workgroup's listed Gaussians; (0, 0): none
+    uint16_t* sample_hist; // [GSR_EQ_SAMPLE_WGS][GSR_EQ_BINS] (gsr_internal.h) or NULL: coarse histogram of the keys of the first workgroups
     uint32_t* host_word;   // may be NULL (then only `frame` is written)
     uint32_t seq;
 };
@@ -37,8 +48,12 @@ struct GsrFrameStatsDev {
 #ifdef __HIPCC__
 // Called by EVERY thread of EVERY workgroup of a 256-thread kernel, after its streaming loop.  tiles_sum / kmin / kmax /
 // key_ovf are the thread's own partial results (kmin = 0xFFFFFFFF, kmax = 0 when it listed nothing).
+// keys / P: the depth-key array the kernel has just written with the loop `for (i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256)`
+// -- the first GSR_EQ_SAMPLE_WGS workgroups read THEIR OWN keys back (every thread the ones it stored itself) and leave their coarse
+// histogram in fs.sample_hist: a regular sample of the frame's depth distribution for the depth sort's bucket mapping (depthsort.hip).
+// lds: >= GSR_EQ_BINS words of LDS that nothing else uses after the loop.
 __device__ __forceinline__ void gsr_frame_stats_commit(const GsrFrameStatsDev& fs, uint64_t tiles_sum, uint32_t kmin, uint32_t kmax,
-                                                       bool key_ovf) {
+                                                       bool key_ovf, const uint32_t* keys, int64_t P, uint32_t* lds) {
     if (!fs.state) return;
     __shared__ uint64_t s_sum[4];
     __shared__ uint32_t s_nmin[4], s_max[4], s_ovf[4];
@@ -48,6 +63,22 @@ __device__ __forceinline__ void gsr_frame_stats_commit(const GsrFrameStatsDev& f
     const uint64_t ovf = __ballot(key_ovf);
     if (lane == 63) { s_sum[w] = wsum; s_nmin[w] = wnmin; s_max[w] = wmax; s_ovf[w] = ovf ? 1u : 0u; }
     __syncthreads();
+    if (fs.sample_hist && blockIdx.x < (unsigned)GSR_EQ_SAMPLE_WGS) {      // (workgroup-uniform; every wave is past its loop: `lds` is free)
+#pragma unroll
+        for (int b = 0; b < GSR_EQ_BINS / 256; ++b) lds[b * 256 + threadIdx.x] = 0u;
+        __syncthreads();
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (int64_t)gridDim.x * 256) {
+            const uint32_t k = keys[i];
+            if (k != GSR_FRAME_KEY_CULLED) atomicAdd(&lds[k >> GSR_EQ_SHIFT], 1u);
+        }
+        __syncthreads();
+        uint16_t* row = fs.sample_hist + (size_t)blockIdx.x * GSR_EQ_BINS;
+#pragma unroll
+        for (int b = 0; b < GSR_EQ_BINS / 256; ++b) {
+            const uint32_t c = lds[b * 256 + threadIdx.x];
+            row[b * 256 + threadIdx.x] = (uint16_t)(c < 65535u ? c : 65535u);
+        }
+    }
     if (threadIdx.x != 0) return;
     uint64_t sum = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
     if (sum > 0x80000000ull) sum = 0x80000000ull;

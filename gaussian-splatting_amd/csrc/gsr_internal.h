@@ -42,6 +42,7 @@ static inline size_t gsr_block_first_cap(int P) { return (size_t)(P > 0 ? P : 1)
 #define GSR_DS_SEG 2048          // a segment = the buckets that start inside one window of this many elements
 #define GSR_DS_CAP 4096          // largest segment sorted in LDS; beyond: the same passes through global memory (slow, reported)
 #define GSR_DS_MAX_P (3 << 20)   // above: the LSD radix sort (the [workgroup][bucket] tables grow with P)
+// (the histogram-equalised bucket mapping and its GSR_EQ_* constants: gsr_frame.h)
 struct GsrDepthSortBufs {
     uint2* pairs[2];             // [P] (key, id) in bucket order / scratch of an oversized segment
     uint32_t* cnt_tab;           // [workgroups][2048] keys per bucket, then their exclusive prefix over the workgroups
@@ -49,6 +50,7 @@ struct GsrDepthSortBufs {
     uint32_t* cnt_total;         // [2048]
     uint32_t* tile_total;        // [2048]
     uint32_t* plan;              // [segments][8]
+    uint32_t* eq_tab;            // [GSR_EQ_BINS] first bucket | buckets << 16 of every coarse bin (written by ds_hist's workgroup 0)
 };
 size_t gsr_depth_bucket_blocks(int P);
 size_t gsr_depth_bucket_segments(int P);
@@ -69,6 +71,7 @@ struct GsrGeom {                 // P-sized
     GsrDepthSortBufs ds;         // bucket depth sort (depthsort.hip); carved for P <= GSR_DS_MAX_P
     uint32_t* num_rendered;      // frame words (gsr_frame.h): [0..1] R as 64 bits, [2] smallest, [3] largest depth key of a listed Gaussian
     uint2* wg_range;             // [GSR_FRAME_MAX_GROUPS] per-workgroup depth-key ranges of the key-producing kernel
+    uint16_t* sample_hist;       // [GSR_EQ_SAMPLE_WGS][GSR_EQ_BINS] coarse key histograms of the first workgroups of the key-producing kernel
     size_t bytes;
 };
 GsrGeom gsr_carve_geom(char* base, int P);
@@ -82,6 +85,7 @@ GsrGeom gsr_carve_geom(char* base, int P);
 #define GSR_DEPTH_KEY_BITS 27
 #define GSR_DEPTH_KEY_BASE 0x3E4CCCCDu
 #define GSR_DEPTH_KEY_CULLED ((1u << GSR_DEPTH_KEY_BITS) - 1u)
+static_assert(GSR_DEPTH_KEY_CULLED == GSR_FRAME_KEY_CULLED && (1 << (GSR_DEPTH_KEY_BITS - GSR_EQ_SHIFT)) == GSR_EQ_BINS, "gsr_frame.h");
 #ifdef __HIPCC__
 // `overflow` is a per-thread flag the caller reports ONCE, after its loop, through gsr_frame_stats_commit: a store through an
 // (unrestricted) host-word pointer inside the streaming loop made hipcc serialise the loop's batched loads (ISA audit: the
@@ -169,8 +173,8 @@ int gsr_radix_sort_pairs_k16(uint16_t* keys[2], uint32_t* vals[2], int64_t n, in
                              uint32_t* digit_total, int items, hipStream_t st);
 // depthsort.hip: depth order + rectangles in depth order + inclusive scan of the tile counts + the emission's block table
 void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, const uint2* rect, uint32_t* frame,
-                                  const uint2* wg_range, int n_range, const GsrDepthSortBufs& b, uint32_t* order, uint2* rect_sorted, uint32_t* offsets, uint2* block_first,
-                                  uint32_t block_first_cap, uint32_t* slow_word, hipStream_t st);
+                                  const uint2* wg_range, int n_range, const uint16_t* sample_hist, const GsrDepthSortBufs& b, uint32_t* order, uint2* rect_sorted,
+                                  uint32_t* offsets, uint2* block_first, uint32_t block_first_cap, uint32_t* slow_word, hipStream_t st);
 // pass plan shared by the sorter and by code that must know which ping-pong buffer holds the result
 int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits /*[8]*/);
 #define GSR_DEPTH_DIGIT_BITS 9      // 27-bit depth keys: 3 passes of 9 bits (round 2: 4 x 8 on 32 bits; 3 x 11 measured slower: 113 vs 91 us)

@@ -686,4 +686,7 @@ GSR_HD void gsr_cov3d_backward(const float* s, float mod, const float* q, const 
 }
 
 // The arithmetic type of the per-Gaussian backward's covariance chain in the product (gsr_project_backward_r's header comment).
-typedef double GsrBwdReal;
+#ifndef GSR_BWD_REAL
+#define GSR_BWD_REAL double      /* A/B builds: GSR_EXTRA_FLAGS=-DGSR_BWD_REAL=float is rounds 1-5's all-fp32 chain */
+#endif
+typedef GSR_BWD_REAL GsrBwdReal;

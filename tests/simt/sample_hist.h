@@ -1,0 +1,19 @@
+// What the first GSR_EQ_SAMPLE_WGS workgroups of a key-producing kernel leave in fs.sample_hist (csrc/gsr_frame.h gsr_frame_stats_commit), restated
+// for the harnesses that are handed bare key arrays: workgroup w of a grid of `n_range` 256-thread workgroups owns the keys w * 256 + t + k * n_range * 256.
+// TEST INFRASTRUCTURE.
+#pragma once
+#include <stdint.h>
+#include <vector>
+#include "gsr_internal.h"
+
+static inline std::vector<uint16_t> simt_sample_hist(const uint32_t* keys, int64_t P, int n_range) {
+    std::vector<uint16_t> h((size_t)GSR_EQ_SAMPLE_WGS * GSR_EQ_BINS, 0);
+    for (int w = 0; w < GSR_EQ_SAMPLE_WGS && w < n_range; ++w) {
+        std::vector<uint32_t> c(GSR_EQ_BINS, 0u);
+        for (int64_t i0 = (int64_t)w * 256; i0 < P; i0 += (int64_t)n_range * 256)
+            for (int64_t i = i0; i < i0 + 256 && i < P; ++i)
+                if (keys[i] != GSR_DEPTH_KEY_CULLED) ++c[keys[i] >> GSR_EQ_SHIFT];
+        for (int b = 0; b < GSR_EQ_BINS; ++b) h[(size_t)w * GSR_EQ_BINS + b] = (uint16_t)(c[b] < 65535u ? c[b] : 65535u);
+    }
+    return h;
+}

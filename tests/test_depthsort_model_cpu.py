@@ -16,47 +16,80 @@ KEY_CULLED = (1 << 27) - 1
 KEY_BASE = 0x3E4CCCCD          # bits(0.2f), gsr_internal.h GSR_DEPTH_KEY_BASE
 
 
-def ds_shift(kmin, kmax):
-    if kmax <= kmin:
-        return 0
-    rng = kmax - kmin
-    s = max(0, rng.bit_length() - BITS)
-    if (rng >> s) > NB - 2:
-        s += 1
-    return s
+EQ_SHIFT, EQ_BINS, EQ_SAMPLE_WGS = 17, 1024, 16      # csrc/gsr_frame.h
 
 
-def robust_range(wg_min, wg_max, threads=256):
-    """ds_hist's robust key range from the per-workgroup (min, max) table of the key-producing kernel (None entries: the workgroup listed
-    nothing): thread t of 256 groups the workgroups t, t + 256, ...; the group's smallest maximum / largest minimum ignores an outlier unless
-    every workgroup of the group has one; the robust range is the widest of the groups' ranges.  Falls back to the true range."""
-    have = [(a, b) for a, b in zip(wg_min, wg_max) if a is not None]
-    if not have:
-        return 0xFFFFFFFF, 0
-    tmin, tmax = min(a for a, _ in have), max(b for _, b in have)
-    gmin, gmax = [], []
-    for t in range(threads):
-        grp = [(wg_min[i], wg_max[i]) for i in range(t, len(wg_min), threads) if wg_min[i] is not None]
-        if grp:
-            gmin.append(max(a for a, _ in grp))
-            gmax.append(min(b for _, b in grp))
-    kmin, kmax = min(gmin), max(gmax)
-    if kmax <= kmin or kmin < tmin or kmax > tmax:
-        return tmin, tmax
-    return kmin, kmax
+def sample_hist(keys, n_range):
+    """What the first 16 workgroups of the key-producing kernel leave (gsr_frame.h): workgroup w of a grid of n_range 256-thread workgroups
+    owns the keys w * 256 + t + k * n_range * 256; the coarse histogram (key >> 17) of its listed keys, saturated at 65535."""
+    P = len(keys)
+    rows = []
+    for w in range(min(EQ_SAMPLE_WGS, n_range)):
+        idx = (np.arange(w * 256, P, n_range * 256)[:, None] + np.arange(256)[None, :]).reshape(-1)
+        k = keys[idx[idx < P]]
+        k = k[k != KEY_CULLED]
+        rows.append(np.minimum(np.bincount(k >> EQ_SHIFT, minlength=EQ_BINS), 65535))
+    return rows
 
 
-def bucket_depth_sort(keys, tiles, key_range=None):
-    """-> (order, inclusive tile scan in depth order, block_first dict, segment sizes).  key_range: the ROBUST (kmin, kmax) the buckets
-    span (robust_range); default: the true extremes."""
+def equalised_table(keys, n_range):
+    """ds_hist's bucket table: (first bucket, buckets) per coarse bin.  Every coarse bin inside the frame's true key range gets one bucket; the
+    remaining ones of the 2046 are handed out in proportion to the sampled mass (integer arithmetic, as in the kernel)."""
+    listed = keys[keys != KEY_CULLED]
+    start, nb = np.zeros(EQ_BINS, np.int64), np.zeros(EQ_BINS, np.int64)
+    if listed.size:
+        tmin, tmax = int(listed.min()), int(listed.max())
+        b_lo, b_hi = tmin >> EQ_SHIFT, min(tmax >> EQ_SHIFT, EQ_BINS - 1)
+    else:
+        b_lo = b_hi = 0
+    c = np.sum(sample_hist(keys, n_range), axis=0).astype(np.int64)
+    c[:b_lo] = 0
+    c[b_hi + 1:] = 0
+    C = int(c.sum())
+    nbins = b_hi - b_lo + 1
+    spare = NB - 2 - nbins
+    assert spare >= 1022
+    for b in range(b_lo, b_hi + 1):
+        nb[b] = 1 + ((spare * int(c[b])) // C if C else spare // nbins)
+    start = np.concatenate([[0], np.cumsum(nb)])[:EQ_BINS]
+    assert int(nb.sum()) <= NB - 2
+    return start, nb
+
+
+def bucket_of(keys, start, nb):
+    b = keys.astype(np.int64) >> EQ_SHIFT
+    return start[b] + (((keys.astype(np.int64) & ((1 << EQ_SHIFT) - 1)) * nb[b]) >> EQ_SHIFT)
+
+
+def first_key_of_bucket(d, start, nb):
+    """smallest key that maps to bucket d (d < buckets in use): the kernel's binary search over the table + the inverse of the in-bin mapping"""
+    lo, hi = 0, EQ_BINS
+    while lo < hi:
+        mid = (lo + hi) >> 1
+        if start[mid] > d:
+            hi = mid
+        else:
+            lo = mid + 1
+    b = lo - 1
+    j = d - int(start[b])
+    x = ((j << EQ_SHIFT) + int(nb[b]) - 1) // int(nb[b]) if nb[b] else 0
+    return (b << EQ_SHIFT) + x
+
+
+def bucket_depth_sort(keys, tiles, n_range=5):
+    """-> (order, inclusive tile scan in depth order, block_first dict, segment sizes).  n_range: workgroups of the key-producing kernel (its
+    first 16 provide the sample the bucket table is equalised with)."""
     P = len(keys)
     listed = keys != KEY_CULLED
     assert ((tiles > 0) == listed).all()
     tmin, tmax = (int(keys[listed].min()), int(keys[listed].max())) if listed.any() else (0xFFFFFFFF, 0)
-    kmin, kmax = (tmin, tmax) if key_range is None else key_range
-    assert tmin <= kmin and kmax <= tmax
-    sh = ds_shift(kmin, kmax)
-    d = np.where(listed, np.minimum((np.maximum(keys.astype(np.int64), kmin) - kmin) >> sh, NB - 2), CULL_BUCKET)
+    start, nb = equalised_table(keys, n_range)
+    used = int(nb.sum())
+    d = np.where(listed, bucket_of(np.where(listed, keys, 0), start, nb), CULL_BUCKET)
+    if listed.any():
+        dl, kl = d[listed], keys[listed].astype(np.int64)
+        o = np.argsort(kl, kind="stable")
+        assert (np.diff(dl[o]) >= 0).all(), "the bucket mapping is monotone in the key"
     assert d[listed].max(initial=0) <= NB - 2, "bucket 2047 is reserved for the tile-less Gaussians"
     cnt = np.bincount(d, minlength=NB)
     tsum = np.bincount(d, weights=tiles, minlength=NB).astype(np.int64)
@@ -91,8 +124,8 @@ def bucket_depth_sort(keys, tiles, key_range=None):
         covered = e
         sizes.append(e - b)
         ids = by_bucket[b:e]
-        base_key = tmin if d0 == 0 else kmin + (d0 << sh)
-        span = (tmax + 1 if d1 > NB - 2 else kmin + (d1 << sh)) - base_key
+        base_key = max(tmin, first_key_of_bucket(d0, start, nb))
+        span = (tmax + 1 if d1 >= used else min(tmax + 1, first_key_of_bucket(d1, start, nb))) - base_key
         rem = keys[ids].astype(np.int64) - base_key
         assert rem.min() >= 0 and rem.max() < max(span, 1), "rebased keys fit the segment's span"
         nbits = 0 if span <= 1 else int(span - 1).bit_length()
@@ -119,7 +152,7 @@ def keys_from_depths(z, culled):
     return k
 
 
-CASES = ["uniform", "ties", "crowd", "gap", "one_key", "all_culled", "single", "last_bucket_straddles_a_window", "outliers"]
+CASES = ["uniform", "ties", "crowd", "gap", "one_key", "all_culled", "single", "last_bucket_straddles_a_window", "outliers", "heavy_tails", "wall"]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -141,21 +174,19 @@ def test_bucket_depth_sort_model_equals_a_stable_sort(case):
         z = rng.uniform(4.0, 4.2, P)
         z[rng.integers(0, P, 12)] = rng.uniform(300, 3000, 12)
         z[rng.integers(0, P, 5)] = rng.uniform(0.21, 0.3, 5)
+    elif case == "heavy_tails":      # round 6: 3 % of the Gaussians far behind / in front of a narrow bulk -- every workgroup of the key-producing kernel
+        z = rng.uniform(4.0, 4.4, P)  # has some, so a range estimate from per-workgroup extremes (round 5) spans them all and the bulk crowds a few buckets
+        far = rng.random(P) < 0.03
+        z[far] = np.exp(rng.uniform(np.log(0.25), np.log(9000.0), int(far.sum())))
+    elif case == "wall":             # half of the scene within 0.3 % of one depth (a wall seen head-on), the rest spread over the frustum
+        z = np.where(rng.random(P) < 0.5, rng.normal(6.0, 0.006, P), rng.uniform(1.0, 40.0, P))
     culled = rng.random(P) < (1.0 if case == "all_culled" else 0.12)
     keys = keys_from_depths(z, culled)
     tiles = np.where(culled, 0, rng.integers(1, 40, P)).astype(np.int64)
-    key_range = None
-    if case == "outliers":
-        # the key-producing kernel's workgroups sample the array with a grid stride: workgroup w of 1024 holds the Gaussians w, w + 1024, ...
-        nwg = 1024
-        wmin = [int(keys[w::nwg][~culled[w::nwg]].min()) if (~culled[w::nwg]).any() else None for w in range(nwg)]
-        wmax = [int(keys[w::nwg][~culled[w::nwg]].max()) if (~culled[w::nwg]).any() else None for w in range(nwg)]
-        key_range = robust_range(wmin, wmax)
-        _, _, _, sizes_true = bucket_depth_sort(keys, tiles)
-        assert max(sizes_true) > CAP, "with the true extremes the outliers push the bulk into oversized segments"
-    order, scan, block_first, sizes = bucket_depth_sort(keys, tiles, key_range)
-    if case == "outliers":
-        assert max(sizes) <= CAP, "the robust range keeps every segment inside the LDS capacity"
+    n_range = (P + 255) // 256      # the key-producing kernel's grid at this size
+    order, scan, block_first, sizes = bucket_depth_sort(keys, tiles, n_range)
+    if case in ("outliers", "gap", "heavy_tails", "wall"):
+        assert max(sizes) <= CAP, "the equalised buckets keep every segment inside the LDS capacity"
     ref = np.argsort(keys, kind="stable")               # (depth key, index): what the LSD sort and the reference's sort leave
     assert (order == ref).all()
     assert (scan == np.cumsum(tiles[ref])).all()

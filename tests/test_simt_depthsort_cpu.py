@@ -2,7 +2,8 @@
 EXECUTED on the CPU, lane by lane, through the SIMT shim of tests/simt/ (512-thread workgroups, wave64 ballots, LDS radix passes): depth order,
 gathered rectangles, the inclusive scan of the tile counts and the emission's per-block table against a stable numpy sort -- on the key
 distributions that select its paths (uniform, ties, a crowded bucket that overflows the LDS segment and goes through global memory, a gap of
-four decades, one key, tile-less Gaussians, ragged sizes).  The kernel SOURCE is what runs (g++ -Itests/simt); the GPU tests of the same
+four decades, one key, tile-less Gaussians, ragged sizes; round 6: far outliers, heavy tails and a wall, which the histogram-equalised buckets
+must keep inside the LDS segments).  The kernel SOURCE is what runs (g++ -Itests/simt); the GPU tests of the same
 properties are tests/test_gpu_bins_sweep.py.  Test infrastructure: tests/_build/libsimt_depthsort.so is never part of the product."""
 import ctypes as C
 import os
@@ -48,13 +49,19 @@ def make_keys(rng, P, kind):
         k = base + (1 << 24) + rng.integers(0, 1 << 16, P)
         k[rng.integers(0, P, 9)] = base + (1 << 26) + rng.integers(0, 1 << 25, 9)
         k[rng.integers(0, P, 4)] = rng.integers(1, 4096, 4)
+    elif kind == "heavy_tails":               # round 6: 3 % of the keys spread over the whole key space around a narrow bulk (every workgroup has some)
+        k = base + (1 << 24) + rng.integers(0, 1 << 16, P)
+        far = rng.random(P) < 0.03
+        k[far] = rng.integers(1, (1 << 27) - 2, int(far.sum()))
+    elif kind == "wall":                      # half of the keys within 2^13 consecutive values, the rest over five octaves
+        k = np.where(rng.random(P) < 0.5, base + (1 << 25) + rng.integers(0, 1 << 13, P), base + rng.integers(0, 5 << 23, P))
     else:
         raise ValueError(kind)
     return k.astype(np.int64)
 
 
 @pytest.mark.parametrize("kind,P", [("uniform", 20_000), ("uniform", 4_097), ("uniform", 300), ("ties", 12_000), ("crowd", 16_000), ("gap", 9_000), ("one_key", 5_000),
-                                    ("outliers", 24_000)])
+                                    ("outliers", 24_000), ("heavy_tails", 40_000), ("wall", 40_000)])
 def test_bucket_depth_sort_on_the_cpu_equals_a_stable_sort(lib, kind, P):
     rng = np.random.default_rng(1000 + P + len(kind))
     keys = make_keys(rng, P, kind)
@@ -67,11 +74,14 @@ def test_bucket_depth_sort_on_the_cpu_equals_a_stable_sort(lib, kind, P):
     tiles = (w * h).astype(np.int64)
     keys[tiles == 0] = CULLED
     listed = tiles > 0
-    # the key-producing kernel's per-workgroup key ranges; "outliers": 1024 workgroups that sample the array with a grid stride (what the
-    # preprocess does), so that ds_hist's robust range has groups of four to work with
-    n_range = 1024 if kind == "outliers" else 5
+    # the key-producing kernel's per-workgroup key ranges: workgroup c of n_range 256-thread workgroups owns the keys c * 256 + t + k * n_range * 256
+    # (the harness derives the first 16 workgroups' coarse sample histograms from the same layout, tests/simt/sample_hist.h)
+    n_range = (P + 255) // 256 if kind in ("outliers", "heavy_tails", "wall") else 5
     wg = np.zeros((n_range, 2), dtype=np.uint32)
-    parts = [np.arange(c, P, n_range) for c in range(n_range)] if kind == "outliers" else np.array_split(np.arange(P), n_range)
+    parts = []
+    for c in range(n_range):
+        idx = (np.arange(c * 256, P, n_range * 256)[:, None] + np.arange(256)[None, :]).reshape(-1)
+        parts.append(idx[idx < P])
     for c, idx in enumerate(parts):
         kk = keys[idx][listed[idx]]
         if kk.size:
@@ -97,15 +107,9 @@ def test_bucket_depth_sort_on_the_cpu_equals_a_stable_sort(lib, kind, P):
     incl = np.cumsum(tiles[ref])
     assert np.array_equal(offsets.astype(np.int64), incl), "inclusive scan of the tile counts differs"
     assert int(frame[6]) == int(keys[listed].min()) and int(frame[7]) == int(keys[listed].max()), "true key range of the frame"
-    if kind == "outliers":
-        from test_depthsort_model_cpu import robust_range
-        wmin = [None if not (a or b) else int(~a & 0xFFFFFFFF) for a, b in wg.tolist()]
-        wmax = [None if not (a or b) else int(b) for a, b in wg.tolist()]
-        assert (int(frame[2]), int(frame[3])) == robust_range(wmin, wmax), "robust key range"
-        assert int(frame[2]) > int(frame[6]) and int(frame[3]) < int(frame[7]) and int(frame[3]) - int(frame[2]) < (1 << 17)
-        assert int(slow[0]) == 0, "with the robust range no segment may overflow the LDS capacity"
-    else:
-        assert (int(frame[2]), int(frame[3])) == (int(frame[6]), int(frame[7])), "five workgroups: nothing to be robust about"
+    assert (int(frame[2]), int(frame[3])) == (int(frame[6]), int(frame[7]))
+    if kind in ("outliers", "heavy_tails", "wall", "gap"):
+        assert int(slow[0]) == 0, "with the equalised buckets no segment of this distribution may overflow the LDS capacity"
     for b in range(nblk):                                             # the Gaussian that holds the first instance of every emission block
         j = int(np.searchsorted(incl, b * TS_ITEMS, side="right"))
         assert tuple(int(v) for v in block_first[b]) == (j, int(incl[j] - tiles[ref][j])), (b, block_first[b].tolist(), j)

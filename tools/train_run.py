@@ -276,6 +276,15 @@ def main():
         torch.cuda.synchronize()
         stg = _lib.profile_read()
         _lib.profile_enable(False)
+        # work counters of the two blend kernels (own pass: they slow the kernels): wave-steps per launch, heaviest wave
+        _lib.profile_enable(False, counters=True)
+        _lib.profile_counters(reset=True)
+        nc_ = min(n, 20)
+        for k in range(nc_):
+            one_iteration(a.iters + k)
+        torch.cuda.synchronize()
+        ctr = _lib.profile_counters(reset=True)
+        _lib.profile_enable(False)
         marks = []
         for k in range(n):
             one_iteration(a.iters + k, marks)
@@ -292,6 +301,10 @@ def main():
                     "gpu_ms_per_phase_torch_events": {k: round(v / n, 4) for k, v in phase.items()},
                     "gpu_ms_total_torch_events": round(sum(phase.values()) / n, 4),
                     "library_stage_ms": {k: round(v["ms"] / n, 4) for k, v in stg.items() if v["launches"]},
+                    "blend_work_per_iteration": {"fwd_wave_steps": ctr["fwd_steps"] / nc_, "fwd_batches": ctr["fwd_batches"] / nc_, "bwd_wave_steps": ctr["bwd_steps"] / nc_,
+                                                 "bwd_batches": ctr["bwd_batches"] / nc_, "fwd_max_wave_steps": ctr["fwd_max_wave_steps"], "bwd_max_wave_steps": ctr["bwd_max_wave_steps"],
+                                                 "note": "a forward wave-step = one list entry blended by the 64 pixels of an 8x8 block; a backward wave-step = one entry x 128 pixels "
+                                                         "(16x8 half tile); the bench frame (P 1 M, R 7.9 M) has 3.31 M / 1.85 M"},
                     "library_stage_launches_per_iteration": {k: round(v["launches"] / n, 2) for k, v in stg.items() if v["launches"]}}
         print("TIMELINE " + json.dumps(timeline), flush=True)
     n_run = a.iters - it0 + 1
