@@ -1170,6 +1170,8 @@ def _run(a):
             import tempfile
             if a.no_pmc or world != 1:
                 return {"error": "skipped (--no-pmc or N > 1)"}
+            if any(k_.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k_ in os.environ):
+                return {"error": "skipped: this process already runs under rocprofv3 (no nested profiler)"}
             exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
             if not exe:
                 return {"error": "rocprofv3 not found"}

@@ -42,10 +42,6 @@ int g_bwd_heavy_first = 2;      // launch order of the blend backward (plan kern
                                 // 3 = every half tile (= wave) on its own, heaviest first (0.325; slower than 2 on the clustered scene: the two halves of
                                 // a tile no longer share their gathered records in one XCD's L2)
 int g_tile_sort_mode = 0;       // 0 = fused emission + two-level sort (tilesort.hip), 1 = legacy emit + LSD passes (A/B)
-#ifdef GSR_AB_VARIANTS
-int g_fwd_bands = 1;            // MEASUREMENT BUILD ONLY (measured and rejected, profiles/r05_ab_fwd_bands_occupancy.json): bands of level-1 buckets (= runs of
-                                // tile rows) whose level-2 sort + blend are issued band by band on two HIP streams (bin_and_render)
-#endif
 
 struct PendingEvent { int stage; hipEvent_t a, b; };
 std::mutex g_prof_mu;
@@ -163,13 +159,8 @@ int check_split_sh(const GsrRasterSettings* s, int P, int M, const float* shs, b
 // 64-byte block of device memory that is zero between frames.  Words are LEASED per call from a per-device pool (ADVICE r02:
 // keyed by device, not by thread -- a host thread that comes and goes leaks nothing, concurrent callers never share a word);
 // never freed (the runtime releases them with the context).
-constexpr int GSR_MAX_FWD_BANDS = 4;
 struct HostWord {
     uint32_t* host = nullptr; uint32_t* dev = nullptr; uint32_t* state = nullptr; uint32_t seq = 0;
-    // band-pipelined forward only (created on first use, they stay with the slot): the second stream and the events that order the bands
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_l2[GSR_MAX_FWD_BANDS] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_done = nullptr;
 };
 std::mutex g_hw_mu;
 std::vector<HostWord> g_hw_pool[GSR_MAX_DEVICES];
@@ -441,11 +432,6 @@ int gsr_set_option(const char* name, int value) {
         gsr_set_render_fwd_lds_pad(value);
         return GSR_OK;
     }
-    if (!strcmp(name, "fwd_bands")) {
-        if (value < 1 || value > GSR_MAX_FWD_BANDS) return fail(GSR_ERR_INVALID_ARG, "fwd_bands must be 1..4");
-        g_fwd_bands = value;
-        return GSR_OK;
-    }
 #endif
     if (!strcmp(name, "tile_sort_mode")) {
         if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "tile_sort_mode must be 0 (fused) or 1 (legacy LSD)");
@@ -706,46 +692,6 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
                                         b.sort_hist, b.digit_total, b.bucket_base, b.blk2_start, goffset_splats, st);
         }
         STAGE_CHECK("emit + level-1 sort");
-#ifdef GSR_AB_VARIANTS
-        // ---- band-pipelined level 2 + blend -- MEASURED AND REJECTED (profiles/r05_ab_fwd_bands_occupancy.json: 0.362 ms per frame
-        // in one launch, 0.388 / 0.393 / 0.422 with 2 / 3 / 4 bands: every cross-stream dependency costs more than the level-2 work it hides, every extra
-        // blend launch has its own ramp and drain); kept in the measurement build with its bit-identity tests.  Level-1 buckets are runs of 2^lb consecutive tiles, and the level-2 sort and the
-        // blend of different buckets are independent.  The blend's launch loses a quarter of its span to its drain, and the level-2 kernels
-        // are latency / VALU bound with most CUs idle: with B bands, band k's level-2 sort + blend go to stream k & 1, every level-2 sort waits for the
-        // previous band's (so it runs UNDER the previous band's blend, not beside its sort), the blends overlap each other's tails, and the second
-        // stream is joined back into the caller's before the call returns.  Same kernels on the same data: every output is the same bits.
-        // Not while stages are timed or waves traced (those passes measure the kernels one after the other), nor in debug mode.
-        int nbands = (g_prof_on || g_count_on || settings->debug || g_render_fwd_variant != 0) ? 1 : g_fwd_bands;
-        const int T0 = cam.tile_y0 * cam.gx, T1 = cam.tile_y1 * cam.gx;      // the tiles this call renders
-        const int nb1 = 1 << plan.hb;
-        const int hb0 = T1 > T0 ? (T0 >> plan.lb) : 0, hb1 = T1 > T0 ? (((T1 - 1) >> plan.lb) + 1) : 0;
-        if (hb1 - hb0 < 2 * nbands) nbands = 1;
-        if (nbands > 1) {
-            if (!hw_slot.aux) {
-                HIP_OK(hipStreamCreateWithFlags(&hw_slot.aux, hipStreamNonBlocking));
-                for (int k = 0; k < GSR_MAX_FWD_BANDS; ++k) HIP_OK(hipEventCreateWithFlags(&hw_slot.ev_l2[k], hipEventDisableTiming));
-                HIP_OK(hipEventCreateWithFlags(&hw_slot.ev_done, hipEventDisableTiming));
-            }
-            for (int k = 0; k < nbands; ++k) {
-                hipStream_t sk = (k & 1) ? hw_slot.aux : st;
-                // buckets [h0, h1) of band k; the first / last band also take the buckets in front of / behind the rendered tiles (their ranges are written)
-                const int h0 = k == 0 ? 0 : hb0 + (int)(((int64_t)(hb1 - hb0) * k) / nbands);
-                const int h1 = k == nbands - 1 ? nb1 : hb0 + (int)(((int64_t)(hb1 - hb0) * (k + 1)) / nbands);
-                if (k > 0) HIP_OK(hipStreamWaitEvent(sk, hw_slot.ev_l2[k - 1], 0));      // (through it: level 1, and everything earlier on `st`)
-                gsr_launch_tile_sort_level2(plan, R, n_tiles, b.keys[0], b.vals[0], b.bucket_base, b.blk2_start, b.hist2, b.tile_base, im.ranges, sk, h0, h1);
-                if (k + 1 < nbands) HIP_OK(hipEventRecord(hw_slot.ev_l2[k], sk));
-                const int t0 = k == 0 ? T0 : (h0 << plan.lb) > T0 ? (h0 << plan.lb) : T0;
-                const int t1 = k == nbands - 1 ? T1 : (h1 << plan.lb) < T1 ? (h1 << plan.lb) : T1;
-                gsr_launch_render_forward(cam, im.ranges, b.vals[0], g.splats, settings->no_backward ? nullptr : im.final_T,
-                                          settings->no_backward ? nullptr : im.n_contrib, settings->no_backward ? nullptr : im.block_steps,
-                                          out_color, out_invdepth, 0, nullptr, sk, t0 - T0, t1 - t0);
-            }
-            HIP_OK(hipEventRecord(hw_slot.ev_done, hw_slot.aux));
-            HIP_OK(hipStreamWaitEvent(st, hw_slot.ev_done, 0));
-            HIP_OK(hipGetLastError());
-            return GSR_OK;
-        }
-#endif  // GSR_AB_VARIANTS
         {   StageTimer t(GSR_STAGE_TILE_SORT, st);
             gsr_launch_tile_sort_level2(plan, R, n_tiles, b.keys[0], b.vals[0], b.bucket_base, b.blk2_start, b.hist2, b.tile_base,
                                         im.ranges, st);

@@ -26,7 +26,9 @@
 // handed out in proportion to the sampled mass, so that the buckets hold about the same number of keys whatever the depth distribution is.
 #define GSR_EQ_SHIFT 17
 #define GSR_EQ_BINS 1024         // 2^(27 - GSR_EQ_SHIFT)
-#define GSR_EQ_SAMPLE_WGS 16
+#ifndef GSR_EQ_SAMPLE_WGS
+#define GSR_EQ_SAMPLE_WGS 16      /* (A/B builds: -DGSR_EQ_SAMPLE_WGS=8) */
+#endif
 #define GSR_FRAME_KEY_CULLED ((1u << 27) - 1u)      // == GSR_DEPTH_KEY_CULLED (gsr_internal.h, checked there)
 
 // counter (device memory, u64, zero between frames): bits [0, 42) sum of the tile counts (a workgroup's part saturates at

@@ -147,25 +147,6 @@ def test_c_abi_forward_on_the_cpu_against_the_oracle(lib, name, no_backward):
     G.check_forward(s, col, radii, invd, aux, out)
 
 
-@pytest.mark.parametrize("name", ["c1", "odd_aa"])
-def test_band_pipelined_level2_and_blend_change_no_bit(lib, name):
-    """MEASUREMENT BUILD ONLY.  Option fwd_bands (round 5, gsr_api.cpp bin_and_render): the level-2 sort and the blend issued band by band (runs of level-1 buckets) on two HIP
-    streams.  Scheduling only -- sub-launches of the same kernels over the same tables: point list, ranges, image, inverse depth, final_T and n_contrib
-    are the bits of the single-launch frame, for 2 / 3 / 4 bands, both builds, and inside a band of tile rows (the multi-GPU call)."""
-    if lib.gsr_set_option(b"fwd_bands", 1) != 0:
-        pytest.skip("fwd_bands is an option of the measurement build (-DGSR_AB_VARIANTS)")
-    cam, sc, opts = G.mk(name)
-    s = G.run_oracle(cam, sc, opts)[0]
-    for no_backward in (False, True):
-        for rows in (None, (2, 7)):
-            base = forward(lib, s, sc, no_backward=no_backward, tile_rows=rows)
-            for nb in (2, 3, 4):
-                with option(lib, b"fwd_bands", nb, 1):
-                    out = forward(lib, s, sc, no_backward=no_backward, tile_rows=rows)
-                assert out["R"] == base["R"] and out["R"] > 0
-                for k in base:
-                    if isinstance(base[k], torch.Tensor):
-                        assert torch.equal(base[k], out[k]), f"fwd_bands={nb}, no_backward={no_backward}, rows={rows}: {k} differs"
 
 
 def test_c_abi_forward_call_forms_band_and_empty_scene(lib):

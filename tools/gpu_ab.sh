@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 if [ -n "$LIBS" ]; then
   for rep in 1 2 3; do
     for lib in $LIBS; do
-      GSR_LIB="$PWD/gaussian-splatting_amd/$lib/libgsr_hip.so" timeout 300 python bench.py --no-other-configs --no-cpu-baseline --no-in-flight --densify-iters 0 > gpurun_out/ab_${lib}_$rep.log 2>&1
+      GSR_LIB="$PWD/gaussian-splatting_amd/$lib/libgsr_hip.so" timeout 300 python bench.py --no-other-configs --no-cpu-baseline --no-in-flight --no-pmc --densify-iters 0 > gpurun_out/ab_${lib}_$rep.log 2>&1
       python - "$lib" "$rep" "gpurun_out/ab_${lib}_$rep.log" <<'PY'
 import json, sys
 d = json.loads([l for l in open(sys.argv[3]) if l.startswith("{")][-1])
@@ -27,7 +27,7 @@ for rep in 1 2; do
   for cfg in "$@"; do
     i=$((i+1))
     opts=""; for o in ${cfg//,/ }; do opts="$opts --opt $o"; done
-    timeout 300 python bench.py --no-other-configs --no-cpu-baseline --no-in-flight --densify-iters 0 $opts > gpurun_out/ab_${i}_$rep.log 2>&1
+    timeout 300 python bench.py --no-other-configs --no-cpu-baseline --no-in-flight --no-pmc --densify-iters 0 $opts > gpurun_out/ab_${i}_$rep.log 2>&1
     python - "$cfg" "$rep" "gpurun_out/ab_${i}_$rep.log" <<'PY'
 import json, sys
 d = json.loads([l for l in open(sys.argv[3]) if l.startswith("{")][-1])

@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 R="$PWD"
 TAG="${ROUND_TAG:-r04}"
-B="--no-cpu-baseline --no-other-configs --no-in-flight --densify-iters 0 --min-warm-seconds 0.2"
+B="--no-cpu-baseline --no-other-configs --no-in-flight --no-pmc --densify-iters 0 --min-warm-seconds 0.2"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_stats" -o r1 -- python "$R/bench.py" --steps 30 --warmup 5 --train-steps 15 $B > "$R/gpurun_out/p_prof_stats.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$R/gpurun_out/prof_fetch" -o r1 -- python "$R/bench.py" --steps 10 --warmup 2 --train-steps 5 $B > "$R/gpurun_out/p_prof_fetch.log" 2>&1
