@@ -95,7 +95,7 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
         uint32_t* __restrict__ cnt_tab, uint32_t* __restrict__ tile_tab) {
     __shared__ uint32_t h_cnt[DS_NB], h_tile[DS_NB];
     __shared__ __attribute__((aligned(16))) uint32_t s_eq[GSR_EQ_BINS];
-    __shared__ uint32_t s_nmin[WG_WAVES], s_max[WG_WAVES], s_w[WG_WAVES];
+    __shared__ uint32_t s_nmin[WG_WAVES], s_max[WG_WAVES], s_w[WG_WAVES], s_w2[WG_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * DS_ITEMS;
     static_assert(GSR_EQ_BINS == 4 * DS_THREADS, "thread t owns the coarse bins 4t .. 4t+3");
@@ -119,24 +119,15 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
         h_cnt[i * DS_THREADS + tid] = 0u;
         h_tile[i * DS_THREADS + tid] = 0u;
     }
-    {   // the frame's true key range
+    // Round 1 (one barrier): the frame's true key range and the sampled keys per coarse bin (thread t owns the coarse bins 4t .. 4t+3)
+    uint32_t c[4] = {0u, 0u, 0u, 0u};
+    {
         uint32_t nm = 0, mx = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             nm = max(nm, rg[j].x);
             mx = max(mx, rg[j].y);
         }
-        nm = wave_incl_max_u32(nm);
-        mx = wave_incl_max_u32(mx);
-        if (lane == 63) { s_nmin[w] = nm; s_max[w] = mx; }
-    }
-    __syncthreads();
-    const uint32_t tmin = ~max(max(s_nmin[0], s_nmin[1]), max(s_nmin[2], s_nmin[3]));
-    const uint32_t tmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-    {   // equalised table: coarse bin b in [b_lo, b_hi] gets 1 + floor(spare * c[b] / C) buckets, c = sampled keys of the bin
-        const bool any = tmax >= tmin;      // (nothing listed: tmin = 0xFFFFFFFF, tmax = 0)
-        const uint32_t b_lo = any ? tmin >> GSR_EQ_SHIFT : 0u, b_hi = any ? min(tmax >> GSR_EQ_SHIFT, (uint32_t)GSR_EQ_BINS - 1u) : 0u;
-        uint32_t c[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int j = 0; j < GSR_EQ_SAMPLE_WGS; ++j) {
             if (j < n_samp) {
@@ -144,16 +135,18 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
                 c[2] += sh[j].y & 0xFFFFu; c[3] += sh[j].y >> 16;
             }
         }
-        uint32_t csum = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t b = 4u * (uint32_t)tid + (uint32_t)i;
-            if (b < b_lo || b > b_hi) c[i] = 0u;      // (a sampled key outside the range cannot exist; an unwritten row could)
-            csum += c[i];
-        }
-        const uint32_t cincl = wave_incl_scan_u32(csum, lane);
-        if (lane == 63) s_w[w] = cincl;
-        __syncthreads();
+        nm = wave_incl_max_u32(nm);
+        mx = wave_incl_max_u32(mx);
+        const uint32_t cs = wave_incl_scan_u32(c[0] + c[1] + c[2] + c[3], lane);
+        if (lane == 63) { s_nmin[w] = nm; s_max[w] = mx; s_w[w] = cs; }
+    }
+    __syncthreads();
+    const uint32_t tmin = ~max(max(s_nmin[0], s_nmin[1]), max(s_nmin[2], s_nmin[3]));
+    const uint32_t tmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    {   // Round 2 (one barrier): coarse bin b in [b_lo, b_hi] gets 1 + floor(spare * c[b] / C) buckets; their exclusive prefix is the table.
+        // (Every sampled key lies inside the true range, so C counts exactly the sampled keys of the bins in range.)
+        const bool any = tmax >= tmin;      // (nothing listed: tmin = 0xFFFFFFFF, tmax = 0)
+        const uint32_t b_lo = any ? tmin >> GSR_EQ_SHIFT : 0u, b_hi = any ? min(tmax >> GSR_EQ_SHIFT, (uint32_t)GSR_EQ_BINS - 1u) : 0u;
         const uint32_t C = s_w[0] + s_w[1] + s_w[2] + s_w[3];
         const uint32_t nbins = b_hi - b_lo + 1u, spare = (uint32_t)DS_NB - 2u - nbins;      // >= 1022
         uint32_t nb[4], nsum = 0;
@@ -166,13 +159,12 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
             nsum += nb[i];
         }
         const uint32_t nincl = wave_incl_scan_u32(nsum, lane);
-        __syncthreads();
-        if (lane == 63) s_w[w] = nincl;
+        if (lane == 63) s_w2[w] = nincl;
         __syncthreads();
         uint32_t run = nincl - nsum;
 #pragma unroll
         for (int k2 = 0; k2 < WG_WAVES; ++k2)
-            if (k2 < w) run += s_w[k2];
+            if (k2 < w) run += s_w2[k2];
         uint4 e;
         e.x = run | (nb[0] << 16); run += nb[0];
         e.y = run | (nb[1] << 16); run += nb[1];
