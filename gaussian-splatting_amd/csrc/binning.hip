@@ -245,7 +245,7 @@ tile_ranges(int64_t R, const KeyT* __restrict__ keys, uint2* __restrict__ ranges
 __global__ void __launch_bounds__(256)
 splat_ingest(int P, const float4* __restrict__ records, int y0, int y1, float4* __restrict__ splats, uint2* __restrict__ rect,
              uint32_t* __restrict__ tiles, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GsrFrameStatsDev fs) {
-    __shared__ uint32_t s_eq[GSR_EQ_BINS];      // (the commit's coarse key histogram, gsr_frame.h)
+    __shared__ uint32_t s_eq[2 * GSR_EQ_BINS];      // (the commit's coarse key histogram, gsr_frame.h)
     GsrFrameAcc acc;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 q0 = records[i * 4 + 0], q1 = records[i * 4 + 1], q2 = records[i * 4 + 2], q3 = records[i * 4 + 3];

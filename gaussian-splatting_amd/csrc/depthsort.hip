@@ -25,9 +25,10 @@
 //               first bucket), 2-3 passes of <= 9 bits; then, in sorted order: Gaussian id, its tile rectangle (gathered),
 //               the INCLUSIVE SCAN of the tile counts (segment base + scan inside the segment) and the per-block table of the
 //               emission -- everything the depth sort's last pass and the two scan kernels used to produce.
-//               A segment beyond the LDS capacity (one bucket holding > 2048 keys more than the window: thousands of Gaussians
-//               within 1/2046 of the depth range) is sorted by the same workgroup with the same passes through global memory --
-//               correct, slow, and reported to the host, which then prefers the LSD sort for a while (gsr_api.cpp).
+//               A segment beyond the LDS capacity (it ends with a bucket of more than 2048 keys) is cut into groups of whole buckets
+//               that fit and sorted group by group; a SINGLE bucket beyond the capacity -- after both levels of the equalised table:
+//               thousands of equal depths -- needs no pass when all its keys are equal, else goes through global memory, is
+//               reported to the host, and the host prefers the LSD sort for a while (gsr_api.cpp).
 //
 // Order: (key, Gaussian index) ascending -- ds_scatter is stable and the segment sort is stable, so equal depths keep index
 // order exactly as the LSD sort (and the reference's stable 64-bit-key sort) leaves them.  No atomics on global memory, no
@@ -51,25 +52,52 @@ constexpr int DS_PASS_BITS = 9;
 constexpr int DS_PASS_BINS = 1 << DS_PASS_BITS;
 static_assert(DS_IPT == 16 && DS_DPT == 8, "layout");
 
-// eq[b] = first bucket | buckets << 16 of coarse bin b (LDS, GSR_EQ_BINS words).  Monotone in the key; every key inside the frame's true
-// range lies in a coarse bin that owns at least one bucket.
-__device__ __forceinline__ uint32_t ds_bucket(uint32_t key, const uint32_t* eq) {
+// eq[b] = first bucket | buckets << 16 of coarse bin b; eq2[j] = the same for sub-bin j of the HOT coarse bin `hot` (GSR_EQ_NO_HOT: no second
+// level); LDS.  Monotone in the key; every key inside the frame's true range lies in a coarse bin that owns at least one bucket, and the
+// sub-bins of the hot bin share its buckets (a sub-bin without a bucket of its own maps to the first bucket at or behind its position).
+struct EqView {
+    const uint32_t* eq;
+    const uint32_t* eq2;
+    uint32_t hot;
+};
+__device__ __forceinline__ uint32_t ds_bucket(uint32_t key, const EqView& v) {
     if (key == GSR_DEPTH_KEY_CULLED) return DS_CULL;
-    const uint32_t e = eq[key >> GSR_EQ_SHIFT];
+    const uint32_t b = key >> GSR_EQ_SHIFT;
+    const uint32_t e = v.eq[b];
+    if (b == v.hot) {
+        const uint32_t e2 = v.eq2[(key >> GSR_EQ_SHIFT2) & ((uint32_t)GSR_EQ_BINS - 1u)], nb2 = e2 >> 16, st2 = e2 & 0xFFFFu;
+        if (nb2) return st2 + (((key & ((1u << GSR_EQ_SHIFT2) - 1u)) * nb2) >> GSR_EQ_SHIFT2);
+        return min(st2, (e & 0xFFFFu) + (e >> 16) - 1u);
+    }
     return (e & 0xFFFFu) + (((key & ((1u << GSR_EQ_SHIFT) - 1u)) * (e >> 16)) >> GSR_EQ_SHIFT);
 }
-// smallest key that maps to bucket d (d below the number of buckets in use): binary search for the coarse bin that owns d
-__device__ __forceinline__ uint32_t ds_bucket_first_key(uint32_t d, const uint32_t* eq) {
+// smallest key that maps to a bucket >= d (d below the number of buckets in use): binary search for the coarse bin that owns d, then --
+// inside the hot bin -- for the first sub-bin whose largest bucket reaches d
+__device__ __forceinline__ uint32_t ds_bucket_first_key(uint32_t d, const EqView& v) {
     uint32_t lo = 0, hi = GSR_EQ_BINS;      // first coarse bin whose first bucket is > d
 #pragma unroll 1
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
-        if ((eq[mid] & 0xFFFFu) > d) hi = mid; else lo = mid + 1;
+        if ((v.eq[mid] & 0xFFFFu) > d) hi = mid; else lo = mid + 1;
     }
     const uint32_t b = lo - 1u;             // (the last bin that starts at or before d: it owns buckets, the empty ones behind it start later)
-    const uint32_t e = eq[b], nb = e >> 16, j = d - (e & 0xFFFFu);
-    // smallest x with (x * nb) >> SHIFT >= j
-    const uint32_t x = nb ? ((j << GSR_EQ_SHIFT) + nb - 1u) / nb : 0u;
+    const uint32_t e = v.eq[b], nb = e >> 16, st = e & 0xFFFFu;
+    if (b == v.hot) {
+        const uint32_t last = st + nb - 1u;
+        lo = 0; hi = GSR_EQ_BINS - 1;       // first sub-bin whose largest bucket is >= d (the last sub-bin's is `last` >= d)
+#pragma unroll 1
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const uint32_t e2 = v.eq2[mid], nb2 = e2 >> 16, st2 = e2 & 0xFFFFu;
+            const uint32_t top = nb2 ? st2 + nb2 - 1u : min(st2, last);
+            if (top >= d) hi = mid; else lo = mid + 1;
+        }
+        const uint32_t e2 = v.eq2[lo], nb2 = e2 >> 16, st2 = e2 & 0xFFFFu;
+        const uint32_t x = (nb2 && st2 < d) ? (((d - st2) << GSR_EQ_SHIFT2) + nb2 - 1u) / nb2 : 0u;
+        return (b << GSR_EQ_SHIFT) + (lo << GSR_EQ_SHIFT2) + x;
+    }
+    // smallest x with (x * nb) >> SHIFT >= d - st
+    const uint32_t x = nb ? (((d - st) << GSR_EQ_SHIFT) + nb - 1u) / nb : 0u;
     return (b << GSR_EQ_SHIFT) + x;
 }
 
@@ -94,8 +122,8 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
         const uint2* __restrict__ wg_range, int n_range, const uint16_t* __restrict__ sample_hist, uint32_t* __restrict__ eq_tab,
         uint32_t* __restrict__ cnt_tab, uint32_t* __restrict__ tile_tab) {
     __shared__ uint32_t h_cnt[DS_NB], h_tile[DS_NB];
-    __shared__ __attribute__((aligned(16))) uint32_t s_eq[GSR_EQ_BINS];
-    __shared__ uint32_t s_nmin[WG_WAVES], s_max[WG_WAVES], s_w[WG_WAVES], s_w2[WG_WAVES];
+    __shared__ __attribute__((aligned(16))) uint32_t s_eq[GSR_EQ_BINS], s_eq2[GSR_EQ_BINS];
+    __shared__ uint32_t s_nmin[WG_WAVES], s_max[WG_WAVES], s_w[WG_WAVES], s_w2[WG_WAVES], s_hotp[WG_WAVES], s_w3[WG_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * DS_ITEMS;
     static_assert(GSR_EQ_BINS == 4 * DS_THREADS, "thread t owns the coarse bins 4t .. 4t+3");
@@ -107,7 +135,7 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
     for (int j = 0; j < 8; ++j) rg[j] = wg_range[min(j * DS_THREADS + tid, n_range - 1)];      // (clamped: duplicates do not change a max)
 #pragma unroll
     for (int j = 0; j < GSR_EQ_SAMPLE_WGS; ++j)      // four 16-bit counts per row (clamped row: masked below)
-        sh[j] = reinterpret_cast<const uint2*>(sample_hist + (size_t)min(j, n_samp - 1) * GSR_EQ_BINS)[tid];
+        sh[j] = reinterpret_cast<const uint2*>(sample_hist + (size_t)min(j, n_samp - 1) * GSR_EQ_SAMPLE_ROW)[tid];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {      // all loads first, the LDS clear rides in their shadow
         const int64_t e0 = base + ((int64_t)v * DS_THREADS + tid) * 4;
@@ -135,14 +163,20 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
                 c[2] += sh[j].y & 0xFFFFu; c[3] += sh[j].y >> 16;
             }
         }
+        // the fullest coarse bin of the summed sample (the lowest one on ties): count << 10 | (1023 - bin); counts <= 16 * 65535 < 2^20
+        uint32_t hp = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hp = max(hp, (c[i] << 10) | ((uint32_t)GSR_EQ_BINS - 1u - (4u * (uint32_t)tid + (uint32_t)i)));
         nm = wave_incl_max_u32(nm);
         mx = wave_incl_max_u32(mx);
+        hp = wave_incl_max_u32(hp);
         const uint32_t cs = wave_incl_scan_u32(c[0] + c[1] + c[2] + c[3], lane);
-        if (lane == 63) { s_nmin[w] = nm; s_max[w] = mx; s_w[w] = cs; }
+        if (lane == 63) { s_nmin[w] = nm; s_max[w] = mx; s_w[w] = cs; s_hotp[w] = hp; }
     }
     __syncthreads();
     const uint32_t tmin = ~max(max(s_nmin[0], s_nmin[1]), max(s_nmin[2], s_nmin[3]));
     const uint32_t tmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    uint32_t hot = GSR_EQ_NO_HOT;
     {   // Round 2 (one barrier): coarse bin b in [b_lo, b_hi] gets 1 + floor(spare * c[b] / C) buckets; their exclusive prefix is the table.
         // (Every sampled key lies inside the true range, so C counts exactly the sampled keys of the bins in range.)
         const bool any = tmax >= tmin;      // (nothing listed: tmin = 0xFFFFFFFF, tmax = 0)
@@ -175,15 +209,65 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
             reinterpret_cast<uint4*>(eq_tab)[tid] = e;
             if (tid == 0) { frame[2] = tmin; frame[3] = tmax; frame[6] = tmin; frame[7] = tmax; }
         }
+        // Second level (gsr_frame.h), workgroup-uniform and rare: one coarse bin holds an eighth of the sample or more.  Its buckets are spread
+        // over its 1024 sub-bins in proportion to THEIR sampled mass (rows of the sample workgroups whose own fullest bin is the same one):
+        // sub-bin j takes the buckets [S + NB * F(<j) / F, S + NB * F(<=j) / F).
+        const uint32_t hpm = max(max(s_hotp[0], s_hotp[1]), max(s_hotp[2], s_hotp[3]));
+        const uint32_t cH = hpm >> 10, H = (uint32_t)GSR_EQ_BINS - 1u - (hpm & ((uint32_t)GSR_EQ_BINS - 1u));
+        hot = (any && C >= 256u && cH * 8u >= C) ? H : GSR_EQ_NO_HOT;
     }
     __syncthreads();
+    if (hot != GSR_EQ_NO_HOT) {
+        const uint32_t* hot_of = reinterpret_cast<const uint32_t*>(sample_hist + (size_t)GSR_EQ_SAMPLE_WGS * GSR_EQ_SAMPLE_ROW);
+        uint32_t f[4] = {0u, 0u, 0u, 0u};
+        uint32_t ho[GSR_EQ_SAMPLE_WGS];
+        uint2 fr[GSR_EQ_SAMPLE_WGS];
+#pragma unroll
+        for (int j = 0; j < GSR_EQ_SAMPLE_WGS; ++j) {      // unconditional loads (clamped row), masked below: one round trip, not sixteen
+            ho[j] = hot_of[min(j, n_samp - 1)];
+            fr[j] = reinterpret_cast<const uint2*>(sample_hist + (size_t)min(j, n_samp - 1) * GSR_EQ_SAMPLE_ROW + GSR_EQ_BINS)[tid];
+        }
+#pragma unroll
+        for (int j = 0; j < GSR_EQ_SAMPLE_WGS; ++j) {
+            const bool use = j < n_samp && ho[j] == hot;
+            f[0] += use ? fr[j].x & 0xFFFFu : 0u; f[1] += use ? fr[j].x >> 16 : 0u;
+            f[2] += use ? fr[j].y & 0xFFFFu : 0u; f[3] += use ? fr[j].y >> 16 : 0u;
+        }
+        const uint32_t fsum = f[0] + f[1] + f[2] + f[3];
+        const uint32_t fincl = wave_incl_scan_u32(fsum, lane);
+        if (lane == 63) s_w3[w] = fincl;
+        __syncthreads();
+        const uint32_t F = s_w3[0] + s_w3[1] + s_w3[2] + s_w3[3];
+        if (F == 0u) {      // (no sample workgroup's own fullest bin is this one: no second level; workgroup-uniform)
+            hot = GSR_EQ_NO_HOT;
+        } else {
+            uint32_t run = fincl - fsum;
+#pragma unroll
+            for (int k2 = 0; k2 < WG_WAVES; ++k2)
+                if (k2 < w) run += s_w3[k2];
+            const uint32_t eH = s_eq[hot], S = eH & 0xFFFFu, NB = eH >> 16;
+            uint32_t e2[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t st2 = S + (uint32_t)(((uint64_t)NB * run) / F), en2 = S + (uint32_t)(((uint64_t)NB * (run + f[i])) / F);
+                run += f[i];
+                e2[i] = st2 | ((en2 - st2) << 16);
+            }
+            const uint4 q = make_uint4(e2[0], e2[1], e2[2], e2[3]);
+            reinterpret_cast<uint4*>(s_eq2)[tid] = q;
+            if (blockIdx.x == 0) reinterpret_cast<uint4*>(eq_tab + GSR_EQ_BINS)[tid] = q;
+            __syncthreads();
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) eq_tab[2 * GSR_EQ_BINS] = hot;
+    const EqView eqv{s_eq, s_eq2, hot};
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int64_t e0 = base + ((int64_t)v * DS_THREADS + tid) * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (e0 + j < P) {
-                const uint32_t d = ds_bucket(k[v][j], s_eq);
+                const uint32_t d = ds_bucket(k[v][j], eqv);
                 atomicAdd(&h_cnt[d], 1u);
                 if (t[v][j]) atomicAdd(&h_tile[d], t[v][j]);
             }
@@ -301,11 +385,14 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t
            uint32_t* __restrict__ plan, int nseg_cap) {
     __shared__ __attribute__((aligned(16))) uint16_t wave_cnt[S3_WAVES][DS_NB];      // 32 KB (a wave counts <= 512 keys)
     __shared__ __attribute__((aligned(16))) uint32_t digit_base[DS_NB];              //  8 KB
-    __shared__ __attribute__((aligned(16))) uint32_t s_eq[GSR_EQ_BINS];              //  4 KB equalised bucket table (ds_hist)
+    __shared__ __attribute__((aligned(16))) uint32_t s_eq[GSR_EQ_BINS], s_eq2[GSR_EQ_BINS];      //  8 KB equalised bucket tables (ds_hist)
     __shared__ uint32_t wsum[S3_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     static_assert(GSR_EQ_BINS == 2 * S3_THREADS, "one 8-byte load per thread");
+    const uint32_t hot = eq_tab[2 * GSR_EQ_BINS];
     reinterpret_cast<uint2*>(s_eq)[tid] = reinterpret_cast<const uint2*>(eq_tab)[tid];      // (the barriers below publish it)
+    if (hot != GSR_EQ_NO_HOT) reinterpret_cast<uint2*>(s_eq2)[tid] = reinterpret_cast<const uint2*>(eq_tab + GSR_EQ_BINS)[tid];
+    const EqView eqv{s_eq, s_eq2, hot};
 
     if ((int)blockIdx.x == nblocks) {
         // ---- the segment plan (one workgroup, beside the scattering ones) ----
@@ -354,8 +441,8 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t
                 e = make_uint4(cnt_excl[d0], cnt_excl[d1], d0, d1);
                 tb = tile_excl[d0];
                 // the keys of buckets [d0, d1): [first key of d0, first key of d1), inside the frame's true range (keys < 2^27: no overflow)
-                key_lo = max(tmin, ds_bucket_first_key(d0, s_eq));
-                key_hi = d1 >= used ? tmax + 1u : min(tmax + 1u, ds_bucket_first_key(d1, s_eq));
+                key_lo = max(tmin, ds_bucket_first_key(d0, eqv));
+                key_hi = d1 >= used ? tmax + 1u : min(tmax + 1u, ds_bucket_first_key(d1, eqv));
             }
             reinterpret_cast<uint4*>(plan)[2 * s] = e;
             reinterpret_cast<uint4*>(plan)[2 * s + 1] = make_uint4(tb, listed, key_lo, key_hi);
@@ -399,7 +486,7 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t
     for (int r = 0; r < S3_IPT; ++r) {
         const int64_t idx = wave_base + r * 64 + lane;
         const bool valid = idx < P;
-        const uint32_t d = ds_bucket(key[r], s_eq);
+        const uint32_t d = ds_bucket(key[r], eqv);
         dig[r] = d;
         const uint64_t mask = match_digit(d, GSR_DS_BITS, __ballot(valid));
         const uint32_t prior = valid ? (uint32_t)wave_cnt[w][d] : 0u;
@@ -602,17 +689,66 @@ __device__ __forceinline__ uint32_t seg_output(const uint32_t (&id)[SG_OUT], uin
     return run - tile_base;
 }
 
+// `n` <= DS_CAP consecutive elements [begin, begin + n) of the bucket-ordered array, keys in [base_key, base_key + 2^nbits): sorted in LDS and written
+// out (order, rectangles, inclusive tile scan from `tile_base`, emission block table).  Returns the tile instances of the run (every thread).
+struct SegLdsMem {
+    uint32_t (*s_key)[DS_CAP];
+    uint16_t (*s_idx)[DS_CAP];
+    uint16_t (*wave_cnt)[DS_PASS_BINS];
+    uint32_t* wsum;
+    uint32_t (*s_wt)[SG_WAVES];
+};
+__device__ __forceinline__ uint32_t seg_sort_in_lds(const SegLdsMem& L, const uint2* __restrict__ pairs0, uint32_t begin, uint32_t n, uint32_t base_key, int nbits,
+                                                    uint32_t tile_base, const uint2* __restrict__ rect, uint32_t* __restrict__ order, uint2* __restrict__ rect_sorted,
+                                                    uint32_t* __restrict__ offsets, uint2* __restrict__ block_first, uint32_t bf_cap, uint32_t last_listed, bool r_ok) {
+    const int tid = threadIdx.x;
+    SegLds m{L.s_key, L.s_idx};
+    {   // all loads, then all LDS writes (a load inside "if (p < n) lds[p] = ..." is waited for one by one)
+        uint32_t kk[SG_OUT];
+#pragma unroll
+        for (int j = 0; j < SG_OUT; ++j) {
+            const uint32_t p = (uint32_t)j * SG_THREADS + (uint32_t)tid;
+            kk[j] = pairs0[begin + (p < n ? p : 0u)].x;
+        }
+#pragma unroll
+        for (int j = 0; j < SG_OUT; ++j) {
+            const uint32_t p = (uint32_t)j * SG_THREADS + (uint32_t)tid;
+            if (p < n) {
+                L.s_key[0][p] = kk[j] - base_key;
+                L.s_idx[0][p] = (uint16_t)p;
+            }
+        }
+    }
+    __syncthreads();
+    const int cur = seg_sort<SegLds, uint16_t>(m, n, nbits, L.wave_cnt, L.wsum);
+    uint32_t ix[SG_OUT], id[SG_OUT];
+#pragma unroll
+    for (int j = 0; j < SG_OUT; ++j) {
+        const uint32_t p = (uint32_t)j * SG_THREADS + (uint32_t)tid;
+        ix[j] = p < n ? (uint32_t)L.s_idx[cur][p] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < SG_OUT; ++j) {
+        const uint32_t p = (uint32_t)j * SG_THREADS + (uint32_t)tid;
+        const uint32_t v = pairs0[begin + ix[j]].y;
+        id[j] = p < n ? v : 0u;
+    }
+    return seg_output(id, n, begin, tile_base, rect, order, rect_sorted, offsets, block_first, bf_cap, last_listed, r_ok, L.s_wt);
+}
+
 __global__ void __launch_bounds__(SG_THREADS)
-ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame, uint2* pairs0, uint2* pairs1,
+ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame, const uint32_t* __restrict__ cnt_total, uint2* pairs0, uint2* pairs1,
            const uint2* __restrict__ rect, uint32_t* __restrict__ order, uint2* __restrict__ rect_sorted, uint32_t* __restrict__ offsets,
            uint2* __restrict__ block_first, uint32_t bf_cap, uint32_t* slow_word /*mapped host word or NULL*/) {
-    __shared__ uint32_t s_key[2][DS_CAP];                       // 32 KB (oversized segments: the 32-bit count table instead)
+    __shared__ uint32_t s_key[2][DS_CAP];                       // 32 KB (a bucket beyond the LDS capacity: the 32-bit count table instead)
     __shared__ uint16_t s_idx[2][DS_CAP];                       // 16 KB
     __shared__ uint16_t wave_cnt[SG_WAVES][DS_PASS_BINS];       //  8 KB
     __shared__ uint32_t wsum[SG_WAVES];
     __shared__ uint32_t s_wt[SG_OUT][SG_WAVES];
+    __shared__ uint32_t s_bc[DS_NB];                            //  8 KB bucket sizes of an oversized segment
+    __shared__ uint32_t s_mm[2][SG_WAVES];
     static_assert(sizeof(uint32_t) * SG_WAVES * DS_PASS_BINS <= sizeof(uint32_t) * 2 * DS_CAP, "count table of the oversized path");
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint4 e = reinterpret_cast<const uint4*>(plan)[2 * blockIdx.x];
     const uint32_t begin = e.x, end = e.y, d0 = e.z, d1 = e.w;
     if (end <= begin) return;
@@ -625,63 +761,69 @@ ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame
     const uint32_t base_key = e2.z, top_key = e2.w;
     const uint32_t span = top_key > base_key ? top_key - base_key : 0u;
     const int nbits = span <= 1u ? 0 : 32 - __clz((int)(span - 1u));
-    (void)d0; (void)d1;
     // (the segments tile [0, listed): exactly one ends at `listed`.  Its end BUCKET need not be 2047 -- behind the last
     // non-empty bucket come empty ones that start at `listed` too -- so the element count decides, not the bucket)
     const uint32_t last_listed = end == listed ? end - 1u : 0xFFFFFFFFu;
+    const SegLdsMem L{s_key, s_idx, wave_cnt, wsum, s_wt};
     if (n <= (uint32_t)DS_CAP) {
-        SegLds m{s_key, s_idx};
-        {   // all loads, then all LDS writes (a load inside "if (p < n) lds[p] = ..." is waited for one by one)
-            uint32_t kk[SG_OUT];
-#pragma unroll
-            for (int j = 0; j < SG_OUT; ++j) {
-                const uint32_t p = (uint32_t)j * SG_THREADS + (uint32_t)tid;
-                kk[j] = pairs0[begin + (p < n ? p : 0u)].x;
-            }
-#pragma unroll
-            for (int j = 0; j < SG_OUT; ++j) {
-                const uint32_t p = (uint32_t)j * SG_THREADS + (uint32_t)tid;
-                if (p < n) {
-                    s_key[0][p] = kk[j] - base_key;
-                    s_idx[0][p] = (uint16_t)p;
-                }
-            }
-        }
-        __syncthreads();
-        const int cur = seg_sort<SegLds, uint16_t>(m, n, nbits, wave_cnt, wsum);
-        uint32_t ix[SG_OUT], id[SG_OUT];
-#pragma unroll
-        for (int j = 0; j < SG_OUT; ++j) {
-            const uint32_t p = (uint32_t)j * SG_THREADS + (uint32_t)tid;
-            ix[j] = p < n ? (uint32_t)s_idx[cur][p] : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < SG_OUT; ++j) {
-            const uint32_t p = (uint32_t)j * SG_THREADS + (uint32_t)tid;
-            const uint32_t v = pairs0[begin + ix[j]].y;
-            id[j] = p < n ? v : 0u;
-        }
-        seg_output(id, n, begin, tile_base, rect, order, rect_sorted, offsets, block_first, bf_cap, last_listed, r_ok, s_wt);
+        seg_sort_in_lds(L, pairs0, begin, n, base_key, nbits, tile_base, rect, order, rect_sorted, offsets, block_first, bf_cap, last_listed, r_ok);
         return;
     }
-    // ---- oversized segment: the same passes through global memory (pairs0 <-> pairs1), then the output in chunks ----
-    if (slow_word && tid == 0) __hip_atomic_store(slow_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    SegGlobal m{pairs0 + begin, pairs1 + begin, base_key};
-    uint32_t (*cnt32)[DS_PASS_BINS] = reinterpret_cast<uint32_t (*)[DS_PASS_BINS]>(&s_key[0][0]);
-    const int cur = seg_sort<SegGlobal, uint32_t>(m, n, nbits, cnt32, wsum);
-    const uint2* sorted = cur ? m.p1 : m.p0;
-    uint32_t tb = tile_base;
+    // ---- oversized segment (round 6: bounded).  It is a run of WHOLE buckets in key order, so it is cut into groups of consecutive buckets of
+    // at most DS_CAP elements, each sorted in LDS like an ordinary segment (with the segment's key span), one after the other.  Only a single
+    // bucket beyond the capacity is left: its own key span is measured (min / max of its keys) -- a run of EQUAL keys, which the second-level
+    // table isolates, needs no pass at all -- otherwise the radix passes go through global memory for that bucket alone.  Reported to the host
+    // (which then prefers the LSD passes for a while) only when it really is slow: passes through global memory, or > 16 chunks of output.
+    const uint32_t nbk = d1 - d0;      // <= 2047
+    for (uint32_t i = (uint32_t)tid; i < nbk; i += (uint32_t)SG_THREADS) s_bc[i] = cnt_total[d0 + i];
+    __syncthreads();
+    uint32_t g_begin = begin, g_d = 0, tb = tile_base;
 #pragma unroll 1
-    for (uint32_t c0 = 0; c0 < n; c0 += (uint32_t)DS_CAP) {
-        const uint32_t mm = min((uint32_t)DS_CAP, n - c0);
-        uint32_t id[SG_OUT];
+    while (g_d < nbk) {      // (every thread walks the same bucket sizes: workgroup-uniform control flow)
+        uint32_t n_g = s_bc[g_d], g_e = g_d + 1u;
+        while (g_e < nbk && n_g + s_bc[g_e] <= (uint32_t)DS_CAP) n_g += s_bc[g_e++];
+        if (n_g != 0u && n_g <= (uint32_t)DS_CAP) {
+            tb += seg_sort_in_lds(L, pairs0, g_begin, n_g, base_key, nbits, tb, rect, order, rect_sorted, offsets, block_first, bf_cap, last_listed, r_ok);
+            __syncthreads();
+        } else if (n_g != 0u) {
+            // one bucket of n_g > DS_CAP keys: its true key span
+            uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
+            for (uint32_t i = (uint32_t)tid; i < n_g; i += (uint32_t)SG_THREADS) {
+                const uint32_t k = pairs0[g_begin + i].x;
+                kmn = min(kmn, k);
+                kmx = max(kmx, k);
+            }
+            kmn = ~wave_incl_max_u32(~kmn);
+            kmx = wave_incl_max_u32(kmx);
+            if (lane == 63) { s_mm[0][w] = kmn; s_mm[1][w] = kmx; }
+            __syncthreads();
 #pragma unroll
-        for (int j = 0; j < SG_OUT; ++j) {
-            const uint32_t p = (uint32_t)j * SG_THREADS + (uint32_t)tid;
-            const uint32_t v = sorted[c0 + (p < mm ? p : 0u)].y;
-            id[j] = p < mm ? v : 0u;
+            for (int k2 = 0; k2 < SG_WAVES; ++k2) { kmn = min(kmn, s_mm[0][k2]); kmx = max(kmx, s_mm[1][k2]); }
+            const uint32_t sp = kmx - kmn + 1u;
+            const int nb_g = sp <= 1u ? 0 : 32 - __clz((int)(sp - 1u));
+            if (slow_word && tid == 0 && (nb_g > 0 || n_g > 16u * (uint32_t)DS_CAP))
+                __hip_atomic_store(slow_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            SegGlobal m{pairs0 + g_begin, pairs1 + g_begin, kmn};
+            uint32_t (*cnt32)[DS_PASS_BINS] = reinterpret_cast<uint32_t (*)[DS_PASS_BINS]>(&s_key[0][0]);
+            __syncthreads();
+            const int cur = seg_sort<SegGlobal, uint32_t>(m, n_g, nb_g, cnt32, wsum);
+            const uint2* sorted = cur ? m.p1 : m.p0;
+#pragma unroll 1
+            for (uint32_t c0 = 0; c0 < n_g; c0 += (uint32_t)DS_CAP) {
+                const uint32_t mm = min((uint32_t)DS_CAP, n_g - c0);
+                uint32_t id[SG_OUT];
+#pragma unroll
+                for (int j = 0; j < SG_OUT; ++j) {
+                    const uint32_t p = (uint32_t)j * SG_THREADS + (uint32_t)tid;
+                    const uint32_t v = sorted[c0 + (p < mm ? p : 0u)].y;
+                    id[j] = p < mm ? v : 0u;
+                }
+                tb += seg_output(id, mm, g_begin + c0, tb, rect, order, rect_sorted, offsets, block_first, bf_cap, last_listed, r_ok, s_wt);
+            }
+            __syncthreads();
         }
-        tb += seg_output(id, mm, begin + c0, tb, rect, order, rect_sorted, offsets, block_first, bf_cap, last_listed, r_ok, s_wt);
+        g_begin += n_g;
+        g_d = g_e;
     }
 }
 
@@ -702,6 +844,6 @@ void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* t
     hipLaunchKernelGGL(ds_scan, dim3(DS_NB / 16), dim3(DS_THREADS), 0, st, nblocks, b.cnt_tab, b.tile_tab, b.cnt_total, b.tile_total);
     hipLaunchKernelGGL(ds_scatter, dim3(nblocks + 1), dim3(S3_THREADS), 0, st, P, nblocks, keys, frame, b.eq_tab, b.cnt_tab, b.cnt_total,
                        b.tile_total, b.pairs[0], order, offsets, rect_sorted, b.plan, nseg_cap);
-    hipLaunchKernelGGL(ds_segsort, dim3(nseg_cap), dim3(SG_THREADS), 0, st, b.plan, frame, b.pairs[0], b.pairs[1], rect, order,
+    hipLaunchKernelGGL(ds_segsort, dim3(nseg_cap), dim3(SG_THREADS), 0, st, b.plan, frame, b.cnt_total, b.pairs[0], b.pairs[1], rect, order,
                        rect_sorted, offsets, block_first, block_first_cap, slow_word);
 }

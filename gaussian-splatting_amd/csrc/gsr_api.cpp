@@ -305,11 +305,11 @@ GsrGeom gsr_carve_geom(char* base, int P) {
         g.ds.cnt_total = (uint32_t*)take(GSR_DS_BUCKETS * 4);
         g.ds.tile_total = (uint32_t*)take(GSR_DS_BUCKETS * 4);
         g.ds.plan = (uint32_t*)take(nseg * 32);
-        g.ds.eq_tab = (uint32_t*)take((size_t)GSR_EQ_BINS * 4);
+        g.ds.eq_tab = (uint32_t*)take((size_t)GSR_EQ_TAB_WORDS * 4);
     }
     g.num_rendered = (uint32_t*)take(128);
     g.wg_range = (uint2*)take((size_t)GSR_FRAME_MAX_GROUPS * 8);
-    g.sample_hist = (uint16_t*)take((size_t)GSR_EQ_SAMPLE_WGS * GSR_EQ_BINS * 2);
+    g.sample_hist = (uint16_t*)take(GSR_EQ_SAMPLE_BYTES);
     g.bytes = off;
     return g;
 }

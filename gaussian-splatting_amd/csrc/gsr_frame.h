@@ -30,6 +30,17 @@
 #define GSR_EQ_SAMPLE_WGS 16      /* (A/B builds: -DGSR_EQ_SAMPLE_WGS=8) */
 #endif
 #define GSR_FRAME_KEY_CULLED ((1u << 27) - 1u)      // == GSR_DEPTH_KEY_CULLED (gsr_internal.h, checked there)
+// Second level, for ONE coarse bin: a sample workgroup also leaves the histogram of its fullest coarse bin ("hot" bin) over GSR_EQ_BINS
+// sub-bins of 2^GSR_EQ_SHIFT2 keys.  When one coarse bin holds an eighth of the sample or more (a wall seen head-on, a cluster within a
+// fraction of a percent of one depth, thousands of equal depths) ds_hist spreads that bin's buckets over its sub-bins in proportion to
+// their mass as well, so that a concentration 128 keys wide -- or a run of ties -- still gets buckets of its own.
+#define GSR_EQ_SHIFT2 7          // GSR_EQ_SHIFT - log2(GSR_EQ_BINS)
+#define GSR_EQ_NO_HOT 0xFFFFFFFFu
+// sample buffer: per sample workgroup a row of 2 * GSR_EQ_BINS 16-bit counts (coarse | sub-bins of its hot bin), then one word per workgroup: its hot bin
+#define GSR_EQ_SAMPLE_ROW (2 * GSR_EQ_BINS)
+#define GSR_EQ_SAMPLE_BYTES ((size_t)GSR_EQ_SAMPLE_WGS * GSR_EQ_SAMPLE_ROW * 2 + (size_t)GSR_EQ_SAMPLE_WGS * 4)
+// table buffer (ds_hist -> ds_scatter): GSR_EQ_BINS words level 1, GSR_EQ_BINS words level 2, then the hot bin (GSR_EQ_NO_HOT: no second level)
+#define GSR_EQ_TAB_WORDS (2 * GSR_EQ_BINS + 16)
 
 // counter (device memory, u64, zero between frames): bits [0, 42) sum of the tile counts (a workgroup's part saturates at
 // 2^31: any total >= 2^31 is refused by the host anyway), [42, 53) workgroups with a key overflow, [53, 64) tickets
@@ -42,7 +53,7 @@ struct GsrFrameStatsDev {
     uint32_t* state;       // NULL: the kernel keeps no statistics (shard projection without binning)
     uint32_t* frame;
     uint2* wg_range;       // [workgroups] (~smallest, largest) depth key of the workgroup's listed Gaussians; (0, 0): none
-    uint16_t* sample_hist; // [GSR_EQ_SAMPLE_WGS][GSR_EQ_BINS] (gsr_internal.h) or NULL: coarse histogram of the keys of the first workgroups
+    uint16_t* sample_hist; // GSR_EQ_SAMPLE_BYTES (layout above) or NULL: key histograms of the first GSR_EQ_SAMPLE_WGS workgroups
     uint32_t* host_word;   // may be NULL (then only `frame` is written)
     uint32_t seq;
 };
@@ -53,7 +64,7 @@ struct GsrFrameStatsDev {
 // keys / P: the depth-key array the kernel has just written with the loop `for (i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256)`
 // -- the first GSR_EQ_SAMPLE_WGS workgroups read THEIR OWN keys back (every thread the ones it stored itself) and leave their coarse
 // histogram in fs.sample_hist: a regular sample of the frame's depth distribution for the depth sort's bucket mapping (depthsort.hip).
-// lds: >= GSR_EQ_BINS words of LDS that nothing else uses after the loop.
+// lds: >= 2 * GSR_EQ_BINS words of LDS that nothing else uses after the loop.
 __device__ __forceinline__ void gsr_frame_stats_commit(const GsrFrameStatsDev& fs, uint64_t tiles_sum, uint32_t kmin, uint32_t kmax,
                                                        bool key_ovf, const uint32_t* keys, int64_t P, uint32_t* lds) {
     if (!fs.state) return;
@@ -66,20 +77,52 @@ __device__ __forceinline__ void gsr_frame_stats_commit(const GsrFrameStatsDev& f
     if (lane == 63) { s_sum[w] = wsum; s_nmin[w] = wnmin; s_max[w] = wmax; s_ovf[w] = ovf ? 1u : 0u; }
     __syncthreads();
     if (fs.sample_hist && blockIdx.x < (unsigned)GSR_EQ_SAMPLE_WGS) {      // (workgroup-uniform; every wave is past its loop: `lds` is free)
+        __shared__ uint32_t s_hot[4];
+        uint32_t* h1 = lds;
+        uint32_t* h2 = lds + GSR_EQ_BINS;
 #pragma unroll
-        for (int b = 0; b < GSR_EQ_BINS / 256; ++b) lds[b * 256 + threadIdx.x] = 0u;
+        for (int b = 0; b < 2 * GSR_EQ_BINS / 256; ++b) lds[b * 256 + threadIdx.x] = 0u;
         __syncthreads();
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (int64_t)gridDim.x * 256) {
-            const uint32_t k = keys[i];
-            if (k != GSR_FRAME_KEY_CULLED) atomicAdd(&lds[k >> GSR_EQ_SHIFT], 1u);
+        // (four keys per trip, loaded unconditionally from a clamped index: one memory round trip per four keys, not per key)
+        const int64_t first = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+        for (int64_t i0 = first; i0 < P; i0 += 4 * stride) {
+            uint32_t kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kk[u] = keys[i0 + u * stride < P ? i0 + u * stride : P - 1];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * stride < P && kk[u] != GSR_FRAME_KEY_CULLED) atomicAdd(&h1[kk[u] >> GSR_EQ_SHIFT], 1u);
         }
         __syncthreads();
-        uint16_t* row = fs.sample_hist + (size_t)blockIdx.x * GSR_EQ_BINS;
+        // the fullest coarse bin of THIS workgroup's sample (the lowest one on ties): count << 10 | (1023 - bin)
+        uint32_t best = 0;
 #pragma unroll
         for (int b = 0; b < GSR_EQ_BINS / 256; ++b) {
+            const uint32_t bin = (uint32_t)b * 256u + threadIdx.x;
+            best = max(best, (h1[bin] << 10) | ((uint32_t)GSR_EQ_BINS - 1u - bin));
+        }
+        best = gsrw::wave_incl_max_u32(best);
+        if (lane == 63) s_hot[w] = best;
+        __syncthreads();
+        const uint32_t hot = (uint32_t)GSR_EQ_BINS - 1u - (max(max(s_hot[0], s_hot[1]), max(s_hot[2], s_hot[3])) & ((uint32_t)GSR_EQ_BINS - 1u));
+        for (int64_t i0 = first; i0 < P; i0 += 4 * stride) {
+            uint32_t kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kk[u] = keys[i0 + u * stride < P ? i0 + u * stride : P - 1];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * stride < P && kk[u] != GSR_FRAME_KEY_CULLED && (kk[u] >> GSR_EQ_SHIFT) == hot)
+                    atomicAdd(&h2[(kk[u] >> GSR_EQ_SHIFT2) & ((uint32_t)GSR_EQ_BINS - 1u)], 1u);
+        }
+        __syncthreads();
+        uint16_t* row = fs.sample_hist + (size_t)blockIdx.x * GSR_EQ_SAMPLE_ROW;
+#pragma unroll
+        for (int b = 0; b < 2 * GSR_EQ_BINS / 256; ++b) {
             const uint32_t c = lds[b * 256 + threadIdx.x];
             row[b * 256 + threadIdx.x] = (uint16_t)(c < 65535u ? c : 65535u);
         }
+        if (threadIdx.x == 0)
+            reinterpret_cast<uint32_t*>(fs.sample_hist + (size_t)GSR_EQ_SAMPLE_WGS * GSR_EQ_SAMPLE_ROW)[blockIdx.x] = hot;
     }
     if (threadIdx.x != 0) return;
     uint64_t sum = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];

@@ -50,7 +50,7 @@ struct GsrDepthSortBufs {
     uint32_t* cnt_total;         // [2048]
     uint32_t* tile_total;        // [2048]
     uint32_t* plan;              // [segments][8]
-    uint32_t* eq_tab;            // [GSR_EQ_BINS] first bucket | buckets << 16 of every coarse bin (written by ds_hist's workgroup 0)
+    uint32_t* eq_tab;            // [GSR_EQ_TAB_WORDS] first bucket | buckets << 16 per coarse bin, the same per sub-bin of the hot coarse bin, the hot bin (ds_hist's workgroup 0)
 };
 size_t gsr_depth_bucket_blocks(int P);
 size_t gsr_depth_bucket_segments(int P);
@@ -71,7 +71,7 @@ struct GsrGeom {                 // P-sized
     GsrDepthSortBufs ds;         // bucket depth sort (depthsort.hip); carved for P <= GSR_DS_MAX_P
     uint32_t* num_rendered;      // frame words (gsr_frame.h): [0..1] R as 64 bits, [2] smallest, [3] largest depth key of a listed Gaussian
     uint2* wg_range;             // [GSR_FRAME_MAX_GROUPS] per-workgroup depth-key ranges of the key-producing kernel
-    uint16_t* sample_hist;       // [GSR_EQ_SAMPLE_WGS][GSR_EQ_BINS] coarse key histograms of the first workgroups of the key-producing kernel
+    uint16_t* sample_hist;       // GSR_EQ_SAMPLE_BYTES: key histograms of the first workgroups of the key-producing kernel (gsr_frame.h)
     size_t bytes;
 };
 GsrGeom gsr_carve_geom(char* base, int P);
@@ -85,7 +85,8 @@ GsrGeom gsr_carve_geom(char* base, int P);
 #define GSR_DEPTH_KEY_BITS 27
 #define GSR_DEPTH_KEY_BASE 0x3E4CCCCDu
 #define GSR_DEPTH_KEY_CULLED ((1u << GSR_DEPTH_KEY_BITS) - 1u)
-static_assert(GSR_DEPTH_KEY_CULLED == GSR_FRAME_KEY_CULLED && (1 << (GSR_DEPTH_KEY_BITS - GSR_EQ_SHIFT)) == GSR_EQ_BINS, "gsr_frame.h");
+static_assert(GSR_DEPTH_KEY_CULLED == GSR_FRAME_KEY_CULLED && (1 << (GSR_DEPTH_KEY_BITS - GSR_EQ_SHIFT)) == GSR_EQ_BINS &&
+              (1 << (GSR_EQ_SHIFT - GSR_EQ_SHIFT2)) == GSR_EQ_BINS, "gsr_frame.h");
 #ifdef __HIPCC__
 // `overflow` is a per-thread flag the caller reports ONCE, after its loop, through gsr_frame_stats_commit: a store through an
 // (unrestricted) host-word pointer inside the streaming loop made hipcc serialise the loop's batched loads (ISA audit: the

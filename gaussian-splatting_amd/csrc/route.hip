@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256)
 ingest_packed(int P, const float4* __restrict__ packed, int y0, int y1, float4* __restrict__ splats, uint2* __restrict__ rect,
               uint32_t* __restrict__ tiles, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GsrFrameStatsDev fs,
               int seg_rows /*0: P contiguous records; else rows per fixed-capacity segment = capacity + 1*/) {
-    __shared__ uint32_t s_eq[GSR_EQ_BINS];      // (the commit's coarse key histogram, gsr_frame.h)
+    __shared__ uint32_t s_eq[2 * GSR_EQ_BINS];      // (the commit's coarse key histogram, gsr_frame.h)
     GsrFrameAcc acc;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
         if (seg_rows) {      // header row, or a row past the segment's count: a Gaussian without tiles

@@ -20,7 +20,7 @@ int simt_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, c
     const size_t nblocks = gsr_depth_bucket_blocks(P), nseg = gsr_depth_bucket_segments(P);
     std::vector<uint2> pairs0((size_t)P + 16), pairs1((size_t)P + 16);
     std::vector<uint32_t> cnt_tab(nblocks * DS_NB), tile_tab(nblocks * DS_NB), cnt_total(DS_NB), tile_total(DS_NB), plan(nseg * 8 + 8);
-    std::vector<uint32_t> eq_tab(GSR_EQ_BINS);
+    std::vector<uint32_t> eq_tab(GSR_EQ_TAB_WORDS);
     const std::vector<uint16_t> sample = simt_sample_hist(keys, P, n_range);
     GsrDepthSortBufs b;
     b.pairs[0] = pairs0.data(); b.pairs[1] = pairs1.data();

@@ -62,8 +62,8 @@ int64_t simt_forward(const GsrRasterSettings* s, int snug, int P, int M, const f
     g.rect_sorted = rect_sorted.data(); g.offsets = offsets.data(); g.num_rendered = frame.data(); g.wg_range = wg_range.data();
     g.ds.pairs[0] = pairs0.data(); g.ds.pairs[1] = pairs1.data(); g.ds.cnt_tab = cnt_tab.data(); g.ds.tile_tab = tile_tab.data();
     g.ds.cnt_total = cnt_total.data(); g.ds.tile_total = tile_total.data(); g.ds.plan = plan.data();
-    std::vector<uint32_t> eq_tab(GSR_EQ_BINS);
-    std::vector<uint16_t> sample_hist((size_t)GSR_EQ_SAMPLE_WGS * GSR_EQ_BINS, 0xFFFFu);      // (poisoned: the kernel must write every row it later reads)
+    std::vector<uint32_t> eq_tab(GSR_EQ_TAB_WORDS);
+    std::vector<uint16_t> sample_hist(GSR_EQ_SAMPLE_BYTES / 2, 0xFFFFu);      // (poisoned: the kernel must write every row it later reads)
     g.ds.eq_tab = eq_tab.data(); g.sample_hist = sample_hist.data();
     GsrFrameStatsDev fs;
     fs.state = state.data(); fs.frame = frame.data(); fs.wg_range = wg_range.data(); fs.sample_hist = sample_hist.data(); fs.host_word = nullptr; fs.seq = 1;
@@ -205,8 +205,8 @@ int64_t simt_forward_sharded(const GsrRasterSettings* s, int snug, int G, const 
             GsrDepthSortBufs ds;
             ds.pairs[0] = pairs0.data(); ds.pairs[1] = pairs1.data(); ds.cnt_tab = cnt_tab.data(); ds.tile_tab = tile_tab.data();
             ds.cnt_total = cnt_total.data(); ds.tile_total = tile_total.data(); ds.plan = plan.data();
-            std::vector<uint32_t> eq_tab(GSR_EQ_BINS);
-            std::vector<uint16_t> sample_hist((size_t)GSR_EQ_SAMPLE_WGS * GSR_EQ_BINS, 0xFFFFu);
+            std::vector<uint32_t> eq_tab(GSR_EQ_TAB_WORDS);
+            std::vector<uint16_t> sample_hist(GSR_EQ_SAMPLE_BYTES / 2, 0xFFFFu);
             ds.eq_tab = eq_tab.data();
             GsrFrameStatsDev fs;
             fs.state = state.data(); fs.frame = frame.data(); fs.wg_range = wg_range.data(); fs.sample_hist = sample_hist.data(); fs.host_word = nullptr; fs.seq = 1;

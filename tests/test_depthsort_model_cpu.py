@@ -16,64 +16,106 @@ KEY_CULLED = (1 << 27) - 1
 KEY_BASE = 0x3E4CCCCD          # bits(0.2f), gsr_internal.h GSR_DEPTH_KEY_BASE
 
 
-EQ_SHIFT, EQ_BINS, EQ_SAMPLE_WGS = 17, 1024, 16      # csrc/gsr_frame.h
+EQ_SHIFT, EQ_BINS, EQ_SAMPLE_WGS, EQ_SHIFT2 = 17, 1024, 16, 7      # csrc/gsr_frame.h
 
 
 def sample_hist(keys, n_range):
     """What the first 16 workgroups of the key-producing kernel leave (gsr_frame.h): workgroup w of a grid of n_range 256-thread workgroups
-    owns the keys w * 256 + t + k * n_range * 256; the coarse histogram (key >> 17) of its listed keys, saturated at 65535."""
+    owns the keys w * 256 + t + k * n_range * 256; per workgroup the coarse histogram (key >> 17) of its listed keys, its fullest coarse bin
+    (the lowest on ties) and the histogram of THAT bin's keys over 1024 sub-bins ((key >> 7) & 1023); counts saturate at 65535."""
     P = len(keys)
     rows = []
     for w in range(min(EQ_SAMPLE_WGS, n_range)):
         idx = (np.arange(w * 256, P, n_range * 256)[:, None] + np.arange(256)[None, :]).reshape(-1)
-        k = keys[idx[idx < P]]
+        k = keys[idx[idx < P]].astype(np.int64)
         k = k[k != KEY_CULLED]
-        rows.append(np.minimum(np.bincount(k >> EQ_SHIFT, minlength=EQ_BINS), 65535))
+        c = np.bincount(k >> EQ_SHIFT, minlength=EQ_BINS)
+        hot = int(np.argmax(c))      # (first = lowest index on ties)
+        kh = k[(k >> EQ_SHIFT) == hot]
+        f = np.bincount((kh >> EQ_SHIFT2) & (EQ_BINS - 1), minlength=EQ_BINS)
+        rows.append((np.minimum(c, 65535), hot, np.minimum(f, 65535)))
     return rows
 
 
-def equalised_table(keys, n_range):
-    """ds_hist's bucket table: (first bucket, buckets) per coarse bin.  Every coarse bin inside the frame's true key range gets one bucket; the
-    remaining ones of the 2046 are handed out in proportion to the sampled mass (integer arithmetic, as in the kernel)."""
-    listed = keys[keys != KEY_CULLED]
-    start, nb = np.zeros(EQ_BINS, np.int64), np.zeros(EQ_BINS, np.int64)
-    if listed.size:
-        tmin, tmax = int(listed.min()), int(listed.max())
-        b_lo, b_hi = tmin >> EQ_SHIFT, min(tmax >> EQ_SHIFT, EQ_BINS - 1)
-    else:
-        b_lo = b_hi = 0
-    c = np.sum(sample_hist(keys, n_range), axis=0).astype(np.int64)
-    c[:b_lo] = 0
-    c[b_hi + 1:] = 0
-    C = int(c.sum())
-    nbins = b_hi - b_lo + 1
-    spare = NB - 2 - nbins
-    assert spare >= 1022
-    for b in range(b_lo, b_hi + 1):
-        nb[b] = 1 + ((spare * int(c[b])) // C if C else spare // nbins)
-    start = np.concatenate([[0], np.cumsum(nb)])[:EQ_BINS]
-    assert int(nb.sum()) <= NB - 2
-    return start, nb
+class EqTable:
+    """ds_hist's bucket tables.  Level 1: (first bucket, buckets) per coarse bin -- every coarse bin inside the frame's true key range gets one
+    bucket, the remaining ones of the 2046 are handed out in proportion to the sampled mass.  Level 2, only when one coarse bin holds an eighth
+    of the sample or more: that bin's buckets spread over its 1024 sub-bins in proportion to their sampled mass.  Integer arithmetic as in the kernel."""
 
-
-def bucket_of(keys, start, nb):
-    b = keys.astype(np.int64) >> EQ_SHIFT
-    return start[b] + (((keys.astype(np.int64) & ((1 << EQ_SHIFT) - 1)) * nb[b]) >> EQ_SHIFT)
-
-
-def first_key_of_bucket(d, start, nb):
-    """smallest key that maps to bucket d (d < buckets in use): the kernel's binary search over the table + the inverse of the in-bin mapping"""
-    lo, hi = 0, EQ_BINS
-    while lo < hi:
-        mid = (lo + hi) >> 1
-        if start[mid] > d:
-            hi = mid
+    def __init__(self, keys, n_range):
+        listed = keys[keys != KEY_CULLED]
+        nb = np.zeros(EQ_BINS, np.int64)
+        any_ = listed.size > 0
+        if any_:
+            tmin, tmax = int(listed.min()), int(listed.max())
+            b_lo, b_hi = tmin >> EQ_SHIFT, min(tmax >> EQ_SHIFT, EQ_BINS - 1)
         else:
-            lo = mid + 1
-    b = lo - 1
-    j = d - int(start[b])
-    x = ((j << EQ_SHIFT) + int(nb[b]) - 1) // int(nb[b]) if nb[b] else 0
-    return (b << EQ_SHIFT) + x
+            b_lo = b_hi = 0
+        rows = sample_hist(keys, n_range)
+        c = np.sum([r[0] for r in rows], axis=0).astype(np.int64)
+        C = int(c.sum())
+        nbins = b_hi - b_lo + 1
+        spare = NB - 2 - nbins
+        assert spare >= 1022
+        for b in range(b_lo, b_hi + 1):
+            nb[b] = 1 + ((spare * int(c[b])) // C if C else spare // nbins)
+        self.start = np.concatenate([[0], np.cumsum(nb)])[:EQ_BINS]
+        self.nb = nb
+        self.used = int(nb.sum())
+        assert self.used <= NB - 2
+        H = int(np.argmax(c))
+        self.hot = H if (any_ and C >= 256 and int(c[H]) * 8 >= C) else None
+        if self.hot is not None:
+            f = np.sum([r[2] for r in rows if r[1] == H] or [np.zeros(EQ_BINS, np.int64)], axis=0).astype(np.int64)
+            F = int(f.sum())
+            if F == 0:
+                self.hot = None
+            else:
+                S, NBH = int(self.start[H]), int(nb[H])
+                cum = np.concatenate([[0], np.cumsum(f)])
+                self.start2 = S + (NBH * cum[:-1]) // F
+                self.nb2 = S + (NBH * cum[1:]) // F - self.start2
+                assert int(self.start2[-1] + self.nb2[-1]) == S + NBH
+
+    def bucket_of(self, keys):
+        k = keys.astype(np.int64)
+        b = k >> EQ_SHIFT
+        d = self.start[b] + (((k & ((1 << EQ_SHIFT) - 1)) * self.nb[b]) >> EQ_SHIFT)
+        if self.hot is not None:
+            h = b == self.hot
+            j = (k[h] >> EQ_SHIFT2) & (EQ_BINS - 1)
+            last = int(self.start[self.hot] + self.nb[self.hot]) - 1
+            d2 = np.where(self.nb2[j] > 0, self.start2[j] + (((k[h] & ((1 << EQ_SHIFT2) - 1)) * self.nb2[j]) >> EQ_SHIFT2), np.minimum(self.start2[j], last))
+            d = d.copy()
+            d[h] = d2
+        return d
+
+    def first_key_of_bucket(self, d):
+        """smallest key that maps to a bucket >= d (d < buckets in use): the kernel's binary searches + the inverse of the in-bin mapping"""
+        lo, hi = 0, EQ_BINS
+        while lo < hi:
+            mid = (lo + hi) >> 1
+            if self.start[mid] > d:
+                hi = mid
+            else:
+                lo = mid + 1
+        b = lo - 1
+        st, nb = int(self.start[b]), int(self.nb[b])
+        if self.hot is not None and b == self.hot:
+            last = st + nb - 1
+            lo, hi = 0, EQ_BINS - 1
+            top = lambda j: int(self.start2[j] + self.nb2[j] - 1) if self.nb2[j] else min(int(self.start2[j]), last)      # noqa: E731
+            while lo < hi:
+                mid = (lo + hi) >> 1
+                if top(mid) >= d:
+                    hi = mid
+                else:
+                    lo = mid + 1
+            st2, nb2 = int(self.start2[lo]), int(self.nb2[lo])
+            x = (((d - st2) << EQ_SHIFT2) + nb2 - 1) // nb2 if (nb2 and st2 < d) else 0
+            return (b << EQ_SHIFT) + (lo << EQ_SHIFT2) + x
+        x = (((d - st) << EQ_SHIFT) + nb - 1) // nb if nb else 0
+        return (b << EQ_SHIFT) + x
 
 
 def bucket_depth_sort(keys, tiles, n_range=5):
@@ -83,9 +125,9 @@ def bucket_depth_sort(keys, tiles, n_range=5):
     listed = keys != KEY_CULLED
     assert ((tiles > 0) == listed).all()
     tmin, tmax = (int(keys[listed].min()), int(keys[listed].max())) if listed.any() else (0xFFFFFFFF, 0)
-    start, nb = equalised_table(keys, n_range)
-    used = int(nb.sum())
-    d = np.where(listed, bucket_of(np.where(listed, keys, 0), start, nb), CULL_BUCKET)
+    eq = EqTable(keys, n_range)
+    used = eq.used
+    d = np.where(listed, eq.bucket_of(np.where(listed, keys, 0)), CULL_BUCKET)
     if listed.any():
         dl, kl = d[listed], keys[listed].astype(np.int64)
         o = np.argsort(kl, kind="stable")
@@ -109,7 +151,7 @@ def bucket_depth_sort(keys, tiles, n_range=5):
         return lo
     order = np.empty(P, np.int64)
     scan = np.empty(P, np.int64)
-    block_first, sizes, covered = {}, [], 0
+    block_first, sizes, covered, spans = {}, [], 0, []
     R = int(tiles.sum())
     for s in range((P + SEG - 1) // SEG + 1):
         x0 = s * SEG
@@ -124,11 +166,13 @@ def bucket_depth_sort(keys, tiles, n_range=5):
         covered = e
         sizes.append(e - b)
         ids = by_bucket[b:e]
-        base_key = max(tmin, first_key_of_bucket(d0, start, nb))
-        span = (tmax + 1 if d1 >= used else min(tmax + 1, first_key_of_bucket(d1, start, nb))) - base_key
+        spans.append(None)
+        base_key = max(tmin, eq.first_key_of_bucket(d0))
+        span = (tmax + 1 if d1 >= used else min(tmax + 1, eq.first_key_of_bucket(d1))) - base_key
         rem = keys[ids].astype(np.int64) - base_key
         assert rem.min() >= 0 and rem.max() < max(span, 1), "rebased keys fit the segment's span"
         nbits = 0 if span <= 1 else int(span - 1).bit_length()
+        spans[-1] = (e - b, int(span))
         ids = ids[np.argsort(rem & ((1 << nbits) - 1), kind="stable")] if nbits else ids
         order[b:e] = ids
         incl = tile_excl[d0] + np.cumsum(tiles[ids])
@@ -143,6 +187,8 @@ def bucket_depth_sort(keys, tiles, n_range=5):
     assert covered == n_listed
     order[n_listed:] = by_bucket[n_listed:]
     scan[n_listed:] = R
+    bucket_depth_sort.last_table = eq
+    bucket_depth_sort.last_spans = spans
     return order, scan, block_first, sizes
 
 
@@ -152,7 +198,7 @@ def keys_from_depths(z, culled):
     return k
 
 
-CASES = ["uniform", "ties", "crowd", "gap", "one_key", "all_culled", "single", "last_bucket_straddles_a_window", "outliers", "heavy_tails", "wall"]
+CASES = ["uniform", "ties", "crowd", "gap", "one_key", "all_culled", "single", "last_bucket_straddles_a_window", "outliers", "heavy_tails", "wall", "wall_thin"]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -180,12 +226,14 @@ def test_bucket_depth_sort_model_equals_a_stable_sort(case):
         z[far] = np.exp(rng.uniform(np.log(0.25), np.log(9000.0), int(far.sum())))
     elif case == "wall":             # half of the scene within 0.3 % of one depth (a wall seen head-on), the rest spread over the frustum
         z = np.where(rng.random(P) < 0.5, rng.normal(6.0, 0.006, P), rng.uniform(1.0, 40.0, P))
+    elif case == "wall_thin":        # 60 % of the scene within 2e-4 of one depth (~1700 consecutive keys): narrower than one coarse bin's bucket
+        z = np.where(rng.random(P) < 0.6, 5.0 * (1.0 + 2e-4 * rng.random(P)), rng.uniform(1.0, 40.0, P))
     culled = rng.random(P) < (1.0 if case == "all_culled" else 0.12)
     keys = keys_from_depths(z, culled)
     tiles = np.where(culled, 0, rng.integers(1, 40, P)).astype(np.int64)
     n_range = (P + 255) // 256      # the key-producing kernel's grid at this size
     order, scan, block_first, sizes = bucket_depth_sort(keys, tiles, n_range)
-    if case in ("outliers", "gap", "heavy_tails", "wall"):
+    if case in ("outliers", "gap", "heavy_tails", "wall", "wall_thin"):
         assert max(sizes) <= CAP, "the equalised buckets keep every segment inside the LDS capacity"
     ref = np.argsort(keys, kind="stable")               # (depth key, index): what the LSD sort and the reference's sort leave
     assert (order == ref).all()
@@ -201,6 +249,12 @@ def test_bucket_depth_sort_model_equals_a_stable_sort(case):
         last = int(np.nonzero(tiles[ref])[0][-1])
         assert block_first[nblk] == (last, int(excl[last])), "the sentinel entry closes the table in EVERY case"
     if case == "crowd":
-        assert max(sizes) > CAP, "this case must exercise the oversized-segment path"
+        # 3/4 of the keys on 48 consecutive values: the second-level table gives every value buckets of its own; the oversized segments that
+        # remain hold EQUAL keys only (span 1: nothing to sort, the stable bucket order is the answer)
+        assert bucket_depth_sort.last_table.hot is not None
+        assert all(sp <= 1 for n, sp in bucket_depth_sort.last_spans if n > CAP)
+        assert max(sizes) <= CAP, "940 ties per value at this size: every value's bucket fits a segment (round 5: one 45 000-key segment)"
+    if case == "wall_thin":
+        assert bucket_depth_sort.last_table.hot is not None and max(sizes) <= CAP
     if case == "uniform":
         assert max(sizes) <= CAP
