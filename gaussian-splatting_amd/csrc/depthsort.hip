@@ -176,7 +176,7 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
     __syncthreads();
     const uint32_t tmin = ~max(max(s_nmin[0], s_nmin[1]), max(s_nmin[2], s_nmin[3]));
     const uint32_t tmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-    uint32_t hot = GSR_EQ_NO_HOT;
+    uint32_t hot = GSR_EQ_NO_HOT, hot_bg = 0u;
     {   // Round 2 (one barrier): coarse bin b in [b_lo, b_hi] gets 1 + floor(spare * c[b] / C) buckets; their exclusive prefix is the table.
         // (Every sampled key lies inside the true range, so C counts exactly the sampled keys of the bins in range.)
         const bool any = tmax >= tmin;      // (nothing listed: tmin = 0xFFFFFFFF, tmax = 0)
@@ -210,35 +210,35 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
             if (tid == 0) { frame[2] = tmin; frame[3] = tmax; frame[6] = tmin; frame[7] = tmax; }
         }
         // Second level (gsr_frame.h), workgroup-uniform and rare: one coarse bin holds an eighth of the sample or more.  Its buckets are spread
-        // over its 1024 sub-bins in proportion to THEIR sampled mass (rows of the sample workgroups whose own fullest bin is the same one):
+        // over its 1024 sub-bins in proportion to THEIR sampled mass (the folded sub-bin histogram minus its flat background, gsr_frame.h):
         // sub-bin j takes the buckets [S + NB * F(<j) / F, S + NB * F(<=j) / F).
         const uint32_t hpm = max(max(s_hotp[0], s_hotp[1]), max(s_hotp[2], s_hotp[3]));
         const uint32_t cH = hpm >> 10, H = (uint32_t)GSR_EQ_BINS - 1u - (hpm & ((uint32_t)GSR_EQ_BINS - 1u));
         hot = (any && C >= 256u && cH * 8u >= C) ? H : GSR_EQ_NO_HOT;
+        hot_bg = (C - cH + (uint32_t)GSR_EQ_BINS - 1u) / (uint32_t)GSR_EQ_BINS;
     }
     __syncthreads();
     if (hot != GSR_EQ_NO_HOT) {
-        const uint32_t* hot_of = reinterpret_cast<const uint32_t*>(sample_hist + (size_t)GSR_EQ_SAMPLE_WGS * GSR_EQ_SAMPLE_ROW);
         uint32_t f[4] = {0u, 0u, 0u, 0u};
-        uint32_t ho[GSR_EQ_SAMPLE_WGS];
         uint2 fr[GSR_EQ_SAMPLE_WGS];
 #pragma unroll
-        for (int j = 0; j < GSR_EQ_SAMPLE_WGS; ++j) {      // unconditional loads (clamped row), masked below: one round trip, not sixteen
-            ho[j] = hot_of[min(j, n_samp - 1)];
+        for (int j = 0; j < GSR_EQ_SAMPLE_WGS; ++j)      // unconditional loads (clamped row), masked below: one round trip, not sixteen
             fr[j] = reinterpret_cast<const uint2*>(sample_hist + (size_t)min(j, n_samp - 1) * GSR_EQ_SAMPLE_ROW + GSR_EQ_BINS)[tid];
-        }
 #pragma unroll
         for (int j = 0; j < GSR_EQ_SAMPLE_WGS; ++j) {
-            const bool use = j < n_samp && ho[j] == hot;
+            const bool use = j < n_samp;
             f[0] += use ? fr[j].x & 0xFFFFu : 0u; f[1] += use ? fr[j].x >> 16 : 0u;
             f[2] += use ? fr[j].y & 0xFFFFu : 0u; f[3] += use ? fr[j].y >> 16 : 0u;
         }
+        // the folded histogram = the hot bin's sub-bins + a flat background of the keys of all other coarse bins
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = f[i] > hot_bg ? f[i] - hot_bg : 0u;
         const uint32_t fsum = f[0] + f[1] + f[2] + f[3];
         const uint32_t fincl = wave_incl_scan_u32(fsum, lane);
         if (lane == 63) s_w3[w] = fincl;
         __syncthreads();
         const uint32_t F = s_w3[0] + s_w3[1] + s_w3[2] + s_w3[3];
-        if (F == 0u) {      // (no sample workgroup's own fullest bin is this one: no second level; workgroup-uniform)
+        if (F == 0u) {      // (nothing above the background: no second level; workgroup-uniform)
             hot = GSR_EQ_NO_HOT;
         } else {
             uint32_t run = fincl - fsum;
@@ -390,12 +390,18 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     static_assert(GSR_EQ_BINS == 2 * S3_THREADS, "one 8-byte load per thread");
     const uint32_t hot = eq_tab[2 * GSR_EQ_BINS];
-    reinterpret_cast<uint2*>(s_eq)[tid] = reinterpret_cast<const uint2*>(eq_tab)[tid];      // (the barriers below publish it)
-    if (hot != GSR_EQ_NO_HOT) reinterpret_cast<uint2*>(s_eq2)[tid] = reinterpret_cast<const uint2*>(eq_tab + GSR_EQ_BINS)[tid];
     const EqView eqv{s_eq, s_eq2, hot};
+    // both tables are requested unconditionally and parked in LDS AFTER the workgroup's key loads have been issued (below): a load that is waited for
+    // up here would put a second memory round trip in front of them
+    auto stage_tables = [&]() {
+        const uint2 t1 = reinterpret_cast<const uint2*>(eq_tab)[tid], t2 = reinterpret_cast<const uint2*>(eq_tab + GSR_EQ_BINS)[tid];
+        reinterpret_cast<uint2*>(s_eq)[tid] = t1;
+        reinterpret_cast<uint2*>(s_eq2)[tid] = t2;      // (garbage when there is no hot bin: never read then)
+    };
 
     if ((int)blockIdx.x == nblocks) {
         // ---- the segment plan (one workgroup, beside the scattering ones) ----
+        stage_tables();      // (the barriers of the scans below publish them)
         uint32_t* cnt_excl = reinterpret_cast<uint32_t*>(&wave_cnt[0][0]);      // [2048]; entry 2047 = number of listed Gaussians
         uint32_t* tile_excl = cnt_excl + DS_NB;
         uint32_t c[S3_DPT], t[S3_DPT];
@@ -460,6 +466,7 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t
         const int64_t idx = wave_base + r * 64 + lane;
         key[r] = keys[idx < P ? idx : (int64_t)P - 1];
     }
+    stage_tables();      // (the barriers of the scan below publish them)
     {   // digit_base[d] = (exclusive scan of the bucket totals)[d] + keys of bucket d in earlier workgroups
         uint32_t v[S3_DPT];
         const uint4 a = reinterpret_cast<const uint4*>(cnt_total)[tid];
@@ -788,10 +795,12 @@ ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame
         } else if (n_g != 0u) {
             // one bucket of n_g > DS_CAP keys: its true key span
             uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
-            for (uint32_t i = (uint32_t)tid; i < n_g; i += (uint32_t)SG_THREADS) {
-                const uint32_t k = pairs0[g_begin + i].x;
-                kmn = min(kmn, k);
-                kmx = max(kmx, k);
+            for (uint32_t i0 = (uint32_t)tid; i0 < n_g; i0 += (uint32_t)SG_OUT * SG_THREADS) {      // eight keys per trip (clamped index: duplicates change no min / max)
+                uint32_t kk[SG_OUT];
+#pragma unroll
+                for (int j = 0; j < SG_OUT; ++j) kk[j] = pairs0[g_begin + min(i0 + (uint32_t)j * SG_THREADS, n_g - 1u)].x;
+#pragma unroll
+                for (int j = 0; j < SG_OUT; ++j) { kmn = min(kmn, kk[j]); kmx = max(kmx, kk[j]); }
             }
             kmn = ~wave_incl_max_u32(~kmn);
             kmx = wave_incl_max_u32(kmx);

@@ -30,15 +30,16 @@
 #define GSR_EQ_SAMPLE_WGS 16      /* (A/B builds: -DGSR_EQ_SAMPLE_WGS=8) */
 #endif
 #define GSR_FRAME_KEY_CULLED ((1u << 27) - 1u)      // == GSR_DEPTH_KEY_CULLED (gsr_internal.h, checked there)
-// Second level, for ONE coarse bin: a sample workgroup also leaves the histogram of its fullest coarse bin ("hot" bin) over GSR_EQ_BINS
-// sub-bins of 2^GSR_EQ_SHIFT2 keys.  When one coarse bin holds an eighth of the sample or more (a wall seen head-on, a cluster within a
-// fraction of a percent of one depth, thousands of equal depths) ds_hist spreads that bin's buckets over its sub-bins in proportion to
-// their mass as well, so that a concentration 128 keys wide -- or a run of ties -- still gets buckets of its own.
+// Second level, for ONE coarse bin.  A sample workgroup also leaves the histogram of (key >> 7) & 1023 over ALL its keys: the 1024 sub-bins (128 keys each) of
+// every coarse bin folded onto one another.  When one coarse bin ("hot") holds an eighth of the sample or more -- a wall seen head-on, a cluster within a
+// fraction of a percent of one depth, thousands of equal depths -- the folded histogram IS that bin's sub-bin histogram plus a flat background from the other
+// bins ((C - c_hot) / 1024 per sub-bin, subtracted), and ds_hist spreads the hot bin's buckets over its sub-bins in proportion to it, so that a
+// concentration 128 keys wide -- or a run of ties -- still gets buckets of its own.  One pass over the keys, no agreement between workgroups needed.
 #define GSR_EQ_SHIFT2 7          // GSR_EQ_SHIFT - log2(GSR_EQ_BINS)
 #define GSR_EQ_NO_HOT 0xFFFFFFFFu
-// sample buffer: per sample workgroup a row of 2 * GSR_EQ_BINS 16-bit counts (coarse | sub-bins of its hot bin), then one word per workgroup: its hot bin
+// sample buffer: per sample workgroup a row of 2 * GSR_EQ_BINS 16-bit counts (coarse | folded sub-bins)
 #define GSR_EQ_SAMPLE_ROW (2 * GSR_EQ_BINS)
-#define GSR_EQ_SAMPLE_BYTES ((size_t)GSR_EQ_SAMPLE_WGS * GSR_EQ_SAMPLE_ROW * 2 + (size_t)GSR_EQ_SAMPLE_WGS * 4)
+#define GSR_EQ_SAMPLE_BYTES ((size_t)GSR_EQ_SAMPLE_WGS * GSR_EQ_SAMPLE_ROW * 2)
 // table buffer (ds_hist -> ds_scatter): GSR_EQ_BINS words level 1, GSR_EQ_BINS words level 2, then the hot bin (GSR_EQ_NO_HOT: no second level)
 #define GSR_EQ_TAB_WORDS (2 * GSR_EQ_BINS + 16)
 
@@ -77,9 +78,8 @@ __device__ __forceinline__ void gsr_frame_stats_commit(const GsrFrameStatsDev& f
     if (lane == 63) { s_sum[w] = wsum; s_nmin[w] = wnmin; s_max[w] = wmax; s_ovf[w] = ovf ? 1u : 0u; }
     __syncthreads();
     if (fs.sample_hist && blockIdx.x < (unsigned)GSR_EQ_SAMPLE_WGS) {      // (workgroup-uniform; every wave is past its loop: `lds` is free)
-        __shared__ uint32_t s_hot[4];
-        uint32_t* h1 = lds;
-        uint32_t* h2 = lds + GSR_EQ_BINS;
+        uint32_t* h1 = lds;                    // coarse bins: key >> 17
+        uint32_t* h2 = lds + GSR_EQ_BINS;      // sub-bins of ALL coarse bins folded onto one another: (key >> 7) & 1023
 #pragma unroll
         for (int b = 0; b < 2 * GSR_EQ_BINS / 256; ++b) lds[b * 256 + threadIdx.x] = 0u;
         __syncthreads();
@@ -91,28 +91,10 @@ __device__ __forceinline__ void gsr_frame_stats_commit(const GsrFrameStatsDev& f
             for (int u = 0; u < 4; ++u) kk[u] = keys[i0 + u * stride < P ? i0 + u * stride : P - 1];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (i0 + u * stride < P && kk[u] != GSR_FRAME_KEY_CULLED) atomicAdd(&h1[kk[u] >> GSR_EQ_SHIFT], 1u);
-        }
-        __syncthreads();
-        // the fullest coarse bin of THIS workgroup's sample (the lowest one on ties): count << 10 | (1023 - bin)
-        uint32_t best = 0;
-#pragma unroll
-        for (int b = 0; b < GSR_EQ_BINS / 256; ++b) {
-            const uint32_t bin = (uint32_t)b * 256u + threadIdx.x;
-            best = max(best, (h1[bin] << 10) | ((uint32_t)GSR_EQ_BINS - 1u - bin));
-        }
-        best = gsrw::wave_incl_max_u32(best);
-        if (lane == 63) s_hot[w] = best;
-        __syncthreads();
-        const uint32_t hot = (uint32_t)GSR_EQ_BINS - 1u - (max(max(s_hot[0], s_hot[1]), max(s_hot[2], s_hot[3])) & ((uint32_t)GSR_EQ_BINS - 1u));
-        for (int64_t i0 = first; i0 < P; i0 += 4 * stride) {
-            uint32_t kk[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) kk[u] = keys[i0 + u * stride < P ? i0 + u * stride : P - 1];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (i0 + u * stride < P && kk[u] != GSR_FRAME_KEY_CULLED && (kk[u] >> GSR_EQ_SHIFT) == hot)
+                if (i0 + u * stride < P && kk[u] != GSR_FRAME_KEY_CULLED) {
+                    atomicAdd(&h1[kk[u] >> GSR_EQ_SHIFT], 1u);
                     atomicAdd(&h2[(kk[u] >> GSR_EQ_SHIFT2) & ((uint32_t)GSR_EQ_BINS - 1u)], 1u);
+                }
         }
         __syncthreads();
         uint16_t* row = fs.sample_hist + (size_t)blockIdx.x * GSR_EQ_SAMPLE_ROW;
@@ -121,8 +103,6 @@ __device__ __forceinline__ void gsr_frame_stats_commit(const GsrFrameStatsDev& f
             const uint32_t c = lds[b * 256 + threadIdx.x];
             row[b * 256 + threadIdx.x] = (uint16_t)(c < 65535u ? c : 65535u);
         }
-        if (threadIdx.x == 0)
-            reinterpret_cast<uint32_t*>(fs.sample_hist + (size_t)GSR_EQ_SAMPLE_WGS * GSR_EQ_SAMPLE_ROW)[blockIdx.x] = hot;
     }
     if (threadIdx.x != 0) return;
     uint64_t sum = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];

@@ -21,8 +21,8 @@ EQ_SHIFT, EQ_BINS, EQ_SAMPLE_WGS, EQ_SHIFT2 = 17, 1024, 16, 7      # csrc/gsr_fr
 
 def sample_hist(keys, n_range):
     """What the first 16 workgroups of the key-producing kernel leave (gsr_frame.h): workgroup w of a grid of n_range 256-thread workgroups
-    owns the keys w * 256 + t + k * n_range * 256; per workgroup the coarse histogram (key >> 17) of its listed keys, its fullest coarse bin
-    (the lowest on ties) and the histogram of THAT bin's keys over 1024 sub-bins ((key >> 7) & 1023); counts saturate at 65535."""
+    owns the keys w * 256 + t + k * n_range * 256; per workgroup the coarse histogram (key >> 17) of its listed keys and the histogram of
+    (key >> 7) & 1023 over the same keys (the 1024 sub-bins of all coarse bins folded onto one another); counts saturate at 65535."""
     P = len(keys)
     rows = []
     for w in range(min(EQ_SAMPLE_WGS, n_range)):
@@ -30,10 +30,8 @@ def sample_hist(keys, n_range):
         k = keys[idx[idx < P]].astype(np.int64)
         k = k[k != KEY_CULLED]
         c = np.bincount(k >> EQ_SHIFT, minlength=EQ_BINS)
-        hot = int(np.argmax(c))      # (first = lowest index on ties)
-        kh = k[(k >> EQ_SHIFT) == hot]
-        f = np.bincount((kh >> EQ_SHIFT2) & (EQ_BINS - 1), minlength=EQ_BINS)
-        rows.append((np.minimum(c, 65535), hot, np.minimum(f, 65535)))
+        f = np.bincount((k >> EQ_SHIFT2) & (EQ_BINS - 1), minlength=EQ_BINS)
+        rows.append((np.minimum(c, 65535), np.minimum(f, 65535)))
     return rows
 
 
@@ -66,7 +64,8 @@ class EqTable:
         H = int(np.argmax(c))
         self.hot = H if (any_ and C >= 256 and int(c[H]) * 8 >= C) else None
         if self.hot is not None:
-            f = np.sum([r[2] for r in rows if r[1] == H] or [np.zeros(EQ_BINS, np.int64)], axis=0).astype(np.int64)
+            bg = (C - int(c[H]) + EQ_BINS - 1) // EQ_BINS      # the other coarse bins' keys, spread flat over the folded sub-bins
+            f = np.maximum(np.sum([r[1] for r in rows], axis=0).astype(np.int64) - bg, 0)
             F = int(f.sum())
             if F == 0:
                 self.hot = None
