@@ -16,8 +16,8 @@ finishes in a second or two).  What each case is there for:
   tiles_65536       exactly 65536 tiles: the largest frame of the fused two-level tile sort (one more tile takes the
                     32-bit-key LSD path, covered by test_gpu_parity.py)
   huge_tiles_65536  the same frame with splats of thousands of tiles each
-  depth_*           depth distributions that select the paths of the bucket depth sort (ties, a crowded bucket -> oversized
-                    segments through global memory, a 4-decade gap, a single key)
+  depth_*           depth distributions that select the paths of the bucket depth sort (ties, a crowd, a 4-decade gap, a single key;
+                    round 6: heavy tails, a wall, a thin wall, > 4096 ties per value -- the equalised bucket tables)
 Reference boundary: gaussian_renderer/__init__.py:91-110; bins = SURVEY 8(c)(3) "tile bin counts bit-exact"."""
 import pytest
 import torch
@@ -48,6 +48,13 @@ CASES = {
     # range, the floaters share the end buckets, whose segments sort on the full keys; 300 K Gaussians = 293 workgroups of the projection kernel,
     # so the robust range has groups of two workgroups to work with
     "depth_outliers": (300_000, 320, 240, 0.004, 16),
+    # round 6: the histogram-equalised buckets (csrc/depthsort.hip ds_hist) -- 3 % of the Gaussians 0.1-300x nearer / farther than a narrow bulk (every
+    # workgroup of the projection kernel holds some); half of them on a slab 0.3 % thick; 60 % on a slab 2e-4 thick (narrower than a first-level bucket:
+    # the second-level table); and a crowd whose 48 depth values hold > 4096 ties each (a single bucket of equal keys: chunked output, no pass)
+    "depth_heavy_tails": (300_000, 320, 240, 0.004, 17),
+    "depth_wall": (300_000, 320, 240, 0.004, 18),
+    "depth_wall_thin": (300_000, 320, 240, 0.004, 19),
+    "depth_crowd_big": (400_000, 320, 240, 0.003, 20),
 }
 
 
@@ -73,11 +80,27 @@ def _reshape_depths(name, sc, cam, seed):
         far, near = torch.randperm(P, generator=g)[:9], torch.randperm(P, generator=g)[:4]
         znew[far] = 400.0 + 2000.0 * torch.rand(9, generator=g)
         znew[near] = 0.3 + 0.2 * torch.rand(4, generator=g)
+    elif name == "depth_heavy_tails":
+        g = torch.Generator().manual_seed(seed + 1000)      # (make_scene draws its screen positions from the SAME seed: a mask from `g` would select a screen edge)
+        znew = 4.0 + 0.4 * torch.rand(P, generator=g)
+        far = torch.rand(P, generator=g) < 0.03
+        znew[far] = torch.exp(torch.empty(int(far.sum())).uniform_(-1.2, 7.0, generator=g))      # 0.3 .. 1100
+    elif name == "depth_wall":
+        g = torch.Generator().manual_seed(seed + 1000)
+        znew = torch.where(torch.rand(P, generator=g) < 0.5, 6.0 + 0.009 * torch.randn(P, generator=g), 1.0 + 39.0 * torch.rand(P, generator=g))
+    elif name == "depth_wall_thin":
+        g = torch.Generator().manual_seed(seed + 1000)
+        znew = torch.where(torch.rand(P, generator=g) < 0.6, 5.0 * (1.0 + 2e-4 * torch.rand(P, generator=g)), 1.0 + 39.0 * torch.rand(P, generator=g))
+    elif name == "depth_crowd_big":
+        g = torch.Generator().manual_seed(seed + 1000)
+        znew = z.clone()
+        crowd = torch.rand(P, generator=g) < 0.75
+        znew[crowd] = 5.0 + torch.randint(0, 48, (int(crowd.sum()),), generator=g).float() * 4.76837158203125e-07
     else:
         return
     f = (znew / z).unsqueeze(1)
     sc.means3D.mul_(f)
-    if name in ("depth_gap", "depth_outliers"):
+    if name in ("depth_gap", "depth_outliers", "depth_heavy_tails", "depth_wall", "depth_wall_thin"):
         sc.scales.mul_(f)          # keep the far cluster's / the floaters' splats visible on screen
 
 
