@@ -120,7 +120,7 @@ __device__ __forceinline__ void load4(const uint32_t* __restrict__ p, int64_t e0
 __global__ void __launch_bounds__(DS_THREADS)
 ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tiles, uint32_t* __restrict__ frame,
         const uint2* __restrict__ wg_range, int n_range, const uint16_t* __restrict__ sample_hist, uint32_t* __restrict__ eq_tab,
-        uint32_t* __restrict__ cnt_tab, uint32_t* __restrict__ tile_tab) {
+        uint16_t* __restrict__ bucket_of, uint32_t* __restrict__ cnt_tab, uint32_t* __restrict__ tile_tab) {
     __shared__ uint32_t h_cnt[DS_NB], h_tile[DS_NB];
     __shared__ __attribute__((aligned(16))) uint32_t s_eq[GSR_EQ_BINS], s_eq2[GSR_EQ_BINS];
     __shared__ uint32_t s_nmin[WG_WAVES], s_max[WG_WAVES], s_w[WG_WAVES], s_w2[WG_WAVES], s_hotp[WG_WAVES], s_w3[WG_WAVES];
@@ -264,14 +264,17 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int64_t e0 = base + ((int64_t)v * DS_THREADS + tid) * 4;
+        uint32_t dd[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            dd[j] = ds_bucket(k[v][j], eqv);      // (keys past P were loaded as "no tile": bucket 2047, never counted)
             if (e0 + j < P) {
-                const uint32_t d = ds_bucket(k[v][j], eqv);
-                atomicAdd(&h_cnt[d], 1u);
-                if (t[v][j]) atomicAdd(&h_tile[d], t[v][j]);
+                atomicAdd(&h_cnt[dd[j]], 1u);
+                if (t[v][j]) atomicAdd(&h_tile[dd[j]], t[v][j]);
             }
         }
+        // the bucket of every key, for ds_scatter (8 bytes per four keys; the array is padded past P)
+        if (e0 < P) *reinterpret_cast<uint2*>(bucket_of + e0) = make_uint2(dd[0] | (dd[1] << 16), dd[2] | (dd[3] << 16));
     }
     __syncthreads();
     uint32_t* crow = cnt_tab + (int64_t)blockIdx.x * DS_NB;
@@ -379,29 +382,25 @@ __device__ __forceinline__ uint32_t ds_block_excl_scan(const uint32_t (&v)[DPT],
 // plan entry of segment s (8 words): begin, end (elements of the bucket-ordered array), first bucket, end bucket, tile
 // instances in front of the segment, number of listed Gaussians, smallest key the segment's buckets can hold, one past the largest
 __global__ void __launch_bounds__(S3_THREADS)
-ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ frame, const uint32_t* __restrict__ eq_tab,
+ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint16_t* __restrict__ bucket_of, const uint32_t* __restrict__ frame, const uint32_t* __restrict__ eq_tab,
            const uint32_t* __restrict__ cnt_tab, const uint32_t* __restrict__ cnt_total, const uint32_t* __restrict__ tile_total,
            uint2* __restrict__ pairs, uint32_t* __restrict__ order, uint32_t* __restrict__ offsets, uint2* __restrict__ rect_sorted,
            uint32_t* __restrict__ plan, int nseg_cap) {
     __shared__ __attribute__((aligned(16))) uint16_t wave_cnt[S3_WAVES][DS_NB];      // 32 KB (a wave counts <= 512 keys)
     __shared__ __attribute__((aligned(16))) uint32_t digit_base[DS_NB];              //  8 KB
-    __shared__ __attribute__((aligned(16))) uint32_t s_eq[GSR_EQ_BINS], s_eq2[GSR_EQ_BINS];      //  8 KB equalised bucket tables (ds_hist)
+    __shared__ __attribute__((aligned(16))) uint32_t s_eq[GSR_EQ_BINS], s_eq2[GSR_EQ_BINS];      //  8 KB equalised bucket tables (ds_hist): the plan workgroup only
     __shared__ uint32_t wsum[S3_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     static_assert(GSR_EQ_BINS == 2 * S3_THREADS, "one 8-byte load per thread");
-    const uint32_t hot = eq_tab[2 * GSR_EQ_BINS];
-    const EqView eqv{s_eq, s_eq2, hot};
-    // both tables are requested unconditionally and parked in LDS AFTER the workgroup's key loads have been issued (below): a load that is waited for
-    // up here would put a second memory round trip in front of them
-    auto stage_tables = [&]() {
-        const uint2 t1 = reinterpret_cast<const uint2*>(eq_tab)[tid], t2 = reinterpret_cast<const uint2*>(eq_tab + GSR_EQ_BINS)[tid];
-        reinterpret_cast<uint2*>(s_eq)[tid] = t1;
-        reinterpret_cast<uint2*>(s_eq2)[tid] = t2;      // (garbage when there is no hot bin: never read then)
-    };
 
     if ((int)blockIdx.x == nblocks) {
         // ---- the segment plan (one workgroup, beside the scattering ones) ----
-        stage_tables();      // (the barriers of the scans below publish them)
+        // the equalised bucket tables of ds_hist (both levels; the second is garbage and never read when there is no hot bin); the barriers of the scans
+        // below publish them
+        const uint32_t hot = eq_tab[2 * GSR_EQ_BINS];
+        const EqView eqv{s_eq, s_eq2, hot};
+        reinterpret_cast<uint2*>(s_eq)[tid] = reinterpret_cast<const uint2*>(eq_tab)[tid];
+        reinterpret_cast<uint2*>(s_eq2)[tid] = reinterpret_cast<const uint2*>(eq_tab + GSR_EQ_BINS)[tid];
         uint32_t* cnt_excl = reinterpret_cast<uint32_t*>(&wave_cnt[0][0]);      // [2048]; entry 2047 = number of listed Gaussians
         uint32_t* tile_excl = cnt_excl + DS_NB;
         uint32_t c[S3_DPT], t[S3_DPT];
@@ -460,13 +459,13 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t
     // the workgroup's keys are requested first: their trip overlaps the bucket-base prologue below.  Wave w owns the
     // contiguous run [w * 512, w * 512 + 512) of the workgroup's keys, item r of a lane is key r * 64 + lane of the run
     const int64_t wave_base = (int64_t)blockIdx.x * DS_ITEMS + (int64_t)w * (64 * S3_IPT);
-    uint32_t key[S3_IPT];
+    uint32_t key[S3_IPT], dig[S3_IPT];
 #pragma unroll
     for (int r = 0; r < S3_IPT; ++r) {
         const int64_t idx = wave_base + r * 64 + lane;
         key[r] = keys[idx < P ? idx : (int64_t)P - 1];
+        dig[r] = bucket_of[idx < P ? idx : (int64_t)P - 1];      // (ds_hist looked the bucket up in the equalised tables once)
     }
-    stage_tables();      // (the barriers of the scan below publish them)
     {   // digit_base[d] = (exclusive scan of the bucket totals)[d] + keys of bucket d in earlier workgroups
         uint32_t v[S3_DPT];
         const uint4 a = reinterpret_cast<const uint4*>(cnt_total)[tid];
@@ -488,13 +487,12 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint32_t
     }
     __syncthreads();
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    uint32_t rank[S3_IPT], dig[S3_IPT];
+    uint32_t rank[S3_IPT];
 #pragma unroll
     for (int r = 0; r < S3_IPT; ++r) {
         const int64_t idx = wave_base + r * 64 + lane;
         const bool valid = idx < P;
-        const uint32_t d = ds_bucket(key[r], eqv);
-        dig[r] = d;
+        const uint32_t d = dig[r];
         const uint64_t mask = match_digit(d, GSR_DS_BITS, __ballot(valid));
         const uint32_t prior = valid ? (uint32_t)wave_cnt[w][d] : 0u;
         rank[r] = prior + (uint32_t)__popcll(mask & lt_mask);
@@ -849,9 +847,9 @@ void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* t
                                   uint32_t* offsets, uint2* block_first, uint32_t block_first_cap, uint32_t* slow_word, hipStream_t st) {
     const int nblocks = (int)gsr_depth_bucket_blocks(P);
     const int nseg_cap = (int)gsr_depth_bucket_segments(P);
-    hipLaunchKernelGGL(ds_hist, dim3(nblocks), dim3(DS_THREADS), 0, st, P, keys, tiles, frame, wg_range, n_range, sample_hist, b.eq_tab, b.cnt_tab, b.tile_tab);
+    hipLaunchKernelGGL(ds_hist, dim3(nblocks), dim3(DS_THREADS), 0, st, P, keys, tiles, frame, wg_range, n_range, sample_hist, b.eq_tab, b.bucket_of, b.cnt_tab, b.tile_tab);
     hipLaunchKernelGGL(ds_scan, dim3(DS_NB / 16), dim3(DS_THREADS), 0, st, nblocks, b.cnt_tab, b.tile_tab, b.cnt_total, b.tile_total);
-    hipLaunchKernelGGL(ds_scatter, dim3(nblocks + 1), dim3(S3_THREADS), 0, st, P, nblocks, keys, frame, b.eq_tab, b.cnt_tab, b.cnt_total,
+    hipLaunchKernelGGL(ds_scatter, dim3(nblocks + 1), dim3(S3_THREADS), 0, st, P, nblocks, keys, b.bucket_of, frame, b.eq_tab, b.cnt_tab, b.cnt_total,
                        b.tile_total, b.pairs[0], order, offsets, rect_sorted, b.plan, nseg_cap);
     hipLaunchKernelGGL(ds_segsort, dim3(nseg_cap), dim3(SG_THREADS), 0, st, b.plan, frame, b.cnt_total, b.pairs[0], b.pairs[1], rect, order,
                        rect_sorted, offsets, block_first, block_first_cap, slow_word);

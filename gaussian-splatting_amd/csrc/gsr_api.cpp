@@ -306,6 +306,7 @@ GsrGeom gsr_carve_geom(char* base, int P) {
         g.ds.tile_total = (uint32_t*)take(GSR_DS_BUCKETS * 4);
         g.ds.plan = (uint32_t*)take(nseg * 32);
         g.ds.eq_tab = (uint32_t*)take((size_t)GSR_EQ_TAB_WORDS * 4);
+        g.ds.bucket_of = (uint16_t*)take((np + 64) * 2);
     }
     g.num_rendered = (uint32_t*)take(128);
     g.wg_range = (uint2*)take((size_t)GSR_FRAME_MAX_GROUPS * 8);

@@ -50,6 +50,7 @@ struct GsrDepthSortBufs {
     uint32_t* cnt_total;         // [2048]
     uint32_t* tile_total;        // [2048]
     uint32_t* plan;              // [segments][8]
+    uint16_t* bucket_of;         // [P] the depth bucket of every key (written by ds_hist, read by ds_scatter: the table lookup is done once)
     uint32_t* eq_tab;            // [GSR_EQ_TAB_WORDS] first bucket | buckets << 16 per coarse bin, the same per sub-bin of the hot coarse bin, the hot bin (ds_hist's workgroup 0)
 };
 size_t gsr_depth_bucket_blocks(int P);

@@ -25,7 +25,8 @@ int simt_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, c
     GsrDepthSortBufs b;
     b.pairs[0] = pairs0.data(); b.pairs[1] = pairs1.data();
     b.cnt_tab = cnt_tab.data(); b.tile_tab = tile_tab.data(); b.cnt_total = cnt_total.data(); b.tile_total = tile_total.data(); b.plan = plan.data();
-    b.eq_tab = eq_tab.data();
+    std::vector<uint16_t> bucket_of((size_t)P + 64);
+    b.eq_tab = eq_tab.data(); b.bucket_of = bucket_of.data();
     gsr_launch_depth_bucket_sort(P, keys, tiles, rect, frame, wg_range, n_range, sample.data(), b, order, rect_sorted, offsets, block_first, bf_cap, slow_word, nullptr);
     if (!simt::launch_error) return 0;
     snprintf(g_err, sizeof(g_err), "bucket depth sort: %s", simt::launch_error);

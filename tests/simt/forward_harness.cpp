@@ -64,7 +64,8 @@ int64_t simt_forward(const GsrRasterSettings* s, int snug, int P, int M, const f
     g.ds.cnt_total = cnt_total.data(); g.ds.tile_total = tile_total.data(); g.ds.plan = plan.data();
     std::vector<uint32_t> eq_tab(GSR_EQ_TAB_WORDS);
     std::vector<uint16_t> sample_hist(GSR_EQ_SAMPLE_BYTES / 2, 0xFFFFu);      // (poisoned: the kernel must write every row it later reads)
-    g.ds.eq_tab = eq_tab.data(); g.sample_hist = sample_hist.data();
+    std::vector<uint16_t> bucket_of(n + 64);
+    g.ds.eq_tab = eq_tab.data(); g.ds.bucket_of = bucket_of.data(); g.sample_hist = sample_hist.data();
     GsrFrameStatsDev fs;
     fs.state = state.data(); fs.frame = frame.data(); fs.wg_range = wg_range.data(); fs.sample_hist = sample_hist.data(); fs.host_word = nullptr; fs.seq = 1;
     auto bail = [&]() -> int64_t { snprintf(g_err, sizeof(g_err), "%s", simt::launch_error ? simt::launch_error : "?"); simt::launch_error = nullptr; return -1; };
@@ -207,7 +208,8 @@ int64_t simt_forward_sharded(const GsrRasterSettings* s, int snug, int G, const 
             ds.cnt_total = cnt_total.data(); ds.tile_total = tile_total.data(); ds.plan = plan.data();
             std::vector<uint32_t> eq_tab(GSR_EQ_TAB_WORDS);
             std::vector<uint16_t> sample_hist(GSR_EQ_SAMPLE_BYTES / 2, 0xFFFFu);
-            ds.eq_tab = eq_tab.data();
+            std::vector<uint16_t> bucket_of(n + 64);
+            ds.eq_tab = eq_tab.data(); ds.bucket_of = bucket_of.data();
             GsrFrameStatsDev fs;
             fs.state = state.data(); fs.frame = frame.data(); fs.wg_range = wg_range.data(); fs.sample_hist = sample_hist.data(); fs.host_word = nullptr; fs.seq = 1;
             const int n_range = gsr_launch_ingest_packed(Pb, recv.data(), cb.tile_y0, cb.tile_y1, splats.data(), rect.data(), tiles.data(), keys0.data(), vals0.data(), fs, 0, nullptr);
