@@ -28,8 +28,9 @@ LIB = os.path.join(OUT, "libgsr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
+AB_SRC = os.path.join(ROOT, "tools", "ab_variants")      # measured-and-rejected kernel variants: NOT part of the product tree, compiled into lib_ab/ only
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-          "-Wall", "-Wno-unused-function"] + (["-DGSR_AB_VARIANTS"] if AB else []) + os.environ.get("GSR_EXTRA_FLAGS", "").split()
+          "-Wall", "-Wno-unused-function"] + (["-DGSR_AB_VARIANTS", "-I" + AB_SRC] if AB else []) + os.environ.get("GSR_EXTRA_FLAGS", "").split()
 UNITS = [
     ("preprocess.hip", ["-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]),
     ("sort.hip", []),
@@ -60,8 +61,8 @@ def _stale(target: str, deps) -> bool:
 
 def _headers():
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    ab = os.path.join(CSRC, "ab")      # measured-and-rejected kernel variants, included by the sources under -DGSR_AB_VARIANTS only
-    if os.path.isdir(ab):
+    ab = AB_SRC                        # measured-and-rejected kernel variants, included by the sources under -DGSR_AB_VARIANTS only
+    if AB and os.path.isdir(ab):
         hs += [os.path.join(ab, f) for f in os.listdir(ab) if f.endswith(".inc")]
     hs.append(os.path.join(ROOT, "include", "gsr.h"))
     hs.append(os.path.abspath(__file__))

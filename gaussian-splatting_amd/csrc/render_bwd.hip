@@ -466,7 +466,7 @@ render_bwd_half(GsrCamDev cam, int n_band_tiles, const uint2* __restrict__ range
 }
 
 #ifdef GSR_AB_VARIANTS
-#include "ab/render_bwd_quad_superbatch.inc"      // measured-and-rejected variants: measurement build only
+#include "render_bwd_quad_superbatch.inc"      // measured-and-rejected variants (tools/ab_variants/): measurement build only
 #endif  // GSR_AB_VARIANTS
 
 // splat_grads[g] = sum of the instance records of Gaussian g.  In emission (= depth) order a Gaussian's records are one
@@ -725,7 +725,7 @@ reduce_stitch(int64_t nunits, const uint32_t* __restrict__ order, const float4* 
 }
 
 #ifdef GSR_AB_VARIANTS
-#include "ab/render_bwd_atomics.inc"      // measured-and-rejected variants: measurement build only
+#include "render_bwd_atomics.inc"      // measured-and-rejected variants (tools/ab_variants/): measurement build only
 #endif  // GSR_AB_VARIANTS
 
 // ------------------------------------------------------------------------------------------------

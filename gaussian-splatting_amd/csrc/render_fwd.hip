@@ -30,7 +30,7 @@
 namespace {
 
 #ifdef GSR_AB_VARIANTS
-#include "ab/render_fwd_block.inc"      // measured-and-rejected variants: measurement build only
+#include "render_fwd_block.inc"      // measured-and-rejected variants (tools/ab_variants/): measurement build only
 #endif  // GSR_AB_VARIANTS
 
 // ------------------------------------------------------------------------------------------------

@@ -449,7 +449,7 @@ int gsr_profile_trace(uint64_t* out, int max_waves);
  *                     passes beyond and for 64 frames after a frame whose depths crowded one bucket; 1 = always LSD; 2 = always
  *                     the bucket sort (all three give bit-identical bins)
  *   level2_scan_mode  0 = automatic, 1 = the tile sort's level-2 scan as its own launch, 2 = folded into the scatter
- * The measurement build (GSR_AB=1 python build.py -> lib_ab/, sources in csrc/ab/) also compiles render_fwd_variant 1 / 3,
+ * The measurement build (GSR_AB=1 python build.py -> lib_ab/, sources in tools/ab_variants/) also compiles render_fwd_variant 1 / 3,
  * render_bwd_variant 1 / 4 / 5 and the round-5 options fwd_bands (level-2 sort + blend band by band on two HIP streams) and
  * render_fwd_lds_pad (resident waves of the forward blend capped through LDS) -- all measured and rejected
  * (profiles/r05_ab_fwd_bands_occupancy.json); the product accepts only the defaults.  (ABI 4 removed the options of experiments
