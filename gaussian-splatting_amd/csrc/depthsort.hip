@@ -8,7 +8,7 @@
 //
 //   ds_hist     per workgroup of 4096 keys: histogram over 2048 depth buckets of (a) the keys, (b) their tile counts.
 //               The bucket of a key comes from a HISTOGRAM-EQUALISED table (round 6): the key space is cut into 1024 coarse bins
-//               (64 per octave of depth); the key-producing kernel's first 16 workgroups leave the coarse histogram of their keys
+//               (64 per octave of depth); 16 workgroups of the key-producing kernel leave the coarse histogram of their keys
 //               (a regular sample of the frame, gsr_frame.h); every coarse bin inside the frame's true key range gets one bucket and
 //               the rest of the 2046 usable ones are handed out in proportion to the sampled mass; inside a coarse bin the buckets
 //               are uniform.  Buckets then hold about P / 2046 keys whatever the depth distribution is -- floaters 100x behind the

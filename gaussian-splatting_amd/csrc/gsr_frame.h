@@ -20,7 +20,7 @@
 #include "gsr_wave.h"
 
 // Histogram-equalised bucket mapping of the depth sort (round 6, depthsort.hip): the 27-bit key space is cut into GSR_EQ_BINS coarse bins of
-// 2^GSR_EQ_SHIFT keys (64 per octave of depth); the first GSR_EQ_SAMPLE_WGS workgroups of the key-producing kernel leave the coarse histogram
+// 2^GSR_EQ_SHIFT keys (64 per octave of depth); GSR_EQ_SAMPLE_WGS workgroups of the key-producing kernel (gsr_frame_sampler_row) leave the coarse histogram
 // of THEIR keys -- a regular sample of the frame, every workgroup's loop strides over the whole array -- and ds_hist turns the summed sample
 // into a (first bucket, buckets) table per coarse bin: one bucket for every coarse bin inside the frame's key range, the rest of the 2046
 // handed out in proportion to the sampled mass, so that the buckets hold about the same number of keys whatever the depth distribution is.
@@ -54,16 +54,31 @@ struct GsrFrameStatsDev {
     uint32_t* state;       // NULL: the kernel keeps no statistics (shard projection without binning)
     uint32_t* frame;
     uint2* wg_range;       // [workgroups] (~smallest, largest) depth key of the workgroup's listed Gaussians; (0, 0): none
-    uint16_t* sample_hist; // GSR_EQ_SAMPLE_BYTES (layout above) or NULL: key histograms of the first GSR_EQ_SAMPLE_WGS workgroups
+    uint16_t* sample_hist; // GSR_EQ_SAMPLE_BYTES (layout above) or NULL: key histograms of the GSR_EQ_SAMPLE_WGS sampling workgroups
     uint32_t* host_word;   // may be NULL (then only `frame` is written)
     uint32_t seq;
 };
+
+// The sampling workgroups of a key-producing kernel of `grid` 256-thread workgroups over P keys (loop: i = wg * 256 + t; i < P; i += grid * 256):
+// sampler r of n = min(GSR_EQ_SAMPLE_WGS, grid) is workgroup lo + ((2 r + 1) (hi - lo)) / (2 n), with [lo, hi) the workgroups that run the fewest
+// iterations if there are at least n of them, else the whole grid.  Returns the row of workgroup `wg`, or -1.  (Host code restates it: tests/simt/sample_hist.h.)
+static inline __host__ __device__ int gsr_frame_sampler_row(int64_t P, unsigned grid, unsigned wg) {
+    const unsigned n = grid < (unsigned)GSR_EQ_SAMPLE_WGS ? grid : (unsigned)GSR_EQ_SAMPLE_WGS;
+    const int64_t stride = (int64_t)grid * 256;
+    const int64_t rem = P > 0 ? P % stride : 0;
+    const unsigned full = rem == 0 ? grid : (unsigned)((rem + 255) / 256);      // workgroups [0, full) run one more iteration than [full, grid)
+    unsigned lo = 0, hi = grid;
+    if (grid - full >= n) lo = full;
+    for (unsigned r = 0; r < n; ++r)
+        if (lo + ((2u * r + 1u) * (hi - lo)) / (2u * n) == wg) return (int)r;
+    return -1;
+}
 
 #ifdef __HIPCC__
 // Called by EVERY thread of EVERY workgroup of a 256-thread kernel, after its streaming loop.  tiles_sum / kmin / kmax /
 // key_ovf are the thread's own partial results (kmin = 0xFFFFFFFF, kmax = 0 when it listed nothing).
 // keys / P: the depth-key array the kernel has just written with the loop `for (i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256)`
-// -- the first GSR_EQ_SAMPLE_WGS workgroups read THEIR OWN keys back (every thread the ones it stored itself) and leave their coarse
+// -- the sampling workgroups (gsr_frame_sampler_row) read THEIR OWN keys back (every thread the ones it stored itself) and leave their coarse
 // histogram in fs.sample_hist: a regular sample of the frame's depth distribution for the depth sort's bucket mapping (depthsort.hip).
 // lds: >= 2 * GSR_EQ_BINS words of LDS that nothing else uses after the loop.
 __device__ __forceinline__ void gsr_frame_stats_commit(const GsrFrameStatsDev& fs, uint64_t tiles_sum, uint32_t kmin, uint32_t kmax,
@@ -77,7 +92,12 @@ __device__ __forceinline__ void gsr_frame_stats_commit(const GsrFrameStatsDev& f
     const uint64_t ovf = __ballot(key_ovf);
     if (lane == 63) { s_sum[w] = wsum; s_nmin[w] = wnmin; s_max[w] = wmax; s_ovf[w] = ovf ? 1u : 0u; }
     __syncthreads();
-    if (fs.sample_hist && blockIdx.x < (unsigned)GSR_EQ_SAMPLE_WGS) {      // (workgroup-uniform; every wave is past its loop: `lds` is free)
+    // Which workgroups sample (gsr_frame_sampler below): spread evenly over the workgroups with the FEWEST loop iterations -- with a grid-stride
+    // loop the last ones of the grid have one fewer unless P is a multiple of the stride -- so that their extra pass ends before the kernel does
+    // (taken by the first workgroups it delayed the second round of workgroups that inherit their slots: +2.5 us on the projection kernel,
+    // measured) and spread, not adjacent, so that an index-ordered array (a Morton-sorted model) is sampled at 16 places, not at one.
+    const int my_row = gsr_frame_sampler_row(P, gridDim.x, blockIdx.x);
+    if (fs.sample_hist && my_row >= 0) {      // (workgroup-uniform; every wave is past its loop: `lds` is free)
         uint32_t* h1 = lds;                    // coarse bins: key >> 17
         uint32_t* h2 = lds + GSR_EQ_BINS;      // sub-bins of ALL coarse bins folded onto one another: (key >> 7) & 1023
 #pragma unroll
@@ -97,7 +117,7 @@ __device__ __forceinline__ void gsr_frame_stats_commit(const GsrFrameStatsDev& f
                 }
         }
         __syncthreads();
-        uint16_t* row = fs.sample_hist + (size_t)blockIdx.x * GSR_EQ_SAMPLE_ROW;
+        uint16_t* row = fs.sample_hist + (size_t)my_row * GSR_EQ_SAMPLE_ROW;
 #pragma unroll
         for (int b = 0; b < 2 * GSR_EQ_BINS / 256; ++b) {
             const uint32_t c = lds[b * 256 + threadIdx.x];

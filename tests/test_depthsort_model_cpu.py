@@ -19,13 +19,24 @@ KEY_BASE = 0x3E4CCCCD          # bits(0.2f), gsr_internal.h GSR_DEPTH_KEY_BASE
 EQ_SHIFT, EQ_BINS, EQ_SAMPLE_WGS, EQ_SHIFT2 = 17, 1024, 16, 7      # csrc/gsr_frame.h
 
 
+def sampler_workgroups(P, grid):
+    """gsr_frame_sampler_row (csrc/gsr_frame.h): the n = min(16, grid) sampling workgroups, spread evenly over the workgroups that run the fewest loop
+    iterations (the last ones of a grid-stride grid) if there are at least n of them, else over the whole grid."""
+    n = min(EQ_SAMPLE_WGS, grid)
+    stride = grid * 256
+    rem = P % stride if P > 0 else 0
+    full = grid if rem == 0 else (rem + 255) // 256
+    lo, hi = (full, grid) if grid - full >= n else (0, grid)
+    return [lo + ((2 * r + 1) * (hi - lo)) // (2 * n) for r in range(n)]
+
+
 def sample_hist(keys, n_range):
-    """What the first 16 workgroups of the key-producing kernel leave (gsr_frame.h): workgroup w of a grid of n_range 256-thread workgroups
+    """What the sampling workgroups of the key-producing kernel leave (gsr_frame.h): workgroup w of a grid of n_range 256-thread workgroups
     owns the keys w * 256 + t + k * n_range * 256; per workgroup the coarse histogram (key >> 17) of its listed keys and the histogram of
     (key >> 7) & 1023 over the same keys (the 1024 sub-bins of all coarse bins folded onto one another); counts saturate at 65535."""
     P = len(keys)
     rows = []
-    for w in range(min(EQ_SAMPLE_WGS, n_range)):
+    for w in sampler_workgroups(P, n_range):
         idx = (np.arange(w * 256, P, n_range * 256)[:, None] + np.arange(256)[None, :]).reshape(-1)
         k = keys[idx[idx < P]].astype(np.int64)
         k = k[k != KEY_CULLED]
@@ -119,7 +130,7 @@ class EqTable:
 
 def bucket_depth_sort(keys, tiles, n_range=5):
     """-> (order, inclusive tile scan in depth order, block_first dict, segment sizes).  n_range: workgroups of the key-producing kernel (its
-    first 16 provide the sample the bucket table is equalised with)."""
+    last 16 provide the sample the bucket table is equalised with)."""
     P = len(keys)
     listed = keys != KEY_CULLED
     assert ((tiles > 0) == listed).all()
