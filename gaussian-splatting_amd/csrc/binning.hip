@@ -245,7 +245,6 @@ tile_ranges(int64_t R, const KeyT* __restrict__ keys, uint2* __restrict__ ranges
 __global__ void __launch_bounds__(256)
 splat_ingest(int P, const float4* __restrict__ records, int y0, int y1, float4* __restrict__ splats, uint2* __restrict__ rect,
              uint32_t* __restrict__ tiles, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GsrFrameStatsDev fs) {
-    __shared__ uint32_t s_eq[2 * GSR_EQ_BINS];      // (the commit's coarse key histogram, gsr_frame.h)
     GsrFrameAcc acc;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 q0 = records[i * 4 + 0], q1 = records[i * 4 + 1], q2 = records[i * 4 + 2], q3 = records[i * 4 + 3];
@@ -266,7 +265,7 @@ splat_ingest(int P, const float4* __restrict__ records, int y0, int y1, float4* 
         vals[i] = (uint32_t)i;
         acc.add(key, t);
     }
-    gsr_frame_stats_commit(fs, acc.tiles, acc.kmin, acc.kmax, acc.ovf, keys, P, s_eq);
+    gsr_frame_stats_commit(fs, acc.tiles, acc.kmin, acc.kmax, acc.ovf);
 }
 
 // fallback of the 27-bit depth sort (a listed Gaussian deeper than 13 107): the full 32-bit keys of round 2

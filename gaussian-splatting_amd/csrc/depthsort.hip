@@ -8,8 +8,8 @@
 //
 //   ds_hist     per workgroup of 4096 keys: histogram over 2048 depth buckets of (a) the keys, (b) their tile counts.
 //               The bucket of a key comes from a HISTOGRAM-EQUALISED table (round 6): the key space is cut into 1024 coarse bins
-//               (64 per octave of depth); 16 workgroups of the key-producing kernel leave the coarse histogram of their keys
-//               (a regular sample of the frame, gsr_frame.h); every coarse bin inside the frame's true key range gets one bucket and
+//               (64 per octave of depth); every workgroup histograms the same 4096 sample keys (64 windows of 64 keys spread over
+//               the array) over them; every coarse bin inside the frame's true key range gets one bucket and
 //               the rest of the 2046 usable ones are handed out in proportion to the sampled mass; inside a coarse bin the buckets
 //               are uniform.  Buckets then hold about P / 2046 keys whatever the depth distribution is -- floaters 100x behind the
 //               scene, a wall, a cluster (rounds 4-5: uniform buckets over the key range, then over a "robust" range; a trained
@@ -114,28 +114,33 @@ __device__ __forceinline__ void load4(const uint32_t* __restrict__ p, int64_t e0
 
 // ---- D1 ------------------------------------------------------------------------------------------------------------
 // Every workgroup first reduces the per-workgroup key ranges the key-producing kernel left (gsr_frame.h; <= 2047 entries of
-// 8 bytes) to the frame's true key range and sums the <= 16 coarse sample histograms (<= 32 KB, 16-byte loads) into the
-// equalised bucket table -- one load round in the shadow of the key loads, the same integers in every workgroup; workgroup 0
-// stores range and table for the kernels that follow.
+// 8 bytes) to the frame's true key range and histograms the SAME 4096 sample keys (64 windows spread over the array: sixteen
+// coalesced loads per thread in the shadow of its own key loads) into the equalised bucket tables -- the same integers in every
+// workgroup; workgroup 0 stores range and tables for the kernels that follow.
 __global__ void __launch_bounds__(DS_THREADS)
 ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tiles, uint32_t* __restrict__ frame,
-        const uint2* __restrict__ wg_range, int n_range, const uint16_t* __restrict__ sample_hist, uint32_t* __restrict__ eq_tab,
+        const uint2* __restrict__ wg_range, int n_range, uint32_t* __restrict__ eq_tab,
         uint16_t* __restrict__ bucket_of, uint32_t* __restrict__ cnt_tab, uint32_t* __restrict__ tile_tab) {
     __shared__ uint32_t h_cnt[DS_NB], h_tile[DS_NB];
-    __shared__ __attribute__((aligned(16))) uint32_t s_eq[GSR_EQ_BINS], s_eq2[GSR_EQ_BINS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_eq[GSR_EQ_BINS], s_eq2[GSR_EQ_BINS];      // the tables; before that: the sample's two histograms
     __shared__ uint32_t s_nmin[WG_WAVES], s_max[WG_WAVES], s_w[WG_WAVES], s_w2[WG_WAVES], s_hotp[WG_WAVES], s_w3[WG_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * DS_ITEMS;
     static_assert(GSR_EQ_BINS == 4 * DS_THREADS, "thread t owns the coarse bins 4t .. 4t+3");
+    static_assert(GSR_EQ_SAMPLE == 16 * DS_THREADS, "sixteen sample keys per thread");
     uint32_t k[4][4], t[4][4];
     uint2 rg[8];
-    uint2 sh[GSR_EQ_SAMPLE_WGS];
-    const int n_samp = n_range < GSR_EQ_SAMPLE_WGS ? n_range : GSR_EQ_SAMPLE_WGS;
+    uint32_t sk[16];
 #pragma unroll
     for (int j = 0; j < 8; ++j) rg[j] = wg_range[min(j * DS_THREADS + tid, n_range - 1)];      // (clamped: duplicates do not change a max)
+    // THE SAMPLE: 64 windows of 64 consecutive keys, window q at ((2 q + 1) P / 128) rounded down to a multiple of 64 -- the same 4096 keys in
+    // every workgroup (coalesced 256-byte loads, L2 hits), so every workgroup builds the same tables; an index past P reads the last key again
 #pragma unroll
-    for (int j = 0; j < GSR_EQ_SAMPLE_WGS; ++j)      // four 16-bit counts per row (clamped row: masked below)
-        sh[j] = reinterpret_cast<const uint2*>(sample_hist + (size_t)min(j, n_samp - 1) * GSR_EQ_SAMPLE_ROW)[tid];
+    for (int j = 0; j < 16; ++j) {
+        const int64_t q = (int64_t)j * WG_WAVES + w;
+        const int64_t i = ((((2 * q + 1) * (int64_t)P) >> 7) & ~(int64_t)63) + lane;
+        sk[j] = keys[i < P ? i : (int64_t)P - 1];
+    }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {      // all loads first, the LDS clear rides in their shadow
         const int64_t e0 = base + ((int64_t)v * DS_THREADS + tid) * 4;
@@ -147,23 +152,30 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
         h_cnt[i * DS_THREADS + tid] = 0u;
         h_tile[i * DS_THREADS + tid] = 0u;
     }
+    reinterpret_cast<uint4*>(s_eq)[tid] = make_uint4(0u, 0u, 0u, 0u);
+    reinterpret_cast<uint4*>(s_eq2)[tid] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    // the sample's histograms: s_eq[key >> 17] (coarse bins), s_eq2[(key >> 7) & 1023] (the 1024 sub-bins of ALL coarse bins folded onto one another)
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (sk[j] != GSR_DEPTH_KEY_CULLED) {
+            atomicAdd(&s_eq[sk[j] >> GSR_EQ_SHIFT], 1u);
+            atomicAdd(&s_eq2[(sk[j] >> GSR_EQ_SHIFT2) & ((uint32_t)GSR_EQ_BINS - 1u)], 1u);
+        }
+    __syncthreads();
     // Round 1 (one barrier): the frame's true key range and the sampled keys per coarse bin (thread t owns the coarse bins 4t .. 4t+3)
-    uint32_t c[4] = {0u, 0u, 0u, 0u};
+    uint32_t c[4], fold[4];
     {
+        const uint4 c4 = reinterpret_cast<const uint4*>(s_eq)[tid], f4 = reinterpret_cast<const uint4*>(s_eq2)[tid];
+        c[0] = c4.x; c[1] = c4.y; c[2] = c4.z; c[3] = c4.w;
+        fold[0] = f4.x; fold[1] = f4.y; fold[2] = f4.z; fold[3] = f4.w;
         uint32_t nm = 0, mx = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             nm = max(nm, rg[j].x);
             mx = max(mx, rg[j].y);
         }
-#pragma unroll
-        for (int j = 0; j < GSR_EQ_SAMPLE_WGS; ++j) {
-            if (j < n_samp) {
-                c[0] += sh[j].x & 0xFFFFu; c[1] += sh[j].x >> 16;
-                c[2] += sh[j].y & 0xFFFFu; c[3] += sh[j].y >> 16;
-            }
-        }
-        // the fullest coarse bin of the summed sample (the lowest one on ties): count << 10 | (1023 - bin); counts <= 16 * 65535 < 2^20
+        // the fullest coarse bin of the sample (the lowest one on ties): count << 10 | (1023 - bin); counts <= 4096
         uint32_t hp = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) hp = max(hp, (c[i] << 10) | ((uint32_t)GSR_EQ_BINS - 1u - (4u * (uint32_t)tid + (uint32_t)i)));
@@ -188,7 +200,7 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
         for (int i = 0; i < 4; ++i) {
             const uint32_t b = 4u * (uint32_t)tid + (uint32_t)i;
             const bool in = b >= b_lo && b <= b_hi;
-            // (spare * c <= 2046 * 16 * 65535 < 2^32)
+            // (spare * c <= 2046 * 4096)
             nb[i] = in ? 1u + (C ? (spare * c[i]) / C : spare / nbins) : 0u;
             nsum += nb[i];
         }
@@ -210,7 +222,8 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
             if (tid == 0) { frame[2] = tmin; frame[3] = tmax; frame[6] = tmin; frame[7] = tmax; }
         }
         // Second level (gsr_frame.h), workgroup-uniform and rare: one coarse bin holds an eighth of the sample or more.  Its buckets are spread
-        // over its 1024 sub-bins in proportion to THEIR sampled mass (the folded sub-bin histogram minus its flat background, gsr_frame.h):
+        // over its 1024 sub-bins in proportion to THEIR sampled mass: the histogram of (key >> 7) & 1023 over ALL sample keys (the sub-bins of all
+        // coarse bins folded onto one another) is the hot bin's sub-bin histogram plus a flat background of the other bins' keys, (C - c_hot) / 1024 each:
         // sub-bin j takes the buckets [S + NB * F(<j) / F, S + NB * F(<=j) / F).
         const uint32_t hpm = max(max(s_hotp[0], s_hotp[1]), max(s_hotp[2], s_hotp[3]));
         const uint32_t cH = hpm >> 10, H = (uint32_t)GSR_EQ_BINS - 1u - (hpm & ((uint32_t)GSR_EQ_BINS - 1u));
@@ -219,17 +232,7 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
     }
     __syncthreads();
     if (hot != GSR_EQ_NO_HOT) {
-        uint32_t f[4] = {0u, 0u, 0u, 0u};
-        uint2 fr[GSR_EQ_SAMPLE_WGS];
-#pragma unroll
-        for (int j = 0; j < GSR_EQ_SAMPLE_WGS; ++j)      // unconditional loads (clamped row), masked below: one round trip, not sixteen
-            fr[j] = reinterpret_cast<const uint2*>(sample_hist + (size_t)min(j, n_samp - 1) * GSR_EQ_SAMPLE_ROW + GSR_EQ_BINS)[tid];
-#pragma unroll
-        for (int j = 0; j < GSR_EQ_SAMPLE_WGS; ++j) {
-            const bool use = j < n_samp;
-            f[0] += use ? fr[j].x & 0xFFFFu : 0u; f[1] += use ? fr[j].x >> 16 : 0u;
-            f[2] += use ? fr[j].y & 0xFFFFu : 0u; f[3] += use ? fr[j].y >> 16 : 0u;
-        }
+        uint32_t f[4] = {fold[0], fold[1], fold[2], fold[3]};
         // the folded histogram = the hot bin's sub-bins + a flat background of the keys of all other coarse bins
 #pragma unroll
         for (int i = 0; i < 4; ++i) f[i] = f[i] > hot_bg ? f[i] - hot_bg : 0u;
@@ -840,14 +843,14 @@ size_t gsr_depth_bucket_blocks(int P) { return ((size_t)(P > 0 ? P : 1) + DS_ITE
 size_t gsr_depth_bucket_segments(int P) { return ((size_t)(P > 0 ? P : 1) + DS_SEG - 1) / DS_SEG + 1; }
 
 // keys[P] (27-bit depth keys, GSR_DEPTH_KEY_CULLED for Gaussians without a tile), tiles[P], rect[P], frame = the words the
-// key-producing kernel's last workgroup wrote, wg_range / sample_hist = what its workgroups left (gsr_frame.h)  ->  order[P], rect_sorted[P], offsets[P] (inclusive scan of the
+// key-producing kernel's last workgroup wrote, wg_range = the key ranges its workgroups left (gsr_frame.h)  ->  order[P], rect_sorted[P], offsets[P] (inclusive scan of the
 // tile counts in depth order), block_first[bf_cap]
 void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, const uint2* rect, uint32_t* frame,
-                                  const uint2* wg_range, int n_range, const uint16_t* sample_hist, const GsrDepthSortBufs& b, uint32_t* order, uint2* rect_sorted,
+                                  const uint2* wg_range, int n_range, const GsrDepthSortBufs& b, uint32_t* order, uint2* rect_sorted,
                                   uint32_t* offsets, uint2* block_first, uint32_t block_first_cap, uint32_t* slow_word, hipStream_t st) {
     const int nblocks = (int)gsr_depth_bucket_blocks(P);
     const int nseg_cap = (int)gsr_depth_bucket_segments(P);
-    hipLaunchKernelGGL(ds_hist, dim3(nblocks), dim3(DS_THREADS), 0, st, P, keys, tiles, frame, wg_range, n_range, sample_hist, b.eq_tab, b.bucket_of, b.cnt_tab, b.tile_tab);
+    hipLaunchKernelGGL(ds_hist, dim3(nblocks), dim3(DS_THREADS), 0, st, P, keys, tiles, frame, wg_range, n_range, b.eq_tab, b.bucket_of, b.cnt_tab, b.tile_tab);
     hipLaunchKernelGGL(ds_scan, dim3(DS_NB / 16), dim3(DS_THREADS), 0, st, nblocks, b.cnt_tab, b.tile_tab, b.cnt_total, b.tile_total);
     hipLaunchKernelGGL(ds_scatter, dim3(nblocks + 1), dim3(S3_THREADS), 0, st, P, nblocks, keys, b.bucket_of, frame, b.eq_tab, b.cnt_tab, b.cnt_total,
                        b.tile_total, b.pairs[0], order, offsets, rect_sorted, b.plan, nseg_cap);

@@ -310,7 +310,6 @@ GsrGeom gsr_carve_geom(char* base, int P) {
     }
     g.num_rendered = (uint32_t*)take(128);
     g.wg_range = (uint2*)take((size_t)GSR_FRAME_MAX_GROUPS * 8);
-    g.sample_hist = (uint16_t*)take(GSR_EQ_SAMPLE_BYTES);
     g.bytes = off;
     return g;
 }
@@ -582,7 +581,6 @@ static GsrFrameStatsDev frame_stats_for(HostWordLease& lease, GsrGeom& g, uint32
     fs.state = lease.hw.state;
     fs.frame = g.num_rendered;
     fs.wg_range = g.wg_range;
-    fs.sample_hist = g.sample_hist;
     fs.host_word = lease.hw.dev;
     fs.seq = seq_out;
     return fs;
@@ -621,7 +619,7 @@ static int bin_and_render(const GsrRasterSettings* settings, const GsrCamDev& ca
     // scan, after the sort, and the GPU idled 5-7 us per frame).
     {   StageTimer t(GSR_STAGE_DEPTH_SORT, st);
         if (bucket) {
-            gsr_launch_depth_bucket_sort(P, g.keys[0], g.tiles, g.rect, g.num_rendered, g.wg_range, n_range, g.sample_hist, g.ds, g.vals[order_buf], g.rect_sorted, g.offsets,
+            gsr_launch_depth_bucket_sort(P, g.keys[0], g.tiles, g.rect, g.num_rendered, g.wg_range, n_range, g.ds, g.vals[order_buf], g.rect_sorted, g.offsets,
                                          g.block_first, bf_cap, slow_word_dev(dev_id), st);
         } else {
             const int ob = gsr_radix_sort_pairs(g.keys, g.vals, P, GSR_DEPTH_KEY_BITS, GSR_DEPTH_DIGIT_BITS, g.sort_hist, g.digit_total,
@@ -798,7 +796,7 @@ int gsr_preprocess_forward(const GsrRasterSettings* settings, int P, int M, cons
     g.splats = reinterpret_cast<float4*>(splat_records);
     {   StageTimer t(GSR_STAGE_PREPROCESS, st);
         GsrFrameStatsDev none;      // nothing is binned here: no frame statistics
-        none.state = nullptr; none.frame = nullptr; none.wg_range = nullptr; none.sample_hist = nullptr; none.host_word = nullptr; none.seq = 0;
+        none.state = nullptr; none.frame = nullptr; none.wg_range = nullptr; none.host_word = nullptr; none.seq = 0;
         gsr_launch_preprocess(cam, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, radii, none, st);
     }
     STAGE_CHECK("preprocess (shard)");

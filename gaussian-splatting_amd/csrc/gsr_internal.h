@@ -42,7 +42,17 @@ static inline size_t gsr_block_first_cap(int P) { return (size_t)(P > 0 ? P : 1)
 #define GSR_DS_SEG 2048          // a segment = the buckets that start inside one window of this many elements
 #define GSR_DS_CAP 4096          // largest segment sorted in LDS; beyond: the same passes through global memory (slow, reported)
 #define GSR_DS_MAX_P (3 << 20)   // above: the LSD radix sort (the [workgroup][bucket] tables grow with P)
-// (the histogram-equalised bucket mapping and its GSR_EQ_* constants: gsr_frame.h)
+// Histogram-equalised bucket mapping (round 6, depthsort.hip ds_hist).  The 27-bit key space is cut into GSR_EQ_BINS coarse bins of 2^GSR_EQ_SHIFT keys
+// (64 per octave of depth); every ds_hist workgroup reads the same GSR_EQ_SAMPLE keys -- GSR_EQ_SAMPLE / 64 windows of 64 consecutive keys spread
+// evenly over the array -- and builds the same tables from them: (first bucket, buckets) per coarse bin, and for ONE "hot" coarse bin (an eighth of
+// the sample or more) the same per sub-bin of 2^GSR_EQ_SHIFT2 keys.
+#define GSR_EQ_SHIFT 17
+#define GSR_EQ_BINS 1024         // 2^(GSR_DEPTH_KEY_BITS - GSR_EQ_SHIFT)
+#define GSR_EQ_SHIFT2 7          // GSR_EQ_SHIFT - log2(GSR_EQ_BINS)
+#define GSR_EQ_SAMPLE 4096
+#define GSR_EQ_NO_HOT 0xFFFFFFFFu
+// table buffer (ds_hist -> ds_scatter): GSR_EQ_BINS words level 1, GSR_EQ_BINS words level 2, then the hot bin (GSR_EQ_NO_HOT: no second level)
+#define GSR_EQ_TAB_WORDS (2 * GSR_EQ_BINS + 16)
 struct GsrDepthSortBufs {
     uint2* pairs[2];             // [P] (key, id) in bucket order / scratch of an oversized segment
     uint32_t* cnt_tab;           // [workgroups][2048] keys per bucket, then their exclusive prefix over the workgroups
@@ -72,7 +82,6 @@ struct GsrGeom {                 // P-sized
     GsrDepthSortBufs ds;         // bucket depth sort (depthsort.hip); carved for P <= GSR_DS_MAX_P
     uint32_t* num_rendered;      // frame words (gsr_frame.h): [0..1] R as 64 bits, [2] smallest, [3] largest depth key of a listed Gaussian
     uint2* wg_range;             // [GSR_FRAME_MAX_GROUPS] per-workgroup depth-key ranges of the key-producing kernel
-    uint16_t* sample_hist;       // GSR_EQ_SAMPLE_BYTES: key histograms of the first workgroups of the key-producing kernel (gsr_frame.h)
     size_t bytes;
 };
 GsrGeom gsr_carve_geom(char* base, int P);
@@ -86,8 +95,7 @@ GsrGeom gsr_carve_geom(char* base, int P);
 #define GSR_DEPTH_KEY_BITS 27
 #define GSR_DEPTH_KEY_BASE 0x3E4CCCCDu
 #define GSR_DEPTH_KEY_CULLED ((1u << GSR_DEPTH_KEY_BITS) - 1u)
-static_assert(GSR_DEPTH_KEY_CULLED == GSR_FRAME_KEY_CULLED && (1 << (GSR_DEPTH_KEY_BITS - GSR_EQ_SHIFT)) == GSR_EQ_BINS &&
-              (1 << (GSR_EQ_SHIFT - GSR_EQ_SHIFT2)) == GSR_EQ_BINS, "gsr_frame.h");
+static_assert((1 << (GSR_DEPTH_KEY_BITS - GSR_EQ_SHIFT)) == GSR_EQ_BINS && (1 << (GSR_EQ_SHIFT - GSR_EQ_SHIFT2)) == GSR_EQ_BINS, "equalised bucket tables");
 #ifdef __HIPCC__
 // `overflow` is a per-thread flag the caller reports ONCE, after its loop, through gsr_frame_stats_commit: a store through an
 // (unrestricted) host-word pointer inside the streaming loop made hipcc serialise the loop's batched loads (ISA audit: the
@@ -175,7 +183,7 @@ int gsr_radix_sort_pairs_k16(uint16_t* keys[2], uint32_t* vals[2], int64_t n, in
                              uint32_t* digit_total, int items, hipStream_t st);
 // depthsort.hip: depth order + rectangles in depth order + inclusive scan of the tile counts + the emission's block table
 void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, const uint2* rect, uint32_t* frame,
-                                  const uint2* wg_range, int n_range, const uint16_t* sample_hist, const GsrDepthSortBufs& b, uint32_t* order, uint2* rect_sorted,
+                                  const uint2* wg_range, int n_range, const GsrDepthSortBufs& b, uint32_t* order, uint2* rect_sorted,
                                   uint32_t* offsets, uint2* block_first, uint32_t block_first_cap, uint32_t* slow_word, hipStream_t st);
 // pass plan shared by the sorter and by code that must know which ping-pong buffer holds the result
 int gsr_sort_plan(int nbits, int max_digit_bits, int* pass_bits /*[8]*/);

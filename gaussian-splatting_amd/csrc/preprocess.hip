@@ -318,8 +318,7 @@ preprocess_fwd_kernel(GsrCamDev camd, int P, const float* __restrict__ means3D, 
         vals[i] = (uint32_t)i;
         acc.add(key, sp.tiles);
     }
-    // (the SH staging tiles are free once every wave has left the loop: the commit reuses them behind its barrier)
-    gsr_frame_stats_commit(fs, acc.tiles, acc.kmin, acc.kmax, acc.ovf, keys, P, reinterpret_cast<uint32_t*>(&s_sh[0][0]));
+    gsr_frame_stats_commit(fs, acc.tiles, acc.kmin, acc.kmax, acc.ovf);
 }
 
 

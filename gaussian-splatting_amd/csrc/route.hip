@@ -123,7 +123,6 @@ __global__ void __launch_bounds__(256)
 ingest_packed(int P, const float4* __restrict__ packed, int y0, int y1, float4* __restrict__ splats, uint2* __restrict__ rect,
               uint32_t* __restrict__ tiles, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GsrFrameStatsDev fs,
               int seg_rows /*0: P contiguous records; else rows per fixed-capacity segment = capacity + 1*/) {
-    __shared__ uint32_t s_eq[2 * GSR_EQ_BINS];      // (the commit's coarse key histogram, gsr_frame.h)
     GsrFrameAcc acc;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
         if (seg_rows) {      // header row, or a row past the segment's count: a Gaussian without tiles
@@ -160,7 +159,7 @@ ingest_packed(int P, const float4* __restrict__ packed, int y0, int y1, float4* 
         vals[i] = (uint32_t)i;
         acc.add(key, t);
     }
-    gsr_frame_stats_commit(fs, acc.tiles, acc.kmin, acc.kmax, acc.ovf, keys, P, s_eq);
+    gsr_frame_stats_commit(fs, acc.tiles, acc.kmin, acc.kmax, acc.ovf);
 }
 
 // out[ids[r]] += rows[r] for r in [0, n): ids are distinct within one launch

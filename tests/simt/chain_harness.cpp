@@ -6,7 +6,6 @@
 #include "tilesort.hip"
 #include "simt_runtime.h"
 #include <vector>
-#include "sample_hist.h"
 
 void gsr_launch_rs_scan(uint32_t* block_hist, int nblocks, int ndigits, uint32_t* digit_total, hipStream_t) {      // sort.hip's rs_scan, restated
     for (int d = 0; d < ndigits; ++d) {
@@ -42,10 +41,9 @@ int64_t simt_bin(int P, int gx, int gy, const uint32_t* keys, const uint32_t* ti
     b.pairs[0] = pairs0.data(); b.pairs[1] = pairs1.data();
     b.cnt_tab = cnt_tab.data(); b.tile_tab = tile_tab.data(); b.cnt_total = cnt_total.data(); b.tile_total = tile_total.data(); b.plan = plan.data();
     std::vector<uint32_t> eq_tab(GSR_EQ_TAB_WORDS);
-    const std::vector<uint16_t> sample = simt_sample_hist(keys, P, n_range);
     std::vector<uint16_t> bucket_of((size_t)P + 64);
     b.eq_tab = eq_tab.data(); b.bucket_of = bucket_of.data();
-    gsr_launch_depth_bucket_sort(P, keys, tiles, rect, frame.data(), wg_range, n_range, sample.data(), b, order, rect_sorted.data(), offsets.data(), block_first.data(), bf_cap, nullptr, nullptr);
+    gsr_launch_depth_bucket_sort(P, keys, tiles, rect, frame.data(), wg_range, n_range, b, order, rect_sorted.data(), offsets.data(), block_first.data(), bf_cap, nullptr, nullptr);
     if (R > 0 && !simt::launch_error) {
         GsrTileSortPlan tp;
         gsr_tile_sort_plan(n_tiles, P, &tp);

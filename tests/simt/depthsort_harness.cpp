@@ -4,7 +4,6 @@
 #include "depthsort.hip"
 #include "simt_runtime.h"
 #include <vector>
-#include "sample_hist.h"
 
 static char g_err[256];
 
@@ -21,13 +20,12 @@ int simt_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, c
     std::vector<uint2> pairs0((size_t)P + 16), pairs1((size_t)P + 16);
     std::vector<uint32_t> cnt_tab(nblocks * DS_NB), tile_tab(nblocks * DS_NB), cnt_total(DS_NB), tile_total(DS_NB), plan(nseg * 8 + 8);
     std::vector<uint32_t> eq_tab(GSR_EQ_TAB_WORDS);
-    const std::vector<uint16_t> sample = simt_sample_hist(keys, P, n_range);
     GsrDepthSortBufs b;
     b.pairs[0] = pairs0.data(); b.pairs[1] = pairs1.data();
     b.cnt_tab = cnt_tab.data(); b.tile_tab = tile_tab.data(); b.cnt_total = cnt_total.data(); b.tile_total = tile_total.data(); b.plan = plan.data();
     std::vector<uint16_t> bucket_of((size_t)P + 64);
     b.eq_tab = eq_tab.data(); b.bucket_of = bucket_of.data();
-    gsr_launch_depth_bucket_sort(P, keys, tiles, rect, frame, wg_range, n_range, sample.data(), b, order, rect_sorted, offsets, block_first, bf_cap, slow_word, nullptr);
+    gsr_launch_depth_bucket_sort(P, keys, tiles, rect, frame, wg_range, n_range, b, order, rect_sorted, offsets, block_first, bf_cap, slow_word, nullptr);
     if (!simt::launch_error) return 0;
     snprintf(g_err, sizeof(g_err), "bucket depth sort: %s", simt::launch_error);
     simt::launch_error = nullptr;

@@ -63,11 +63,10 @@ int64_t simt_forward(const GsrRasterSettings* s, int snug, int P, int M, const f
     g.ds.pairs[0] = pairs0.data(); g.ds.pairs[1] = pairs1.data(); g.ds.cnt_tab = cnt_tab.data(); g.ds.tile_tab = tile_tab.data();
     g.ds.cnt_total = cnt_total.data(); g.ds.tile_total = tile_total.data(); g.ds.plan = plan.data();
     std::vector<uint32_t> eq_tab(GSR_EQ_TAB_WORDS);
-    std::vector<uint16_t> sample_hist(GSR_EQ_SAMPLE_BYTES / 2, 0xFFFFu);      // (poisoned: the kernel must write every row it later reads)
     std::vector<uint16_t> bucket_of(n + 64);
-    g.ds.eq_tab = eq_tab.data(); g.ds.bucket_of = bucket_of.data(); g.sample_hist = sample_hist.data();
+    g.ds.eq_tab = eq_tab.data(); g.ds.bucket_of = bucket_of.data();
     GsrFrameStatsDev fs;
-    fs.state = state.data(); fs.frame = frame.data(); fs.wg_range = wg_range.data(); fs.sample_hist = sample_hist.data(); fs.host_word = nullptr; fs.seq = 1;
+    fs.state = state.data(); fs.frame = frame.data(); fs.wg_range = wg_range.data(); fs.host_word = nullptr; fs.seq = 1;
     auto bail = [&]() -> int64_t { snprintf(g_err, sizeof(g_err), "%s", simt::launch_error ? simt::launch_error : "?"); simt::launch_error = nullptr; return -1; };
     const int n_range = gsr_launch_preprocess(c, P, means3D, shs, colors_precomp, opacities, scales, rotations, nullptr, g, radii, fs, nullptr);
     if (simt::launch_error) return bail();
@@ -79,7 +78,7 @@ int64_t simt_forward(const GsrRasterSettings* s, int snug, int P, int M, const f
     const uint32_t bf_cap = (uint32_t)gsr_block_first_cap(P);
     const int64_t nblk = ((int64_t)R + GSR_TS_ITEMS - 1) / GSR_TS_ITEMS;
     std::vector<uint2> block_first(std::max<size_t>(bf_cap, (size_t)nblk + 2));
-    gsr_launch_depth_bucket_sort(P, g.keys[0], g.tiles, g.rect, frame.data(), wg_range.data(), n_range, sample_hist.data(), g.ds, g.vals[1], g.rect_sorted, g.offsets,
+    gsr_launch_depth_bucket_sort(P, g.keys[0], g.tiles, g.rect, frame.data(), wg_range.data(), n_range, g.ds, g.vals[1], g.rect_sorted, g.offsets,
                                  block_first.data(), bf_cap, nullptr, nullptr);
     if (simt::launch_error) return bail();
     std::vector<uint64_t> words((size_t)R + 16);
@@ -151,7 +150,7 @@ int64_t simt_forward_sharded(const GsrRasterSettings* s, int snug, int G, const 
         GsrGeom g{};
         g.splats = records.data(); g.rect = rect.data(); g.tiles = tiles.data(); g.keys[0] = keys0.data(); g.vals[0] = vals0.data();
         GsrFrameStatsDev none;
-        none.state = nullptr; none.frame = nullptr; none.wg_range = nullptr; none.sample_hist = nullptr; none.host_word = nullptr; none.seq = 0;
+        none.state = nullptr; none.frame = nullptr; none.wg_range = nullptr; none.host_word = nullptr; none.seq = 0;
         GsrCamDev cs = c;
         cs.tile_y0 = 0; cs.tile_y1 = c.gy;      // the records leave the rank: rectangles of the FULL frame
         gsr_launch_preprocess(cs, Pg, means3D + (size_t)lo * 3, shs + (size_t)lo * M * 3, nullptr, opacities + lo, scales + (size_t)lo * 3, rotations + (size_t)lo * 4,
@@ -207,11 +206,10 @@ int64_t simt_forward_sharded(const GsrRasterSettings* s, int snug, int G, const 
             ds.pairs[0] = pairs0.data(); ds.pairs[1] = pairs1.data(); ds.cnt_tab = cnt_tab.data(); ds.tile_tab = tile_tab.data();
             ds.cnt_total = cnt_total.data(); ds.tile_total = tile_total.data(); ds.plan = plan.data();
             std::vector<uint32_t> eq_tab(GSR_EQ_TAB_WORDS);
-            std::vector<uint16_t> sample_hist(GSR_EQ_SAMPLE_BYTES / 2, 0xFFFFu);
             std::vector<uint16_t> bucket_of(n + 64);
             ds.eq_tab = eq_tab.data(); ds.bucket_of = bucket_of.data();
             GsrFrameStatsDev fs;
-            fs.state = state.data(); fs.frame = frame.data(); fs.wg_range = wg_range.data(); fs.sample_hist = sample_hist.data(); fs.host_word = nullptr; fs.seq = 1;
+            fs.state = state.data(); fs.frame = frame.data(); fs.wg_range = wg_range.data(); fs.host_word = nullptr; fs.seq = 1;
             const int n_range = gsr_launch_ingest_packed(Pb, recv.data(), cb.tile_y0, cb.tile_y1, splats.data(), rect.data(), tiles.data(), keys0.data(), vals0.data(), fs, 0, nullptr);
             if (simt::launch_error) return bail();
             const uint32_t R = frame[0];
@@ -219,7 +217,7 @@ int64_t simt_forward_sharded(const GsrRasterSettings* s, int snug, int G, const 
             const uint32_t bf_cap = (uint32_t)gsr_block_first_cap(Pb);
             const int64_t nblk = ((int64_t)R + GSR_TS_ITEMS - 1) / GSR_TS_ITEMS;
             std::vector<uint2> block_first(std::max<size_t>(bf_cap, (size_t)nblk + 2));
-            gsr_launch_depth_bucket_sort(Pb, keys0.data(), tiles.data(), rect.data(), frame.data(), wg_range.data(), n_range, sample_hist.data(), ds, vals1.data(), rect_sorted.data(), offsets.data(),
+            gsr_launch_depth_bucket_sort(Pb, keys0.data(), tiles.data(), rect.data(), frame.data(), wg_range.data(), n_range, ds, vals1.data(), rect_sorted.data(), offsets.data(),
                                          block_first.data(), bf_cap, nullptr, nullptr);
             if (simt::launch_error) return bail();
             if (R > 0) {

@@ -16,34 +16,18 @@ KEY_CULLED = (1 << 27) - 1
 KEY_BASE = 0x3E4CCCCD          # bits(0.2f), gsr_internal.h GSR_DEPTH_KEY_BASE
 
 
-EQ_SHIFT, EQ_BINS, EQ_SAMPLE_WGS, EQ_SHIFT2 = 17, 1024, 16, 7      # csrc/gsr_frame.h
+EQ_SHIFT, EQ_BINS, EQ_SHIFT2 = 17, 1024, 7      # csrc/gsr_internal.h
 
 
-def sampler_workgroups(P, grid):
-    """gsr_frame_sampler_row (csrc/gsr_frame.h): the n = min(16, grid) sampling workgroups, spread evenly over the workgroups that run the fewest loop
-    iterations (the last ones of a grid-stride grid) if there are at least n of them, else over the whole grid."""
-    n = min(EQ_SAMPLE_WGS, grid)
-    stride = grid * 256
-    rem = P % stride if P > 0 else 0
-    full = grid if rem == 0 else (rem + 255) // 256
-    lo, hi = (full, grid) if grid - full >= n else (0, grid)
-    return [lo + ((2 * r + 1) * (hi - lo)) // (2 * n) for r in range(n)]
-
-
-def sample_hist(keys, n_range):
-    """What the sampling workgroups of the key-producing kernel leave (gsr_frame.h): workgroup w of a grid of n_range 256-thread workgroups
-    owns the keys w * 256 + t + k * n_range * 256; per workgroup the coarse histogram (key >> 17) of its listed keys and the histogram of
-    (key >> 7) & 1023 over the same keys (the 1024 sub-bins of all coarse bins folded onto one another); counts saturate at 65535."""
+def sample_keys(keys):
+    """The 4096 keys every ds_hist workgroup histograms (csrc/depthsort.hip): 64 windows of 64 consecutive keys, window q at ((2 q + 1) P / 128) rounded
+    down to a multiple of 64; an index past P reads the last key again; tile-less keys do not count."""
     P = len(keys)
-    rows = []
-    for w in sampler_workgroups(P, n_range):
-        idx = (np.arange(w * 256, P, n_range * 256)[:, None] + np.arange(256)[None, :]).reshape(-1)
-        k = keys[idx[idx < P]].astype(np.int64)
-        k = k[k != KEY_CULLED]
-        c = np.bincount(k >> EQ_SHIFT, minlength=EQ_BINS)
-        f = np.bincount((k >> EQ_SHIFT2) & (EQ_BINS - 1), minlength=EQ_BINS)
-        rows.append((np.minimum(c, 65535), np.minimum(f, 65535)))
-    return rows
+    q = np.arange(64, dtype=np.int64)
+    start = (((2 * q + 1) * P) >> 7) & ~np.int64(63)
+    idx = np.minimum((start[:, None] + np.arange(64)[None, :]).reshape(-1), P - 1)
+    k = keys[idx].astype(np.int64)
+    return k[k != KEY_CULLED]
 
 
 class EqTable:
@@ -51,7 +35,7 @@ class EqTable:
     bucket, the remaining ones of the 2046 are handed out in proportion to the sampled mass.  Level 2, only when one coarse bin holds an eighth
     of the sample or more: that bin's buckets spread over its 1024 sub-bins in proportion to their sampled mass.  Integer arithmetic as in the kernel."""
 
-    def __init__(self, keys, n_range):
+    def __init__(self, keys):
         listed = keys[keys != KEY_CULLED]
         nb = np.zeros(EQ_BINS, np.int64)
         any_ = listed.size > 0
@@ -60,8 +44,9 @@ class EqTable:
             b_lo, b_hi = tmin >> EQ_SHIFT, min(tmax >> EQ_SHIFT, EQ_BINS - 1)
         else:
             b_lo = b_hi = 0
-        rows = sample_hist(keys, n_range)
-        c = np.sum([r[0] for r in rows], axis=0).astype(np.int64)
+        k = sample_keys(keys) if len(keys) else np.zeros(0, np.int64)
+        c = np.bincount(k >> EQ_SHIFT, minlength=EQ_BINS).astype(np.int64)
+        fold = np.bincount((k >> EQ_SHIFT2) & (EQ_BINS - 1), minlength=EQ_BINS).astype(np.int64)
         C = int(c.sum())
         nbins = b_hi - b_lo + 1
         spare = NB - 2 - nbins
@@ -76,7 +61,7 @@ class EqTable:
         self.hot = H if (any_ and C >= 256 and int(c[H]) * 8 >= C) else None
         if self.hot is not None:
             bg = (C - int(c[H]) + EQ_BINS - 1) // EQ_BINS      # the other coarse bins' keys, spread flat over the folded sub-bins
-            f = np.maximum(np.sum([r[1] for r in rows], axis=0).astype(np.int64) - bg, 0)
+            f = np.maximum(fold - bg, 0)
             F = int(f.sum())
             if F == 0:
                 self.hot = None
@@ -128,14 +113,13 @@ class EqTable:
         return (b << EQ_SHIFT) + x
 
 
-def bucket_depth_sort(keys, tiles, n_range=5):
-    """-> (order, inclusive tile scan in depth order, block_first dict, segment sizes).  n_range: workgroups of the key-producing kernel (its
-    last 16 provide the sample the bucket table is equalised with)."""
+def bucket_depth_sort(keys, tiles):
+    """-> (order, inclusive tile scan in depth order, block_first dict, segment sizes)."""
     P = len(keys)
     listed = keys != KEY_CULLED
     assert ((tiles > 0) == listed).all()
     tmin, tmax = (int(keys[listed].min()), int(keys[listed].max())) if listed.any() else (0xFFFFFFFF, 0)
-    eq = EqTable(keys, n_range)
+    eq = EqTable(keys)
     used = eq.used
     d = np.where(listed, eq.bucket_of(np.where(listed, keys, 0)), CULL_BUCKET)
     if listed.any():
@@ -241,8 +225,7 @@ def test_bucket_depth_sort_model_equals_a_stable_sort(case):
     culled = rng.random(P) < (1.0 if case == "all_culled" else 0.12)
     keys = keys_from_depths(z, culled)
     tiles = np.where(culled, 0, rng.integers(1, 40, P)).astype(np.int64)
-    n_range = (P + 255) // 256      # the key-producing kernel's grid at this size
-    order, scan, block_first, sizes = bucket_depth_sort(keys, tiles, n_range)
+    order, scan, block_first, sizes = bucket_depth_sort(keys, tiles)
     if case in ("outliers", "gap", "heavy_tails", "wall", "wall_thin"):
         assert max(sizes) <= CAP, "the equalised buckets keep every segment inside the LDS capacity"
     ref = np.argsort(keys, kind="stable")               # (depth key, index): what the LSD sort and the reference's sort leave

@@ -77,7 +77,6 @@ def test_bucket_depth_sort_on_the_cpu_equals_a_stable_sort(lib, kind, P):
     keys[tiles == 0] = CULLED
     listed = tiles > 0
     # the key-producing kernel's per-workgroup key ranges: workgroup c of n_range 256-thread workgroups owns the keys c * 256 + t + k * n_range * 256
-    # (the harness derives the last 16 workgroups' coarse sample histograms from the same layout, tests/simt/sample_hist.h)
     n_range = min(1024, (P + 255) // 256) if kind in ("outliers", "heavy_tails", "wall", "wall_thin") or P > 100_000 else 5
     wg = np.zeros((n_range, 2), dtype=np.uint32)
     parts = []

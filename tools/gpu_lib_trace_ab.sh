@@ -13,7 +13,7 @@ for lib in ${LIBS:-lib lib_prev}; do
   cd "$R"
   python tools/kernel_trace_stats.py gpurun_out/prof_ab_$lib gpurun_out/kernel_stats_$lib.csv 0.25 > /dev/null
   echo "== $lib"; tail -1 gpurun_out/trace_ab_$lib.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['train_iters_per_s'], d['train_iters_per_s_sparse_adam'])"
-  python tools/kernel_trace_timeline.py gpurun_out/prof_ab_$lib gpurun_out/kernel_timeline_$lib.json 0.3 | head -1 | cut -c1-400
+  python tools/kernel_trace_timeline.py gpurun_out/prof_ab_$lib gpurun_out/kernel_timeline_$lib.json 0.3 | head -16 | cut -c1-400
   find gpurun_out/prof_ab_$lib -name "*kernel_trace*" -delete
 done
 python - <<'PY'
