@@ -133,12 +133,13 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
     uint32_t sk[16];
 #pragma unroll
     for (int j = 0; j < 8; ++j) rg[j] = wg_range[min(j * DS_THREADS + tid, n_range - 1)];      // (clamped: duplicates do not change a max)
-    // THE SAMPLE: 64 windows of 64 consecutive keys, window q at ((2 q + 1) P / 128) rounded down to a multiple of 64 -- the same 4096 keys in
-    // every workgroup (coalesced 256-byte loads, L2 hits), so every workgroup builds the same tables; an index past P reads the last key again
+    // THE SAMPLE: 256 windows of 16 consecutive keys (one 64-byte line each), window q at ((2 q + 1) P / 512) rounded down to a multiple of 16 -- the
+    // same 4096 keys in every workgroup (L2 hits; a wave's load touches four lines), so every workgroup builds the same tables; an index past P
+    // reads the last key again.  Many short windows: neighbours in the array are often neighbours in space (clones sit next to each other).
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const int64_t q = (int64_t)j * WG_WAVES + w;
-        const int64_t i = ((((2 * q + 1) * (int64_t)P) >> 7) & ~(int64_t)63) + lane;
+        const int64_t q = (int64_t)j * 16 + (tid >> 4);
+        const int64_t i = ((((2 * q + 1) * (int64_t)P) >> 9) & ~(int64_t)15) + (tid & 15);
         sk[j] = keys[i < P ? i : (int64_t)P - 1];
     }
 #pragma unroll
@@ -188,7 +189,7 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
     __syncthreads();
     const uint32_t tmin = ~max(max(s_nmin[0], s_nmin[1]), max(s_nmin[2], s_nmin[3]));
     const uint32_t tmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-    uint32_t hot = GSR_EQ_NO_HOT, hot_bg = 0u;
+    uint32_t hot = GSR_EQ_NO_HOT, hot_bg = 0u, hot_floor = 1u;
     {   // Round 2 (one barrier): coarse bin b in [b_lo, b_hi] gets 1 + floor(spare * c[b] / C) buckets; their exclusive prefix is the table.
         // (Every sampled key lies inside the true range, so C counts exactly the sampled keys of the bins in range.)
         const bool any = tmax >= tmin;      // (nothing listed: tmin = 0xFFFFFFFF, tmax = 0)
@@ -229,19 +230,24 @@ ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
         const uint32_t cH = hpm >> 10, H = (uint32_t)GSR_EQ_BINS - 1u - (hpm & ((uint32_t)GSR_EQ_BINS - 1u));
         hot = (any && C >= 256u && cH * 8u >= C) ? H : GSR_EQ_NO_HOT;
         hot_bg = (C - cH + (uint32_t)GSR_EQ_BINS - 1u) / (uint32_t)GSR_EQ_BINS;
+        hot_floor = max(1u, cH >> 10);
     }
     __syncthreads();
     if (hot != GSR_EQ_NO_HOT) {
         uint32_t f[4] = {fold[0], fold[1], fold[2], fold[3]};
         // the folded histogram = the hot bin's sub-bins + a flat background of the keys of all other coarse bins
+        // ... and every sub-bin keeps a floor of hot_floor = max(1, c_hot / 1024) -- its share if the hot bin were filled evenly: where the bin really
+        // is a wall or a run of ties the excess dominates and takes most of the buckets; where it is merely a well-filled bin the excess is noise
+        // and the floor keeps the second level close to the uniform split of the first (without it a few lucky sub-bins took ALL the bin's buckets
+        // and an eighth of the frame shared a handful of them: the grown scene of the training run fell back to the LSD passes on 15 % of its frames)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) f[i] = f[i] > hot_bg ? f[i] - hot_bg : 0u;
+        for (int i = 0; i < 4; ++i) f[i] = (f[i] > hot_bg ? f[i] - hot_bg : 0u) + hot_floor;
         const uint32_t fsum = f[0] + f[1] + f[2] + f[3];
         const uint32_t fincl = wave_incl_scan_u32(fsum, lane);
         if (lane == 63) s_w3[w] = fincl;
         __syncthreads();
         const uint32_t F = s_w3[0] + s_w3[1] + s_w3[2] + s_w3[3];
-        if (F == 0u) {      // (nothing above the background: no second level; workgroup-uniform)
+        if (F == 0u) {      // (cannot happen with the floor; kept as a guard; workgroup-uniform)
             hot = GSR_EQ_NO_HOT;
         } else {
             uint32_t run = fincl - fsum;

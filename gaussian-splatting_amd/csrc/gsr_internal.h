@@ -43,7 +43,7 @@ static inline size_t gsr_block_first_cap(int P) { return (size_t)(P > 0 ? P : 1)
 #define GSR_DS_CAP 4096          // largest segment sorted in LDS; beyond: the same passes through global memory (slow, reported)
 #define GSR_DS_MAX_P (3 << 20)   // above: the LSD radix sort (the [workgroup][bucket] tables grow with P)
 // Histogram-equalised bucket mapping (round 6, depthsort.hip ds_hist).  The 27-bit key space is cut into GSR_EQ_BINS coarse bins of 2^GSR_EQ_SHIFT keys
-// (64 per octave of depth); every ds_hist workgroup reads the same GSR_EQ_SAMPLE keys -- GSR_EQ_SAMPLE / 64 windows of 64 consecutive keys spread
+// (64 per octave of depth); every ds_hist workgroup reads the same GSR_EQ_SAMPLE keys -- GSR_EQ_SAMPLE / 16 windows of 16 consecutive keys spread
 // evenly over the array -- and builds the same tables from them: (first bucket, buckets) per coarse bin, and for ONE "hot" coarse bin (an eighth of
 // the sample or more) the same per sub-bin of 2^GSR_EQ_SHIFT2 keys.
 #define GSR_EQ_SHIFT 17

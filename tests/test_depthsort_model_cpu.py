@@ -20,12 +20,12 @@ EQ_SHIFT, EQ_BINS, EQ_SHIFT2 = 17, 1024, 7      # csrc/gsr_internal.h
 
 
 def sample_keys(keys):
-    """The 4096 keys every ds_hist workgroup histograms (csrc/depthsort.hip): 64 windows of 64 consecutive keys, window q at ((2 q + 1) P / 128) rounded
-    down to a multiple of 64; an index past P reads the last key again; tile-less keys do not count."""
+    """The 4096 keys every ds_hist workgroup histograms (csrc/depthsort.hip): 256 windows of 16 consecutive keys, window q at ((2 q + 1) P / 512)
+    rounded down to a multiple of 16; an index past P reads the last key again; tile-less keys do not count."""
     P = len(keys)
-    q = np.arange(64, dtype=np.int64)
-    start = (((2 * q + 1) * P) >> 7) & ~np.int64(63)
-    idx = np.minimum((start[:, None] + np.arange(64)[None, :]).reshape(-1), P - 1)
+    q = np.arange(256, dtype=np.int64)
+    start = (((2 * q + 1) * P) >> 9) & ~np.int64(15)
+    idx = np.minimum((start[:, None] + np.arange(16)[None, :]).reshape(-1), P - 1)
     k = keys[idx].astype(np.int64)
     return k[k != KEY_CULLED]
 
@@ -61,7 +61,7 @@ class EqTable:
         self.hot = H if (any_ and C >= 256 and int(c[H]) * 8 >= C) else None
         if self.hot is not None:
             bg = (C - int(c[H]) + EQ_BINS - 1) // EQ_BINS      # the other coarse bins' keys, spread flat over the folded sub-bins
-            f = np.maximum(fold - bg, 0)
+            f = np.maximum(fold - bg, 0) + max(1, int(c[H]) >> 10)      # excess over the background + the floor of an evenly filled bin
             F = int(f.sum())
             if F == 0:
                 self.hot = None
@@ -192,7 +192,7 @@ def keys_from_depths(z, culled):
     return k
 
 
-CASES = ["uniform", "ties", "crowd", "gap", "one_key", "all_culled", "single", "last_bucket_straddles_a_window", "outliers", "heavy_tails", "wall", "wall_thin"]
+CASES = ["uniform", "ties", "crowd", "gap", "one_key", "all_culled", "single", "last_bucket_straddles_a_window", "outliers", "heavy_tails", "wall", "wall_thin", "full_bin"]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -222,11 +222,14 @@ def test_bucket_depth_sort_model_equals_a_stable_sort(case):
         z = np.where(rng.random(P) < 0.5, rng.normal(6.0, 0.006, P), rng.uniform(1.0, 40.0, P))
     elif case == "wall_thin":        # 60 % of the scene within 2e-4 of one depth (~1700 consecutive keys): narrower than one coarse bin's bucket
         z = np.where(rng.random(P) < 0.6, 5.0 * (1.0 + 2e-4 * rng.random(P)), rng.uniform(1.0, 40.0, P))
+    elif case == "full_bin":         # a third of the scene EVENLY spread over one coarse bin (a well-filled bin, not a wall): the second level must not concentrate its buckets
+        P = 600_000
+        z = np.where(rng.random(P) < 0.35, rng.uniform(4.0, 4.0 * (1 + 1.0 / 64), P), rng.uniform(2.0, 40.0, P))
     culled = rng.random(P) < (1.0 if case == "all_culled" else 0.12)
     keys = keys_from_depths(z, culled)
     tiles = np.where(culled, 0, rng.integers(1, 40, P)).astype(np.int64)
     order, scan, block_first, sizes = bucket_depth_sort(keys, tiles)
-    if case in ("outliers", "gap", "heavy_tails", "wall", "wall_thin"):
+    if case in ("outliers", "gap", "heavy_tails", "wall", "wall_thin", "full_bin"):
         assert max(sizes) <= CAP, "the equalised buckets keep every segment inside the LDS capacity"
     ref = np.argsort(keys, kind="stable")               # (depth key, index): what the LSD sort and the reference's sort leave
     assert (order == ref).all()

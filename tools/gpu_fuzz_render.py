@@ -267,14 +267,18 @@ for it in range(N):
             gm[k] = [float(f"{dd.max().item():.3e}"), float(f"{q:.3e}")]
             desc["grad_metrics"] = gm
             stats["worst_grad_err"] = max(stats["worst_grad_err"], dd.max().item() if not degenerate else 0.0)
-            if degenerate and not (dd.max().item() < bar_max and q < bar_p):
+            if not (dd.max().item() < bar_max and q < bar_p):
                 # Conditioning-aware bar (round 5): a needle's exponent cancels in fp32, in the kernel AND in the fp32 oracle.  What fp32 can resolve on
                 # THIS frame is measured by the oracle itself -- its fp32 gradients against its fp64 gradients (seed 53, frames 92 / 137: 2.4e-3 .. 1.3e-2
                 # of max |grad|, the image itself moves by 3e-3) -- and the kernel must be no farther from the fp64 values than three times that.
                 r64 = oracle_fp64()
                 if r64 and r64.get(k) is not None:
-                    e_hip, e_o32 = within(a, r64[k], k)[1], within(b, r64[k], k)[1]
-                    if e_hip < max(bar_max, 3.0 * e_o32):
+                    ok_hip, e_hip = within(a, r64[k], k)
+                    e_o32 = within(b, r64[k], k)[1]
+                    # Round 6: ordinary kinds are adjudicated too, at their OWN bars -- the fp32 oracle's autograd is itself up to 2e-4 of max |grad|
+                    # from its fp64 evaluation on ordinary clouds (seed 7, frame 85: oracle 1.03e-4, kernel 4.4e-6), and since the per-Gaussian
+                    # backward's covariance chain runs in fp64 the kernel is the accurate side: it must be inside the bars of the fp64 gradients.
+                    if (e_hip < max(bar_max, 3.0 * e_o32)) if degenerate else ok_hip:
                         stats["adjudicated_by_fp64"].append({"it": it, "kind": kind, "P": P, "tensor": k, "kernel_vs_fp32_oracle": float(f"{dd.max().item():.3e}"),
                                                              "kernel_vs_fp64": float(f"{e_hip:.3e}"), "fp32_oracle_vs_fp64": float(f"{e_o32:.3e}")})
                         continue
