@@ -169,6 +169,7 @@ std::atomic<int> g_lsd_frames[GSR_MAX_DEVICES];      // per device: frames for w
 std::atomic<int> g_lsd_backoff[GSR_MAX_DEVICES];     // per device: length of the next such stay (doubles per failed retry; heuristic only)
 std::atomic<int> g_lsd_probation[GSR_MAX_DEVICES];   // per device: clean bucket-sort frames still needed after a stay before the back-off is forgotten
 uint32_t* g_slow_word_dev[GSR_MAX_DEVICES] = {nullptr};      // its device-side address
+std::atomic<int> g_debug_dirty_tickets{0};           // TEST HOOK (gsr_set_option debug_dirty_control_block): tickets preloaded into the next frame's counter, once
 uint32_t* g_slow_word[GSR_MAX_DEVICES] = {nullptr};  // per device, mapped host memory: set (1) by ds_segsort when a segment overflowed the LDS capacity;
                                                      // read and cleared by the next lease on that device.  A heuristic flag: a store that races the
                                                      // clear is at worst seen one frame later or lost once, never attributed to another device
@@ -200,7 +201,11 @@ int lease_host_word(HostWordLease& lease, hipStream_t st) {
         hipError_t e = hipHostMalloc((void**)&nw.host, 64, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent);
         if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&nw.dev, nw.host, 0);
         if (e == hipSuccess) e = hipMalloc((void**)&nw.state, 64);
-        if (e == hipSuccess) e = hipMemset(nw.state, 0, 64);
+        // cleared ON THE CALLER'S STREAM, in front of the kernel that will count in it: hipMemset() of device memory is queued on the null stream and
+        // returns before it has run, and a non-blocking stream (every torch side stream) is not ordered behind the null stream -- the clear could land
+        // in the middle of the first frame, lose its tickets, and leave a counter that is never zero again (round 6: a GPU suite run lost
+        // the second caller's first frame of tests/test_gpu_parity.py::test_concurrent_forward_calls_from_two_host_threads and every frame after it)
+        if (e == hipSuccess) e = hipMemsetAsync(nw.state, 0, 64, st);
         if (e != hipSuccess) {      // (nothing half-made is leaked or pooled)
             if (nw.state) (void)hipFree(nw.state);
             if (nw.host) (void)hipHostFree(nw.host);
@@ -433,6 +438,11 @@ int gsr_set_option(const char* name, int value) {
         return GSR_OK;
     }
 #endif
+    if (!strcmp(name, "debug_dirty_control_block")) {      // test hook, one shot: see frame_stats_for
+        if (value < 0 || value > 2047) return fail(GSR_ERR_INVALID_ARG, "debug_dirty_control_block: 0..2047 tickets");
+        g_debug_dirty_tickets.store(value);
+        return GSR_OK;
+    }
     if (!strcmp(name, "tile_sort_mode")) {
         if (value != 0 && value != 1) return fail(GSR_ERR_INVALID_ARG, "tile_sort_mode must be 0 (fused) or 1 (legacy LSD)");
         g_tile_sort_mode = value;
@@ -470,6 +480,7 @@ int gsr_profile_trace(uint64_t* out, int max_waves) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpy(out, ctr + GSR_TRACE_BASE, (size_t)n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     (void)hipMemset(ctr + GSR_TRACE_BASE, 0, (size_t)GSR_TRACE_WAVES * 4 * sizeof(unsigned long long));
+    (void)hipStreamSynchronize(nullptr);      // (the clear is queued on the null stream: done before a kernel of a non-blocking stream traces again)
     return n;
 }
 int gsr_profile_counters(uint64_t* out, int n, int reset) {
@@ -478,7 +489,7 @@ int gsr_profile_counters(uint64_t* out, int n, int reset) {
     unsigned long long* ctr = counters_for_current_device();
     if (ctr) {
         if (hipMemcpy(host, ctr, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return fail(GSR_ERR_HIP, "counter read-back failed");
-        if (reset) (void)hipMemset(ctr, 0, sizeof(host));
+        if (reset) { (void)hipMemset(ctr, 0, sizeof(host)); (void)hipStreamSynchronize(nullptr); }
     }
     for (int i = 0; i < n && i < GSR_COUNTER_COUNT; ++i) out[i] = host[i];
     return GSR_OK;
@@ -562,11 +573,18 @@ static int wait_for_R(HostWord& hw, uint32_t seq, hipStream_t st, const uint32_t
     if (!got) {
         HIP_OK(hipStreamSynchronize(st));
         if (w[1] != seq) {
-            uint32_t r9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // frame words: [0..1] R, [8] "a depth key overflowed" (gsr_frame.h)
-            HIP_OK(hipMemcpy(r9, num_rendered_dev, sizeof(r9), hipMemcpyDeviceToHost));
-            hw.host[0] = r9[0];
-            hw.host[2] = r9[1];
-            hw.host[3] = r9[8] ? 1u : 0u;      // (the fallback recovers the key-overflow flag too, not only R)
+            uint32_t r[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // frame words: [0..1] R, [8] "a depth key overflowed", [9] sequence number (gsr_frame.h)
+            HIP_OK(hipMemcpy(r, num_rendered_dev, sizeof(r), hipMemcpyDeviceToHost));
+            if (r[9] != seq) {
+                // the stream is idle and NO workgroup drew the last ticket: the slot's counter was not zero when the frame began (or lost
+                // tickets on the way).  It is never handed on in that state, and the frame is refused instead of rendered with a made-up R
+                HIP_OK(hipMemsetAsync(hw.state, 0, 64, st));
+                HIP_OK(hipStreamSynchronize(st));
+                return fail(GSR_ERR_HIP, "the frame statistics of this call were never published (control block reset; the call can be repeated)");
+            }
+            hw.host[0] = r[0];
+            hw.host[2] = r[1];
+            hw.host[3] = r[8] ? 1u : 0u;      // (the fallback recovers the key-overflow flag too, not only R)
         }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -578,7 +596,13 @@ static GsrFrameStatsDev frame_stats_for(HostWordLease& lease, GsrGeom& g, uint32
     seq_out = ++lease.hw.seq;
     lease.settled = false;
     GsrFrameStatsDev fs;
-    fs.state = lease.hw.state;
+    fs.state = lease.hw.state + 2u * (seq_out & 1u);               // two 64-bit counters per slot, used alternately (gsr_frame.h)
+    fs.state_other = lease.hw.state + 2u * ((seq_out & 1u) ^ 1u);
+    if (const int t = g_debug_dirty_tickets.exchange(0)) {       // test hook: this frame meets a counter that is not zero (tests/test_simt_abi_cpu.py)
+        const unsigned long long dirt = ((unsigned long long)t << 53) | 5ull;
+        (void)hipMemcpyAsync(fs.state, &dirt, sizeof(dirt), hipMemcpyHostToDevice, lease.st);
+        (void)hipStreamSynchronize(lease.st);
+    }
     fs.frame = g.num_rendered;
     fs.wg_range = g.wg_range;
     fs.host_word = lease.hw.dev;

@@ -12,6 +12,9 @@
 // value tells the workgroup that drew the last ticket so, and hands it the totals: it copies R to the geometry buffer,
 // publishes it to the mapped host word (value first, sequence number last, system-scope release) and RESETS the counter, so
 // the next lease finds it zeroed.  The counter belongs to the host-word lease (gsr_api.cpp), never to two frames at once.
+// A slot holds TWO counters and its frames alternate between them; the last workgroup also clears the one it did not use (round 6: a
+// counter that does not start at zero publishes a partial R early and is left non-zero again by the workgroups that come after -- for
+// ever; with the second counter such a state lasts one frame).
 // One atomic per workgroup, nothing to order, no spinning.  (First version: five atomics and an acq_rel ticket -- the
 // agent-scope release / acquire is an L2 write-back / invalidate on this multi-XCD part and doubled the preprocess kernel.)
 #pragma once
@@ -23,11 +26,13 @@
 // 2^31: any total >= 2^31 is refused by the host anyway), [42, 53) workgroups with a key overflow, [53, 64) tickets
 // -> the key-producing kernels run at most GSR_FRAME_MAX_GROUPS workgroups
 // frame words (geometry buffer, GsrGeom::num_rendered): [0] R low, [1] R high; written by ds_hist: [2] / [3] and [6] / [7] the smallest / largest depth key of a listed
-// Gaussian (depthsort.hip); [8] "a depth key needed more than 27 bits" (a copy of host word [3])
+// Gaussian (depthsort.hip); [8] "a depth key needed more than 27 bits" (a copy of host word [3]); [9] the sequence number (a copy of host word [1])
 // host word (mapped): [0] R low, [1] sequence number, [2] R high, [3] "a depth key needed more than 27 bits"
 #define GSR_FRAME_MAX_GROUPS 2047
 struct GsrFrameStatsDev {
     uint32_t* state;       // NULL: the kernel keeps no statistics (shard projection without binning)
+    uint32_t* state_other = nullptr;      // the slot's SECOND counter (the frames of a slot alternate between two): cleared by this frame's last workgroup too, so
+                           // that a counter that was ever left dirty costs one frame, not every frame after it; may be NULL
     uint32_t* frame;
     uint2* wg_range;       // [workgroups] (~smallest, largest) depth key of the workgroup's listed Gaussians; (0, 0): none
     uint32_t* host_word;   // may be NULL (then only `frame` is written)
@@ -65,8 +70,11 @@ __device__ __forceinline__ void gsr_frame_stats_commit(const GsrFrameStatsDev& f
     const uint32_t n_ovf = (uint32_t)(tot >> 42) & 0x7FFu;
     fs.frame[0] = (uint32_t)R;
     fs.frame[1] = (uint32_t)(R >> 32);
-    fs.frame[8] = n_ovf ? 1u : 0u;      // (read by the host only when the mapped word did not arrive: gsr_api.cpp wait_for_R)
+    fs.frame[8] = n_ovf ? 1u : 0u;      // ([8], [9]: read by the host only when the mapped word did not arrive: gsr_api.cpp wait_for_R)
+    fs.frame[9] = fs.seq;
     __hip_atomic_store(ctr, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (read next by a later kernel)
+    if (fs.state_other)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(fs.state_other), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (fs.host_word) {      // value first, then the sequence number (system-scope release)
         __hip_atomic_store(fs.host_word + 0, (uint32_t)R, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(fs.host_word + 2, (uint32_t)(R >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -462,7 +462,9 @@ int gsr_profile_trace(uint64_t* out, int max_waves);
  *                    their heaviest half, 1 = tiles by the sum of their four blocks (round 3), 3 = every half tile on its own,
  *                    0 = index order; scheduling only -- the gradients are the same bits in every order
  * and ssim_variant (0 = marching-wave SSIM / training-loss kernels, 1 = the LDS-tiled form), ssim_target_waves (launch shape of
- * the marching form), preprocess_grid_cap. */
+ * the marching form), preprocess_grid_cap.
+ * Test hook: debug_dirty_control_block = t preloads t tickets into the frame counter of the NEXT forward call, once (a counter that is
+ * not zero when a frame begins, csrc/gsr_frame.h): that frame is wrong or refused, the ones after it must be right again. */
 int gsr_set_option(const char* name, int value);
 
 #ifdef __cplusplus

@@ -793,6 +793,36 @@ def test_more_than_65536_tiles_uses_32bit_tile_keys(no_backward):
     assert torch.isfinite(out["color"]).all()
 
 
+def test_a_frame_counter_that_is_not_zero_costs_one_frame():
+    """csrc/gsr_frame.h sums R in a device counter that must be zero when a frame begins.  Round 6 met one that was not (the control block of a second
+    concurrent caller): it published a partial R early, was left non-zero again by the workgroups behind, and every later frame on that slot was wrong.
+    The test hook `debug_dirty_control_block` preloads tickets into the NEXT frame's counter: after ONE stray ticket that frame may be wrong, the frames
+    after it are the scene's own again (a slot alternates between two counters; the last workgroup clears both); with more tickets than workgroups no
+    workgroup is the last, and the host -- stream idle, frame words unpublished -- clears the slot and refuses the frame."""
+    from diff_gaussian_rasterization import GaussianRasterizer, _lib
+    dev = torch.device("cuda:0")
+    cam = make_camera(320, 240)
+    scenes = [make_scene(30_000, cam, seed=41, s_med=0.02).to(dev), make_scene(9_000, cam, seed=42, s_med=0.05).to(dev)]
+    rs = gpu_settings(oracle_settings(cam, bg=torch.tensor([0.1, 0.2, 0.3])), dev)
+
+    def render(i):
+        sc = scenes[i]
+        with torch.no_grad():
+            out = GaussianRasterizer(rs)(means3D=sc.means3D, means2D=None, opacities=sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+        torch.cuda.synchronize()
+        return out
+    want = render(0)
+    _lib.set_option("debug_dirty_control_block", 1)
+    render(1)                                               # (another scene: the leftover of a frame is exactly what the SAME frame would miss next time)
+    for i in range(4):
+        assert all(torch.equal(a, b) for a, b in zip(render(0), want)), f"frame {i + 1} after a stray ticket"
+    _lib.set_option("debug_dirty_control_block", 1500)
+    with pytest.raises(_lib.GsrError, match="never published"):
+        render(1)
+    for i in range(2):
+        assert all(torch.equal(a, b) for a, b in zip(render(0), want)), f"frame {i + 1} after a refused frame"
+
+
 def test_concurrent_forward_calls_from_two_host_threads():
     """Round 4 moved R (and the depth-key range) into a per-call device counter + mapped host word that the preprocess kernel's
     last workgroup publishes (csrc/gsr_frame.h); both are LEASED per call.  Two host threads rendering different scenes on their
