@@ -27,8 +27,8 @@
 //               emission -- everything the depth sort's last pass and the two scan kernels used to produce.
 //               A segment beyond the LDS capacity (it ends with a bucket of more than 2048 keys) is cut into groups of whole buckets
 //               that fit and sorted group by group; a SINGLE bucket beyond the capacity -- after both levels of the equalised table:
-//               thousands of equal depths -- needs no pass when all its keys are equal, else goes through global memory, is
-//               reported to the host, and the host prefers the LSD sort for a while (gsr_api.cpp).
+//               thousands of equal depths -- needs no pass when all its keys are equal, else goes through global memory; that, or more than
+//               three capacities of equal keys in one bucket, is reported to the host, which prefers the LSD sort for a while (gsr_api.cpp).
 //
 // Order: (key, Gaussian index) ascending -- ds_scatter is stable and the segment sort is stable, so equal depths keep index
 // order exactly as the LSD sort (and the reference's stable 64-bit-key sort) leaves them.  No atomics on global memory, no
@@ -49,6 +49,7 @@ constexpr int DS_DPT = DS_NB / DS_THREADS;             // 8 buckets per thread
 constexpr int DS_SEG = GSR_DS_SEG;
 constexpr int DS_CAP = GSR_DS_CAP;
 constexpr int DS_PASS_BITS = 9;
+constexpr int DS_SLOW_CHUNKS = 3;                      // a single bucket of equal keys beyond this many LDS capacities is reported (ds_segsort)
 constexpr int DS_PASS_BINS = 1 << DS_PASS_BITS;
 static_assert(DS_IPT == 16 && DS_DPT == 8, "layout");
 
@@ -787,7 +788,10 @@ ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame
     // at most DS_CAP elements, each sorted in LDS like an ordinary segment (with the segment's key span), one after the other.  Only a single
     // bucket beyond the capacity is left: its own key span is measured (min / max of its keys) -- a run of EQUAL keys, which the second-level
     // table isolates, needs no pass at all -- otherwise the radix passes go through global memory for that bucket alone.  Reported to the host
-    // (which then prefers the LSD passes for a while) only when it really is slow: passes through global memory, or > 16 chunks of output.
+    // (which then prefers the LSD passes for a while) only when it really is slower than they are: passes through global memory, or more than
+    // DS_SLOW_CHUNKS chunks of output by this one workgroup -- measured (profiles/r06_depth_distribution_probe.json, 750 000 keys on 48 values =
+    // 15 600 ties per bucket): ~25 us per chunk of 4096, ds_segsort 92 us where the whole frame's LSD passes + scan take 84 us against this path's
+    // 31 us + the longest segment; break-even at ~2 chunks.
     const uint32_t nbk = d1 - d0;      // <= 2047
     for (uint32_t i = (uint32_t)tid; i < nbk; i += (uint32_t)SG_THREADS) s_bc[i] = cnt_total[d0 + i];
     __syncthreads();
@@ -817,7 +821,7 @@ ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame
             for (int k2 = 0; k2 < SG_WAVES; ++k2) { kmn = min(kmn, s_mm[0][k2]); kmx = max(kmx, s_mm[1][k2]); }
             const uint32_t sp = kmx - kmn + 1u;
             const int nb_g = sp <= 1u ? 0 : 32 - __clz((int)(sp - 1u));
-            if (slow_word && tid == 0 && (nb_g > 0 || n_g > 16u * (uint32_t)DS_CAP))
+            if (slow_word && tid == 0 && (nb_g > 0 || n_g > (uint32_t)DS_SLOW_CHUNKS * (uint32_t)DS_CAP))
                 __hip_atomic_store(slow_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             SegGlobal m{pairs0 + g_begin, pairs1 + g_begin, kmn};
             uint32_t (*cnt32)[DS_PASS_BINS] = reinterpret_cast<uint32_t (*)[DS_PASS_BINS]>(&s_key[0][0]);

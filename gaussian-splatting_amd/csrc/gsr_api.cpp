@@ -466,6 +466,7 @@ int gsr_profile_enable(int on) {
         if (g_counters_dev[d]) {
             const unsigned long long mode = trace ? 1ull : 0ull;
             (void)hipMemcpy(g_counters_dev[d] + GSR_TRACE_MODE_WORD, &mode, sizeof(mode), hipMemcpyHostToDevice);
+            (void)hipStreamSynchronize(nullptr);      // (null-stream work: finished before a kernel of a non-blocking stream reads the word)
         }
     }
     g_prof_on = (on & 1) != 0;
@@ -488,6 +489,7 @@ int gsr_profile_counters(uint64_t* out, int n, int reset) {
     unsigned long long host[GSR_COUNTER_COUNT] = {0};
     unsigned long long* ctr = counters_for_current_device();
     if (ctr) {
+        if (hipDeviceSynchronize() != hipSuccess) return fail(GSR_ERR_HIP, "counter read-back failed");      // (kernels of every stream have counted)
         if (hipMemcpy(host, ctr, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return fail(GSR_ERR_HIP, "counter read-back failed");
         if (reset) { (void)hipMemset(ctr, 0, sizeof(host)); (void)hipStreamSynchronize(nullptr); }
     }

@@ -41,6 +41,8 @@ def make_keys(rng, P, kind):
         k = base + rng.integers(0, 64, P) * 4099
     elif kind == "crowd":                     # 3/4 of the keys inside 48 consecutive values: one bucket far beyond the LDS segment
         k = np.where(rng.random(P) < 0.75, base + 777_000 + rng.integers(0, 48, P), base + rng.integers(0, 1 << 22, P))
+    elif kind == "crowd_16":                  # 3/4 of the keys on 16 values: buckets of equal keys several LDS capacities long
+        k = np.where(rng.random(P) < 0.75, base + 777_000 + rng.integers(0, 16, P), base + rng.integers(0, 1 << 22, P))
     elif kind == "gap":
         k = np.where(rng.random(P) < 0.5, base + rng.integers(0, 4096, P), base + (1 << 25) + rng.integers(0, 1 << 12, P))
     elif kind == "one_key":
@@ -63,7 +65,7 @@ def make_keys(rng, P, kind):
 
 
 @pytest.mark.parametrize("kind,P", [("uniform", 20_000), ("uniform", 4_097), ("uniform", 300), ("ties", 12_000), ("crowd", 16_000), ("gap", 9_000), ("one_key", 5_000),
-                                    ("outliers", 24_000), ("heavy_tails", 40_000), ("wall", 40_000), ("wall_thin", 40_000), ("crowd", 400_000), ("one_key", 80_000)])
+                                    ("outliers", 24_000), ("heavy_tails", 40_000), ("wall", 40_000), ("wall_thin", 40_000), ("crowd", 400_000), ("crowd_16", 400_000), ("one_key", 80_000)])
 def test_bucket_depth_sort_on_the_cpu_equals_a_stable_sort(lib, kind, P):
     rng = np.random.default_rng(1000 + P + len(kind))
     keys = make_keys(rng, P, kind)
@@ -119,7 +121,10 @@ def test_bucket_depth_sort_on_the_cpu_equals_a_stable_sort(lib, kind, P):
     if kind == "crowd" and P > 100_000:
         # 300 000 keys on 48 values = 6 250 equal keys per bucket: oversized segments remain, but of ONE key each -- no pass, only the chunked output
         assert int(slow[0]) == 0, "a bucket of a few thousand equal keys takes the chunked output path and is NOT reported as slow"
+    elif kind == "crowd_16":
+        # 300 000 keys on 16 values = 18 750 equal keys per bucket: more than three LDS capacities for ONE workgroup each -- slower than the LSD passes
+        assert int(slow[0]) != 0, "buckets of > 3 capacities of equal keys are reported (the host prefers the LSD passes for a while)"
     elif kind == "one_key" and P > 16 * 4096:
-        assert int(slow[0]) != 0, "one bucket of 70 000 equal keys is > 16 chunks for one workgroup: reported"
+        assert int(slow[0]) != 0, "one bucket of 70 000 equal keys is > 3 chunks for one workgroup: reported"
     elif kind == "uniform":
         assert int(slow[0]) == 0
