@@ -27,8 +27,10 @@
 //               emission -- everything the depth sort's last pass and the two scan kernels used to produce.
 //               A segment beyond the LDS capacity (it ends with a bucket of more than 2048 keys) is cut into groups of whole buckets
 //               that fit and sorted group by group; a SINGLE bucket beyond the capacity -- after both levels of the equalised table:
-//               thousands of equal depths -- needs no pass when all its keys are equal, else goes through global memory; that, or more than
-//               three capacities of equal keys in one bucket, is reported to the host, which prefers the LSD sort for a while (gsr_api.cpp).
+//               thousands of equal depths -- that the table knows to hold ONE key value is written out by as many workgroups as it has
+//               chunks (the workgroups of the windows it covers, which own no bucket); otherwise its key span is measured: equal keys need
+//               no pass, anything else goes through global memory.  That, or more than three capacities of equal keys the table did not
+//               know about, is reported to the host, which prefers the LSD sort for a while (gsr_api.cpp).
 //
 // Order: (key, Gaussian index) ascending -- ds_scatter is stable and the segment sort is stable, so equal depths keep index
 // order exactly as the LSD sort (and the reference's stable 64-bit-key sort) leaves them.  No atomics on global memory, no
@@ -49,7 +51,7 @@ constexpr int DS_DPT = DS_NB / DS_THREADS;             // 8 buckets per thread
 constexpr int DS_SEG = GSR_DS_SEG;
 constexpr int DS_CAP = GSR_DS_CAP;
 constexpr int DS_PASS_BITS = 9;
-constexpr int DS_SLOW_CHUNKS = 3;                      // a single bucket of equal keys beyond this many LDS capacities is reported (ds_segsort)
+constexpr int DS_SLOW_CHUNKS = 3;                      // a single bucket of equal keys beyond this many LDS capacities that the TABLE does not know to be one key value is reported (ds_segsort)
 constexpr int DS_PASS_BINS = 1 << DS_PASS_BITS;
 static_assert(DS_IPT == 16 && DS_DPT == 8, "layout");
 
@@ -389,8 +391,10 @@ __device__ __forceinline__ uint32_t ds_block_excl_scan(const uint32_t (&v)[DPT],
     return wbase + incl - tsum;
 }
 
-// plan entry of segment s (8 words): begin, end (elements of the bucket-ordered array), first bucket, end bucket, tile
-// instances in front of the segment, number of listed Gaussians, smallest key the segment's buckets can hold, one past the largest
+// plan entry of window s (GSR_DS_PLAN_WORDS = 12 words): begin, end (elements of the bucket-ordered array), first bucket, end bucket (bit 31: the last
+// bucket is more than a capacity of one key value, its chunks behind the first are written by helpers), tile instances in front of the segment, number of
+// listed Gaussians, smallest key the segment's buckets can hold, one past the largest; helper job of the window's workgroup: first element of the chunk
+// (GSR_DS_NO_HELP: none), its length | its bucket << 16, first element of that bucket, tile instances in front of that bucket
 __global__ void __launch_bounds__(S3_THREADS)
 ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint16_t* __restrict__ bucket_of, const uint32_t* __restrict__ frame, const uint32_t* __restrict__ eq_tab,
            const uint32_t* __restrict__ cnt_tab, const uint32_t* __restrict__ cnt_total, const uint32_t* __restrict__ tile_total,
@@ -445,22 +449,50 @@ ds_scatter(int P, int nblocks, const uint32_t* __restrict__ keys, const uint16_t
             }
             return lo;
         };
+        // bucket d holds ONE key value (by the table: the keys that map to it are [first key of d, first key of d + 1) inside the frame's range)
+        auto one_key_bucket = [&](uint32_t d) {
+            const uint32_t lo = max(tmin, ds_bucket_first_key(d, eqv));
+            const uint32_t hi = d + 1u >= used ? tmax + 1u : min(tmax + 1u, ds_bucket_first_key(d + 1u, eqv));
+            return hi <= lo + 1u;
+        };
         for (int s = tid; s < nseg_cap; s += S3_THREADS) {
             uint4 e = make_uint4(0u, 0u, 0u, 0u);
+            uint4 h = make_uint4(GSR_DS_NO_HELP, 0u, 0u, 0u);
             uint32_t tb = 0, key_lo = 0, key_hi = 0;
             const uint64_t x0 = (uint64_t)s * DS_SEG;
             if (x0 < listed) {
                 const uint32_t d0 = lower_bound((uint32_t)x0);
                 const uint64_t x1 = x0 + DS_SEG;
-                const uint32_t d1 = x1 >= listed ? DS_CULL : lower_bound((uint32_t)x1);
+                uint32_t d1 = x1 >= listed ? DS_CULL : lower_bound((uint32_t)x1);
                 e = make_uint4(cnt_excl[d0], cnt_excl[d1], d0, d1);
                 tb = tile_excl[d0];
                 // the keys of buckets [d0, d1): [first key of d0, first key of d1), inside the frame's true range (keys < 2^27: no overflow)
                 key_lo = max(tmin, ds_bucket_first_key(d0, eqv));
                 key_hi = d1 >= used ? tmax + 1u : min(tmax + 1u, ds_bucket_first_key(d1, eqv));
+                if (e.y > e.x) {
+                    // the segment's last bucket (the one that holds its last element; a bucket beyond the LDS capacity is always the last: the next one
+                    // starts outside the window).  More than a capacity of ONE key value: the owner writes its first chunk, the workgroups of the
+                    // windows the bucket covers write the others (below) -- flagged in bit 31 of the end bucket
+                    const uint32_t dl = lower_bound(e.y) - 1u;
+                    if (e.y - cnt_excl[dl] > (uint32_t)DS_CAP && one_key_bucket(dl)) e.w = d1 | GSR_DS_TIE_HELPED;
+                }
             }
-            reinterpret_cast<uint4*>(plan)[2 * s] = e;
-            reinterpret_cast<uint4*>(plan)[2 * s + 1] = make_uint4(tb, listed, key_lo, key_hi);
+            // HELPER JOB of window s (whether it owns a segment or not): chunk c >= 1 of a bucket of more than a capacity of one key value goes to the
+            // first window that starts at or behind the chunk.  Such a bucket began more than a window in front of the chunk, so it is the bucket that holds the
+            // element at the start of the PREVIOUS window.
+            if (s >= 1 && x0 - DS_SEG < listed) {
+                const uint32_t p = (uint32_t)(x0 - DS_SEG);
+                const uint32_t dc = lower_bound(p + 1u) - 1u;      // (cnt_excl[0] = 0 <= p: at least 1)
+                const uint32_t bb = cnt_excl[dc], be = cnt_excl[dc + 1u];
+                if (be - bb > (uint32_t)DS_CAP && p < be) {
+                    const uint32_t c = ((uint32_t)x0 - bb) / (uint32_t)DS_CAP, cs = bb + c * (uint32_t)DS_CAP;
+                    if (c >= 1u && (uint64_t)cs + DS_SEG > x0 && cs < be && one_key_bucket(dc))
+                        h = make_uint4(cs, min((uint32_t)DS_CAP, be - cs) | (dc << 16), bb, tile_excl[dc]);
+                }
+            }
+            reinterpret_cast<uint4*>(plan)[3 * s] = e;
+            reinterpret_cast<uint4*>(plan)[3 * s + 1] = make_uint4(tb, listed, key_lo, key_hi);
+            reinterpret_cast<uint4*>(plan)[3 * s + 2] = h;
         }
         return;
     }
@@ -752,7 +784,8 @@ __device__ __forceinline__ uint32_t seg_sort_in_lds(const SegLdsMem& L, const ui
 }
 
 __global__ void __launch_bounds__(SG_THREADS)
-ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame, const uint32_t* __restrict__ cnt_total, uint2* pairs0, uint2* pairs1,
+ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame, const uint32_t* __restrict__ cnt_total, const uint32_t* __restrict__ cnt_tab,
+           const uint32_t* __restrict__ tile_tab, int nblocks, uint2* pairs0, uint2* pairs1,
            const uint2* __restrict__ rect, uint32_t* __restrict__ order, uint2* __restrict__ rect_sorted, uint32_t* __restrict__ offsets,
            uint2* __restrict__ block_first, uint32_t bf_cap, uint32_t* slow_word /*mapped host word or NULL*/) {
     __shared__ uint32_t s_key[2][DS_CAP];                       // 32 KB (a bucket beyond the LDS capacity: the 32-bit count table instead)
@@ -764,13 +797,64 @@ ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame
     __shared__ uint32_t s_mm[2][SG_WAVES];
     static_assert(sizeof(uint32_t) * SG_WAVES * DS_PASS_BINS <= sizeof(uint32_t) * 2 * DS_CAP, "count table of the oversized path");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint4 e = reinterpret_cast<const uint4*>(plan)[2 * blockIdx.x];
-    const uint32_t begin = e.x, end = e.y, d0 = e.z, d1 = e.w;
-    if (end <= begin) return;
-    const uint4 e2 = reinterpret_cast<const uint4*>(plan)[2 * blockIdx.x + 1];
+    const uint4 e = reinterpret_cast<const uint4*>(plan)[3 * blockIdx.x];
+    const uint4 e2 = reinterpret_cast<const uint4*>(plan)[3 * blockIdx.x + 1];
+    const uint4 e3 = reinterpret_cast<const uint4*>(plan)[3 * blockIdx.x + 2];
+    const uint32_t begin = e.x, end = e.y, d0 = e.z, d1 = e.w & ~GSR_DS_TIE_HELPED;
+    const bool tie_helped = (e.w & GSR_DS_TIE_HELPED) != 0u;
     const uint32_t tile_base = e2.x, listed = e2.y;
-    const uint32_t n = end - begin;
     const bool r_ok = frame[1] == 0u && (int32_t)frame[0] >= 0;      // R < 2^31 (else the host refuses the frame: no table writes)
+    if (e3.x != GSR_DS_NO_HELP) {
+        // ---- helper job (round 6): chunk [cs, cs + len) of a bucket of EQUAL keys that is longer than the LDS capacity.  Equal keys are already in their
+        // final order (ds_scatter is stable): only the output is left, and its tile scan starts at the bucket's tile base + the tile counts of the bucket's
+        // elements in front of the chunk.  Those are whole contributions of ds_hist's workgroups -- the [workgroup][bucket] tables hold their sizes (scanned by
+        // ds_scan: cnt_tab[b][d] = elements of bucket d from workgroups < b) and tile sums -- plus a part of ONE workgroup's, at most 4096 elements, which are
+        // added up from their rectangles.  Constant time whatever the bucket's length (first version: every helper summed ALL elements in front of its
+        // chunk, ~5 us per 4096: a bucket of 60 000 took 73 us).
+        const uint32_t cs = e3.x, len = e3.y & 0xFFFFu, dbk = e3.y >> 16, bb = e3.z, front = cs - bb;
+        if (tid == 0) s_mm[1][0] = front;      // start (inside the bucket) of the workgroup contribution the chunk start cuts; `front`: it cuts none
+        __syncthreads();
+        uint32_t tsum = 0;
+#pragma unroll 1
+        for (int b0 = 0; b0 < nblocks; b0 += SG_THREADS) {
+            const int b = min(b0 + tid, nblocks - 1);
+            const uint32_t c0 = cnt_tab[(int64_t)b * DS_NB + dbk], tt = tile_tab[(int64_t)b * DS_NB + dbk];
+            const uint32_t cn = cnt_tab[(int64_t)min(b + 1, nblocks - 1) * DS_NB + dbk], ct = cnt_total[dbk];
+            const uint32_t c1 = b + 1 < nblocks ? cn : ct;
+            const bool valid = b0 + tid < nblocks, whole = valid && c1 <= front;      // (selects, not branches: a load under a branch is waited for alone)
+            tsum += whole ? tt : 0u;
+            if (valid && !whole && c0 < front) s_mm[1][0] = c0;      // (exactly one workgroup's contribution straddles the chunk start)
+        }
+        __syncthreads();
+        {
+            const uint32_t p0 = s_mm[1][0], part = front - p0;      // <= 4096 elements [bb + p0, bb + front)
+            uint32_t idv[SG_OUT];
+#pragma unroll
+            for (int j = 0; j < SG_OUT; ++j) idv[j] = pairs0[bb + p0 + min((uint32_t)j * SG_THREADS + (uint32_t)tid, part ? part - 1u : 0u)].y;
+            uint2 rv[SG_OUT];
+#pragma unroll
+            for (int j = 0; j < SG_OUT; ++j) rv[j] = rect[idv[j]];
+#pragma unroll
+            for (int j = 0; j < SG_OUT; ++j) tsum += (uint32_t)j * SG_THREADS + (uint32_t)tid < part ? rect_area(rv[j]) : 0u;
+        }
+        tsum = wave_incl_scan_u32(tsum, lane);
+        if (lane == 63) s_mm[0][w] = tsum;
+        __syncthreads();
+        uint32_t tfront = 0;
+#pragma unroll
+        for (int k2 = 0; k2 < SG_WAVES; ++k2) tfront += s_mm[0][k2];
+        uint32_t id[SG_OUT];
+#pragma unroll
+        for (int j = 0; j < SG_OUT; ++j) {
+            const uint32_t p = (uint32_t)j * SG_THREADS + (uint32_t)tid;
+            const uint32_t v = pairs0[cs + (p < len ? p : 0u)].y;
+            id[j] = p < len ? v : 0u;
+        }
+        seg_output(id, len, cs, e3.w + tfront, rect, order, rect_sorted, offsets, block_first, bf_cap, listed - 1u, r_ok, s_wt);
+        __syncthreads();
+    }
+    if (end <= begin) return;
+    const uint32_t n = end - begin;
     // keys of the segment lie in [base_key, top_key): the key span of its buckets under the equalised mapping (the plan workgroup of
     // ds_scatter inverted the table)
     const uint32_t base_key = e2.z, top_key = e2.w;
@@ -793,16 +877,45 @@ ds_segsort(const uint32_t* __restrict__ plan, const uint32_t* __restrict__ frame
     // 15 600 ties per bucket): ~25 us per chunk of 4096, ds_segsort 92 us where the whole frame's LSD passes + scan take 84 us against this path's
     // 31 us + the longest segment; break-even at ~2 chunks.
     const uint32_t nbk = d1 - d0;      // <= 2047
-    for (uint32_t i = (uint32_t)tid; i < nbk; i += (uint32_t)SG_THREADS) s_bc[i] = cnt_total[d0 + i];
+    {   // s_bc[i] = elements of the segment's buckets 0 .. i (inclusive prefix of the bucket sizes; thread t owns entries 4t .. 4t+3).  The groups are
+        // found by binary search in it: walking the sizes one by one was a chain of one LDS round trip per bucket, and the segment in front of a
+        // crowd holds hundreds of (empty) buckets -- the crowd frame of tools/gpu_depth_distribution_probe.py spent 40 of its 69 us there
+        static_assert(DS_NB == 4 * SG_THREADS, "four bucket sizes per thread");
+        uint32_t c4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t b = 4u * (uint32_t)tid + (uint32_t)i;
+            c4[i] = cnt_total[min(d0 + b, (uint32_t)DS_NB - 1u)];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4u * (uint32_t)tid + (uint32_t)i >= nbk) c4[i] = 0u;
+        uint32_t run = seg_excl_scan(c4[0] + c4[1] + c4[2] + c4[3], wsum, lane, w);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { run += c4[i]; s_bc[4 * tid + i] = run; }
+    }
     __syncthreads();
     uint32_t g_begin = begin, g_d = 0, tb = tile_base;
 #pragma unroll 1
-    while (g_d < nbk) {      // (every thread walks the same bucket sizes: workgroup-uniform control flow)
-        uint32_t n_g = s_bc[g_d], g_e = g_d + 1u;
-        while (g_e < nbk && n_g + s_bc[g_e] <= (uint32_t)DS_CAP) n_g += s_bc[g_e++];
+    while (g_d < nbk) {      // (every thread does the same searches: workgroup-uniform control flow)
+        // the group: buckets [g_d, g_e) with g_e the largest end whose elements fit the capacity -- at least one bucket
+        const uint32_t before = g_d ? s_bc[g_d - 1u] : 0u;
+        uint32_t lo = g_d + 1u, hi = nbk;      // largest e in [g_d + 1, nbk] with s_bc[e - 1] - before <= DS_CAP (or g_d + 1)
+#pragma unroll 1
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1u) >> 1;
+            if (s_bc[mid - 1u] - before <= (uint32_t)DS_CAP) lo = mid; else hi = mid - 1u;
+        }
+        const uint32_t g_e = lo, n_g = s_bc[g_e - 1u] - before;
         if (n_g != 0u && n_g <= (uint32_t)DS_CAP) {
             tb += seg_sort_in_lds(L, pairs0, g_begin, n_g, base_key, nbits, tb, rect, order, rect_sorted, offsets, block_first, bf_cap, last_listed, r_ok);
             __syncthreads();
+        } else if (n_g != 0u && tie_helped) {
+            // one bucket of n_g > DS_CAP keys, ONE key value by the table: its first chunk here, the others by the helpers (above); nothing behind it
+            uint32_t id[SG_OUT];
+#pragma unroll
+            for (int j = 0; j < SG_OUT; ++j) id[j] = pairs0[g_begin + (uint32_t)j * SG_THREADS + (uint32_t)tid].y;
+            seg_output(id, (uint32_t)DS_CAP, g_begin, tb, rect, order, rect_sorted, offsets, block_first, bf_cap, last_listed, r_ok, s_wt);
         } else if (n_g != 0u) {
             // one bucket of n_g > DS_CAP keys: its true key span
             uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
@@ -864,6 +977,6 @@ void gsr_launch_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* t
     hipLaunchKernelGGL(ds_scan, dim3(DS_NB / 16), dim3(DS_THREADS), 0, st, nblocks, b.cnt_tab, b.tile_tab, b.cnt_total, b.tile_total);
     hipLaunchKernelGGL(ds_scatter, dim3(nblocks + 1), dim3(S3_THREADS), 0, st, P, nblocks, keys, b.bucket_of, frame, b.eq_tab, b.cnt_tab, b.cnt_total,
                        b.tile_total, b.pairs[0], order, offsets, rect_sorted, b.plan, nseg_cap);
-    hipLaunchKernelGGL(ds_segsort, dim3(nseg_cap), dim3(SG_THREADS), 0, st, b.plan, frame, b.cnt_total, b.pairs[0], b.pairs[1], rect, order,
+    hipLaunchKernelGGL(ds_segsort, dim3(nseg_cap), dim3(SG_THREADS), 0, st, b.plan, frame, b.cnt_total, b.cnt_tab, b.tile_tab, nblocks, b.pairs[0], b.pairs[1], rect, order,
                        rect_sorted, offsets, block_first, block_first_cap, slow_word);
 }

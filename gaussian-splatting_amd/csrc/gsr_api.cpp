@@ -309,7 +309,7 @@ GsrGeom gsr_carve_geom(char* base, int P) {
         g.ds.tile_tab = (uint32_t*)take(nblk * GSR_DS_BUCKETS * 4);
         g.ds.cnt_total = (uint32_t*)take(GSR_DS_BUCKETS * 4);
         g.ds.tile_total = (uint32_t*)take(GSR_DS_BUCKETS * 4);
-        g.ds.plan = (uint32_t*)take(nseg * 32);
+        g.ds.plan = (uint32_t*)take(nseg * GSR_DS_PLAN_WORDS * 4);
         g.ds.eq_tab = (uint32_t*)take((size_t)GSR_EQ_TAB_WORDS * 4);
         g.ds.bucket_of = (uint16_t*)take((np + 64) * 2);
     }

@@ -53,13 +53,16 @@ static inline size_t gsr_block_first_cap(int P) { return (size_t)(P > 0 ? P : 1)
 #define GSR_EQ_NO_HOT 0xFFFFFFFFu
 // table buffer (ds_hist -> ds_scatter): GSR_EQ_BINS words level 1, GSR_EQ_BINS words level 2, then the hot bin (GSR_EQ_NO_HOT: no second level)
 #define GSR_EQ_TAB_WORDS (2 * GSR_EQ_BINS + 16)
+#define GSR_DS_PLAN_WORDS 12           // words per window of the segment plan (depthsort.hip ds_scatter)
+#define GSR_DS_NO_HELP 0xFFFFFFFFu     // plan word 8: the window's workgroup has no helper job
+#define GSR_DS_TIE_HELPED 0x80000000u  // plan word 3, bit 31: the segment's last bucket is more than a capacity of one key value; helpers write its chunks behind the first
 struct GsrDepthSortBufs {
     uint2* pairs[2];             // [P] (key, id) in bucket order / scratch of an oversized segment
     uint32_t* cnt_tab;           // [workgroups][2048] keys per bucket, then their exclusive prefix over the workgroups
     uint32_t* tile_tab;          // [workgroups][2048] tile instances per bucket
     uint32_t* cnt_total;         // [2048]
     uint32_t* tile_total;        // [2048]
-    uint32_t* plan;              // [segments][8]
+    uint32_t* plan;              // [segments][GSR_DS_PLAN_WORDS]
     uint16_t* bucket_of;         // [P] the depth bucket of every key (written by ds_hist, read by ds_scatter: the table lookup is done once)
     uint32_t* eq_tab;            // [GSR_EQ_TAB_WORDS] first bucket | buckets << 16 per coarse bin, the same per sub-bin of the hot coarse bin, the hot bin (ds_hist's workgroup 0)
 };

@@ -9,6 +9,8 @@ hard in round 5, frozen as fixtures so that `pytest -m gpu` (and the kernel sour
  (seed 53, frame 137)  1524 needles, 31x257     } max |grad| from its own fp64 evaluation
  (seed 71, frame 32)   48 needles, cov3D_precomp call form (adjudicated by fp64 in round 5)
  (seed 71, frame 78)   1494 extreme needles (condition numbers >= 1e5), 480x270: finite gradients; a sign flip of the exponent
+ (seed 101, frame 172) 1670 needles: round 6's worst kernel-vs-fp64 distance on the final binaries (rotations 6.1e-3 where the fp32 oracle is 3.6e-2)
+ (seed 202, frame 263) 134 needles: scales 2.1e-3 from fp64 where the fp32 oracle is 3.6e-3 (the closest the two came in 1 100 frames)
 
 Per frame the file holds the INPUTS of the operator call (settings record, every tensor of the call form, the loss weights) and the
 EXPECTED outputs: radii, and the gradient of the frame's loss with respect to every input from the oracle's autograd evaluated in
@@ -26,7 +28,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import fuzz_frames as F  # noqa: E402
 
-FRAMES = [(71, 109), (53, 92), (53, 137), (71, 32), (71, 78)]
+FRAMES = [(71, 109), (53, 92), (53, 137), (71, 32), (71, 78), (101, 172), (202, 263)]
 SETTINGS_FIELDS = ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix", "sh_degree",
                    "campos", "prefiltered", "debug", "antialiasing")
 

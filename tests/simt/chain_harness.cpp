@@ -31,7 +31,7 @@ int64_t simt_bin(int P, int gx, int gy, const uint32_t* keys, const uint32_t* ti
     const int n_tiles = gx * gy;
     const size_t nblocks = gsr_depth_bucket_blocks(P), nseg = gsr_depth_bucket_segments(P);
     std::vector<uint2> pairs0((size_t)P + 16), pairs1((size_t)P + 16), rect_sorted((size_t)P + 16);
-    std::vector<uint32_t> cnt_tab(nblocks * GSR_DS_BUCKETS), tile_tab(nblocks * GSR_DS_BUCKETS), cnt_total(GSR_DS_BUCKETS), tile_total(GSR_DS_BUCKETS), plan(nseg * 8 + 8),
+    std::vector<uint32_t> cnt_tab(nblocks * GSR_DS_BUCKETS), tile_tab(nblocks * GSR_DS_BUCKETS), cnt_total(GSR_DS_BUCKETS), tile_total(GSR_DS_BUCKETS), plan(nseg * GSR_DS_PLAN_WORDS + 16),
         offsets((size_t)P + 16), frame(64, 0u);
     const uint32_t bf_cap = (uint32_t)gsr_block_first_cap(P);
     const int64_t nblk = ((int64_t)R + GSR_TS_ITEMS - 1) / GSR_TS_ITEMS;

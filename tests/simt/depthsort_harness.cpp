@@ -18,7 +18,7 @@ int simt_depth_bucket_sort(int P, const uint32_t* keys, const uint32_t* tiles, c
                            uint32_t* order, uint2* rect_sorted, uint32_t* offsets, uint2* block_first, uint32_t bf_cap, uint32_t* slow_word) {
     const size_t nblocks = gsr_depth_bucket_blocks(P), nseg = gsr_depth_bucket_segments(P);
     std::vector<uint2> pairs0((size_t)P + 16), pairs1((size_t)P + 16);
-    std::vector<uint32_t> cnt_tab(nblocks * DS_NB), tile_tab(nblocks * DS_NB), cnt_total(DS_NB), tile_total(DS_NB), plan(nseg * 8 + 8);
+    std::vector<uint32_t> cnt_tab(nblocks * DS_NB), tile_tab(nblocks * DS_NB), cnt_total(DS_NB), tile_total(DS_NB), plan(nseg * GSR_DS_PLAN_WORDS + 16);
     std::vector<uint32_t> eq_tab(GSR_EQ_TAB_WORDS);
     GsrDepthSortBufs b;
     b.pairs[0] = pairs0.data(); b.pairs[1] = pairs1.data();

@@ -55,7 +55,7 @@ int64_t simt_forward(const GsrRasterSettings* s, int snug, int P, int M, const f
     std::vector<uint2> rect(n), rect_sorted(n), wg_range(GSR_FRAME_MAX_GROUPS + 1), pairs0(n), pairs1(n);
     std::vector<uint32_t> tiles(n), keys0(n), keys1(n), vals0(n), vals1(n), offsets(n), frame(64, 0u), state(16, 0u);
     const size_t nblocks = gsr_depth_bucket_blocks(P), nseg = gsr_depth_bucket_segments(P);
-    std::vector<uint32_t> cnt_tab(nblocks * GSR_DS_BUCKETS), tile_tab(nblocks * GSR_DS_BUCKETS), cnt_total(GSR_DS_BUCKETS), tile_total(GSR_DS_BUCKETS), plan(nseg * 8 + 8);
+    std::vector<uint32_t> cnt_tab(nblocks * GSR_DS_BUCKETS), tile_tab(nblocks * GSR_DS_BUCKETS), cnt_total(GSR_DS_BUCKETS), tile_total(GSR_DS_BUCKETS), plan(nseg * GSR_DS_PLAN_WORDS + 16);
     GsrGeom g{};
     g.splats = splats.data(); g.rect = rect.data(); g.tiles = tiles.data(); g.clamped = nullptr;
     g.keys[0] = keys0.data(); g.keys[1] = keys1.data(); g.vals[0] = vals0.data(); g.vals[1] = vals1.data();
@@ -201,7 +201,7 @@ int64_t simt_forward_sharded(const GsrRasterSettings* s, int snug, int G, const 
             std::vector<uint2> rect(n), rect_sorted(n), wg_range(GSR_FRAME_MAX_GROUPS + 1), pairs0(n), pairs1(n);
             std::vector<uint32_t> tiles(n), keys0(n), keys1(n), vals0(n), vals1(n), offsets(n), frame(64, 0u), state(16, 0u);
             const size_t nblocks = gsr_depth_bucket_blocks(Pb), nseg = gsr_depth_bucket_segments(Pb);
-            std::vector<uint32_t> cnt_tab(nblocks * GSR_DS_BUCKETS), tile_tab(nblocks * GSR_DS_BUCKETS), cnt_total(GSR_DS_BUCKETS), tile_total(GSR_DS_BUCKETS), plan(nseg * 8 + 8);
+            std::vector<uint32_t> cnt_tab(nblocks * GSR_DS_BUCKETS), tile_tab(nblocks * GSR_DS_BUCKETS), cnt_total(GSR_DS_BUCKETS), tile_total(GSR_DS_BUCKETS), plan(nseg * GSR_DS_PLAN_WORDS + 16);
             GsrDepthSortBufs ds;
             ds.pairs[0] = pairs0.data(); ds.pairs[1] = pairs1.data(); ds.cnt_tab = cnt_tab.data(); ds.tile_tab = tile_tab.data();
             ds.cnt_total = cnt_total.data(); ds.tile_total = tile_total.data(); ds.plan = plan.data();

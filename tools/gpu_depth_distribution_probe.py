@@ -26,7 +26,8 @@ def main():
     W, H, P = 1920, 1080, 1_000_000
     cam = make_camera(W, H)
     out = {"lib": os.environ.get("GSR_LIB", "product")}
-    for case in ("uniform", "outliers_24", "heavy_tails", "wall", "crowd"):
+    cases = tuple(os.environ.get("PROBE_CASES", "uniform,outliers_24,heavy_tails,wall,crowd").split(","))      # (PROBE_CASES=crowd under rocprofv3: that frame's kernels)
+    for case in cases:
         sc = make_scene(P, cam, seed=0, s_med=0.012)
         g = torch.Generator().manual_seed(5)
 
@@ -45,7 +46,7 @@ def main():
             rescale(idx, (6.0 + 0.009 * torch.randn(idx.numel(), generator=g)) / sc.means3D[idx, 2])
         elif case == "crowd":
             idx = torch.nonzero(torch.rand(P, generator=g) < 0.75).reshape(-1)
-            z = (torch.tensor(5.0).view(torch.int32) + torch.randint(0, 48, (idx.numel(),), generator=g, dtype=torch.int32)).view(torch.float32)
+            z = (torch.tensor(5.0).view(torch.int32) + torch.randint(0, int(os.environ.get("PROBE_CROWD_VALUES", "48")), (idx.numel(),), generator=g, dtype=torch.int32)).view(torch.float32)
             rescale(idx, z / sc.means3D[idx, 2])
         d = sc.to(dev)
         camd = cam.to(dev)
