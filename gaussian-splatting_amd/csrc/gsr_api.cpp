@@ -233,9 +233,11 @@ int lease_host_word(HostWordLease& lease, hipStream_t st) {
         }
     }
     lease.hw.host[3] = 0;
-    volatile uint32_t* slow = g_slow_word[dev_id];
-    if (slow[0]) {               // a recent frame on this device: thousands of Gaussians in one depth bucket -- its segment went
-        slow[0] = 0;             // through global memory.  Stay with the LSD passes for a while, then try again: 64 frames the first
+    uint32_t* slow = g_slow_word[dev_id];
+    // (read and cleared in ONE step: two concurrent callers never both see the same report and double the stay twice -- ADVICE r05)
+    if (__atomic_load_n(slow, __ATOMIC_RELAXED) && __atomic_exchange_n(slow, 0u, __ATOMIC_RELAXED)) {
+                                 // a recent frame on this device: thousands of Gaussians in one depth bucket -- its segment went
+                                 // through global memory.  Stay with the LSD passes for a while, then try again: 64 frames the first
         int back = g_lsd_backoff[dev_id].load();      // time, twice as long after every retry that met an oversized segment again
         if (back < 64) back = 64;                     // (a scene that always crowds a bucket pays one slow frame in 65, 129, ... 8193)
         g_lsd_frames[dev_id].store(back);
