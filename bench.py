@@ -170,6 +170,9 @@ def _run(a):
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # Measurement hook (never set by the driver): GSR_BENCH_PAD_MB=n keeps an n-MiB allocation alive from the start -- every later allocation moves
+    # (round 6: does a leg's rate depend on WHERE the allocator puts its arrays?  tools/gpu_bench_pad_sweep.sh)
+    _pad = torch.empty(max(1, int(float(os.environ.get("GSR_BENCH_PAD_MB", "0")) * (1 << 20))), dtype=torch.uint8, device=dev) if os.environ.get("GSR_BENCH_PAD_MB") else None
     if world > 1:
         import datetime
         tmo = datetime.timedelta(seconds=int(os.environ.get("GSR_BENCH_TIMEOUT_S", "180")))      # a hung collective must not eat the driver's slot

@@ -8,7 +8,7 @@
 //
 //   ds_hist     per workgroup of 4096 keys: histogram over 2048 depth buckets of (a) the keys, (b) their tile counts.
 //               The bucket of a key comes from a HISTOGRAM-EQUALISED table (round 6): the key space is cut into 1024 coarse bins
-//               (64 per octave of depth); every workgroup histograms the same 4096 sample keys (64 windows of 64 keys spread over
+//               (64 per octave of depth); every workgroup histograms the same 4096 sample keys (256 windows of 16 keys spread over
 //               the array) over them; every coarse bin inside the frame's true key range gets one bucket and
 //               the rest of the 2046 usable ones are handed out in proportion to the sampled mass; inside a coarse bin the buckets
 //               are uniform.  Buckets then hold about P / 2046 keys whatever the depth distribution is -- floaters 100x behind the
@@ -117,8 +117,8 @@ __device__ __forceinline__ void load4(const uint32_t* __restrict__ p, int64_t e0
 
 // ---- D1 ------------------------------------------------------------------------------------------------------------
 // Every workgroup first reduces the per-workgroup key ranges the key-producing kernel left (gsr_frame.h; <= 2047 entries of
-// 8 bytes) to the frame's true key range and histograms the SAME 4096 sample keys (64 windows spread over the array: sixteen
-// coalesced loads per thread in the shadow of its own key loads) into the equalised bucket tables -- the same integers in every
+// 8 bytes) to the frame's true key range and histograms the SAME 4096 sample keys (256 windows spread over the array: sixteen
+// loads per thread in the shadow of its own key loads) into the equalised bucket tables -- the same integers in every
 // workgroup; workgroup 0 stores range and tables for the kernels that follow.
 __global__ void __launch_bounds__(DS_THREADS)
 ds_hist(int P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tiles, uint32_t* __restrict__ frame,

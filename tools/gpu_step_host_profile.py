@@ -99,4 +99,28 @@ for _ in range(100):
     step()
     torch.cuda.synchronize()
 out["sync_ms_per_step"] = round((time.perf_counter() - t0) / 100 * 1e3, 4)
+# Does the optimizer phase depend on where the allocator puts things?  (round 6: the same Adam kernel at 257 and at 298 us)  A dummy allocation of `pad` bytes
+# is made BEFORE the allocator's cache is dropped and the step re-allocates its scratch and gradients; 100 steps each, GPU time of the phases from events.
+if os.environ.get("PERTURB", "1") == "1":
+    out["gpu_ms_by_allocation_perturbation"] = {}
+    for pad in (0, 1 << 20, 7 << 20, 33 << 20, 129 << 20, 0):
+        torch.cuda.synchronize()
+        dummy = None
+        torch.cuda.empty_cache()
+        dummy = torch.empty(max(pad, 1), dtype=torch.uint8, device=dev)
+        for _ in range(20):
+            step()
+        marks = []
+        for _ in range(100):
+            step(None, marks)
+        torch.cuda.synchronize()
+        ph = {}
+        for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+            key = n1 if n1 != "start" else "between"
+            ph[key] = ph.get(key, 0.0) + e0.elapsed_time(e1)
+        g = [t.grad.data_ptr() % (1 << 21) for t in params]
+        out["gpu_ms_by_allocation_perturbation"][f"{pad >> 20} MiB #{len(out['gpu_ms_by_allocation_perturbation'])}"] = {
+            "optimizer": round(ph["optimizer"] / 100, 4), "backward": round(ph["backward"] / 100, 4), "forward": round(ph["forward"] / 100, 4),
+            "total": round(sum(ph.values()) / 100, 4), "grad_ptr_mod_2MiB": g, "sh_grad_ptr": hex(params[1].grad.data_ptr())}
+        del dummy
 print(json.dumps(out))
