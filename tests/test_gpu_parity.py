@@ -905,3 +905,20 @@ def test_wave_trace_of_the_blend_launches_accounts_for_every_step():
         assert int((t[:, 3] & np.uint64(0xFFFF)).sum()) == total, (kernel, int((t[:, 3] & np.uint64(0xFFFF)).sum()), total)
         tl = wave_timeline(tr, kernel)
         assert tl["waves"] == len(t) and tl["span_us"] > 0 and -0.5 < tl["tail_loss"] < 2.0
+
+
+def test_first_frames_of_concurrent_callers_in_fresh_processes():
+    """The moment the library creates one control block per concurrent caller (gsr_api.cpp lease_host_word) only exists once per process per caller, so it is
+    exercised in FRESH processes: four host threads render their first frames at the same time on their own non-blocking streams; every frame of every thread
+    equals the frame of the same scene rendered alone, and nothing is left dirty behind them (tools/gpu_first_frame_stress.py; round 6: a block cleared with
+    hipMemset -- the null stream, asynchronous on this runtime -- could lose its counter to the first kernel that counted in it)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_first_frame_stress.py"), "--trials", "3", "--threads", "4", "--frames", "6"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["trials"] == 3 and d["failed_trials"] == 0, d
