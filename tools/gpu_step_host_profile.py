@@ -99,6 +99,12 @@ for _ in range(100):
     step()
     torch.cuda.synchronize()
 out["sync_ms_per_step"] = round((time.perf_counter() - t0) / 100 * 1e3, 4)
+# where the largest arrays of the optimizer sit (the SH tensor: parameter, gradient, both moments)
+try:
+    st_sh = opt.state[params[1]]
+    out["sh_ptrs"] = {"p": hex(params[1].data_ptr()), "g": hex(params[1].grad.data_ptr()), "m": hex(st_sh["exp_avg"].data_ptr()), "v": hex(st_sh["exp_avg_sq"].data_ptr())}
+except Exception as ex:      # noqa: BLE001
+    out["sh_ptrs"] = repr(ex)
 # Does the optimizer phase depend on where the allocator puts things?  (round 6: the same Adam kernel at 257 and at 298 us)  A dummy allocation of `pad` bytes
 # is made BEFORE the allocator's cache is dropped and the step re-allocates its scratch and gradients; 100 steps each, GPU time of the phases from events.
 if os.environ.get("PERTURB", "1") == "1":
