@@ -45,6 +45,12 @@ class DensifyStats:
         g = viewspace_grad
         P = int(g.shape[0]) if g.dim() == 2 else -1
         acc = (self.xyz_gradient_accum, self.denom, self.max_radii2D)
+        if g.is_cuda and visible.dtype == torch.int64 and P > 0:
+            # train.py:129,166 hands over `(radii > 0).nonzero()`, a [V, 1] list of DISTINCT row indices: the same rows as a mask
+            # (two small kernels), so that the unchanged caller's argument reaches the one-pass form below as well
+            mask = torch.zeros(P, dtype=torch.bool, device=g.device)
+            mask[visible.reshape(-1)] = True
+            visible = mask
         # the HIP pass reads P mask bytes and P rows of every array: a MASK of exactly P elements (bool / uint8) on the gradient's
         # device, accumulators of P rows -- an index tensor, a shorter mask or a tensor on another device takes the torch expression
         if (g.is_cuda and g.dtype == torch.float32 and g.dim() == 2 and g.shape[1] == 3 and g.is_contiguous()
@@ -196,3 +202,47 @@ def reset_opacity(optimizer, cap: float = 0.01, opacity_activation=torch.sigmoid
         optimizer.state[p] = state
     g["params"][0] = p
     return p
+
+
+def attach(gaussians):
+    """Binds this module's density control to an instance of the reference's `scene.gaussian_model.GaussianModel` (duck-typed: any object with
+    its attributes), so that the UNCHANGED caller reaches it through the method calls it already makes (train.py:164-174):
+
+        gaussians = GaussianModel(dataset.sh_degree, opt.optimizer_type)      # train.py:36
+        ...
+        gaussians.training_setup(opt)                                          # train.py:38
+        gsr_scene.densify.attach(gaussians)                                    # <- the one added line
+
+    Replaced on the instance (the class is not touched):
+      add_densification_stats(viewspace_point_tensor, update_filter)   gaussian_model.py:471-473 -> one HIP pass (gsr_density_stats) on a HIP device
+      densify_and_prune(max_grad, min_opacity, extent, max_screen_size, radii)   gaussian_model.py:448-469 -> the single repack above; the model's
+          parameter attributes, its three statistics arrays and `tmp_radii` are left exactly as the reference leaves them
+      reset_opacity()                                                  gaussian_model.py:258-261
+    Returns the instance."""
+    import types
+
+    def _stats(self):
+        return DensifyStats(self.xyz_gradient_accum, self.denom, self.max_radii2D)
+
+    def add_densification_stats(self, viewspace_point_tensor, update_filter):
+        _stats(self).add(viewspace_point_tensor.grad, update_filter, None)      # (max_radii2D is updated by the caller itself, train.py:166)
+
+    def densify_and_prune_(self, max_grad, min_opacity, extent, max_screen_size, radii):
+        params, new_stats, _tmp = densify_and_prune(self.optimizer, _stats(self), max_grad, min_opacity, extent, max_screen_size,
+                                                    percent_dense=self.percent_dense, scaling_activation=self.scaling_activation,
+                                                    scaling_inverse_activation=self.scaling_inverse_activation,
+                                                    opacity_activation=self.opacity_activation, radii=radii)
+        self._xyz, self._features_dc, self._features_rest = params["xyz"], params["f_dc"], params["f_rest"]
+        self._opacity, self._scaling, self._rotation = params["opacity"], params["scaling"], params["rotation"]
+        self.xyz_gradient_accum, self.denom, self.max_radii2D = new_stats.xyz_gradient_accum, new_stats.denom, new_stats.max_radii2D
+        self.tmp_radii = None
+        if self._xyz.is_cuda:
+            torch.cuda.empty_cache()
+
+    def reset_opacity_(self):
+        self._opacity = reset_opacity(self.optimizer, 0.01, self.opacity_activation, self.inverse_opacity_activation)
+
+    gaussians.add_densification_stats = types.MethodType(add_densification_stats, gaussians)
+    gaussians.densify_and_prune = types.MethodType(densify_and_prune_, gaussians)
+    gaussians.reset_opacity = types.MethodType(reset_opacity_, gaussians)
+    return gaussians

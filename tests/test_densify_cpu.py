@@ -130,3 +130,91 @@ def test_matches_the_reference_gaussian_model(max_screen_size):
         sys.path.remove(REF)
         for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.") or k.startswith("scene.")]:
             sys.modules.pop(k, None)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "scene", "gaussian_model.py")), reason="reference tree not present")
+@pytest.mark.parametrize("max_screen_size", [None, 20])
+def test_attach_drives_the_reference_gaussian_model_through_its_own_method_names(max_screen_size):
+    """gsr_scene.densify.attach(gaussians): the reference's OWN GaussianModel instance, once with its own methods and once with the three methods the
+    adapter binds, through the calls train.py:164-174 makes (add_densification_stats, densify_and_prune, reset_opacity) -- every attribute the
+    caller reads afterwards and the optimizer's state are the same bits."""
+    from gsr_scene.densify import attach
+    sys.path.insert(0, REF)
+    try:
+        sys.modules.pop("scene", None)
+        pkg = types.ModuleType("scene")
+        pkg.__path__ = [os.path.join(REF, "scene")]
+        with mock.patch.dict(sys.modules, {"scene": pkg}):
+            import importlib
+            gm = importlib.import_module("scene.gaussian_model")
+            real_zeros = torch.zeros
+
+            def cpu_zeros(*a, **k):
+                k.pop("device", None)
+                return real_zeros(*a, **k)
+
+            P, extent, thr, min_op = 600, 4.0, 0.0006, 0.005
+            t = _scene(P, 21)
+
+            def model():
+                m = gm.GaussianModel(3)
+                rp, ropt = _optimizer(t)
+                m._xyz, m._features_dc, m._features_rest = rp["xyz"], rp["f_dc"], rp["f_rest"]
+                m._opacity, m._scaling, m._rotation = rp["opacity"], rp["scaling"], rp["rotation"]
+                m.optimizer, m.percent_dense = ropt, 0.01
+                st = _stats(P, 22)
+                m.xyz_gradient_accum, m.denom, m.max_radii2D = st.xyz_gradient_accum.clone(), st.denom.clone(), st.max_radii2D.clone()
+                return m
+            g = torch.Generator().manual_seed(5)
+            view = types.SimpleNamespace(grad=torch.randn(P, 3, generator=g) * 1e-3)
+            seen = torch.rand(P, generator=g) < 0.7
+            radii = torch.arange(P, dtype=torch.float32)
+            a, b = model(), attach(model())
+            assert b.densify_and_prune.__func__ is not gm.GaussianModel.densify_and_prune
+            with mock.patch.object(torch, "zeros", cpu_zeros):
+                for m in (a, b):
+                    m.add_densification_stats(view, seen)
+                assert torch.equal(a.xyz_gradient_accum, b.xyz_gradient_accum) and torch.equal(a.denom, b.denom)
+                for m in (a, b):
+                    torch.manual_seed(77)
+                    m.densify_and_prune(thr, min_op, extent, max_screen_size, radii.clone())
+                    m.reset_opacity()
+            assert a._xyz.shape[0] != P and a.tmp_radii is None and b.tmp_radii is None
+            for name in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+                pa, pb = getattr(a, name), getattr(b, name)
+                assert isinstance(pb, nn.Parameter) and pb.requires_grad and torch.equal(pa.detach(), pb.detach()), name
+                for s in ("exp_avg", "exp_avg_sq"):
+                    assert torch.equal(a.optimizer.state[pa][s], b.optimizer.state[pb][s]), (name, s)
+            for name in ("xyz_gradient_accum", "denom", "max_radii2D"):
+                assert torch.equal(getattr(a, name), getattr(b, name)), name
+            assert torch.equal(a.get_opacity, b.get_opacity) and torch.equal(a.get_scaling, b.get_scaling)      # the model's own accessors
+    finally:
+        sys.path.remove(REF)
+        for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.") or k.startswith("scene.")]:
+            sys.modules.pop(k, None)
+
+
+def test_attach_on_a_duck_typed_model():
+    """The same adapter on an object that only has the attributes (the GPU box has no reference tree): the bound methods leave the attributes the caller
+    reads in place and consistent with the optimizer."""
+    from gsr_scene.densify import attach
+    P = 300
+    t = _scene(P, 31)
+    rp, ropt = _optimizer(t)
+    st = _stats(P, 32)
+    m = types.SimpleNamespace(_xyz=rp["xyz"], _features_dc=rp["f_dc"], _features_rest=rp["f_rest"], _opacity=rp["opacity"], _scaling=rp["scaling"],
+                              _rotation=rp["rotation"], optimizer=ropt, percent_dense=0.01, xyz_gradient_accum=st.xyz_gradient_accum, denom=st.denom,
+                              max_radii2D=st.max_radii2D, tmp_radii=None, scaling_activation=torch.exp, scaling_inverse_activation=torch.log,
+                              opacity_activation=torch.sigmoid, inverse_opacity_activation=lambda p: torch.log(p / (1 - p)))
+    attach(m)
+    view = types.SimpleNamespace(grad=torch.full((P, 3), 1e-3))
+    before = m.denom.clone()
+    m.add_densification_stats(view, torch.ones(P, dtype=torch.bool))
+    assert torch.equal(m.denom, before + 1)
+    torch.manual_seed(3)
+    m.densify_and_prune(0.0006, 0.005, 4.0, 20, torch.arange(P, dtype=torch.float32))
+    n = m._xyz.shape[0]
+    assert n != P and all(getattr(m, k).shape[0] == n for k in ("_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "xyz_gradient_accum", "denom", "max_radii2D"))
+    assert all(g["params"][0] is getattr(m, a) for g, a in zip(m.optimizer.param_groups, ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")))
+    m.reset_opacity()
+    assert float(torch.sigmoid(m._opacity).max()) <= 0.01 + 1e-6 and m.optimizer.param_groups[3]["params"][0] is m._opacity

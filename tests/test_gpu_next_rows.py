@@ -533,6 +533,31 @@ def test_density_statistics_kernel_matches_the_reference_expression(P):
         _lib.check(_lib.load().gsr_density_stats(5, None, None, None, None, None, None, None), "gsr_density_stats")
 
 
+def test_density_statistics_through_the_attached_method_with_the_callers_index_list():
+    """gsr_scene.densify.attach(gaussians): `gaussians.add_densification_stats(viewspace_point_tensor, visibility_filter)` exactly as train.py:129,170 calls
+    it -- `visibility_filter` is `(radii > 0).nonzero()`, a [V, 1] index list, and the gradient is read from `.grad` -- equals the reference's torch
+    expression (scene/gaussian_model.py:471-473) on the same arrays."""
+    import types
+    from gsr_scene.densify import attach
+    dev = torch.device("cuda:0")
+    P = 50_000
+    g = torch.Generator().manual_seed(9)
+    m = types.SimpleNamespace(xyz_gradient_accum=torch.zeros(P, 1, device=dev), denom=torch.zeros(P, 1, device=dev), max_radii2D=torch.zeros(P, device=dev))
+    attach(m)
+    acc, den = torch.zeros(P, 1, device=dev), torch.zeros(P, 1, device=dev)
+    for it in range(4):
+        view = types.SimpleNamespace(grad=(torch.randn(P, 3, generator=g) * 1e-3).to(dev))
+        radii = torch.randint(0, 9, (P,), generator=g, dtype=torch.int32).to(dev)
+        visibility_filter = (radii > 0).nonzero()
+        m.add_densification_stats(view, visibility_filter)
+        acc[visibility_filter] += torch.norm(view.grad[visibility_filter, :2], dim=-1, keepdim=True)
+        den[visibility_filter] += 1
+    torch.cuda.synchronize()
+    assert torch.equal(m.denom, den) and float(den.max()) == 4.0
+    assert (m.xyz_gradient_accum - acc).abs().max().item() <= 2e-6 * max(1.0, acc.abs().max().item())
+    assert not m.max_radii2D.any()      # (train.py:166 updates it itself)
+
+
 def test_training_loop_with_density_control():
     """train.py:111-186 in miniature on the drop-in pieces: render (split-SH form), reference loss, backward, density
     statistics from the operator's means2D gradient and radii, FusedAdam step, clone / split / prune every 50 iterations
