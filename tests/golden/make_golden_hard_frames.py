@@ -11,6 +11,11 @@ hard in round 5, frozen as fixtures so that `pytest -m gpu` (and the kernel sour
  (seed 71, frame 78)   1494 extreme needles (condition numbers >= 1e5), 480x270: finite gradients; a sign flip of the exponent
  (seed 101, frame 172) 1670 needles: round 6's worst kernel-vs-fp64 distance on the final binaries (rotations 6.1e-3 where the fp32 oracle is 3.6e-2)
  (seed 202, frame 263) 134 needles: scales 2.1e-3 from fp64 where the fp32 oracle is 3.6e-3 (the closest the two came in 1 100 frames)
+ (seed 404, frame 72)  55 Gaussians at the frustum's edge, antialiased, depth loss: ONE pixel whose alpha sits on 1/255 takes the other branch in the kernel
+                       (image error there 3.5e-4 = one alpha quantum) and moves the rotation gradient by 4.1e-3 of max |grad|; without that pixel 4.8e-6
+ (seed 303, frame 189) 9 needles, five pixels with a threshold inside the exponent's cancellation noise: rotations 1.6e-2 from fp64 with them, 4.2e-5 without
+                       (the fp32 oracle: 1.3e-2).  Both frames are stored with the loss weights zeroed at those pixels: what is pinned is "the gradients
+                       agree wherever no threshold is within noise".
 
 Per frame the file holds the INPUTS of the operator call (settings record, every tensor of the call form, the loss weights) and the
 EXPECTED outputs: radii, and the gradient of the frame's loss with respect to every input from the oracle's autograd evaluated in
@@ -28,7 +33,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import fuzz_frames as F  # noqa: E402
 
-FRAMES = [(71, 109), (53, 92), (53, 137), (71, 32), (71, 78), (101, 172), (202, 263)]
+FRAMES = [(71, 109), (53, 92), (53, 137), (71, 32), (71, 78), (101, 172), (202, 263), (404, 72), (303, 189)]
+# frames whose ONLY failure was a pixel with a hard blend threshold inside fp32's rounding noise (either branch is a correct fp32 result: the pixel's
+# branch feeds the gradients too): their loss weights are stored with zeros at those pixels (tests/fuzz_frames.py threshold_pixels)
+WITHOUT_THRESHOLD_PIXELS = {(404, 72), (303, 189)}
 SETTINGS_FIELDS = ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix", "sh_degree",
                    "campos", "prefiltered", "debug", "antialiasing")
 
@@ -38,6 +46,14 @@ def main():
     for seed, it in FRAMES:
         f = F.frame(seed, it)
         key = f"{seed}_{it}"
+        if (seed, it) in WITHOUT_THRESHOLD_PIXELS:
+            near = F.threshold_pixels(f)
+            keep = (~near).to(f.wc.dtype)
+            f.wc = f.wc * keep
+            if f.use_depth:
+                f.wd = f.wd * keep
+            out[f"{key}/threshold_pixels"] = torch.nonzero(near).numpy().astype(np.int32)
+            print(f"{key}: {int(near.sum())} pixel(s) with a threshold within noise, loss weights zeroed there", flush=True)
         for name in SETTINGS_FIELDS:
             v = getattr(f.s, name)
             out[f"{key}/settings/{name}"] = v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)

@@ -5,7 +5,10 @@ the ORACLE'S AUTOGRAD EVALUATED IN FP64 on the same fp32 inputs:
     |grad - grad64| <= max(1e-3, 1.5 x the fp32 oracle's own distance from grad64) x max |grad64|        per input tensor
 
 -- i.e. 1e-3 wherever fp32 can resolve the frame at all (the fp32 oracle is within 6.7e-4), and never worse than 1.5 x what an fp32
-evaluation of the same algorithm loses.  Frame 71_109 is the one round 5's library FAILED (rotation gradient 2.4e-3 from fp64, fp32 oracle
+evaluation of the same algorithm loses.  Frames 404_72 and 303_189 (round 6) failed the randomised cross-check for ONE reason: a pixel where a hard
+threshold of the blend (alpha vs 1/255, the exponent's sign, T vs 1e-4) lies inside fp32's rounding noise took the other branch in the kernel -- a
+correct fp32 result -- and its branch feeds the gradients (one pixel: 4.1e-3 of max |grad|).  They are stored with the loss weights zeroed at those
+pixels (tests/fuzz_frames.py threshold_pixels): the gradients must agree wherever no threshold is within noise (404_72: 4.8e-6 there).  Frame 71_109 is the one round 5's library FAILED (rotation gradient 2.4e-3 from fp64, fp32 oracle
 3.2e-4): the per-Gaussian backward's covariance chain now runs in fp64 (csrc/gsr_math.h gsr_project_backward_r).
 
 GPU leg: through the shipped package on cuda:0.  CPU leg (`-m "not gpu"`): the same kernel source through tests/simt on the two small
@@ -101,7 +104,7 @@ def test_hard_frame_gradients_against_the_fp64_oracle_on_the_gpu(key):
         assert max(v[0] for v in rep.values()) <= 1e-3
 
 
-@pytest.mark.parametrize("key", ["71_109", "71_32"])
+@pytest.mark.parametrize("key", ["71_109", "71_32", "404_72", "303_189"])
 def test_hard_frame_gradients_against_the_fp64_oracle_kernel_source_on_the_cpu(key):
     import simt_build
     from test_simt_package_cpu import package_on_the_cpu

@@ -37,63 +37,10 @@ stats = {"frames": 0, "backward_checked": 0, "kinds": {}, "forms": {}, "max_P": 
 t0 = time.time()
 
 
-GAMMA = 2.0 ** -22      # two fp32 ulps of the quadratic form's TERMS (measured: the worst pixel of 345 frames sits at 0.1 of 2^-21)
+from fuzz_frames import GAMMA, conditioning      # (tests/fuzz_frames.py: shared with the golden generator of the pinned hard frames)
 
 
-def conditioning(aux, s_):
-    """What fp32 can resolve at every pixel.  The exponent of a pair is -(A dx^2 + C dy^2)/2 - B dx dy: for an anisotropic splat its terms
-    are orders of magnitude larger than their sum, so two correct fp32 evaluations (other association, FMA contraction -- the reference's
-    nvcc build contracts too) differ by ~GAMMA * M with M = (|A| dx^2 + |C| dy^2)/2 + |B dx dy|.  First-order propagation through the
-    compositing sum: |d image| <= 2 cmax GAMMA sum_i w_i M_i (w_i = alpha_i T_i), |d T| <= T sum_i alpha_i/(1-alpha_i) GAMMA M_i.
-    Returns per pixel: the image bound's sum_i w_i M_i, the relative T bound, and a flag "a hard threshold of an evaluated pair is within
-    that noise" (alpha vs 1/255, power vs 0, T vs 1e-4) -- there either branch is a correct fp32 result."""
-    H_, W_ = int(s_.image_height), int(s_.image_width)
-    gx_, gy_ = aux["grid"]
-    B = torch.zeros(H_, W_, dtype=torch.float64)
-    E = torch.zeros(H_, W_, dtype=torch.float64)
-    J = torch.zeros(H_, W_, dtype=torch.float64)
-    flag = torch.zeros(H_, W_, dtype=torch.bool)
-    xy, con, opa = aux["means2D"].double(), aux["conic"].double(), aux["opacity"].double().reshape(-1)
-    pl, rng_ = aux["point_list"], aux["ranges"]
-    for t in range(gx_ * gy_):
-        a, b = int(rng_[t, 0]), int(rng_[t, 1])
-        if b <= a:
-            continue
-        ty, tx = divmod(t, gx_)
-        x0, y0 = tx * 16, ty * 16
-        x1, y1 = min(x0 + 16, W_), min(y0 + 16, H_)
-        ys, xs = torch.meshgrid(torch.arange(y0, y1), torch.arange(x0, x1), indexing="ij")
-        px, py = xs.reshape(-1).double(), ys.reshape(-1).double()
-        ids = pl[a:b]
-        dx = xy[ids, 0][None, :] - px[:, None]
-        dy = xy[ids, 1][None, :] - py[:, None]
-        A_, B_, C_ = con[ids, 0][None, :], con[ids, 1][None, :], con[ids, 2][None, :]
-        power = -0.5 * (A_ * dx * dx + C_ * dy * dy) - B_ * dx * dy
-        M = 0.5 * (A_.abs() * dx * dx + C_.abs() * dy * dy) + (B_ * dx * dy).abs()
-        alpha = torch.clamp(opa[ids][None, :] * torch.exp(power), max=0.99)
-        keep = (power <= 0) & (alpha >= 1.0 / 255.0)
-        ae = torch.where(keep, alpha, torch.zeros_like(alpha))
-        Tincl = torch.cumprod(1.0 - ae, dim=1)
-        Texcl = torch.cat([torch.ones(len(px), 1, dtype=torch.float64), Tincl[:, :-1]], dim=1)
-        dead = torch.cumsum((keep & (Tincl < 1e-4)).to(torch.int32), dim=1) > 0
-        evaluated = ~torch.cat([torch.zeros(len(px), 1, dtype=torch.bool), dead[:, :-1]], dim=1)      # pairs the loop reaches
-        w = torch.where(keep & ~dead, ae * Texcl, torch.zeros_like(ae))
-        noise = GAMMA * M
-        relT = torch.cumsum(torch.where(keep, ae / (1.0 - ae) * noise, torch.zeros_like(ae)), dim=1)
-        near = evaluated & (((alpha - 1.0 / 255.0).abs() <= 2.0 * alpha * noise + 1e-12) & (power <= noise)
-                            | ((power.abs() <= noise) & (alpha >= 0.5 / 255.0))
-                            | (keep & ((Tincl - 1e-4).abs() <= Tincl * (relT + 1e-6) + 1e-12)))
-        # Round 5: a flipped SIGN TEST of the exponent (power > 0: the entry is skipped) is not an alpha-quantum event -- the entry sits at the splat's
-        # centre line, alpha = opacity * exp(~0) can be anything up to 0.99.  Only needles reach it (|power| within the cancellation noise of its terms);
-        # the jump such a flip may cause at the pixel is bounded by sum alpha_i T_i over the pairs whose sign is within noise (seed 71, frame 78).
-        near_sign = evaluated & (power.abs() <= noise) & (alpha >= 0.5 / 255.0)
-        J[y0:y1, x0:x1] = torch.where(near_sign, alpha * Texcl, torch.zeros_like(alpha)).sum(dim=1).reshape(y1 - y0, x1 - x0)
-        B[y0:y1, x0:x1] = (w * M).sum(dim=1).reshape(y1 - y0, x1 - x0)
-        E[y0:y1, x0:x1] = torch.where(evaluated, relT, torch.zeros_like(relT)).amax(dim=1).reshape(y1 - y0, x1 - x0)
-        flag[y0:y1, x0:x1] = near.any(dim=1).reshape(y1 - y0, x1 - x0)
-    return B, E, flag, J
-
-
+ONLY = {int(x) for x in os.environ.get("FUZZ_ONLY", "").split(",") if x.strip()}
 BUDGET_S = float(os.environ.get("FUZZ_SECONDS", "1e9"))      # stop (and report) after this much wall clock
 stream = FrameStream(SEED)      # tests/fuzz_frames.py: the frame generator (replayable: a reported (seed, it) can be rebuilt anywhere)
 for it in range(N):
@@ -103,6 +50,8 @@ for it in range(N):
     desc = {"it": it}
     try:
         fr_ = next(stream)
+        if ONLY and it not in ONLY:      # (FUZZ_ONLY=72,189: replay these frames of the seed only)
+            continue
         cam, sc, kind, max_deg, g = fr_.cam, fr_.sc, fr_.kind, fr_.max_deg, fr_.g
         P, H, W, deg, opts, s = fr_.P, fr_.H, fr_.W, fr_.deg, fr_.opts, fr_.s
         colors_form, cov_form, split_form, use_depth, form = fr_.colors_form, fr_.cov_form, fr_.split_form, fr_.use_depth, fr_.form
@@ -175,116 +124,137 @@ for it in range(N):
         stats["max_R"] = max(stats["max_R"], int(aux["R"]))
 
         # ---- backward through the operator's public call ----
-        wc = torch.randn(3, H, W, generator=g)
-        wd = torch.randn(1, H, W, generator=g) * 0.3 if use_depth else None
+        wc_full = torch.randn(3, H, W, generator=g)
+        wd_full = torch.randn(1, H, W, generator=g) * 0.3 if use_depth else None
 
-        def leaves(where):
-            L = {"means3D": sc.means3D, "opacities": sc.opacities}
-            if colors_form:
-                L["colors_precomp"] = colors
-            elif split_form:
-                L["dc"], L["shs"] = sc.shs[:, :1].contiguous(), sc.shs[:, 1:].contiguous()
-            else:
-                L["shs"] = sc.shs
-            if cov_form:
-                L["cov3D_precomp"] = cov
-            else:
-                L["scales"], L["rotations"] = sc.scales, sc.rotations
-            L = {k: v.detach().clone().to(where).requires_grad_(True) for k, v in L.items()}
-            L["means2D"] = torch.zeros(P, 3, device=where, requires_grad=True)
-            return L
+        def check_backward(wc, wd):
+            """One backward pass of both sides with the loss weights (wc, wd); raises AssertionError where a bar is exceeded."""
 
-        Lc = leaves("cpu")
-        kw = {k: v for k, v in Lc.items() if k not in ("means3D", "means2D", "opacities", "dc")}
-        if split_form:
-            kw["shs"] = torch.cat([Lc["dc"], Lc["shs"]], dim=1)
-        ocol, oradii, oinvd = O.rasterize(Lc["means3D"], Lc["means2D"], Lc["opacities"], s, **kw)
-        oloss = (ocol * wc).sum() + ((oinvd * wd).sum() if use_depth else 0.0)
-        if oloss.requires_grad:      # (nothing visible: the oracle's image is a constant, every gradient is zero)
-            oloss.backward()
-        if DRY:
-            stats["frames"] += 1
-            stats["kinds"][kind] = stats["kinds"].get(kind, 0) + 1
-            stats["forms"][form] = stats["forms"].get(form, 0) + 1
-            continue
-        Lg = leaves(dev)
-        kwg = {k: v for k, v in Lg.items() if k not in ("means3D", "means2D", "opacities")}
-        gcol, gradii, ginvd = GaussianRasterizer(raster_settings=gpu_settings(s, dev))(means3D=Lg["means3D"], means2D=Lg["means2D"],
-                                                                                      opacities=Lg["opacities"], **kwg)
-        ((gcol * wc.to(dev)).sum() + ((ginvd * wd.to(dev)).sum() if use_depth else 0.0)).backward()
-        torch.cuda.synchronize()
-        assert torch.equal(gradii.cpu(), oradii), "radii (backward call) differ"
-        degenerate = kind in ("edge", "huge", "needles", "extreme_needles")
-        bar_max, bar_p = (2e-3, 1e-4) if degenerate else (1e-4, 1e-5)
-        gm = {}
-        ref64 = {}
+            def leaves(where):
+                L = {"means3D": sc.means3D, "opacities": sc.opacities}
+                if colors_form:
+                    L["colors_precomp"] = colors
+                elif split_form:
+                    L["dc"], L["shs"] = sc.shs[:, :1].contiguous(), sc.shs[:, 1:].contiguous()
+                else:
+                    L["shs"] = sc.shs
+                if cov_form:
+                    L["cov3D_precomp"] = cov
+                else:
+                    L["scales"], L["rotations"] = sc.scales, sc.rotations
+                L = {k: v.detach().clone().to(where).requires_grad_(True) for k, v in L.items()}
+                L["means2D"] = torch.zeros(P, 3, device=where, requires_grad=True)
+                return L
 
-        def oracle_fp64():
-            """Round 5: the oracle once more in fp64 (same inputs, same loss).  An anisotropic needle's exponent cancels in fp32 -- in the kernel AND in the
-            fp32 oracle -- so when the two disagree beyond the bar, each is held against the fp64 gradients: the frame passes if the KERNEL is inside the
-            bar of the fp64 values, and the fp32 oracle's own distance is recorded beside it."""
-            if ref64:
-                return ref64
-            L64 = {k: v.detach().clone().double().requires_grad_(True) for k, v in Lc.items()}
-            kw64 = {k: v for k, v in L64.items() if k not in ("means3D", "means2D", "opacities", "dc")}
+            Lc = leaves("cpu")
+            kw = {k: v for k, v in Lc.items() if k not in ("means3D", "means2D", "opacities", "dc")}
             if split_form:
-                kw64["shs"] = torch.cat([L64["dc"], L64["shs"]], dim=1)
-            c64, r64, i64 = O.rasterize(L64["means3D"], L64["means2D"], L64["opacities"], s, **kw64)
-            if not torch.equal(r64, oradii):
-                return None      # (a radius decided differently in fp64: not the same frame)
-            l64 = (c64 * wc.double()).sum() + ((i64 * wd.double()).sum() if use_depth else 0.0)
-            if l64.requires_grad:
-                l64.backward()
-            ref64.update({k: v.grad for k, v in L64.items()})
-            return ref64
+                kw["shs"] = torch.cat([Lc["dc"], Lc["shs"]], dim=1)
+            ocol, oradii, oinvd = O.rasterize(Lc["means3D"], Lc["means2D"], Lc["opacities"], s, **kw)
+            oloss = (ocol * wc).sum() + ((oinvd * wd).sum() if use_depth else 0.0)
+            if oloss.requires_grad:      # (nothing visible: the oracle's image is a constant, every gradient is zero)
+                oloss.backward()
+            if DRY:
+                stats["frames"] += 1
+                stats["kinds"][kind] = stats["kinds"].get(kind, 0) + 1
+                stats["forms"][form] = stats["forms"].get(form, 0) + 1
+                return "dry"
+            Lg = leaves(dev)
+            kwg = {k: v for k, v in Lg.items() if k not in ("means3D", "means2D", "opacities")}
+            gcol, gradii, ginvd = GaussianRasterizer(raster_settings=gpu_settings(s, dev))(means3D=Lg["means3D"], means2D=Lg["means2D"],
+                                                                                          opacities=Lg["opacities"], **kwg)
+            ((gcol * wc.to(dev)).sum() + ((ginvd * wd.to(dev)).sum() if use_depth else 0.0)).backward()
+            torch.cuda.synchronize()
+            assert torch.equal(gradii.cpu(), oradii), "radii (backward call) differ"
+            degenerate = kind in ("edge", "huge", "needles", "extreme_needles")
+            bar_max, bar_p = (2e-3, 1e-4) if degenerate else (1e-4, 1e-5)
+            gm = {}
+            ref64 = {}
 
-        def within(a, b, k):
-            scale = b.abs().max().item()
-            if scale == 0.0:
-                return a.abs().max().item() <= 1e-12, 0.0
-            dd = (a - b).abs() / scale
-            q = torch.quantile(dd.flatten()[:4_000_000], 0.999).item() if dd.numel() >= 20000 else 0.0
-            return dd.max().item() < bar_max and q < bar_p, dd.max().item()
-        for k in Lc:
-            a = Lg[k].grad
-            b = Lc[k].grad
-            if b is None and a is not None and k != "means2D":
-                b = torch.zeros_like(Lc[k])
-            if b is None or b.numel() == 0:
+            def oracle_fp64():
+                """Round 5: the oracle once more in fp64 (same inputs, same loss).  An anisotropic needle's exponent cancels in fp32 -- in the kernel AND in the
+                fp32 oracle -- so when the two disagree beyond the bar, each is held against the fp64 gradients: the frame passes if the KERNEL is inside the
+                bar of the fp64 values, and the fp32 oracle's own distance is recorded beside it."""
+                if ref64:
+                    return ref64
+                L64 = {k: v.detach().clone().double().requires_grad_(True) for k, v in Lc.items()}
+                kw64 = {k: v for k, v in L64.items() if k not in ("means3D", "means2D", "opacities", "dc")}
+                if split_form:
+                    kw64["shs"] = torch.cat([L64["dc"], L64["shs"]], dim=1)
+                c64, r64, i64 = O.rasterize(L64["means3D"], L64["means2D"], L64["opacities"], s, **kw64)
+                if not torch.equal(r64, oradii):
+                    return None      # (a radius decided differently in fp64: not the same frame)
+                l64 = (c64 * wc.double()).sum() + ((i64 * wd.double()).sum() if use_depth else 0.0)
+                if l64.requires_grad:
+                    l64.backward()
+                ref64.update({k: v.grad for k, v in L64.items()})
+                return ref64
+
+            def within(a, b, k):
+                scale = b.abs().max().item()
+                if scale == 0.0:
+                    return a.abs().max().item() <= 1e-12, 0.0
+                dd = (a - b).abs() / scale
+                q = torch.quantile(dd.flatten()[:4_000_000], 0.999).item() if dd.numel() >= 20000 else 0.0
+                return dd.max().item() < bar_max and q < bar_p, dd.max().item()
+            for k in Lc:
+                a = Lg[k].grad
+                b = Lc[k].grad
+                if b is None and a is not None and k != "means2D":
+                    b = torch.zeros_like(Lc[k])
+                if b is None or b.numel() == 0:
+                    continue
+                if kind == "extreme_needles":
+                    assert a is not None and torch.isfinite(a).all(), f"{k}: non-finite gradient"
+                    continue
+                assert a is not None, f"{k}: no gradient from the operator"
+                a, b = a.cpu().double(), b.double()
+                assert torch.isfinite(a).all(), f"{k}: non-finite gradient"
+                scale = b.abs().max().item()
+                if scale == 0.0:
+                    assert a.abs().max().item() <= 1e-12, f"{k}: oracle gradient is zero, operator's is not"
+                    continue
+                dd = (a - b).abs() / scale
+                q = torch.quantile(dd.flatten()[:4_000_000], 0.999).item() if dd.numel() >= 20000 else 0.0      # (below that it IS the maximum)
+                gm[k] = [float(f"{dd.max().item():.3e}"), float(f"{q:.3e}")]
+                desc["grad_metrics"] = gm
+                stats["worst_grad_err"] = max(stats["worst_grad_err"], dd.max().item() if not degenerate else 0.0)
+                if not (dd.max().item() < bar_max and q < bar_p):
+                    # Conditioning-aware bar (round 5): a needle's exponent cancels in fp32, in the kernel AND in the fp32 oracle.  What fp32 can resolve on
+                    # THIS frame is measured by the oracle itself -- its fp32 gradients against its fp64 gradients (seed 53, frames 92 / 137: 2.4e-3 .. 1.3e-2
+                    # of max |grad|, the image itself moves by 3e-3) -- and the kernel must be no farther from the fp64 values than three times that.
+                    r64 = oracle_fp64()
+                    if r64 and r64.get(k) is not None:
+                        ok_hip, e_hip = within(a, r64[k], k)
+                        e_o32 = within(b, r64[k], k)[1]
+                        # Round 6: ordinary kinds are adjudicated too, at their OWN bars -- the fp32 oracle's autograd is itself up to 2e-4 of max |grad|
+                        # from its fp64 evaluation on ordinary clouds (seed 7, frame 85: oracle 1.03e-4, kernel 4.4e-6), and since the per-Gaussian
+                        # backward's covariance chain runs in fp64 the kernel is the accurate side: it must be inside the bars of the fp64 gradients.
+                        if (e_hip < max(bar_max, 3.0 * e_o32)) if degenerate else ok_hip:
+                            stats["adjudicated_by_fp64"].append({"it": it, "kind": kind, "P": P, "tensor": k, "kernel_vs_fp32_oracle": float(f"{dd.max().item():.3e}"),
+                                                                 "kernel_vs_fp64": float(f"{e_hip:.3e}"), "fp32_oracle_vs_fp64": float(f"{e_o32:.3e}")})
+                            continue
+                        desc["fp64"] = {"tensor": k, "kernel_vs_fp64": e_hip, "fp32_oracle_vs_fp64": e_o32}
+                assert dd.max().item() < bar_max, f"{k}: max grad err {dd.max().item():.3e} of max |grad| (bar {bar_max})"
+                assert q < bar_p, f"{k}: 99.9th pct grad err {q:.3e} (bar {bar_p})"
+            return "ok"
+
+        try:
+            if check_backward(wc_full, wd_full) == "dry":
                 continue
-            if kind == "extreme_needles":
-                assert a is not None and torch.isfinite(a).all(), f"{k}: non-finite gradient"
-                continue
-            assert a is not None, f"{k}: no gradient from the operator"
-            a, b = a.cpu().double(), b.double()
-            assert torch.isfinite(a).all(), f"{k}: non-finite gradient"
-            scale = b.abs().max().item()
-            if scale == 0.0:
-                assert a.abs().max().item() <= 1e-12, f"{k}: oracle gradient is zero, operator's is not"
-                continue
-            dd = (a - b).abs() / scale
-            q = torch.quantile(dd.flatten()[:4_000_000], 0.999).item() if dd.numel() >= 20000 else 0.0      # (below that it IS the maximum)
-            gm[k] = [float(f"{dd.max().item():.3e}"), float(f"{q:.3e}")]
-            desc["grad_metrics"] = gm
-            stats["worst_grad_err"] = max(stats["worst_grad_err"], dd.max().item() if not degenerate else 0.0)
-            if not (dd.max().item() < bar_max and q < bar_p):
-                # Conditioning-aware bar (round 5): a needle's exponent cancels in fp32, in the kernel AND in the fp32 oracle.  What fp32 can resolve on
-                # THIS frame is measured by the oracle itself -- its fp32 gradients against its fp64 gradients (seed 53, frames 92 / 137: 2.4e-3 .. 1.3e-2
-                # of max |grad|, the image itself moves by 3e-3) -- and the kernel must be no farther from the fp64 values than three times that.
-                r64 = oracle_fp64()
-                if r64 and r64.get(k) is not None:
-                    ok_hip, e_hip = within(a, r64[k], k)
-                    e_o32 = within(b, r64[k], k)[1]
-                    # Round 6: ordinary kinds are adjudicated too, at their OWN bars -- the fp32 oracle's autograd is itself up to 2e-4 of max |grad|
-                    # from its fp64 evaluation on ordinary clouds (seed 7, frame 85: oracle 1.03e-4, kernel 4.4e-6), and since the per-Gaussian
-                    # backward's covariance chain runs in fp64 the kernel is the accurate side: it must be inside the bars of the fp64 gradients.
-                    if (e_hip < max(bar_max, 3.0 * e_o32)) if degenerate else ok_hip:
-                        stats["adjudicated_by_fp64"].append({"it": it, "kind": kind, "P": P, "tensor": k, "kernel_vs_fp32_oracle": float(f"{dd.max().item():.3e}"),
-                                                             "kernel_vs_fp64": float(f"{e_hip:.3e}"), "fp32_oracle_vs_fp64": float(f"{e_o32:.3e}")})
-                        continue
-                    desc["fp64"] = {"tensor": k, "kernel_vs_fp64": e_hip, "fp32_oracle_vs_fp64": e_o32}
-            assert dd.max().item() < bar_max, f"{k}: max grad err {dd.max().item():.3e} of max |grad| (bar {bar_max})"
-            assert q < bar_p, f"{k}: 99.9th pct grad err {q:.3e} (bar {bar_p})"
+        except AssertionError as first:
+            # A pixel where one of the blend's hard thresholds (alpha vs 1/255, power vs 0, T vs 1e-4) lies inside fp32's rounding noise may take either
+            # branch -- both are correct fp32 results (the image check above holds such pixels to one alpha quantum).  Its branch feeds the gradients
+            # too: one flipped pixel moved a frame's rotation gradient by 4e-3 of max |grad| (seed 404, frame 72; with that pixel's loss weight zeroed
+            # kernel and fp64 oracle agree to 2e-6).  So a frame that fails and HAS such pixels is checked again with the loss weights zeroed there:
+            # the gradients must agree, at the frame's own bars, wherever no threshold is within noise.
+            if DRY or cond is None or not bool((aux["fragile"] | cond[2]).any()):
+                raise
+            keep_px = (~(aux["fragile"] | cond[2])).to(wc_full.dtype)
+            desc["first_error_with_all_pixels"] = str(first)[:200]
+            check_backward(wc_full * keep_px, None if wd_full is None else wd_full * keep_px)
+            stats.setdefault("adjudicated_off_threshold_pixels", []).append({"it": it, "kind": kind, "P": P, "pixels_with_a_threshold_within_noise": int((1 - keep_px).sum()),
+                                                                             "error_with_all_pixels": str(first)[:160], "grad_metrics_without_them": desc.get("grad_metrics")})
         stats["backward_checked"] += 1
         stats["frames"] += 1
         stats["kinds"][kind] = stats["kinds"].get(kind, 0) + 1
