@@ -122,6 +122,8 @@ def test_fixture_is_what_the_generator_makes():
     f = F.frame(71, 109)
     fr = load_frame("71_109")
     assert fr["kind"] == f.kind == "needles" and fr["form"] == f.form
-    assert torch.equal(fr["ins"]["scales"], f.sc.scales) and torch.equal(fr["ins"]["rotations"], f.sc.rotations)
-    assert torch.equal(fr["wc"], f.wc) and torch.equal(fr["wd"], f.wd)
-    assert torch.equal(fr["s"].viewmatrix, f.s.viewmatrix) and fr["s"].scale_modifier == f.s.scale_modifier
+    # (to a few ulps: the generator's exp / log / trigonometry are the host CPU's vectorised ones -- the fixture was made in the build container)
+    same = lambda a, b: a.shape == b.shape and torch.allclose(a, b, rtol=2e-6, atol=1e-7)      # noqa: E731
+    assert same(fr["ins"]["scales"], f.sc.scales) and same(fr["ins"]["rotations"], f.sc.rotations)
+    assert same(fr["wc"], f.wc) and same(fr["wd"], f.wd)
+    assert same(fr["s"].viewmatrix, f.s.viewmatrix) and fr["s"].scale_modifier == f.s.scale_modifier
