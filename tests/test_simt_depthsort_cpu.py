@@ -65,7 +65,7 @@ def make_keys(rng, P, kind):
 
 
 @pytest.mark.parametrize("kind,P", [("uniform", 20_000), ("uniform", 4_097), ("uniform", 300), ("ties", 12_000), ("crowd", 16_000), ("gap", 9_000), ("one_key", 5_000),
-                                    ("outliers", 24_000), ("heavy_tails", 40_000), ("wall", 40_000), ("wall_thin", 40_000), ("crowd", 400_000), ("crowd_16", 400_000), ("one_key", 80_000)])
+                                    ("outliers", 24_000), ("heavy_tails", 40_000), ("wall", 40_000), ("wall_thin", 40_000), ("crowd", 400_000), ("crowd_16", 400_000), ("one_key", 80_000), ("one_key", 2_200_000)])
 def test_bucket_depth_sort_on_the_cpu_equals_a_stable_sort(lib, kind, P):
     rng = np.random.default_rng(1000 + P + len(kind))
     keys = make_keys(rng, P, kind)
