@@ -766,7 +766,8 @@ def _run(a):
                     "depth": depth_image}
 
         unchanged = {}
-        for okey, otype in (("default_torch_adam", "default"), ("sparse_adam", "sparse_adam"), ("sparse_adam_one_added_line", "sparse_adam")):
+        for okey, otype in (("default_torch_adam", "default"), ("sparse_adam", "sparse_adam"), ("sparse_adam_one_added_line", "sparse_adam"),
+                            ("default_one_added_line", "default")):
             pc = _RefModel(sc, otype)
             if okey.endswith("one_added_line"):
                 # train.py + `gsr_scene.densify.attach(gaussians)` behind `gaussians.training_setup(opt)`: the instance's
@@ -809,8 +810,9 @@ def _run(a):
             del pc
         unchanged["what"] = ("train.py:104-186's op sequence verbatim on the three drop-in packages only: render() glue in the separate_sh form with torch "
                              "activations, torch l1_loss, fused_ssim, loss.item() every iteration, torch boolean-index density statistics, exposure optimizer, "
-                             "then torch.optim.Adam (train.py's default optimizer_type) / SparseGaussianAdam (--optimizer_type sparse_adam); sparse_adam_one_added_line: the same with "
-                             "gsr_scene.densify.attach(gaussians) behind training_setup() -- the density statistics as one HIP pass through the method name the caller already uses")
+                             "then torch.optim.Adam (train.py's default optimizer_type) / SparseGaussianAdam (--optimizer_type sparse_adam); *_one_added_line: the same with "
+                             "gsr_scene.densify.attach(gaussians) behind training_setup() -- the density statistics as one HIP pass through the method name the caller already uses, "
+                             "and train.py's default torch.optim.Adam replaced by gsr_optim.FusedAdam with the same groups and state")
 
     # ---- "report it/s at fixed P in {1e5, 1e6, 3e6}" (configs[2] stand-in at fixed size): the headline train step (fused loss,
     # dense fused Adam, views cycled) on the same generator at the two other sizes; 1e6 is train_iters_per_s itself ----
@@ -1414,12 +1416,13 @@ def _run(a):
         out["train_unchanged_caller"] = unchanged
         out["train_iters_per_s_unchanged_caller"] = None if not unchanged else unchanged["default_torch_adam"]["iters_per_s"]
         out["train_iters_per_s_unchanged_caller_sparse_adam"] = None if not unchanged else unchanged["sparse_adam"]["iters_per_s"]
-        out["train_iters_per_s_unchanged_caller_one_added_line"] = None if not unchanged else unchanged["sparse_adam_one_added_line"]["iters_per_s"]
+        out["train_iters_per_s_unchanged_caller_one_added_line"] = None if not unchanged else unchanged["default_one_added_line"]["iters_per_s"]
+        out["train_iters_per_s_unchanged_caller_sparse_adam_one_added_line"] = None if not unchanged else unchanged["sparse_adam_one_added_line"]["iters_per_s"]
         out["train_iters_per_s_fixed_P"] = fixed_P
         out["train_low_visibility"] = low_vis
         tail_keys = ["roofline_notes", "blend_timeline", "forward_reference_rectangles", "forward_frames_in_flight", "train_low_visibility",
                      "train_unchanged_caller", "cpu_baseline", "roofline_train", "roofline", "stage_ms", "retimed", "forward_reference_rectangles_ms",
-                     "train_iters_per_s_fixed_P", "train_iters_per_s_unchanged_caller_one_added_line", "train_iters_per_s_unchanged_caller_sparse_adam", "train_iters_per_s_unchanged_caller",
+                     "train_iters_per_s_fixed_P", "train_iters_per_s_unchanged_caller_sparse_adam_one_added_line", "train_iters_per_s_unchanged_caller_one_added_line", "train_iters_per_s_unchanged_caller_sparse_adam", "train_iters_per_s_unchanged_caller",
                      "train_iters_per_s_sparse_adam", "train_ms_per_iter", "train_iters_per_s", "ms_per_step", "value_reference_bins", "value"]
         head_keys = ["other_configs_forward", "train_full_loop_configs2", "train_densify", "stages", "train_step"]
         ordered = {k: out[k] for k in head_keys if k in out}

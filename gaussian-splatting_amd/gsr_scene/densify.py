@@ -204,7 +204,7 @@ def reset_opacity(optimizer, cap: float = 0.01, opacity_activation=torch.sigmoid
     return p
 
 
-def attach(gaussians):
+def attach(gaussians, fused_adam: bool = True):
     """Binds this module's density control to an instance of the reference's `scene.gaussian_model.GaussianModel` (duck-typed: any object with
     its attributes), so that the UNCHANGED caller reaches it through the method calls it already makes (train.py:164-174):
 
@@ -218,8 +218,19 @@ def attach(gaussians):
       densify_and_prune(max_grad, min_opacity, extent, max_screen_size, radii)   gaussian_model.py:448-469 -> the single repack above; the model's
           parameter attributes, its three statistics arrays and `tmp_radii` are left exactly as the reference leaves them
       reset_opacity()                                                  gaussian_model.py:258-261
+    fused_adam (default): when `gaussians.optimizer` is a plain `torch.optim.Adam` over HIP tensors -- train.py's default `optimizer_type`
+    (scene/gaussian_model.py:193-199) -- it is replaced by `gsr_optim.FusedAdam` with the SAME param groups and state (one HIP kernel for the
+    six tensors instead of torch's foreach chain; same state-dict layout, so `capture()` / `restore()` and the density control keep working).
     Returns the instance."""
     import types
+    opt = getattr(gaussians, "optimizer", None)
+    if fused_adam and type(opt) is torch.optim.Adam and all(p.is_cuda and p.dtype == torch.float32 for g in opt.param_groups for p in g["params"]) \
+            and not any(g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False) for g in opt.param_groups):
+        from gsr_optim import FusedAdam
+        new_opt = FusedAdam(opt.param_groups, lr=opt.defaults["lr"], betas=opt.defaults["betas"], eps=opt.defaults["eps"])
+        for p_, st_ in opt.state.items():      # (the same tensors: exp_avg / exp_avg_sq / step, torch.optim.Adam's layout)
+            new_opt.state[p_] = {"step": int(st_["step"]) if "step" in st_ else 0, "exp_avg": st_["exp_avg"], "exp_avg_sq": st_["exp_avg_sq"]}
+        gaussians.optimizer = new_opt
 
     def _stats(self):
         return DensifyStats(self.xyz_gradient_accum, self.denom, self.max_radii2D)

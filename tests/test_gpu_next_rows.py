@@ -558,6 +558,62 @@ def test_density_statistics_through_the_attached_method_with_the_callers_index_l
     assert not m.max_radii2D.any()      # (train.py:166 updates it itself)
 
 
+def test_attach_replaces_the_default_adam_with_the_fused_one_and_keeps_its_state():
+    """gsr_scene.densify.attach(gaussians): `gaussians.optimizer`, a torch.optim.Adam over HIP tensors with the reference's six named groups (train.py's
+    default optimizer_type), becomes gsr_optim.FusedAdam over the SAME groups and state tensors; stepping it equals stepping an untouched torch.optim.Adam
+    copy (parameters to two ulps, moments to 1e-6 relative), the learning-rate schedule reaches it through param_groups, the state dict keeps
+    torch's layout."""
+    import copy
+    import types
+    from gsr_optim import FusedAdam
+    from gsr_scene.densify import attach
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    P = 20_000
+    shapes = {"xyz": (P, 3), "f_dc": (P, 1, 3), "f_rest": (P, 15, 3), "opacity": (P, 1), "scaling": (P, 3), "rotation": (P, 4)}
+    lrs = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 1.25e-4, "opacity": 0.025, "scaling": 5e-3, "rotation": 1e-3}
+
+    def build():
+        ps = {k: torch.nn.Parameter(torch.randn(s, generator=torch.Generator().manual_seed(7)).to(dev)) for k, s in shapes.items()}
+        opt = torch.optim.Adam([{"params": [ps[k]], "lr": lrs[k], "name": k} for k in shapes], lr=0.0, eps=1e-15)
+        return ps, opt
+    pa, oa = build()
+    pb, ob = build()
+    grads = [{k: torch.randn(s, generator=g).to(dev) for k, s in shapes.items()} for _ in range(3)]
+
+    def step(ps, opt, gr):
+        for k in shapes:
+            ps[k].grad = gr[k].clone()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    step(pa, oa, grads[0])
+    step(pb, ob, grads[0])                      # both have a populated state now
+    m = types.SimpleNamespace(optimizer=ob, xyz_gradient_accum=torch.zeros(P, 1, device=dev), denom=torch.zeros(P, 1, device=dev), max_radii2D=torch.zeros(P, device=dev))
+    before = {k: ob.state[pb[k]]["exp_avg"] for k in shapes}
+    attach(m)
+    assert type(m.optimizer) is FusedAdam and [g_["name"] for g_ in m.optimizer.param_groups] == list(shapes)
+    assert all(m.optimizer.state[pb[k]]["exp_avg"] is before[k] for k in shapes)      # the same state tensors, not copies
+    for g_ in m.optimizer.param_groups:         # update_learning_rate (scene/gaussian_model.py:215-227) reaches it
+        if g_["name"] == "xyz":
+            g_["lr"] = 3.2e-4
+    for g_ in oa.param_groups:
+        if g_["name"] == "xyz":
+            g_["lr"] = 3.2e-4
+    for gr in grads[1:]:
+        step(pa, oa, gr)
+        step(pb, m.optimizer, gr)
+    torch.cuda.synchronize()
+    for k in shapes:
+        stepsize = lrs[k] if k != "xyz" else 3.2e-4
+        assert (pa[k] - pb[k]).abs().max().item() <= 1e-5 * stepsize + 2.5e-7 * max(1.0, pa[k].abs().max().item()), k      # (two ulps of the parameter itself)
+        for s_ in ("exp_avg", "exp_avg_sq"):
+            a_, b_ = oa.state[pa[k]][s_], m.optimizer.state[pb[k]][s_]
+            assert (a_ - b_).abs().max().item() <= 1e-6 * a_.abs().max().item(), (k, s_)
+    sd = m.optimizer.state_dict()
+    assert set(sd["state"][0]) >= {"step", "exp_avg", "exp_avg_sq"} and int(sd["state"][0]["step"]) == 3
+    del copy
+
+
 def test_training_loop_with_density_control():
     """train.py:111-186 in miniature on the drop-in pieces: render (split-SH form), reference loss, backward, density
     statistics from the operator's means2D gradient and radii, FusedAdam step, clone / split / prune every 50 iterations
