@@ -34,7 +34,7 @@ rows = [
     ("32 cameras cycled / 3 parameter sets cycled", f"{d['forward_cycled_views']['ms_per_frame']:.4f} / {d['forward_cycled_scenes']['ms_per_frame']:.4f} ms per frame"),
     ("three independent frames in flight on 3 HIP streams (a camera-list loop; **not** `value`)", f"{d['forward_frames_in_flight']['ms_per_frame']:.4f} ms per frame = {d['forward_frames_in_flight']['Mpix_s']:.0f} Mpix/s"),
     ("train step (fused L1+SSIM loss, fused Adam)", f"**{d['train_iters_per_s']:.1f} it/s** ({d['train_ms_per_iter']:.4f} ms); SparseGaussianAdam + separate-SH form {d['train_iters_per_s_sparse_adam']:.1f}; L1 only {d['train_iters_per_s_l1']:.1f}; depth-supervised {d['train_iters_per_s_depth_supervised']:.1f}; SH step inside the backward {sh['dense_adam_sh_step_in_backward']:.1f} / {sh['sparse_adam_sh_step_in_backward']:.1f} (dense / sparse)"),
-    ("**train step, the unchanged caller's op sequence** (`train.py:104-186` verbatim on the three drop-in packages: `render()` glue with torch activations, torch `l1_loss`, `fused_ssim`, `loss.item()` every iteration, torch boolean-index density statistics, exposure optimizer)", f"**{d['train_iters_per_s_unchanged_caller']:.1f} it/s** with `torch.optim.Adam` (train.py's default `optimizer_type`; torch's foreach Adam alone is ≈ 1.5 ms of the {d['train_unchanged_caller']['default_torch_adam']['ms_per_iter']:.2f} ms) — **{d['train_iters_per_s_unchanged_caller_sparse_adam']:.1f} it/s** with `--optimizer_type sparse_adam` (`SparseGaussianAdam.step(visible, N)`)"),
+    ("**train step, the unchanged caller's op sequence** (`train.py:104-186` verbatim on the three drop-in packages: `render()` glue with torch activations, torch `l1_loss`, `fused_ssim`, `loss.item()` every iteration, torch boolean-index density statistics, exposure optimizer)", f"**{d['train_iters_per_s_unchanged_caller']:.1f} it/s** with `torch.optim.Adam` (train.py's default `optimizer_type`; torch's foreach Adam alone is ≈ 1.5 ms of the {d['train_unchanged_caller']['default_torch_adam']['ms_per_iter']:.2f} ms) — **{d['train_iters_per_s_unchanged_caller_sparse_adam']:.1f} it/s** with `--optimizer_type sparse_adam` (`SparseGaussianAdam.step(visible, N)`); with ONE added line, `gsr_scene.densify.attach(gaussians)` behind `training_setup()` (INTEGRATION.md §3): **{d.get('train_iters_per_s_unchanged_caller_one_added_line') or float('nan'):.1f} it/s** with the default optimizer (it becomes the fused kernel, same groups and state), {d.get('train_iters_per_s_unchanged_caller_sparse_adam_one_added_line') or float('nan'):.1f} with sparse_adam"),
     ("train step at fixed P (SURVEY 8(d); headline step)", sp(f"P = 1e5: {fp['100000']['iters_per_s']:.0f} it/s (R = {fp['100000']['num_rendered_view0']:,}); 1e6: {fp['1000000']['iters_per_s']:.0f}; 3e6: {fp['3000000']['iters_per_s']:.0f} (R = {fp['3000000']['num_rendered_view0']:,})")),
     ("backward stages (ms)", ", ".join(f"{n} {st[n]:.4f}" for n in ("render_bwd", "gather_bwd", "preprocess_bwd"))),
     ("train with density control every 100 it. (P 1.03 → 1.23 M)", f"{d['train_iters_per_s_densify']:.1f} it/s; {wt['clone_split_prune_events']} clone / split / prune events of {wt['ms_per_event']:.1f} ms, plain iterations {wt['plain_iteration_ms_median']:.2f} ms median, " + ("no stall beyond 20 ms outside the events" if not wt["stalls_over_20ms_outside_events"] else f"stalls outside the events: {wt['stalls_over_20ms_outside_events']} ms ({wt['iters_per_s_without_those_stalls']:.1f} it/s without them)")),
